@@ -1,0 +1,191 @@
+/*
+ * oracle.h -- CPU restatement (plain C, FP64) of the nonlinear-least-squares path of
+ * Unsigned-Long/slam-tricks (st17-ceres / st20-g2o / st3-calibration / st7-ransac).
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT THE PRODUCT.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load liboracle.so.  The product (include/stba.h,
+ * slam-tricks_amd/csrc) never links, loads or calls anything in this directory.
+ *
+ * Parity status.  The arithmetic of the reference's "Ceres CPU path" lives in third-party
+ * code that is absent from /root/reference and from this image (Ceres <= 2.1, Sophus >= 1.0,
+ * Eigen 3, g2o; all un-pinned: st17-ceres/src/CMakeLists.txt:3-5, st20-g2o/src/CMakeLists.txt:7-12).
+ * What the oracle is pinned against (tests/test_oracle_*.py):
+ *   - st7-ransac/pyDraw/drawerResult.py:12-16  parabola known answers on good.csv / bad.csv
+ *   - st17-ceres/img/release.png               published PnP true/init pose, convergence to truth
+ *   - st17-ceres/src/ceres_bound.cpp:26-65     x*=3 (free) and x*=2 (upper bound 2)
+ *   - st3-calibration/calib/1..9.txt           real corner data; cost trace 1736.8916 -> 133.5132
+ *   - st17-ceres/docs/notes.tex:131-144        4x3 quaternion-plus Jacobian
+ *   - central differences of every residual (numpy), scipy.optimize.least_squares fixed points
+ * The Levenberg-Marquardt iteration *trace* follows Ceres' published algorithm
+ * (trust_region_minimizer / levenberg_marquardt_strategy, constants below) but cannot be
+ * diffed against a Ceres binary here: per-iteration trace parity vs real Ceres is UNPINNED;
+ * converged parameters are pinned by the fixtures above.
+ *
+ * Conventions (reference file:line):
+ *   quaternion storage (x,y,z,w)            Eigen/Sophus SO3::data(), solver.hpp:267
+ *   camera pose = camera-to-world           test_ceres.h:66-71 (SE3_CtoW.inverse() * landmark)
+ *   camera local update  q <- q (x) exp(dtheta), t <- t + dt
+ *                                           solver.hpp:38-45, test_g2o.h:36-39
+ *   camera tangent order [dtheta(3), dt(3)] test_g2o.h:36-39 (v[0:3] rot, v[3:6] pos)
+ *   cost = 1/2 sum r^2                      Ceres (release.png "Initial cost")
+ */
+#ifndef STBA_ORACLE_H
+#define STBA_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------- SO3 / SE3 primitives (Sophus semantics) ---------------- */
+void orc_quat_to_rot(const double q[4], double R[9]);            /* row-major R (cam->world) */
+void orc_rot_to_quat(const double R[9], double q[4]);
+void orc_quat_mul(const double a[4], const double b[4], double out[4]);
+void orc_so3_exp(const double w[3], double q[4]);
+void orc_so3_log(const double q[4], double w[3]);
+/* LieLocalParameterization<SO3d>::Plus  (solver.hpp:38-45, test_ceres.h:22-29) */
+void orc_so3_plus(const double q[4], const double d[3], double out[4]);
+/* LieLocalParameterization<SO3d>::ComputeJacobian = Dx_this_mul_exp_x_at_0, 4x3 row-major
+ * (solver.hpp:48-54; spelled out in st17-ceres/docs/notes.tex:131-144) */
+void orc_so3_plus_jacobian(const double q[4], double J[12]);
+/* LieR3LocalParameterization::Plus (solver.hpp:67-78): log(exp(x) exp(d)) */
+void orc_so3r3_plus(const double x[3], const double d[3], double out[3]);
+/* Sophus SE3 exp/log, tangent [rho(3), theta(3)] (calib.cpp:300,318,397-402) */
+void orc_se3_exp(const double xi[6], double q[4], double t[3]);
+void orc_se3_log(const double q[4], const double t[3], double xi[6]);
+
+/* ---------------- reprojection factor (a1/a2) ---------------- */
+/* test_ceres.h:63-80, solver.hpp:108-124: r = proj(R^T (L - t)) - feature */
+void orc_reproj_residual(const double q[4], const double t[3], const double L[3],
+                         const double f[2], double r[2]);
+/* Same value, but written exactly as the autodiff path evaluates it: the quaternion is used
+ * un-normalised through Eigen's v + 2w(u x v) + 2 u x (u x v) rotation formula, so that
+ * d r / d q (ambient, 2x4) is what Ceres autodiff would produce. */
+void orc_reproj_residual_ambient(const double q[4], const double t[3], const double L[3],
+                                 const double f[2], double r[2]);
+/* Analytic local Jacobians.  Jc: 2x6 row-major [d/dtheta | d/dt]; Jp: 2x3 row-major d/dL.
+ * rot_mode 0: correct right-perturbation derivative A*hat(pInC)   (== autodiff)
+ * rot_mode 1: the reference's formula A*hat(R^T L)  (solver.hpp:195,425; drops the t term) */
+void orc_reproj_jacobian(const double q[4], const double t[3], const double L[3],
+                         double Jc[12], double Jp[6], int rot_mode);
+
+/* ---------------- LM options / summary (Ceres defaults) ---------------- */
+typedef struct {
+    int    max_num_iterations;            /* 50 */
+    double initial_trust_region_radius;   /* 1e4 */
+    double max_trust_region_radius;       /* 1e16 */
+    double min_trust_region_radius;       /* 1e-32 */
+    double min_relative_decrease;         /* 1e-3 */
+    double min_lm_diagonal;               /* 1e-6 */
+    double max_lm_diagonal;               /* 1e32 */
+    double function_tolerance;            /* 1e-6 */
+    double gradient_tolerance;            /* 1e-10 */
+    double parameter_tolerance;           /* 1e-8 */
+    int    jacobi_scaling;                /* 1 */
+    int    num_threads;                   /* 1 (reference pins 1: test_ceres.h:143) */
+    int    fixed_iterations;              /* 0; >0: run exactly this many iterations, no
+                                             convergence tests (bench / cpu_baseline mode) */
+} orc_lm_options;
+
+enum { ORC_CONVERGENCE = 0, ORC_NO_CONVERGENCE = 1, ORC_FAILURE = 2 };
+enum { ORC_TERM_NONE = 0, ORC_TERM_GRADIENT = 1, ORC_TERM_FUNCTION = 2, ORC_TERM_PARAMETER = 3,
+       ORC_TERM_MAX_ITER = 4, ORC_TERM_MIN_RADIUS = 5, ORC_TERM_SOLVER_FAIL = 6,
+       ORC_TERM_FIXED = 7 };
+
+typedef struct {
+    int    termination_type;   /* ORC_CONVERGENCE ... */
+    int    termination_reason; /* ORC_TERM_* */
+    int    num_iterations;     /* iterations performed, not counting iteration 0 */
+    int    num_successful_steps;
+    int    num_unsuccessful_steps;
+    double initial_cost;
+    double final_cost;
+    double final_radius;
+    double final_gradient_max_norm;
+    double seconds_total;
+    double seconds_linearize, seconds_schur, seconds_solve, seconds_backsub, seconds_cost;
+} orc_lm_summary;
+
+/* One row per iteration (row 0 = initial point): cost, cost_change, gradient_max_norm,
+ * step_norm, relative_decrease, radius, accepted  -> 7 doubles per row. */
+#define ORC_TRACE_COLS 7
+
+void orc_lm_default_options(orc_lm_options* o);
+
+/* ---------------- bundle adjustment (st20-g2o semantics) ---------------- */
+typedef struct {
+    int n_cams, n_pts, n_obs;
+    double* cams;                 /* n_cams*7 : qx qy qz qw tx ty tz   (in/out) */
+    double* pts;                  /* n_pts*3                           (in/out) */
+    const int* obs_cam;           /* n_obs */
+    const int* obs_pt;            /* n_obs, NON-DECREASING (landmark-major: sim_data.h:38-47) */
+    const double* obs_feat;       /* n_obs*2 normalised image-plane coords */
+    const unsigned char* cam_fixed; /* n_cams*6 or NULL; 1 = dof held constant
+                                       (test_ceres.h:127-130 fixes all 6 of cams 0, N-1) */
+    const unsigned char* pt_fixed;  /* n_pts or NULL; 1 = landmark constant (PnP, solver.hpp) */
+} orc_ba_problem;
+
+/* residuals r[n_obs*2], Jc[n_obs*12], Jp[n_obs*6] (any may be NULL); returns cost */
+double orc_ba_evaluate(const orc_ba_problem* p, double* r, double* Jc, double* Jp);
+
+/* Block normal equations at the current point (undamped):
+ * Hcc[n_cams*36] row-major 6x6, gc[n_cams*6] (= J^T r), Hpp[n_pts*9], gp[n_pts*3].
+ * Fixed dofs have zero rows/cols. */
+void orc_ba_normal_blocks(const orc_ba_problem* p, const double* r, const double* Jc,
+                          const double* Jp, double* Hcc, double* gc, double* Hpp, double* gp);
+
+/* Reduced camera system for damping vectors dc[n_cams*6], dp[n_pts*3] (added to the diagonal):
+ * S[(6 n_cams)^2] dense row-major, LOWER triangle + diagonal valid; rhs[6 n_cams] = -(gc - W Hpp^-1 gp).
+ * Fixed camera dofs get unit diagonal / zero rhs.  Only landmarks [pt_begin, pt_end) contribute
+ * their Schur terms and only their observations contribute Hcc (landmark sharding);
+ * pass 0, n_pts for the whole problem. */
+void orc_ba_reduced_system(const orc_ba_problem* p, const double* Jc, const double* Jp,
+                           const double* r, const double* dc, const double* dp,
+                           int pt_begin, int pt_end, double* S, double* rhs);
+
+/* dense SPD solve helpers (in place, row-major, lower).  return 0 ok / k>0 first bad pivot */
+int  orc_cholesky_lower(double* A, int n, int num_threads);
+void orc_cholesky_solve(const double* L, int n, double* b);
+
+/* Full LM with point-block Schur elimination + dense Cholesky on the reduced system.
+ * trace: (max_num_iterations+1)*ORC_TRACE_COLS doubles or NULL. */
+int orc_ba_solve(orc_ba_problem* p, const orc_lm_options* opt, orc_lm_summary* sum, double* trace);
+
+/* Per-landmark triangulation with cameras fixed (sim_data.h:165-194, sim_data.cpp:299-311):
+ * Gauss-Newton/LM on each landmark independently.  Updates pts in place. */
+void orc_ba_triangulate(orc_ba_problem* p, int max_iter);
+
+/* ---------------- generic dense LM (curve fit, bounds demo, PnP via callbacks) ------- */
+/* Residual callback: x (n_params ambient) -> r[n_res], J[n_res*n_local] row-major in LOCAL
+ * coordinates (J may be NULL).  plus: x_new = x (+) delta (NULL = Euclidean). */
+typedef int (*orc_residual_fn)(void* user, const double* x, double* r, double* J);
+typedef void (*orc_plus_fn)(void* user, const double* x, const double* delta, double* x_new);
+int orc_dense_lm(orc_residual_fn fn, orc_plus_fn plus, void* user, int n_params, int n_local,
+                 int n_res, double* x, const double* lower, const double* upper,
+                 const orc_lm_options* opt, orc_lm_summary* sum, double* trace);
+
+/* ---------------- st17 PnP ---------------- */
+/* SelfGaussNewton, solver.hpp:387-462.  rot_mode as in orc_reproj_jacobian.
+ * Returns the number of iterations executed (the reference's `i`). */
+int orc_pnp_gauss_newton(int n, const double* pts_w, const double* feats, double q[4], double t[3],
+                         int rot_mode, int max_iter, double* change_trace);
+
+/* ---------------- st7 parabola (float arithmetic, parabola.hpp:98-130) ---------------- */
+void orc_parabola_least_square(int n, const float* xy, float abc[3]);
+int  orc_parabola_gauss_newton(int n, const float* xy, int iters, float abc[3]);
+
+/* ---------------- st3 calibration (calib.cpp:247-262, 282-422) ---------------- */
+/* params: [alpha beta u0 v0 k1 k2 k3 p1 p2 | xi_0(6) ... xi_{V-1}(6)], xi = se3 [rho,theta].
+ * obj[V*C*2] board points (X,Y), img[V*C*2] measured pixels.
+ * Evaluate e[V*C*2] (pred - measured) and optional per-corner Jacobians
+ * Ji[V*C*2*9] (2x9: d e / d(intr,dist)) and Jx[V*C*2*6] (2x6: d e / d left-perturbation). */
+double orc_calib_evaluate(int n_views, int n_corners, const double* params, const double* obj,
+                          const double* img, double* e, double* Ji, double* Jx);
+/* totalOptimization: plain Gauss-Newton, <=max_iter, stop |update|<1e-8.  sse_trace[max_iter]
+ * receives sum e^2 at the START of each iteration.  Returns iterations executed. */
+int orc_calib_gauss_newton(int n_views, int n_corners, double* params, const double* obj,
+                           const double* img, int max_iter, double* sse_trace);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

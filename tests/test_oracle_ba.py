@@ -1,0 +1,152 @@
+"""CPU tests of the oracle's bundle-adjustment path: Schur reduction vs the full normal
+equations, landmark-shard additivity, LM convergence on the reference-sized st20
+scene, and an independent cross-check of the fixed point with scipy.optimize.least_squares."""
+import numpy as np
+import pytest
+from scipy.optimize import least_squares
+
+
+def small_scene(scenes, **kw):
+    args = dict(n_cams=6, n_pts=40, seed=7, pos_noise=0.05, ang_noise_deg=1.0)
+    args.update(kw)
+    return scenes.st20_scene(**args)
+
+
+def make_ba(O, s, **kw):
+    return O.BA(s["cams0"], s["pts0"], s["obs_cam"], s["obs_pt"], s["obs_feat"], s["cam_fixed"], **kw)
+
+
+def full_normal_solution(ba, r, Jc, Jp, dc, dp):
+    """dense (6C+3P) normal equations with numpy, fixed dofs pinned"""
+    nc, npt = ba.nc, ba.np_
+    n = 6 * nc + 3 * npt
+    J = np.zeros((2 * ba.no, n))
+    for i in range(ba.no):
+        c, j = ba.obs_cam[i], ba.obs_pt[i]
+        J[2 * i:2 * i + 2, 6 * c:6 * c + 6] = Jc[i]
+        J[2 * i:2 * i + 2, 6 * nc + 3 * j:6 * nc + 3 * j + 3] = Jp[i]
+    H = J.T @ J + np.diag(np.concatenate([dc.reshape(-1), dp.reshape(-1)]))
+    g = J.T @ r.reshape(-1)
+    fixed = np.concatenate([ba.cam_fixed.reshape(-1).astype(bool), np.zeros(3 * npt, bool)])
+    H[fixed, :] = 0; H[:, fixed] = 0; H[fixed, fixed] = 1.0; g[fixed] = 0
+    return np.linalg.solve(H, -g)
+
+
+def test_normal_blocks_match_dense(O, scenes):
+    s = small_scene(scenes)
+    ba = make_ba(O, s)
+    cost, r, Jc, Jp = ba.evaluate()
+    assert abs(cost - 0.5 * (r ** 2).sum()) < 1e-15 * max(1, cost)
+    Hcc, gc, Hpp, gp = ba.normal_blocks(r, Jc, Jp)
+    for c in range(ba.nc):
+        m = ba.obs_cam == c
+        assert np.allclose(Hcc[c], np.einsum("nki,nkj->ij", Jc[m], Jc[m]), atol=1e-12)
+        assert np.allclose(gc[c], np.einsum("nki,nk->i", Jc[m], r[m]), atol=1e-12)
+    for j in range(ba.np_):
+        m = ba.obs_pt == j
+        assert np.allclose(Hpp[j], np.einsum("nki,nkj->ij", Jp[m], Jp[m]), atol=1e-12)
+    assert np.all(Jc[ba.obs_cam == 0] == 0) and np.all(Jc[ba.obs_cam == ba.nc - 1] == 0)   # constant cameras
+
+
+def test_schur_equals_full_system(O, scenes):
+    s = small_scene(scenes)
+    ba = make_ba(O, s)
+    _, r, Jc, Jp = ba.evaluate()
+    rng = np.random.default_rng(0)
+    dc = rng.uniform(0.01, 0.1, (ba.nc, 6)); dp = rng.uniform(0.01, 0.1, (ba.np_, 3))
+    S, rhs = ba.reduced_system(r, Jc, Jp, dc, dp)
+    Sfull = np.tril(S) + np.tril(S, -1).T
+    dxc = np.linalg.solve(Sfull, rhs)
+    ref = full_normal_solution(ba, r, Jc, Jp, dc, dp)
+    assert np.allclose(dxc, ref[:6 * ba.nc], atol=1e-9)
+    rc, L = O.cholesky_lower(S)
+    assert rc == 0
+    assert np.allclose(O.cholesky_solve(L, rhs), dxc, atol=1e-10)
+
+
+def test_landmark_shards_add_up(O, scenes):
+    """per-shard partial reduced systems sum to the whole one."""
+    s = small_scene(scenes, n_pts=60)
+    ba = make_ba(O, s)
+    _, r, Jc, Jp = ba.evaluate()
+    dc = np.full((ba.nc, 6), 0.03); dp = np.full((ba.np_, 3), 0.02)
+    S, rhs = ba.reduced_system(r, Jc, Jp, dc, dp)
+    cuts = [0, 17, 41, ba.np_]
+    Ssum = np.zeros_like(S); rsum = np.zeros_like(rhs)
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        Sp, rp = ba.reduced_system(r, Jc, Jp, dc, dp, a, b)
+        Ssum += Sp; rsum += rp
+    assert np.allclose(Ssum, S, atol=1e-11) and np.allclose(rsum, rhs, atol=1e-11)
+
+
+def test_st20_reference_size_converges_to_truth(O, scenes):
+    """29 cameras x 600 landmarks, noise (0.3 m, 3 deg) as test_ceres.cpp:13; first/last camera
+    constant (test_ceres.h:127-130).  Noise-free observations -> pose = truth."""
+    s = scenes.st20_scene()
+    assert len(s["cams0"]) == 29 and len(s["pts0"]) == 600
+    ba = make_ba(O, s)
+    summ, tr = ba.solve()
+    assert summ.termination_type == 0
+    assert summ.initial_cost > 1.0 and summ.final_cost < 1e-11      # float-rounded features floor
+    assert summ.num_iterations <= 12
+    q, qt = ba.cams[:, :4], s["cams_true"][:, :4]
+    assert np.minimum(np.abs(q - qt).max(1), np.abs(q + qt).max(1)).max() < 1e-6
+    assert np.abs(ba.cams[:, 4:] - s["cams_true"][:, 4:]).max() < 1e-5
+    assert np.all(ba.cams[0] == s["cams0"][0]) and np.all(ba.cams[-1] == s["cams0"][-1])
+    assert np.all(np.diff(tr[tr[:, 6] > 0, 0]) <= 0)                # monotone on accepted steps
+
+
+def test_fixed_point_matches_scipy(O, scenes):
+    """independent solver (scipy TRF) on the same noisy problem reaches the same minimiser"""
+    s = small_scene(scenes, n_cams=12, n_pts=80, pix_noise=1e-3, seed=11)
+    ba = make_ba(O, s)
+    summ, _ = ba.solve(function_tolerance=1e-14, parameter_tolerance=1e-14, gradient_tolerance=1e-14,
+                       max_num_iterations=100)
+    nc, npt = ba.nc, ba.np_
+    free = ~s["cam_fixed"].reshape(-1).astype(bool)
+    cams0, pts0 = s["cams0"], s["pts0"]
+
+    def unpack(x):
+        d = np.zeros(6 * nc); d[free] = x[:free.sum()]
+        cams = cams0.copy()
+        for c in range(nc):
+            cams[c, :4] = O.so3_plus(cams0[c, :4], d[6 * c:6 * c + 3])
+            cams[c, 4:] = cams0[c, 4:] + d[6 * c + 3:6 * c + 6]
+        return cams, pts0 + x[free.sum():].reshape(-1, 3)
+
+    def fun(x):
+        cams, pts = unpack(x)
+        f, _ = scenes.project(cams, pts, s["obs_cam"], s["obs_pt"])
+        return (f - s["obs_feat"]).reshape(-1)
+    sol = least_squares(fun, np.zeros(free.sum() + 3 * npt), method="trf", xtol=1e-15, ftol=1e-15, gtol=1e-15)
+    cams_s, pts_s = unpack(sol.x)
+    assert abs(sol.cost - summ.final_cost) <= 1e-9 * summ.final_cost
+    q, qs = ba.cams[:, :4], cams_s[:, :4]
+    assert np.minimum(np.abs(q - qs).max(1), np.abs(q + qs).max(1)).max() < 1e-6
+    assert np.abs(ba.cams[:, 4:] - cams_s[:, 4:]).max() < 1e-5
+    assert np.abs(ba.pts - pts_s).max() < 1e-4
+
+
+def test_triangulation_matches_scene_generator(O, scenes):
+    s = small_scene(scenes, retriangulate=False)
+    ba = make_ba(O, s)
+    ba.triangulate()
+    ref = scenes.triangulate(s["cams0"], s["pts0"], s["obs_cam"], s["obs_pt"], s["obs_feat"])
+    assert np.abs(ba.pts - ref).max() < 1e-6
+
+
+def test_two_view_scene(O, scenes):
+    s = scenes.two_view_scene(n_pts=300)
+    ba = make_ba(O, s)
+    summ, _ = ba.solve()
+    assert summ.termination_type == 0 and summ.final_cost < 1e-18
+    q, qt = ba.cams[1, :4], s["cams_true"][1, :4]
+    assert min(np.abs(q - qt).max(), np.abs(q + qt).max()) < 1e-8
+    assert np.abs(ba.cams[1, 4:] - s["cams_true"][1, 4:]).max() < 1e-7
+
+
+def test_fixed_iterations_mode(O, scenes):
+    s = small_scene(scenes, pix_noise=1e-3)
+    ba = make_ba(O, s)
+    summ, tr = ba.solve(fixed_iterations=9)
+    assert summ.num_iterations == 9 and len(tr) == 10

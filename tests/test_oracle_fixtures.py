@@ -1,0 +1,131 @@
+"""Pins the oracle against every known answer the reference holds for this path
+(SURVEY.md section 4 / tests/golden/known_answers.json).  CPU only."""
+import os
+
+import numpy as np
+
+from conftest import GOLDEN
+import zhang_init as Z
+
+
+def _csv(name):
+    return np.loadtxt(os.path.join(GOLDEN, name), delimiter=",")
+
+
+def test_parabola_known_answers(O, known):
+    ka = known["st7_parabola"]
+    good, bad = _csv("st7_ransac/good.csv"), _csv("st7_ransac/bad.csv")
+    assert good.shape == (100, 2) and bad.shape == (200, 2)
+    # values are printed with 6 significant digits (drawerResult.py:12-16)
+    assert np.allclose(O.parabola_least_square(good), ka["leastSquare_good"], rtol=2e-5)
+    assert np.allclose(O.parabola_least_square(bad), ka["leastSquare_bad"], rtol=2e-5)
+    g, _ = O.parabola_gauss_newton(good, 10)
+    b, _ = O.parabola_gauss_newton(bad, 10)
+    assert np.allclose(g, ka["gaussNewton_good_10"], rtol=2e-5)
+    assert np.allclose(b, ka["gaussNewton_bad_10"], rtol=2e-5)
+
+
+def test_parabola_through_dense_lm(O, known):
+    """the same fit through the LM driver (FP64) lands on the same answer"""
+    good = _csv("st7_ransac/good.csv")
+    x, y = good[:, 0], good[:, 1]
+
+    def res(p):
+        return p[0] * x * x + p[1] * x + p[2] - y, np.stack([x * x, x, np.ones_like(x)], 1)
+    p, summ, _ = O.dense_lm(res, [1.0, 0.0, 0.0], len(x))
+    assert summ.termination_type == 0
+    assert np.allclose(p, known["st7_parabola"]["gaussNewton_good_10"], rtol=5e-5)
+
+
+def test_ceres_bound_demo(O, known):
+    ka = known["st17_ceres_bound"]
+
+    def res(p):
+        return np.array([p[0] - 3.0]), np.array([[1.0]])          # ceres_bound.cpp:19
+    x, summ, _ = O.dense_lm(res, [ka["x0"]], 1)
+    assert abs(x[0] - ka["x_free"]) < 1e-8 and summ.termination_type == 0
+    x, summ, _ = O.dense_lm(res, [ka["x0"]], 1, lower=[ka["lower"]], upper=[ka["upper"]])
+    assert abs(x[0] - ka["x_bounded"]) < 1e-12 and summ.termination_type == 0
+
+
+def test_published_pnp_poses(scenes, known):
+    ka = known["st17_pnp"]
+    real, init = scenes.pnp_published_poses()
+    for pose, q, t in ((real, ka["q_true_xyzw"], ka["t_true"]), (init, ka["q_init_xyzw"], ka["t_init"])):
+        qq = np.array(q)
+        assert min(np.abs(pose[:4] - qq).max(), np.abs(pose[:4] + qq).max()) < 6e-6   # 5 printed digits
+        assert np.allclose(pose[4:], t)
+
+
+def test_pnp_gauss_newton_converges_to_published_truth(O, scenes, known):
+    """SelfGaussNewton (solver.hpp:387-462) from the published init reaches the published truth;
+    the reference's rotation Jacobian (rot_mode=1) reaches the same fixed point in more
+    iterations (release.png: SizedCostFunction 8 it. vs autodiff 6)."""
+    s = scenes.pnp_scene(seed=17)
+    assert 10 <= len(s["pts"]) <= 40
+    q, t, it0, _ = O.pnp_gauss_newton(s["pts"], s["feats"], s["pose_init"][:4], s["pose_init"][4:], 0)
+    qt = s["pose_true"][:4]
+    assert min(np.abs(q - qt).max(), np.abs(q + qt).max()) < 1e-9
+    assert np.allclose(t, s["pose_true"][4:], atol=1e-8)
+    q1, t1, it1, _ = O.pnp_gauss_newton(s["pts"], s["feats"], s["pose_init"][:4], s["pose_init"][4:], 1, max_iter=40)
+    assert min(np.abs(q1 - qt).max(), np.abs(q1 + qt).max()) < 1e-7
+    assert it1 > it0
+    assert it0 <= known["st17_pnp"]["release_iterations"]["SelfGaussNewton"] + 1
+
+
+def test_pnp_lm_as_ba_with_fixed_landmarks(O, scenes, known):
+    """SolvePnPWith*: one camera, landmarks constant, Ceres-style LM; cost -> ~0 in a handful of
+    iterations as in release.png (6 it., final cost 4e-21)."""
+    s = scenes.pnp_scene(seed=17)
+    n = len(s["pts"])
+    ba = O.BA(s["pose_init"][None], s["pts"], np.zeros(n, np.int32), np.arange(n, dtype=np.int32), s["feats"],
+              pt_fixed=np.ones(n, np.uint8))
+    summ, tr = ba.solve()
+    assert summ.termination_type == 0
+    assert summ.final_cost < known["st17_pnp"]["final_cost_below"]
+    assert 4 <= summ.num_iterations <= 9
+    qt = s["pose_true"][:4]
+    assert min(np.abs(ba.cams[0, :4] - qt).max(), np.abs(ba.cams[0, :4] + qt).max()) < 1e-9
+
+
+def test_calibration_fixture(O, known):
+    """st3-calibration/calib/1..9.txt: Zhang init + totalOptimization reproduce the recorded
+    intrinsics and cost trace."""
+    ka = known["st3_calibration"]
+    obj, img = Z.read_corners(os.path.join(GOLDEN, "st3_calib"), ka["board_square_m"])
+    assert obj.shape == (9, 40, 2)
+    p0 = Z.zhang_init(obj, img, lambda R, t: O.se3_log(O.rot_to_quat(R), t))
+    assert np.allclose(p0[:4], ka["init_fx_fy_u0_v0"], rtol=2e-7)
+    p, it, sse = O.calib_gauss_newton(p0, obj, img, 10)
+    assert abs(sse[0] - ka["sse_first"]) < 5e-4
+    done = sse[~np.isnan(sse)]
+    assert abs(done[-1] - ka["sse_last"]) < 5e-4
+    assert np.allclose(p[:4], ka["final_intr_dist"][:4], rtol=0, atol=6e-4)      # printed to 3 decimals
+    assert np.allclose(p[4:7], ka["final_intr_dist"][4:7], rtol=2e-6)
+    assert np.allclose(p[7:9], ka["final_intr_dist"][7:9], rtol=2e-3, atol=2e-9)
+    assert abs(it - ka["gn_iterations"]) <= 1
+
+
+def test_calibration_jacobian_numeric(O, scenes):
+    s = scenes.calib_scene(n_views=3, rows=3, cols=4, seed=5)
+    params = np.concatenate([s["intr_true"], s["xis_true"].reshape(-1)])
+    _, e, Ji, Jx = O.calib_evaluate(params, s["obj"], s["img"])
+    eps = 1e-6
+    for k in range(9):
+        d = np.zeros_like(params); d[k] = eps * max(1.0, abs(params[k]))
+        ep = O.calib_evaluate(params + d, s["obj"], s["img"], jac=False)[1]
+        em = O.calib_evaluate(params - d, s["obj"], s["img"], jac=False)[1]
+        num = (ep - em) / (2 * d[k])
+        assert np.allclose(num, Ji[..., k], rtol=2e-5, atol=2e-4)
+    # left perturbation exp(d) * T of view 1 (calib.cpp:397-402)
+    v = 1
+    for k in range(6):
+        d = np.zeros(6); d[k] = eps
+        def shifted(sign):
+            Rd, td = scenes.se3_exp(sign * d)
+            R, t = scenes.se3_exp(params[9 + 6 * v: 15 + 6 * v])
+            pp = params.copy()
+            pp[9 + 6 * v: 15 + 6 * v] = scenes.se3_log(Rd @ R, Rd @ t + td)
+            return O.calib_evaluate(pp, s["obj"], s["img"], jac=False)[1]
+        num = (shifted(+1) - shifted(-1)) / (2 * eps)
+        assert np.allclose(num[v], Jx[v, ..., k], rtol=1e-5, atol=1e-3)
