@@ -1,0 +1,194 @@
+/*
+ * stba.h -- C ABI of the MI355X-native nonlinear-least-squares engine ("slam-tricks bundle
+ * adjustment").  This is the drop-in boundary for the one hot path of Unsigned-Long/slam-tricks:
+ * the Ceres-driven NLS solve of st17-ceres / st20-g2o / st3-calibration.
+ *
+ * Plain C: opaque handles, caller-owned buffers, int status codes, no exceptions, no torch or
+ * HIP types in any signature (a HIP stream is passed as void*).  Everything FP64.
+ * All `double*`/`int*` arguments are HOST pointers unless the name ends in `_dev`.
+ *
+ * What each entry point replaces in the reference (paths relative to /root/reference):
+ *
+ *   stba_ba_create / _set_params / _get_params
+ *        ceres::Problem construction for the BA factor graph: AddResidualBlock(ProjectFactor,
+ *        {SO3, POS, landmark}) + AddParameterBlock(SO3, 4, LieLocalParameterization<SO3d>) +
+ *        SetParameterBlockConstant               st20-g2o/src/include/test_ceres.h:109-130
+ *        (same factor with constant landmarks = the PnP problems of
+ *                                                st17-ceres/src/include/solver.hpp:247-385)
+ *   stba_ba_evaluate      CostFunction::Evaluate over all residual blocks: residuals + Jacobians
+ *                         test_ceres.h:63-80 (ProjectFactor), solver.hpp:168-212 (analytic form,
+ *                         with the hat(pInC) rotation block -- SURVEY.md header fact 2),
+ *                         composed with LieLocalParameterization::ComputeJacobian solver.hpp:48-54
+ *   stba_ba_normal_blocks block-sparse J^T J / J^T r      solver.hpp:402-436 (H += J^T J, g += -J^T r),
+ *                         block structure sim_data.h:108-159
+ *   stba_ba_reduced_system / stba_ba_solve_reduced / stba_ba_back_substitute
+ *                         options.linear_solver_type = SPARSE_SCHUR   test_ceres.h:145
+ *                         (g2o: BlockSolver<6,3> + setMarginalized    test_g2o.h:95-100,121)
+ *   stba_ba_apply_step    LieLocalParameterization::Plus solver.hpp:38-45 / oplusImpl test_g2o.h:36-39,60-63
+ *   stba_ba_solve         ceres::Solve(options, &problem, &summary)   test_ceres.h:148, solver.hpp:286
+ *   stba_ba_lm_iterations fixed-work LM iterations (bench mode; no reference counterpart)
+ *   stba_ba_triangulate   per-landmark Triangulation solves           sim_data.cpp:299-311
+ *   stba_dense_*          the small dense problems: DENSE_QR path     solver.hpp:282, ceres_bound.cpp:40
+ *   stba_cholesky_*       dense SPD factor/solve used on the reduced camera system
+ *                         (hMat.ldlt().solve(gMat) solver.hpp:438; calib.cpp:393)
+ */
+#ifndef STBA_H
+#define STBA_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define STBA_VERSION 1
+
+/* status codes */
+enum {
+    STBA_OK = 0,
+    STBA_ERR_INVALID_ARGUMENT = -1,
+    STBA_ERR_NO_DEVICE = -2,       /* no HIP device / runtime failure: the product has no CPU fallback */
+    STBA_ERR_HIP = -3,
+    STBA_ERR_NOT_POSITIVE_DEFINITE = -4,
+    STBA_ERR_ALLOC = -5,
+    STBA_ERR_STATE = -6,
+    STBA_ERR_CALLBACK = -7
+};
+
+const char* stba_status_string(int status);
+const char* stba_last_error(void);      /* thread-local detail of the last failure */
+int stba_version(void);
+/* number of visible HIP devices (0 => every compute entry point returns STBA_ERR_NO_DEVICE) */
+int stba_device_count(void);
+
+/* ---- Levenberg-Marquardt options: the fields the reference sets plus Ceres' defaults --------
+ * (solver.hpp:272-282, test_ceres.h:133-146; defaults: SURVEY.md 8c) */
+typedef struct {
+    int    max_num_iterations;            /* 50 */
+    double initial_trust_region_radius;   /* 1e4 */
+    double max_trust_region_radius;       /* 1e16 */
+    double min_trust_region_radius;       /* 1e-32 */
+    double min_relative_decrease;         /* 1e-3 */
+    double min_lm_diagonal;               /* 1e-6 */
+    double max_lm_diagonal;               /* 1e32 */
+    double function_tolerance;            /* 1e-6 */
+    double gradient_tolerance;            /* 1e-10 */
+    double parameter_tolerance;           /* 1e-8 */
+    int    jacobi_scaling;                /* 1 */
+    int    num_threads;                   /* accepted and ignored (reference sets 1) */
+    int    minimizer_progress_to_stdout;  /* solver.hpp:278 */
+    int    update_state_every_iteration;  /* solver.hpp:277: copy parameters back before callbacks */
+} stba_lm_options;
+
+void stba_lm_default_options(stba_lm_options* opt);
+
+enum { STBA_CONVERGENCE = 0, STBA_NO_CONVERGENCE = 1, STBA_FAILURE = 2 };
+enum { STBA_TERM_NONE = 0, STBA_TERM_GRADIENT = 1, STBA_TERM_FUNCTION = 2, STBA_TERM_PARAMETER = 3,
+       STBA_TERM_MAX_ITER = 4, STBA_TERM_MIN_RADIUS = 5, STBA_TERM_SOLVER_FAIL = 6,
+       STBA_TERM_FIXED = 7, STBA_TERM_USER = 8 };
+
+typedef struct {
+    int    termination_type;
+    int    termination_reason;
+    int    num_iterations;
+    int    num_successful_steps;
+    int    num_unsuccessful_steps;
+    double initial_cost;
+    double final_cost;
+    double final_radius;
+    double final_gradient_max_norm;
+    double seconds_total;
+    /* device time per phase, milliseconds, summed over iterations (hipEvent) */
+    double ms_linearize, ms_schur, ms_solve, ms_backsub, ms_cost;
+} stba_lm_summary;
+
+/* iteration trace row: cost, cost_change, gradient_max_norm, step_norm, relative_decrease,
+ * radius, accepted */
+#define STBA_TRACE_COLS 7
+
+/* IterationCallback (solver.hpp:215-245, test_ceres.h:83-96): return 0 to continue */
+typedef int (*stba_iteration_callback)(void* user, int iteration, double cost, double cost_change,
+                                       double gradient_max_norm, double step_norm, double radius,
+                                       int step_is_successful);
+
+/* cross-rank sum of `count` doubles resident on the device, enqueued on `hip_stream`
+ * (landmark sharding, SURVEY.md 8e: RCCL all-reduce of the reduced camera system).  Return 0. */
+typedef int (*stba_allreduce_fn)(void* user, void* buf_dev, size_t count, void* hip_stream);
+
+/* ================================ bundle-adjustment engine ================================ */
+typedef struct stba_ba stba_ba;
+
+/* cams: n_cams*7 (qx qy qz qw tx ty tz, camera-to-world); pts: n_pts*3; observations in any
+ * order (the engine regroups them landmark-major); obs_feat: n_obs*2 normalised image coords.
+ * cam_fixed: n_cams*6 bytes (1 = dof constant; NULL = all free; order [rot(3), pos(3)]);
+ * pt_fixed: n_pts bytes (1 = landmark constant; NULL = all free).
+ * hip_stream: hipStream_t to enqueue on (NULL = the engine creates its own). */
+int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double* cams,
+                   const double* pts, const int* obs_cam, const int* obs_pt, const double* obs_feat,
+                   const unsigned char* cam_fixed, const unsigned char* pt_fixed, void* hip_stream);
+int stba_ba_destroy(stba_ba* ba);
+int stba_ba_set_params(stba_ba* ba, const double* cams, const double* pts);
+int stba_ba_get_params(stba_ba* ba, double* cams, double* pts);
+/* multi-GPU: this engine holds one landmark shard; all cameras are replicated.  The hook sums
+ * the packed reduced system / scalars across ranks.  rank 0 owns the once-only diagonal terms. */
+int stba_ba_set_allreduce(stba_ba* ba, stba_allreduce_fn fn, void* user, int rank, int world_size);
+/* padded order of the dense reduced system (multiple of the factorisation block) */
+int stba_ba_reduced_dim(const stba_ba* ba, int* n, int* n_padded);
+
+/* --- stage entry points (each runs the HIP kernels and optionally copies results out) ------ */
+/* residuals r[n_obs*2], Jc[n_obs*12] (2x6 row-major), Jp[n_obs*6] (2x3), in the caller's
+ * observation order; any output may be NULL.  cost = 1/2 sum r^2. */
+int stba_ba_evaluate(stba_ba* ba, double* cost, double* r, double* Jc, double* Jp);
+/* cost only (residual kernel without Jacobians), at the current parameters */
+int stba_ba_cost(stba_ba* ba, double* cost);
+/* needs a preceding stba_ba_evaluate.  Hcc[n_cams*36], gc[n_cams*6], Hpp[n_pts*9], gp[n_pts*3] */
+int stba_ba_normal_blocks(stba_ba* ba, double* Hcc, double* gc, double* Hpp, double* gp);
+/* needs normal blocks.  dc[n_cams*6], dp[n_pts*3]: diagonal damping.  S: n*n row-major with
+ * n = 6*n_cams (lower triangle valid), rhs[n].  S/rhs may be NULL (device-only). */
+int stba_ba_reduced_system(stba_ba* ba, const double* dc, const double* dp, double* S, double* rhs);
+/* Cholesky + solve of the reduced system on the device: dxc[n_cams*6] */
+int stba_ba_solve_reduced(stba_ba* ba, double* dxc);
+/* dxp[n_pts*3] from the camera step currently on the device */
+int stba_ba_back_substitute(stba_ba* ba, double* dxp);
+/* trial point = current (+) step on the device; returns its cost; accept != 0 keeps it */
+int stba_ba_apply_step(stba_ba* ba, int accept, double* new_cost);
+
+/* --- whole solves ------------------------------------------------------------------------ */
+/* trace: (max_num_iterations+1)*STBA_TRACE_COLS doubles or NULL */
+int stba_ba_solve(stba_ba* ba, const stba_lm_options* opt, stba_lm_summary* summary, double* trace,
+                  stba_iteration_callback cb, void* cb_user);
+/* exactly `iterations` LM iterations, each re-linearising, solving and evaluating the trial
+ * point; no convergence tests.  The unit of work bench.py times.  Parameters stay on the device. */
+int stba_ba_lm_iterations(stba_ba* ba, const stba_lm_options* opt, int iterations,
+                          stba_lm_summary* summary, double* trace);
+/* per-landmark refinement with cameras fixed (sim_data.cpp:299-311) */
+int stba_ba_triangulate(stba_ba* ba, int max_iter);
+
+/* average device time (ms) of the residual+Jacobian kernel over `reps` back-to-back launches,
+ * measured with hipEvents on the engine's stream (bench.py roofline leg). */
+int stba_ba_time_linearize(stba_ba* ba, int reps, double* ms_avg);
+
+/* ================================ dense SPD solver ======================================== */
+/* A: n*n row-major SPD (lower triangle read), overwritten by L (lower).  Runs the blocked MFMA
+ * Cholesky on the device.  Returns STBA_ERR_NOT_POSITIVE_DEFINITE if a pivot fails. */
+int stba_cholesky_factor(double* A, int n, void* hip_stream);
+/* solves A x = b for one right-hand side: b overwritten by x */
+int stba_cholesky_solve(const double* A, int n, double* b, void* hip_stream);
+/* device-resident timing of factor+solve on an n x n synthetic SPD system, ms per solve */
+int stba_cholesky_time(int n, int reps, double* ms_avg, void* hip_stream);
+
+/* ================================ small dense LM problems ================================ */
+/* Residual blocks evaluated by a HOST callback (user CostFunction::Evaluate, solver.hpp:168-212;
+ * autodiff functors are differentiated on the host by the C++ shim), normal equations + LM
+ * step on the device.  x: n_params ambient; J row-major n_res x n_local in LOCAL coordinates. */
+typedef int (*stba_residual_fn)(void* user, const double* x, double* r, double* J);
+typedef void (*stba_plus_fn)(void* user, const double* x, const double* delta, double* x_new);
+int stba_dense_solve(stba_residual_fn fn, stba_plus_fn plus, void* user, int n_params, int n_local,
+                     int n_res, double* x, const double* lower, const double* upper,
+                     const stba_lm_options* opt, stba_lm_summary* summary, double* trace,
+                     stba_iteration_callback cb, void* cb_user);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,276 @@
+"""slam-tricks_amd -- MI355X-native nonlinear-least-squares / bundle-adjustment engine.
+
+Python here is only a thin ctypes view of the C ABI (include/stba.h) exported by
+slam-tricks_amd/libstba.so (HIP kernels for gfx950) plus the seeded scene generators; the
+product is the shared library.  Nothing in this package imports, links or calls oracle/.
+The library has no CPU fallback: on a machine without a HIP device every compute call raises
+StbaError(STBA_ERR_NO_DEVICE).
+
+Import with  importlib.import_module("slam-tricks_amd")  (the hyphen is the repository's name).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libstba.so")
+TRACE_COLS = 7
+TERM_REASON = {0: "none", 1: "gradient", 2: "function", 3: "parameter", 4: "max_iter",
+               5: "min_radius", 6: "solver_fail", 7: "fixed", 8: "user"}
+_lib = None
+
+
+class StbaError(RuntimeError):
+    def __init__(self, code, where):
+        self.code = code
+        msg = _lib.stba_last_error().decode() if _lib is not None else ""
+        super().__init__(f"{where}: status {code} ({_lib.stba_status_string(code).decode()}) {msg}")
+
+
+class LMOptions(C.Structure):
+    _fields_ = [("max_num_iterations", C.c_int), ("initial_trust_region_radius", C.c_double),
+                ("max_trust_region_radius", C.c_double), ("min_trust_region_radius", C.c_double),
+                ("min_relative_decrease", C.c_double), ("min_lm_diagonal", C.c_double),
+                ("max_lm_diagonal", C.c_double), ("function_tolerance", C.c_double),
+                ("gradient_tolerance", C.c_double), ("parameter_tolerance", C.c_double),
+                ("jacobi_scaling", C.c_int), ("num_threads", C.c_int),
+                ("minimizer_progress_to_stdout", C.c_int), ("update_state_every_iteration", C.c_int)]
+
+
+class LMSummary(C.Structure):
+    _fields_ = [("termination_type", C.c_int), ("termination_reason", C.c_int), ("num_iterations", C.c_int),
+                ("num_successful_steps", C.c_int), ("num_unsuccessful_steps", C.c_int),
+                ("initial_cost", C.c_double), ("final_cost", C.c_double), ("final_radius", C.c_double),
+                ("final_gradient_max_norm", C.c_double), ("seconds_total", C.c_double),
+                ("ms_linearize", C.c_double), ("ms_schur", C.c_double), ("ms_solve", C.c_double),
+                ("ms_backsub", C.c_double), ("ms_cost", C.c_double)]
+
+    def as_dict(self):
+        d = {k: getattr(self, k) for k, _ in self._fields_}
+        d["termination_reason"] = TERM_REASON.get(d["termination_reason"], "?")
+        return d
+
+
+ITER_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double,
+                      C.c_double, C.c_int)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+RESIDUAL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double))
+PLUS_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double))
+
+# every symbol include/stba.h declares (tests check the library exports all of them)
+EXPORTS = ["stba_status_string", "stba_last_error", "stba_version", "stba_device_count",
+           "stba_lm_default_options", "stba_ba_create", "stba_ba_destroy", "stba_ba_set_params",
+           "stba_ba_get_params", "stba_ba_set_allreduce", "stba_ba_reduced_dim", "stba_ba_evaluate",
+           "stba_ba_cost", "stba_ba_normal_blocks", "stba_ba_reduced_system", "stba_ba_solve_reduced",
+           "stba_ba_back_substitute", "stba_ba_apply_step", "stba_ba_solve", "stba_ba_lm_iterations",
+           "stba_ba_triangulate", "stba_ba_time_linearize", "stba_cholesky_factor", "stba_cholesky_solve",
+           "stba_cholesky_time", "stba_dense_solve"]
+
+
+def lib():
+    """Loads libstba.so; raises if it has not been built (no fallback of any kind)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: run `python __graft_entry__.py build` "
+                              "(hipcc, gfx950).  There is no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        L.stba_status_string.restype = C.c_char_p
+        L.stba_last_error.restype = C.c_char_p
+        _lib = L
+    return _lib
+
+
+def _chk(code, where):
+    if code != 0:
+        raise StbaError(code, where)
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def device_count():
+    return lib().stba_device_count()
+
+
+def default_options(**kw):
+    o = LMOptions()
+    lib().stba_lm_default_options(C.byref(o))
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+class BAEngine:
+    """Device-resident bundle-adjustment problem (one landmark shard per engine)."""
+
+    def __init__(self, cams, pts, obs_cam, obs_pt, obs_feat, cam_fixed=None, pt_fixed=None, stream=None):
+        self._h = C.c_void_p()
+        cams = _f64(cams).reshape(-1, 7)
+        pts = _f64(pts).reshape(-1, 3)
+        oc = np.ascontiguousarray(obs_cam, dtype=np.int32)
+        op = np.ascontiguousarray(obs_pt, dtype=np.int32)
+        of = _f64(obs_feat).reshape(-1, 2)
+        cf = None if cam_fixed is None else np.ascontiguousarray(cam_fixed, dtype=np.uint8).reshape(-1, 6)
+        pf = None if pt_fixed is None else np.ascontiguousarray(pt_fixed, dtype=np.uint8)
+        self.nc, self.np_, self.no = len(cams), len(pts), len(oc)
+        self._keep = []
+        _chk(lib().stba_ba_create(C.byref(self._h), self.nc, self.np_, self.no, _p(cams), _p(pts), _p(oc), _p(op),
+                                  _p(of), _p(cf), _p(pf), C.c_void_p(stream or 0)), "stba_ba_create")
+
+    def close(self):
+        if self._h:
+            lib().stba_ba_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- parameters
+    def set_params(self, cams=None, pts=None):
+        _chk(lib().stba_ba_set_params(self._h, _p(None if cams is None else _f64(cams)),
+                                      _p(None if pts is None else _f64(pts))), "stba_ba_set_params")
+
+    def get_params(self):
+        cams = np.zeros((self.nc, 7)); pts = np.zeros((self.np_, 3))
+        _chk(lib().stba_ba_get_params(self._h, _p(cams), _p(pts)), "stba_ba_get_params")
+        return cams, pts
+
+    def set_allreduce(self, fn, rank, world):
+        cb = ALLREDUCE_FN(fn)
+        self._keep.append(cb)
+        _chk(lib().stba_ba_set_allreduce(self._h, cb, None, rank, world), "stba_ba_set_allreduce")
+
+    def reduced_dim(self):
+        n, npad = C.c_int(), C.c_int()
+        _chk(lib().stba_ba_reduced_dim(self._h, C.byref(n), C.byref(npad)), "stba_ba_reduced_dim")
+        return n.value, npad.value
+
+    # ---- stages
+    def evaluate(self, jac=True, residuals=True):
+        cost = C.c_double()
+        r = np.zeros((self.no, 2)) if residuals else None
+        Jc = np.zeros((self.no, 2, 6)) if jac else None
+        Jp = np.zeros((self.no, 2, 3)) if jac else None
+        _chk(lib().stba_ba_evaluate(self._h, C.byref(cost), _p(r), _p(Jc), _p(Jp)), "stba_ba_evaluate")
+        return cost.value, r, Jc, Jp
+
+    def cost(self):
+        c = C.c_double()
+        _chk(lib().stba_ba_cost(self._h, C.byref(c)), "stba_ba_cost")
+        return c.value
+
+    def normal_blocks(self):
+        Hcc = np.zeros((self.nc, 6, 6)); gc = np.zeros((self.nc, 6))
+        Hpp = np.zeros((self.np_, 3, 3)); gp = np.zeros((self.np_, 3))
+        _chk(lib().stba_ba_normal_blocks(self._h, _p(Hcc), _p(gc), _p(Hpp), _p(gp)), "stba_ba_normal_blocks")
+        return Hcc, gc, Hpp, gp
+
+    def reduced_system(self, dc, dp, fetch=True):
+        n = 6 * self.nc
+        S = np.zeros((n, n)) if fetch else None
+        rhs = np.zeros(n) if fetch else None
+        _chk(lib().stba_ba_reduced_system(self._h, _p(_f64(dc)), _p(_f64(dp)), _p(S), _p(rhs)),
+             "stba_ba_reduced_system")
+        return S, rhs
+
+    def solve_reduced(self):
+        dxc = np.zeros(6 * self.nc)
+        _chk(lib().stba_ba_solve_reduced(self._h, _p(dxc)), "stba_ba_solve_reduced")
+        return dxc
+
+    def back_substitute(self):
+        dxp = np.zeros((self.np_, 3))
+        _chk(lib().stba_ba_back_substitute(self._h, _p(dxp)), "stba_ba_back_substitute")
+        return dxp
+
+    def apply_step(self, accept=True):
+        c = C.c_double()
+        _chk(lib().stba_ba_apply_step(self._h, int(bool(accept)), C.byref(c)), "stba_ba_apply_step")
+        return c.value
+
+    # ---- solves
+    def solve(self, opt=None, callback=None, **kw):
+        opt = opt or default_options(**kw)
+        trace = np.zeros((opt.max_num_iterations + 1, TRACE_COLS))
+        summ = LMSummary()
+        cb = ITER_CB(callback) if callback else C.cast(None, ITER_CB)
+        _chk(lib().stba_ba_solve(self._h, C.byref(opt), C.byref(summ), _p(trace), cb, None), "stba_ba_solve")
+        return summ, trace[: summ.num_iterations + 1]
+
+    def lm_iterations(self, iterations, opt=None, **kw):
+        opt = opt or default_options(**kw)
+        trace = np.zeros((iterations + 1, TRACE_COLS))
+        summ = LMSummary()
+        _chk(lib().stba_ba_lm_iterations(self._h, C.byref(opt), int(iterations), C.byref(summ), _p(trace)),
+             "stba_ba_lm_iterations")
+        return summ, trace
+
+    def triangulate(self, max_iter=50):
+        _chk(lib().stba_ba_triangulate(self._h, int(max_iter)), "stba_ba_triangulate")
+
+    def time_linearize(self, reps=20):
+        ms = C.c_double()
+        _chk(lib().stba_ba_time_linearize(self._h, int(reps), C.byref(ms)), "stba_ba_time_linearize")
+        return ms.value
+
+
+def cholesky_factor(A, stream=None):
+    A = _f64(A).copy()
+    _chk(lib().stba_cholesky_factor(_p(A), A.shape[0], C.c_void_p(stream or 0)), "stba_cholesky_factor")
+    return np.tril(A)
+
+
+def cholesky_solve(A, b, stream=None):
+    A = _f64(A); x = _f64(b).copy()
+    _chk(lib().stba_cholesky_solve(_p(A), A.shape[0], _p(x), C.c_void_p(stream or 0)), "stba_cholesky_solve")
+    return x
+
+
+def cholesky_time(n, reps=5, stream=None):
+    ms = C.c_double()
+    _chk(lib().stba_cholesky_time(int(n), int(reps), C.byref(ms), C.c_void_p(stream or 0)), "stba_cholesky_time")
+    return ms.value
+
+
+def dense_solve(residual, x0, n_res, n_local=None, plus=None, lower=None, upper=None, opt=None, callback=None, **kw):
+    """residual(x) -> (r[n_res], J[n_res, n_local] or None-ignored); plus(x, d) -> x_new.
+    The residual/Jacobian callback runs on the host (it is user code, like
+    CostFunction::Evaluate); normal equations and the damped Cholesky step run on the device."""
+    x = _f64(x0).copy()
+    n_params = x.size
+    n_local = n_local or n_params
+
+    def _fn(_u, xp, rp, Jp):
+        xx = np.ctypeslib.as_array(xp, shape=(n_params,)).copy()
+        r, J = residual(xx)
+        np.ctypeslib.as_array(rp, shape=(n_res,))[:] = r
+        if Jp:
+            np.ctypeslib.as_array(Jp, shape=(n_res * n_local,))[:] = np.asarray(J, dtype=np.float64).reshape(-1)
+        return 0
+
+    def _plus(_u, xp, dp, op):
+        xx = np.ctypeslib.as_array(xp, shape=(n_params,)).copy()
+        dd = np.ctypeslib.as_array(dp, shape=(n_local,)).copy()
+        np.ctypeslib.as_array(op, shape=(n_params,))[:] = plus(xx, dd)
+
+    opt = opt or default_options(**kw)
+    trace = np.zeros((opt.max_num_iterations + 1, TRACE_COLS))
+    summ = LMSummary()
+    cfn = RESIDUAL_FN(_fn)
+    cplus = PLUS_FN(_plus) if plus is not None else C.cast(None, PLUS_FN)
+    cb = ITER_CB(callback) if callback else C.cast(None, ITER_CB)
+    lo = None if lower is None else _f64(lower)
+    up = None if upper is None else _f64(upper)
+    _chk(lib().stba_dense_solve(cfn, cplus, None, n_params, n_local, n_res, _p(x), _p(lo), _p(up), C.byref(opt),
+                                C.byref(summ), _p(trace), cb, None), "stba_dense_solve")
+    return x, summ, trace[: summ.num_iterations + 1]

@@ -1,0 +1,760 @@
+// ba_kernels.hip -- HIP kernels of the bundle-adjustment hot path for gfx950 (MI355X), FP64.
+//
+// Reference semantics (paths relative to /root/reference):
+//   residual            st20-g2o/src/include/test_ceres.h:63-80   r = proj(R^T (L - t)) - feature
+//   Jacobian            st17-ceres/src/include/solver.hpp:183-209 with the hat(pInC) rotation block
+//                       (SURVEY.md header fact 2; == autodiff composed with solver.hpp:48-54)
+//   J^T J / J^T r       solver.hpp:402-436; block structure st20-g2o/src/include/sim_data.h:108-159
+//   Schur elimination   SPARSE_SCHUR, test_ceres.h:145 / setMarginalized, test_g2o.h:121
+//   manifold update     solver.hpp:38-45, test_g2o.h:36-39,60-63
+//
+// Data layout in HBM (all device resident for the whole solve):
+//   cams   [n_cams][7]   qx qy qz qw tx ty tz          (56 B/camera; staged into LDS per workgroup)
+//   pts    [n_pts][3]
+//   obs    landmark-major: feat double2[n_obs], obs_cam int[n_obs], obs_pt int[n_obs]
+//   r      double2[n_obs];  Jc [n_obs][12] (2x6 row-major: d/dtheta | d/dt);  Jp [n_obs][6] (2x3)
+//   Hpp6   [n_pts][6] (xx xy xz yy yz zz), gp [n_pts][3], Hinv6 [n_pts][6]
+//   Hcc    [n_cams][36], gc [n_cams][6]
+//   S      [lda][lda] dense reduced camera system (lower triangle), lda = padded 6*n_cams
+#include "ba_kernels.hpp"
+
+namespace stba {
+
+// ===========================================================================================
+// residual + Jacobian, one observation per lane.
+// Algorithmic HBM traffic per observation: 24 B (feature + 2 indices) + landmark 24 B / (obs per
+// landmark) read; 16 B (r) + 96 B (Jc) + 48 B (Jp) written = 186.5 B at 10 obs/landmark
+// (SURVEY.md 8d).  Camera blocks are staged once per workgroup in LDS; the per-lane 96 B / 48 B
+// Jacobian rows are transposed through LDS so that every global store instruction writes
+// 16 B x 64 contiguous lanes.
+// ===========================================================================================
+template <bool CAMS_IN_LDS, bool WITH_JAC>
+__global__ __launch_bounds__(LIN_THREADS) void ba_linearize_kernel(LinArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* s_jc = smem;                                   // [LIN_THREADS][13]
+    double* s_jp = smem + (WITH_JAC ? LIN_THREADS * 13 : 0);   // [LIN_THREADS][7]
+    double* s_cam = s_jp + (WITH_JAC ? LIN_THREADS * 7 : 0);   // [n_cams][7]
+    const int tid = threadIdx.x;
+    if (CAMS_IN_LDS) {
+        for (int i = tid; i < a.n_cams * 7; i += LIN_THREADS) s_cam[i] = a.cams[i];
+        __syncthreads();
+    }
+    double cost = 0.0;
+    const int n_tiles = (a.n_obs + LIN_THREADS - 1) / LIN_THREADS;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int base = tile * LIN_THREADS;
+        const int i = base + tid;
+        if (i < a.n_obs) {
+            const double2 f = a.feat[i];
+            const int c = a.obs_cam[i], j = a.obs_pt[i];
+            const double* cam = CAMS_IN_LDS ? (s_cam + c * 7) : (a.cams + (size_t)c * 7);
+            double q[4] = {cam[0], cam[1], cam[2], cam[3]};
+            const double t0 = cam[4], t1 = cam[5], t2 = cam[6];
+            const double* L = a.pts + (size_t)j * 3;
+            const double d0 = L[0] - t0, d1 = L[1] - t1, d2 = L[2] - t2;
+            double R[9];
+            quat_to_rot(q, R);
+            const double x = R[0] * d0 + R[3] * d1 + R[6] * d2;   // R^T (L - t)
+            const double y = R[1] * d0 + R[4] * d1 + R[7] * d2;
+            const double z = R[2] * d0 + R[5] * d1 + R[8] * d2;
+            const double iz = 1.0 / z;
+            const double xn = x * iz, yn = y * iz;
+            const double r0 = xn - f.x, r1 = yn - f.y;
+            if (a.r) a.r[i] = make_double2(r0, r1);
+            cost += r0 * r0 + r1 * r1;
+            if (WITH_JAC) {
+                // A = [[iz,0,-xn iz],[0,iz,-yn iz]];  A*hat(pInC) in closed form
+                const unsigned cm = a.cam_fixed ? a.cam_fixed[c] : 0u;
+                const bool pf = a.pt_fixed ? (a.pt_fixed[j] != 0) : false;
+                double* jc = s_jc + tid * 13;
+                double* jp = s_jp + tid * 7;
+                jc[0] = (cm & 1u) ? 0.0 : xn * yn;
+                jc[1] = (cm & 2u) ? 0.0 : -(1.0 + xn * xn);
+                jc[2] = (cm & 4u) ? 0.0 : yn;
+                jc[6] = (cm & 1u) ? 0.0 : 1.0 + yn * yn;
+                jc[7] = (cm & 2u) ? 0.0 : -xn * yn;
+                jc[8] = (cm & 4u) ? 0.0 : -xn;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    // (A R^T)_{0k} = iz*R[k][0] - xn*iz*R[k][2];  row 1 with R[k][1], yn
+                    const double p0 = iz * (R[k * 3 + 0] - xn * R[k * 3 + 2]);
+                    const double p1 = iz * (R[k * 3 + 1] - yn * R[k * 3 + 2]);
+                    const bool fx = (cm >> (3 + k)) & 1u;
+                    jc[3 + k] = fx ? 0.0 : -p0;
+                    jc[9 + k] = fx ? 0.0 : -p1;
+                    jp[k] = pf ? 0.0 : p0;
+                    jp[3 + k] = pf ? 0.0 : p1;
+                }
+            }
+        }
+        if (WITH_JAC) {
+            __syncthreads();
+            const int n_here = min(LIN_THREADS, a.n_obs - base);
+            // Jc: n_here*12 doubles, written as double2 (16 B per lane, contiguous across lanes)
+            double* gjc = a.Jc + (size_t)base * 12;
+            for (int e = tid; e < n_here * 6; e += LIN_THREADS) {
+                const int o = e / 6, k = (e - o * 6) * 2;
+                const double* s = s_jc + o * 13 + k;
+                *reinterpret_cast<double2*>(gjc + 2 * (size_t)e) = make_double2(s[0], s[1]);
+            }
+            double* gjp = a.Jp + (size_t)base * 6;
+            for (int e = tid; e < n_here * 3; e += LIN_THREADS) {
+                const int o = e / 3, k = (e - o * 3) * 2;
+                const double* s = s_jp + o * 7 + k;
+                *reinterpret_cast<double2*>(gjp + 2 * (size_t)e) = make_double2(s[0], s[1]);
+            }
+            __syncthreads();
+        }
+    }
+    // deterministic block reduction of the cost
+    __shared__ double s_red[LIN_THREADS / 64];
+    for (int off = 32; off > 0; off >>= 1) cost += __shfl_down(cost, off, 64);
+    if ((tid & 63) == 0) s_red[tid >> 6] = cost;
+    __syncthreads();
+    if (tid == 0) {
+        double s = 0.0;
+        for (int w = 0; w < LIN_THREADS / 64; ++w) s += s_red[w];
+        a.cost_partial[blockIdx.x] = s;
+    }
+}
+
+size_t lin_lds_bytes(int n_cams, bool cams_in_lds, bool with_jac) {
+    size_t d = 0;
+    if (with_jac) d += (size_t)LIN_THREADS * 20;
+    if (cams_in_lds) d += (size_t)n_cams * 7;
+    return d * sizeof(double) + 16;
+}
+
+int launch_linearize(const LinArgs& a, bool with_jac, int grid, hipStream_t st) {
+    const bool in_lds = lin_lds_bytes(a.n_cams, true, with_jac) <= LIN_MAX_LDS;
+    const size_t lds = lin_lds_bytes(a.n_cams, in_lds, with_jac);
+    static bool attr = false;
+    if (!attr) {
+        STBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_linearize_kernel<true, true>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, LIN_MAX_LDS));
+        STBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_linearize_kernel<true, false>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, LIN_MAX_LDS));
+        STBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_linearize_kernel<false, true>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, LIN_MAX_LDS));
+        attr = true;
+    }
+    if (in_lds && with_jac)
+        hipLaunchKernelGGL((ba_linearize_kernel<true, true>), dim3(grid), dim3(LIN_THREADS), lds, st, a);
+    else if (in_lds)
+        hipLaunchKernelGGL((ba_linearize_kernel<true, false>), dim3(grid), dim3(LIN_THREADS), lds, st, a);
+    else if (with_jac)
+        hipLaunchKernelGGL((ba_linearize_kernel<false, true>), dim3(grid), dim3(LIN_THREADS), lds, st, a);
+    else
+        hipLaunchKernelGGL((ba_linearize_kernel<false, false>), dim3(grid), dim3(LIN_THREADS), lds, st, a);
+    STBA_HIP(hipGetLastError());
+    return STBA_OK;
+}
+
+// ===========================================================================================
+// scalar reductions (fixed order => deterministic)
+// ===========================================================================================
+// out[k] = sum_i partial[i*stride + k], k < K ; one workgroup
+__global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restrict__ partial, int n,
+                                                           int stride, int K, double* __restrict__ out) {
+    __shared__ double s[256];
+    for (int k = 0; k < K; ++k) {
+        double v = 0.0;
+        for (int i = threadIdx.x; i < n; i += 256) v += partial[(size_t)i * stride + k];
+        s[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) {
+            if (threadIdx.x < off) s[threadIdx.x] += s[threadIdx.x + off];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) out[k] = s[0];
+        __syncthreads();
+    }
+}
+
+int launch_sum_partials(const double* partial, int n, int stride, int K, double* out, hipStream_t st) {
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, st, partial, n, stride, K, out);
+    STBA_HIP(hipGetLastError());
+    return STBA_OK;
+}
+
+// max |v[i]| over n entries -> out[0] (single workgroup, grid-stride)
+__global__ __launch_bounds__(1024) void absmax_kernel(const double* __restrict__ v, size_t n,
+                                                      const double* __restrict__ v2, size_t n2,
+                                                      double* __restrict__ out) {
+    __shared__ double s[1024];
+    double m = 0.0;
+    for (size_t i = threadIdx.x; i < n; i += 1024) m = fmax(m, fabs(v[i]));
+    for (size_t i = threadIdx.x; i < n2; i += 1024) m = fmax(m, fabs(v2[i]));
+    s[threadIdx.x] = m;
+    __syncthreads();
+    for (int off = 512; off > 0; off >>= 1) {
+        if (threadIdx.x < off) s[threadIdx.x] = fmax(s[threadIdx.x], s[threadIdx.x + off]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = s[0];
+}
+
+int launch_absmax(const double* v, size_t n, const double* v2, size_t n2, double* out, hipStream_t st) {
+    hipLaunchKernelGGL(absmax_kernel, dim3(1), dim3(1024), 0, st, v, n, v2, n2, out);
+    STBA_HIP(hipGetLastError());
+    return STBA_OK;
+}
+
+// ===========================================================================================
+// point blocks: Hpp_j = sum Jp^T Jp, gp_j = sum Jp^T r over the landmark's observation segment
+// ===========================================================================================
+__global__ __launch_bounds__(256) void ba_point_blocks_kernel(int n_pts, const int* __restrict__ pt_start,
+                                                              const double* __restrict__ Jp,
+                                                              const double2* __restrict__ r,
+                                                              double* __restrict__ Hpp6, double* __restrict__ gp) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n_pts) return;
+    double h0 = 0, h1 = 0, h2 = 0, h3 = 0, h4 = 0, h5 = 0, g0 = 0, g1 = 0, g2 = 0;
+    const int e = pt_start[j + 1];
+    for (int i = pt_start[j]; i < e; ++i) {
+        const double2* p = reinterpret_cast<const double2*>(Jp + (size_t)i * 6);
+        const double2 a = p[0], b = p[1], c = p[2];   // a.x a.y b.x | b.y c.x c.y
+        const double2 ri = r[i];
+        const double j00 = a.x, j01 = a.y, j02 = b.x, j10 = b.y, j11 = c.x, j12 = c.y;
+        h0 += j00 * j00 + j10 * j10; h1 += j00 * j01 + j10 * j11; h2 += j00 * j02 + j10 * j12;
+        h3 += j01 * j01 + j11 * j11; h4 += j01 * j02 + j11 * j12; h5 += j02 * j02 + j12 * j12;
+        g0 += j00 * ri.x + j10 * ri.y; g1 += j01 * ri.x + j11 * ri.y; g2 += j02 * ri.x + j12 * ri.y;
+    }
+    double* H = Hpp6 + (size_t)j * 6;
+    H[0] = h0; H[1] = h1; H[2] = h2; H[3] = h3; H[4] = h4; H[5] = h5;
+    double* g = gp + (size_t)j * 3;
+    g[0] = g0; g[1] = g1; g[2] = g2;
+}
+
+int launch_point_blocks(int n_pts, const int* pt_start, const double* Jp, const double2* r, double* Hpp6,
+                        double* gp, hipStream_t st) {
+    hipLaunchKernelGGL(ba_point_blocks_kernel, dim3((n_pts + 255) / 256), dim3(256), 0, st, n_pts, pt_start,
+                       Jp, r, Hpp6, gp);
+    STBA_HIP(hipGetLastError());
+    return STBA_OK;
+}
+
+// ===========================================================================================
+// camera blocks: wave-segmented reduction over the camera-sorted permutation.
+// One wave per chunk (<= CAM_CHUNK observations of ONE camera): each lane accumulates the 21
+// unique entries of Jc^T Jc and the 6 of Jc^T r over its strided share, a wave shuffle tree
+// reduces them, lane 0 writes the chunk partial; a second kernel adds the chunks of a camera
+// in order (deterministic, no atomics).
+// ===========================================================================================
+__global__ __launch_bounds__(256) void ba_camera_partial_kernel(int n_chunks, const int* __restrict__ chunk_begin,
+                                                                const int* __restrict__ chunk_end,
+                                                                const int* __restrict__ cam_perm,
+                                                                const double* __restrict__ Jc,
+                                                                const double2* __restrict__ r,
+                                                                double* __restrict__ partial) {
+    const int lane = threadIdx.x & 63;
+    const int ch = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ch >= n_chunks) return;
+    double acc[27];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) acc[k] = 0.0;
+    const int e = chunk_end[ch];
+    for (int p = chunk_begin[ch] + lane; p < e; p += 64) {
+        const int i = cam_perm[p];
+        const double2* pj = reinterpret_cast<const double2*>(Jc + (size_t)i * 12);
+        double j[12];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { const double2 v = pj[k]; j[2 * k] = v.x; j[2 * k + 1] = v.y; }
+        const double2 ri = r[i];
+        int idx = 0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int b = 0; b <= a; ++b) acc[idx++] += j[a] * j[b] + j[6 + a] * j[6 + b];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) acc[21 + a] += j[a] * ri.x + j[6 + a] * ri.y;
+    }
+#pragma unroll
+    for (int k = 0; k < 27; ++k) {
+        double v = acc[k];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        acc[k] = v;
+    }
+    if (lane == 0) {
+        double* o = partial + (size_t)ch * 28;
+#pragma unroll
+        for (int k = 0; k < 27; ++k) o[k] = acc[k];
+    }
+}
+
+__global__ __launch_bounds__(256) void ba_camera_final_kernel(int n_cams, const int* __restrict__ cam_chunk_start,
+                                                              const double* __restrict__ partial,
+                                                              double* __restrict__ Hcc, double* __restrict__ gc) {
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    const int c = gid / 27, k = gid - c * 27;
+    if (c >= n_cams) return;
+    double s = 0.0;
+    const int e = cam_chunk_start[c + 1];
+    for (int ch = cam_chunk_start[c]; ch < e; ++ch) s += partial[(size_t)ch * 28 + k];
+    if (k < 21) {
+        int a = 0, b = k;
+        while (b > a) { ++a; b -= a; }   // k = a(a+1)/2 + b
+        Hcc[(size_t)c * 36 + a * 6 + b] = s;
+        Hcc[(size_t)c * 36 + b * 6 + a] = s;
+    } else {
+        gc[(size_t)c * 6 + (k - 21)] = s;
+    }
+}
+
+int launch_camera_blocks(int n_cams, int n_chunks, const int* chunk_begin, const int* chunk_end,
+                         const int* cam_chunk_start, const int* cam_perm, const double* Jc, const double2* r,
+                         double* partial, double* Hcc, double* gc, hipStream_t st) {
+    if (n_chunks > 0)
+        hipLaunchKernelGGL(ba_camera_partial_kernel, dim3((n_chunks + 3) / 4), dim3(256), 0, st, n_chunks,
+                           chunk_begin, chunk_end, cam_perm, Jc, r, partial);
+    hipLaunchKernelGGL(ba_camera_final_kernel, dim3((n_cams * 27 + 255) / 256), dim3(256), 0, st, n_cams,
+                       cam_chunk_start, partial, Hcc, gc);
+    STBA_HIP(hipGetLastError());
+    return STBA_OK;
+}
+
+// ===========================================================================================
+// Levenberg-Marquardt diagonal (Ceres LevenbergMarquardtStrategy + jacobi_scaling):
+//   scale_i = 1/(1+sqrt(H_ii))            (first call only)
+//   d_i = clamp(H_ii scale_i^2, min, max) / radius / scale_i^2
+// diag entry i of a block array with `bs` dofs per block, `bstride` doubles per block and
+// diagonal element k at offset doff(k).
+// ===========================================================================================
+__global__ __launch_bounds__(256) void lm_diagonal_kernel(int n, int bs, int bstride, int kind,
+                                                          const double* __restrict__ H, double* __restrict__ scale,
+                                                          int init_scale, int use_scaling,
+                                                          const double* __restrict__ radius_dev, double radius_host,
+                                                          double dmin, double dmax, double* __restrict__ d) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int blk = i / bs, k = i - blk * bs;
+    // kind 0: full bs x bs row-major block; kind 1: symmetric 3x3 packed (xx xy xz yy yz zz)
+    // kind 2: H is the diagonal itself
+    const int off = (kind == 0) ? k * (bs + 1) : (kind == 1 ? (k == 0 ? 0 : (k == 1 ? 3 : 5)) : 0);
+    const double h = H[(size_t)blk * bstride + off];
+    double s = 1.0;
+    if (use_scaling) {
+        if (init_scale) { s = 1.0 / (1.0 + sqrt(h)); scale[i] = s; }
+        else s = scale[i];
+    } else if (init_scale) scale[i] = 1.0;
+    const double radius = radius_dev ? radius_dev[0] : radius_host;
+    const double s2 = s * s;
+    const double v = fmin(fmax(h * s2, dmin), dmax);
+    d[i] = v / radius / s2;
+}
+
+int launch_lm_diagonal(int n, int bs, int bstride, int kind, const double* H, double* scale, int init_scale,
+                       int use_scaling, double radius, double dmin, double dmax, double* d, hipStream_t st) {
+    hipLaunchKernelGGL(lm_diagonal_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, bs, bstride, kind, H,
+                       scale, init_scale, use_scaling, (const double*)nullptr, radius, dmin, dmax, d);
+    STBA_HIP(hipGetLastError());
+    return STBA_OK;
+}
+
+// (Hpp + diag(dp))^-1 per landmark; zero for constant / degenerate landmarks
+__global__ __launch_bounds__(256) void ba_point_invert_kernel(int n_pts, const double* __restrict__ Hpp6,
+                                                              const double* __restrict__ dp,
+                                                              const unsigned char* __restrict__ pt_fixed,
+                                                              double* __restrict__ Hinv6) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n_pts) return;
+    double H[6], Hi[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 6; ++k) H[k] = Hpp6[(size_t)j * 6 + k];
+    H[0] += dp[(size_t)j * 3]; H[3] += dp[(size_t)j * 3 + 1]; H[5] += dp[(size_t)j * 3 + 2];
+    const bool fixed = pt_fixed ? (pt_fixed[j] != 0) : false;
+    if (fixed || !inv3_sym6(H, Hi)) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) Hi[k] = 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) Hinv6[(size_t)j * 6 + k] = Hi[k];
+}
+
+int launch_point_invert(int n_pts, const double* Hpp6, const double* dp, const unsigned char* pt_fixed,
+                        double* Hinv6, hipStream_t st) {
+    hipLaunchKernelGGL(ba_point_invert_kernel, dim3((n_pts + 255) / 256), dim3(256), 0, st, n_pts, Hpp6, dp,
+                       pt_fixed, Hinv6);
+    STBA_HIP(hipGetLastError());
+    return STBA_OK;
+}
+
+// ===========================================================================================
+// Schur complement of the landmark blocks, one observation per lane:
+//   E_i = W_i Hpp_j^-1 (6x3),  rhs[c_i] += E_i gp_j,
+//   S[c_i, c_l] -= E_i W_l^T  for every observation l of the same landmark with c_l <= c_i
+// (lower block triangle; within a diagonal block only a >= b).  FP64 hardware atomics
+// (global_atomic_add_f64) into the dense S.
+// ===========================================================================================
+__device__ inline void load_jc_jp(const double* __restrict__ Jc, const double* __restrict__ Jp, int i,
+                                  double jc[12], double jp[6]) {
+    const double2* pc = reinterpret_cast<const double2*>(Jc + (size_t)i * 12);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { const double2 v = pc[k]; jc[2 * k] = v.x; jc[2 * k + 1] = v.y; }
+    const double2* pp = reinterpret_cast<const double2*>(Jp + (size_t)i * 6);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { const double2 v = pp[k]; jp[2 * k] = v.x; jp[2 * k + 1] = v.y; }
+}
+
+__global__ __launch_bounds__(256) void ba_schur_kernel(int n_obs, const int* __restrict__ obs_cam,
+                                                       const int* __restrict__ obs_pt,
+                                                       const int* __restrict__ pt_start,
+                                                       const double* __restrict__ Jc, const double* __restrict__ Jp,
+                                                       const double* __restrict__ Hinv6, const double* __restrict__ gp,
+                                                       double* __restrict__ S, int lda, double* __restrict__ rhs) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_obs) return;
+    const int c = obs_cam[i], j = obs_pt[i];
+    double Hi[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) Hi[k] = Hinv6[(size_t)j * 6 + k];
+    if (Hi[0] == 0.0 && Hi[3] == 0.0 && Hi[5] == 0.0) return;   // constant / degenerate landmark
+    double jc[12], jp[6];
+    load_jc_jp(Jc, Jp, i, jc, jp);
+    // W = Jc^T Jp (6x3), E = W Hinv (6x3)
+    double E[18];
+    double egp[6];
+    const double g0 = gp[(size_t)j * 3], g1 = gp[(size_t)j * 3 + 1], g2 = gp[(size_t)j * 3 + 2];
+    bool any = false;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+        const double w0 = jc[a] * jp[0] + jc[6 + a] * jp[3];
+        const double w1 = jc[a] * jp[1] + jc[6 + a] * jp[4];
+        const double w2 = jc[a] * jp[2] + jc[6 + a] * jp[5];
+        E[a * 3 + 0] = w0 * Hi[0] + w1 * Hi[1] + w2 * Hi[2];
+        E[a * 3 + 1] = w0 * Hi[1] + w1 * Hi[3] + w2 * Hi[4];
+        E[a * 3 + 2] = w0 * Hi[2] + w1 * Hi[4] + w2 * Hi[5];
+        egp[a] = E[a * 3] * g0 + E[a * 3 + 1] * g1 + E[a * 3 + 2] * g2;
+        any |= (w0 != 0.0) | (w1 != 0.0) | (w2 != 0.0);
+    }
+    if (!any) return;   // constant camera: zero Jacobian columns
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+        if (egp[a] != 0.0) unsafeAtomicAdd(&rhs[c * 6 + a], egp[a]);
+    const int e = pt_start[j + 1];
+    for (int l = pt_start[j]; l < e; ++l) {
+        const int c2 = obs_cam[l];
+        if (c2 > c) continue;
+        double jc2[12], jp2[6];
+        load_jc_jp(Jc, Jp, l, jc2, jp2);
+        double* Sblk = S + (size_t)(c * 6) * lda + c2 * 6;
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+            const double w0 = jc2[b] * jp2[0] + jc2[6 + b] * jp2[3];
+            const double w1 = jc2[b] * jp2[1] + jc2[6 + b] * jp2[4];
+            const double w2 = jc2[b] * jp2[2] + jc2[6 + b] * jp2[5];
+            if (w0 == 0.0 && w1 == 0.0 && w2 == 0.0) continue;   // constant dof of camera c2
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                if (c2 == c && b > a) continue;
+                const double v = E[a * 3] * w0 + E[a * 3 + 1] * w1 + E[a * 3 + 2] * w2;
+                unsafeAtomicAdd(&Sblk[(size_t)a * lda + b], -v);
+            }
+        }
+    }
+}
+
+int launch_schur(int n_obs, const int* obs_cam, const int* obs_pt, const int* pt_start, const double* Jc,
+                 const double* Jp, const double* Hinv6, const double* gp, double* S, int lda, double* rhs,
+                 hipStream_t st) {
+    if (n_obs > 0)
+        hipLaunchKernelGGL(ba_schur_kernel, dim3((n_obs + 255) / 256), dim3(256), 0, st, n_obs, obs_cam, obs_pt,
+                           pt_start, Jc, Jp, Hinv6, gp, S, lda, rhs);
+    STBA_HIP(hipGetLastError());
+    return STBA_OK;
+}
+
+// S diagonal blocks += Hcc (this rank's partial), rhs -= gc; packs diag(Hcc) and gc behind S
+// so that one all-reduce carries everything (extras: [diagHcc | gc], n entries each).
+__global__ __launch_bounds__(256) void ba_reduced_add_camera_kernel(int n_cams, const double* __restrict__ Hcc,
+                                                                    const double* __restrict__ gc,
+                                                                    double* __restrict__ S, int lda,
+                                                                    double* __restrict__ rhs,
+                                                                    double* __restrict__ ex_diag,
+                                                                    double* __restrict__ ex_gc) {
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    const int c = gid / 36, k = gid - c * 36;
+    if (c >= n_cams) return;
+    const int a = k / 6, b = k - a * 6;
+    const double h = Hcc[(size_t)c * 36 + k];
+    if (b <= a) S[(size_t)(c * 6 + a) * lda + c * 6 + b] += h;
+    if (a == b) {
+        ex_diag[c * 6 + a] = h;
+        const double g = gc[c * 6 + a];
+        ex_gc[c * 6 + a] = g;
+        rhs[c * 6 + a] -= g;
+    }
+}
+
+// after the (optional) all-reduce: S_ii += dc_i (or 1 for constant dofs), rhs_i = 0 for constant
+__global__ __launch_bounds__(256) void ba_reduced_damp_kernel(int n, const double* __restrict__ dc,
+                                                              const unsigned char* __restrict__ cam_fixed,
+                                                              double* __restrict__ S, int lda,
+                                                              double* __restrict__ rhs) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int c = i / 6, a = i - c * 6;
+    const bool fx = cam_fixed ? ((cam_fixed[c] >> a) & 1u) : false;
+    if (fx) { S[(size_t)i * lda + i] += 1.0; rhs[i] = 0.0; }
+    else S[(size_t)i * lda + i] += dc[i];
+}
+
+int launch_reduced_add_camera(int n_cams, const double* Hcc, const double* gc, double* S, int lda, double* rhs,
+                              double* ex_diag, double* ex_gc, hipStream_t st) {
+    hipLaunchKernelGGL(ba_reduced_add_camera_kernel, dim3((n_cams * 36 + 255) / 256), dim3(256), 0, st, n_cams,
+                       Hcc, gc, S, lda, rhs, ex_diag, ex_gc);
+    STBA_HIP(hipGetLastError());
+    return STBA_OK;
+}
+
+int launch_reduced_damp(int n, const double* dc, const unsigned char* cam_fixed, double* S, int lda, double* rhs,
+                        hipStream_t st) {
+    hipLaunchKernelGGL(ba_reduced_damp_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, dc, cam_fixed, S, lda,
+                       rhs);
+    STBA_HIP(hipGetLastError());
+    return STBA_OK;
+}
+
+// ===========================================================================================
+// back-substitution: dxp_j = Hinv_j ( -gp_j - sum_l Jp_l^T (Jc_l dxc[c_l]) )
+// ===========================================================================================
+__global__ __launch_bounds__(256) void ba_backsub_kernel(int n_pts, const int* __restrict__ pt_start,
+                                                         const int* __restrict__ obs_cam,
+                                                         const double* __restrict__ Jc, const double* __restrict__ Jp,
+                                                         const double* __restrict__ Hinv6, const double* __restrict__ gp,
+                                                         const double* __restrict__ dxc, double* __restrict__ dxp) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n_pts) return;
+    double v0 = -gp[(size_t)j * 3], v1 = -gp[(size_t)j * 3 + 1], v2 = -gp[(size_t)j * 3 + 2];
+    const int e = pt_start[j + 1];
+    for (int l = pt_start[j]; l < e; ++l) {
+        const int c = obs_cam[l];
+        double jc[12], jp[6];
+        load_jc_jp(Jc, Jp, l, jc, jp);
+        double m0 = 0.0, m1 = 0.0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) { const double d = dxc[c * 6 + a]; m0 += jc[a] * d; m1 += jc[6 + a] * d; }
+        v0 -= jp[0] * m0 + jp[3] * m1;
+        v1 -= jp[1] * m0 + jp[4] * m1;
+        v2 -= jp[2] * m0 + jp[5] * m1;
+    }
+    const double* Hi = Hinv6 + (size_t)j * 6;
+    dxp[(size_t)j * 3 + 0] = Hi[0] * v0 + Hi[1] * v1 + Hi[2] * v2;
+    dxp[(size_t)j * 3 + 1] = Hi[1] * v0 + Hi[3] * v1 + Hi[4] * v2;
+    dxp[(size_t)j * 3 + 2] = Hi[2] * v0 + Hi[4] * v1 + Hi[5] * v2;
+}
+
+int launch_backsub(int n_pts, const int* pt_start, const int* obs_cam, const double* Jc, const double* Jp,
+                   const double* Hinv6, const double* gp, const double* dxc, double* dxp, hipStream_t st) {
+    hipLaunchKernelGGL(ba_backsub_kernel, dim3((n_pts + 255) / 256), dim3(256), 0, st, n_pts, pt_start, obs_cam, Jc,
+                       Jp, Hinv6, gp, dxc, dxp);
+    STBA_HIP(hipGetLastError());
+    return STBA_OK;
+}
+
+// ===========================================================================================
+// manifold update + step statistics.  partial[block][4] = { |x_new - x|^2, |x|^2 (current),
+// model term sum(-1/2 g d + 1/2 D d^2), unused }
+// ===========================================================================================
+__device__ inline void block_sum4(double v[4], double* out) {
+    __shared__ double s[4][4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        double x = v[k];
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+        if (lane == 0) s[w][k] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) out[threadIdx.x] = s[0][threadIdx.x] + s[1][threadIdx.x] + s[2][threadIdx.x] + s[3][threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void ba_update_cams_kernel(int n_cams, const double* __restrict__ cams,
+                                                             const double* __restrict__ dxc,
+                                                             const unsigned char* __restrict__ cam_fixed,
+                                                             const double* __restrict__ gc, const double* __restrict__ dc,
+                                                             double* __restrict__ cams_new, double* __restrict__ partial) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    double v[4] = {0, 0, 0, 0};
+    if (c < n_cams) {
+        const unsigned cm = cam_fixed ? cam_fixed[c] : 0u;
+        double d[6], q[4], qn[4];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) d[a] = ((cm >> a) & 1u) ? 0.0 : dxc[c * 6 + a];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) q[a] = cams[(size_t)c * 7 + a];
+        so3_plus(q, d, qn);
+        const bool rot_active = (cm & 7u) != 7u, pos_active = (cm & 56u) != 56u;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const double out = rot_active ? qn[a] : q[a];
+            cams_new[(size_t)c * 7 + a] = out;
+            if (rot_active) { v[0] += (out - q[a]) * (out - q[a]); v[1] += q[a] * q[a]; }
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const double t = cams[(size_t)c * 7 + 4 + a];
+            cams_new[(size_t)c * 7 + 4 + a] = t + d[3 + a];
+            if (pos_active) { v[0] += d[3 + a] * d[3 + a]; v[1] += t * t; }
+        }
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+            if (!((cm >> a) & 1u)) v[2] += -0.5 * gc[c * 6 + a] * d[a] + 0.5 * dc[c * 6 + a] * d[a] * d[a];
+    }
+    block_sum4(v, partial + (size_t)blockIdx.x * 4);
+}
+
+__global__ __launch_bounds__(256) void ba_update_pts_kernel(int n_pts, const double* __restrict__ pts,
+                                                            const double* __restrict__ dxp,
+                                                            const unsigned char* __restrict__ pt_fixed,
+                                                            const double* __restrict__ gp, const double* __restrict__ dp,
+                                                            double* __restrict__ pts_new, double* __restrict__ partial) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    double v[4] = {0, 0, 0, 0};
+    if (j < n_pts) {
+        const bool fx = pt_fixed ? (pt_fixed[j] != 0) : false;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const double p = pts[(size_t)j * 3 + a];
+            const double d = fx ? 0.0 : dxp[(size_t)j * 3 + a];
+            pts_new[(size_t)j * 3 + a] = p + d;
+            if (!fx) {
+                v[0] += d * d; v[1] += p * p;
+                v[2] += -0.5 * gp[(size_t)j * 3 + a] * d + 0.5 * dp[(size_t)j * 3 + a] * d * d;
+            }
+        }
+    }
+    block_sum4(v, partial + (size_t)blockIdx.x * 4);
+}
+
+int launch_update(int n_cams, int n_pts, const double* cams, const double* pts, const double* dxc,
+                  const double* dxp, const unsigned char* cam_fixed, const unsigned char* pt_fixed,
+                  const double* gc, const double* dc, const double* gp, const double* dp, double* cams_new,
+                  double* pts_new, double* partial_c, double* partial_p, hipStream_t st) {
+    hipLaunchKernelGGL(ba_update_cams_kernel, dim3((n_cams + 255) / 256), dim3(256), 0, st, n_cams, cams, dxc,
+                       cam_fixed, gc, dc, cams_new, partial_c);
+    if (n_pts > 0)
+        hipLaunchKernelGGL(ba_update_pts_kernel, dim3((n_pts + 255) / 256), dim3(256), 0, st, n_pts, pts, dxp,
+                           pt_fixed, gp, dp, pts_new, partial_p);
+    STBA_HIP(hipGetLastError());
+    return STBA_OK;
+}
+
+// ===========================================================================================
+// per-landmark triangulation with cameras fixed (sim_data.h:165-194, sim_data.cpp:299-311):
+// damped Gauss-Newton on each 3x3 system, one landmark per lane.
+// ===========================================================================================
+__global__ __launch_bounds__(256) void ba_triangulate_kernel(int n_pts, const int* __restrict__ pt_start,
+                                                             const int* __restrict__ obs_cam,
+                                                             const double2* __restrict__ feat,
+                                                             const double* __restrict__ cams, double* __restrict__ pts,
+                                                             const unsigned char* __restrict__ pt_fixed, int max_iter) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n_pts) return;
+    if (pt_fixed && pt_fixed[j]) return;
+    const int b = pt_start[j], e = pt_start[j + 1];
+    if (e - b < 1) return;
+    double L[3] = {pts[(size_t)j * 3], pts[(size_t)j * 3 + 1], pts[(size_t)j * 3 + 2]};
+    auto eval = [&](const double* P, double* H, double* g) -> double {
+        double cost = 0.0;
+        if (H) { for (int k = 0; k < 6; ++k) H[k] = 0.0; g[0] = g[1] = g[2] = 0.0; }
+        for (int i = b; i < e; ++i) {
+            const double* cam = cams + (size_t)obs_cam[i] * 7;
+            double q[4] = {cam[0], cam[1], cam[2], cam[3]}, R[9];
+            quat_to_rot(q, R);
+            const double d0 = P[0] - cam[4], d1 = P[1] - cam[5], d2 = P[2] - cam[6];
+            const double x = R[0] * d0 + R[3] * d1 + R[6] * d2;
+            const double y = R[1] * d0 + R[4] * d1 + R[7] * d2;
+            const double z = R[2] * d0 + R[5] * d1 + R[8] * d2;
+            const double iz = 1.0 / z, xn = x * iz, yn = y * iz;
+            const double2 f = feat[i];
+            const double r0 = xn - f.x, r1 = yn - f.y;
+            cost += r0 * r0 + r1 * r1;
+            if (H) {
+                double j0[3], j1[3];
+                for (int k = 0; k < 3; ++k) {
+                    j0[k] = iz * (R[k * 3 + 0] - xn * R[k * 3 + 2]);
+                    j1[k] = iz * (R[k * 3 + 1] - yn * R[k * 3 + 2]);
+                }
+                H[0] += j0[0] * j0[0] + j1[0] * j1[0]; H[1] += j0[0] * j0[1] + j1[0] * j1[1];
+                H[2] += j0[0] * j0[2] + j1[0] * j1[2]; H[3] += j0[1] * j0[1] + j1[1] * j1[1];
+                H[4] += j0[1] * j0[2] + j1[1] * j1[2]; H[5] += j0[2] * j0[2] + j1[2] * j1[2];
+                for (int k = 0; k < 3; ++k) g[k] -= j0[k] * r0 + j1[k] * r1;
+            }
+        }
+        return cost;
+    };
+    double lambda = 1e-4;
+    double H[6], g[3];
+    double cost = eval(L, H, g);
+    for (int it = 0; it < max_iter; ++it) {
+        double Hd[6] = {H[0] + lambda * (H[0] + 1e-12), H[1], H[2], H[3] + lambda * (H[3] + 1e-12), H[4],
+                        H[5] + lambda * (H[5] + 1e-12)};
+        double Hi[6];
+        if (!inv3_sym6(Hd, Hi)) break;
+        const double d0 = Hi[0] * g[0] + Hi[1] * g[1] + Hi[2] * g[2];
+        const double d1 = Hi[1] * g[0] + Hi[3] * g[1] + Hi[4] * g[2];
+        const double d2 = Hi[2] * g[0] + Hi[4] * g[1] + Hi[5] * g[2];
+        double Ln[3] = {L[0] + d0, L[1] + d1, L[2] + d2};
+        const double nc = eval(Ln, nullptr, nullptr);
+        if (nc < cost && nc == nc) {
+            const double dn = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
+            const double rel = (cost - nc) / (cost + 1e-300);
+            L[0] = Ln[0]; L[1] = Ln[1]; L[2] = Ln[2];
+            cost = eval(L, H, g);
+            lambda = fmax(lambda * 0.1, 1e-12);
+            if (dn < 1e-12 || rel < 1e-14) break;
+        } else {
+            lambda *= 10.0;
+            if (lambda > 1e12) break;
+        }
+    }
+    pts[(size_t)j * 3] = L[0]; pts[(size_t)j * 3 + 1] = L[1]; pts[(size_t)j * 3 + 2] = L[2];
+}
+
+int launch_triangulate(int n_pts, const int* pt_start, const int* obs_cam, const double2* feat, const double* cams,
+                       double* pts, const unsigned char* pt_fixed, int max_iter, hipStream_t st) {
+    hipLaunchKernelGGL(ba_triangulate_kernel, dim3((n_pts + 255) / 256), dim3(256), 0, st, n_pts, pt_start, obs_cam,
+                       feat, cams, pts, pt_fixed, max_iter);
+    STBA_HIP(hipGetLastError());
+    return STBA_OK;
+}
+
+// ===========================================================================================
+// dense normal equations for the small problems: H = J^T J (n x n, n <= 256), g = J^T r
+// one workgroup per (a, b-chunk): plain, these problems are tiny (6..129 unknowns)
+// ===========================================================================================
+__global__ __launch_bounds__(256) void dense_normal_kernel(int n_res, int n, const double* __restrict__ J,
+                                                           const double* __restrict__ r, double* __restrict__ H,
+                                                           int ldh, double* __restrict__ g) {
+    // block (a): computes row a of H (lower part) and g[a]
+    const int a = blockIdx.x;
+    __shared__ double s[256];
+    for (int b = 0; b <= a + 1; ++b) {     // b == a+1 -> gradient
+        double v = 0.0;
+        for (int i = threadIdx.x; i < n_res; i += 256) {
+            const double ja = J[(size_t)i * n + a];
+            v += ja * ((b <= a) ? J[(size_t)i * n + b] : r[i]);
+        }
+        s[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) {
+            if (threadIdx.x < off) s[threadIdx.x] += s[threadIdx.x + off];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            if (b <= a) H[(size_t)a * ldh + b] = s[0];
+            else g[a] = s[0];
+        }
+        __syncthreads();
+    }
+}
+
+int launch_dense_normal(int n_res, int n, const double* J, const double* r, double* H, int ldh, double* g,
+                        hipStream_t st) {
+    hipLaunchKernelGGL(dense_normal_kernel, dim3(n), dim3(256), 0, st, n_res, n, J, r, H, ldh, g);
+    STBA_HIP(hipGetLastError());
+    return STBA_OK;
+}
+
+}  // namespace stba

@@ -1,0 +1,57 @@
+// ba_kernels.hpp -- launch wrappers of the BA hot-path kernels (definitions in ba_kernels.hip)
+#pragma once
+#include "common.hpp"
+
+namespace stba {
+
+constexpr int LIN_THREADS = 512;               // observations per workgroup tile
+constexpr int LIN_MAX_LDS = 160 * 1024 - 512;  // dynamic LDS budget of the linearize kernel
+constexpr int CAM_CHUNK = 256;                 // observations per camera-side reduction chunk
+
+struct LinArgs {
+    int n_obs, n_cams;
+    const double* cams;              // [n_cams][7]
+    const double* pts;               // [n_pts][3]
+    const double2* feat;             // [n_obs]
+    const int* obs_cam;
+    const int* obs_pt;
+    const unsigned char* cam_fixed;  // [n_cams] bitmask (bit a = dof a constant) or null
+    const unsigned char* pt_fixed;   // [n_pts] or null
+    double2* r;                      // [n_obs]
+    double* Jc;                      // [n_obs][12]
+    double* Jp;                      // [n_obs][6]
+    double* cost_partial;            // [grid]
+};
+
+size_t lin_lds_bytes(int n_cams, bool cams_in_lds, bool with_jac);
+int launch_linearize(const LinArgs& a, bool with_jac, int grid, hipStream_t st);
+int launch_sum_partials(const double* partial, int n, int stride, int K, double* out, hipStream_t st);
+int launch_absmax(const double* v, size_t n, const double* v2, size_t n2, double* out, hipStream_t st);
+int launch_point_blocks(int n_pts, const int* pt_start, const double* Jp, const double2* r, double* Hpp6,
+                        double* gp, hipStream_t st);
+int launch_camera_blocks(int n_cams, int n_chunks, const int* chunk_begin, const int* chunk_end,
+                         const int* cam_chunk_start, const int* cam_perm, const double* Jc, const double2* r,
+                         double* partial, double* Hcc, double* gc, hipStream_t st);
+int launch_lm_diagonal(int n, int bs, int bstride, int kind, const double* H, double* scale, int init_scale,
+                       int use_scaling, double radius, double dmin, double dmax, double* d, hipStream_t st);
+int launch_point_invert(int n_pts, const double* Hpp6, const double* dp, const unsigned char* pt_fixed,
+                        double* Hinv6, hipStream_t st);
+int launch_schur(int n_obs, const int* obs_cam, const int* obs_pt, const int* pt_start, const double* Jc,
+                 const double* Jp, const double* Hinv6, const double* gp, double* S, int lda, double* rhs,
+                 hipStream_t st);
+int launch_reduced_add_camera(int n_cams, const double* Hcc, const double* gc, double* S, int lda, double* rhs,
+                              double* ex_diag, double* ex_gc, hipStream_t st);
+int launch_reduced_damp(int n, const double* dc, const unsigned char* cam_fixed, double* S, int lda, double* rhs,
+                        hipStream_t st);
+int launch_backsub(int n_pts, const int* pt_start, const int* obs_cam, const double* Jc, const double* Jp,
+                   const double* Hinv6, const double* gp, const double* dxc, double* dxp, hipStream_t st);
+int launch_update(int n_cams, int n_pts, const double* cams, const double* pts, const double* dxc,
+                  const double* dxp, const unsigned char* cam_fixed, const unsigned char* pt_fixed,
+                  const double* gc, const double* dc, const double* gp, const double* dp, double* cams_new,
+                  double* pts_new, double* partial_c, double* partial_p, hipStream_t st);
+int launch_triangulate(int n_pts, const int* pt_start, const int* obs_cam, const double2* feat, const double* cams,
+                       double* pts, const unsigned char* pt_fixed, int max_iter, hipStream_t st);
+int launch_dense_normal(int n_res, int n, const double* J, const double* r, double* H, int ldh, double* g,
+                        hipStream_t st);
+
+}  // namespace stba

@@ -1,0 +1,101 @@
+// common.hpp -- shared host/device helpers for the gfx950 NLS engine.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "../../include/stba.h"
+
+namespace stba {
+
+// ---- error plumbing: no exceptions cross the C ABI -----------------------------------------
+extern thread_local std::string g_last_error;
+inline int fail(int code, const std::string& msg) {
+    g_last_error = msg;
+    return code;
+}
+#define STBA_HIP(call)                                                                       \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            return ::stba::fail((e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice)      \
+                                    ? STBA_ERR_NO_DEVICE : STBA_ERR_HIP,                     \
+                                std::string(#call) + ": " + hipGetErrorString(e_));          \
+        }                                                                                    \
+    } while (0)
+#define STBA_TRY(call)                     \
+    do {                                   \
+        int s_ = (call);                   \
+        if (s_ != STBA_OK) return s_;      \
+    } while (0)
+
+int require_device();   // STBA_OK or STBA_ERR_NO_DEVICE (there is no CPU fallback)
+
+// ---- dense Cholesky on the device (dense_chol.hip) -----------------------------------------
+constexpr int CHOL_NB = 128;
+// padded order: multiple of CHOL_NB with at least one spare row (the last row carries the rhs)
+inline int chol_padded_dim(int n) { return ((n + 1 + CHOL_NB - 1) / CHOL_NB) * CHOL_NB; }
+// A_dev: lda x lda row-major, lda = chol_padded_dim(n).  Rows/cols [n, lda-1) must hold the
+// identity, row lda-1 holds rhs^T in columns [0, n) (and 1 on its diagonal).  On return the
+// lower triangle holds L, row lda-1 holds y = L^-1 rhs, x_dev[0..lda) the solution of A x = rhs.
+// flag_dev: int, set to (row+1) of the first non-positive pivot among real rows.
+int chol_factor_solve_dev(double* A_dev, int lda, int n, double* x_dev, int* flag_dev, hipStream_t st);
+// fills the padding (identity) and the rhs row of a padded system
+int chol_prepare_padding_dev(double* A_dev, int lda, int n, const double* rhs_dev, hipStream_t st);
+
+// ---- small device math ----------------------------------------------------------------------
+__host__ __device__ inline void quat_to_rot(const double q[4], double R[9]) {
+    const double x = q[0], y = q[1], z = q[2], w = q[3];
+    const double xx = x * x, yy = y * y, zz = z * z;
+    const double xy = x * y, xz = x * z, yz = y * z, wx = w * x, wy = w * y, wz = w * z;
+    R[0] = 1 - 2 * (yy + zz); R[1] = 2 * (xy - wz);     R[2] = 2 * (xz + wy);
+    R[3] = 2 * (xy + wz);     R[4] = 1 - 2 * (xx + zz); R[5] = 2 * (yz - wx);
+    R[6] = 2 * (xz - wy);     R[7] = 2 * (yz + wx);     R[8] = 1 - 2 * (xx + yy);
+}
+
+// Sophus SO3::exp (quaternion x,y,z,w)
+__host__ __device__ inline void so3_exp(const double w[3], double q[4]) {
+    const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+    double imag, real;
+    if (th2 < 1e-20) {
+        const double th4 = th2 * th2;
+        imag = 0.5 - th2 / 48.0 + th4 / 3840.0;
+        real = 1.0 - th2 / 8.0 + th4 / 384.0;
+    } else {
+        const double th = sqrt(th2);
+        imag = sin(0.5 * th) / th;
+        real = cos(0.5 * th);
+    }
+    q[0] = imag * w[0]; q[1] = imag * w[1]; q[2] = imag * w[2]; q[3] = real;
+}
+
+// q (x) exp(d), renormalised: LieLocalParameterization<SO3d>::Plus (solver.hpp:38-45)
+__host__ __device__ inline void so3_plus(const double q[4], const double d[3], double out[4]) {
+    double e[4];
+    so3_exp(d, e);
+    const double ax = q[0], ay = q[1], az = q[2], aw = q[3];
+    const double bx = e[0], by = e[1], bz = e[2], bw = e[3];
+    const double ox = aw * bx + ax * bw + ay * bz - az * by;
+    const double oy = aw * by - ax * bz + ay * bw + az * bx;
+    const double oz = aw * bz + ax * by - ay * bx + az * bw;
+    const double ow = aw * bw - ax * bx - ay * by - az * bz;
+    const double n = sqrt(ox * ox + oy * oy + oz * oz + ow * ow);
+    out[0] = ox / n; out[1] = oy / n; out[2] = oz / n; out[3] = ow / n;
+}
+
+// inverse of the symmetric 3x3 given as (xx,xy,xz,yy,yz,zz); returns false if not SPD-ish
+__host__ __device__ inline bool inv3_sym6(const double A[6], double Ai[6]) {
+    const double a = A[0], b = A[1], c = A[2], d = A[3], e = A[4], f = A[5];
+    const double C00 = d * f - e * e, C01 = c * e - b * f, C02 = b * e - c * d;
+    const double det = a * C00 + b * C01 + c * C02;
+    if (!(det > 0.0) || !(fabs(det) < 1e300)) return false;
+    const double inv = 1.0 / det;
+    Ai[0] = C00 * inv; Ai[1] = C01 * inv; Ai[2] = C02 * inv;
+    Ai[3] = (a * f - c * c) * inv; Ai[4] = (b * c - a * e) * inv; Ai[5] = (a * d - b * b) * inv;
+    return true;
+}
+
+}  // namespace stba

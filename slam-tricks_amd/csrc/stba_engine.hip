@@ -1,0 +1,1011 @@
+// stba_engine.hip -- host side of the MI355X NLS engine and its C ABI (include/stba.h).
+// The Levenberg-Marquardt control flow follows Ceres' TrustRegionMinimizer +
+// LevenbergMarquardtStrategy (the solver behind ceres::Solve at
+// st20-g2o/src/include/test_ceres.h:148 and st17-ceres/src/include/solver.hpp:286) with the
+// defaults listed in SURVEY.md 8c; all arithmetic on problem-sized data runs in HIP kernels.
+// There is no CPU fallback: without a HIP device every compute entry point fails.
+#include <algorithm>
+#include <chrono>
+#include <vector>
+
+#include "ba_kernels.hpp"
+
+namespace stba {
+
+thread_local std::string g_last_error;
+
+int require_device() {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(STBA_ERR_NO_DEVICE, std::string("no HIP device visible (") +
+                                            (e == hipSuccess ? "count=0" : hipGetErrorString(e)) +
+                                            "); libstba has no CPU fallback");
+    return STBA_OK;
+}
+
+static double wall_s() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+template <class T>
+static int dev_alloc(T** p, size_t count) {
+    *p = nullptr;
+    if (count == 0) count = 1;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T));
+    if (e != hipSuccess) return fail(STBA_ERR_ALLOC, std::string("hipMalloc: ") + hipGetErrorString(e));
+    return STBA_OK;
+}
+
+template <class T>
+static int upload(T* dst, const T* src, size_t count, hipStream_t st) {
+    if (count == 0) return STBA_OK;
+    STBA_HIP(hipMemcpyAsync(dst, src, count * sizeof(T), hipMemcpyHostToDevice, st));
+    return STBA_OK;
+}
+
+template <class T>
+static int download(T* dst, const T* src, size_t count, hipStream_t st) {
+    if (count == 0) return STBA_OK;
+    STBA_HIP(hipMemcpyAsync(dst, src, count * sizeof(T), hipMemcpyDeviceToHost, st));
+    return STBA_OK;
+}
+
+// scalar slots in the extras region behind S (summed across ranks together with S)
+enum { SC_COST2 = 0, SC_GPMAX0 = 8, SC_MAX_WORLD = 64 };
+// trial-point scalars: [0..3] summed across ranks (landmark shards), [4..6] camera terms
+enum { TS_COST2 = 0, TS_STEP2 = 1, TS_X2 = 2, TS_MODEL = 3, TS_CAM = 4, TS_COUNT = 8 };
+
+}  // namespace stba
+
+using namespace stba;
+
+struct stba_ba {
+    int nc = 0, np = 0, no = 0, n = 0, lda = 0;
+    hipStream_t st = nullptr;
+    bool own_stream = false;
+    std::vector<int> perm;   // sorted position -> caller's observation index
+    // device
+    double* cams[2] = {nullptr, nullptr};
+    double* pts[2] = {nullptr, nullptr};
+    int cur = 0;
+    double2* feat = nullptr;
+    int *obs_cam = nullptr, *obs_pt = nullptr, *pt_start = nullptr;
+    int *cam_perm = nullptr, *chunk_begin = nullptr, *chunk_end = nullptr, *cam_chunk_start = nullptr;
+    int n_chunks = 0;
+    unsigned char *cam_fixed = nullptr, *pt_fixed = nullptr;
+    double2* r = nullptr;
+    double *Jc = nullptr, *Jp = nullptr;
+    double *Hpp6 = nullptr, *gp = nullptr, *Hinv6 = nullptr, *dp = nullptr, *scale_p = nullptr;
+    double *Hcc = nullptr, *gc = nullptr, *cam_partial = nullptr, *dc = nullptr, *scale_c = nullptr;
+    double* Sbuf = nullptr;   // [S lda*lda | ex_diag lda | ex_gc lda | rhs lda | ex_scalar lda]
+    double *dxc = nullptr, *dxp = nullptr;
+    double *cost_partial = nullptr, *upd_partial_c = nullptr, *upd_partial_p = nullptr;
+    double* trial = nullptr;   // TS_COUNT doubles
+    int* flag = nullptr;
+    int lin_grid = 1;
+    stba_allreduce_fn ar = nullptr;
+    void* ar_user = nullptr;
+    int rank = 0, world = 1;
+    bool have_lin = false, have_blocks = false, have_reduced = false, have_dxc = false, have_dxp = false;
+    bool scale_init = false;
+    hipEvent_t ev[8] = {};
+
+    double* S() const { return Sbuf; }
+    double* ex_diag() const { return Sbuf + (size_t)lda * lda; }
+    double* ex_gc() const { return Sbuf + (size_t)lda * lda + lda; }
+    double* rhs() const { return Sbuf + (size_t)lda * lda + 2 * (size_t)lda; }
+    double* ex_scalar() const { return Sbuf + (size_t)lda * lda + 3 * (size_t)lda; }
+    size_t sbuf_count() const { return (size_t)lda * lda + 4 * (size_t)lda; }
+};
+
+namespace stba {
+
+static void ba_free(stba_ba* b) {
+    auto F = [](void* p) { if (p) (void)hipFree(p); };
+    F(b->cams[0]); F(b->cams[1]); F(b->pts[0]); F(b->pts[1]); F(b->feat); F(b->obs_cam); F(b->obs_pt);
+    F(b->pt_start); F(b->cam_perm); F(b->chunk_begin); F(b->chunk_end); F(b->cam_chunk_start); F(b->cam_fixed);
+    F(b->pt_fixed); F(b->r); F(b->Jc); F(b->Jp); F(b->Hpp6); F(b->gp); F(b->Hinv6); F(b->dp); F(b->scale_p);
+    F(b->Hcc); F(b->gc); F(b->cam_partial); F(b->dc); F(b->scale_c); F(b->Sbuf); F(b->dxc); F(b->dxp);
+    F(b->cost_partial); F(b->upd_partial_c); F(b->upd_partial_p); F(b->trial); F(b->flag);
+    for (auto& e : b->ev) if (e) (void)hipEventDestroy(e);
+    if (b->own_stream && b->st) (void)hipStreamDestroy(b->st);
+    delete b;
+}
+
+static LinArgs lin_args(stba_ba* b, int which, bool store_r) {
+    LinArgs a;
+    a.n_obs = b->no; a.n_cams = b->nc;
+    a.cams = b->cams[which]; a.pts = b->pts[which];
+    a.feat = b->feat; a.obs_cam = b->obs_cam; a.obs_pt = b->obs_pt;
+    a.cam_fixed = b->cam_fixed; a.pt_fixed = b->pt_fixed;
+    a.r = store_r ? b->r : nullptr; a.Jc = b->Jc; a.Jp = b->Jp; a.cost_partial = b->cost_partial;
+    return a;
+}
+
+// residuals + Jacobians at parameter buffer `which`; sum r^2 -> *cost2_dev
+static int ba_linearize(stba_ba* b, int which, double* cost2_dev) {
+    STBA_TRY(launch_linearize(lin_args(b, which, true), true, b->lin_grid, b->st));
+    return launch_sum_partials(b->cost_partial, b->lin_grid, 1, 1, cost2_dev, b->st);
+}
+
+// residual-only kernel (nothing stored): sum r^2 -> *cost2_dev
+static int ba_cost_only(stba_ba* b, int which, double* cost2_dev) {
+    STBA_TRY(launch_linearize(lin_args(b, which, false), false, b->lin_grid, b->st));
+    return launch_sum_partials(b->cost_partial, b->lin_grid, 1, 1, cost2_dev, b->st);
+}
+
+static int ba_normal_blocks(stba_ba* b) {
+    STBA_TRY(launch_point_blocks(b->np, b->pt_start, b->Jp, b->r, b->Hpp6, b->gp, b->st));
+    return launch_camera_blocks(b->nc, b->n_chunks, b->chunk_begin, b->chunk_end, b->cam_chunk_start, b->cam_perm,
+                                b->Jc, b->r, b->cam_partial, b->Hcc, b->gc, b->st);
+}
+
+struct Damping {
+    bool explicit_d = false;   // dc / dp were uploaded by the caller
+    double radius = 1e4, dmin = 1e-6, dmax = 1e32;
+    int use_scaling = 1;
+};
+
+// S (damped, padded, rhs row in place) on the device.  One cross-rank sum carries S, diag(Hcc),
+// gc, rhs and the scalar slots.
+static int ba_build_reduced(stba_ba* b, const Damping& dm) {
+    const int init_scale = b->scale_init ? 0 : 1;
+    if (!dm.explicit_d)
+        STBA_TRY(launch_lm_diagonal(3 * b->np, 3, 6, 1, b->Hpp6, b->scale_p, init_scale, dm.use_scaling, dm.radius,
+                                    dm.dmin, dm.dmax, b->dp, b->st));
+    STBA_TRY(launch_point_invert(b->np, b->Hpp6, b->dp, b->pt_fixed, b->Hinv6, b->st));
+    const size_t zero_count = (size_t)b->lda * b->lda + 3 * (size_t)b->lda;   // scalar slots are kept
+    STBA_HIP(hipMemsetAsync(b->Sbuf, 0, zero_count * sizeof(double), b->st));
+    STBA_TRY(launch_schur(b->no, b->obs_cam, b->obs_pt, b->pt_start, b->Jc, b->Jp, b->Hinv6, b->gp, b->S(), b->lda,
+                          b->rhs(), b->st));
+    STBA_TRY(launch_reduced_add_camera(b->nc, b->Hcc, b->gc, b->S(), b->lda, b->rhs(), b->ex_diag(), b->ex_gc(),
+                                       b->st));
+    if (b->ar && b->world > 1) {
+        if (b->ar(b->ar_user, b->Sbuf, b->sbuf_count(), b->st) != 0)
+            return fail(STBA_ERR_CALLBACK, "all-reduce hook failed");
+    }
+    if (!dm.explicit_d)
+        STBA_TRY(launch_lm_diagonal(b->n, 1, 1, 2, b->ex_diag(), b->scale_c, init_scale, dm.use_scaling, dm.radius,
+                                    dm.dmin, dm.dmax, b->dc, b->st));
+    b->scale_init = true;
+    STBA_TRY(launch_reduced_damp(b->n, b->dc, b->cam_fixed, b->S(), b->lda, b->rhs(), b->st));
+    return chol_prepare_padding_dev(b->S(), b->lda, b->n, b->rhs(), b->st);
+}
+
+// cost slot + per-rank |gp|_inf slot, filled before the reduced system is built
+static int ba_fill_scalar_slots(stba_ba* b, const double* cost2_dev) {
+    STBA_HIP(hipMemsetAsync(b->ex_scalar(), 0, (size_t)b->lda * sizeof(double), b->st));
+    STBA_HIP(hipMemcpyAsync(b->ex_scalar() + SC_COST2, cost2_dev, sizeof(double), hipMemcpyDeviceToDevice, b->st));
+    return launch_absmax(b->gp, (size_t)3 * b->np, nullptr, 0, b->ex_scalar() + SC_GPMAX0 + b->rank, b->st);
+}
+
+static int ba_trial(stba_ba* b) {
+    const int cur = b->cur, nxt = cur ^ 1;
+    const int cb = (b->nc + 255) / 256, pb = (b->np + 255) / 256;
+    STBA_TRY(launch_update(b->nc, b->np, b->cams[cur], b->pts[cur], b->dxc, b->dxp, b->cam_fixed, b->pt_fixed,
+                           b->ex_gc(), b->dc, b->gp, b->dp, b->cams[nxt], b->pts[nxt], b->upd_partial_c,
+                           b->upd_partial_p, b->st));
+    STBA_HIP(hipMemsetAsync(b->trial, 0, TS_COUNT * sizeof(double), b->st));
+    if (b->np > 0) STBA_TRY(launch_sum_partials(b->upd_partial_p, pb, 4, 3, b->trial + TS_STEP2, b->st));
+    STBA_TRY(launch_sum_partials(b->upd_partial_c, cb, 4, 3, b->trial + TS_CAM, b->st));
+    STBA_TRY(ba_cost_only(b, nxt, b->trial + TS_COST2));
+    if (b->ar && b->world > 1) {
+        if (b->ar(b->ar_user, b->trial, 4, b->st) != 0) return fail(STBA_ERR_CALLBACK, "all-reduce hook failed");
+    }
+    return STBA_OK;
+}
+
+struct LMState {
+    double cost = 0, gmax = 0, radius = 0, decrease = 2.0, x_norm = 0;
+};
+
+static void default_options(stba_lm_options* o) {
+    o->max_num_iterations = 50;
+    o->initial_trust_region_radius = 1e4;
+    o->max_trust_region_radius = 1e16;
+    o->min_trust_region_radius = 1e-32;
+    o->min_relative_decrease = 1e-3;
+    o->min_lm_diagonal = 1e-6;
+    o->max_lm_diagonal = 1e32;
+    o->function_tolerance = 1e-6;
+    o->gradient_tolerance = 1e-10;
+    o->parameter_tolerance = 1e-8;
+    o->jacobi_scaling = 1;
+    o->num_threads = 1;
+    o->minimizer_progress_to_stdout = 0;
+    o->update_state_every_iteration = 0;
+}
+
+// reads {cost2, gpmax slots, gc} after a reduced-system build and returns cost / gradient max norm
+static int ba_read_linear_scalars(stba_ba* b, double* cost, double* gmax) {
+    std::vector<double> h((size_t)SC_GPMAX0 + b->world);
+    std::vector<double> g((size_t)b->n);
+    STBA_TRY(download(h.data(), b->ex_scalar(), h.size(), b->st));
+    STBA_TRY(download(g.data(), b->ex_gc(), g.size(), b->st));
+    STBA_HIP(hipStreamSynchronize(b->st));
+    *cost = 0.5 * h[SC_COST2];
+    double m = 0.0;
+    for (int k = 0; k < b->world; ++k) m = std::max(m, h[SC_GPMAX0 + k]);
+    for (double v : g) m = std::max(m, std::fabs(v));
+    *gmax = m;
+    return STBA_OK;
+}
+
+static int ba_run_lm(stba_ba* b, const stba_lm_options* opt_in, int fixed_iterations, stba_lm_summary* sum,
+                     double* trace, stba_iteration_callback cb, void* cb_user) {
+    stba_lm_options opt;
+    if (opt_in) opt = *opt_in; else default_options(&opt);
+    if (b->world > SC_MAX_WORLD) return fail(STBA_ERR_INVALID_ARGUMENT, "world size too large");
+    stba_lm_summary s;
+    memset(&s, 0, sizeof s);
+    const double t_start = wall_s();
+    const bool fixed = fixed_iterations > 0;
+    const int max_iter = fixed ? fixed_iterations : opt.max_num_iterations;
+    float ms = 0.f;
+    hipEvent_t* ev = b->ev;
+
+    b->scale_init = false;
+    Damping dm;
+    dm.dmin = opt.min_lm_diagonal; dm.dmax = opt.max_lm_diagonal; dm.use_scaling = opt.jacobi_scaling;
+    LMState L;
+    L.radius = opt.initial_trust_region_radius;
+
+    // ---- iteration 0: linearise at the start point
+    STBA_HIP(hipEventRecord(ev[0], b->st));
+    STBA_TRY(ba_linearize(b, b->cur, b->trial + TS_COST2));
+    STBA_TRY(ba_normal_blocks(b));
+    STBA_HIP(hipEventRecord(ev[1], b->st));
+    STBA_TRY(ba_fill_scalar_slots(b, b->trial + TS_COST2));
+    bool need_build = true;      // reduced system must be (re)built before the next solve
+    bool lin_timing_pending = true;
+
+    int iter = 0;
+    s.termination_type = STBA_NO_CONVERGENCE;
+    s.termination_reason = STBA_TERM_MAX_ITER;
+    bool first = true;
+    double x_norm = 0.0;
+
+    while (true) {
+        if (!first) {
+            if (iter >= max_iter) {
+                s.termination_type = fixed ? STBA_CONVERGENCE : STBA_NO_CONVERGENCE;
+                s.termination_reason = fixed ? STBA_TERM_FIXED : STBA_TERM_MAX_ITER;
+                break;
+            }
+            if (!fixed && L.radius < opt.min_trust_region_radius) {
+                s.termination_type = STBA_CONVERGENCE; s.termination_reason = STBA_TERM_MIN_RADIUS;
+                break;
+            }
+        }
+        // ---- reduced system for the current radius
+        dm.radius = L.radius;
+        STBA_HIP(hipEventRecord(ev[2], b->st));
+        if (need_build) STBA_TRY(ba_build_reduced(b, dm));
+        STBA_HIP(hipEventRecord(ev[3], b->st));
+        if (first) {
+            STBA_TRY(ba_read_linear_scalars(b, &L.cost, &L.gmax));
+            s.initial_cost = L.cost;
+            if (trace) {
+                memset(trace, 0, sizeof(double) * STBA_TRACE_COLS);
+                trace[0] = L.cost; trace[2] = L.gmax; trace[5] = L.radius; trace[6] = 1;
+            }
+            first = false;
+            if (opt.minimizer_progress_to_stdout)
+                printf("iter      cost      cost_change  |gradient|   |step|    tr_ratio  tr_radius\n"
+                       "%4d  %.6e    0.00e+00    %.2e   0.00e+00   0.00e+00  %.2e\n", 0, L.cost, L.gmax, L.radius);
+            if (!fixed && L.gmax <= opt.gradient_tolerance) {
+                s.termination_type = STBA_CONVERGENCE; s.termination_reason = STBA_TERM_GRADIENT;
+                break;
+            }
+            if (max_iter <= 0) break;
+        }
+        ++iter;
+        // ---- factor + solve, back-substitute, trial point
+        int flag_h = 0;
+        STBA_TRY(chol_factor_solve_dev(b->S(), b->lda, b->n, b->dxc, b->flag, b->st));
+        STBA_HIP(hipEventRecord(ev[4], b->st));
+        STBA_TRY(launch_backsub(b->np, b->pt_start, b->obs_cam, b->Jc, b->Jp, b->Hinv6, b->gp, b->dxc, b->dxp, b->st));
+        STBA_HIP(hipEventRecord(ev[5], b->st));
+        STBA_TRY(ba_trial(b));
+        STBA_HIP(hipEventRecord(ev[6], b->st));
+        double ts[TS_COUNT];
+        STBA_TRY(download(ts, b->trial, TS_COUNT, b->st));
+        STBA_TRY(download(&flag_h, b->flag, 1, b->st));
+        STBA_HIP(hipStreamSynchronize(b->st));
+        if (lin_timing_pending) { (void)hipEventElapsedTime(&ms, ev[0], ev[1]); s.ms_linearize += ms; lin_timing_pending = false; }
+        (void)hipEventElapsedTime(&ms, ev[2], ev[3]); s.ms_schur += ms;
+        (void)hipEventElapsedTime(&ms, ev[3], ev[4]); s.ms_solve += ms;
+        (void)hipEventElapsedTime(&ms, ev[4], ev[5]); s.ms_backsub += ms;
+        (void)hipEventElapsedTime(&ms, ev[5], ev[6]); s.ms_cost += ms;
+
+        bool step_ok = (flag_h == 0);
+        const double new_cost = 0.5 * ts[TS_COST2];
+        const double step_norm = std::sqrt(ts[TS_STEP2] + ts[TS_CAM + 0]);
+        x_norm = std::sqrt(ts[TS_X2] + ts[TS_CAM + 1]);
+        const double model_change = ts[TS_MODEL] + ts[TS_CAM + 2];
+        if (step_ok && (!(model_change > 0.0) || !std::isfinite(model_change) || !std::isfinite(new_cost)))
+            step_ok = false;
+        double cost_change = 0.0, rho = 0.0;
+        bool accepted = false, stop = false;
+        if (step_ok) {
+            cost_change = L.cost - new_cost;
+            rho = cost_change / model_change;
+            if (!fixed) {
+                if (step_norm <= opt.parameter_tolerance * (x_norm + opt.parameter_tolerance)) {
+                    s.termination_type = STBA_CONVERGENCE; s.termination_reason = STBA_TERM_PARAMETER;
+                    stop = true;
+                } else if (std::fabs(cost_change) <= opt.function_tolerance * L.cost) {
+                    if (rho > opt.min_relative_decrease) {
+                        b->cur ^= 1; L.cost = new_cost; ++s.num_successful_steps; accepted = true;
+                    }
+                    s.termination_type = STBA_CONVERGENCE; s.termination_reason = STBA_TERM_FUNCTION;
+                    stop = true;
+                }
+            }
+            if (!stop) accepted = rho > opt.min_relative_decrease;
+        }
+        if (trace) {
+            double* tr = trace + (size_t)iter * STBA_TRACE_COLS;
+            tr[0] = step_ok ? new_cost : L.cost; tr[1] = cost_change; tr[2] = L.gmax; tr[3] = step_ok ? step_norm : 0.0;
+            tr[4] = rho; tr[5] = L.radius; tr[6] = accepted ? 1 : 0;
+        }
+        if (stop) {
+            if (accepted) b->have_lin = b->have_blocks = false;
+            break;
+        }
+        if (accepted) {
+            b->cur ^= 1;
+            L.cost = new_cost;
+            ++s.num_successful_steps;
+            const double t = 2.0 * rho - 1.0;
+            L.radius = std::min(opt.max_trust_region_radius, L.radius / std::max(1.0 / 3.0, 1.0 - t * t * t));
+            L.decrease = 2.0;
+        } else {
+            ++s.num_unsuccessful_steps;
+            L.radius /= L.decrease;
+            L.decrease *= 2.0;
+        }
+        need_build = true;
+        if (accepted || fixed) {
+            // re-linearise at the (new) current point
+            STBA_HIP(hipEventRecord(ev[0], b->st));
+            STBA_TRY(ba_linearize(b, b->cur, b->trial + TS_COST2));
+            STBA_TRY(ba_normal_blocks(b));
+            STBA_HIP(hipEventRecord(ev[1], b->st));
+            STBA_TRY(ba_fill_scalar_slots(b, b->trial + TS_COST2));
+            lin_timing_pending = true;
+            // gradient of the new point is needed for the convergence test: it arrives with the
+            // next reduced-system build (one collective per iteration); build it now.
+            dm.radius = L.radius;
+            STBA_HIP(hipEventRecord(ev[2], b->st));
+            STBA_TRY(ba_build_reduced(b, dm));
+            STBA_HIP(hipEventRecord(ev[3], b->st));
+            need_build = false;
+            double c2, g2;
+            STBA_TRY(ba_read_linear_scalars(b, &c2, &g2));
+            (void)hipEventElapsedTime(&ms, ev[0], ev[1]); s.ms_linearize += ms; lin_timing_pending = false;
+            (void)hipEventElapsedTime(&ms, ev[2], ev[3]); s.ms_schur += ms;
+            L.gmax = g2;
+            if (accepted) L.cost = c2;   // same value as new_cost up to summation order
+        }
+        if (trace) { trace[(size_t)iter * STBA_TRACE_COLS + 2] = L.gmax; trace[(size_t)iter * STBA_TRACE_COLS + 5] = L.radius; }
+        if (opt.minimizer_progress_to_stdout)
+            printf("%4d  %.6e   % .2e    %.2e   %.2e  % .2e  %.2e\n", iter, L.cost, cost_change, L.gmax, step_norm, rho,
+                   L.radius);
+        if (cb) {
+            if (cb(cb_user, iter, L.cost, cost_change, L.gmax, step_norm, L.radius, accepted ? 1 : 0) != 0) {
+                s.termination_type = STBA_CONVERGENCE; s.termination_reason = STBA_TERM_USER;
+                break;
+            }
+        }
+        if (accepted && !fixed && L.gmax <= opt.gradient_tolerance) {
+            s.termination_type = STBA_CONVERGENCE; s.termination_reason = STBA_TERM_GRADIENT;
+            break;
+        }
+    }
+    STBA_HIP(hipStreamSynchronize(b->st));
+    s.num_iterations = iter;
+    s.final_cost = L.cost;
+    s.final_radius = L.radius;
+    s.final_gradient_max_norm = L.gmax;
+    s.seconds_total = wall_s() - t_start;
+    b->have_lin = b->have_blocks = b->have_reduced = b->have_dxc = b->have_dxp = false;
+    if (sum) *sum = s;
+    return STBA_OK;
+}
+
+}  // namespace stba
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+extern "C" {
+
+const char* stba_status_string(int status) {
+    switch (status) {
+        case STBA_OK: return "ok";
+        case STBA_ERR_INVALID_ARGUMENT: return "invalid argument";
+        case STBA_ERR_NO_DEVICE: return "no HIP device (no CPU fallback)";
+        case STBA_ERR_HIP: return "HIP runtime error";
+        case STBA_ERR_NOT_POSITIVE_DEFINITE: return "matrix not positive definite";
+        case STBA_ERR_ALLOC: return "device allocation failed";
+        case STBA_ERR_STATE: return "call order / state error";
+        case STBA_ERR_CALLBACK: return "callback failed";
+        default: return "unknown";
+    }
+}
+
+const char* stba_last_error(void) { return g_last_error.c_str(); }
+int stba_version(void) { return STBA_VERSION; }
+
+int stba_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void stba_lm_default_options(stba_lm_options* opt) { if (opt) default_options(opt); }
+
+int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double* cams, const double* pts,
+                   const int* obs_cam, const int* obs_pt, const double* obs_feat, const unsigned char* cam_fixed,
+                   const unsigned char* pt_fixed, void* hip_stream) {
+    if (!out) return fail(STBA_ERR_INVALID_ARGUMENT, "out is null");
+    *out = nullptr;
+    if (n_cams <= 0 || n_pts < 0 || n_obs < 0 || !cams || (n_pts > 0 && !pts) ||
+        (n_obs > 0 && (!obs_cam || !obs_pt || !obs_feat)))
+        return fail(STBA_ERR_INVALID_ARGUMENT, "stba_ba_create: null or empty input");
+    for (int i = 0; i < n_obs; ++i)
+        if (obs_cam[i] < 0 || obs_cam[i] >= n_cams || obs_pt[i] < 0 || obs_pt[i] >= n_pts)
+            return fail(STBA_ERR_INVALID_ARGUMENT, "stba_ba_create: observation index out of range");
+    STBA_TRY(require_device());
+    stba_ba* b = new stba_ba();
+    b->nc = n_cams; b->np = n_pts; b->no = n_obs; b->n = 6 * n_cams; b->lda = chol_padded_dim(b->n);
+    if (hip_stream) b->st = reinterpret_cast<hipStream_t>(hip_stream);
+    else {
+        hipError_t e = hipStreamCreate(&b->st);
+        if (e != hipSuccess) { delete b; return fail(STBA_ERR_HIP, hipGetErrorString(e)); }
+        b->own_stream = true;
+    }
+    int rc = STBA_OK;
+    auto bail = [&](int code) { ba_free(b); return code; };
+    for (auto& e : b->ev) {
+        if (hipEventCreate(&e) != hipSuccess) return bail(fail(STBA_ERR_HIP, "hipEventCreate"));
+    }
+    hipDeviceProp_t prop;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    int num_cu = 256;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) num_cu = prop.multiProcessorCount;
+
+    // ---- landmark-major regrouping (stable counting sort) and the camera-side permutation
+    std::vector<int> pt_start(n_pts + 1, 0);
+    for (int i = 0; i < n_obs; ++i) ++pt_start[obs_pt[i] + 1];
+    for (int j = 0; j < n_pts; ++j) pt_start[j + 1] += pt_start[j];
+    b->perm.resize(n_obs);
+    {
+        std::vector<int> fill(pt_start.begin(), pt_start.end() - 1);
+        for (int i = 0; i < n_obs; ++i) b->perm[fill[obs_pt[i]]++] = i;
+    }
+    std::vector<int> s_cam(n_obs), s_pt(n_obs);
+    std::vector<double> s_feat((size_t)n_obs * 2);
+    for (int p = 0; p < n_obs; ++p) {
+        const int i = b->perm[p];
+        s_cam[p] = obs_cam[i]; s_pt[p] = obs_pt[i];
+        s_feat[2 * (size_t)p] = obs_feat[2 * (size_t)i]; s_feat[2 * (size_t)p + 1] = obs_feat[2 * (size_t)i + 1];
+    }
+    std::vector<int> cam_start(n_cams + 1, 0);
+    for (int p = 0; p < n_obs; ++p) ++cam_start[s_cam[p] + 1];
+    for (int c = 0; c < n_cams; ++c) cam_start[c + 1] += cam_start[c];
+    std::vector<int> cam_perm(n_obs);
+    {
+        std::vector<int> fill(cam_start.begin(), cam_start.end() - 1);
+        for (int p = 0; p < n_obs; ++p) cam_perm[fill[s_cam[p]]++] = p;
+    }
+    std::vector<int> chunk_begin, chunk_end, cam_chunk_start(n_cams + 1, 0);
+    for (int c = 0; c < n_cams; ++c) {
+        cam_chunk_start[c] = (int)chunk_begin.size();
+        for (int s0 = cam_start[c]; s0 < cam_start[c + 1]; s0 += CAM_CHUNK) {
+            chunk_begin.push_back(s0);
+            chunk_end.push_back(std::min(s0 + CAM_CHUNK, cam_start[c + 1]));
+        }
+    }
+    cam_chunk_start[n_cams] = (int)chunk_begin.size();
+    b->n_chunks = (int)chunk_begin.size();
+    std::vector<unsigned char> cmask;
+    if (cam_fixed) {
+        cmask.resize(n_cams);
+        for (int c = 0; c < n_cams; ++c) {
+            unsigned m = 0;
+            for (int a = 0; a < 6; ++a) if (cam_fixed[c * 6 + a]) m |= (1u << a);
+            cmask[c] = (unsigned char)m;
+        }
+    }
+    const int n_tiles = (n_obs + LIN_THREADS - 1) / LIN_THREADS;
+    const size_t lds = lin_lds_bytes(n_cams, lin_lds_bytes(n_cams, true, true) <= (size_t)LIN_MAX_LDS, true);
+    const int per_cu = std::max(1, std::min(4, (int)((160 * 1024) / std::max<size_t>(lds, 1))));
+    b->lin_grid = std::max(1, std::min(n_tiles, num_cu * per_cu));
+
+#define A_(call) do { rc = (call); if (rc != STBA_OK) return bail(rc); } while (0)
+    const size_t no = (size_t)n_obs, np = (size_t)n_pts, nc = (size_t)n_cams;
+    for (int k = 0; k < 2; ++k) { A_(dev_alloc(&b->cams[k], nc * 7)); A_(dev_alloc(&b->pts[k], np * 3)); }
+    A_(dev_alloc(&b->feat, no)); A_(dev_alloc(&b->obs_cam, no)); A_(dev_alloc(&b->obs_pt, no));
+    A_(dev_alloc(&b->pt_start, np + 1)); A_(dev_alloc(&b->cam_perm, no));
+    A_(dev_alloc(&b->chunk_begin, (size_t)b->n_chunks)); A_(dev_alloc(&b->chunk_end, (size_t)b->n_chunks));
+    A_(dev_alloc(&b->cam_chunk_start, nc + 1));
+    if (cam_fixed) A_(dev_alloc(&b->cam_fixed, nc));
+    if (pt_fixed) A_(dev_alloc(&b->pt_fixed, np));
+    A_(dev_alloc(&b->r, no)); A_(dev_alloc(&b->Jc, no * 12)); A_(dev_alloc(&b->Jp, no * 6));
+    A_(dev_alloc(&b->Hpp6, np * 6)); A_(dev_alloc(&b->gp, np * 3)); A_(dev_alloc(&b->Hinv6, np * 6));
+    A_(dev_alloc(&b->dp, np * 3)); A_(dev_alloc(&b->scale_p, np * 3));
+    A_(dev_alloc(&b->Hcc, nc * 36)); A_(dev_alloc(&b->gc, nc * 6)); A_(dev_alloc(&b->cam_partial, (size_t)b->n_chunks * 28));
+    A_(dev_alloc(&b->dc, nc * 6)); A_(dev_alloc(&b->scale_c, nc * 6));
+    A_(dev_alloc(&b->Sbuf, b->sbuf_count()));
+    A_(dev_alloc(&b->dxc, (size_t)b->lda)); A_(dev_alloc(&b->dxp, np * 3));
+    A_(dev_alloc(&b->cost_partial, (size_t)b->lin_grid));
+    A_(dev_alloc(&b->upd_partial_c, (size_t)((n_cams + 255) / 256) * 4));
+    A_(dev_alloc(&b->upd_partial_p, (size_t)((n_pts + 255) / 256 + 1) * 4));
+    A_(dev_alloc(&b->trial, (size_t)TS_COUNT)); A_(dev_alloc(&b->flag, 1));
+
+    A_(upload(b->cams[0], cams, nc * 7, b->st)); A_(upload(b->pts[0], pts, np * 3, b->st));
+    A_(upload(reinterpret_cast<double*>(b->feat), s_feat.data(), no * 2, b->st));
+    A_(upload(b->obs_cam, s_cam.data(), no, b->st)); A_(upload(b->obs_pt, s_pt.data(), no, b->st));
+    A_(upload(b->pt_start, pt_start.data(), np + 1, b->st)); A_(upload(b->cam_perm, cam_perm.data(), no, b->st));
+    A_(upload(b->chunk_begin, chunk_begin.data(), (size_t)b->n_chunks, b->st));
+    A_(upload(b->chunk_end, chunk_end.data(), (size_t)b->n_chunks, b->st));
+    A_(upload(b->cam_chunk_start, cam_chunk_start.data(), nc + 1, b->st));
+    if (cam_fixed) A_(upload(b->cam_fixed, cmask.data(), nc, b->st));
+    if (pt_fixed) A_(upload(b->pt_fixed, pt_fixed, np, b->st));
+    if (hipMemsetAsync(b->dxc, 0, (size_t)b->lda * sizeof(double), b->st) != hipSuccess ||
+        hipMemsetAsync(b->Sbuf, 0, b->sbuf_count() * sizeof(double), b->st) != hipSuccess ||
+        hipStreamSynchronize(b->st) != hipSuccess)
+        return bail(fail(STBA_ERR_HIP, "stba_ba_create: initial memset/sync failed"));
+#undef A_
+    *out = b;
+    return STBA_OK;
+}
+
+int stba_ba_destroy(stba_ba* ba) {
+    if (!ba) return STBA_OK;
+    if (ba->st) (void)hipStreamSynchronize(ba->st);
+    ba_free(ba);
+    return STBA_OK;
+}
+
+int stba_ba_set_params(stba_ba* b, const double* cams, const double* pts) {
+    if (!b) return fail(STBA_ERR_INVALID_ARGUMENT, "null engine");
+    if (cams) STBA_TRY(upload(b->cams[b->cur], cams, (size_t)b->nc * 7, b->st));
+    if (pts) STBA_TRY(upload(b->pts[b->cur], pts, (size_t)b->np * 3, b->st));
+    STBA_HIP(hipStreamSynchronize(b->st));
+    b->have_lin = b->have_blocks = b->have_reduced = b->have_dxc = b->have_dxp = false;
+    return STBA_OK;
+}
+
+int stba_ba_get_params(stba_ba* b, double* cams, double* pts) {
+    if (!b) return fail(STBA_ERR_INVALID_ARGUMENT, "null engine");
+    if (cams) STBA_TRY(download(cams, b->cams[b->cur], (size_t)b->nc * 7, b->st));
+    if (pts) STBA_TRY(download(pts, b->pts[b->cur], (size_t)b->np * 3, b->st));
+    STBA_HIP(hipStreamSynchronize(b->st));
+    return STBA_OK;
+}
+
+int stba_ba_set_allreduce(stba_ba* b, stba_allreduce_fn fn, void* user, int rank, int world_size) {
+    if (!b || world_size < 1 || rank < 0 || rank >= world_size || world_size > SC_MAX_WORLD)
+        return fail(STBA_ERR_INVALID_ARGUMENT, "stba_ba_set_allreduce: bad rank/world");
+    b->ar = fn; b->ar_user = user; b->rank = rank; b->world = world_size;
+    return STBA_OK;
+}
+
+int stba_ba_reduced_dim(const stba_ba* b, int* n, int* n_padded) {
+    if (!b) return fail(STBA_ERR_INVALID_ARGUMENT, "null engine");
+    if (n) *n = b->n;
+    if (n_padded) *n_padded = b->lda;
+    return STBA_OK;
+}
+
+int stba_ba_evaluate(stba_ba* b, double* cost, double* r, double* Jc, double* Jp) {
+    if (!b) return fail(STBA_ERR_INVALID_ARGUMENT, "null engine");
+    STBA_TRY(ba_linearize(b, b->cur, b->trial + TS_COST2));
+    double c2 = 0.0;
+    STBA_TRY(download(&c2, b->trial + TS_COST2, 1, b->st));
+    const size_t no = (size_t)b->no;
+    std::vector<double> tr, tjc, tjp;
+    if (r) { tr.resize(no * 2); STBA_TRY(download(tr.data(), reinterpret_cast<double*>(b->r), no * 2, b->st)); }
+    if (Jc) { tjc.resize(no * 12); STBA_TRY(download(tjc.data(), b->Jc, no * 12, b->st)); }
+    if (Jp) { tjp.resize(no * 6); STBA_TRY(download(tjp.data(), b->Jp, no * 6, b->st)); }
+    STBA_HIP(hipStreamSynchronize(b->st));
+    for (size_t p = 0; p < no; ++p) {   // back to the caller's observation order
+        const size_t i = (size_t)b->perm[p];
+        if (r) memcpy(r + i * 2, tr.data() + p * 2, 2 * sizeof(double));
+        if (Jc) memcpy(Jc + i * 12, tjc.data() + p * 12, 12 * sizeof(double));
+        if (Jp) memcpy(Jp + i * 6, tjp.data() + p * 6, 6 * sizeof(double));
+    }
+    if (cost) *cost = 0.5 * c2;
+    b->have_lin = true;
+    b->have_blocks = b->have_reduced = b->have_dxc = b->have_dxp = false;
+    return STBA_OK;
+}
+
+int stba_ba_cost(stba_ba* b, double* cost) {
+    if (!b || !cost) return fail(STBA_ERR_INVALID_ARGUMENT, "null argument");
+    STBA_TRY(ba_cost_only(b, b->cur, b->trial + TS_COST2));
+    double c2 = 0.0;
+    STBA_TRY(download(&c2, b->trial + TS_COST2, 1, b->st));
+    STBA_HIP(hipStreamSynchronize(b->st));
+    *cost = 0.5 * c2;
+    return STBA_OK;
+}
+
+int stba_ba_normal_blocks(stba_ba* b, double* Hcc, double* gc, double* Hpp, double* gp) {
+    if (!b) return fail(STBA_ERR_INVALID_ARGUMENT, "null engine");
+    if (!b->have_lin) return fail(STBA_ERR_STATE, "stba_ba_normal_blocks needs stba_ba_evaluate first");
+    STBA_TRY(ba_normal_blocks(b));
+    std::vector<double> h6;
+    if (Hcc) STBA_TRY(download(Hcc, b->Hcc, (size_t)b->nc * 36, b->st));
+    if (gc) STBA_TRY(download(gc, b->gc, (size_t)b->nc * 6, b->st));
+    if (Hpp) { h6.resize((size_t)b->np * 6); STBA_TRY(download(h6.data(), b->Hpp6, h6.size(), b->st)); }
+    if (gp) STBA_TRY(download(gp, b->gp, (size_t)b->np * 3, b->st));
+    STBA_HIP(hipStreamSynchronize(b->st));
+    if (Hpp)
+        for (size_t j = 0; j < (size_t)b->np; ++j) {
+            const double* s = h6.data() + j * 6;
+            double* d = Hpp + j * 9;
+            d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; d[3] = s[1]; d[4] = s[3]; d[5] = s[4]; d[6] = s[2]; d[7] = s[4]; d[8] = s[5];
+        }
+    b->have_blocks = true;
+    return STBA_OK;
+}
+
+int stba_ba_reduced_system(stba_ba* b, const double* dc, const double* dp, double* S, double* rhs) {
+    if (!b || !dc || !dp) return fail(STBA_ERR_INVALID_ARGUMENT, "null argument");
+    if (!b->have_blocks) return fail(STBA_ERR_STATE, "stba_ba_reduced_system needs stba_ba_normal_blocks first");
+    STBA_TRY(upload(b->dc, dc, (size_t)b->n, b->st));
+    STBA_TRY(upload(b->dp, dp, (size_t)b->np * 3, b->st));
+    Damping dm;
+    dm.explicit_d = true;
+    STBA_HIP(hipMemsetAsync(b->ex_scalar(), 0, (size_t)b->lda * sizeof(double), b->st));
+    STBA_TRY(ba_build_reduced(b, dm));
+    if (S) STBA_HIP(hipMemcpy2DAsync(S, (size_t)b->n * sizeof(double), b->S(), (size_t)b->lda * sizeof(double),
+                                     (size_t)b->n * sizeof(double), (size_t)b->n, hipMemcpyDeviceToHost, b->st));
+    if (rhs) STBA_TRY(download(rhs, b->rhs(), (size_t)b->n, b->st));
+    STBA_HIP(hipStreamSynchronize(b->st));
+    b->have_reduced = true;
+    b->have_dxc = b->have_dxp = false;
+    return STBA_OK;
+}
+
+int stba_ba_solve_reduced(stba_ba* b, double* dxc) {
+    if (!b) return fail(STBA_ERR_INVALID_ARGUMENT, "null engine");
+    if (!b->have_reduced) return fail(STBA_ERR_STATE, "stba_ba_solve_reduced needs stba_ba_reduced_system first");
+    STBA_TRY(chol_factor_solve_dev(b->S(), b->lda, b->n, b->dxc, b->flag, b->st));
+    int flag_h = 0;
+    STBA_TRY(download(&flag_h, b->flag, 1, b->st));
+    if (dxc) STBA_TRY(download(dxc, b->dxc, (size_t)b->n, b->st));
+    STBA_HIP(hipStreamSynchronize(b->st));
+    b->have_reduced = false;   // S now holds the factor
+    if (flag_h != 0) return fail(STBA_ERR_NOT_POSITIVE_DEFINITE, "reduced camera system: pivot " + std::to_string(flag_h));
+    b->have_dxc = true;
+    return STBA_OK;
+}
+
+int stba_ba_back_substitute(stba_ba* b, double* dxp) {
+    if (!b) return fail(STBA_ERR_INVALID_ARGUMENT, "null engine");
+    if (!b->have_dxc) return fail(STBA_ERR_STATE, "stba_ba_back_substitute needs stba_ba_solve_reduced first");
+    STBA_TRY(launch_backsub(b->np, b->pt_start, b->obs_cam, b->Jc, b->Jp, b->Hinv6, b->gp, b->dxc, b->dxp, b->st));
+    if (dxp) STBA_TRY(download(dxp, b->dxp, (size_t)b->np * 3, b->st));
+    STBA_HIP(hipStreamSynchronize(b->st));
+    b->have_dxp = true;
+    return STBA_OK;
+}
+
+int stba_ba_apply_step(stba_ba* b, int accept, double* new_cost) {
+    if (!b) return fail(STBA_ERR_INVALID_ARGUMENT, "null engine");
+    if (!b->have_dxp) return fail(STBA_ERR_STATE, "stba_ba_apply_step needs stba_ba_back_substitute first");
+    STBA_TRY(ba_trial(b));
+    double ts[TS_COUNT];
+    STBA_TRY(download(ts, b->trial, TS_COUNT, b->st));
+    STBA_HIP(hipStreamSynchronize(b->st));
+    if (new_cost) *new_cost = 0.5 * ts[TS_COST2];
+    if (accept) {
+        b->cur ^= 1;
+        b->have_lin = b->have_blocks = b->have_reduced = b->have_dxc = b->have_dxp = false;
+    }
+    return STBA_OK;
+}
+
+int stba_ba_solve(stba_ba* b, const stba_lm_options* opt, stba_lm_summary* summary, double* trace,
+                  stba_iteration_callback cb, void* cb_user) {
+    if (!b) return fail(STBA_ERR_INVALID_ARGUMENT, "null engine");
+    return ba_run_lm(b, opt, 0, summary, trace, cb, cb_user);
+}
+
+int stba_ba_lm_iterations(stba_ba* b, const stba_lm_options* opt, int iterations, stba_lm_summary* summary,
+                          double* trace) {
+    if (!b || iterations <= 0) return fail(STBA_ERR_INVALID_ARGUMENT, "bad argument");
+    return ba_run_lm(b, opt, iterations, summary, trace, nullptr, nullptr);
+}
+
+int stba_ba_triangulate(stba_ba* b, int max_iter) {
+    if (!b) return fail(STBA_ERR_INVALID_ARGUMENT, "null engine");
+    STBA_TRY(launch_triangulate(b->np, b->pt_start, b->obs_cam, b->feat, b->cams[b->cur], b->pts[b->cur], b->pt_fixed,
+                                max_iter, b->st));
+    STBA_HIP(hipStreamSynchronize(b->st));
+    b->have_lin = b->have_blocks = b->have_reduced = b->have_dxc = b->have_dxp = false;
+    return STBA_OK;
+}
+
+int stba_ba_time_linearize(stba_ba* b, int reps, double* ms_avg) {
+    if (!b || reps <= 0 || !ms_avg) return fail(STBA_ERR_INVALID_ARGUMENT, "bad argument");
+    LinArgs a = lin_args(b, b->cur, true);
+    STBA_TRY(launch_linearize(a, true, b->lin_grid, b->st));   // warm
+    STBA_HIP(hipEventRecord(b->ev[0], b->st));
+    for (int k = 0; k < reps; ++k) STBA_TRY(launch_linearize(a, true, b->lin_grid, b->st));
+    STBA_HIP(hipEventRecord(b->ev[1], b->st));
+    STBA_HIP(hipStreamSynchronize(b->st));
+    float ms = 0.f;
+    STBA_HIP(hipEventElapsedTime(&ms, b->ev[0], b->ev[1]));
+    *ms_avg = (double)ms / reps;
+    b->have_lin = b->have_blocks = b->have_reduced = b->have_dxc = b->have_dxp = false;
+    return STBA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// dense SPD solver entry points
+// ---------------------------------------------------------------------------------------------
+struct DenseWs {
+    int n = 0, lda = 0;
+    double *A = nullptr, *x = nullptr, *rhs = nullptr;
+    int* flag = nullptr;
+    hipStream_t st = nullptr;
+    bool own = false;
+    ~DenseWs() {
+        if (A) (void)hipFree(A);
+        if (x) (void)hipFree(x);
+        if (rhs) (void)hipFree(rhs);
+        if (flag) (void)hipFree(flag);
+        if (own && st) (void)hipStreamDestroy(st);
+    }
+    int init(int n_, void* stream) {
+        n = n_; lda = chol_padded_dim(n);
+        if (stream) st = reinterpret_cast<hipStream_t>(stream);
+        else { STBA_HIP(hipStreamCreate(&st)); own = true; }
+        STBA_TRY(dev_alloc(&A, (size_t)lda * lda)); STBA_TRY(dev_alloc(&x, (size_t)lda));
+        STBA_TRY(dev_alloc(&rhs, (size_t)lda)); STBA_TRY(dev_alloc(&flag, 1));
+        return STBA_OK;
+    }
+    // host A (n x n, lower used) -> padded device matrix
+    int load(const double* hostA, const double* host_rhs) {
+        STBA_HIP(hipMemsetAsync(A, 0, (size_t)lda * lda * sizeof(double), st));
+        STBA_HIP(hipMemcpy2DAsync(A, (size_t)lda * sizeof(double), hostA, (size_t)n * sizeof(double),
+                                  (size_t)n * sizeof(double), (size_t)n, hipMemcpyHostToDevice, st));
+        STBA_HIP(hipMemsetAsync(rhs, 0, (size_t)lda * sizeof(double), st));
+        if (host_rhs) STBA_TRY(upload(rhs, host_rhs, (size_t)n, st));
+        return chol_prepare_padding_dev(A, lda, n, rhs, st);
+    }
+};
+
+int stba_cholesky_factor(double* A, int n, void* hip_stream) {
+    if (!A || n <= 0) return fail(STBA_ERR_INVALID_ARGUMENT, "bad argument");
+    STBA_TRY(require_device());
+    DenseWs w;
+    STBA_TRY(w.init(n, hip_stream));
+    STBA_TRY(w.load(A, nullptr));
+    STBA_TRY(chol_factor_solve_dev(w.A, w.lda, n, w.x, w.flag, w.st));
+    int flag_h = 0;
+    STBA_TRY(download(&flag_h, w.flag, 1, w.st));
+    STBA_HIP(hipMemcpy2DAsync(A, (size_t)n * sizeof(double), w.A, (size_t)w.lda * sizeof(double),
+                              (size_t)n * sizeof(double), (size_t)n, hipMemcpyDeviceToHost, w.st));
+    STBA_HIP(hipStreamSynchronize(w.st));
+    if (flag_h) return fail(STBA_ERR_NOT_POSITIVE_DEFINITE, "pivot " + std::to_string(flag_h));
+    return STBA_OK;
+}
+
+int stba_cholesky_solve(const double* A, int n, double* bvec, void* hip_stream) {
+    if (!A || !bvec || n <= 0) return fail(STBA_ERR_INVALID_ARGUMENT, "bad argument");
+    STBA_TRY(require_device());
+    DenseWs w;
+    STBA_TRY(w.init(n, hip_stream));
+    STBA_TRY(w.load(A, bvec));
+    STBA_TRY(chol_factor_solve_dev(w.A, w.lda, n, w.x, w.flag, w.st));
+    int flag_h = 0;
+    STBA_TRY(download(&flag_h, w.flag, 1, w.st));
+    STBA_TRY(download(bvec, w.x, (size_t)n, w.st));
+    STBA_HIP(hipStreamSynchronize(w.st));
+    if (flag_h) return fail(STBA_ERR_NOT_POSITIVE_DEFINITE, "pivot " + std::to_string(flag_h));
+    return STBA_OK;
+}
+
+__global__ void synth_spd_kernel(double* A, int lda, int n) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)lda * lda) return;
+    const int i = (int)(idx / lda), j = (int)(idx % lda);
+    double v = 0.0;
+    if (i < n && j < n) {
+        const unsigned h = (unsigned)(i * 2654435761u) ^ (unsigned)(j * 40503u);
+        const unsigned g = (unsigned)(j * 2654435761u) ^ (unsigned)(i * 40503u);
+        v = ((double)((h ^ g) & 1023u) / 1024.0 - 0.5);   // symmetric in (i,j)
+        if (i == j) v += (double)n;
+    }
+    A[idx] = v;
+}
+
+int stba_cholesky_time(int n, int reps, double* ms_avg, void* hip_stream) {
+    if (n <= 0 || reps <= 0 || !ms_avg) return fail(STBA_ERR_INVALID_ARGUMENT, "bad argument");
+    STBA_TRY(require_device());
+    DenseWs w;
+    STBA_TRY(w.init(n, hip_stream));
+    hipEvent_t e0, e1;
+    STBA_HIP(hipEventCreate(&e0)); STBA_HIP(hipEventCreate(&e1));
+    double total = 0.0;
+    const size_t cnt = (size_t)w.lda * w.lda;
+    for (int k = 0; k < reps + 1; ++k) {
+        hipLaunchKernelGGL(synth_spd_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, w.st, w.A, w.lda, n);
+        STBA_HIP(hipMemsetAsync(w.rhs, 0, (size_t)w.lda * sizeof(double), w.st));
+        STBA_TRY(chol_prepare_padding_dev(w.A, w.lda, n, w.rhs, w.st));
+        STBA_HIP(hipEventRecord(e0, w.st));
+        STBA_TRY(chol_factor_solve_dev(w.A, w.lda, n, w.x, w.flag, w.st));
+        STBA_HIP(hipEventRecord(e1, w.st));
+        STBA_HIP(hipStreamSynchronize(w.st));
+        float ms = 0.f;
+        STBA_HIP(hipEventElapsedTime(&ms, e0, e1));
+        if (k > 0) total += ms;
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    *ms_avg = total / reps;
+    return STBA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// small dense LM problems: residual blocks evaluated by a host callback (the user's
+// CostFunction::Evaluate), normal equations + damped Cholesky step on the device.
+// ---------------------------------------------------------------------------------------------
+int stba_dense_solve(stba_residual_fn fn, stba_plus_fn plus, void* user, int n_params, int n_local, int n_res,
+                     double* x, const double* lower, const double* upper, const stba_lm_options* opt_in,
+                     stba_lm_summary* summary, double* trace, stba_iteration_callback cb, void* cb_user) {
+    if (!fn || !x || n_params <= 0 || n_local <= 0 || n_res <= 0)
+        return fail(STBA_ERR_INVALID_ARGUMENT, "stba_dense_solve: bad argument");
+    if ((lower || upper) && plus)
+        return fail(STBA_ERR_INVALID_ARGUMENT, "bounds are only supported on Euclidean parameter blocks");
+    STBA_TRY(require_device());
+    stba_lm_options opt;
+    if (opt_in) opt = *opt_in; else default_options(&opt);
+    const int n = n_local;
+    DenseWs w;
+    STBA_TRY(w.init(n, nullptr));
+    double *dJ = nullptr, *dr = nullptr, *dH = nullptr, *dg = nullptr;
+    STBA_TRY(dev_alloc(&dJ, (size_t)n_res * n)); STBA_TRY(dev_alloc(&dr, (size_t)n_res));
+    STBA_TRY(dev_alloc(&dH, (size_t)n * n)); STBA_TRY(dev_alloc(&dg, (size_t)n));
+    struct Guard { double *a, *b, *c, *d; ~Guard() { (void)hipFree(a); (void)hipFree(b); (void)hipFree(c); (void)hipFree(d); } } guard{dJ, dr, dH, dg};
+    std::vector<double> r(n_res), J((size_t)n_res * n), H((size_t)n * n), Hd((size_t)n * n), g(n), dx(n), scale(n),
+        xn(n_params), rn(n_res), dvec(n);
+    stba_lm_summary s;
+    memset(&s, 0, sizeof s);
+    const double t_start = wall_s();
+    const bool bounded = lower || upper;
+
+    auto linearize = [&]() -> int {   // H = J^T J, g = J^T r on the device
+        STBA_TRY(upload(dJ, J.data(), J.size(), w.st)); STBA_TRY(upload(dr, r.data(), r.size(), w.st));
+        STBA_HIP(hipMemsetAsync(dH, 0, (size_t)n * n * sizeof(double), w.st));
+        STBA_TRY(launch_dense_normal(n_res, n, dJ, dr, dH, n, dg, w.st));
+        STBA_TRY(download(H.data(), dH, H.size(), w.st)); STBA_TRY(download(g.data(), dg, g.size(), w.st));
+        STBA_HIP(hipStreamSynchronize(w.st));
+        return STBA_OK;
+    };
+    auto gmax_of = [&]() {
+        double m = 0.0;
+        for (int a = 0; a < n; ++a) {
+            if (!bounded) m = std::max(m, std::fabs(g[a]));
+            else {
+                double y = x[a] - g[a];
+                if (lower && y < lower[a]) y = lower[a];
+                if (upper && y > upper[a]) y = upper[a];
+                m = std::max(m, std::fabs(x[a] - y));
+            }
+        }
+        return m;
+    };
+    auto norm_of = [&](const double* v, int k) { double q = 0; for (int a = 0; a < k; ++a) q += v[a] * v[a]; return std::sqrt(q); };
+
+    if (fn(user, x, r.data(), J.data()) != 0) return fail(STBA_ERR_CALLBACK, "residual callback failed");
+    double cost = 0.0;
+    for (double v : r) cost += v * v;
+    cost *= 0.5;
+    s.initial_cost = cost;
+    STBA_TRY(linearize());
+    for (int a = 0; a < n; ++a) scale[a] = opt.jacobi_scaling ? 1.0 / (1.0 + std::sqrt(H[(size_t)a * n + a])) : 1.0;
+    double gmax = gmax_of(), radius = opt.initial_trust_region_radius, decrease = 2.0, x_norm = norm_of(x, n_params);
+    int iter = 0;
+    if (trace) { memset(trace, 0, sizeof(double) * STBA_TRACE_COLS); trace[0] = cost; trace[2] = gmax; trace[5] = radius; trace[6] = 1; }
+    s.termination_type = STBA_NO_CONVERGENCE; s.termination_reason = STBA_TERM_MAX_ITER;
+    bool done = false;
+    if (gmax <= opt.gradient_tolerance) { s.termination_type = STBA_CONVERGENCE; s.termination_reason = STBA_TERM_GRADIENT; done = true; }
+    while (!done) {
+        if (iter >= opt.max_num_iterations) { s.termination_type = STBA_NO_CONVERGENCE; s.termination_reason = STBA_TERM_MAX_ITER; break; }
+        if (radius < opt.min_trust_region_radius) { s.termination_type = STBA_CONVERGENCE; s.termination_reason = STBA_TERM_MIN_RADIUS; break; }
+        ++iter;
+        Hd = H;
+        for (int a = 0; a < n; ++a) {
+            const double s2 = scale[a] * scale[a];
+            const double d = std::min(std::max(H[(size_t)a * n + a] * s2, opt.min_lm_diagonal), opt.max_lm_diagonal);
+            dvec[a] = d / radius / s2;
+            Hd[(size_t)a * n + a] += dvec[a];
+            dx[a] = -g[a];
+        }
+        STBA_TRY(w.load(Hd.data(), dx.data()));
+        STBA_TRY(chol_factor_solve_dev(w.A, w.lda, n, w.x, w.flag, w.st));
+        int flag_h = 0;
+        STBA_TRY(download(&flag_h, w.flag, 1, w.st)); STBA_TRY(download(dx.data(), w.x, (size_t)n, w.st));
+        STBA_HIP(hipStreamSynchronize(w.st));
+        bool ok = (flag_h == 0);
+        double model_change = 0.0, new_cost = 0.0, step_norm = 0.0, rho = 0.0, cost_change = 0.0;
+        if (ok) {
+            for (int a = 0; a < n; ++a) model_change += -0.5 * g[a] * dx[a] + 0.5 * dvec[a] * dx[a] * dx[a];
+            if (!(model_change > 0.0) || !std::isfinite(model_change)) ok = false;
+        }
+        bool accepted = false;
+        if (ok) {
+            if (plus) plus(user, x, dx.data(), xn.data());
+            else for (int a = 0; a < n_params; ++a) xn[a] = x[a] + dx[a];
+            if (bounded)
+                for (int a = 0; a < n_params; ++a) {
+                    if (lower && xn[a] < lower[a]) xn[a] = lower[a];
+                    if (upper && xn[a] > upper[a]) xn[a] = upper[a];
+                }
+            if (fn(user, xn.data(), rn.data(), nullptr) != 0) ok = false;
+        }
+        if (ok) {
+            for (double v : rn) new_cost += v * v;
+            new_cost *= 0.5;
+            for (int a = 0; a < n_params; ++a) step_norm += (xn[a] - x[a]) * (xn[a] - x[a]);
+            step_norm = std::sqrt(step_norm);
+            cost_change = cost - new_cost;
+            rho = cost_change / model_change;
+            if (trace) { double* tr = trace + (size_t)iter * STBA_TRACE_COLS; tr[0] = new_cost; tr[1] = cost_change; tr[3] = step_norm; tr[4] = rho; }
+            if (step_norm <= opt.parameter_tolerance * (x_norm + opt.parameter_tolerance)) {
+                s.termination_type = STBA_CONVERGENCE; s.termination_reason = STBA_TERM_PARAMETER;
+                if (trace) { trace[(size_t)iter * STBA_TRACE_COLS + 5] = radius; trace[(size_t)iter * STBA_TRACE_COLS + 2] = gmax; }
+                break;
+            }
+            if (std::fabs(cost_change) <= opt.function_tolerance * cost) {
+                if (rho > opt.min_relative_decrease) {
+                    memcpy(x, xn.data(), sizeof(double) * n_params); cost = new_cost; ++s.num_successful_steps;
+                    if (trace) trace[(size_t)iter * STBA_TRACE_COLS + 6] = 1;
+                }
+                s.termination_type = STBA_CONVERGENCE; s.termination_reason = STBA_TERM_FUNCTION;
+                if (trace) { trace[(size_t)iter * STBA_TRACE_COLS + 5] = radius; trace[(size_t)iter * STBA_TRACE_COLS + 2] = gmax; }
+                break;
+            }
+            accepted = rho > opt.min_relative_decrease;
+        }
+        if (accepted) {
+            memcpy(x, xn.data(), sizeof(double) * n_params);
+            cost = new_cost; x_norm = norm_of(x, n_params); ++s.num_successful_steps;
+            if (fn(user, x, r.data(), J.data()) != 0) return fail(STBA_ERR_CALLBACK, "residual callback failed");
+            STBA_TRY(linearize());
+            gmax = gmax_of();
+            const double t = 2.0 * rho - 1.0;
+            radius = std::min(opt.max_trust_region_radius, radius / std::max(1.0 / 3.0, 1.0 - t * t * t));
+            decrease = 2.0;
+        } else {
+            ++s.num_unsuccessful_steps;
+            radius /= decrease; decrease *= 2.0;
+        }
+        if (trace) {
+            double* tr = trace + (size_t)iter * STBA_TRACE_COLS;
+            if (!ok) { tr[0] = cost; tr[1] = 0; tr[3] = 0; tr[4] = 0; }
+            tr[2] = gmax; tr[5] = radius; tr[6] = accepted ? 1 : 0;
+        }
+        if (opt.minimizer_progress_to_stdout)
+            printf("%4d  %.6e   % .2e    %.2e   %.2e  % .2e  %.2e\n", iter, cost, cost_change, gmax, step_norm, rho, radius);
+        if (cb && cb(cb_user, iter, cost, cost_change, gmax, step_norm, radius, accepted ? 1 : 0) != 0) {
+            s.termination_type = STBA_CONVERGENCE; s.termination_reason = STBA_TERM_USER; break;
+        }
+        if (accepted && gmax <= opt.gradient_tolerance) { s.termination_type = STBA_CONVERGENCE; s.termination_reason = STBA_TERM_GRADIENT; break; }
+    }
+    s.num_iterations = iter; s.final_cost = cost; s.final_radius = radius; s.final_gradient_max_norm = gmax;
+    s.seconds_total = wall_s() - t_start;
+    if (summary) *summary = s;
+    return STBA_OK;
+}
+
+}  // extern "C"

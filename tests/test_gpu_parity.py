@@ -1,0 +1,284 @@
+"""GPU parity tests: the HIP path (through the C ABI, slam-tricks_amd/libstba.so) against the
+CPU oracle on the same seeded inputs.  FP64 everywhere; tolerances are stated per test and sit
+far inside north_star's 1e-6 (residuals) / 1e-5 (pose)."""
+import importlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def st():
+    mod = importlib.import_module("slam-tricks_amd")
+    assert mod.device_count() > 0, "GPU tests need a HIP device"
+    return mod
+
+
+def engine(st, s, **kw):
+    return st.BAEngine(s["cams0"], s["pts0"], s["obs_cam"], s["obs_pt"], s["obs_feat"], s["cam_fixed"], **kw)
+
+
+def oracle(O, s, **kw):
+    return O.BA(s["cams0"], s["pts0"], s["obs_cam"], s["obs_pt"], s["obs_feat"], s["cam_fixed"], **kw)
+
+
+def pose_err(cams, ref):
+    q, qr = cams[:, :4], ref[:, :4]
+    dq = np.minimum(np.abs(q - qr).max(1), np.abs(q + qr).max(1)).max()      # sign-invariant
+    return dq, np.abs(cams[:, 4:] - ref[:, 4:]).max()
+
+
+# ------------------------------------------------------------------------------- dense Cholesky
+@pytest.mark.parametrize("n", [1, 6, 12, 127, 128, 129, 300, 777])
+def test_cholesky_solve_matches_numpy(st, n):
+    rng = np.random.default_rng(n)
+    A = rng.normal(size=(n, n)); A = A @ A.T + n * np.eye(n)
+    b = rng.normal(size=n)
+    x = st.cholesky_solve(A, b)
+    assert np.allclose(x, np.linalg.solve(A, b), rtol=1e-9, atol=1e-11)
+    L = st.cholesky_factor(A)
+    assert np.allclose(L, np.linalg.cholesky(A), rtol=1e-10, atol=1e-10)
+
+
+def test_cholesky_mfma_layout_asymmetric(st):
+    """catches a transposed / mis-mapped MFMA tile: strongly asymmetric rows"""
+    n = 640
+    rng = np.random.default_rng(1)
+    B = rng.normal(size=(n, n)) * np.linspace(0.1, 3.0, n)[:, None]
+    A = B @ B.T + np.diag(np.linspace(1.0, 50.0, n))
+    L = st.cholesky_factor(A)
+    assert np.abs(L @ L.T - A).max() < 1e-9 * np.abs(A).max()
+
+
+def test_cholesky_not_positive_definite(st):
+    A = np.eye(200); A[150, 150] = -1.0
+    with pytest.raises(st.StbaError) as e:
+        st.cholesky_solve(A, np.ones(200))
+    assert e.value.code == -4
+
+
+def test_cholesky_matches_oracle(st, O):
+    n = 333
+    rng = np.random.default_rng(3)
+    A = rng.normal(size=(n, n)); A = A @ A.T + n * np.eye(n)
+    rc, Lo = O.cholesky_lower(A)
+    assert rc == 0
+    assert np.allclose(st.cholesky_factor(A), np.tril(Lo), rtol=1e-11, atol=1e-11)
+
+
+# ------------------------------------------------------------------------------- stage kernels
+@pytest.fixture(scope="module")
+def small(scenes):
+    return scenes.st20_scene(n_cams=12, n_pts=300, seed=5, pos_noise=0.1, ang_noise_deg=1.5, pix_noise=1e-3)
+
+
+def test_residual_jacobian_elementwise(st, O, small):
+    s = small
+    e, o = engine(st, s), oracle(O, s)
+    cost, r, Jc, Jp = e.evaluate()
+    co, ro, Jco, Jpo = o.evaluate()
+    assert abs(cost - co) <= 1e-13 * co
+    assert np.abs(r - ro).max() < 1e-14
+    assert np.abs(Jc - Jco).max() < 1e-12 and np.abs(Jp - Jpo).max() < 1e-12
+    assert np.all(Jc[s["obs_cam"] == 0] == 0)            # constant camera: columns dropped
+    assert abs(e.cost() - co) <= 1e-13 * co
+
+
+def test_residual_jacobian_unsorted_observations(st, O, small):
+    """observations in arbitrary order come back in the caller's order"""
+    s = dict(small)
+    rng = np.random.default_rng(0)
+    p = rng.permutation(len(s["obs_cam"]))
+    su = dict(s, obs_cam=s["obs_cam"][p], obs_pt=s["obs_pt"][p], obs_feat=s["obs_feat"][p])
+    _, r, Jc, Jp = engine(st, su).evaluate()
+    _, ro, Jco, Jpo = oracle(O, s).evaluate()
+    assert np.abs(r - ro[p]).max() < 1e-14 and np.abs(Jc - Jco[p]).max() < 1e-12 and np.abs(Jp - Jpo[p]).max() < 1e-12
+
+
+def test_normal_blocks(st, O, small):
+    e, o = engine(st, small), oracle(O, small)
+    e.evaluate()
+    Hcc, gc, Hpp, gp = e.normal_blocks()
+    _, ro, Jco, Jpo = o.evaluate()
+    Hcco, gco, Hppo, gpo = o.normal_blocks(ro, Jco, Jpo)
+    for a, b in ((Hcc, Hcco), (gc, gco), (Hpp, Hppo), (gp, gpo)):
+        assert np.abs(a - b).max() <= 1e-12 * max(1.0, np.abs(b).max())
+
+
+def test_reduced_system_and_step(st, O, small):
+    s = small
+    e, o = engine(st, s), oracle(O, s)
+    e.evaluate(); e.normal_blocks()
+    _, ro, Jco, Jpo = o.evaluate()
+    rng = np.random.default_rng(1)
+    dc = rng.uniform(0.01, 0.1, (e.nc, 6)); dp = rng.uniform(0.01, 0.1, (e.np_, 3))
+    S, rhs = e.reduced_system(dc, dp)
+    So, rhso = o.reduced_system(ro, Jco, Jpo, dc, dp)
+    scale = np.abs(So).max()
+    assert np.abs(np.tril(S) - np.tril(So)).max() < 1e-11 * scale
+    assert np.abs(rhs - rhso).max() < 1e-11 * max(1.0, np.abs(rhso).max())
+    dxc = e.solve_reduced()
+    Sf = np.tril(So) + np.tril(So, -1).T
+    ref = np.linalg.solve(Sf, rhso)
+    assert np.abs(dxc - ref).max() < 1e-9 * max(1.0, np.abs(ref).max())
+    dxp = e.back_substitute()
+    # full-system check: (H + D) [dxc; dxp] = -g
+    Hcco, gco, Hppo, gpo = o.normal_blocks(ro, Jco, Jpo)
+    v = -gpo.copy()
+    for i in range(o.no):
+        c, j = o.obs_cam[i], o.obs_pt[i]
+        v[j] -= Jpo[i].T @ (Jco[i] @ ref[6 * c:6 * c + 6])
+    Hd = Hppo + np.einsum("ij,jk->ijk", dp, np.eye(3))
+    ref_p = np.linalg.solve(Hd, v[..., None])[..., 0]
+    assert np.abs(dxp - ref_p).max() < 1e-9 * max(1.0, np.abs(ref_p).max())
+    new_cost = e.apply_step(accept=True)
+    cams, pts = e.get_params()
+    o2 = O.BA(cams, pts, s["obs_cam"], s["obs_pt"], s["obs_feat"], s["cam_fixed"])
+    assert abs(new_cost - o2.evaluate(jac=False)[0]) <= 1e-12 * new_cost
+
+
+def test_pnp_is_ba_with_constant_landmarks(st, O, scenes, known):
+    """st17 SolvePnPWith*: one camera, constant landmarks -> published truth (release.png)"""
+    s = scenes.pnp_scene(seed=17)
+    n = len(s["pts"])
+    args = (s["pose_init"][None], s["pts"], np.zeros(n, np.int32), np.arange(n, dtype=np.int32), s["feats"])
+    e = st.BAEngine(*args, pt_fixed=np.ones(n, np.uint8))
+    summ, tr = e.solve()
+    o = O.BA(*args, pt_fixed=np.ones(n, np.uint8))
+    so, tro = o.solve()
+    cams, _ = e.get_params()
+    assert summ.termination_type == 0 and summ.final_cost < known["st17_pnp"]["final_cost_below"]
+    assert summ.num_iterations == so.num_iterations
+    dq, dt = pose_err(cams, s["pose_true"][None])
+    assert dq < 1e-9 and dt < 1e-8
+    dq, dt = pose_err(cams, o.cams)
+    assert dq < 1e-10 and dt < 1e-10
+
+
+# ------------------------------------------------------------------------------- whole solves
+def test_st20_reference_size_matches_oracle_trace(st, O, scenes):
+    """the reference's own BA size: 29 cameras x 600 landmarks (test_ceres.cpp:8-13)"""
+    s = scenes.st20_scene()
+    e, o = engine(st, s), oracle(O, s)
+    summ, tr = e.solve()
+    so, tro = o.solve()
+    assert summ.termination_type == so.termination_type == 0
+    assert summ.num_iterations == so.num_iterations
+    assert summ.termination_reason == so.termination_reason
+    n = min(len(tr), len(tro))
+    big = tro[:n, 0] > 1e-9                      # relative agreement while the cost is above round-off
+    assert np.allclose(tr[:n, 0][big], tro[:n, 0][big], rtol=1e-6)
+    assert np.all(tr[:n, 6] == tro[:n, 6])       # same accept / reject sequence
+    cams, pts = e.get_params()
+    dq, dt = pose_err(cams, o.cams)
+    assert dq < 1e-8 and dt < 1e-8               # north_star: 1e-5 on pose
+    assert np.abs(pts - o.pts).max() < 1e-7
+    dq, dt = pose_err(cams, s["cams_true"])
+    assert dq < 1e-6 and dt < 1e-5
+    assert np.all(cams[0] == s["cams0"][0]) and np.all(cams[-1] == s["cams0"][-1])
+
+
+def test_noisy_problem_matched_final_cost(st, O, scenes):
+    s = scenes.st20_scene(n_cams=40, n_pts=2000, max_obs_per_pt=8, seed=9, pix_noise=1e-3)
+    e, o = engine(st, s), oracle(O, s)
+    summ, tr = e.solve()
+    so, tro = o.solve()
+    assert summ.termination_type == 0
+    assert abs(summ.final_cost - so.final_cost) <= 1e-6 * so.final_cost      # north_star: 1e-6 on residuals
+    assert summ.num_iterations == so.num_iterations
+    cams, pts = e.get_params()
+    dq, dt = pose_err(cams, o.cams)
+    assert dq < 1e-7 and dt < 1e-6
+
+
+def test_two_view_config_c2(st, O, scenes):
+    """BASELINE config C2: 2 cameras, 5k points, 10k observations"""
+    s = scenes.two_view_scene(n_pts=5000)
+    e, o = engine(st, s), oracle(O, s)
+    summ, _ = e.solve()
+    so, _ = o.solve()
+    assert summ.termination_type == 0 and summ.final_cost < 1e-16
+    assert summ.num_iterations == so.num_iterations
+    cams, _ = e.get_params()
+    dq, dt = pose_err(cams, s["cams_true"])
+    assert dq < 1e-8 and dt < 1e-7
+    assert cams[1, 4] == s["cams0"][1, 4]        # the gauge-fixing dof stayed put
+
+
+def test_fixed_work_iterations(st, O, scenes):
+    s = scenes.st20_scene(n_cams=20, n_pts=500, seed=4, pix_noise=1e-3)
+    e, o = engine(st, s), oracle(O, s)
+    summ, tr = e.lm_iterations(7)
+    so, tro = o.solve(fixed_iterations=7)
+    assert summ.num_iterations == 7 and len(tr) == 8
+    assert np.allclose(tr[:, 0], tro[:, 0], rtol=1e-6)
+    assert np.all(tr[:, 6] == tro[:, 6])
+
+
+def test_triangulation_kernel(st, O, scenes):
+    s = scenes.st20_scene(n_cams=15, n_pts=400, seed=8, retriangulate=False)
+    e, o = engine(st, s), oracle(O, s)
+    e.triangulate(); o.triangulate()
+    _, pts = e.get_params()
+    assert np.abs(pts - o.pts).max() < 1e-8
+
+
+def test_degenerate_inputs(st):
+    """a landmark with a single observation and a camera with none"""
+    cams = np.array([[0, 0, 0, 1, 0, 0, 0.0], [0, 0, 0, 1, 1, 0, 0.0], [0, 0, 0, 1, 2, 0, 0.0]])
+    pts = np.array([[0.1, 0.2, 5.0], [0.5, -0.2, 6.0], [0.0, 0.0, 4.0]])
+    oc = np.array([0, 1, 0, 1, 0], np.int32); op = np.array([0, 0, 1, 1, 2], np.int32)
+    feat = np.array([[0.02, 0.04], [-0.18, 0.04], [0.08, -0.03], [-0.08, -0.03], [0.0, 0.0]])
+    e = st.BAEngine(cams, pts, oc, op, feat, cam_fixed=np.array([[1] * 6, [0] * 6, [0] * 6], np.uint8))
+    cost, r, Jc, Jp = e.evaluate()
+    assert np.isfinite(cost) and r.shape == (5, 2)
+    summ, _ = e.solve(max_num_iterations=5)
+    assert np.isfinite(summ.final_cost)
+
+
+# ------------------------------------------------------------------------------- small dense problems
+def test_dense_curve_fit_c1(st, O, scenes, known):
+    """BASELINE config C1: 1k residuals, 3 parameters, through the CostFunction-callback path"""
+    d = scenes.curve_fit_data(1000)
+    x, y = d[:, 0], d[:, 1]
+
+    def res(p):
+        return p[0] * x * x + p[1] * x + p[2] - y, np.stack([x * x, x, np.ones_like(x)], 1)
+    p, summ, tr = st.dense_solve(res, [1.0, 0.0, 0.0], len(x))
+    po, so, tro = O.dense_lm(res, [1.0, 0.0, 0.0], len(x))
+    assert summ.termination_type == 0 and summ.num_iterations == so.num_iterations
+    assert np.allclose(p, po, rtol=1e-10)
+    assert np.allclose(p, [1.0, 2.0, 3.0], atol=0.1)
+
+
+def test_dense_bounds_demo(st, known):
+    ka = known["st17_ceres_bound"]
+
+    def res(p):
+        return np.array([p[0] - 3.0]), np.array([[1.0]])
+    x, _, _ = st.dense_solve(res, [ka["x0"]], 1)
+    assert abs(x[0] - ka["x_free"]) < 1e-8
+    x, _, _ = st.dense_solve(res, [ka["x0"]], 1, lower=[ka["lower"]], upper=[ka["upper"]])
+    assert abs(x[0] - ka["x_bounded"]) < 1e-12
+
+
+def test_dense_pnp_with_manifold_callbacks(st, O, scenes):
+    """SolvePnPWithSizedCostFunction-style: user Evaluate + LocalParameterization::Plus on the host"""
+    s = scenes.pnp_scene(seed=17)
+    n = len(s["pts"])
+
+    def res(x):
+        r = np.zeros(2 * n); J = np.zeros((2 * n, 6))
+        for k in range(n):
+            r[2 * k:2 * k + 2] = O.reproj_residual(x[:4], x[4:], s["pts"][k], s["feats"][k])
+            J[2 * k:2 * k + 2] = O.reproj_jacobian(x[:4], x[4:], s["pts"][k], 0)[0]
+        return r, J
+
+    def plus(x, d):
+        return np.concatenate([O.so3_plus(x[:4], d[:3]), x[4:] + d[3:]])
+    x, summ, _ = st.dense_solve(res, s["pose_init"], 2 * n, n_local=6, plus=plus)
+    assert summ.termination_type == 0 and summ.final_cost < 1e-17
+    dq, dt = pose_err(x[None], s["pose_true"][None])
+    assert dq < 1e-9 and dt < 1e-8
