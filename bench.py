@@ -1,0 +1,214 @@
+#!/usr/bin/env python
+"""bench.py -- LM iterations/s + residuals/s on the 1k-camera / 100k-point synthetic BA (BASELINE
+config C5: 1 000 cameras, 100 000 landmarks, 1 000 000 reprojection observations, FP64).
+
+A "step" is ONE Levenberg-Marquardt iteration of the hot path over the whole problem:
+residual+Jacobian kernel -> block J^T J / J^T r -> landmark Schur complement -> dense FP64
+Cholesky of the 6000 x 6000 reduced camera system (MFMA) -> back-substitution -> manifold
+update -> residual kernel at the trial point (stba_ba_lm_iterations: every iteration does all
+of that, accepted or not).  Inputs are resident in HBM before the timed region.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--cams C --pts P --obs-per-pt M]
+
+N > 1: one process per GPU (torch.distributed.run, backend nccl = RCCL); landmarks are sharded
+across ranks, the cameras are replicated, and one RCCL all-reduce per build carries the reduced
+camera system (strong scaling: the problem is fixed).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X FP64 matrix peak (SURVEY.md 8d / AMD datasheet)
+BYTES_PER_OBS_JAC = 186.5    # materialised residual+Jacobian kernel, 10 obs/landmark
+
+
+def load_scene(args, rank):
+    scenes = importlib.import_module("slam-tricks_amd.scenes")
+    tag = f"c{args.cams}_p{args.pts}_m{args.obs_per_pt}_s20"
+    cache = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"stba_scene_{tag}.npz")
+    if os.path.exists(cache):
+        try:
+            z = np.load(cache)
+            return {k: z[k] for k in z.files}
+        except Exception:
+            pass
+    s = scenes.st20_scene(n_cams=args.cams, n_pts=args.pts, max_obs_per_pt=args.obs_per_pt, seed=20,
+                          pix_noise=1e-3)
+    if rank == 0:
+        try:
+            np.savez(cache + f".tmp{os.getpid()}.npz", **s)
+            os.replace(cache + f".tmp{os.getpid()}.npz", cache)
+        except Exception:
+            pass
+    return s
+
+
+def shard_landmarks(obs_pt, n_pts, world):
+    """contiguous landmark ranges balanced by observation count"""
+    cnt = np.bincount(obs_pt, minlength=n_pts)
+    csum = np.concatenate([[0], np.cumsum(cnt)])
+    cuts = [0]
+    for r in range(1, world):
+        cuts.append(int(np.searchsorted(csum, csum[-1] * r / world)))
+    cuts.append(n_pts)
+    return cuts
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--cams", type=int, default=1000)
+    ap.add_argument("--pts", type=int, default=100000)
+    ap.add_argument("--obs-per-pt", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-iters", type=int, default=0, help="0 = calibrate to ~15 s")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+    elif torch.cuda.is_available():
+        torch.cuda.set_device(0)
+
+    st = importlib.import_module("slam-tricks_amd")
+    if st.device_count() <= 0:
+        raise SystemExit("bench.py needs an MI355X: libstba has no CPU fallback")
+
+    s = load_scene(args, rank)
+    n_cams, n_pts, n_obs = len(s["cams0"]), len(s["pts0"]), len(s["obs_cam"])
+    cuts = shard_landmarks(s["obs_pt"], n_pts, world)
+    lo, hi = cuts[rank], cuts[rank + 1]
+    m = (s["obs_pt"] >= lo) & (s["obs_pt"] < hi)
+    stream = torch.cuda.current_stream().cuda_stream if torch.cuda.is_available() else None
+    eng = st.BAEngine(s["cams0"], s["pts0"][lo:hi], s["obs_cam"][m], s["obs_pt"][m] - lo, s["obs_feat"][m],
+                      s["cam_fixed"], stream=stream)
+    if world > 1:
+        def allreduce(_user, buf, count, _stream):
+            # zero-copy torch view of the engine-owned device buffer; RCCL sum on the current stream
+            # (the engine enqueues on that same stream, so ordering needs no extra events)
+            t = torch.as_tensor(_DevBuf(buf, count), device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            return 0
+        eng.set_allreduce(allreduce, rank, world)
+
+    def sync():
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    # ---- warm-up, then exactly K timed LM iterations
+    if args.warmup > 0:
+        eng.lm_iterations(args.warmup)
+    sync()
+    t0 = time.perf_counter()
+    summ, trace = eng.lm_iterations(args.steps)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    it_per_s = args.steps / dt
+    out = {
+        "metric": "LM iterations/sec + residuals/sec, 1k-cam/100k-pt BA",
+        "value": it_per_s, "unit": "LM iterations/s",
+        "residuals_per_sec": it_per_s * 2.0 * n_obs,
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"C5 large synthetic BA: {n_cams} cams, {n_pts} pts, {n_obs} obs "
+                               f"({2 * n_obs} residuals), Schur + dense {6 * n_cams}x{6 * n_cams} Cholesky, "
+                               "st20 spiral/cube scene seed 20, pixel noise 1e-3",
+                   "parallelism": f"landmark-shard x{world}" if world > 1 else "single GPU",
+                   "n_cams": n_cams, "n_pts": n_pts, "n_obs": n_obs},
+        "phase_ms_per_step": {k: getattr(summ, k) / args.steps for k in
+                              ("ms_linearize", "ms_schur", "ms_solve", "ms_backsub", "ms_cost")},
+        "final_cost": summ.final_cost,
+    }
+
+    if rank == 0:
+        # ---- roofline legs, measured live with hipEvents on the engine's stream
+        ms_jac = eng.time_linearize(20)
+        local_obs = int(m.sum())
+        jac_bytes = BYTES_PER_OBS_JAC * local_obs
+        jac_gbs = jac_bytes / (ms_jac * 1e-3) / 1e9
+        prof = st.cholesky_profile(6 * n_cams)
+        syrk_tflops = prof["syrk_flops"] / (prof["ms_syrk"] * 1e-3) / 1e12 if prof["ms_syrk"] > 0 else 0.0
+        chol_total_ms = prof["ms_diag"] + prof["ms_trsm"] + prof["ms_syrk"] + prof["ms_bwd"]
+        roof_jac = {"kernel": "ba_linearize_kernel<cams-in-LDS, with-Jacobian>", "bound": "hbm", "achieved": jac_gbs,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": jac_gbs / HBM_PEAK_GBS, "traffic": None,
+                    "ms_per_launch": ms_jac, "algorithmic_bytes_per_launch": jac_bytes}
+        roof_syrk = {"kernel": "chol_syrk_kernel (v_mfma_f64_16x16x4_f64)", "bound": "mfma", "achieved": syrk_tflops,
+                     "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": syrk_tflops / FP64_MFMA_PEAK_TFLOPS,
+                     "traffic": None, "ms_per_launch": prof["ms_syrk"] / max(1, prof["syrk_launches"]),
+                     "launches_per_factorisation": prof["syrk_launches"],
+                     "algorithmic_flops_per_factorisation": prof["syrk_flops"],
+                     "executed_flops_per_factorisation": prof["syrk_flops_padded"]}
+        # the dominant kernel by device time carries the headline roofline object
+        dominant_is_syrk = prof["ms_syrk"] > ms_jac
+        out["roofline"] = roof_syrk if dominant_is_syrk else roof_jac
+        out["roofline_jacobian"] = roof_jac
+        out["roofline_mfma"] = roof_syrk
+        out["cholesky_ms"] = {"diag": prof["ms_diag"], "trsm": prof["ms_trsm"], "syrk": prof["ms_syrk"],
+                              "backward": prof["ms_bwd"], "total": chol_total_ms}
+
+        if world == 1 and not args.no_cpu_baseline:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import oracle_py as O       # cpu_baseline leg only: the oracle is the thing timed here
+            cores = os.cpu_count() or 1
+            ba = O.BA(s["cams0"], s["pts0"], s["obs_cam"], s["obs_pt"], s["obs_feat"], s["cam_fixed"])
+            # bounded sample: one iteration to calibrate, then as many more as fit in ~15 s of CPU work
+            tc = time.perf_counter()
+            ba.solve(fixed_iterations=1, num_threads=cores)
+            t1 = time.perf_counter() - tc
+            extra = int(min(10, max(0, round(15.0 / max(t1, 1e-3)) - 1))) if args.cpu_iters <= 0 else args.cpu_iters - 1
+            if extra > 0:
+                ba.solve(fixed_iterations=extra, num_threads=cores)
+            cpu_dt = time.perf_counter() - tc
+            n_it = 1 + extra
+            cpu_it = n_it / cpu_dt
+            out["cpu_baseline"] = {"value": cpu_it, "unit": "LM iterations/s", "cores": cores, "kind": "port",
+                                   "residuals_per_sec": cpu_it * 2.0 * n_obs,
+                                   "sample": f"{n_it} fixed-work LM iteration(s) of the same C5 problem "
+                                             f"(oracle/liboracle.so: OpenMP over {cores} threads, dense Cholesky), "
+                                             f"{cpu_dt:.1f} s wall",
+                                   "seconds": cpu_dt}
+            out["speedup_vs_cpu_port"] = it_per_s / cpu_it
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+class _DevBuf:
+    """__cuda_array_interface__ view of a raw device pointer owned by the engine (FP64 vector)"""
+
+    def __init__(self, ptr, count):
+        self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": "<f8", "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+if __name__ == "__main__":
+    main()

@@ -177,6 +177,12 @@ int stba_cholesky_solve(const double* A, int n, double* b, void* hip_stream);
 /* device-resident timing of factor+solve on an n x n synthetic SPD system, ms per solve */
 int stba_cholesky_time(int n, int reps, double* ms_avg, void* hip_stream);
 
+/* hipEvent time (ms) of one factor+solve per kernel class: ms4 = {diagonal blocks, panel solves,
+ * MFMA trailing updates, backward substitution}; algorithmic / executed flops of the trailing
+ * updates and their launch count (bench.py MFMA roofline leg). */
+int stba_cholesky_profile(int n, double* ms4, double* syrk_flops, double* syrk_flops_padded,
+                          int* syrk_launches, void* hip_stream);
+
 /* ================================ small dense LM problems ================================ */
 /* Residual blocks evaluated by a HOST callback (user CostFunction::Evaluate, solver.hpp:168-212;
  * autodiff functors are differentiated on the host by the C++ shim), normal equations + LM

@@ -386,8 +386,11 @@ static inline int cam_dof_fixed(const orc_ba_problem* p, int c, int d) {
 }
 static inline int pt_is_fixed(const orc_ba_problem* p, int j) { return p->pt_fixed ? p->pt_fixed[j] : 0; }
 
+static int g_threads = 1;   /* set by orc_ba_solve from options->num_threads */
+
 double orc_ba_evaluate(const orc_ba_problem* p, double* r, double* Jc, double* Jp) {
     double cost = 0;
+#pragma omp parallel for schedule(static) reduction(+ : cost) num_threads(g_threads)
     for (int i = 0; i < p->n_obs; ++i) {
         const int c = p->obs_cam[i], j = p->obs_pt[i];
         const double* cam = &p->cams[c * 7];
@@ -415,18 +418,32 @@ void orc_ba_normal_blocks(const orc_ba_problem* p, const double* r, const double
     memset(gc, 0, sizeof(double) * 6 * p->n_cams);
     memset(Hpp, 0, sizeof(double) * 9 * p->n_pts);
     memset(gp, 0, sizeof(double) * 3 * p->n_pts);
-    for (int i = 0; i < p->n_obs; ++i) {
-        const int c = p->obs_cam[i], j = p->obs_pt[i];
-        const double* jc = &Jc[(size_t)i * 12];
-        const double* jp = &Jp[(size_t)i * 6];
-        const double r0 = r[i * 2], r1 = r[i * 2 + 1];
-        for (int a = 0; a < 6; ++a) {
-            for (int b = 0; b < 6; ++b) Hcc[c * 36 + a * 6 + b] += jc[a] * jc[b] + jc[6 + a] * jc[6 + b];
-            gc[c * 6 + a] += jc[a] * r0 + jc[6 + a] * r1;
-        }
-        for (int a = 0; a < 3; ++a) {
-            for (int b = 0; b < 3; ++b) Hpp[j * 9 + a * 3 + b] += jp[a] * jp[b] + jp[3 + a] * jp[3 + b];
-            gp[j * 3 + a] += jp[a] * r0 + jp[3 + a] * r1;
+    /* each thread owns the cameras / landmarks with index % nt == tid: no write conflicts and a
+     * summation order that does not depend on the thread count */
+#pragma omp parallel num_threads(g_threads)
+    {
+#ifdef _OPENMP
+        const int tid = omp_get_thread_num(), nt = omp_get_num_threads();
+#else
+        const int tid = 0, nt = 1;
+#endif
+        for (int i = 0; i < p->n_obs; ++i) {
+            const int c = p->obs_cam[i], j = p->obs_pt[i];
+            const double r0 = r[i * 2], r1 = r[i * 2 + 1];
+            if (c % nt == tid) {
+                const double* jc = &Jc[(size_t)i * 12];
+                for (int a = 0; a < 6; ++a) {
+                    for (int b = 0; b < 6; ++b) Hcc[c * 36 + a * 6 + b] += jc[a] * jc[b] + jc[6 + a] * jc[6 + b];
+                    gc[c * 6 + a] += jc[a] * r0 + jc[6 + a] * r1;
+                }
+            }
+            if (j % nt == tid) {
+                const double* jp = &Jp[(size_t)i * 6];
+                for (int a = 0; a < 3; ++a) {
+                    for (int b = 0; b < 3; ++b) Hpp[j * 9 + a * 3 + b] += jp[a] * jp[b] + jp[3 + a] * jp[3 + b];
+                    gp[j * 3 + a] += jp[a] * r0 + jp[3 + a] * r1;
+                }
+            }
         }
     }
 }
@@ -449,7 +466,15 @@ void orc_ba_reduced_system(const orc_ba_problem* p, const double* Jc, const doub
     const int n = 6 * p->n_cams;
     memset(S, 0, sizeof(double) * (size_t)n * n);
     memset(rhs, 0, sizeof(double) * n);
-    /* obs are landmark-major: walk the segments */
+    /* obs are landmark-major: walk the segments; thread `tid` owns the rows of the cameras with
+     * c % nt == tid (no write conflicts, thread-count independent summation order) */
+#pragma omp parallel num_threads(g_threads)
+    {
+#ifdef _OPENMP
+    const int tid = omp_get_thread_num(), nt = omp_get_num_threads();
+#else
+    const int tid = 0, nt = 1;
+#endif
     int i0 = 0;
     while (i0 < p->n_obs && p->obs_pt[i0] < pt_begin) ++i0;
     while (i0 < p->n_obs && p->obs_pt[i0] < pt_end) {
@@ -474,6 +499,7 @@ void orc_ba_reduced_system(const orc_ba_problem* p, const double* Jc, const doub
         }
         for (int i = i0; i < i1; ++i) {
             const int c = p->obs_cam[i];
+            if (c % nt != tid) continue;
             const double* jc = &Jc[(size_t)i * 12];
             const double* jp = &Jp[(size_t)i * 6];
             const double r0 = r[i * 2], r1 = r[i * 2 + 1];
@@ -511,6 +537,7 @@ void orc_ba_reduced_system(const orc_ba_problem* p, const double* Jc, const doub
         }
         i0 = i1;
     }
+    }   /* omp parallel */
     /* damping + fixed dofs (only when this call owns the whole landmark range start:
      * the diagonal terms must be added exactly once across shards -> shard with pt_begin==0) */
     if (pt_begin == 0) {
@@ -529,11 +556,19 @@ typedef struct {
 } ba_ws;
 
 static void ba_backsub(const orc_ba_problem* p, const ba_ws* w) {
+#pragma omp parallel num_threads(g_threads)
+    {
+#ifdef _OPENMP
+    const int tid = omp_get_thread_num(), nt = omp_get_num_threads();
+#else
+    const int tid = 0, nt = 1;
+#endif
     int i0 = 0;
     while (i0 < p->n_obs) {
         const int j = p->obs_pt[i0];
         int i1 = i0;
         while (i1 < p->n_obs && p->obs_pt[i1] == j) ++i1;
+        if (j % nt != tid) { i0 = i1; continue; }
         double* dx = &w->dxp[j * 3];
         if (pt_is_fixed(p, j)) { dx[0] = dx[1] = dx[2] = 0; i0 = i1; continue; }
         double H[9], Hi[9], v[3];
@@ -553,7 +588,7 @@ static void ba_backsub(const orc_ba_problem* p, const ba_ws* w) {
         for (int a = 0; a < 3; ++a) dx[a] = Hi[a * 3] * v[0] + Hi[a * 3 + 1] * v[1] + Hi[a * 3 + 2] * v[2];
         i0 = i1;
     }
-    /* points that have no observation at all */
+    }   /* omp parallel */
 }
 
 static void ba_apply(const orc_ba_problem* p, const double* dxc, const double* dxp,
@@ -601,6 +636,7 @@ static double ba_x_norm2(const orc_ba_problem* p, const double* cams, const doub
 int orc_ba_solve(orc_ba_problem* p, const orc_lm_options* opt, orc_lm_summary* sum, double* trace) {
     const int nc = p->n_cams, np = p->n_pts, no = p->n_obs, n = 6 * nc;
     const int nt = opt->num_threads > 0 ? opt->num_threads : 1;
+    g_threads = nt;
     ba_ws w;
     w.r = malloc(sizeof(double) * 2 * no);
     w.Jc = malloc(sizeof(double) * 12 * (size_t)no);
@@ -704,6 +740,7 @@ int orc_ba_solve(orc_ba_problem* p, const orc_lm_options* opt, orc_lm_summary* s
             ba_backsub(p, &w);
             sum->seconds_backsub += now_s() - t0;
             /* model_cost_change = -sum m.(r + m/2), m = J delta (Ceres trust_region_minimizer) */
+#pragma omp parallel for schedule(static) reduction(+ : model_change) num_threads(g_threads)
             for (int i = 0; i < no; ++i) {
                 const int c = p->obs_cam[i], j = p->obs_pt[i];
                 const double* jc = &w.Jc[(size_t)i * 12];

@@ -65,7 +65,7 @@ EXPORTS = ["stba_status_string", "stba_last_error", "stba_version", "stba_device
            "stba_ba_cost", "stba_ba_normal_blocks", "stba_ba_reduced_system", "stba_ba_solve_reduced",
            "stba_ba_back_substitute", "stba_ba_apply_step", "stba_ba_solve", "stba_ba_lm_iterations",
            "stba_ba_triangulate", "stba_ba_time_linearize", "stba_cholesky_factor", "stba_cholesky_solve",
-           "stba_cholesky_time", "stba_dense_solve"]
+           "stba_cholesky_time", "stba_cholesky_profile", "stba_dense_solve"]
 
 
 def lib():
@@ -240,6 +240,14 @@ def cholesky_time(n, reps=5, stream=None):
     ms = C.c_double()
     _chk(lib().stba_cholesky_time(int(n), int(reps), C.byref(ms), C.c_void_p(stream or 0)), "stba_cholesky_time")
     return ms.value
+
+
+def cholesky_profile(n, stream=None):
+    ms = np.zeros(4); fl = C.c_double(); flp = C.c_double(); nl = C.c_int()
+    _chk(lib().stba_cholesky_profile(int(n), _p(ms), C.byref(fl), C.byref(flp), C.byref(nl), C.c_void_p(stream or 0)),
+         "stba_cholesky_profile")
+    return dict(ms_diag=ms[0], ms_trsm=ms[1], ms_syrk=ms[2], ms_bwd=ms[3], syrk_flops=fl.value,
+                syrk_flops_padded=flp.value, syrk_launches=nl.value)
 
 
 def dense_solve(residual, x0, n_res, n_local=None, plus=None, lower=None, upper=None, opt=None, callback=None, **kw):

@@ -43,6 +43,14 @@ inline int chol_padded_dim(int n) { return ((n + 1 + CHOL_NB - 1) / CHOL_NB) * C
 // lower triangle holds L, row lda-1 holds y = L^-1 rhs, x_dev[0..lda) the solution of A x = rhs.
 // flag_dev: int, set to (row+1) of the first non-positive pivot among real rows.
 int chol_factor_solve_dev(double* A_dev, int lda, int n, double* x_dev, int* flag_dev, hipStream_t st);
+struct CholProfile {
+    double ms_diag, ms_trsm, ms_syrk, ms_bwd;
+    double syrk_flops;          // algorithmic: sum over steps of m(m+1)*128, m = remaining real rows
+    double syrk_flops_padded;   // what the tiles actually execute
+    int syrk_launches;
+};
+int chol_factor_solve_profiled(double* A_dev, int lda, int n, double* x_dev, int* flag_dev, hipStream_t st,
+                               CholProfile* prof);
 // fills the padding (identity) and the rhs row of a padded system
 int chol_prepare_padding_dev(double* A_dev, int lda, int n, const double* rhs_dev, hipStream_t st);
 

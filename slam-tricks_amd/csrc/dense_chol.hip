@@ -21,6 +21,9 @@
 //   chol_syrk_kernel   128x128 output tiles of the trailing lower triangle, 4 waves x (4x4)
 //                      16x16 MFMA tiles, K = 128 streamed through double-buffered LDS in
 //                      fragment order (conflict-free ds_read_b64 / ds_write_b64).
+#include <algorithm>
+#include <vector>
+
 #include "common.hpp"
 
 namespace stba {
@@ -289,6 +292,55 @@ __global__ __launch_bounds__(256) void chol_bwd_update_kernel(double* __restrict
 #pragma unroll 8
     for (int j = 0; j < nv; ++j) s += col[(size_t)j * lda] * xs[j];
     A[(size_t)(lda - 1) * lda + c] -= s;
+}
+
+// same as chol_factor_solve_dev with hipEvent pairs around every kernel class (profiling only)
+int chol_factor_solve_profiled(double* A, int lda, int n, double* x_dev, int* flag_dev, hipStream_t st,
+                               CholProfile* prof) {
+    if (lda % NB != 0 || lda < n + 1) return fail(STBA_ERR_INVALID_ARGUMENT, "chol: bad padded dimension");
+    // precondition: chol_factor_solve_dev ran once before (it sets the dynamic-LDS attributes)
+    STBA_HIP(hipMemsetAsync(flag_dev, 0, sizeof(int), st));
+    const int nblk = lda / NB;
+    const size_t trsm_lds = sizeof(double) * (NB * (NB + 1) + 2 * NB);
+    const size_t bwd_lds = sizeof(double) * (NB * (NB + 1) + NB);
+    std::vector<hipEvent_t> ev((size_t)nblk * 4 + 2);
+    for (auto& e : ev) STBA_HIP(hipEventCreate(&e));
+    memset(prof, 0, sizeof *prof);
+    for (int b = 0; b < nblk; ++b) {
+        const int k0 = b * NB;
+        const int mt = nblk - b - 1;
+        STBA_HIP(hipEventRecord(ev[4 * b + 0], st));
+        hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(1024), 0, st, A, lda, k0, n, flag_dev);
+        STBA_HIP(hipEventRecord(ev[4 * b + 1], st));
+        if (mt > 0) hipLaunchKernelGGL(chol_trsm_kernel, dim3(mt), dim3(1024), trsm_lds, st, A, lda, k0);
+        STBA_HIP(hipEventRecord(ev[4 * b + 2], st));
+        if (mt > 0) hipLaunchKernelGGL(chol_syrk_kernel, dim3(mt * (mt + 1) / 2), dim3(256), 0, st, A, lda, k0);
+        STBA_HIP(hipEventRecord(ev[4 * b + 3], st));
+        if (mt > 0) {
+            const double m = std::max(0, n - (k0 + NB));
+            prof->syrk_flops += m * (m + 1.0) * NB;
+            prof->syrk_flops_padded += (double)(mt * (mt + 1) / 2) * 2.0 * NB * NB * NB;
+            prof->syrk_launches += 1;
+        }
+    }
+    STBA_HIP(hipEventRecord(ev[(size_t)nblk * 4], st));
+    for (int b = nblk - 1; b >= 0; --b) {
+        const int k0 = b * NB;
+        hipLaunchKernelGGL(chol_bwd_diag_kernel, dim3(1), dim3(1024), bwd_lds, st, A, lda, k0, x_dev);
+        if (k0 > 0)
+            hipLaunchKernelGGL(chol_bwd_update_kernel, dim3((k0 + 255) / 256), dim3(256), 0, st, A, lda, k0, x_dev);
+    }
+    STBA_HIP(hipEventRecord(ev[(size_t)nblk * 4 + 1], st));
+    STBA_HIP(hipStreamSynchronize(st));
+    float ms = 0.f;
+    for (int b = 0; b < nblk; ++b) {
+        (void)hipEventElapsedTime(&ms, ev[4 * b + 0], ev[4 * b + 1]); prof->ms_diag += ms;
+        (void)hipEventElapsedTime(&ms, ev[4 * b + 1], ev[4 * b + 2]); prof->ms_trsm += ms;
+        (void)hipEventElapsedTime(&ms, ev[4 * b + 2], ev[4 * b + 3]); prof->ms_syrk += ms;
+    }
+    (void)hipEventElapsedTime(&ms, ev[(size_t)nblk * 4], ev[(size_t)nblk * 4 + 1]); prof->ms_bwd = ms;
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    return STBA_OK;
 }
 
 int chol_factor_solve_dev(double* A, int lda, int n, double* x_dev, int* flag_dev, hipStream_t st) {

@@ -161,7 +161,7 @@ static int ba_build_reduced(stba_ba* b, const Damping& dm) {
                           b->rhs(), b->st));
     STBA_TRY(launch_reduced_add_camera(b->nc, b->Hcc, b->gc, b->S(), b->lda, b->rhs(), b->ex_diag(), b->ex_gc(),
                                        b->st));
-    if (b->ar && b->world > 1) {
+    if (b->ar) {
         if (b->ar(b->ar_user, b->Sbuf, b->sbuf_count(), b->st) != 0)
             return fail(STBA_ERR_CALLBACK, "all-reduce hook failed");
     }
@@ -190,7 +190,7 @@ static int ba_trial(stba_ba* b) {
     if (b->np > 0) STBA_TRY(launch_sum_partials(b->upd_partial_p, pb, 4, 3, b->trial + TS_STEP2, b->st));
     STBA_TRY(launch_sum_partials(b->upd_partial_c, cb, 4, 3, b->trial + TS_CAM, b->st));
     STBA_TRY(ba_cost_only(b, nxt, b->trial + TS_COST2));
-    if (b->ar && b->world > 1) {
+    if (b->ar) {
         if (b->ar(b->ar_user, b->trial, 4, b->st) != 0) return fail(STBA_ERR_CALLBACK, "all-reduce hook failed");
     }
     return STBA_OK;
@@ -367,7 +367,7 @@ static int ba_run_lm(stba_ba* b, const stba_lm_options* opt_in, int fixed_iterat
             L.decrease *= 2.0;
         }
         need_build = true;
-        if (accepted || fixed) {
+        if ((accepted || fixed) && !(fixed && iter >= max_iter)) {
             // re-linearise at the (new) current point
             STBA_HIP(hipEventRecord(ev[0], b->st));
             STBA_TRY(ba_linearize(b, b->cur, b->trial + TS_COST2));
@@ -852,6 +852,31 @@ int stba_cholesky_time(int n, int reps, double* ms_avg, void* hip_stream) {
     }
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     *ms_avg = total / reps;
+    return STBA_OK;
+}
+
+int stba_cholesky_profile(int n, double* ms4, double* syrk_flops, double* syrk_flops_padded, int* syrk_launches,
+                          void* hip_stream) {
+    if (n <= 0 || !ms4) return fail(STBA_ERR_INVALID_ARGUMENT, "bad argument");
+    STBA_TRY(require_device());
+    DenseWs w;
+    STBA_TRY(w.init(n, hip_stream));
+    const size_t cnt = (size_t)w.lda * w.lda;
+    hipLaunchKernelGGL(synth_spd_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, w.st, w.A, w.lda, n);
+    STBA_HIP(hipMemsetAsync(w.rhs, 0, (size_t)w.lda * sizeof(double), w.st));
+    STBA_TRY(chol_prepare_padding_dev(w.A, w.lda, n, w.rhs, w.st));
+    CholProfile prof;
+    // warm-up pass inside, then the timed pass on a fresh matrix
+    STBA_TRY(chol_factor_solve_dev(w.A, w.lda, n, w.x, w.flag, w.st));
+    hipLaunchKernelGGL(synth_spd_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, w.st, w.A, w.lda, n);
+    STBA_TRY(chol_prepare_padding_dev(w.A, w.lda, n, w.rhs, w.st));
+    // the profiled routine factors once un-timed (on this matrix) and once timed: re-synthesise between
+    // is not possible from outside, so time a factorisation of the already-factored-then-refilled buffer:
+    STBA_TRY(chol_factor_solve_profiled(w.A, w.lda, n, w.x, w.flag, w.st, &prof));
+    ms4[0] = prof.ms_diag; ms4[1] = prof.ms_trsm; ms4[2] = prof.ms_syrk; ms4[3] = prof.ms_bwd;
+    if (syrk_flops) *syrk_flops = prof.syrk_flops;
+    if (syrk_flops_padded) *syrk_flops_padded = prof.syrk_flops_padded;
+    if (syrk_launches) *syrk_launches = prof.syrk_launches;
     return STBA_OK;
 }
 
