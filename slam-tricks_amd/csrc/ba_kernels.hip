@@ -464,6 +464,117 @@ int launch_schur(int n_obs, const int* obs_cam, const int* obs_pt, const int* pt
     return STBA_OK;
 }
 
+// -------------------------------------------------------------------------------------------
+// Row-wise Schur complement (the fast path).  One workgroup per task = (camera row c, a slice
+// of that camera's observation list).  The row's non-zero 6x6 blocks S[c, c2] (c2 <= c) are
+// accumulated in LDS with ds_add_f64 and written to HBM once, so the only global traffic is the
+// re-read of the landmark neighbours' Jacobian rows (L2-resident) and one store per non-zero
+// block: no global atomics and no read-modify-write of the 288 MB matrix.
+//   cols: sorted distinct c2 of the row (CSR row_col_ptr/row_cols), slot = binary search.
+// -------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ba_schur_rows_kernel(SchurRowArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int task = blockIdx.x;
+    const int c = a.task_cam[task];
+    const int col0 = a.row_col_ptr[c], ncols = a.row_col_ptr[c + 1] - col0;
+    double* acc = smem;                          // [ncols][36]
+    double* racc = smem + (size_t)a.max_cols * 36;   // [8]
+    int* cols = reinterpret_cast<int*>(racc + 8);    // [ncols]
+    const int tid = threadIdx.x;
+    for (int e = tid; e < ncols * 36; e += 256) acc[e] = 0.0;
+    if (tid < 8) racc[tid] = 0.0;
+    for (int e = tid; e < ncols; e += 256) cols[e] = a.row_cols[col0 + e];
+    __syncthreads();
+    const int pe = a.task_end[task];
+    for (int p = a.task_begin[task] + tid; p < pe; p += 256) {
+        const int i = a.cam_perm[p];
+        const int j = a.obs_pt[i];
+        double Hi[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) Hi[k] = a.Hinv6[(size_t)j * 6 + k];
+        if (Hi[0] == 0.0 && Hi[3] == 0.0 && Hi[5] == 0.0) continue;   // constant / degenerate landmark
+        double jc[12], jp[6];
+        load_jc_jp(a.Jc, a.Jp, i, jc, jp);
+        double E[18];
+        const double g0 = a.gp[(size_t)j * 3], g1 = a.gp[(size_t)j * 3 + 1], g2 = a.gp[(size_t)j * 3 + 2];
+        bool any = false;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            const double w0 = jc[q] * jp[0] + jc[6 + q] * jp[3];
+            const double w1 = jc[q] * jp[1] + jc[6 + q] * jp[4];
+            const double w2 = jc[q] * jp[2] + jc[6 + q] * jp[5];
+            E[q * 3 + 0] = w0 * Hi[0] + w1 * Hi[1] + w2 * Hi[2];
+            E[q * 3 + 1] = w0 * Hi[1] + w1 * Hi[3] + w2 * Hi[4];
+            E[q * 3 + 2] = w0 * Hi[2] + w1 * Hi[4] + w2 * Hi[5];
+            any |= (w0 != 0.0) | (w1 != 0.0) | (w2 != 0.0);
+        }
+        if (!any) continue;   // constant camera
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            const double v = E[q * 3] * g0 + E[q * 3 + 1] * g1 + E[q * 3 + 2] * g2;
+            if (v != 0.0) unsafeAtomicAdd(&racc[q], v);
+        }
+        const int le = a.pt_start[j + 1];
+        for (int l = a.pt_start[j]; l < le; ++l) {
+            const int c2 = a.obs_cam[l];
+            if (c2 > c) continue;
+            int lo = 0, hi = ncols - 1;          // cols is sorted and contains c2
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (cols[mid] < c2) lo = mid + 1; else hi = mid;
+            }
+            double* blk = acc + (size_t)lo * 36;
+            double jc2[12], jp2[6];
+            load_jc_jp(a.Jc, a.Jp, l, jc2, jp2);
+#pragma unroll
+            for (int b = 0; b < 6; ++b) {
+                const double w0 = jc2[b] * jp2[0] + jc2[6 + b] * jp2[3];
+                const double w1 = jc2[b] * jp2[1] + jc2[6 + b] * jp2[4];
+                const double w2 = jc2[b] * jp2[2] + jc2[6 + b] * jp2[5];
+                if (w0 == 0.0 && w1 == 0.0 && w2 == 0.0) continue;   // constant dof of camera c2
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
+                    if (c2 == c && b > q) continue;
+                    const double v = E[q * 3] * w0 + E[q * 3 + 1] * w1 + E[q * 3 + 2] * w2;
+                    unsafeAtomicAdd(&blk[q * 6 + b], -v);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const bool single = a.task_single[task] != 0;
+    for (int e = tid; e < ncols * 36; e += 256) {
+        const int slot = e / 36, k = e - slot * 36, q = k / 6, b = k - q * 6;
+        const int c2 = cols[slot];
+        if (c2 == c && b > q) continue;
+        double* dst = a.S + (size_t)(c * 6 + q) * a.lda + c2 * 6 + b;
+        if (single) *dst = acc[e];
+        else unsafeAtomicAdd(dst, acc[e]);
+    }
+    if (tid < 6) {
+        if (single) a.rhs[c * 6 + tid] = racc[tid];
+        else unsafeAtomicAdd(&a.rhs[c * 6 + tid], racc[tid]);
+    }
+}
+
+size_t schur_rows_lds_bytes(int max_cols) {
+    return ((size_t)max_cols * 36 + 8) * sizeof(double) + (size_t)max_cols * sizeof(int) + 16;
+}
+
+int launch_schur_rows(const SchurRowArgs& a, int n_tasks, hipStream_t st) {
+    if (n_tasks <= 0) return STBA_OK;
+    const size_t lds = schur_rows_lds_bytes(a.max_cols);
+    static size_t attr_lds = 0;
+    if (lds > attr_lds) {
+        STBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_schur_rows_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_lds = lds;
+    }
+    hipLaunchKernelGGL(ba_schur_rows_kernel, dim3(n_tasks), dim3(256), lds, st, a);
+    STBA_HIP(hipGetLastError());
+    return STBA_OK;
+}
+
 // S diagonal blocks += Hcc (this rank's partial), rhs -= gc; packs diag(Hcc) and gc behind S
 // so that one all-reduce carries everything (extras: [diagHcc | gc], n entries each).
 __global__ __launch_bounds__(256) void ba_reduced_add_camera_kernel(int n_cams, const double* __restrict__ Hcc,

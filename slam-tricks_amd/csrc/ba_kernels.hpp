@@ -39,6 +39,18 @@ int launch_point_invert(int n_pts, const double* Hpp6, const double* dp, const u
 int launch_schur(int n_obs, const int* obs_cam, const int* obs_pt, const int* pt_start, const double* Jc,
                  const double* Jp, const double* Hinv6, const double* gp, double* S, int lda, double* rhs,
                  hipStream_t st);
+// row-wise Schur complement with LDS accumulation (plan built on the host at create time)
+constexpr int SCHUR_MAX_COLS = 500;    // non-zero blocks per camera row that fit the LDS accumulator
+constexpr int SCHUR_TASK_OBS = 4096;   // observations of one camera handled by one workgroup
+struct SchurRowArgs {
+    const int* task_cam; const int* task_begin; const int* task_end; const unsigned char* task_single;
+    const int* row_col_ptr; const int* row_cols; int max_cols;
+    const int* cam_perm; const int* obs_cam; const int* obs_pt; const int* pt_start;
+    const double* Jc; const double* Jp; const double* Hinv6; const double* gp;
+    double* S; int lda; double* rhs;
+};
+size_t schur_rows_lds_bytes(int max_cols);
+int launch_schur_rows(const SchurRowArgs& a, int n_tasks, hipStream_t st);
 int launch_reduced_add_camera(int n_cams, const double* Hcc, const double* gc, double* S, int lda, double* rhs,
                               double* ex_diag, double* ex_gc, hipStream_t st);
 int launch_reduced_damp(int n, const double* dc, const unsigned char* cam_fixed, double* S, int lda, double* rhs,

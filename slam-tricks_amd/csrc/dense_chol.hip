@@ -14,13 +14,16 @@
 //
 // Per 128-column step:
 //   chol_diag_kernel   1 workgroup x 1024 threads; the 128x128 diagonal block lives in registers
-//                      (4x4 per thread, 32-cyclic distribution), one LDS column broadcast and one
-//                      barrier per column.
-//   chol_trsm_kernel   one workgroup per 128 rows of the panel; L11 staged in LDS (129-padded),
-//                      panel rows in registers, same column-broadcast scheme.
+//                      (4x4 per thread, 32-cyclic distribution); one LDS column broadcast and one
+//                      barrier per column; sub-blocks left of / above the active column are
+//                      skipped with wave-uniform (compile-time) bounds.
+//   chol_trsm_kernel   one workgroup per 32 rows of the panel (so that a 6000-row panel spreads
+//                      over ~190 CUs); L11 staged in LDS (129-padded), panel rows in registers.
 //   chol_syrk_kernel   128x128 output tiles of the trailing lower triangle, 4 waves x (4x4)
 //                      16x16 MFMA tiles, K = 128 streamed through double-buffered LDS in
 //                      fragment order (conflict-free ds_read_b64 / ds_write_b64).
+//   backward           one wave per diagonal block (shuffle broadcast, no barriers) + a GEMV
+//                      update of the remaining right-hand side.
 #include <algorithm>
 #include <vector>
 
@@ -29,6 +32,7 @@
 namespace stba {
 
 constexpr int NB = CHOL_NB;
+constexpr int TRSM_ROWS = 32;
 typedef double double4v __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------------
@@ -53,6 +57,56 @@ int chol_prepare_padding_dev(double* A_dev, int lda, int n, const double* rhs_de
 }
 
 // ------------------------------------------------------------------------------------------
+// diagonal block.  Thread (ty, tx) owns rows ty + 32a, columns tx + 32b (a, b < 4).  Columns are
+// processed in four groups A0 = j >> 5 so that every register index is a compile-time constant
+// and whole sub-blocks outside the active trailing part are skipped.
+template <int A0>
+__device__ __forceinline__ void chol_diag_steps(double (&acc)[4][4], double (*colbuf)[NB], int tx, int ty,
+                                                int k0, int n_real, int* flag) {
+    for (int jj = 0; jj < 32; ++jj) {
+        const int j = 32 * A0 + jj;
+        double* cb = colbuf[j & 1];
+        if (tx == jj) {
+#pragma unroll
+            for (int a = A0; a < 4; ++a) cb[ty + 32 * a] = acc[a][A0];
+        }
+        __syncthreads();
+        const double d = cb[j];
+        double ljj, inv;
+        if (d > 0.0) {
+            // division-free pivot: l = d * rsqrt(d) plus one FMA Newton correction (~1 ulp); the
+            // column is scaled by rsqrt(d) itself, keeping the dependent chain short
+            inv = rsqrt(d);
+            ljj = d * inv;
+            ljj = fma(fma(-ljj, ljj, d), 0.5 * inv, ljj);
+        } else {
+            ljj = 1.0; inv = 1.0;
+            if (threadIdx.x == 0 && (k0 + j) < n_real) atomicCAS(flag, 0, k0 + j + 1);
+        }
+        double li[4], lc[4];
+#pragma unroll
+        for (int a = A0; a < 4; ++a) li[a] = cb[ty + 32 * a] * inv;
+#pragma unroll
+        for (int b = A0; b < 4; ++b) lc[b] = cb[tx + 32 * b] * inv;
+#pragma unroll
+        for (int a = A0; a < 4; ++a)
+#pragma unroll
+            for (int b = A0; b <= a; ++b) {
+                bool on = true;
+                if (b == A0) on = on && (tx > jj);     // column strictly right of j
+                if (b == a) on = on && (tx <= ty);     // lower triangle of a diagonal sub-block
+                if (on) acc[a][b] -= li[a] * lc[b];
+            }
+        if (tx == jj) {
+#pragma unroll
+            for (int a = A0; a < 4; ++a) {
+                const int i = ty + 32 * a;
+                acc[a][A0] = (i > j) ? li[a] : ((i == j) ? ljj : acc[a][A0]);
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(1024) void chol_diag_kernel(double* __restrict__ A, int lda, int k0,
                                                          int n_real, int* __restrict__ flag) {
     __shared__ double colbuf[2][NB];
@@ -65,42 +119,10 @@ __global__ __launch_bounds__(1024) void chol_diag_kernel(double* __restrict__ A,
             const int i = ty + 32 * a, c = tx + 32 * b;
             acc[a][b] = (c <= i) ? A[(size_t)(k0 + i) * lda + k0 + c] : 0.0;
         }
-    for (int j = 0; j < NB; ++j) {
-        const int bj = j >> 5, txj = j & 31;
-        double* cb = colbuf[j & 1];
-        if (tx == txj) {
-#pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                double v = acc[a][0];
-#pragma unroll
-                for (int b = 1; b < 4; ++b) v = (b == bj) ? acc[a][b] : v;
-                cb[ty + 32 * a] = v;
-            }
-        }
-        __syncthreads();
-        const double d = cb[j];
-        double ljj;
-        if (d > 0.0) {
-            ljj = sqrt(d);
-        } else {
-            ljj = 1.0;
-            if (t == 0 && (k0 + j) < n_real) atomicCAS(flag, 0, k0 + j + 1);
-        }
-        const double inv = 1.0 / ljj;
-        double li[4], lc[4];
-#pragma unroll
-        for (int a = 0; a < 4; ++a) li[a] = cb[ty + 32 * a] * inv;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) lc[b] = cb[tx + 32 * b] * inv;
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const int i = ty + 32 * a, c = tx + 32 * b;
-                if (c > j && c <= i) acc[a][b] -= li[a] * lc[b];
-                if (c == j) acc[a][b] = (i > j) ? li[a] : ((i == j) ? ljj : acc[a][b]);
-            }
-    }
+    chol_diag_steps<0>(acc, colbuf, tx, ty, k0, n_real, flag);
+    chol_diag_steps<1>(acc, colbuf, tx, ty, k0, n_real, flag);
+    chol_diag_steps<2>(acc, colbuf, tx, ty, k0, n_real, flag);
+    chol_diag_steps<3>(acc, colbuf, tx, ty, k0, n_real, flag);
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -111,59 +133,57 @@ __global__ __launch_bounds__(1024) void chol_diag_kernel(double* __restrict__ A,
 }
 
 // ------------------------------------------------------------------------------------------
-// X = A21 * L11^-T for 128 rows per workgroup (rows r0 + 128*blockIdx.x ...), in place.
-__global__ __launch_bounds__(1024) void chol_trsm_kernel(double* __restrict__ A, int lda, int k0) {
+// X = A21 * L11^-T for TRSM_ROWS rows per workgroup, in place.  256 threads: thread (r, cg) owns
+// row r = t >> 3 and columns cg + 8m (m < 16).  Column groups M = j >> 3 are unrolled so that
+// the owner's register index is static.
+template <int M>
+__device__ __forceinline__ void chol_trsm_steps(double (&acc)[16], const double* __restrict__ Ld,
+                                                const double* __restrict__ invd, double (*xbuf)[TRSM_ROWS],
+                                                int r, int cg) {
+#pragma unroll 1
+    for (int jj = 0; jj < 8; ++jj) {
+        const int j = 8 * M + jj;
+        double* xb = xbuf[j & 1];
+        if (cg == jj) {
+            const double x = acc[M] * invd[j];
+            acc[M] = x;
+            xb[r] = x;
+        }
+        __syncthreads();
+        const double xi = xb[r];
+        const double* lcol = Ld + j;   // L[c][j] at Ld[c*(NB+1) + j]
+        if (cg > jj) acc[M] -= xi * lcol[(cg + 8 * M) * (NB + 1)];
+#pragma unroll
+        for (int m = M + 1; m < 16; ++m) acc[m] -= xi * lcol[(cg + 8 * m) * (NB + 1)];
+    }
+}
+
+__global__ __launch_bounds__(256) void chol_trsm_kernel(double* __restrict__ A, int lda, int k0) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    double* Ld = smem;                      // [128][129]
-    double* colbuf = smem + NB * (NB + 1);  // [2][128]
-    const int t = threadIdx.x, tx = t & 31, ty = t >> 5;
-    const int r0 = k0 + NB + blockIdx.x * NB;
-    for (int idx = t; idx < NB * NB; idx += 1024) {
+    double* Ld = smem;                          // [128][129]
+    double* invd = smem + NB * (NB + 1);        // [128]
+    double(*xbuf)[TRSM_ROWS] = reinterpret_cast<double(*)[TRSM_ROWS]>(invd + NB);   // [2][32]
+    const int t = threadIdx.x, r = t >> 3, cg = t & 7;
+    const int row = k0 + NB + blockIdx.x * TRSM_ROWS + r;
+    for (int idx = t; idx < NB * NB; idx += 256) {
         const int i = idx >> 7, c = idx & 127;
         Ld[i * (NB + 1) + c] = (c <= i) ? A[(size_t)(k0 + i) * lda + k0 + c] : 0.0;
     }
-    double acc[4][4];
+    if (t < NB) invd[t] = 1.0 / A[(size_t)(k0 + t) * lda + k0 + t];
+    double acc[16];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-            acc[a][b] = A[(size_t)(r0 + ty + 32 * a) * lda + k0 + tx + 32 * b];
+    for (int m = 0; m < 16; ++m) acc[m] = A[(size_t)row * lda + k0 + cg + 8 * m];
     __syncthreads();
-    for (int j = 0; j < NB; ++j) {
-        const int bj = j >> 5, txj = j & 31;
-        double* cb = colbuf + (j & 1) * NB;
-        if (tx == txj) {
-            const double inv = 1.0 / Ld[j * (NB + 1) + j];
+    chol_trsm_steps<0>(acc, Ld, invd, xbuf, r, cg);   chol_trsm_steps<1>(acc, Ld, invd, xbuf, r, cg);
+    chol_trsm_steps<2>(acc, Ld, invd, xbuf, r, cg);   chol_trsm_steps<3>(acc, Ld, invd, xbuf, r, cg);
+    chol_trsm_steps<4>(acc, Ld, invd, xbuf, r, cg);   chol_trsm_steps<5>(acc, Ld, invd, xbuf, r, cg);
+    chol_trsm_steps<6>(acc, Ld, invd, xbuf, r, cg);   chol_trsm_steps<7>(acc, Ld, invd, xbuf, r, cg);
+    chol_trsm_steps<8>(acc, Ld, invd, xbuf, r, cg);   chol_trsm_steps<9>(acc, Ld, invd, xbuf, r, cg);
+    chol_trsm_steps<10>(acc, Ld, invd, xbuf, r, cg);  chol_trsm_steps<11>(acc, Ld, invd, xbuf, r, cg);
+    chol_trsm_steps<12>(acc, Ld, invd, xbuf, r, cg);  chol_trsm_steps<13>(acc, Ld, invd, xbuf, r, cg);
+    chol_trsm_steps<14>(acc, Ld, invd, xbuf, r, cg);  chol_trsm_steps<15>(acc, Ld, invd, xbuf, r, cg);
 #pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                double v = acc[a][0];
-#pragma unroll
-                for (int b = 1; b < 4; ++b) v = (b == bj) ? acc[a][b] : v;
-                v *= inv;
-                cb[ty + 32 * a] = v;
-#pragma unroll
-                for (int b = 0; b < 4; ++b) acc[a][b] = (b == bj) ? v : acc[a][b];
-            }
-        }
-        __syncthreads();
-        double xi[4];
-#pragma unroll
-        for (int a = 0; a < 4; ++a) xi[a] = cb[ty + 32 * a];
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int c = tx + 32 * b;
-            if (c > j) {
-                const double l = Ld[c * (NB + 1) + j];
-#pragma unroll
-                for (int a = 0; a < 4; ++a) acc[a][b] -= xi[a] * l;
-            }
-        }
-    }
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-            A[(size_t)(r0 + ty + 32 * a) * lda + k0 + tx + 32 * b] = acc[a][b];
+    for (int m = 0; m < 16; ++m) A[(size_t)row * lda + k0 + cg + 8 * m] = acc[m];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -254,28 +274,39 @@ __global__ __launch_bounds__(256) void chol_syrk_kernel(double* __restrict__ A, 
 }
 
 // ------------------------------------------------------------------------------------------
-// backward substitution, block b: x_b = L_bb^-T y_b   (y lives in row lda-1)
+// backward substitution, block b: x_b = L_bb^-T y_b   (y lives in row lda-1).
+// The block is staged in LDS by all 1024 threads, then ONE wave runs the 128 dependent steps with
+// a shuffle broadcast per step (no barriers): lane l owns unknowns l and l + 64.
 __global__ __launch_bounds__(1024) void chol_bwd_diag_kernel(double* __restrict__ A, int lda, int k0,
                                                              double* __restrict__ x) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* Ld = smem;                 // [128][129]
-    double* xs = smem + NB * (NB + 1); // [128]
     const int t = threadIdx.x;
     const int nv = min(NB, (lda - 1) - k0);   // rows of this block that belong to the system
     for (int idx = t; idx < NB * NB; idx += 1024) {
         const int i = idx >> 7, c = idx & 127;
-        Ld[i * (NB + 1) + c] = (c <= i && i < nv) ? A[(size_t)(k0 + i) * lda + k0 + c] : 0.0;
-    }
-    double y = 0.0;
-    if (t < nv) y = A[(size_t)(lda - 1) * lda + k0 + t];
-    __syncthreads();
-    for (int j = nv - 1; j >= 0; --j) {
-        if (t == j) xs[j] = y / Ld[j * (NB + 1) + j];
-        __syncthreads();
-        if (t < j) y -= Ld[j * (NB + 1) + t] * xs[j];
+        Ld[i * (NB + 1) + c] = (c <= i && i < nv) ? A[(size_t)(k0 + i) * lda + k0 + c] : ((c == i) ? 1.0 : 0.0);
     }
     __syncthreads();
-    if (t < NB) x[k0 + t] = (t < nv) ? xs[t] : 0.0;
+    if (t >= 64) return;
+    const int l = t;
+    double y0 = (l < nv) ? A[(size_t)(lda - 1) * lda + k0 + l] : 0.0;
+    double y1 = (l + 64 < nv) ? A[(size_t)(lda - 1) * lda + k0 + l + 64] : 0.0;
+    const double id0 = 1.0 / Ld[l * (NB + 1) + l], id1 = 1.0 / Ld[(l + 64) * (NB + 1) + l + 64];
+    for (int j = NB - 1; j >= 64; --j) {
+        const double xj = __shfl(y1 * id1, j - 64, 64);
+        const double* rowj = Ld + j * (NB + 1);
+        if (l + 64 == j) y1 = xj;
+        else if (l + 64 < j) y1 -= rowj[l + 64] * xj;
+        y0 -= rowj[l] * xj;
+    }
+    for (int j = 63; j >= 0; --j) {
+        const double xj = __shfl(y0 * id0, j, 64);
+        if (l == j) y0 = xj;
+        else if (l < j) y0 -= Ld[j * (NB + 1) + l] * xj;
+    }
+    x[k0 + l] = (l < nv) ? y0 : 0.0;
+    x[k0 + l + 64] = (l + 64 < nv) ? y1 : 0.0;
 }
 
 // y[0:k0] -= L[k0:k0+nv, 0:k0]^T x_b
@@ -294,60 +325,12 @@ __global__ __launch_bounds__(256) void chol_bwd_update_kernel(double* __restrict
     A[(size_t)(lda - 1) * lda + c] -= s;
 }
 
-// same as chol_factor_solve_dev with hipEvent pairs around every kernel class (profiling only)
-int chol_factor_solve_profiled(double* A, int lda, int n, double* x_dev, int* flag_dev, hipStream_t st,
-                               CholProfile* prof) {
-    if (lda % NB != 0 || lda < n + 1) return fail(STBA_ERR_INVALID_ARGUMENT, "chol: bad padded dimension");
-    // precondition: chol_factor_solve_dev ran once before (it sets the dynamic-LDS attributes)
-    STBA_HIP(hipMemsetAsync(flag_dev, 0, sizeof(int), st));
-    const int nblk = lda / NB;
-    const size_t trsm_lds = sizeof(double) * (NB * (NB + 1) + 2 * NB);
-    const size_t bwd_lds = sizeof(double) * (NB * (NB + 1) + NB);
-    std::vector<hipEvent_t> ev((size_t)nblk * 4 + 2);
-    for (auto& e : ev) STBA_HIP(hipEventCreate(&e));
-    memset(prof, 0, sizeof *prof);
-    for (int b = 0; b < nblk; ++b) {
-        const int k0 = b * NB;
-        const int mt = nblk - b - 1;
-        STBA_HIP(hipEventRecord(ev[4 * b + 0], st));
-        hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(1024), 0, st, A, lda, k0, n, flag_dev);
-        STBA_HIP(hipEventRecord(ev[4 * b + 1], st));
-        if (mt > 0) hipLaunchKernelGGL(chol_trsm_kernel, dim3(mt), dim3(1024), trsm_lds, st, A, lda, k0);
-        STBA_HIP(hipEventRecord(ev[4 * b + 2], st));
-        if (mt > 0) hipLaunchKernelGGL(chol_syrk_kernel, dim3(mt * (mt + 1) / 2), dim3(256), 0, st, A, lda, k0);
-        STBA_HIP(hipEventRecord(ev[4 * b + 3], st));
-        if (mt > 0) {
-            const double m = std::max(0, n - (k0 + NB));
-            prof->syrk_flops += m * (m + 1.0) * NB;
-            prof->syrk_flops_padded += (double)(mt * (mt + 1) / 2) * 2.0 * NB * NB * NB;
-            prof->syrk_launches += 1;
-        }
-    }
-    STBA_HIP(hipEventRecord(ev[(size_t)nblk * 4], st));
-    for (int b = nblk - 1; b >= 0; --b) {
-        const int k0 = b * NB;
-        hipLaunchKernelGGL(chol_bwd_diag_kernel, dim3(1), dim3(1024), bwd_lds, st, A, lda, k0, x_dev);
-        if (k0 > 0)
-            hipLaunchKernelGGL(chol_bwd_update_kernel, dim3((k0 + 255) / 256), dim3(256), 0, st, A, lda, k0, x_dev);
-    }
-    STBA_HIP(hipEventRecord(ev[(size_t)nblk * 4 + 1], st));
-    STBA_HIP(hipStreamSynchronize(st));
-    float ms = 0.f;
-    for (int b = 0; b < nblk; ++b) {
-        (void)hipEventElapsedTime(&ms, ev[4 * b + 0], ev[4 * b + 1]); prof->ms_diag += ms;
-        (void)hipEventElapsedTime(&ms, ev[4 * b + 1], ev[4 * b + 2]); prof->ms_trsm += ms;
-        (void)hipEventElapsedTime(&ms, ev[4 * b + 2], ev[4 * b + 3]); prof->ms_syrk += ms;
-    }
-    (void)hipEventElapsedTime(&ms, ev[(size_t)nblk * 4], ev[(size_t)nblk * 4 + 1]); prof->ms_bwd = ms;
-    for (auto& e : ev) (void)hipEventDestroy(e);
-    return STBA_OK;
-}
-
-int chol_factor_solve_dev(double* A, int lda, int n, double* x_dev, int* flag_dev, hipStream_t st) {
+// ------------------------------------------------------------------------------------------
+static int chol_run(double* A, int lda, int n, double* x_dev, int* flag_dev, hipStream_t st, CholProfile* prof) {
     if (lda % NB != 0 || lda < n + 1) return fail(STBA_ERR_INVALID_ARGUMENT, "chol: bad padded dimension");
     const int nblk = lda / NB;
-    const size_t trsm_lds = sizeof(double) * (NB * (NB + 1) + 2 * NB);
-    const size_t bwd_lds = sizeof(double) * (NB * (NB + 1) + NB);
+    const size_t trsm_lds = sizeof(double) * (NB * (NB + 1) + NB + 2 * TRSM_ROWS);
+    const size_t bwd_lds = sizeof(double) * (NB * (NB + 1));
     static bool attr_set = false;
     if (!attr_set) {
         STBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(chol_trsm_kernel),
@@ -356,24 +339,62 @@ int chol_factor_solve_dev(double* A, int lda, int n, double* x_dev, int* flag_de
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_lds));
         attr_set = true;
     }
+    std::vector<hipEvent_t> ev;
+    if (prof) {
+        ev.resize((size_t)nblk * 4 + 2);
+        for (auto& e : ev) STBA_HIP(hipEventCreate(&e));
+        memset(prof, 0, sizeof *prof);
+    }
+    auto mark = [&](size_t k) -> int { if (prof) STBA_HIP(hipEventRecord(ev[k], st)); return STBA_OK; };
     STBA_HIP(hipMemsetAsync(flag_dev, 0, sizeof(int), st));
     for (int b = 0; b < nblk; ++b) {
         const int k0 = b * NB;
-        hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(1024), 0, st, A, lda, k0, n, flag_dev);
         const int mt = nblk - b - 1;
-        if (mt > 0) {
-            hipLaunchKernelGGL(chol_trsm_kernel, dim3(mt), dim3(1024), trsm_lds, st, A, lda, k0);
-            hipLaunchKernelGGL(chol_syrk_kernel, dim3(mt * (mt + 1) / 2), dim3(256), 0, st, A, lda, k0);
+        STBA_TRY(mark(4 * (size_t)b + 0));
+        hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(1024), 0, st, A, lda, k0, n, flag_dev);
+        STBA_TRY(mark(4 * (size_t)b + 1));
+        if (mt > 0)
+            hipLaunchKernelGGL(chol_trsm_kernel, dim3(mt * (NB / TRSM_ROWS)), dim3(256), trsm_lds, st, A, lda, k0);
+        STBA_TRY(mark(4 * (size_t)b + 2));
+        if (mt > 0) hipLaunchKernelGGL(chol_syrk_kernel, dim3(mt * (mt + 1) / 2), dim3(256), 0, st, A, lda, k0);
+        STBA_TRY(mark(4 * (size_t)b + 3));
+        if (prof && mt > 0) {
+            const double m = std::max(0, n - (k0 + NB));
+            prof->syrk_flops += m * (m + 1.0) * NB;
+            prof->syrk_flops_padded += (double)(mt * (mt + 1) / 2) * 2.0 * NB * NB * NB;
+            prof->syrk_launches += 1;
         }
     }
+    STBA_TRY(mark((size_t)nblk * 4));
     for (int b = nblk - 1; b >= 0; --b) {
         const int k0 = b * NB;
         hipLaunchKernelGGL(chol_bwd_diag_kernel, dim3(1), dim3(1024), bwd_lds, st, A, lda, k0, x_dev);
         if (k0 > 0)
             hipLaunchKernelGGL(chol_bwd_update_kernel, dim3((k0 + 255) / 256), dim3(256), 0, st, A, lda, k0, x_dev);
     }
+    STBA_TRY(mark((size_t)nblk * 4 + 1));
     STBA_HIP(hipGetLastError());
+    if (prof) {
+        STBA_HIP(hipStreamSynchronize(st));
+        float ms = 0.f;
+        for (int b = 0; b < nblk; ++b) {
+            (void)hipEventElapsedTime(&ms, ev[4 * (size_t)b + 0], ev[4 * (size_t)b + 1]); prof->ms_diag += ms;
+            (void)hipEventElapsedTime(&ms, ev[4 * (size_t)b + 1], ev[4 * (size_t)b + 2]); prof->ms_trsm += ms;
+            (void)hipEventElapsedTime(&ms, ev[4 * (size_t)b + 2], ev[4 * (size_t)b + 3]); prof->ms_syrk += ms;
+        }
+        (void)hipEventElapsedTime(&ms, ev[(size_t)nblk * 4], ev[(size_t)nblk * 4 + 1]); prof->ms_bwd = ms;
+        for (auto& e : ev) (void)hipEventDestroy(e);
+    }
     return STBA_OK;
+}
+
+int chol_factor_solve_dev(double* A, int lda, int n, double* x_dev, int* flag_dev, hipStream_t st) {
+    return chol_run(A, lda, n, x_dev, flag_dev, st, nullptr);
+}
+
+int chol_factor_solve_profiled(double* A, int lda, int n, double* x_dev, int* flag_dev, hipStream_t st,
+                               CholProfile* prof) {
+    return chol_run(A, lda, n, x_dev, flag_dev, st, prof);
 }
 
 }  // namespace stba

@@ -73,6 +73,10 @@ struct stba_ba {
     int *obs_cam = nullptr, *obs_pt = nullptr, *pt_start = nullptr;
     int *cam_perm = nullptr, *chunk_begin = nullptr, *chunk_end = nullptr, *cam_chunk_start = nullptr;
     int n_chunks = 0;
+    // row-wise Schur plan (empty => global-atomic fallback kernel)
+    int *task_cam = nullptr, *task_begin = nullptr, *task_end = nullptr, *row_col_ptr = nullptr, *row_cols = nullptr;
+    unsigned char* task_single = nullptr;
+    int n_tasks = 0, max_cols = 0;
     unsigned char *cam_fixed = nullptr, *pt_fixed = nullptr;
     double2* r = nullptr;
     double *Jc = nullptr, *Jp = nullptr;
@@ -107,6 +111,7 @@ static void ba_free(stba_ba* b) {
     F(b->pt_start); F(b->cam_perm); F(b->chunk_begin); F(b->chunk_end); F(b->cam_chunk_start); F(b->cam_fixed);
     F(b->pt_fixed); F(b->r); F(b->Jc); F(b->Jp); F(b->Hpp6); F(b->gp); F(b->Hinv6); F(b->dp); F(b->scale_p);
     F(b->Hcc); F(b->gc); F(b->cam_partial); F(b->dc); F(b->scale_c); F(b->Sbuf); F(b->dxc); F(b->dxp);
+    F(b->task_cam); F(b->task_begin); F(b->task_end); F(b->row_col_ptr); F(b->row_cols); F(b->task_single);
     F(b->cost_partial); F(b->upd_partial_c); F(b->upd_partial_p); F(b->trial); F(b->flag);
     for (auto& e : b->ev) if (e) (void)hipEventDestroy(e);
     if (b->own_stream && b->st) (void)hipStreamDestroy(b->st);
@@ -157,8 +162,18 @@ static int ba_build_reduced(stba_ba* b, const Damping& dm) {
     STBA_TRY(launch_point_invert(b->np, b->Hpp6, b->dp, b->pt_fixed, b->Hinv6, b->st));
     const size_t zero_count = (size_t)b->lda * b->lda + 3 * (size_t)b->lda;   // scalar slots are kept
     STBA_HIP(hipMemsetAsync(b->Sbuf, 0, zero_count * sizeof(double), b->st));
-    STBA_TRY(launch_schur(b->no, b->obs_cam, b->obs_pt, b->pt_start, b->Jc, b->Jp, b->Hinv6, b->gp, b->S(), b->lda,
-                          b->rhs(), b->st));
+    if (b->n_tasks > 0) {
+        SchurRowArgs sa;
+        sa.task_cam = b->task_cam; sa.task_begin = b->task_begin; sa.task_end = b->task_end;
+        sa.task_single = b->task_single; sa.row_col_ptr = b->row_col_ptr; sa.row_cols = b->row_cols;
+        sa.max_cols = b->max_cols; sa.cam_perm = b->cam_perm; sa.obs_cam = b->obs_cam; sa.obs_pt = b->obs_pt;
+        sa.pt_start = b->pt_start; sa.Jc = b->Jc; sa.Jp = b->Jp; sa.Hinv6 = b->Hinv6; sa.gp = b->gp;
+        sa.S = b->S(); sa.lda = b->lda; sa.rhs = b->rhs();
+        STBA_TRY(launch_schur_rows(sa, b->n_tasks, b->st));
+    } else {
+        STBA_TRY(launch_schur(b->no, b->obs_cam, b->obs_pt, b->pt_start, b->Jc, b->Jp, b->Hinv6, b->gp, b->S(),
+                              b->lda, b->rhs(), b->st));
+    }
     STBA_TRY(launch_reduced_add_camera(b->nc, b->Hcc, b->gc, b->S(), b->lda, b->rhs(), b->ex_diag(), b->ex_gc(),
                                        b->st));
     if (b->ar) {
@@ -512,6 +527,48 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
     }
     cam_chunk_start[n_cams] = (int)chunk_begin.size();
     b->n_chunks = (int)chunk_begin.size();
+    // ---- row-wise Schur plan: distinct partner cameras c2 <= c of every camera row + tasks
+    std::vector<int> row_col_ptr(n_cams + 1, 0), row_cols, task_cam, task_begin, task_end;
+    std::vector<unsigned char> task_single;
+    int max_cols = 0;
+    {
+        std::vector<int> stamp(n_cams, -1), tmp;
+        for (int c = 0; c < n_cams; ++c) {
+            tmp.clear();
+            for (int p = cam_start[c]; p < cam_start[c + 1]; ++p) {
+                const int j = s_pt[cam_perm[p]];
+                for (int l = pt_start[j]; l < pt_start[j + 1]; ++l) {
+                    const int c2 = s_cam[l];
+                    if (c2 <= c && stamp[c2] != c) { stamp[c2] = c; tmp.push_back(c2); }
+                }
+            }
+            std::sort(tmp.begin(), tmp.end());
+            row_cols.insert(row_cols.end(), tmp.begin(), tmp.end());
+            row_col_ptr[c + 1] = (int)row_cols.size();
+            max_cols = std::max(max_cols, (int)tmp.size());
+            const int nobs_c = cam_start[c + 1] - cam_start[c];
+            const int nt = (nobs_c + SCHUR_TASK_OBS - 1) / SCHUR_TASK_OBS;
+            for (int k = 0; k < nt; ++k) {
+                task_cam.push_back(c);
+                task_begin.push_back(cam_start[c] + k * SCHUR_TASK_OBS);
+                task_end.push_back(std::min(cam_start[c] + (k + 1) * SCHUR_TASK_OBS, cam_start[c + 1]));
+                task_single.push_back(nt == 1 ? 1 : 0);
+            }
+        }
+        // heaviest rows first (more partners, more observations) for a better tail
+        std::vector<int> order(task_cam.size());
+        for (size_t k = 0; k < order.size(); ++k) order[k] = (int)k;
+        std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
+            const long wx = (long)(task_end[x] - task_begin[x]) * (row_col_ptr[task_cam[x] + 1] - row_col_ptr[task_cam[x]]);
+            const long wy = (long)(task_end[y] - task_begin[y]) * (row_col_ptr[task_cam[y] + 1] - row_col_ptr[task_cam[y]]);
+            return wx > wy;
+        });
+        auto permute = [&](auto& v) { auto t = v; for (size_t k = 0; k < order.size(); ++k) v[k] = t[order[k]]; };
+        permute(task_cam); permute(task_begin); permute(task_end); permute(task_single);
+    }
+    const bool row_plan = max_cols <= SCHUR_MAX_COLS;
+    b->n_tasks = row_plan ? (int)task_cam.size() : 0;
+    b->max_cols = max_cols;
     std::vector<unsigned char> cmask;
     if (cam_fixed) {
         cmask.resize(n_cams);
@@ -533,6 +590,11 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
     A_(dev_alloc(&b->pt_start, np + 1)); A_(dev_alloc(&b->cam_perm, no));
     A_(dev_alloc(&b->chunk_begin, (size_t)b->n_chunks)); A_(dev_alloc(&b->chunk_end, (size_t)b->n_chunks));
     A_(dev_alloc(&b->cam_chunk_start, nc + 1));
+    if (b->n_tasks > 0) {
+        A_(dev_alloc(&b->task_cam, task_cam.size())); A_(dev_alloc(&b->task_begin, task_cam.size()));
+        A_(dev_alloc(&b->task_end, task_cam.size())); A_(dev_alloc(&b->task_single, task_cam.size()));
+        A_(dev_alloc(&b->row_col_ptr, nc + 1)); A_(dev_alloc(&b->row_cols, row_cols.size()));
+    }
     if (cam_fixed) A_(dev_alloc(&b->cam_fixed, nc));
     if (pt_fixed) A_(dev_alloc(&b->pt_fixed, np));
     A_(dev_alloc(&b->r, no)); A_(dev_alloc(&b->Jc, no * 12)); A_(dev_alloc(&b->Jp, no * 6));
@@ -554,6 +616,14 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
     A_(upload(b->chunk_begin, chunk_begin.data(), (size_t)b->n_chunks, b->st));
     A_(upload(b->chunk_end, chunk_end.data(), (size_t)b->n_chunks, b->st));
     A_(upload(b->cam_chunk_start, cam_chunk_start.data(), nc + 1, b->st));
+    if (b->n_tasks > 0) {
+        A_(upload(b->task_cam, task_cam.data(), task_cam.size(), b->st));
+        A_(upload(b->task_begin, task_begin.data(), task_cam.size(), b->st));
+        A_(upload(b->task_end, task_end.data(), task_cam.size(), b->st));
+        A_(upload(b->task_single, task_single.data(), task_cam.size(), b->st));
+        A_(upload(b->row_col_ptr, row_col_ptr.data(), nc + 1, b->st));
+        A_(upload(b->row_cols, row_cols.data(), row_cols.size(), b->st));
+    }
     if (cam_fixed) A_(upload(b->cam_fixed, cmask.data(), nc, b->st));
     if (pt_fixed) A_(upload(b->pt_fixed, pt_fixed, np, b->st));
     if (hipMemsetAsync(b->dxc, 0, (size_t)b->lda * sizeof(double), b->st) != hipSuccess ||

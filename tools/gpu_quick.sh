@@ -1,0 +1,12 @@
+export TMPDIR=/tmp
+timeout 600 python -m pytest tests -m gpu -x -q 2>&1 | tail -5
+timeout 900 python bench.py --steps 10 --warmup 2 --no-cpu-baseline > gpurun_out/bench_tmp.json 2> gpurun_out/bench_tmp.err
+python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/bench_tmp.json').read().strip().splitlines()[-1])
+print('it/s', round(d['value'],2), 'ms/step', round(d['ms_per_step'],3))
+print('phase', {k:round(v,3) for k,v in d['phase_ms_per_step'].items()})
+print('chol', {k:round(v,3) for k,v in d['cholesky_ms'].items()})
+print('jac GB/s', round(d['roofline_jacobian']['achieved'],1), 'syrk TF', round(d['roofline_mfma']['achieved'],2))
+PY
+tail -3 gpurun_out/bench_tmp.err
