@@ -57,51 +57,118 @@ int chol_prepare_padding_dev(double* A_dev, int lda, int n, const double* rhs_de
 }
 
 // ------------------------------------------------------------------------------------------
-// diagonal block.  Thread (ty, tx) owns rows ty + 32a, columns tx + 32b (a, b < 4).  Columns are
-// processed in four groups A0 = j >> 5 so that every register index is a compile-time constant
-// and whole sub-blocks outside the active trailing part are skipped.
+// fast reciprocal square root: v_rsq_f64 + two Newton steps (FMA only, ~1 ulp), and sqrt from it.
+__device__ __forceinline__ double fast_rsqrt(double d) {
+    double y = __builtin_amdgcn_rsq(d);
+    double t = d * y;
+    y = fma(0.5 * y, fma(-t, y, 1.0), y);
+    t = d * y;
+    y = fma(0.5 * y, fma(-t, y, 1.0), y);
+    return y;
+}
+__device__ __forceinline__ double sqrt_from_rsqrt(double d, double y) {
+    double g = d * y;
+    return fma(fma(-g, g, d), 0.5 * y, g);
+}
+
+// ------------------------------------------------------------------------------------------
+// diagonal block, column blocks of width 4 (32 block steps instead of 128 column steps).
+// Thread (ty, tx) owns rows ty + 32a, columns tx + 32b (a, b < 4) in registers.  Per block step:
+//   owners publish the 4 panel columns to LDS -> barrier -> 128 threads (one per row) factor the
+//   4x4 diagonal mini-block redundantly (division-free rsqrt chain) and scale their panel row by
+//   its inverse transpose -> barrier -> everybody applies the rank-4 update to its sub-blocks.
 template <int A0>
-__device__ __forceinline__ void chol_diag_steps(double (&acc)[4][4], double (*colbuf)[NB], int tx, int ty,
-                                                int k0, int n_real, int* flag) {
-    for (int jj = 0; jj < 32; ++jj) {
-        const int j = 32 * A0 + jj;
-        double* cb = colbuf[j & 1];
-        if (tx == jj) {
+__device__ __forceinline__ void chol_diag_blocksteps(double (&acc)[4][4], double (*P)[5], double (*Lp)[5], int t,
+                                                     int tx, int ty, int k0, int n_real, int* flag) {
+#pragma unroll 1
+    for (int jb = 0; jb < 8; ++jb) {
+        const int o = 4 * jb;                 // column offset of the block inside sub-block column A0
+        const int j0 = 32 * A0 + o;           // first column of the block
+        const bool owner = (tx >= o) && (tx < o + 4);
+        if (owner) {
 #pragma unroll
-            for (int a = A0; a < 4; ++a) cb[ty + 32 * a] = acc[a][A0];
+            for (int a = A0; a < 4; ++a) P[ty + 32 * a][tx - o] = acc[a][A0];
         }
         __syncthreads();
-        const double d = cb[j];
-        double ljj, inv;
-        if (d > 0.0) {
-            // division-free pivot: l = d * rsqrt(d) plus one FMA Newton correction (~1 ulp); the
-            // column is scaled by rsqrt(d) itself, keeping the dependent chain short
-            inv = rsqrt(d);
-            ljj = d * inv;
-            ljj = fma(fma(-ljj, ljj, d), 0.5 * inv, ljj);
-        } else {
-            ljj = 1.0; inv = 1.0;
-            if (threadIdx.x == 0 && (k0 + j) < n_real) atomicCAS(flag, 0, k0 + j + 1);
+        if (t < NB && t >= j0) {
+            const int i = t;
+            double D[4][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c <= r; ++c) D[r][c] = P[j0 + r][c];
+            double p[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) p[c] = P[i][c];
+            // 4x4 Cholesky G (lower), right-looking so that the dependent chain per pivot is
+            // rsq -> 2 Newton steps -> scale -> one FMA into the next pivot
+            double G[4][4], y[4];
+            bool bad = false;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                double d = D[c][c];
+                if (!(d > 0.0)) { bad = bad || ((k0 + j0 + c) < n_real); d = 1.0; }
+                y[c] = fast_rsqrt(d);
+                G[c][c] = sqrt_from_rsqrt(d, y[c]);
+#pragma unroll
+                for (int r = c + 1; r < 4; ++r) G[r][c] = D[r][c] * y[c];
+#pragma unroll
+                for (int r = c + 1; r < 4; ++r)
+#pragma unroll
+                    for (int q = c + 1; q <= r; ++q) D[r][q] = fma(-G[r][c], G[q][c], D[r][q]);
+            }
+            if (bad && i == j0) atomicCAS(flag, 0, k0 + j0 + 1);
+            double l[4];
+            if (i >= j0 + 4) {
+                // row of L: solve l G^T = p, right-looking
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    l[c] = p[c] * y[c];
+#pragma unroll
+                    for (int q = c + 1; q < 4; ++q) p[q] = fma(-l[c], G[q][c], p[q]);
+                }
+            } else {
+                const int r = i - j0;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    double v = 0.0;
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) v = (rr == r && c <= rr) ? G[rr][c] : v;
+                    l[c] = v;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) Lp[i][c] = l[c];
         }
-        double li[4], lc[4];
+        __syncthreads();
+        double li[4][4], lc[4][4];
 #pragma unroll
-        for (int a = A0; a < 4; ++a) li[a] = cb[ty + 32 * a] * inv;
+        for (int a = A0; a < 4; ++a)
 #pragma unroll
-        for (int b = A0; b < 4; ++b) lc[b] = cb[tx + 32 * b] * inv;
+            for (int k = 0; k < 4; ++k) li[a][k] = Lp[ty + 32 * a][k];
+#pragma unroll
+        for (int b = A0; b < 4; ++b)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) lc[b][k] = Lp[tx + 32 * b][k];
 #pragma unroll
         for (int a = A0; a < 4; ++a)
 #pragma unroll
             for (int b = A0; b <= a; ++b) {
                 bool on = true;
-                if (b == A0) on = on && (tx > jj);     // column strictly right of j
-                if (b == a) on = on && (tx <= ty);     // lower triangle of a diagonal sub-block
-                if (on) acc[a][b] -= li[a] * lc[b];
+                if (b == A0) on = on && (tx >= o + 4);   // columns right of the block
+                if (b == a) on = on && (tx <= ty);       // lower triangle of a diagonal sub-block
+                if (on) {
+                    double v = acc[a][b];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v = fma(-li[a][k], lc[b][k], v);
+                    acc[a][b] = v;
+                }
             }
-        if (tx == jj) {
+        if (owner) {
 #pragma unroll
             for (int a = A0; a < 4; ++a) {
-                const int i = ty + 32 * a;
-                acc[a][A0] = (i > j) ? li[a] : ((i == j) ? ljj : acc[a][A0]);
+                const int i = ty + 32 * a, c = tx + 32 * A0;
+                if (i >= c) acc[a][A0] = Lp[i][tx - o];
             }
         }
     }
@@ -109,7 +176,8 @@ __device__ __forceinline__ void chol_diag_steps(double (&acc)[4][4], double (*co
 
 __global__ __launch_bounds__(1024) void chol_diag_kernel(double* __restrict__ A, int lda, int k0,
                                                          int n_real, int* __restrict__ flag) {
-    __shared__ double colbuf[2][NB];
+    __shared__ double P[NB][5];
+    __shared__ double Lp[NB][5];
     const int t = threadIdx.x, tx = t & 31, ty = t >> 5;
     double acc[4][4];
 #pragma unroll
@@ -119,10 +187,10 @@ __global__ __launch_bounds__(1024) void chol_diag_kernel(double* __restrict__ A,
             const int i = ty + 32 * a, c = tx + 32 * b;
             acc[a][b] = (c <= i) ? A[(size_t)(k0 + i) * lda + k0 + c] : 0.0;
         }
-    chol_diag_steps<0>(acc, colbuf, tx, ty, k0, n_real, flag);
-    chol_diag_steps<1>(acc, colbuf, tx, ty, k0, n_real, flag);
-    chol_diag_steps<2>(acc, colbuf, tx, ty, k0, n_real, flag);
-    chol_diag_steps<3>(acc, colbuf, tx, ty, k0, n_real, flag);
+    chol_diag_blocksteps<0>(acc, P, Lp, t, tx, ty, k0, n_real, flag);
+    chol_diag_blocksteps<1>(acc, P, Lp, t, tx, ty, k0, n_real, flag);
+    chol_diag_blocksteps<2>(acc, P, Lp, t, tx, ty, k0, n_real, flag);
+    chol_diag_blocksteps<3>(acc, P, Lp, t, tx, ty, k0, n_real, flag);
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -133,55 +201,103 @@ __global__ __launch_bounds__(1024) void chol_diag_kernel(double* __restrict__ A,
 }
 
 // ------------------------------------------------------------------------------------------
-// X = A21 * L11^-T for TRSM_ROWS rows per workgroup, in place.  256 threads: thread (r, cg) owns
-// row r = t >> 3 and columns cg + 8m (m < 16).  Column groups M = j >> 3 are unrolled so that
-// the owner's register index is static.
-template <int M>
-__device__ __forceinline__ void chol_trsm_steps(double (&acc)[16], const double* __restrict__ Ld,
-                                                const double* __restrict__ invd, double (*xbuf)[TRSM_ROWS],
-                                                int r, int cg) {
-#pragma unroll 1
-    for (int jj = 0; jj < 8; ++jj) {
-        const int j = 8 * M + jj;
-        double* xb = xbuf[j & 1];
-        if (cg == jj) {
-            const double x = acc[M] * invd[j];
-            acc[M] = x;
-            xb[r] = x;
-        }
-        __syncthreads();
-        const double xi = xb[r];
-        const double* lcol = Ld + j;   // L[c][j] at Ld[c*(NB+1) + j]
-        if (cg > jj) acc[M] -= xi * lcol[(cg + 8 * M) * (NB + 1)];
+// shared by the panel solve and the backward substitution: stage the 128x128 lower block in LDS
+// (row stride LDS_LD, 16 B aligned rows) and invert its sixteen 8x8 diagonal blocks:
+// Gi[J][k][m] = (L_JJ^-1)[k][m].  Called by all threads of the workgroup; ends with a barrier.
+constexpr int LDS_LD = 130;
+template <int NT>
+__device__ __forceinline__ void stage_block_and_inverses(const double* __restrict__ A, int lda, int k0, int nv,
+                                                         double* __restrict__ Ld, double* __restrict__ invd,
+                                                         double* __restrict__ Gi, int t) {
+    // one 1 KiB row per wave instruction (16 B per lane), all loads of a thread issued back to back
+    constexpr int ITER = NB * (NB / 2) / NT;
+    double2 v[ITER];
 #pragma unroll
-        for (int m = M + 1; m < 16; ++m) acc[m] -= xi * lcol[(cg + 8 * m) * (NB + 1)];
+    for (int k = 0; k < ITER; ++k) {
+        const int idx = t + k * NT;
+        const int i = idx >> 6, c = (idx & 63) * 2;
+        v[k] = make_double2(0.0, 0.0);
+        if (c <= i && i < nv) v[k] = *reinterpret_cast<const double2*>(&A[(size_t)(k0 + i) * lda + k0 + c]);
+    }
+#pragma unroll
+    for (int k = 0; k < ITER; ++k) {
+        const int idx = t + k * NT;
+        const int i = idx >> 6, c = (idx & 63) * 2;
+        double2 w = v[k];
+        if (c + 1 > i) w.y = 0.0;                    // strictly upper element of the pair
+        if (i >= nv) { w.x = (c == i) ? 1.0 : 0.0; w.y = (c + 1 == i) ? 1.0 : 0.0; }
+        *reinterpret_cast<double2*>(&Ld[i * LDS_LD + c]) = w;
+    }
+    __syncthreads();
+    if (t < NB) invd[t] = 1.0 / Ld[t * LDS_LD + t];
+    __syncthreads();
+    if (t < NB) {
+        const int J = t >> 3, m = t & 7;
+        double x[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            double s = (k == m) ? 1.0 : 0.0;
+#pragma unroll
+            for (int q = 0; q < k; ++q) s = fma(-Ld[(8 * J + k) * LDS_LD + 8 * J + q], (q >= m) ? x[q] : 0.0, s);
+            x[k] = (k >= m) ? s * invd[8 * J + k] : 0.0;
+            Gi[(J * 8 + k) * 8 + m] = x[k];
+        }
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------
+// X = A21 * L11^-T for TRSM_ROWS rows per workgroup, in place, in column blocks of width 8.
+// 256 threads: thread (r, cg) owns row r = t >> 3 and columns cg + 8m (m < 16), i.e. exactly one
+// column of every 8-wide block; the 8 threads of a row are 8 consecutive lanes, so a block step
+// needs only lane shuffles (no LDS hand-off, no barrier):
+//   x = T_J * Gi_J^T (8 shuffles), then columns to the right -= X_J * L11[c, J-block]^T.
+template <int J>
+__device__ __forceinline__ void chol_trsm_block(double (&acc)[16], const double* __restrict__ Ld,
+                                                const double* __restrict__ Gi, int lane, int cg) {
+    const int base = lane & ~7;
+    const double tv = acc[J];
+    double x = 0.0;
+    const double* gi = Gi + (J * 8 + cg) * 8;      // row cg of the inverse block: Gi[J][cg][m]
+#pragma unroll
+    for (int m = 0; m < 8; ++m) x = fma(__shfl(tv, base + m, 64), gi[m], x);
+    acc[J] = x;
+    double xs[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) xs[k] = __shfl(x, base + k, 64);
+#pragma unroll
+    for (int m = J + 1; m < 16; ++m) {
+        const double2* lrow = reinterpret_cast<const double2*>(Ld + (cg + 8 * m) * LDS_LD + 8 * J);
+        double v = acc[m];
+#pragma unroll
+        for (int k2 = 0; k2 < 4; ++k2) {
+            const double2 l2 = lrow[k2];
+            v = fma(-xs[2 * k2], l2.x, v);
+            v = fma(-xs[2 * k2 + 1], l2.y, v);
+        }
+        acc[m] = v;
     }
 }
 
 __global__ __launch_bounds__(256) void chol_trsm_kernel(double* __restrict__ A, int lda, int k0) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    double* Ld = smem;                          // [128][129]
-    double* invd = smem + NB * (NB + 1);        // [128]
-    double(*xbuf)[TRSM_ROWS] = reinterpret_cast<double(*)[TRSM_ROWS]>(invd + NB);   // [2][32]
-    const int t = threadIdx.x, r = t >> 3, cg = t & 7;
+    double* Ld = smem;                          // [128][130]
+    double* Gi = smem + NB * LDS_LD;            // [16][8][8]
+    double* invd = Gi + 16 * 64;                // [128]
+    const int t = threadIdx.x, r = t >> 3, cg = t & 7, lane = t & 63;
     const int row = k0 + NB + blockIdx.x * TRSM_ROWS + r;
-    for (int idx = t; idx < NB * NB; idx += 256) {
-        const int i = idx >> 7, c = idx & 127;
-        Ld[i * (NB + 1) + c] = (c <= i) ? A[(size_t)(k0 + i) * lda + k0 + c] : 0.0;
-    }
-    if (t < NB) invd[t] = 1.0 / A[(size_t)(k0 + t) * lda + k0 + t];
     double acc[16];
 #pragma unroll
     for (int m = 0; m < 16; ++m) acc[m] = A[(size_t)row * lda + k0 + cg + 8 * m];
-    __syncthreads();
-    chol_trsm_steps<0>(acc, Ld, invd, xbuf, r, cg);   chol_trsm_steps<1>(acc, Ld, invd, xbuf, r, cg);
-    chol_trsm_steps<2>(acc, Ld, invd, xbuf, r, cg);   chol_trsm_steps<3>(acc, Ld, invd, xbuf, r, cg);
-    chol_trsm_steps<4>(acc, Ld, invd, xbuf, r, cg);   chol_trsm_steps<5>(acc, Ld, invd, xbuf, r, cg);
-    chol_trsm_steps<6>(acc, Ld, invd, xbuf, r, cg);   chol_trsm_steps<7>(acc, Ld, invd, xbuf, r, cg);
-    chol_trsm_steps<8>(acc, Ld, invd, xbuf, r, cg);   chol_trsm_steps<9>(acc, Ld, invd, xbuf, r, cg);
-    chol_trsm_steps<10>(acc, Ld, invd, xbuf, r, cg);  chol_trsm_steps<11>(acc, Ld, invd, xbuf, r, cg);
-    chol_trsm_steps<12>(acc, Ld, invd, xbuf, r, cg);  chol_trsm_steps<13>(acc, Ld, invd, xbuf, r, cg);
-    chol_trsm_steps<14>(acc, Ld, invd, xbuf, r, cg);  chol_trsm_steps<15>(acc, Ld, invd, xbuf, r, cg);
+    stage_block_and_inverses<256>(A, lda, k0, NB, Ld, invd, Gi, t);
+    chol_trsm_block<0>(acc, Ld, Gi, lane, cg);   chol_trsm_block<1>(acc, Ld, Gi, lane, cg);
+    chol_trsm_block<2>(acc, Ld, Gi, lane, cg);   chol_trsm_block<3>(acc, Ld, Gi, lane, cg);
+    chol_trsm_block<4>(acc, Ld, Gi, lane, cg);   chol_trsm_block<5>(acc, Ld, Gi, lane, cg);
+    chol_trsm_block<6>(acc, Ld, Gi, lane, cg);   chol_trsm_block<7>(acc, Ld, Gi, lane, cg);
+    chol_trsm_block<8>(acc, Ld, Gi, lane, cg);   chol_trsm_block<9>(acc, Ld, Gi, lane, cg);
+    chol_trsm_block<10>(acc, Ld, Gi, lane, cg);  chol_trsm_block<11>(acc, Ld, Gi, lane, cg);
+    chol_trsm_block<12>(acc, Ld, Gi, lane, cg);  chol_trsm_block<13>(acc, Ld, Gi, lane, cg);
+    chol_trsm_block<14>(acc, Ld, Gi, lane, cg);  chol_trsm_block<15>(acc, Ld, Gi, lane, cg);
 #pragma unroll
     for (int m = 0; m < 16; ++m) A[(size_t)row * lda + k0 + cg + 8 * m] = acc[m];
 }
@@ -189,24 +305,40 @@ __global__ __launch_bounds__(256) void chol_trsm_kernel(double* __restrict__ A, 
 // ------------------------------------------------------------------------------------------
 // Trailing update C(i,j) -= P_i P_j^T over the lower-triangle 128x128 tiles, P = panel columns
 // [k0, k0+128).  256 threads = 4 waves in a 2x2 grid, each wave 64x64 = 4x4 MFMA tiles.
-__global__ __launch_bounds__(256) void chol_syrk_kernel(double* __restrict__ A, int lda, int k0) {
+// tile_mode 0: every lower-triangle tile; 1: only the first tile column (the next panel, look-ahead);
+// 2: everything except the first tile column.
+__global__ __launch_bounds__(256) void chol_syrk_kernel(double* __restrict__ A, int lda, int k0, int tile_mode) {
     __shared__ __attribute__((aligned(16))) double sA[2][2048];
     __shared__ __attribute__((aligned(16))) double sB[2][2048];
     const int id = blockIdx.x;
-    int ti = (int)((sqrt(8.0 * (double)id + 1.0) - 1.0) * 0.5);
-    while (ti * (ti + 1) / 2 > id) --ti;
-    while ((ti + 1) * (ti + 2) / 2 <= id) ++ti;
-    const int tj = id - ti * (ti + 1) / 2;
+    int ti, tj;
+    if (tile_mode == 1) {
+        ti = id; tj = 0;
+    } else {
+        ti = (int)((sqrt(8.0 * (double)id + 1.0) - 1.0) * 0.5);
+        while (ti * (ti + 1) / 2 > id) --ti;
+        while ((ti + 1) * (ti + 2) / 2 <= id) ++ti;
+        tj = id - ti * (ti + 1) / 2;
+        if (tile_mode == 2) { ++ti; ++tj; }
+    }
     const int r0 = k0 + NB;
     const int row_i = r0 + ti * NB, row_j = r0 + tj * NB;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int wr = w >> 1, wc = w & 1;
 
+    // accumulators start from C (C/D layout of v_mfma_f64_16x16x4_f64: col = lane&15,
+    // row = (lane>>4) + 4*reg); the A fragment is negated, so the epilogue is a plain store
     double4v acc[4][4];
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int n = 0; n < 4; ++n) acc[m][n] = (double4v){0.0, 0.0, 0.0, 0.0};
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = row_i + wr * 64 + m * 16 + (lane >> 4) + 4 * r;
+                const int col = row_j + wc * 64 + n * 16 + (lane & 15);
+                acc[m][n][r] = A[(size_t)row * lda + col];
+            }
 
     // staging map: pass p, half h -> row = (lane&15) + 16*(w + 4p), k = 2*((lane>>4) + 4h)
     double2 ga[2][2], gb[2][2];
@@ -247,7 +379,7 @@ __global__ __launch_bounds__(256) void chol_syrk_kernel(double* __restrict__ A, 
         for (int kq = 0; kq < 4; ++kq) {
             double a[4], b[4];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) a[m] = sA[buf][((kq * 8 + wr * 4 + m) << 6) + lane];
+            for (int m = 0; m < 4; ++m) a[m] = -sA[buf][((kq * 8 + wr * 4 + m) << 6) + lane];
 #pragma unroll
             for (int n = 0; n < 4; ++n) b[n] = sB[buf][((kq * 8 + wc * 4 + n) << 6) + lane];
 #pragma unroll
@@ -268,45 +400,63 @@ __global__ __launch_bounds__(256) void chol_syrk_kernel(double* __restrict__ A, 
             for (int r = 0; r < 4; ++r) {
                 const int row = row_i + wr * 64 + m * 16 + (lane >> 4) + 4 * r;
                 const int col = row_j + wc * 64 + n * 16 + (lane & 15);
-                double* p = &A[(size_t)row * lda + col];
-                *p -= acc[m][n][r];
+                A[(size_t)row * lda + col] = acc[m][n][r];
             }
 }
 
 // ------------------------------------------------------------------------------------------
 // backward substitution, block b: x_b = L_bb^-T y_b   (y lives in row lda-1).
-// The block is staged in LDS by all 1024 threads, then ONE wave runs the 128 dependent steps with
-// a shuffle broadcast per step (no barriers): lane l owns unknowns l and l + 64.
+// The block and the inverses of its 8x8 diagonal blocks are staged in LDS by all 1024 threads;
+// then ONE wave runs 16 block steps with lane shuffles only: lane l owns unknowns l and l + 64.
 __global__ __launch_bounds__(1024) void chol_bwd_diag_kernel(double* __restrict__ A, int lda, int k0,
                                                              double* __restrict__ x) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    double* Ld = smem;                 // [128][129]
+    double* Ld = smem;                          // [128][130]
+    double* Gi = smem + NB * LDS_LD;            // [16][8][8]
+    double* invd = Gi + 16 * 64;                // [128]
     const int t = threadIdx.x;
-    const int nv = min(NB, (lda - 1) - k0);   // rows of this block that belong to the system
-    for (int idx = t; idx < NB * NB; idx += 1024) {
-        const int i = idx >> 7, c = idx & 127;
-        Ld[i * (NB + 1) + c] = (c <= i && i < nv) ? A[(size_t)(k0 + i) * lda + k0 + c] : ((c == i) ? 1.0 : 0.0);
-    }
-    __syncthreads();
+    const int nv = min(NB, (lda - 1) - k0);     // rows of this block that belong to the system
+    stage_block_and_inverses<1024>(A, lda, k0, nv, Ld, invd, Gi, t);
     if (t >= 64) return;
     const int l = t;
-    double y0 = (l < nv) ? A[(size_t)(lda - 1) * lda + k0 + l] : 0.0;
-    double y1 = (l + 64 < nv) ? A[(size_t)(lda - 1) * lda + k0 + l + 64] : 0.0;
-    const double id0 = 1.0 / Ld[l * (NB + 1) + l], id1 = 1.0 / Ld[(l + 64) * (NB + 1) + l + 64];
-    for (int j = NB - 1; j >= 64; --j) {
-        const double xj = __shfl(y1 * id1, j - 64, 64);
-        const double* rowj = Ld + j * (NB + 1);
-        if (l + 64 == j) y1 = xj;
-        else if (l + 64 < j) y1 -= rowj[l + 64] * xj;
-        y0 -= rowj[l] * xj;
+    double y[2];
+    y[0] = (l < nv) ? A[(size_t)(lda - 1) * lda + k0 + l] : 0.0;
+    y[1] = (l + 64 < nv) ? A[(size_t)(lda - 1) * lda + k0 + l + 64] : 0.0;
+#pragma unroll
+    for (int h = 1; h >= 0; --h) {
+#pragma unroll 1
+        for (int Jh = 7; Jh >= 0; --Jh) {
+            const int J = 8 * h + Jh;               // block of unknowns 8J .. 8J+7, owned by lanes 8Jh .. 8Jh+7
+            const int base = 8 * Jh, m = l & 7;
+            // x_m = sum_{k >= m} Gi[J][k][m] * y_k   (transpose of the inverse block)
+            double xm = 0.0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) xm = fma(Gi[(J * 8 + k) * 8 + m], __shfl(y[h], base + k, 64), xm);
+            if ((l >> 3) == Jh) y[h] = xm;
+            double xs[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) xs[k] = __shfl(y[h], base + k, 64);
+            // remaining unknowns t' < 8J: y_t' -= sum_k L[8J+k][t'] x_k
+            if (h == 1) {
+                double v0 = y[0], v1 = y[1];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const double* rowk = Ld + (8 * J + k) * LDS_LD;
+                    v0 = fma(-rowk[l], xs[k], v0);
+                    if (l + 64 < 8 * J) v1 = fma(-rowk[l + 64], xs[k], v1);
+                }
+                y[0] = v0; y[1] = v1;
+            } else {
+                double v0 = y[0];
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (l < 8 * J) v0 = fma(-Ld[(8 * J + k) * LDS_LD + l], xs[k], v0);
+                y[0] = v0;
+            }
+        }
     }
-    for (int j = 63; j >= 0; --j) {
-        const double xj = __shfl(y0 * id0, j, 64);
-        if (l == j) y0 = xj;
-        else if (l < j) y0 -= Ld[j * (NB + 1) + l] * xj;
-    }
-    x[k0 + l] = (l < nv) ? y0 : 0.0;
-    x[k0 + l + 64] = (l + 64 < nv) ? y1 : 0.0;
+    x[k0 + l] = (l < nv) ? y[0] : 0.0;
+    x[k0 + l + 64] = (l + 64 < nv) ? y[1] : 0.0;
 }
 
 // y[0:k0] -= L[k0:k0+nv, 0:k0]^T x_b
@@ -329,8 +479,8 @@ __global__ __launch_bounds__(256) void chol_bwd_update_kernel(double* __restrict
 static int chol_run(double* A, int lda, int n, double* x_dev, int* flag_dev, hipStream_t st, CholProfile* prof) {
     if (lda % NB != 0 || lda < n + 1) return fail(STBA_ERR_INVALID_ARGUMENT, "chol: bad padded dimension");
     const int nblk = lda / NB;
-    const size_t trsm_lds = sizeof(double) * (NB * (NB + 1) + NB + 2 * TRSM_ROWS);
-    const size_t bwd_lds = sizeof(double) * (NB * (NB + 1));
+    const size_t trsm_lds = sizeof(double) * (NB * LDS_LD + 16 * 64 + NB);
+    const size_t bwd_lds = sizeof(double) * (NB * LDS_LD + 16 * 64 + NB);
     static bool attr_set = false;
     if (!attr_set) {
         STBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(chol_trsm_kernel),
@@ -347,22 +497,81 @@ static int chol_run(double* A, int lda, int n, double* x_dev, int* flag_dev, hip
     }
     auto mark = [&](size_t k) -> int { if (prof) STBA_HIP(hipEventRecord(ev[k], st)); return STBA_OK; };
     STBA_HIP(hipMemsetAsync(flag_dev, 0, sizeof(int), st));
-    for (int b = 0; b < nblk; ++b) {
-        const int k0 = b * NB;
-        const int mt = nblk - b - 1;
-        STBA_TRY(mark(4 * (size_t)b + 0));
-        hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(1024), 0, st, A, lda, k0, n, flag_dev);
-        STBA_TRY(mark(4 * (size_t)b + 1));
-        if (mt > 0)
-            hipLaunchKernelGGL(chol_trsm_kernel, dim3(mt * (NB / TRSM_ROWS)), dim3(256), trsm_lds, st, A, lda, k0);
-        STBA_TRY(mark(4 * (size_t)b + 2));
-        if (mt > 0) hipLaunchKernelGGL(chol_syrk_kernel, dim3(mt * (mt + 1) / 2), dim3(256), 0, st, A, lda, k0);
-        STBA_TRY(mark(4 * (size_t)b + 3));
-        if (prof && mt > 0) {
-            const double m = std::max(0, n - (k0 + NB));
-            prof->syrk_flops += m * (m + 1.0) * NB;
-            prof->syrk_flops_padded += (double)(mt * (mt + 1) / 2) * 2.0 * NB * NB * NB;
-            prof->syrk_launches += 1;
+    if (prof) {
+        // serial schedule: one kernel class at a time, so the per-class event times are clean
+        for (int b = 0; b < nblk; ++b) {
+            const int k0 = b * NB;
+            const int mt = nblk - b - 1;
+            STBA_TRY(mark(4 * (size_t)b + 0));
+            hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(1024), 0, st, A, lda, k0, n, flag_dev);
+            STBA_TRY(mark(4 * (size_t)b + 1));
+            if (mt > 0)
+                hipLaunchKernelGGL(chol_trsm_kernel, dim3(mt * (NB / TRSM_ROWS)), dim3(256), trsm_lds, st, A, lda, k0);
+            STBA_TRY(mark(4 * (size_t)b + 2));
+            if (mt > 0) hipLaunchKernelGGL(chol_syrk_kernel, dim3(mt * (mt + 1) / 2), dim3(256), 0, st, A, lda, k0, 0);
+            STBA_TRY(mark(4 * (size_t)b + 3));
+            if (mt > 0) {
+                const double m = std::max(0, n - (k0 + NB));
+                prof->syrk_flops += m * (m + 1.0) * NB;
+                prof->syrk_flops_padded += (double)(mt * (mt + 1) / 2) * 2.0 * NB * NB * NB;
+                prof->syrk_launches += 1;
+            }
+        }
+    } else {
+        // look-ahead schedule: the panel of step b+1 (diagonal block + panel solve, on `st`) overlaps
+        // the bulk of the trailing update of step b (on a side stream); only the update of the
+        // next panel's tile column sits on the critical path.
+        static hipStream_t su = nullptr;
+        static std::vector<hipEvent_t> evP, evN;
+        static hipEvent_t evU = nullptr;
+        if (!su) {
+            // bulk trailing updates run at the LOWEST priority so that panel kernels win dispatch slots
+            int lo_prio = 0, hi_prio = 0;
+            STBA_HIP(hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio));
+            STBA_HIP(hipStreamCreateWithPriority(&su, hipStreamNonBlocking, lo_prio));
+            STBA_HIP(hipEventCreateWithFlags(&evU, hipEventDisableTiming));
+        }
+        while ((int)evP.size() < nblk) {
+            hipEvent_t e1, e2;
+            STBA_HIP(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
+            STBA_HIP(hipEventCreateWithFlags(&e2, hipEventDisableTiming));
+            evP.push_back(e1); evN.push_back(e2);
+        }
+        hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(1024), 0, st, A, lda, 0, n, flag_dev);
+        if (nblk > 1)
+            hipLaunchKernelGGL(chol_trsm_kernel, dim3((nblk - 1) * (NB / TRSM_ROWS)), dim3(256), trsm_lds, st, A, lda, 0);
+        STBA_HIP(hipEventRecord(evP[0], st));
+        // look-ahead only pays while the bulk update is longer than the panel chain (measured on
+        // MI355X: cross-stream hand-offs cost ~7-14 us each and the panel is ~65 us under contention)
+        constexpr int LOOKAHEAD_MIN_MT = 36;
+        int b = 0;
+        for (; b + 1 < nblk && (nblk - b - 1) >= LOOKAHEAD_MIN_MT; ++b) {
+            const int k0 = b * NB;
+            const int mt = nblk - b - 1;
+            STBA_HIP(hipStreamWaitEvent(su, evP[b], 0));
+            hipLaunchKernelGGL(chol_syrk_kernel, dim3(mt), dim3(256), 0, su, A, lda, k0, 1);
+            STBA_HIP(hipEventRecord(evN[b], su));
+            if (mt > 1)
+                hipLaunchKernelGGL(chol_syrk_kernel, dim3(mt * (mt - 1) / 2), dim3(256), 0, su, A, lda, k0, 2);
+            STBA_HIP(hipStreamWaitEvent(st, evN[b], 0));
+            const int k1 = k0 + NB;
+            hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(1024), 0, st, A, lda, k1, n, flag_dev);
+            if (mt > 1)
+                hipLaunchKernelGGL(chol_trsm_kernel, dim3((mt - 1) * (NB / TRSM_ROWS)), dim3(256), trsm_lds, st, A, lda, k1);
+            STBA_HIP(hipEventRecord(evP[b + 1], st));
+        }
+        if (b > 0) {
+            STBA_HIP(hipEventRecord(evU, su));
+            STBA_HIP(hipStreamWaitEvent(st, evU, 0));
+        }
+        for (; b + 1 < nblk; ++b) {   // serial tail on the caller's stream
+            const int k0 = b * NB;
+            const int mt = nblk - b - 1;
+            hipLaunchKernelGGL(chol_syrk_kernel, dim3(mt * (mt + 1) / 2), dim3(256), 0, st, A, lda, k0, 0);
+            const int k1 = k0 + NB;
+            hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(1024), 0, st, A, lda, k1, n, flag_dev);
+            if (mt > 1)
+                hipLaunchKernelGGL(chol_trsm_kernel, dim3((mt - 1) * (NB / TRSM_ROWS)), dim3(256), trsm_lds, st, A, lda, k1);
         }
     }
     STBA_TRY(mark((size_t)nblk * 4));
