@@ -1,0 +1,738 @@
+// stba/ceres.h -- the reference's operator API (the slice of the Ceres Solver C++ API that
+// Unsigned-Long/slam-tricks uses) as a header-only C++17 layer over the C ABI in stba.h.
+//
+// A maintainer of the reference switches  #include "ceres/ceres.h"  to
+//     #include "stba/ceres.h"
+//     namespace ceres = stba_ceres;
+// and links libstba.so; call sites keep their shape (INTEGRATION.md shows the diff).
+//
+// Entry points mirrored (paths relative to /root/reference):
+//   CostFunction::Evaluate, SizedCostFunction<2,3,3>        st17-ceres/src/include/solver.hpp:157-212
+//   AutoDiffCostFunction<F,2,4,3>, <F,2,3>                  solver.hpp:135, st20-g2o/src/include/sim_data.h:175
+//   DynamicAutoDiffCostFunction<F> (+AddParameterBlock/SetNumResiduals)
+//                                                           solver.hpp:104,263-265, test_ceres.h:56,112-115,
+//                                                           st17-ceres/src/ceres_bound.cpp:14,29-30
+//   LocalParameterization {Plus, ComputeJacobian, GlobalSize, LocalSize}
+//                                                           solver.hpp:30-94, test_ceres.h:14-45
+//   Problem::{AddResidualBlock, AddParameterBlock, SetParameterBlockConstant,
+//             SetParameterLowerBound, SetParameterUpperBound}
+//                                                           solver.hpp:267-270, test_ceres.h:119-130,
+//                                                           ceres_bound.cpp:32,51-53
+//   Solver::Options / Summary::BriefReport / Solve / IterationCallback
+//                                                           solver.hpp:215-290, test_ceres.h:83-151
+//
+// Where the work runs.  User CostFunction::Evaluate / autodiff functors are host code and are
+// evaluated on the host (as in the reference); everything else -- normal equations, Schur
+// complement, Cholesky, LM step -- runs in libstba's HIP kernels:
+//   * residual blocks that are all stba_ceres::ReprojectionFactor (the built-in form of
+//     ns_st20::ProjectFactor, test_ceres.h:47-81) -> fully device-resident BA engine (stba_ba_*):
+//     residuals and Jacobians are computed by the HIP kernel too;
+//   * any other problem -> the callback path of stba_dense_solve (<= 4096 local parameters).
+// There is no CPU solver behind this header: without a HIP device Solve() reports FAILURE.
+#ifndef STBA_CERES_H
+#define STBA_CERES_H
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <initializer_list>
+#include <map>
+#include <memory>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "../stba.h"
+
+namespace stba_ceres {
+
+// ------------------------------------------------------------------------------------------
+// forward-mode dual numbers (ceres::Jet)
+// ------------------------------------------------------------------------------------------
+template <typename T, int N>
+struct Jet {
+    T a;
+    T v[N];
+    Jet() : a(T(0)) { for (int i = 0; i < N; ++i) v[i] = T(0); }
+    Jet(const T& value) : a(value) { for (int i = 0; i < N; ++i) v[i] = T(0); }   // NOLINT
+    Jet(const T& value, int k) : a(value) { for (int i = 0; i < N; ++i) v[i] = T(0); v[k] = T(1); }
+    Jet& operator+=(const Jet& y) { *this = *this + y; return *this; }
+    Jet& operator-=(const Jet& y) { *this = *this - y; return *this; }
+    Jet& operator*=(const Jet& y) { *this = *this * y; return *this; }
+    Jet& operator/=(const Jet& y) { *this = *this / y; return *this; }
+};
+#define STBA_JET_BIN(op, expr_a, expr_v)                                                         \
+    template <typename T, int N> inline Jet<T, N> operator op(const Jet<T, N>& f, const Jet<T, N>& g) { \
+        Jet<T, N> h; h.a = expr_a; for (int i = 0; i < N; ++i) h.v[i] = expr_v; return h; }
+STBA_JET_BIN(+, f.a + g.a, f.v[i] + g.v[i])
+STBA_JET_BIN(-, f.a - g.a, f.v[i] - g.v[i])
+STBA_JET_BIN(*, f.a * g.a, f.a * g.v[i] + f.v[i] * g.a)
+STBA_JET_BIN(/, f.a / g.a, (f.v[i] - (f.a / g.a) * g.v[i]) / g.a)
+#undef STBA_JET_BIN
+template <typename T, int N> inline Jet<T, N> operator-(const Jet<T, N>& f) { Jet<T, N> h; h.a = -f.a; for (int i = 0; i < N; ++i) h.v[i] = -f.v[i]; return h; }
+template <typename T, int N> inline Jet<T, N> operator+(const Jet<T, N>& f, T s) { Jet<T, N> h = f; h.a += s; return h; }
+template <typename T, int N> inline Jet<T, N> operator+(T s, const Jet<T, N>& f) { return f + s; }
+template <typename T, int N> inline Jet<T, N> operator-(const Jet<T, N>& f, T s) { Jet<T, N> h = f; h.a -= s; return h; }
+template <typename T, int N> inline Jet<T, N> operator-(T s, const Jet<T, N>& f) { return (-f) + s; }
+template <typename T, int N> inline Jet<T, N> operator*(const Jet<T, N>& f, T s) { Jet<T, N> h; h.a = f.a * s; for (int i = 0; i < N; ++i) h.v[i] = f.v[i] * s; return h; }
+template <typename T, int N> inline Jet<T, N> operator*(T s, const Jet<T, N>& f) { return f * s; }
+template <typename T, int N> inline Jet<T, N> operator/(const Jet<T, N>& f, T s) { return f * (T(1) / s); }
+template <typename T, int N> inline Jet<T, N> operator/(T s, const Jet<T, N>& g) { return Jet<T, N>(s) / g; }
+template <typename T, int N> inline bool operator<(const Jet<T, N>& f, const Jet<T, N>& g) { return f.a < g.a; }
+template <typename T, int N> inline bool operator>(const Jet<T, N>& f, const Jet<T, N>& g) { return f.a > g.a; }
+template <typename T, int N> inline bool operator<(const Jet<T, N>& f, T g) { return f.a < g; }
+template <typename T, int N> inline bool operator>(const Jet<T, N>& f, T g) { return f.a > g; }
+template <typename T, int N> inline Jet<T, N> sqrt(const Jet<T, N>& f) { Jet<T, N> h; h.a = std::sqrt(f.a); const T d = T(0.5) / h.a; for (int i = 0; i < N; ++i) h.v[i] = f.v[i] * d; return h; }
+template <typename T, int N> inline Jet<T, N> sin(const Jet<T, N>& f) { Jet<T, N> h; h.a = std::sin(f.a); const T d = std::cos(f.a); for (int i = 0; i < N; ++i) h.v[i] = f.v[i] * d; return h; }
+template <typename T, int N> inline Jet<T, N> cos(const Jet<T, N>& f) { Jet<T, N> h; h.a = std::cos(f.a); const T d = -std::sin(f.a); for (int i = 0; i < N; ++i) h.v[i] = f.v[i] * d; return h; }
+template <typename T, int N> inline Jet<T, N> atan2(const Jet<T, N>& y, const Jet<T, N>& x) { Jet<T, N> h; h.a = std::atan2(y.a, x.a); const T d = T(1) / (x.a * x.a + y.a * y.a); for (int i = 0; i < N; ++i) h.v[i] = (x.a * y.v[i] - y.a * x.v[i]) * d; return h; }
+template <typename T, int N> inline Jet<T, N> abs(const Jet<T, N>& f) { return f.a < T(0) ? -f : f; }
+using std::sqrt; using std::sin; using std::cos; using std::atan2; using std::abs;
+
+// ------------------------------------------------------------------------------------------
+// enums / small types
+// ------------------------------------------------------------------------------------------
+enum LinearSolverType { DENSE_NORMAL_CHOLESKY, DENSE_QR, SPARSE_NORMAL_CHOLESKY, DENSE_SCHUR, SPARSE_SCHUR,
+                        ITERATIVE_SCHUR, CGNR };
+enum CallbackReturnType { SOLVER_CONTINUE, SOLVER_ABORT, SOLVER_TERMINATE_SUCCESSFULLY };
+enum TerminationType { CONVERGENCE, NO_CONVERGENCE, FAILURE, USER_SUCCESS, USER_FAILURE };
+enum Ownership { DO_NOT_TAKE_OWNERSHIP, TAKE_OWNERSHIP };
+constexpr int DYNAMIC = -1;
+
+class LossFunction { public: virtual ~LossFunction() = default; };   // the reference only passes nullptr
+
+struct IterationSummary {
+    int iteration = 0;
+    bool step_is_valid = false, step_is_successful = false;
+    double cost = 0, cost_change = 0, gradient_max_norm = 0, step_norm = 0, relative_decrease = 0,
+           trust_region_radius = 0;
+};
+
+class IterationCallback {
+public:
+    virtual ~IterationCallback() = default;
+    virtual CallbackReturnType operator()(const IterationSummary& summary) = 0;
+};
+
+// ------------------------------------------------------------------------------------------
+// CostFunction family
+// ------------------------------------------------------------------------------------------
+class CostFunction {
+public:
+    virtual ~CostFunction() = default;
+    virtual bool Evaluate(double const* const* parameters, double* residuals, double** jacobians) const = 0;
+    const std::vector<int>& parameter_block_sizes() const { return parameter_block_sizes_; }
+    int num_residuals() const { return num_residuals_; }
+protected:
+    std::vector<int>* mutable_parameter_block_sizes() { return &parameter_block_sizes_; }
+    void set_num_residuals(int n) { num_residuals_ = n; }
+private:
+    std::vector<int> parameter_block_sizes_;
+    int num_residuals_ = 0;
+};
+
+template <int kNumResiduals, int... Ns>
+class SizedCostFunction : public CostFunction {
+public:
+    SizedCostFunction() {
+        set_num_residuals(kNumResiduals);
+        *mutable_parameter_block_sizes() = std::vector<int>{Ns...};
+    }
+};
+
+namespace internal {
+template <int... Ns> struct Sum;
+template <> struct Sum<> { static constexpr int value = 0; };
+template <int N, int... Ns> struct Sum<N, Ns...> { static constexpr int value = N + Sum<Ns...>::value; };
+
+// calls functor(p0, p1, ..., residuals) with the parameter pointers unpacked
+template <typename F, typename T, size_t... I>
+inline bool CallVariadic(const F& f, T const* const* params, T* residuals, std::index_sequence<I...>) {
+    return f(params[I]..., residuals);
+}
+}  // namespace internal
+
+template <typename CostFunctor, int kNumResiduals, int... Ns>
+class AutoDiffCostFunction : public SizedCostFunction<kNumResiduals, Ns...> {
+public:
+    explicit AutoDiffCostFunction(CostFunctor* functor, Ownership own = TAKE_OWNERSHIP) : functor_(functor), own_(own) {}
+    ~AutoDiffCostFunction() override { if (own_ == TAKE_OWNERSHIP) delete functor_; }
+    bool Evaluate(double const* const* parameters, double* residuals, double** jacobians) const override {
+        constexpr int kBlocks = sizeof...(Ns);
+        constexpr int kParams = internal::Sum<Ns...>::value;
+        if (!jacobians) return internal::CallVariadic(*functor_, parameters, residuals, std::make_index_sequence<kBlocks>{});
+        using JetT = Jet<double, kParams>;
+        const int sizes[kBlocks] = {Ns...};
+        JetT x[kParams];
+        JetT const* ptrs[kBlocks];
+        int off = 0;
+        for (int b = 0; b < kBlocks; ++b) {
+            ptrs[b] = x + off;
+            for (int k = 0; k < sizes[b]; ++k) x[off + k] = JetT(parameters[b][k], off + k);
+            off += sizes[b];
+        }
+        JetT out[kNumResiduals];
+        if (!internal::CallVariadic(*functor_, ptrs, out, std::make_index_sequence<kBlocks>{})) return false;
+        off = 0;
+        for (int b = 0; b < kBlocks; ++b) {
+            for (int r = 0; r < kNumResiduals; ++r) {
+                if (b == 0) residuals[r] = out[r].a;
+                if (jacobians[b])
+                    for (int k = 0; k < sizes[b]; ++k) jacobians[b][r * sizes[b] + k] = out[r].v[off + k];
+            }
+            off += sizes[b];
+        }
+        return true;
+    }
+private:
+    CostFunctor* functor_;
+    Ownership own_;
+};
+
+template <typename CostFunctor, int Stride = 4>
+class DynamicAutoDiffCostFunction : public CostFunction {
+public:
+    explicit DynamicAutoDiffCostFunction(CostFunctor* functor, Ownership own = TAKE_OWNERSHIP) : functor_(functor), own_(own) {}
+    ~DynamicAutoDiffCostFunction() override { if (own_ == TAKE_OWNERSHIP) delete functor_; }
+    void AddParameterBlock(int size) { mutable_parameter_block_sizes()->push_back(size); }
+    void SetNumResiduals(int n) { set_num_residuals(n); }
+    bool Evaluate(double const* const* parameters, double* residuals, double** jacobians) const override {
+        const auto& sizes = parameter_block_sizes();
+        const int nb = (int)sizes.size(), nr = num_residuals();
+        if (!jacobians) return (*functor_)(parameters, residuals);
+        using JetT = Jet<double, Stride>;
+        int total = 0;
+        for (int s : sizes) total += s;
+        std::vector<JetT> x(total), out(nr);
+        std::vector<JetT const*> ptrs(nb);
+        std::vector<int> blk(total), loc(total);
+        for (int b = 0, o = 0; b < nb; ++b) {
+            ptrs[b] = x.data() + o;
+            for (int k = 0; k < sizes[b]; ++k, ++o) { blk[o] = b; loc[o] = k; }
+        }
+        // ceil(total / Stride) passes, Stride partial derivatives per pass (as Ceres does)
+        for (int start = 0; start < total || start == 0; start += Stride) {
+            for (int b = 0, o = 0; b < nb; ++b)
+                for (int k = 0; k < sizes[b]; ++k, ++o) {
+                    x[o] = JetT(parameters[b][k]);
+                    if (o >= start && o < start + Stride) x[o].v[o - start] = 1.0;
+                }
+            if (!(*functor_)(ptrs.data(), out.data())) return false;
+            for (int r = 0; r < nr; ++r) {
+                residuals[r] = out[r].a;
+                for (int o = start; o < std::min(total, start + Stride); ++o)
+                    if (jacobians[blk[o]]) jacobians[blk[o]][r * sizes[blk[o]] + loc[o]] = out[r].v[o - start];
+            }
+            if (total == 0) break;
+        }
+        return true;
+    }
+private:
+    CostFunctor* functor_;
+    Ownership own_;
+};
+
+// ------------------------------------------------------------------------------------------
+// LocalParameterization (Ceres <= 2.1 API, as the reference uses it)
+// ------------------------------------------------------------------------------------------
+class LocalParameterization {
+public:
+    virtual ~LocalParameterization() = default;
+    virtual bool Plus(const double* x, const double* delta, double* x_plus_delta) const = 0;
+    virtual bool ComputeJacobian(const double* x, double* jacobian) const = 0;   // GlobalSize x LocalSize, row-major
+    virtual int GlobalSize() const = 0;
+    virtual int LocalSize() const = 0;
+};
+
+// ------------------------------------------------------------------------------------------
+// built-in factor / manifold kinds the HIP kernels implement natively
+// ------------------------------------------------------------------------------------------
+// q (x,y,z,w) <- q (x) exp(delta): LieLocalParameterization<Sophus::SO3d> (solver.hpp:30-61)
+class QuaternionRightPlus : public LocalParameterization {
+public:
+    bool Plus(const double* q, const double* d, double* out) const override {
+        const double th2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+        double im, re;
+        if (th2 < 1e-20) { im = 0.5 - th2 / 48.0; re = 1.0 - th2 / 8.0; }
+        else { const double th = std::sqrt(th2); im = std::sin(0.5 * th) / th; re = std::cos(0.5 * th); }
+        const double bx = im * d[0], by = im * d[1], bz = im * d[2], bw = re;
+        const double ax = q[0], ay = q[1], az = q[2], aw = q[3];
+        double o[4] = {aw * bx + ax * bw + ay * bz - az * by, aw * by - ax * bz + ay * bw + az * bx,
+                       aw * bz + ax * by - ay * bx + az * bw, aw * bw - ax * bx - ay * by - az * bz};
+        const double n = std::sqrt(o[0] * o[0] + o[1] * o[1] + o[2] * o[2] + o[3] * o[3]);
+        for (int i = 0; i < 4; ++i) out[i] = o[i] / n;
+        return true;
+    }
+    bool ComputeJacobian(const double* q, double* J) const override {   // notes.tex:131-144
+        const double x = 0.5 * q[0], y = 0.5 * q[1], z = 0.5 * q[2], w = 0.5 * q[3];
+        const double M[12] = {w, -z, y, z, w, -x, -y, x, w, -x, -y, -z};
+        std::memcpy(J, M, sizeof M);
+        return true;
+    }
+    int GlobalSize() const override { return 4; }
+    int LocalSize() const override { return 3; }
+};
+
+// ns_st20::ProjectFactor (test_ceres.h:47-81) as a built-in: blocks {SO3 quaternion 4, POS 3,
+// landmark 3}, residual = proj(R^T (L - t)) - feature.  Evaluate() is provided for completeness
+// (ambient 2x4 quaternion Jacobian), but a Problem made only of these runs fully on the GPU.
+class ReprojectionFactor : public SizedCostFunction<2, 4, 3, 3> {
+public:
+    ReprojectionFactor(double fx, double fy) : fx_(fx), fy_(fy) {}
+    static ReprojectionFactor* Create(const double* feature) { return new ReprojectionFactor(feature[0], feature[1]); }
+    double fx() const { return fx_; }
+    double fy() const { return fy_; }
+    template <typename T>
+    bool operator()(const T* q, const T* t, const T* L, T* r) const {
+        // conj(q) * (L - t) with Eigen's v + 2w(u x v) + 2 u x (u x v), u = -q.xyz
+        const T u0 = -q[0], u1 = -q[1], u2 = -q[2], w = q[3];
+        const T v0 = L[0] - t[0], v1 = L[1] - t[1], v2 = L[2] - t[2];
+        const T a0 = T(2.0) * (u1 * v2 - u2 * v1), a1 = T(2.0) * (u2 * v0 - u0 * v2), a2 = T(2.0) * (u0 * v1 - u1 * v0);
+        const T x = v0 + w * a0 + (u1 * a2 - u2 * a1);
+        const T y = v1 + w * a1 + (u2 * a0 - u0 * a2);
+        const T z = v2 + w * a2 + (u0 * a1 - u1 * a0);
+        r[0] = x / z - T(fx_);
+        r[1] = y / z - T(fy_);
+        return true;
+    }
+    bool Evaluate(double const* const* p, double* residuals, double** jacobians) const override {
+        if (!jacobians) return (*this)(p[0], p[1], p[2], residuals);
+        using J10 = Jet<double, 10>;
+        J10 x[10], out[2];
+        for (int k = 0; k < 4; ++k) x[k] = J10(p[0][k], k);
+        for (int k = 0; k < 3; ++k) { x[4 + k] = J10(p[1][k], 4 + k); x[7 + k] = J10(p[2][k], 7 + k); }
+        (*this)(x, x + 4, x + 7, out);
+        for (int r = 0; r < 2; ++r) {
+            residuals[r] = out[r].a;
+            if (jacobians[0]) for (int k = 0; k < 4; ++k) jacobians[0][r * 4 + k] = out[r].v[k];
+            if (jacobians[1]) for (int k = 0; k < 3; ++k) jacobians[1][r * 3 + k] = out[r].v[4 + k];
+            if (jacobians[2]) for (int k = 0; k < 3; ++k) jacobians[2][r * 3 + k] = out[r].v[7 + k];
+        }
+        return true;
+    }
+private:
+    double fx_, fy_;
+};
+
+// ------------------------------------------------------------------------------------------
+// Problem
+// ------------------------------------------------------------------------------------------
+class Problem {
+public:
+    struct Options {
+        Ownership cost_function_ownership = TAKE_OWNERSHIP, loss_function_ownership = TAKE_OWNERSHIP,
+                  local_parameterization_ownership = TAKE_OWNERSHIP;
+    };
+    Problem() = default;
+    explicit Problem(const Options& o) : options_(o) {}
+    Problem(const Problem&) = delete;
+    Problem& operator=(const Problem&) = delete;
+    ~Problem() {
+        // the reference never frees what it news (solver.hpp:104,258; test_ceres.h:56,106): the problem
+        // owns cost functions and parameterisations, shared pointers are freed once.
+        if (options_.cost_function_ownership == TAKE_OWNERSHIP) for (auto* c : owned_costs_) delete c;
+        if (options_.local_parameterization_ownership == TAKE_OWNERSHIP) for (auto* l : owned_params_) delete l;
+        if (options_.loss_function_ownership == TAKE_OWNERSHIP) for (auto* l : owned_losses_) delete l;
+    }
+
+    void AddParameterBlock(double* values, int size, LocalParameterization* local = nullptr) {
+        Block& b = block(values, size);
+        if (local) { b.local = local; owned_params_.insert(local); }
+    }
+    template <typename... Ts>
+    void AddResidualBlock(CostFunction* cost, LossFunction* loss, double* x0, Ts*... xs) {
+        AddResidualBlock(cost, loss, std::vector<double*>{x0, xs...});
+    }
+    void AddResidualBlock(CostFunction* cost, LossFunction* loss, std::initializer_list<double*> blocks) {
+        AddResidualBlock(cost, loss, std::vector<double*>(blocks));
+    }
+    void AddResidualBlock(CostFunction* cost, LossFunction* loss, const std::vector<double*>& blocks) {
+        Residual r;
+        r.cost = cost;
+        const auto& sizes = cost->parameter_block_sizes();
+        if (sizes.size() != blocks.size()) { std::fprintf(stderr, "stba_ceres: block count mismatch\n"); std::abort(); }
+        for (size_t i = 0; i < blocks.size(); ++i) r.blocks.push_back(block(blocks[i], sizes[i]).index);
+        residuals_.push_back(r);
+        owned_costs_.insert(cost);
+        if (loss) owned_losses_.insert(loss);
+    }
+    void SetParameterBlockConstant(double* values) { find(values).constant = true; }
+    void SetParameterBlockVariable(double* values) { find(values).constant = false; }
+    void SetParameterLowerBound(double* values, int index, double lower) { Block& b = find(values); b.ensure_bounds(); b.lower[index] = lower; }
+    void SetParameterUpperBound(double* values, int index, double upper) { Block& b = find(values); b.ensure_bounds(); b.upper[index] = upper; }
+    int NumParameterBlocks() const { return (int)blocks_.size(); }
+    int NumResidualBlocks() const { return (int)residuals_.size(); }
+    int NumResiduals() const { int n = 0; for (auto& r : residuals_) n += r.cost->num_residuals(); return n; }
+
+    // ---- internals used by Solve ----
+    struct Block {
+        double* ptr = nullptr; int size = 0, index = 0; bool constant = false;
+        LocalParameterization* local = nullptr;
+        std::vector<double> lower, upper;
+        int local_size() const { return local ? local->LocalSize() : size; }
+        void ensure_bounds() { if (lower.empty()) { lower.assign(size, -1e300); upper.assign(size, 1e300); } }
+    };
+    struct Residual { CostFunction* cost = nullptr; std::vector<int> blocks; };
+    std::vector<Block>& blocks() { return blocks_; }
+    std::vector<Residual>& residuals() { return residuals_; }
+
+private:
+    Block& block(double* p, int size) {
+        auto it = index_.find(p);
+        if (it != index_.end()) {
+            if (blocks_[it->second].size != size) { std::fprintf(stderr, "stba_ceres: block re-added with another size\n"); std::abort(); }
+            return blocks_[it->second];
+        }
+        Block b; b.ptr = p; b.size = size; b.index = (int)blocks_.size();
+        index_[p] = b.index;
+        blocks_.push_back(b);
+        return blocks_.back();
+    }
+    Block& find(double* p) {
+        auto it = index_.find(p);
+        if (it == index_.end()) { std::fprintf(stderr, "stba_ceres: unknown parameter block\n"); std::abort(); }
+        return blocks_[it->second];
+    }
+    Options options_;
+    std::vector<Block> blocks_;
+    std::vector<Residual> residuals_;
+    std::map<double*, int> index_;
+    std::set<CostFunction*> owned_costs_;
+    std::set<LocalParameterization*> owned_params_;
+    std::set<LossFunction*> owned_losses_;
+};
+
+// ------------------------------------------------------------------------------------------
+// Solver
+// ------------------------------------------------------------------------------------------
+class Solver {
+public:
+    struct Options {
+        int max_num_iterations = 50;
+        int num_threads = 1;
+        LinearSolverType linear_solver_type = SPARSE_NORMAL_CHOLESKY;
+        bool minimizer_progress_to_stdout = false;
+        bool update_state_every_iteration = false;
+        std::vector<IterationCallback*> callbacks;
+        double initial_trust_region_radius = 1e4, max_trust_region_radius = 1e16, min_trust_region_radius = 1e-32,
+               min_relative_decrease = 1e-3, min_lm_diagonal = 1e-6, max_lm_diagonal = 1e32,
+               function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
+        bool jacobi_scaling = true;
+    };
+    struct Summary {
+        TerminationType termination_type = FAILURE;
+        std::string message;
+        double initial_cost = 0, final_cost = 0, total_time_in_seconds = 0;
+        int num_successful_steps = 0, num_unsuccessful_steps = 0;
+        std::vector<IterationSummary> iterations;
+        std::string execution_path;   // "gpu-ba" | "gpu-dense-callback"
+        std::string BriefReport() const {
+            char buf[512];
+            const char* t = termination_type == CONVERGENCE ? "CONVERGENCE" : termination_type == NO_CONVERGENCE ? "NO_CONVERGENCE"
+                            : termination_type == FAILURE ? "FAILURE" : "USER";
+            std::snprintf(buf, sizeof buf, "stba Solver Summary: Iterations: %d, Initial cost: %e, Final cost: %e, Termination: %s",
+                          (int)iterations.size(), initial_cost, final_cost, t);
+            return buf;
+        }
+        std::string FullReport() const { return BriefReport() + " [" + execution_path + "] " + message; }
+    };
+};
+
+namespace internal {
+
+inline stba_lm_options ToC(const Solver::Options& o) {
+    stba_lm_options c;
+    stba_lm_default_options(&c);
+    c.max_num_iterations = o.max_num_iterations;
+    c.initial_trust_region_radius = o.initial_trust_region_radius;
+    c.max_trust_region_radius = o.max_trust_region_radius;
+    c.min_trust_region_radius = o.min_trust_region_radius;
+    c.min_relative_decrease = o.min_relative_decrease;
+    c.min_lm_diagonal = o.min_lm_diagonal;
+    c.max_lm_diagonal = o.max_lm_diagonal;
+    c.function_tolerance = o.function_tolerance;
+    c.gradient_tolerance = o.gradient_tolerance;
+    c.parameter_tolerance = o.parameter_tolerance;
+    c.jacobi_scaling = o.jacobi_scaling ? 1 : 0;
+    c.num_threads = o.num_threads;
+    c.minimizer_progress_to_stdout = o.minimizer_progress_to_stdout ? 1 : 0;
+    c.update_state_every_iteration = o.update_state_every_iteration ? 1 : 0;
+    return c;
+}
+
+struct CallbackCtx {
+    const Solver::Options* options;
+    Solver::Summary* summary;
+    void (*sync_state)(void*);   // copies the current iterate into the user's parameter memory
+    void* sync_user;
+    bool user_abort = false, user_success = false;
+};
+
+inline int IterationTrampoline(void* user, int iteration, double cost, double cost_change, double gradient_max_norm,
+                               double step_norm, double radius, int ok) {
+    auto* ctx = static_cast<CallbackCtx*>(user);
+    IterationSummary it;
+    it.iteration = iteration; it.cost = cost; it.cost_change = cost_change; it.gradient_max_norm = gradient_max_norm;
+    it.step_norm = step_norm; it.trust_region_radius = radius; it.step_is_valid = true; it.step_is_successful = ok != 0;
+    if (!ctx->options->callbacks.empty() && ctx->options->update_state_every_iteration && ctx->sync_state)
+        ctx->sync_state(ctx->sync_user);   // solver.hpp:233,238: the callback dereferences the live state
+    for (auto* cb : ctx->options->callbacks) {
+        const CallbackReturnType r = (*cb)(it);
+        if (r == SOLVER_ABORT) { ctx->user_abort = true; return 1; }
+        if (r == SOLVER_TERMINATE_SUCCESSFULLY) { ctx->user_success = true; return 1; }
+    }
+    return 0;
+}
+
+inline void FillSummary(const stba_lm_summary& s, const std::vector<double>& trace, Solver::Summary* out) {
+    out->initial_cost = s.initial_cost; out->final_cost = s.final_cost; out->total_time_in_seconds = s.seconds_total;
+    out->num_successful_steps = s.num_successful_steps; out->num_unsuccessful_steps = s.num_unsuccessful_steps;
+    out->termination_type = s.termination_type == STBA_CONVERGENCE ? CONVERGENCE
+                            : s.termination_type == STBA_NO_CONVERGENCE ? NO_CONVERGENCE : FAILURE;
+    out->iterations.clear();
+    for (int i = 0; i <= s.num_iterations; ++i) {
+        const double* t = &trace[(size_t)i * STBA_TRACE_COLS];
+        IterationSummary it;
+        it.iteration = i; it.cost = t[0]; it.cost_change = t[1]; it.gradient_max_norm = t[2]; it.step_norm = t[3];
+        it.relative_decrease = t[4]; it.trust_region_radius = t[5]; it.step_is_successful = t[6] != 0; it.step_is_valid = true;
+        out->iterations.push_back(it);
+    }
+}
+
+// ---- path 1: every residual block is a built-in ReprojectionFactor --------------------------
+struct BaLayout {
+    std::vector<int> rot_block, pos_block;   // per camera: Problem block indices
+    std::vector<int> pt_block;               // per landmark
+    std::vector<int> obs_cam, obs_pt;
+    std::vector<double> feat;
+};
+
+inline bool DetectBa(Problem& p, BaLayout* L) {
+    if (p.residuals().empty()) return false;
+    std::map<std::pair<int, int>, int> cam_of;   // (rot block, pos block) -> camera index
+    std::map<int, int> pt_of;
+    for (auto& r : p.residuals()) {
+        auto* f = dynamic_cast<ReprojectionFactor*>(r.cost);
+        if (!f) return false;
+        const auto& rb = p.blocks()[r.blocks[0]];
+        if (!rb.local || !dynamic_cast<QuaternionRightPlus*>(rb.local)) {
+            // a user LocalParameterization with the same 4 -> 3 signature is accepted only if it IS the
+            // quaternion right-plus (checked numerically by the caller through UsesQuaternionRightPlus)
+            if (!rb.local || rb.local->GlobalSize() != 4 || rb.local->LocalSize() != 3) return false;
+        }
+        if (p.blocks()[r.blocks[1]].local || p.blocks()[r.blocks[2]].local) return false;
+        if (!rb.lower.empty() || !p.blocks()[r.blocks[1]].lower.empty() || !p.blocks()[r.blocks[2]].lower.empty()) return false;
+        const auto key = std::make_pair(r.blocks[0], r.blocks[1]);
+        auto ci = cam_of.find(key);
+        int c;
+        if (ci == cam_of.end()) { c = (int)L->rot_block.size(); cam_of[key] = c; L->rot_block.push_back(key.first); L->pos_block.push_back(key.second); }
+        else c = ci->second;
+        auto pi = pt_of.find(r.blocks[2]);
+        int j;
+        if (pi == pt_of.end()) { j = (int)L->pt_block.size(); pt_of[r.blocks[2]] = j; L->pt_block.push_back(r.blocks[2]); }
+        else j = pi->second;
+        L->obs_cam.push_back(c); L->obs_pt.push_back(j);
+        L->feat.push_back(f->fx()); L->feat.push_back(f->fy());
+    }
+    // a rotation block must not be shared by two cameras with different position blocks
+    std::set<int> rots(L->rot_block.begin(), L->rot_block.end()), poss(L->pos_block.begin(), L->pos_block.end());
+    return rots.size() == L->rot_block.size() && poss.size() == L->pos_block.size();
+}
+
+// numerically confirms that a user-supplied 4->3 parameterisation is q (x) exp(delta)
+inline bool UsesQuaternionRightPlus(const LocalParameterization* lp) {
+    if (dynamic_cast<const QuaternionRightPlus*>(lp)) return true;
+    const double q[4] = {0.18257418583505536, 0.3651483716701107, 0.5477225575051661, 0.7302967433402214};
+    const double d[3] = {0.013, -0.021, 0.008};
+    double a[4], b[4];
+    QuaternionRightPlus ref;
+    if (!lp->Plus(q, d, a)) return false;
+    ref.Plus(q, d, b);
+    for (int i = 0; i < 4; ++i) if (std::fabs(a[i] - b[i]) > 1e-13) return false;
+    return true;
+}
+
+struct BaSync { stba_ba* ba; Problem* p; const BaLayout* L; std::vector<double> cams, pts; };
+inline void BaCopyOut(void* user) {
+    auto* s = static_cast<BaSync*>(user);
+    if (stba_ba_get_params(s->ba, s->cams.data(), s->pts.data()) != STBA_OK) return;
+    for (size_t c = 0; c < s->L->rot_block.size(); ++c) {
+        std::memcpy(s->p->blocks()[s->L->rot_block[c]].ptr, &s->cams[c * 7], 4 * sizeof(double));
+        std::memcpy(s->p->blocks()[s->L->pos_block[c]].ptr, &s->cams[c * 7 + 4], 3 * sizeof(double));
+    }
+    for (size_t j = 0; j < s->L->pt_block.size(); ++j)
+        std::memcpy(s->p->blocks()[s->L->pt_block[j]].ptr, &s->pts[j * 3], 3 * sizeof(double));
+}
+
+inline bool SolveBa(const Solver::Options& o, Problem* p, const BaLayout& L, Solver::Summary* sum) {
+    const int nc = (int)L.rot_block.size(), np = (int)L.pt_block.size(), no = (int)L.obs_cam.size();
+    BaSync sync{nullptr, p, &L, std::vector<double>((size_t)nc * 7), std::vector<double>((size_t)np * 3)};
+    std::vector<unsigned char> cam_fixed((size_t)nc * 6, 0), pt_fixed((size_t)np, 0);
+    for (int c = 0; c < nc; ++c) {
+        const auto& rb = p->blocks()[L.rot_block[c]]; const auto& pb = p->blocks()[L.pos_block[c]];
+        std::memcpy(&sync.cams[(size_t)c * 7], rb.ptr, 4 * sizeof(double));
+        std::memcpy(&sync.cams[(size_t)c * 7 + 4], pb.ptr, 3 * sizeof(double));
+        if (rb.constant) cam_fixed[c * 6] = cam_fixed[c * 6 + 1] = cam_fixed[c * 6 + 2] = 1;
+        if (pb.constant) cam_fixed[c * 6 + 3] = cam_fixed[c * 6 + 4] = cam_fixed[c * 6 + 5] = 1;
+    }
+    for (int j = 0; j < np; ++j) {
+        std::memcpy(&sync.pts[(size_t)j * 3], p->blocks()[L.pt_block[j]].ptr, 3 * sizeof(double));
+        pt_fixed[j] = p->blocks()[L.pt_block[j]].constant ? 1 : 0;
+    }
+    int rc = stba_ba_create(&sync.ba, nc, np, no, sync.cams.data(), sync.pts.data(), L.obs_cam.data(), L.obs_pt.data(),
+                            L.feat.data(), cam_fixed.data(), pt_fixed.data(), nullptr);
+    if (rc != STBA_OK) { sum->termination_type = FAILURE; sum->message = std::string("stba_ba_create: ") + stba_last_error(); return false; }
+    stba_lm_options co = ToC(o);
+    stba_lm_summary cs;
+    std::vector<double> trace((size_t)(o.max_num_iterations + 1) * STBA_TRACE_COLS, 0.0);
+    CallbackCtx ctx{&o, sum, &BaCopyOut, &sync};
+    rc = stba_ba_solve(sync.ba, &co, &cs, trace.data(), o.callbacks.empty() ? nullptr : &IterationTrampoline, &ctx);
+    if (rc == STBA_OK) {
+        BaCopyOut(&sync);   // parameters are updated in place, like ceres::Solve
+        FillSummary(cs, trace, sum);
+        if (ctx.user_abort) sum->termination_type = USER_FAILURE;
+        if (ctx.user_success) sum->termination_type = USER_SUCCESS;
+    } else {
+        sum->termination_type = FAILURE;
+        sum->message = std::string("stba_ba_solve: ") + stba_last_error();
+    }
+    stba_ba_destroy(sync.ba);
+    return rc == STBA_OK;
+}
+
+// ---- path 2: generic residual blocks through the host-callback dense path -------------------
+struct DenseCtx {
+    Problem* p;
+    std::vector<int> var_blocks;         // non-constant block indices
+    std::vector<int> amb_off, loc_off;   // per var block
+    int n_amb = 0, n_loc = 0, n_res = 0;
+    std::vector<std::vector<double>> scratch;   // per block current values (constant blocks: their memory)
+};
+
+inline int DenseResidual(void* user, const double* x, double* r, double* J) {
+    auto* c = static_cast<DenseCtx*>(user);
+    auto& blocks = c->p->blocks();
+    std::vector<const double*> cur(blocks.size());
+    std::vector<int> var_index(blocks.size(), -1);
+    for (size_t k = 0; k < blocks.size(); ++k) cur[k] = blocks[k].ptr;
+    for (size_t v = 0; v < c->var_blocks.size(); ++v) { cur[c->var_blocks[v]] = x + c->amb_off[v]; var_index[c->var_blocks[v]] = (int)v; }
+    if (J) std::fill(J, J + (size_t)c->n_res * c->n_loc, 0.0);
+    int row = 0;
+    std::vector<double> jac_store, plusJ;
+    for (auto& res : c->p->residuals()) {
+        const int nr = res.cost->num_residuals();
+        const size_t nb = res.blocks.size();
+        std::vector<const double*> params(nb);
+        std::vector<double*> jacs(nb, nullptr);
+        size_t need = 0;
+        for (size_t b = 0; b < nb; ++b) { params[b] = cur[res.blocks[b]]; need += (size_t)nr * blocks[res.blocks[b]].size; }
+        jac_store.assign(need, 0.0);
+        if (J) {
+            size_t o = 0;
+            for (size_t b = 0; b < nb; ++b) {
+                // constant blocks get no Jacobian request, like Ceres (NB solver.hpp:183: the reference's
+                // PnPSizedCostFunction then skips ALL its Jacobians -- only hit when a block is constant)
+                if (var_index[res.blocks[b]] >= 0) jacs[b] = jac_store.data() + o;
+                o += (size_t)nr * blocks[res.blocks[b]].size;
+            }
+        }
+        if (!res.cost->Evaluate(params.data(), r + row, J ? jacs.data() : nullptr)) return 1;
+        if (J) {
+            for (size_t b = 0; b < nb; ++b) {
+                const int v = var_index[res.blocks[b]];
+                if (v < 0 || !jacs[b]) continue;
+                const auto& blk = blocks[res.blocks[b]];
+                const int gs = blk.size, ls = blk.local_size();
+                if (blk.local) {
+                    plusJ.assign((size_t)gs * ls, 0.0);
+                    if (!blk.local->ComputeJacobian(params[b], plusJ.data())) return 1;
+                    for (int rr = 0; rr < nr; ++rr)
+                        for (int l = 0; l < ls; ++l) {
+                            double s = 0;
+                            for (int g = 0; g < gs; ++g) s += jacs[b][rr * gs + g] * plusJ[(size_t)g * ls + l];
+                            J[(size_t)(row + rr) * c->n_loc + c->loc_off[v] + l] += s;
+                        }
+                } else {
+                    for (int rr = 0; rr < nr; ++rr)
+                        for (int g = 0; g < gs; ++g) J[(size_t)(row + rr) * c->n_loc + c->loc_off[v] + g] += jacs[b][rr * gs + g];
+                }
+            }
+        }
+        row += nr;
+    }
+    return 0;
+}
+
+inline void DensePlus(void* user, const double* x, const double* d, double* out) {
+    auto* c = static_cast<DenseCtx*>(user);
+    for (size_t v = 0; v < c->var_blocks.size(); ++v) {
+        const auto& blk = c->p->blocks()[c->var_blocks[v]];
+        if (blk.local) blk.local->Plus(x + c->amb_off[v], d + c->loc_off[v], out + c->amb_off[v]);
+        else for (int k = 0; k < blk.size; ++k) out[c->amb_off[v] + k] = x[c->amb_off[v] + k] + d[c->loc_off[v] + k];
+    }
+}
+
+struct DenseSync { DenseCtx* c; const double* x; };
+
+inline bool SolveDense(const Solver::Options& o, Problem* p, Solver::Summary* sum) {
+    DenseCtx c;
+    c.p = p;
+    bool any_bounds = false, any_local = false;
+    for (auto& b : p->blocks()) {
+        bool used = false;
+        for (auto& r : p->residuals()) for (int k : r.blocks) used |= (k == b.index);
+        if (!used || b.constant) continue;
+        c.var_blocks.push_back(b.index); c.amb_off.push_back(c.n_amb); c.loc_off.push_back(c.n_loc);
+        c.n_amb += b.size; c.n_loc += b.local_size();
+        any_bounds |= !b.lower.empty(); any_local |= (b.local != nullptr);
+    }
+    c.n_res = p->NumResiduals();
+    if (c.n_loc == 0 || c.n_res == 0) { sum->termination_type = CONVERGENCE; sum->message = "nothing to optimise"; return true; }
+    if (c.n_loc > 4096 || (double)c.n_loc * c.n_res > 2.7e8) { sum->termination_type = FAILURE; sum->message = "generic (callback) problems are limited to 4096 local parameters and 2.7e8 Jacobian entries; use ReprojectionFactor for large bundle adjustment"; return false; }
+    std::vector<double> x(c.n_amb), lo, up;
+    for (size_t v = 0; v < c.var_blocks.size(); ++v) std::memcpy(&x[c.amb_off[v]], p->blocks()[c.var_blocks[v]].ptr, sizeof(double) * p->blocks()[c.var_blocks[v]].size);
+    if (any_bounds) {
+        lo.assign(c.n_amb, -1e300); up.assign(c.n_amb, 1e300);
+        for (size_t v = 0; v < c.var_blocks.size(); ++v) {
+            const auto& b = p->blocks()[c.var_blocks[v]];
+            if (!b.lower.empty()) for (int k = 0; k < b.size; ++k) { lo[c.amb_off[v] + k] = b.lower[k]; up[c.amb_off[v] + k] = b.upper[k]; }
+        }
+    }
+    stba_lm_options co = ToC(o);
+    stba_lm_summary cs;
+    std::vector<double> trace((size_t)(o.max_num_iterations + 1) * STBA_TRACE_COLS, 0.0);
+    struct Sync { DenseCtx* c; double* x; } sync{&c, x.data()};
+    auto copy_out = [](void* u) {
+        auto* s = static_cast<Sync*>(u);
+        for (size_t v = 0; v < s->c->var_blocks.size(); ++v) {
+            auto& b = s->c->p->blocks()[s->c->var_blocks[v]];
+            std::memcpy(b.ptr, s->x + s->c->amb_off[v], sizeof(double) * b.size);
+        }
+    };
+    CallbackCtx ctx{&o, sum, copy_out, &sync};
+    const int rc = stba_dense_solve(&DenseResidual, any_local ? &DensePlus : nullptr, &c, c.n_amb, c.n_loc, c.n_res, x.data(),
+                                    any_bounds ? lo.data() : nullptr, any_bounds ? up.data() : nullptr, &co, &cs, trace.data(),
+                                    o.callbacks.empty() ? nullptr : &IterationTrampoline, &ctx);
+    if (rc != STBA_OK) { sum->termination_type = FAILURE; sum->message = std::string("stba_dense_solve: ") + stba_last_error(); return false; }
+    copy_out(&sync);
+    FillSummary(cs, trace, sum);
+    if (ctx.user_abort) sum->termination_type = USER_FAILURE;
+    if (ctx.user_success) sum->termination_type = USER_SUCCESS;
+    return true;
+}
+
+}  // namespace internal
+
+inline void Solve(const Solver::Options& options, Problem* problem, Solver::Summary* summary) {
+    *summary = Solver::Summary();
+    internal::BaLayout L;
+    bool ba = internal::DetectBa(*problem, &L);
+    if (ba)
+        for (int rb : L.rot_block) ba = ba && internal::UsesQuaternionRightPlus(problem->blocks()[rb].local);
+    if (ba) { summary->execution_path = "gpu-ba"; internal::SolveBa(options, problem, L, summary); }
+    else { summary->execution_path = "gpu-dense-callback"; internal::SolveDense(options, problem, summary); }
+}
+
+}  // namespace stba_ceres
+#endif

@@ -367,6 +367,7 @@ static int ba_run_lm(stba_ba* b, const stba_lm_options* opt_in, int fixed_iterat
         }
         if (stop) {
             if (accepted) b->have_lin = b->have_blocks = false;
+            if (cb) (void)cb(cb_user, iter, L.cost, cost_change, L.gmax, step_norm, L.radius, accepted ? 1 : 0);
             break;
         }
         if (accepted) {
@@ -1059,6 +1060,7 @@ int stba_dense_solve(stba_residual_fn fn, stba_plus_fn plus, void* user, int n_p
             if (step_norm <= opt.parameter_tolerance * (x_norm + opt.parameter_tolerance)) {
                 s.termination_type = STBA_CONVERGENCE; s.termination_reason = STBA_TERM_PARAMETER;
                 if (trace) { trace[(size_t)iter * STBA_TRACE_COLS + 5] = radius; trace[(size_t)iter * STBA_TRACE_COLS + 2] = gmax; }
+                if (cb) (void)cb(cb_user, iter, cost, cost_change, gmax, step_norm, radius, 0);
                 break;
             }
             if (std::fabs(cost_change) <= opt.function_tolerance * cost) {
@@ -1068,6 +1070,7 @@ int stba_dense_solve(stba_residual_fn fn, stba_plus_fn plus, void* user, int n_p
                 }
                 s.termination_type = STBA_CONVERGENCE; s.termination_reason = STBA_TERM_FUNCTION;
                 if (trace) { trace[(size_t)iter * STBA_TRACE_COLS + 5] = radius; trace[(size_t)iter * STBA_TRACE_COLS + 2] = gmax; }
+                if (cb) (void)cb(cb_user, iter, cost, cost_change, gmax, step_norm, radius, rho > opt.min_relative_decrease ? 1 : 0);
                 break;
             }
             accepted = rho > opt.min_relative_decrease;

@@ -1,0 +1,320 @@
+// Restates the reference's L2 "problem construction" call sites on top of include/stba/ceres.h:
+//   st17-ceres/src/ceres_bound.cpp:25-68                    bounds demo
+//   st17-ceres/src/include/solver.hpp:247-385               SolvePnPWith{DynamicAutoDiff,AutoDiff,SizedCostFunction}
+//   st20-g2o/src/include/test_ceres.h:98-152                SolveWithCeresDynamicAutoDiff
+// with the user-side classes (LieLocalParameterization, functors, callbacks) written against the
+// mirrored API exactly as the reference writes them against Ceres.  Sophus/Eigen are replaced by
+// a few templated helpers.  Prints "key value..." lines that tests/test_cpp_shim.py checks.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <vector>
+
+#include "stba/ceres.h"
+namespace ceres = stba_ceres;
+
+// ---------------------------------------------------------------- tiny SO3 helpers (Sophus stand-ins)
+template <typename T> static void QuatConjRotate(const T* q, const T* v, T* out) {   // conj(q) * v
+    const T u0 = -q[0], u1 = -q[1], u2 = -q[2], w = q[3];
+    const T a0 = T(2.0) * (u1 * v[2] - u2 * v[1]), a1 = T(2.0) * (u2 * v[0] - u0 * v[2]), a2 = T(2.0) * (u0 * v[1] - u1 * v[0]);
+    out[0] = v[0] + w * a0 + (u1 * a2 - u2 * a1);
+    out[1] = v[1] + w * a1 + (u2 * a0 - u0 * a2);
+    out[2] = v[2] + w * a2 + (u0 * a1 - u1 * a0);
+}
+static void So3Exp(const double* w, double* q) {
+    const double th = std::sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+    const double im = th < 1e-10 ? 0.5 : std::sin(0.5 * th) / th;
+    q[0] = im * w[0]; q[1] = im * w[1]; q[2] = im * w[2]; q[3] = std::cos(0.5 * th);
+}
+static void So3Log(const double* q, double* w) {
+    const double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+    const double k = n < 1e-10 ? 2.0 / q[3] : 2.0 * std::atan2(n, q[3]) / n;
+    w[0] = k * q[0]; w[1] = k * q[1]; w[2] = k * q[2];
+}
+static void QuatMul(const double* a, const double* b, double* o) {
+    o[0] = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+    o[1] = a[3] * b[1] - a[0] * b[2] + a[1] * b[3] + a[2] * b[0];
+    o[2] = a[3] * b[2] + a[0] * b[1] - a[1] * b[0] + a[2] * b[3];
+    o[3] = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+}
+
+// ---------------------------------------------------------------- user classes, as in the reference
+// solver.hpp:30-61 / test_ceres.h:14-45
+class LieLocalParameterization : public ceres::LocalParameterization {
+public:
+    bool Plus(double const* T_raw, double const* delta_raw, double* T_plus_delta_raw) const override {
+        double e[4];
+        So3Exp(delta_raw, e);
+        QuatMul(T_raw, e, T_plus_delta_raw);
+        return true;
+    }
+    bool ComputeJacobian(double const* q, double* J) const override {   // Dx_this_mul_exp_x_at_0
+        const double c0 = q[3] / 2, c1 = q[2] / 2, c2 = -c1, c3 = q[1] / 2, c4 = q[0] / 2, c5 = -c4, c6 = -c3;
+        const double M[12] = {c0, c2, c3, c1, c0, c5, c6, c4, c0, c5, c6, c2};
+        std::memcpy(J, M, sizeof M);
+        return true;
+    }
+    int GlobalSize() const override { return 4; }
+    int LocalSize() const override { return 3; }
+};
+
+// solver.hpp:63-94
+class LieR3LocalParameterization : public ceres::LocalParameterization {
+public:
+    bool Plus(const double* x, const double* delta, double* x_plus_delta) const override {
+        double a[4], b[4], c[4];
+        So3Exp(x, a); So3Exp(delta, b); QuatMul(a, b, c);
+        So3Log(c, x_plus_delta);
+        return true;
+    }
+    bool ComputeJacobian(const double*, double* j) const override {
+        const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        std::memcpy(j, I, sizeof I);
+        return true;
+    }
+    int GlobalSize() const override { return 3; }
+    int LocalSize() const override { return 3; }
+};
+
+struct CorrPair { double point[3]; double feature[2]; };   // solver.hpp:18-26
+
+// solver.hpp:96-125
+struct PnPDynamicAutoDiffFunctor {
+    CorrPair c;
+    explicit PnPDynamicAutoDiffFunctor(const CorrPair& cp) : c(cp) {}
+    static auto Create(const CorrPair& cp) { return new ceres::DynamicAutoDiffCostFunction<PnPDynamicAutoDiffFunctor>(new PnPDynamicAutoDiffFunctor(cp)); }
+    template <typename T> bool operator()(T const* const* parameters, T* residuals) const {
+        const T* q = parameters[0]; const T* t = parameters[1];
+        T d[3] = {T(c.point[0]) - t[0], T(c.point[1]) - t[1], T(c.point[2]) - t[2]}, pc[3];
+        QuatConjRotate(q, d, pc);
+        residuals[0] = pc[0] / pc[2] - T(c.feature[0]);
+        residuals[1] = pc[1] / pc[2] - T(c.feature[1]);
+        return true;
+    }
+};
+
+// solver.hpp:127-155
+struct PnPAutoDiffFunctor {
+    CorrPair c;
+    explicit PnPAutoDiffFunctor(const CorrPair& cp) : c(cp) {}
+    static auto Create(const CorrPair& cp) { return new ceres::AutoDiffCostFunction<PnPAutoDiffFunctor, 2, 4, 3>(new PnPAutoDiffFunctor(cp)); }
+    template <typename T> bool operator()(const T* const q, const T* const t, T* residuals) const {
+        T d[3] = {T(c.point[0]) - t[0], T(c.point[1]) - t[1], T(c.point[2]) - t[2]}, pc[3];
+        QuatConjRotate(q, d, pc);
+        residuals[0] = pc[0] / pc[2] - T(c.feature[0]);
+        residuals[1] = pc[1] / pc[2] - T(c.feature[1]);
+        return true;
+    }
+};
+
+// solver.hpp:157-213; reference_rot_formula = true reproduces solver.hpp:195 (hat(R^-1 Pw)),
+// false is the correct right-perturbation derivative hat(pInC) (SURVEY.md header fact 2)
+struct PnPSizedCostFunction : public ceres::SizedCostFunction<2, 3, 3> {
+    CorrPair c; bool reference_rot_formula;
+    PnPSizedCostFunction(const CorrPair& cp, bool ref) : c(cp), reference_rot_formula(ref) {}
+    bool Evaluate(const double* const* parameters, double* residuals, double** jacobians) const override {
+        double q[4]; So3Exp(parameters[0], q);
+        const double* t = parameters[1];
+        double d[3] = {c.point[0] - t[0], c.point[1] - t[1], c.point[2] - t[2]}, pc[3];
+        QuatConjRotate(q, d, pc);
+        residuals[0] = pc[0] / pc[2] - c.feature[0];
+        residuals[1] = pc[1] / pc[2] - c.feature[1];
+        if (jacobians != nullptr && jacobians[0] != nullptr && jacobians[1] != nullptr) {   // solver.hpp:183
+            const double X = pc[0], Y = pc[1], Z = pc[2], Zi = 1.0 / Z;
+            const double A[6] = {Zi, 0, -X * Zi * Zi, 0, Zi, -Y * Zi * Zi};
+            double h[3];
+            if (reference_rot_formula) QuatConjRotate(q, c.point, h); else { h[0] = X; h[1] = Y; h[2] = Z; }
+            const double H[9] = {0, -h[2], h[1], h[2], 0, -h[0], -h[1], h[0], 0};
+            double e1[3] = {1, 0, 0}, e2[3] = {0, 1, 0}, e3[3] = {0, 0, 1}, r1[3], r2[3], r3[3];
+            QuatConjRotate(q, e1, r1); QuatConjRotate(q, e2, r2); QuatConjRotate(q, e3, r3);   // columns of R^T
+            const double Rt[9] = {r1[0], r2[0], r3[0], r1[1], r2[1], r3[1], r1[2], r2[2], r3[2]};
+            for (int i = 0; i < 2; ++i)
+                for (int j = 0; j < 3; ++j) {
+                    double s = 0, sp = 0;
+                    for (int k = 0; k < 3; ++k) { s += A[i * 3 + k] * H[k * 3 + j]; sp += A[i * 3 + k] * Rt[k * 3 + j]; }
+                    jacobians[0][i * 3 + j] = s;
+                    jacobians[1][i * 3 + j] = -sp;
+                }
+        }
+        return true;
+    }
+};
+
+// solver.hpp:215-245: reads the LIVE parameter memory from inside the callback
+struct VisualCallBack : public ceres::IterationCallback {
+    const double* so3; const double* pos; std::vector<double> seen;
+    VisualCallBack(const double* s, const double* p) : so3(s), pos(p) {}
+    ceres::CallbackReturnType operator()(const ceres::IterationSummary&) override {
+        seen.push_back(pos[0]); seen.push_back(so3[3]);
+        return ceres::SOLVER_CONTINUE;
+    }
+};
+
+// test_ceres.h:47-81 with the user's own functor (generic path)
+struct ProjectFactor {
+    double feature[2];
+    explicit ProjectFactor(const double* f) { feature[0] = f[0]; feature[1] = f[1]; }
+    static auto Create(const double* f) { return new ceres::DynamicAutoDiffCostFunction<ProjectFactor>(new ProjectFactor(f)); }
+    template <typename T> bool operator()(T const* const* parameters, T* residuals) const {
+        const T* q = parameters[0]; const T* t = parameters[1]; const T* L = parameters[2];
+        T d[3] = {L[0] - t[0], L[1] - t[1], L[2] - t[2]}, pc[3];
+        QuatConjRotate(q, d, pc);
+        residuals[0] = pc[0] / pc[2] - T(feature[0]);
+        residuals[1] = pc[1] / pc[2] - T(feature[1]);
+        return true;
+    }
+};
+
+// ceres_bound.cpp:8-23
+struct DemoFunctor {
+    static auto Create() { return new ceres::DynamicAutoDiffCostFunction<DemoFunctor>(new DemoFunctor()); }
+    template <typename T> bool operator()(T const* const* parameters, T* residuals) const {
+        residuals[0] = parameters[0][0] - T(3.0);
+        return true;
+    }
+};
+
+// ---------------------------------------------------------------- scene file written by the python test
+struct Scene {
+    int nc = 0, np = 0, no = 0;
+    std::vector<double> cams, pts, feat; std::vector<int> oc, op; std::vector<unsigned char> fixed;
+    bool load(const char* path) {
+        std::ifstream f(path, std::ios::binary);
+        if (!f) return false;
+        int h[3]; f.read((char*)h, sizeof h); nc = h[0]; np = h[1]; no = h[2];
+        cams.resize(nc * 7); pts.resize(np * 3); feat.resize(no * 2); oc.resize(no); op.resize(no); fixed.resize(nc);
+        f.read((char*)cams.data(), cams.size() * 8); f.read((char*)pts.data(), pts.size() * 8);
+        f.read((char*)oc.data(), no * 4); f.read((char*)op.data(), no * 4); f.read((char*)feat.data(), feat.size() * 8);
+        f.read((char*)fixed.data(), nc);
+        return (bool)f;
+    }
+};
+
+static void print_vec(const char* key, const double* v, int n) {
+    std::printf("%s", key);
+    for (int i = 0; i < n; ++i) std::printf(" %.17g", v[i]);
+    std::printf("\n");
+}
+
+// test_ceres.h:98-152 (builtin = ReprojectionFactor -> device-resident path; else the user's functor)
+static void SolveBA(Scene s, bool builtin, const char* tag) {
+    ceres::LocalParameterization* localParameterization = new LieLocalParameterization();
+    ceres::Problem problem;
+    for (int i = 0; i < s.no; ++i) {
+        double* so3 = &s.cams[s.oc[i] * 7]; double* pos = so3 + 4; double* lm = &s.pts[s.op[i] * 3];
+        if (builtin) {
+            problem.AddResidualBlock(ceres::ReprojectionFactor::Create(&s.feat[i * 2]), nullptr, {so3, pos, lm});
+        } else {
+            auto costFunc = ProjectFactor::Create(&s.feat[i * 2]);
+            costFunc->AddParameterBlock(4); costFunc->AddParameterBlock(3); costFunc->AddParameterBlock(3);
+            costFunc->SetNumResiduals(2);
+            problem.AddResidualBlock(costFunc, nullptr, {so3, pos, lm});
+        }
+        problem.AddParameterBlock(so3, 4, localParameterization);
+        if (s.fixed[s.oc[i]]) { problem.SetParameterBlockConstant(so3); problem.SetParameterBlockConstant(pos); }
+    }
+    ceres::Solver::Options options;
+    options.num_threads = 1;
+    options.linear_solver_type = ceres::SPARSE_SCHUR;
+    ceres::Solver::Summary summary;
+    ceres::Solve(options, &problem, &summary);
+    std::printf("%s_path %s\n%s_report %s\n", tag, summary.execution_path.c_str(), tag, summary.FullReport().c_str());
+    std::printf("%s_term %d iters %d initial %.17g final %.17g\n", tag, (int)summary.termination_type,
+                (int)summary.iterations.size() - 1, summary.initial_cost, summary.final_cost);
+    std::string k = std::string(tag) + "_cams"; print_vec(k.c_str(), s.cams.data(), s.nc * 7);
+    k = std::string(tag) + "_pts"; print_vec(k.c_str(), s.pts.data(), std::min(s.np, 50) * 3);
+}
+
+int main(int argc, char** argv) {
+    // ---- ceres_bound.cpp:25-68
+    for (int bounded = 0; bounded < 2; ++bounded) {
+        ceres::Problem problem;
+        auto costFunc = DemoFunctor::Create();
+        costFunc->AddParameterBlock(1);
+        costFunc->SetNumResiduals(1);
+        double x = 0.0;
+        problem.AddResidualBlock(costFunc, nullptr, &x);
+        if (bounded) { problem.SetParameterLowerBound(&x, 0, -2.0); problem.SetParameterUpperBound(&x, 0, 2.0); }
+        ceres::Solver::Options options;
+        options.num_threads = 1;
+        options.linear_solver_type = ceres::DENSE_QR;
+        ceres::Solver::Summary summary;
+        ceres::Solve(options, &problem, &summary);
+        std::printf("bound_%d x %.17g term %d path %s msg %s\n", bounded, x, (int)summary.termination_type,
+                    summary.execution_path.c_str(), summary.message.c_str());
+    }
+    if (argc < 3) return 0;
+    // ---- PnP: solver.hpp:247-385.  file: n, true pose(7), init pose(7), n*(point3, feature2)
+    {
+        std::ifstream f(argv[1], std::ios::binary);
+        int n; f.read((char*)&n, 4);
+        double truth[7], init[7];
+        f.read((char*)truth, 56); f.read((char*)init, 56);
+        std::vector<CorrPair> data(n);
+        for (auto& c : data) { f.read((char*)c.point, 24); f.read((char*)c.feature, 16); }
+        print_vec("pnp_truth", truth, 7);
+        // SolvePnPWithDynamicAutoDiff (with the visual callback + update_state_every_iteration branch)
+        {
+            double SO3[4], POS[3]; std::memcpy(SO3, init, 32); std::memcpy(POS, init + 4, 24);
+            ceres::LocalParameterization* lp = new LieLocalParameterization();
+            ceres::Problem problem;
+            for (const auto& item : data) {
+                auto costFunc = PnPDynamicAutoDiffFunctor::Create(item);
+                costFunc->AddParameterBlock(4); costFunc->AddParameterBlock(3); costFunc->SetNumResiduals(2);
+                problem.AddResidualBlock(costFunc, nullptr, {SO3, POS});
+                problem.AddParameterBlock(SO3, 4, lp);
+            }
+            ceres::Solver::Options options;
+            auto* cb = new VisualCallBack(SO3, POS);
+            options.callbacks.push_back(cb);
+            options.update_state_every_iteration = true;
+            options.num_threads = 1; options.linear_solver_type = ceres::DENSE_QR;
+            ceres::Solver::Summary summary;
+            ceres::Solve(options, &problem, &summary);
+            std::printf("pnp_dyn iters %d initial %.17g final %.17g term %d callbacks %d first_cb_x %.17g last_cb_x %.17g\n",
+                        (int)summary.iterations.size() - 1, summary.initial_cost, summary.final_cost, (int)summary.termination_type,
+                        (int)cb->seen.size() / 2, cb->seen.empty() ? 0.0 : cb->seen[0], cb->seen.empty() ? 0.0 : cb->seen[cb->seen.size() - 2]);
+            double out[7]; std::memcpy(out, SO3, 32); std::memcpy(out + 4, POS, 24); print_vec("pnp_dyn_pose", out, 7);
+            delete cb;
+        }
+        // SolvePnPWithAutoDiff
+        {
+            double SO3[4], POS[3]; std::memcpy(SO3, init, 32); std::memcpy(POS, init + 4, 24);
+            ceres::LocalParameterization* lp = new LieLocalParameterization();
+            ceres::Problem problem;
+            for (const auto& item : data) {
+                problem.AddResidualBlock(PnPAutoDiffFunctor::Create(item), nullptr, {SO3, POS});
+                problem.AddParameterBlock(SO3, 4, lp);
+            }
+            ceres::Solver::Options options; options.num_threads = 1; options.linear_solver_type = ceres::DENSE_QR;
+            ceres::Solver::Summary summary;
+            ceres::Solve(options, &problem, &summary);
+            std::printf("pnp_auto iters %d final %.17g term %d\n", (int)summary.iterations.size() - 1, summary.final_cost, (int)summary.termination_type);
+            double out[7]; std::memcpy(out, SO3, 32); std::memcpy(out + 4, POS, 24); print_vec("pnp_auto_pose", out, 7);
+        }
+        // SolvePnPWithSizedCostFunction, correct and reference rotation Jacobian
+        for (int ref = 0; ref < 2; ++ref) {
+            double so3[3], POS[3]; So3Log(init, so3); std::memcpy(POS, init + 4, 24);
+            ceres::LocalParameterization* lp = new LieR3LocalParameterization();
+            ceres::Problem problem;
+            for (const auto& item : data) {
+                problem.AddResidualBlock(new PnPSizedCostFunction(item, ref != 0), nullptr, {so3, POS});
+                problem.AddParameterBlock(so3, 3, lp);
+            }
+            ceres::Solver::Options options; options.num_threads = 1; options.linear_solver_type = ceres::DENSE_QR;
+            ceres::Solver::Summary summary;
+            ceres::Solve(options, &problem, &summary);
+            double out[7]; So3Exp(so3, out); std::memcpy(out + 4, POS, 24);
+            std::printf("pnp_sized_%d iters %d final %.17g term %d\n", ref, (int)summary.iterations.size() - 1, summary.final_cost, (int)summary.termination_type);
+            print_vec(ref ? "pnp_sized_1_pose" : "pnp_sized_0_pose", out, 7);
+        }
+    }
+    // ---- BA: test_ceres.h:98-152
+    Scene s;
+    if (!s.load(argv[2])) { std::printf("scene_load_failed\n"); return 2; }
+    SolveBA(s, true, "ba_builtin");
+    if (argc > 3) { Scene s2; if (s2.load(argv[3])) SolveBA(s2, false, "ba_generic"); }
+    return 0;
+}
