@@ -15,7 +15,6 @@ across ranks, the cameras are replicated, and one RCCL all-reduce per build carr
 camera system (strong scaling: the problem is fixed).  Rank 0 prints ONE JSON line.
 """
 import argparse
-import ctypes
 import importlib
 import json
 import os
@@ -54,17 +53,6 @@ def load_scene(args, rank):
     return s
 
 
-def shard_landmarks(obs_pt, n_pts, world):
-    """contiguous landmark ranges balanced by observation count"""
-    cnt = np.bincount(obs_pt, minlength=n_pts)
-    csum = np.concatenate([[0], np.cumsum(cnt)])
-    cuts = [0]
-    for r in range(1, world):
-        cuts.append(int(np.searchsorted(csum, csum[-1] * r / world)))
-    cuts.append(n_pts)
-    return cuts
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -97,20 +85,13 @@ def main():
 
     s = load_scene(args, rank)
     n_cams, n_pts, n_obs = len(s["cams0"]), len(s["pts0"]), len(s["obs_cam"])
-    cuts = shard_landmarks(s["obs_pt"], n_pts, world)
-    lo, hi = cuts[rank], cuts[rank + 1]
-    m = (s["obs_pt"] >= lo) & (s["obs_pt"] < hi)
+    sharding = importlib.import_module("slam-tricks_amd.sharding")
+    sh = sharding.make_shard(s, rank, world)
     stream = torch.cuda.current_stream().cuda_stream if torch.cuda.is_available() else None
-    eng = st.BAEngine(s["cams0"], s["pts0"][lo:hi], s["obs_cam"][m], s["obs_pt"][m] - lo, s["obs_feat"][m],
-                      s["cam_fixed"], stream=stream)
+    eng = st.BAEngine(sh["cams0"], sh["pts0"], sh["obs_cam"], sh["obs_pt"], sh["obs_feat"], sh["cam_fixed"],
+                      stream=stream)
     if world > 1:
-        def allreduce(_user, buf, count, _stream):
-            # zero-copy torch view of the engine-owned device buffer; RCCL sum on the current stream
-            # (the engine enqueues on that same stream, so ordering needs no extra events)
-            t = torch.as_tensor(_DevBuf(buf, count), device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.SUM)
-            return 0
-        eng.set_allreduce(allreduce, rank, world)
+        eng.set_allreduce(sharding.torch_allreduce_hook(dist, torch), rank, world)
 
     def sync():
         if torch.cuda.is_available():
@@ -151,7 +132,7 @@ def main():
     if rank == 0:
         # ---- roofline legs, measured live with hipEvents on the engine's stream
         ms_jac = eng.time_linearize(20)
-        local_obs = int(m.sum())
+        local_obs = len(sh["obs_cam"])
         jac_bytes = BYTES_PER_OBS_JAC * local_obs
         jac_gbs = jac_bytes / (ms_jac * 1e-3) / 1e9
         prof = st.cholesky_profile(6 * n_cams)
@@ -200,14 +181,6 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-
-
-class _DevBuf:
-    """__cuda_array_interface__ view of a raw device pointer owned by the engine (FP64 vector)"""
-
-    def __init__(self, ptr, count):
-        self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": "<f8", "data": (int(ptr), False),
-                                         "version": 2, "strides": None}
 
 
 if __name__ == "__main__":

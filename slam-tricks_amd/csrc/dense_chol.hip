@@ -521,9 +521,9 @@ static int chol_run(double* A, int lda, int n, double* x_dev, int* flag_dev, hip
         // look-ahead schedule: the panel of step b+1 (diagonal block + panel solve, on `st`) overlaps
         // the bulk of the trailing update of step b (on a side stream); only the update of the
         // next panel's tile column sits on the critical path.
-        static hipStream_t su = nullptr;
-        static std::vector<hipEvent_t> evP, evN;
-        static hipEvent_t evU = nullptr;
+        static thread_local hipStream_t su = nullptr;
+        static thread_local std::vector<hipEvent_t> evP, evN;
+        static thread_local hipEvent_t evU = nullptr;
         if (!su) {
             // bulk trailing updates run at the LOWEST priority so that panel kernels win dispatch slots
             int lo_prio = 0, hi_prio = 0;
