@@ -1,0 +1,15 @@
+"""runs only the residual+Jacobian kernel on the C5 problem (for PMC counter passes)"""
+import importlib, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+st = importlib.import_module("slam-tricks_amd")
+scenes = importlib.import_module("slam-tricks_amd.scenes")
+cache = os.path.join(os.environ.get("TMPDIR", "/tmp"), "stba_scene_c1000_p100000_m10_s20.npz")
+if os.path.exists(cache):
+    z = np.load(cache); s = {k: z[k] for k in z.files}
+else:
+    s = scenes.st20_scene(n_cams=1000, n_pts=100000, max_obs_per_pt=10, seed=20, pix_noise=1e-3)
+    np.savez(cache, **s)
+e = st.BAEngine(s["cams0"], s["pts0"], s["obs_cam"], s["obs_pt"], s["obs_feat"], s["cam_fixed"])
+print("ms per launch", e.time_linearize(int(sys.argv[1]) if len(sys.argv) > 1 else 5))
