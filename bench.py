@@ -138,8 +138,18 @@ def main():
         prof = st.cholesky_profile(6 * n_cams)
         syrk_tflops = prof["syrk_flops"] / (prof["ms_syrk"] * 1e-3) / 1e12 if prof["ms_syrk"] > 0 else 0.0
         chol_total_ms = prof["ms_diag"] + prof["ms_trsm"] + prof["ms_syrk"] + prof["ms_bwd"]
+        # HBM bytes per launch from the PMC passes (tools/pmc_jacobian.sh -> profiles/pmc_jacobian.json);
+        # only valid for the C5 shape it was collected on
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_jacobian.json")) as f:
+                pj = json.load(f)
+            if local_obs == 1000000:
+                traffic = pj["hbm_bytes_per_launch"]
+        except Exception:
+            pass
         roof_jac = {"kernel": "ba_linearize_kernel<cams-in-LDS, with-Jacobian>", "bound": "hbm", "achieved": jac_gbs,
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": jac_gbs / HBM_PEAK_GBS, "traffic": None,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": jac_gbs / HBM_PEAK_GBS, "traffic": traffic,
                     "ms_per_launch": ms_jac, "algorithmic_bytes_per_launch": jac_bytes}
         roof_syrk = {"kernel": "chol_syrk_kernel (v_mfma_f64_16x16x4_f64)", "bound": "mfma", "achieved": syrk_tflops,
                      "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": syrk_tflops / FP64_MFMA_PEAK_TFLOPS,
