@@ -10,6 +10,7 @@ Import with  importlib.import_module("slam-tricks_amd")  (the hyphen is the repo
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -75,6 +76,16 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"{LIB_PATH} is missing: run `python __graft_entry__.py build` "
                               "(hipcc, gfx950).  There is no CPU fallback.")
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.  If libstba (linked
+        # against /opt/rocm) were loaded first and torch imported later, two runtimes would coexist
+        # and torch.cuda would report "No HIP GPUs are available".  Importing torch first makes
+        # libstba bind to the runtime torch already loaded (same soname).  Opt out with
+        # STBA_NO_TORCH_PRELOAD=1 (pure C/C++ hosts never see this: they link /opt/rocm directly).
+        if "torch" not in sys.modules and os.environ.get("STBA_NO_TORCH_PRELOAD", "0") != "1":
+            try:
+                import torch  # noqa: F401
+            except Exception:
+                pass
         L = C.CDLL(LIB_PATH)
         L.stba_status_string.restype = C.c_char_p
         L.stba_last_error.restype = C.c_char_p

@@ -16,6 +16,8 @@
 //   Hpp6   [n_pts][6] (xx xy xz yy yz zz), gp [n_pts][3], Hinv6 [n_pts][6]
 //   Hcc    [n_cams][36], gc [n_cams][6]
 //   S      [lda][lda] dense reduced camera system (lower triangle), lda = padded 6*n_cams
+#include <algorithm>
+
 #include "ba_kernels.hpp"
 
 namespace stba {
@@ -177,25 +179,45 @@ int launch_sum_partials(const double* partial, int n, int stride, int K, double*
     return STBA_OK;
 }
 
-// max |v[i]| over n entries -> out[0] (single workgroup, grid-stride)
-__global__ __launch_bounds__(1024) void absmax_kernel(const double* __restrict__ v, size_t n,
-                                                      const double* __restrict__ v2, size_t n2,
-                                                      double* __restrict__ out) {
-    __shared__ double s[1024];
+// max |v[i]| over n (+ n2) entries -> out[0]: grid-stride partial maxima, last block finishes
+// (max is order-independent, so this stays deterministic)
+__global__ __launch_bounds__(256) void absmax_partial_kernel(const double* __restrict__ v, size_t n,
+                                                             const double* __restrict__ v2, size_t n2,
+                                                             double* __restrict__ partial) {
+    __shared__ double s[256];
     double m = 0.0;
-    for (size_t i = threadIdx.x; i < n; i += 1024) m = fmax(m, fabs(v[i]));
-    for (size_t i = threadIdx.x; i < n2; i += 1024) m = fmax(m, fabs(v2[i]));
+    const size_t stride = (size_t)gridDim.x * 256, i0 = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (size_t i = i0; i < n; i += stride) m = fmax(m, fabs(v[i]));
+    for (size_t i = i0; i < n2; i += stride) m = fmax(m, fabs(v2[i]));
     s[threadIdx.x] = m;
     __syncthreads();
-    for (int off = 512; off > 0; off >>= 1) {
+    for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) s[threadIdx.x] = fmax(s[threadIdx.x], s[threadIdx.x + off]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = s[0];
+}
+
+__global__ __launch_bounds__(256) void absmax_final_kernel(const double* __restrict__ partial, int n,
+                                                           double* __restrict__ out) {
+    __shared__ double s[256];
+    double m = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) m = fmax(m, partial[i]);
+    s[threadIdx.x] = m;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
         if (threadIdx.x < off) s[threadIdx.x] = fmax(s[threadIdx.x], s[threadIdx.x + off]);
         __syncthreads();
     }
     if (threadIdx.x == 0) out[0] = s[0];
 }
 
-int launch_absmax(const double* v, size_t n, const double* v2, size_t n2, double* out, hipStream_t st) {
-    hipLaunchKernelGGL(absmax_kernel, dim3(1), dim3(1024), 0, st, v, n, v2, n2, out);
+int launch_absmax(const double* v, size_t n, const double* v2, size_t n2, double* out, double* partial, int n_partial,
+                  hipStream_t st) {
+    const size_t total = n + n2;
+    int grid = (int)std::min<size_t>((size_t)n_partial, std::max<size_t>(1, (total + 2047) / 2048));
+    hipLaunchKernelGGL(absmax_partial_kernel, dim3(grid), dim3(256), 0, st, v, n, v2, n2, partial);
+    hipLaunchKernelGGL(absmax_final_kernel, dim3(1), dim3(256), 0, st, partial, grid, out);
     STBA_HIP(hipGetLastError());
     return STBA_OK;
 }
@@ -472,7 +494,7 @@ int launch_schur(int n_obs, const int* obs_cam, const int* obs_pt, const int* pt
 // block: no global atomics and no read-modify-write of the 288 MB matrix.
 //   cols: sorted distinct c2 of the row (CSR row_col_ptr/row_cols), slot = binary search.
 // -------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ba_schur_rows_kernel(SchurRowArgs a) {
+__global__ __launch_bounds__(SCHUR_THREADS) void ba_schur_rows_kernel(SchurRowArgs a) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int task = blockIdx.x;
     const int c = a.task_cam[task];
@@ -481,12 +503,12 @@ __global__ __launch_bounds__(256) void ba_schur_rows_kernel(SchurRowArgs a) {
     double* racc = smem + (size_t)a.max_cols * 36;   // [8]
     int* cols = reinterpret_cast<int*>(racc + 8);    // [ncols]
     const int tid = threadIdx.x;
-    for (int e = tid; e < ncols * 36; e += 256) acc[e] = 0.0;
+    for (int e = tid; e < ncols * 36; e += SCHUR_THREADS) acc[e] = 0.0;
     if (tid < 8) racc[tid] = 0.0;
-    for (int e = tid; e < ncols; e += 256) cols[e] = a.row_cols[col0 + e];
+    for (int e = tid; e < ncols; e += SCHUR_THREADS) cols[e] = a.row_cols[col0 + e];
     __syncthreads();
     const int pe = a.task_end[task];
-    for (int p = a.task_begin[task] + tid; p < pe; p += 256) {
+    for (int p = a.task_begin[task] + tid; p < pe; p += SCHUR_THREADS) {
         const int i = a.cam_perm[p];
         const int j = a.obs_pt[i];
         double Hi[6];
@@ -543,7 +565,7 @@ __global__ __launch_bounds__(256) void ba_schur_rows_kernel(SchurRowArgs a) {
     }
     __syncthreads();
     const bool single = a.task_single[task] != 0;
-    for (int e = tid; e < ncols * 36; e += 256) {
+    for (int e = tid; e < ncols * 36; e += SCHUR_THREADS) {
         const int slot = e / 36, k = e - slot * 36, q = k / 6, b = k - q * 6;
         const int c2 = cols[slot];
         if (c2 == c && b > q) continue;
@@ -570,7 +592,7 @@ int launch_schur_rows(const SchurRowArgs& a, int n_tasks, hipStream_t st) {
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_lds = lds;
     }
-    hipLaunchKernelGGL(ba_schur_rows_kernel, dim3(n_tasks), dim3(256), lds, st, a);
+    hipLaunchKernelGGL(ba_schur_rows_kernel, dim3(n_tasks), dim3(SCHUR_THREADS), lds, st, a);
     STBA_HIP(hipGetLastError());
     return STBA_OK;
 }

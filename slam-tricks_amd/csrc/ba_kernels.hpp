@@ -26,7 +26,8 @@ struct LinArgs {
 size_t lin_lds_bytes(int n_cams, bool cams_in_lds, bool with_jac);
 int launch_linearize(const LinArgs& a, bool with_jac, int grid, hipStream_t st);
 int launch_sum_partials(const double* partial, int n, int stride, int K, double* out, hipStream_t st);
-int launch_absmax(const double* v, size_t n, const double* v2, size_t n2, double* out, hipStream_t st);
+int launch_absmax(const double* v, size_t n, const double* v2, size_t n2, double* out, double* partial, int n_partial,
+                  hipStream_t st);
 int launch_point_blocks(int n_pts, const int* pt_start, const double* Jp, const double2* r, double* Hpp6,
                         double* gp, hipStream_t st);
 int launch_camera_blocks(int n_cams, int n_chunks, const int* chunk_begin, const int* chunk_end,
@@ -41,7 +42,8 @@ int launch_schur(int n_obs, const int* obs_cam, const int* obs_pt, const int* pt
                  hipStream_t st);
 // row-wise Schur complement with LDS accumulation (plan built on the host at create time)
 constexpr int SCHUR_MAX_COLS = 500;    // non-zero blocks per camera row that fit the LDS accumulator
-constexpr int SCHUR_TASK_OBS = 4096;   // observations of one camera handled by one workgroup
+constexpr int SCHUR_TASK_OBS = 4096;
+constexpr int SCHUR_THREADS = 1024;    // one camera row per workgroup: 16 waves hide the L2 gathers   // observations of one camera handled by one workgroup
 struct SchurRowArgs {
     const int* task_cam; const int* task_begin; const int* task_end; const unsigned char* task_single;
     const int* row_col_ptr; const int* row_cols; int max_cols;

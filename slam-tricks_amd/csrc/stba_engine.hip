@@ -192,7 +192,8 @@ static int ba_build_reduced(stba_ba* b, const Damping& dm) {
 static int ba_fill_scalar_slots(stba_ba* b, const double* cost2_dev) {
     STBA_HIP(hipMemsetAsync(b->ex_scalar(), 0, (size_t)b->lda * sizeof(double), b->st));
     STBA_HIP(hipMemcpyAsync(b->ex_scalar() + SC_COST2, cost2_dev, sizeof(double), hipMemcpyDeviceToDevice, b->st));
-    return launch_absmax(b->gp, (size_t)3 * b->np, nullptr, 0, b->ex_scalar() + SC_GPMAX0 + b->rank, b->st);
+    return launch_absmax(b->gp, (size_t)3 * b->np, nullptr, 0, b->ex_scalar() + SC_GPMAX0 + b->rank, b->upd_partial_p,
+                         (b->np + 255) / 256 + 1, b->st);
 }
 
 static int ba_trial(stba_ba* b) {
