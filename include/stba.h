@@ -183,6 +183,20 @@ int stba_cholesky_time(int n, int reps, double* ms_avg, void* hip_stream);
 int stba_cholesky_profile(int n, double* ms4, double* syrk_flops, double* syrk_flops_padded,
                           int* syrk_launches, void* hip_stream);
 
+/* ================================ Zhang calibration (st3-calibration) ==================== */
+/* CalibSolver::totalOptimization's residual / Jacobian blocks (st3-calibration/src/src/calib.cpp:311-391,
+ * distortNormPt :254-262, normPt2ImgPt :247-252) evaluated by a HIP kernel, one corner per lane.
+ * params: [alpha beta u0 v0 k1 k2 k3 p1 p2 | xi_0(6) .. xi_{V-1}(6)], xi = se3 log [rho, theta];
+ * obj / img: [V*C*2] board points (X, Y) / measured pixels.  Outputs (any may be NULL):
+ * sse = sum e^2, e[V*C*2], Ji[V*C*18] (2x9 intrinsics+distortion), Jx[V*C*12] (2x6 left pose perturbation). */
+int stba_calib_evaluate(int n_views, int n_corners, const double* params, const double* obj, const double* img,
+                        double* sse, double* e, double* Ji, double* Jx);
+/* totalOptimization (calib.cpp:282-422): plain Gauss-Newton, <= max_iter iterations, stop when
+ * |update| < 1e-8; additive update of the 9 shared parameters, left-multiplicative SE3 update of
+ * every view.  params in/out; sse_trace[max_iter] receives sum e^2 at the start of each iteration. */
+int stba_calib_gauss_newton(int n_views, int n_corners, double* params, const double* obj, const double* img,
+                            int max_iter, double* sse_trace, int* iterations);
+
 /* ================================ small dense LM problems ================================ */
 /* Residual blocks evaluated by a HOST callback (user CostFunction::Evaluate, solver.hpp:168-212;
  * autodiff functors are differentiated on the host by the C++ shim), normal equations + LM

@@ -66,7 +66,8 @@ EXPORTS = ["stba_status_string", "stba_last_error", "stba_version", "stba_device
            "stba_ba_cost", "stba_ba_normal_blocks", "stba_ba_reduced_system", "stba_ba_solve_reduced",
            "stba_ba_back_substitute", "stba_ba_apply_step", "stba_ba_solve", "stba_ba_lm_iterations",
            "stba_ba_triangulate", "stba_ba_time_linearize", "stba_cholesky_factor", "stba_cholesky_solve",
-           "stba_cholesky_time", "stba_cholesky_profile", "stba_dense_solve"]
+           "stba_cholesky_time", "stba_cholesky_profile", "stba_calib_evaluate", "stba_calib_gauss_newton",
+           "stba_dense_solve"]
 
 
 def lib():
@@ -259,6 +260,31 @@ def cholesky_profile(n, stream=None):
          "stba_cholesky_profile")
     return dict(ms_diag=ms[0], ms_trsm=ms[1], ms_syrk=ms[2], ms_bwd=ms[3], syrk_flops=fl.value,
                 syrk_flops_padded=flp.value, syrk_launches=nl.value)
+
+
+def calib_evaluate(params, obj, img, jac=True):
+    """st3 calibration residual / Jacobian kernel.  obj, img: (V, C, 2)"""
+    obj, img = _f64(obj), _f64(img)
+    V, Cn = obj.shape[0], obj.shape[1]
+    sse = C.c_double()
+    e = np.zeros((V, Cn, 2))
+    Ji = np.zeros((V, Cn, 2, 9)) if jac else None
+    Jx = np.zeros((V, Cn, 2, 6)) if jac else None
+    _chk(lib().stba_calib_evaluate(V, Cn, _p(_f64(params)), _p(obj), _p(img), C.byref(sse), _p(e), _p(Ji), _p(Jx)),
+         "stba_calib_evaluate")
+    return sse.value, e, Ji, Jx
+
+
+def calib_gauss_newton(params, obj, img, max_iter=10):
+    """CalibSolver::totalOptimization on the device; returns (params, iterations, sse_trace)"""
+    params = _f64(params).copy()
+    obj, img = _f64(obj), _f64(img)
+    V, Cn = obj.shape[0], obj.shape[1]
+    tr = np.full(max_iter, np.nan)
+    it = C.c_int()
+    _chk(lib().stba_calib_gauss_newton(V, Cn, _p(params), _p(obj), _p(img), int(max_iter), _p(tr), C.byref(it)),
+         "stba_calib_gauss_newton")
+    return params, it.value, tr
 
 
 def dense_solve(residual, x0, n_res, n_local=None, plus=None, lower=None, upper=None, opt=None, callback=None, **kw):

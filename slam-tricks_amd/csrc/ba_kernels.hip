@@ -854,6 +854,93 @@ int launch_triangulate(int n_pts, const int* pt_start, const int* obs_cam, const
 }
 
 // ===========================================================================================
+// Zhang calibration factor (st3-calibration/src/src/calib.cpp:247-262 distortNormPt/normPt2ImgPt,
+// :311-391 residual + Jacobian blocks), one chessboard corner per lane.
+//   params = [alpha beta u0 v0 k1 k2 k3 p1 p2 | xi_0 .. xi_{V-1}], xi = se3 log [rho, theta]
+//   e = predicted - measured pixel (calib.cpp:334)
+//   Ji (2x9): d e / d(intrinsics, distortion)   (:337-348)
+//   Jx (2x6): d e / d(left perturbation of the view pose), [I | -hat(P')] chain (:352-380)
+// Optionally also scatters the rows into a dense row-major Jacobian Jd [2*V*C][9+6V] (zero elsewhere).
+// ===========================================================================================
+__global__ __launch_bounds__(256) void calib_linearize_kernel(int n_views, int n_corners, const double* __restrict__ params,
+                                                              const double* __restrict__ obj, const double* __restrict__ img,
+                                                              double* __restrict__ e, double* __restrict__ Ji,
+                                                              double* __restrict__ Jx, double* __restrict__ Jd,
+                                                              double* __restrict__ sse_partial) {
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    const int total = n_views * n_corners;
+    double sq = 0.0;
+    if (o < total) {
+        const int v = o / n_corners;
+        const double alpha = params[0], beta = params[1], u0 = params[2], v0 = params[3];
+        const double k1 = params[4], k2 = params[5], k3 = params[6], p1 = params[7], p2 = params[8];
+        double xi[6], R[9], t[3];
+        for (int k = 0; k < 6; ++k) xi[k] = params[9 + v * 6 + k];
+        se3_exp_rt(xi, R, t);
+        const double X = obj[(size_t)o * 2], Y = obj[(size_t)o * 2 + 1];
+        const double Xp = R[0] * X + R[1] * Y + t[0], Yp = R[3] * X + R[4] * Y + t[1], Zp = R[6] * X + R[7] * Y + t[2];
+        const double iz = 1.0 / Zp, xn = Xp * iz, yn = Yp * iz;
+        const double r2 = xn * xn + yn * yn, r4 = r2 * r2, r6 = r4 * r2;
+        const double rad = 1.0 + k1 * r2 + k2 * r4 + k3 * r6;
+        const double xd = xn * rad + 2.0 * p1 * xn * yn + p2 * (r2 + 2.0 * xn * xn);
+        const double yd = yn * rad + 2.0 * p2 * xn * yn + p1 * (r2 + 2.0 * yn * yn);
+        const double e0 = alpha * xd + u0 - img[(size_t)o * 2], e1 = beta * yd + v0 - img[(size_t)o * 2 + 1];
+        sq = e0 * e0 + e1 * e1;
+        if (e) { e[(size_t)o * 2] = e0; e[(size_t)o * 2 + 1] = e1; }
+        if (Ji || Jx || Jd) {
+            double ji[18] = {xd, 0, 1, 0, alpha * xn * r2, alpha * xn * r4, alpha * xn * r6, 2.0 * alpha * xn * yn,
+                             alpha * (r2 + 2.0 * xn * xn),
+                             0, yd, 0, 1, beta * yn * r2, beta * yn * r4, beta * yn * r6, beta * (r2 + 2.0 * yn * yn),
+                             2.0 * beta * xn * yn};
+            const double dx = 2.0 * k1 * xn + 4.0 * k2 * r2 * xn + 6.0 * k3 * r4 * xn;
+            const double dy = 2.0 * k1 * yn + 4.0 * k2 * r2 * yn + 6.0 * k3 * r4 * yn;
+            const double d00 = rad + xn * dx + 2.0 * p1 * yn + 6.0 * p2 * xn;
+            const double d01 = xn * dy + 2.0 * p1 * xn + 2.0 * p2 * yn;
+            const double d10 = yn * dx + 2.0 * p1 * xn + 2.0 * p2 * yn;
+            const double d11 = rad + yn * dy + 2.0 * p2 * xn + 6.0 * p1 * yn;
+            const double N[6] = {iz, 0, -Xp * iz * iz, 0, iz, -Yp * iz * iz};
+            double M[6];
+            for (int b = 0; b < 3; ++b) {
+                M[b] = alpha * (d00 * N[b] + d01 * N[3 + b]);
+                M[3 + b] = beta * (d10 * N[b] + d11 * N[3 + b]);
+            }
+            // [I | -hat(P')]:  -hat(P') = [[0, Zp, -Yp], [-Zp, 0, Xp], [Yp, -Xp, 0]]
+            const double nH[9] = {0, Zp, -Yp, -Zp, 0, Xp, Yp, -Xp, 0};
+            double jx[12];
+            for (int a = 0; a < 2; ++a)
+                for (int b = 0; b < 3; ++b) {
+                    jx[a * 6 + b] = M[a * 3 + b];
+                    jx[a * 6 + 3 + b] = M[a * 3] * nH[b] + M[a * 3 + 1] * nH[3 + b] + M[a * 3 + 2] * nH[6 + b];
+                }
+            if (Ji) for (int k = 0; k < 18; ++k) Ji[(size_t)o * 18 + k] = ji[k];
+            if (Jx) for (int k = 0; k < 12; ++k) Jx[(size_t)o * 12 + k] = jx[k];
+            if (Jd) {
+                const int n = 9 + 6 * n_views;
+                for (int a = 0; a < 2; ++a) {
+                    double* row = Jd + (size_t)(2 * o + a) * n;
+                    for (int k = 0; k < 9; ++k) row[k] = ji[a * 9 + k];
+                    for (int k = 0; k < 6; ++k) row[9 + v * 6 + k] = jx[a * 6 + k];
+                }
+            }
+        }
+    }
+    __shared__ double s_red[4];
+    for (int off = 32; off > 0; off >>= 1) sq += __shfl_down(sq, off, 64);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = sq;
+    __syncthreads();
+    if (threadIdx.x == 0) sse_partial[blockIdx.x] = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+}
+
+int launch_calib_linearize(int n_views, int n_corners, const double* params, const double* obj, const double* img,
+                           double* e, double* Ji, double* Jx, double* Jd, double* sse_partial, hipStream_t st) {
+    const int total = n_views * n_corners;
+    hipLaunchKernelGGL(calib_linearize_kernel, dim3((total + 255) / 256), dim3(256), 0, st, n_views, n_corners, params, obj,
+                       img, e, Ji, Jx, Jd, sse_partial);
+    STBA_HIP(hipGetLastError());
+    return STBA_OK;
+}
+
+// ===========================================================================================
 // dense normal equations for the small problems: H = J^T J (n x n, n <= 256), g = J^T r
 // one workgroup per (a, b-chunk): plain, these problems are tiny (6..129 unknowns)
 // ===========================================================================================

@@ -94,6 +94,28 @@ __host__ __device__ inline void so3_plus(const double q[4], const double d[3], d
     out[0] = ox / n; out[1] = oy / n; out[2] = oz / n; out[3] = ow / n;
 }
 
+// Sophus SE3::exp for the tangent [rho, theta]: rotation matrix + translation V(theta) rho
+__host__ __device__ inline void se3_exp_rt(const double xi[6], double R[9], double t[3]) {
+    double q[4];
+    so3_exp(xi + 3, q);
+    quat_to_rot(q, R);
+    const double w0 = xi[3], w1 = xi[4], w2 = xi[5];
+    const double th2 = w0 * w0 + w1 * w1 + w2 * w2;
+    double a, b;
+    if (th2 < 1e-20) { a = 0.5 - th2 / 24.0; b = 1.0 / 6.0 - th2 / 120.0; }
+    else { const double th = sqrt(th2); a = (1.0 - cos(th)) / th2; b = (th - sin(th)) / (th2 * th); }
+    // V = I + a K + b K^2,  K = hat(w)
+    const double K[9] = {0, -w2, w1, w2, 0, -w0, -w1, w0, 0};
+    double K2[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) K2[i * 3 + j] = K[i * 3] * K[j] + K[i * 3 + 1] * K[3 + j] + K[i * 3 + 2] * K[6 + j];
+    for (int i = 0; i < 3; ++i) {
+        double s = 0.0;
+        for (int j = 0; j < 3; ++j) s += ((i == j ? 1.0 : 0.0) + a * K[i * 3 + j] + b * K2[i * 3 + j]) * xi[j];
+        t[i] = s;
+    }
+}
+
 // inverse of the symmetric 3x3 given as (xx,xy,xz,yy,yz,zz); returns false if not SPD-ish
 __host__ __device__ inline bool inv3_sym6(const double A[6], double Ai[6]) {
     const double a = A[0], b = A[1], c = A[2], d = A[3], e = A[4], f = A[5];

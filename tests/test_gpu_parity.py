@@ -282,3 +282,44 @@ def test_dense_pnp_with_manifold_callbacks(st, O, scenes):
     assert summ.termination_type == 0 and summ.final_cost < 1e-17
     dq, dt = pose_err(x[None], s["pose_true"][None])
     assert dq < 1e-9 and dt < 1e-8
+
+
+# ------------------------------------------------------------------------------- st3 calibration (a8, C3)
+def test_calibration_kernel_matches_oracle(st, O, scenes):
+    s = scenes.calib_scene(n_views=20, rows=8, cols=11, seed=3)            # BASELINE config C3: 20 x 88
+    params = np.concatenate([s["intr_true"] * (1 + 1e-3), s["xis_true"].reshape(-1) + 1e-3])
+    sse, e, Ji, Jx = st.calib_evaluate(params, s["obj"], s["img"])
+    sso, eo, Jio, Jxo = O.calib_evaluate(params, s["obj"], s["img"])
+    assert abs(sse - sso) <= 1e-12 * sso
+    assert np.abs(e - eo).max() < 1e-9                                      # pixels, values ~1e3
+    assert np.abs(Ji - Jio).max() <= 1e-11 * np.abs(Jio).max()
+    assert np.abs(Jx - Jxo).max() <= 1e-11 * np.abs(Jxo).max()
+
+
+def test_calibration_gauss_newton_c3(st, O, scenes):
+    s = scenes.calib_scene(n_views=20, rows=8, cols=11, seed=3)
+    p0 = np.concatenate([s["intr_true"][:4] * (1 + 5e-3), np.zeros(5), s["xis_true"].reshape(-1)])
+    p, it, tr = st.calib_gauss_newton(p0, s["obj"], s["img"], 10)
+    po, ito, tro = O.calib_gauss_newton(p0, s["obj"], s["img"], 10)
+    assert it == ito
+    n = np.count_nonzero(~np.isnan(tro))
+    assert np.allclose(tr[:n], tro[:n], rtol=1e-9)
+    assert np.allclose(p[:4], po[:4], rtol=1e-10) and np.allclose(p[4:9], po[4:9], rtol=1e-7, atol=1e-10)
+    assert np.allclose(p[9:], po[9:], rtol=1e-8, atol=1e-10)
+    assert np.allclose(p[:4], s["intr_true"][:4], rtol=2e-3)              # recovers the generating intrinsics
+
+
+def test_calibration_real_fixture(st, O, known):
+    """st3-calibration/calib/1..9.txt through the device path: recorded cost trace and intrinsics"""
+    import os
+    import zhang_init as Z
+    from conftest import GOLDEN
+    ka = known["st3_calibration"]
+    obj, img = Z.read_corners(os.path.join(GOLDEN, "st3_calib"), ka["board_square_m"])
+    p0 = Z.zhang_init(obj, img, lambda R, t: O.se3_log(O.rot_to_quat(R), t))
+    p, it, tr = st.calib_gauss_newton(p0, obj, img, 10)
+    done = tr[~np.isnan(tr)]
+    assert abs(done[0] - ka["sse_first"]) < 5e-4 and abs(done[-1] - ka["sse_last"]) < 5e-4
+    assert np.allclose(p[:4], ka["final_intr_dist"][:4], rtol=0, atol=6e-4)
+    assert np.allclose(p[4:7], ka["final_intr_dist"][4:7], rtol=2e-6)
+    assert abs(it - ka["gn_iterations"]) <= 1
