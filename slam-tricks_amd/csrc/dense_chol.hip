@@ -72,132 +72,147 @@ __device__ __forceinline__ double sqrt_from_rsqrt(double d, double y) {
 }
 
 // ------------------------------------------------------------------------------------------
-// diagonal block, column blocks of width 4 (32 block steps instead of 128 column steps).
-// Thread (ty, tx) owns rows ty + 32a, columns tx + 32b (a, b < 4) in registers.  Per block step:
-//   owners publish the 4 panel columns to LDS -> barrier -> 128 threads (one per row) factor the
-//   4x4 diagonal mini-block redundantly (division-free rsqrt chain) and scale their panel row by
-//   its inverse transpose -> barrier -> everybody applies the rank-4 update to its sub-blocks.
-template <int A0>
-__device__ __forceinline__ void chol_diag_blocksteps(double (&acc)[4][4], double (*P)[5], double (*Lp)[5], int t,
-                                                     int tx, int ty, int k0, int n_real, int* flag) {
+// diagonal block: 256 threads = 4 waves, the 128x128 block lives in MFMA accumulator layout
+// (8x8 tiles of 16x16; wave w owns tile rows w and 7-w = 9 lower tiles, balanced), processed in
+// 16 block steps of 8 columns:
+//   a. lanes holding the 8 panel columns publish them to LDS                     -> barrier
+//   c. 128 row threads factor the 8x8 diagonal mini-block redundantly (right-looking,
+//      division-free v_rsq_f64 + Newton chain) and solve their panel row         -> barrier
+//   e. rank-8 update of the trailing tiles on the matrix cores: two v_mfma_f64_16x16x4_f64 per
+//      tile, operands straight from the scaled panel rows in LDS (2 x 8 B per lane per tile
+//      instead of 32 LDS reads per thread for the same flops on the VALU)
+//   f. the finished panel columns are written back into the accumulators.
+template <int Jt>
+__device__ __forceinline__ void chol_diag_tilecol(double4v (&acc)[2][8], double (*P)[9], double (*Lp)[9], int t, int lr,
+                                                  int lc, const int (&Irow)[2], int k0, int n_real, int* flag) {
+    // tile column Jt is a compile-time constant so that every accumulator index is static (a runtime
+    // tile index makes the compiler spill the accumulators to scratch)
 #pragma unroll 1
-    for (int jb = 0; jb < 8; ++jb) {
-        const int o = 4 * jb;                 // column offset of the block inside sub-block column A0
-        const int j0 = 32 * A0 + o;           // first column of the block
-        const bool owner = (tx >= o) && (tx < o + 4);
-        if (owner) {
+    for (int h = 0; h < 2; ++h) {
+        const int j0 = 16 * Jt + 8 * h;
+        // a. publish the 8 panel columns (lanes with (lc >> 3) == h)
+        if ((lc >> 3) == h) {
 #pragma unroll
-            for (int a = A0; a < 4; ++a) P[ty + 32 * a][tx - o] = acc[a][A0];
+            for (int s = 0; s < 2; ++s)
+                if (Irow[s] >= Jt) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) P[16 * Irow[s] + lr + 4 * r][lc & 7] = acc[s][Jt][r];
+                }
         }
         __syncthreads();
+        // c. one thread per row at or below the block
         if (t < NB && t >= j0) {
             const int i = t;
-            double D[4][4];
+            double D[8][8], y[8], p[8], l[8];
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+            for (int r = 0; r < 8; ++r)
 #pragma unroll
                 for (int c = 0; c <= r; ++c) D[r][c] = P[j0 + r][c];
-            double p[4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) p[c] = P[i][c];
-            // 4x4 Cholesky G (lower), right-looking so that the dependent chain per pivot is
-            // rsq -> 2 Newton steps -> scale -> one FMA into the next pivot
-            double G[4][4], y[4];
+            for (int c = 0; c < 8; ++c) p[c] = P[i][c];
             bool bad = false;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
+            for (int c = 0; c < 8; ++c) {
                 double d = D[c][c];
                 if (!(d > 0.0)) { bad = bad || ((k0 + j0 + c) < n_real); d = 1.0; }
                 y[c] = fast_rsqrt(d);
-                G[c][c] = sqrt_from_rsqrt(d, y[c]);
+                D[c][c] = sqrt_from_rsqrt(d, y[c]);
 #pragma unroll
-                for (int r = c + 1; r < 4; ++r) G[r][c] = D[r][c] * y[c];
+                for (int r = c + 1; r < 8; ++r) D[r][c] *= y[c];
 #pragma unroll
-                for (int r = c + 1; r < 4; ++r)
+                for (int r = c + 1; r < 8; ++r)
 #pragma unroll
-                    for (int q = c + 1; q <= r; ++q) D[r][q] = fma(-G[r][c], G[q][c], D[r][q]);
+                    for (int q = c + 1; q <= r; ++q) D[r][q] = fma(-D[r][c], D[q][c], D[r][q]);
             }
             if (bad && i == j0) atomicCAS(flag, 0, k0 + j0 + 1);
-            double l[4];
-            if (i >= j0 + 4) {
-                // row of L: solve l G^T = p, right-looking
+            // l G^T = p, right-looking.  Rows INSIDE the 8x8 block take the same path: row r of
+            // D = G G^T solves to row r of G in its first r+1 entries; the entries right of the
+            // diagonal come out as garbage, but they only ever meet (i) panel-column elements that
+            // step f overwrites and (ii) strictly-upper elements nobody reads.
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    l[c] = p[c] * y[c];
+            for (int c = 0; c < 8; ++c) {
+                l[c] = p[c] * y[c];
 #pragma unroll
-                    for (int q = c + 1; q < 4; ++q) p[q] = fma(-l[c], G[q][c], p[q]);
-                }
-            } else {
-                const int r = i - j0;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    double v = 0.0;
-#pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) v = (rr == r && c <= rr) ? G[rr][c] : v;
-                    l[c] = v;
-                }
+                for (int q = c + 1; q < 8; ++q) p[q] = fma(-l[c], D[q][c], p[q]);
             }
 #pragma unroll
-            for (int c = 0; c < 4; ++c) Lp[i][c] = l[c];
+            for (int c = 0; c < 8; ++c) Lp[i][c] = l[c];
         }
         __syncthreads();
-        double li[4][4], lc[4][4];
+        // e. rank-8 update of the trailing tiles on the matrix cores (tile columns > Jt, and Jt itself
+        //    while its right half is still trailing, i.e. h == 0)
 #pragma unroll
-        for (int a = A0; a < 4; ++a)
+        for (int s = 0; s < 2; ++s) {
+            const int I = Irow[s];
+            if (I > Jt || (I == Jt && h == 0)) {
+                const double a0 = -Lp[16 * I + lc][lr], a1 = -Lp[16 * I + lc][4 + lr];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) li[a][k] = Lp[ty + 32 * a][k];
+                for (int J = Jt; J < 8; ++J)
+                    if (J <= I && (J > Jt || h == 0)) {
+                        const double b0 = Lp[16 * J + lc][lr], b1 = Lp[16 * J + lc][4 + lr];
+                        acc[s][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[s][J], 0, 0, 0);
+                        acc[s][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[s][J], 0, 0, 0);
+                    }
+            }
+        }
+        // f. finished columns of the panel -> accumulators (rows at or below the column)
+        if ((lc >> 3) == h) {
 #pragma unroll
-        for (int b = A0; b < 4; ++b)
+            for (int s = 0; s < 2; ++s)
+                if (Irow[s] >= Jt) {
+                    const int col = 16 * Jt + lc;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) lc[b][k] = Lp[tx + 32 * b][k];
-#pragma unroll
-        for (int a = A0; a < 4; ++a)
-#pragma unroll
-            for (int b = A0; b <= a; ++b) {
-                bool on = true;
-                if (b == A0) on = on && (tx >= o + 4);   // columns right of the block
-                if (b == a) on = on && (tx <= ty);       // lower triangle of a diagonal sub-block
-                if (on) {
-                    double v = acc[a][b];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) v = fma(-li[a][k], lc[b][k], v);
-                    acc[a][b] = v;
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = 16 * Irow[s] + lr + 4 * r;
+                        const double v = Lp[row][lc & 7];
+                        acc[s][Jt][r] = (row >= col) ? v : acc[s][Jt][r];
+                    }
                 }
-            }
-        if (owner) {
-#pragma unroll
-            for (int a = A0; a < 4; ++a) {
-                const int i = ty + 32 * a, c = tx + 32 * A0;
-                if (i >= c) acc[a][A0] = Lp[i][tx - o];
-            }
         }
     }
 }
 
-__global__ __launch_bounds__(1024) void chol_diag_kernel(double* __restrict__ A, int lda, int k0,
+__global__ __launch_bounds__(256) void chol_diag_kernel(double* __restrict__ A, int lda, int k0,
                                                          int n_real, int* __restrict__ flag) {
-    __shared__ double P[NB][5];
-    __shared__ double Lp[NB][5];
-    const int t = threadIdx.x, tx = t & 31, ty = t >> 5;
-    double acc[4][4];
+    __shared__ double P[NB][9];
+    __shared__ double Lp[NB][9];
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int lr = lane >> 4, lc = lane & 15;
+    const int Irow[2] = {w, 7 - w};
+    double4v acc[2][8];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int i = ty + 32 * a, c = tx + 32 * b;
-            acc[a][b] = (c <= i) ? A[(size_t)(k0 + i) * lda + k0 + c] : 0.0;
+        for (int J = 0; J < 8; ++J) {
+            const bool in = (J <= Irow[s]);
+            const double* src = A + (size_t)(k0 + 16 * Irow[s] + lr) * lda + k0 + 16 * (in ? J : 0) + lc;
+            double4v tmp;
+            tmp[0] = in ? src[0] : 0.0;
+            tmp[1] = in ? src[(size_t)4 * lda] : 0.0;
+            tmp[2] = in ? src[(size_t)8 * lda] : 0.0;
+            tmp[3] = in ? src[(size_t)12 * lda] : 0.0;
+            acc[s][J] = tmp;
         }
-    chol_diag_blocksteps<0>(acc, P, Lp, t, tx, ty, k0, n_real, flag);
-    chol_diag_blocksteps<1>(acc, P, Lp, t, tx, ty, k0, n_real, flag);
-    chol_diag_blocksteps<2>(acc, P, Lp, t, tx, ty, k0, n_real, flag);
-    chol_diag_blocksteps<3>(acc, P, Lp, t, tx, ty, k0, n_real, flag);
+    chol_diag_tilecol<0>(acc, P, Lp, t, lr, lc, Irow, k0, n_real, flag);
+    chol_diag_tilecol<1>(acc, P, Lp, t, lr, lc, Irow, k0, n_real, flag);
+    chol_diag_tilecol<2>(acc, P, Lp, t, lr, lc, Irow, k0, n_real, flag);
+    chol_diag_tilecol<3>(acc, P, Lp, t, lr, lc, Irow, k0, n_real, flag);
+    chol_diag_tilecol<4>(acc, P, Lp, t, lr, lc, Irow, k0, n_real, flag);
+    chol_diag_tilecol<5>(acc, P, Lp, t, lr, lc, Irow, k0, n_real, flag);
+    chol_diag_tilecol<6>(acc, P, Lp, t, lr, lc, Irow, k0, n_real, flag);
+    chol_diag_tilecol<7>(acc, P, Lp, t, lr, lc, Irow, k0, n_real, flag);
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int i = ty + 32 * a, c = tx + 32 * b;
-            if (c <= i) A[(size_t)(k0 + i) * lda + k0 + c] = acc[a][b];
-        }
+        for (int J = 0; J < 8; ++J)
+            if (J <= Irow[s]) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * Irow[s] + lr + 4 * r, col = 16 * J + lc;
+                    if (col <= row) A[(size_t)(k0 + row) * lda + k0 + col] = acc[s][J][r];
+                }
+            }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -503,7 +518,7 @@ static int chol_run(double* A, int lda, int n, double* x_dev, int* flag_dev, hip
             const int k0 = b * NB;
             const int mt = nblk - b - 1;
             STBA_TRY(mark(4 * (size_t)b + 0));
-            hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(1024), 0, st, A, lda, k0, n, flag_dev);
+            hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), 0, st, A, lda, k0, n, flag_dev);
             STBA_TRY(mark(4 * (size_t)b + 1));
             if (mt > 0)
                 hipLaunchKernelGGL(chol_trsm_kernel, dim3(mt * (NB / TRSM_ROWS)), dim3(256), trsm_lds, st, A, lda, k0);
@@ -537,7 +552,7 @@ static int chol_run(double* A, int lda, int n, double* x_dev, int* flag_dev, hip
             STBA_HIP(hipEventCreateWithFlags(&e2, hipEventDisableTiming));
             evP.push_back(e1); evN.push_back(e2);
         }
-        hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(1024), 0, st, A, lda, 0, n, flag_dev);
+        hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), 0, st, A, lda, 0, n, flag_dev);
         if (nblk > 1)
             hipLaunchKernelGGL(chol_trsm_kernel, dim3((nblk - 1) * (NB / TRSM_ROWS)), dim3(256), trsm_lds, st, A, lda, 0);
         STBA_HIP(hipEventRecord(evP[0], st));
@@ -555,7 +570,7 @@ static int chol_run(double* A, int lda, int n, double* x_dev, int* flag_dev, hip
                 hipLaunchKernelGGL(chol_syrk_kernel, dim3(mt * (mt - 1) / 2), dim3(256), 0, su, A, lda, k0, 2);
             STBA_HIP(hipStreamWaitEvent(st, evN[b], 0));
             const int k1 = k0 + NB;
-            hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(1024), 0, st, A, lda, k1, n, flag_dev);
+            hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), 0, st, A, lda, k1, n, flag_dev);
             if (mt > 1)
                 hipLaunchKernelGGL(chol_trsm_kernel, dim3((mt - 1) * (NB / TRSM_ROWS)), dim3(256), trsm_lds, st, A, lda, k1);
             STBA_HIP(hipEventRecord(evP[b + 1], st));
@@ -569,7 +584,7 @@ static int chol_run(double* A, int lda, int n, double* x_dev, int* flag_dev, hip
             const int mt = nblk - b - 1;
             hipLaunchKernelGGL(chol_syrk_kernel, dim3(mt * (mt + 1) / 2), dim3(256), 0, st, A, lda, k0, 0);
             const int k1 = k0 + NB;
-            hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(1024), 0, st, A, lda, k1, n, flag_dev);
+            hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), 0, st, A, lda, k1, n, flag_dev);
             if (mt > 1)
                 hipLaunchKernelGGL(chol_trsm_kernel, dim3((mt - 1) * (NB / TRSM_ROWS)), dim3(256), trsm_lds, st, A, lda, k1);
         }

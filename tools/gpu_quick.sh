@@ -1,5 +1,5 @@
 export TMPDIR=/tmp
-timeout 600 python -m pytest tests -m gpu -x -q 2>&1 | tail -5
+timeout 600 python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed"
 timeout 900 python bench.py --steps 10 --warmup 2 --no-cpu-baseline > gpurun_out/bench_tmp.json 2> gpurun_out/bench_tmp.err
 python - <<'PY'
 import json
