@@ -320,12 +320,26 @@ __global__ __launch_bounds__(256) void chol_trsm_kernel(double* __restrict__ A, 
 // ------------------------------------------------------------------------------------------
 // Trailing update C(i,j) -= P_i P_j^T over the lower-triangle 128x128 tiles, P = panel columns
 // [k0, k0+128).  256 threads = 4 waves in a 2x2 grid, each wave 64x64 = 4x4 MFMA tiles.
+// Tile shapes: TM x 128 outputs per workgroup (256 threads = 4 waves).
+//   TM = 128: waves 2x2, each 64x64 = 4x4 MFMA tiles; 64 KB LDS -> 2 workgroups per CU.  Best for
+//             very large grids (measured 89 % of the FP64 MFMA peak at 1128 tiles).
+//   TM =  64: waves 1x4, each 64x32 = 4x2 MFMA tiles; 48 KB LDS -> 3 workgroups per CU, twice as
+//             many (half-size) tiles: less tail quantisation and better phase overlap on the
+//             mid-size and small trailing matrices that dominate the step count.
 // tile_mode 0: every lower-triangle tile; 1: only the first tile column (the next panel, look-ahead);
 // 2: everything except the first tile column.
+template <int TM>
 __global__ __launch_bounds__(256) void chol_syrk_kernel(double* __restrict__ A, int lda, int k0, int tile_mode) {
-    __shared__ __attribute__((aligned(16))) double sA[2][2048];
+    constexpr int RBA = TM / 16;            // 16-row blocks of the A tile
+    constexpr int WR = TM / 64;             // wave grid rows (2 or 1)
+    constexpr int WC = 4 / WR;              // wave grid cols (2 or 4)
+    constexpr int MB = 4;                   // MFMA row blocks per wave (64 rows)
+    constexpr int NBK = 8 / WC;             // MFMA col blocks per wave (4 or 2)
+    constexpr int PA = TM / 64;             // staging passes for the A tile
+    __shared__ __attribute__((aligned(16))) double sA[2][TM * 16];
     __shared__ __attribute__((aligned(16))) double sB[2][2048];
-    const int id = blockIdx.x;
+    const int sub = (TM == 64) ? (blockIdx.x & 1) : 0;
+    const int id = (TM == 64) ? (blockIdx.x >> 1) : blockIdx.x;
     int ti, tj;
     if (tile_mode == 1) {
         ti = id; tj = 0;
@@ -337,26 +351,26 @@ __global__ __launch_bounds__(256) void chol_syrk_kernel(double* __restrict__ A, 
         if (tile_mode == 2) { ++ti; ++tj; }
     }
     const int r0 = k0 + NB;
-    const int row_i = r0 + ti * NB, row_j = r0 + tj * NB;
+    const int row_i = r0 + ti * NB + sub * 64, row_j = r0 + tj * NB;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    const int wr = w >> 1, wc = w & 1;
+    const int wr = w / WC, wc = w % WC;
 
     // accumulators start from C (C/D layout of v_mfma_f64_16x16x4_f64: col = lane&15,
     // row = (lane>>4) + 4*reg); the A fragment is negated, so the epilogue is a plain store
-    double4v acc[4][4];
+    double4v acc[MB][NBK];
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < MB; ++m)
 #pragma unroll
-        for (int n = 0; n < 4; ++n)
+        for (int n = 0; n < NBK; ++n)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = row_i + wr * 64 + m * 16 + (lane >> 4) + 4 * r;
-                const int col = row_j + wc * 64 + n * 16 + (lane & 15);
+                const int row = row_i + wr * (MB * 16) + m * 16 + (lane >> 4) + 4 * r;
+                const int col = row_j + wc * (NBK * 16) + n * 16 + (lane & 15);
                 acc[m][n][r] = A[(size_t)row * lda + col];
             }
 
     // staging map: pass p, half h -> row = (lane&15) + 16*(w + 4p), k = 2*((lane>>4) + 4h)
-    double2 ga[2][2], gb[2][2];
+    double2 ga[PA][2], gb[2][2];
     const int lrow = lane & 15, lkp = lane >> 4;
     auto gload = [&](int kc) {
 #pragma unroll
@@ -365,7 +379,7 @@ __global__ __launch_bounds__(256) void chol_syrk_kernel(double* __restrict__ A, 
             for (int h = 0; h < 2; ++h) {
                 const int row = lrow + 16 * (w + 4 * p);
                 const int k = 2 * (lkp + 4 * h);
-                ga[p][h] = *reinterpret_cast<const double2*>(&A[(size_t)(row_i + row) * lda + k0 + kc * 16 + k]);
+                if (p < PA) ga[p < PA ? p : 0][h] = *reinterpret_cast<const double2*>(&A[(size_t)(row_i + row) * lda + k0 + kc * 16 + k]);
                 gb[p][h] = *reinterpret_cast<const double2*>(&A[(size_t)(row_j + row) * lda + k0 + kc * 16 + k]);
             }
     };
@@ -376,11 +390,14 @@ __global__ __launch_bounds__(256) void chol_syrk_kernel(double* __restrict__ A, 
             for (int h = 0; h < 2; ++h) {
                 const int rb = w + 4 * p;                 // 16-row block index
                 const int k = 2 * (lkp + 4 * h);
-                const int pos0 = (((k >> 2) * 8 + rb) << 6) + ((k & 3) << 4) + lrow;
-                sA[buf][pos0] = ga[p][h].x;
-                sA[buf][pos0 + 16] = ga[p][h].y;          // k+1: (k&3) is even so +1 -> +16
-                sB[buf][pos0] = gb[p][h].x;
-                sB[buf][pos0 + 16] = gb[p][h].y;
+                if (p < PA) {
+                    const int posa = (((k >> 2) * RBA + rb) << 6) + ((k & 3) << 4) + lrow;
+                    sA[buf][posa] = ga[p < PA ? p : 0][h].x;
+                    sA[buf][posa + 16] = ga[p < PA ? p : 0][h].y;   // k+1: (k&3) is even so +1 -> +16
+                }
+                const int posb = (((k >> 2) * 8 + rb) << 6) + ((k & 3) << 4) + lrow;
+                sB[buf][posb] = gb[p][h].x;
+                sB[buf][posb + 16] = gb[p][h].y;
             }
     };
     gload(0);
@@ -392,51 +409,91 @@ __global__ __launch_bounds__(256) void chol_syrk_kernel(double* __restrict__ A, 
         if (kc + 1 < KC) gload(kc + 1);
 #pragma unroll
         for (int kq = 0; kq < 4; ++kq) {
-            double a[4], b[4];
+            double a[MB], b[NBK];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) a[m] = -sA[buf][((kq * 8 + wr * 4 + m) << 6) + lane];
+            for (int m = 0; m < MB; ++m) a[m] = -sA[buf][((kq * RBA + wr * MB + m) << 6) + lane];
 #pragma unroll
-            for (int n = 0; n < 4; ++n) b[n] = sB[buf][((kq * 8 + wc * 4 + n) << 6) + lane];
+            for (int n = 0; n < NBK; ++n) b[n] = sB[buf][((kq * 8 + wc * NBK + n) << 6) + lane];
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
+            for (int m = 0; m < MB; ++m)
 #pragma unroll
-                for (int n = 0; n < 4; ++n)
+                for (int n = 0; n < NBK; ++n)
                     acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[n], acc[m][n], 0, 0, 0);
         }
         if (kc + 1 < KC) lstore(buf ^ 1);
         __syncthreads();
     }
-    // C/D layout of v_mfma_f64_16x16x4_f64: col = lane&15, row = (lane>>4) + 4*reg
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < MB; ++m)
 #pragma unroll
-        for (int n = 0; n < 4; ++n)
+        for (int n = 0; n < NBK; ++n)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = row_i + wr * 64 + m * 16 + (lane >> 4) + 4 * r;
-                const int col = row_j + wc * 64 + n * 16 + (lane & 15);
+                const int row = row_i + wr * (MB * 16) + m * 16 + (lane >> 4) + 4 * r;
+                const int col = row_j + wc * (NBK * 16) + n * 16 + (lane & 15);
                 A[(size_t)row * lda + col] = acc[m][n][r];
             }
 }
 
+// picks the tile shape by grid size (tiles128 = number of 128x128 tiles of the launch)
+static void launch_syrk(double* A, int lda, int k0, int tile_mode, int tiles128, hipStream_t st) {
+    static const int force = [] { const char* e = getenv("STBA_SYRK_TM"); return e ? atoi(e) : 0; }();
+    static const int big = [] { const char* e = getenv("STBA_SYRK_BIG"); return e ? atoi(e) : 1000000; }();
+    const bool use64 = force == 64 || (force != 128 && tiles128 < big);
+    if (use64) hipLaunchKernelGGL(chol_syrk_kernel<64>, dim3(2 * tiles128), dim3(256), 0, st, A, lda, k0, tile_mode);
+    else hipLaunchKernelGGL(chol_syrk_kernel<128>, dim3(tiles128), dim3(256), 0, st, A, lda, k0, tile_mode);
+}
+
 // ------------------------------------------------------------------------------------------
-// backward substitution, block b: x_b = L_bb^-T y_b   (y lives in row lda-1).
-// The block and the inverses of its 8x8 diagonal blocks are staged in LDS by all 1024 threads;
-// then ONE wave runs 16 block steps with lane shuffles only: lane l owns unknowns l and l + 64.
-__global__ __launch_bounds__(1024) void chol_bwd_diag_kernel(double* __restrict__ A, int lda, int k0,
+// backward substitution, one launch per 128-unknown block b (from the last block up):
+//   workgroup 0      applies the previous block's solution x_{b+1} to ITS OWN 128 right-hand-side
+//                    entries, then solves x_b = L_bb^-T y_b: the block and the inverses of its
+//                    8x8 diagonal blocks are staged in LDS by all 1024 threads, then ONE wave runs
+//                    16 block steps with lane shuffles only (lane l owns unknowns l and l + 64);
+//   workgroups 1..   apply x_{b+1} to the remaining entries y[0 : k0)   (GEMV with the row panel).
+// y lives in row lda-1 (it was forward-substituted for free by the factorisation).
+__global__ __launch_bounds__(1024) void chol_bwd_step_kernel(double* __restrict__ A, int lda, int k0, int has_next,
                                                              double* __restrict__ x) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* Ld = smem;                          // [128][130]
     double* Gi = smem + NB * LDS_LD;            // [16][8][8]
     double* invd = Gi + 16 * 64;                // [128]
+    double* xs = invd + NB;                     // [128] previous block's solution
+    double* ybuf = xs + NB;                     // [128] this block's right-hand side
     const int t = threadIdx.x;
+    const int kn = k0 + NB;                                  // first row of the previous (next-lower) block
+    const int nvn = has_next ? min(NB, (lda - 1) - kn) : 0;   // its rows that belong to the system
+    if (t < NB) xs[t] = (t < nvn) ? x[kn + t] : 0.0;
+    __syncthreads();
+    if (blockIdx.x > 0) {
+        const int c = (blockIdx.x - 1) * 1024 + t;
+        if (c < k0) {
+            double s = 0.0;
+            const double* col = A + (size_t)kn * lda + c;
+#pragma unroll 8
+            for (int j = 0; j < nvn; ++j) s = fma(col[(size_t)j * lda], xs[j], s);
+            A[(size_t)(lda - 1) * lda + c] -= s;
+        }
+        return;
+    }
     const int nv = min(NB, (lda - 1) - k0);     // rows of this block that belong to the system
+    if (t < NB) {
+        double yv = (t < nv) ? A[(size_t)(lda - 1) * lda + k0 + t] : 0.0;
+        if (t < nv) {
+            double s = 0.0;
+            const double* col = A + (size_t)kn * lda + k0 + t;
+#pragma unroll 8
+            for (int j = 0; j < nvn; ++j) s = fma(col[(size_t)j * lda], xs[j], s);
+            yv -= s;
+        }
+        ybuf[t] = yv;
+    }
     stage_block_and_inverses<1024>(A, lda, k0, nv, Ld, invd, Gi, t);
     if (t >= 64) return;
     const int l = t;
     double y[2];
-    y[0] = (l < nv) ? A[(size_t)(lda - 1) * lda + k0 + l] : 0.0;
-    y[1] = (l + 64 < nv) ? A[(size_t)(lda - 1) * lda + k0 + l + 64] : 0.0;
+    y[0] = ybuf[l];
+    y[1] = ybuf[l + 64];
 #pragma unroll
     for (int h = 1; h >= 0; --h) {
 #pragma unroll 1
@@ -448,24 +505,24 @@ __global__ __launch_bounds__(1024) void chol_bwd_diag_kernel(double* __restrict_
 #pragma unroll
             for (int k = 0; k < 8; ++k) xm = fma(Gi[(J * 8 + k) * 8 + m], __shfl(y[h], base + k, 64), xm);
             if ((l >> 3) == Jh) y[h] = xm;
-            double xs[8];
+            double xv[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) xs[k] = __shfl(y[h], base + k, 64);
+            for (int k = 0; k < 8; ++k) xv[k] = __shfl(y[h], base + k, 64);
             // remaining unknowns t' < 8J: y_t' -= sum_k L[8J+k][t'] x_k
             if (h == 1) {
                 double v0 = y[0], v1 = y[1];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     const double* rowk = Ld + (8 * J + k) * LDS_LD;
-                    v0 = fma(-rowk[l], xs[k], v0);
-                    if (l + 64 < 8 * J) v1 = fma(-rowk[l + 64], xs[k], v1);
+                    v0 = fma(-rowk[l], xv[k], v0);
+                    if (l + 64 < 8 * J) v1 = fma(-rowk[l + 64], xv[k], v1);
                 }
                 y[0] = v0; y[1] = v1;
             } else {
                 double v0 = y[0];
 #pragma unroll
                 for (int k = 0; k < 8; ++k)
-                    if (l < 8 * J) v0 = fma(-Ld[(8 * J + k) * LDS_LD + l], xs[k], v0);
+                    if (l < 8 * J) v0 = fma(-Ld[(8 * J + k) * LDS_LD + l], xv[k], v0);
                 y[0] = v0;
             }
         }
@@ -474,33 +531,17 @@ __global__ __launch_bounds__(1024) void chol_bwd_diag_kernel(double* __restrict_
     x[k0 + l + 64] = (l + 64 < nv) ? y[1] : 0.0;
 }
 
-// y[0:k0] -= L[k0:k0+nv, 0:k0]^T x_b
-__global__ __launch_bounds__(256) void chol_bwd_update_kernel(double* __restrict__ A, int lda, int k0,
-                                                              const double* __restrict__ x) {
-    __shared__ double xs[NB];
-    const int nv = min(NB, (lda - 1) - k0);
-    if (threadIdx.x < NB) xs[threadIdx.x] = (threadIdx.x < nv) ? x[k0 + threadIdx.x] : 0.0;
-    __syncthreads();
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= k0) return;
-    double s = 0.0;
-    const double* col = A + (size_t)k0 * lda + c;
-#pragma unroll 8
-    for (int j = 0; j < nv; ++j) s += col[(size_t)j * lda] * xs[j];
-    A[(size_t)(lda - 1) * lda + c] -= s;
-}
-
 // ------------------------------------------------------------------------------------------
 static int chol_run(double* A, int lda, int n, double* x_dev, int* flag_dev, hipStream_t st, CholProfile* prof) {
     if (lda % NB != 0 || lda < n + 1) return fail(STBA_ERR_INVALID_ARGUMENT, "chol: bad padded dimension");
     const int nblk = lda / NB;
     const size_t trsm_lds = sizeof(double) * (NB * LDS_LD + 16 * 64 + NB);
-    const size_t bwd_lds = sizeof(double) * (NB * LDS_LD + 16 * 64 + NB);
+    const size_t bwd_lds = sizeof(double) * (NB * LDS_LD + 16 * 64 + 3 * NB);
     static bool attr_set = false;
     if (!attr_set) {
         STBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(chol_trsm_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)trsm_lds));
-        STBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(chol_bwd_diag_kernel),
+        STBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(chol_bwd_step_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_lds));
         attr_set = true;
     }
@@ -523,7 +564,7 @@ static int chol_run(double* A, int lda, int n, double* x_dev, int* flag_dev, hip
             if (mt > 0)
                 hipLaunchKernelGGL(chol_trsm_kernel, dim3(mt * (NB / TRSM_ROWS)), dim3(256), trsm_lds, st, A, lda, k0);
             STBA_TRY(mark(4 * (size_t)b + 2));
-            if (mt > 0) hipLaunchKernelGGL(chol_syrk_kernel, dim3(mt * (mt + 1) / 2), dim3(256), 0, st, A, lda, k0, 0);
+            if (mt > 0) launch_syrk(A, lda, k0, 0, mt * (mt + 1) / 2, st);
             STBA_TRY(mark(4 * (size_t)b + 3));
             if (mt > 0) {
                 const double m = std::max(0, n - (k0 + NB));
@@ -558,16 +599,16 @@ static int chol_run(double* A, int lda, int n, double* x_dev, int* flag_dev, hip
         STBA_HIP(hipEventRecord(evP[0], st));
         // look-ahead only pays while the bulk update is longer than the panel chain (measured on
         // MI355X: cross-stream hand-offs cost ~7-14 us each and the panel is ~65 us under contention)
-        constexpr int LOOKAHEAD_MIN_MT = 36;
+        static const int LOOKAHEAD_MIN_MT = [] { const char* e = getenv("STBA_LOOKAHEAD_MIN_MT"); return e ? atoi(e) : 36; }();
         int b = 0;
         for (; b + 1 < nblk && (nblk - b - 1) >= LOOKAHEAD_MIN_MT; ++b) {
             const int k0 = b * NB;
             const int mt = nblk - b - 1;
             STBA_HIP(hipStreamWaitEvent(su, evP[b], 0));
-            hipLaunchKernelGGL(chol_syrk_kernel, dim3(mt), dim3(256), 0, su, A, lda, k0, 1);
+            launch_syrk(A, lda, k0, 1, mt, su);
             STBA_HIP(hipEventRecord(evN[b], su));
             if (mt > 1)
-                hipLaunchKernelGGL(chol_syrk_kernel, dim3(mt * (mt - 1) / 2), dim3(256), 0, su, A, lda, k0, 2);
+                launch_syrk(A, lda, k0, 2, mt * (mt - 1) / 2, su);
             STBA_HIP(hipStreamWaitEvent(st, evN[b], 0));
             const int k1 = k0 + NB;
             hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), 0, st, A, lda, k1, n, flag_dev);
@@ -582,7 +623,7 @@ static int chol_run(double* A, int lda, int n, double* x_dev, int* flag_dev, hip
         for (; b + 1 < nblk; ++b) {   // serial tail on the caller's stream
             const int k0 = b * NB;
             const int mt = nblk - b - 1;
-            hipLaunchKernelGGL(chol_syrk_kernel, dim3(mt * (mt + 1) / 2), dim3(256), 0, st, A, lda, k0, 0);
+            launch_syrk(A, lda, k0, 0, mt * (mt + 1) / 2, st);
             const int k1 = k0 + NB;
             hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), 0, st, A, lda, k1, n, flag_dev);
             if (mt > 1)
@@ -592,9 +633,9 @@ static int chol_run(double* A, int lda, int n, double* x_dev, int* flag_dev, hip
     STBA_TRY(mark((size_t)nblk * 4));
     for (int b = nblk - 1; b >= 0; --b) {
         const int k0 = b * NB;
-        hipLaunchKernelGGL(chol_bwd_diag_kernel, dim3(1), dim3(1024), bwd_lds, st, A, lda, k0, x_dev);
-        if (k0 > 0)
-            hipLaunchKernelGGL(chol_bwd_update_kernel, dim3((k0 + 255) / 256), dim3(256), 0, st, A, lda, k0, x_dev);
+        const int has_next = (b < nblk - 1) ? 1 : 0;
+        const int grid = 1 + (has_next ? (k0 + 1023) / 1024 : 0);
+        hipLaunchKernelGGL(chol_bwd_step_kernel, dim3(grid), dim3(1024), bwd_lds, st, A, lda, k0, has_next, x_dev);
     }
     STBA_TRY(mark((size_t)nblk * 4 + 1));
     STBA_HIP(hipGetLastError());
