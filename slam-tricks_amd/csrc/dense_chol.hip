@@ -294,17 +294,24 @@ __device__ __forceinline__ void chol_trsm_block(double (&acc)[16], const double*
     }
 }
 
-__global__ __launch_bounds__(256) void chol_trsm_kernel(double* __restrict__ A, int lda, int k0) {
+__global__ __launch_bounds__(256) void chol_trsm_kernel(double* __restrict__ A, int lda, int k0, int n_row_wgs,
+                                                        double* __restrict__ Xinv) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* Ld = smem;                          // [128][130]
     double* Gi = smem + NB * LDS_LD;            // [16][8][8]
     double* invd = Gi + 16 * 64;                // [128]
     const int t = threadIdx.x, r = t >> 3, cg = t & 7, lane = t & 63;
+    // the last 4 workgroups run the same solve on the rows of the identity: X = I * L11^-T is the
+    // (upper-triangular) inverse transpose of the diagonal block, used by the backward substitution
+    const bool ident = (int)blockIdx.x >= n_row_wgs;
+    const int rid = ((int)blockIdx.x - n_row_wgs) * TRSM_ROWS + r;
     const int row = k0 + NB + blockIdx.x * TRSM_ROWS + r;
+    const int nv = min(NB, (lda - 1) - k0);     // rows of the diagonal block that belong to the system
     double acc[16];
 #pragma unroll
-    for (int m = 0; m < 16; ++m) acc[m] = A[(size_t)row * lda + k0 + cg + 8 * m];
-    stage_block_and_inverses<256>(A, lda, k0, NB, Ld, invd, Gi, t);
+    for (int m = 0; m < 16; ++m)
+        acc[m] = ident ? ((cg + 8 * m == rid) ? 1.0 : 0.0) : A[(size_t)row * lda + k0 + cg + 8 * m];
+    stage_block_and_inverses<256>(A, lda, k0, ident ? nv : NB, Ld, invd, Gi, t);
     chol_trsm_block<0>(acc, Ld, Gi, lane, cg);   chol_trsm_block<1>(acc, Ld, Gi, lane, cg);
     chol_trsm_block<2>(acc, Ld, Gi, lane, cg);   chol_trsm_block<3>(acc, Ld, Gi, lane, cg);
     chol_trsm_block<4>(acc, Ld, Gi, lane, cg);   chol_trsm_block<5>(acc, Ld, Gi, lane, cg);
@@ -313,8 +320,13 @@ __global__ __launch_bounds__(256) void chol_trsm_kernel(double* __restrict__ A, 
     chol_trsm_block<10>(acc, Ld, Gi, lane, cg);  chol_trsm_block<11>(acc, Ld, Gi, lane, cg);
     chol_trsm_block<12>(acc, Ld, Gi, lane, cg);  chol_trsm_block<13>(acc, Ld, Gi, lane, cg);
     chol_trsm_block<14>(acc, Ld, Gi, lane, cg);  chol_trsm_block<15>(acc, Ld, Gi, lane, cg);
+    if (ident) {
 #pragma unroll
-    for (int m = 0; m < 16; ++m) A[(size_t)row * lda + k0 + cg + 8 * m] = acc[m];
+        for (int m = 0; m < 16; ++m) Xinv[(size_t)rid * NB + cg + 8 * m] = acc[m];
+    } else {
+#pragma unroll
+        for (int m = 0; m < 16; ++m) A[(size_t)row * lda + k0 + cg + 8 * m] = acc[m];
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -447,88 +459,65 @@ static void launch_syrk(double* A, int lda, int k0, int tile_mode, int tiles128,
 // ------------------------------------------------------------------------------------------
 // backward substitution, one launch per 128-unknown block b (from the last block up):
 //   workgroup 0      applies the previous block's solution x_{b+1} to ITS OWN 128 right-hand-side
-//                    entries, then solves x_b = L_bb^-T y_b: the block and the inverses of its
-//                    8x8 diagonal blocks are staged in LDS by all 1024 threads, then ONE wave runs
-//                    16 block steps with lane shuffles only (lane l owns unknowns l and l + 64);
+//                    entries, then x_b = (L_bb^-T) y_b as a 128x128 GEMV with the inverse transpose
+//                    the panel-solve kernel produced during the factorisation;
 //   workgroups 1..   apply x_{b+1} to the remaining entries y[0 : k0)   (GEMV with the row panel).
 // y lives in row lda-1 (it was forward-substituted for free by the factorisation).
+constexpr int BWD_ROW_CHUNKS = 8;   // the 128 panel rows are split 8 ways so that enough CUs pull the panel
 __global__ __launch_bounds__(1024) void chol_bwd_step_kernel(double* __restrict__ A, int lda, int k0, int has_next,
-                                                             double* __restrict__ x) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    double* Ld = smem;                          // [128][130]
-    double* Gi = smem + NB * LDS_LD;            // [16][8][8]
-    double* invd = Gi + 16 * 64;                // [128]
-    double* xs = invd + NB;                     // [128] previous block's solution
-    double* ybuf = xs + NB;                     // [128] this block's right-hand side
+                                                             const double* __restrict__ Xinv, double* __restrict__ x) {
+    __shared__ double xs[NB];                       // previous block's solution
+    __shared__ double part[BWD_ROW_CHUNKS][NB];     // partial sums of this block's own update
+    __shared__ double ybuf[NB];                     // this block's right-hand side
     const int t = threadIdx.x;
     const int kn = k0 + NB;                                  // first row of the previous (next-lower) block
     const int nvn = has_next ? min(NB, (lda - 1) - kn) : 0;   // its rows that belong to the system
     if (t < NB) xs[t] = (t < nvn) ? x[kn + t] : 0.0;
     __syncthreads();
+    constexpr int RPC = NB / BWD_ROW_CHUNKS;        // rows per chunk (16)
     if (blockIdx.x > 0) {
-        const int c = (blockIdx.x - 1) * 1024 + t;
+        // update role: workgroup = (column chunk of 1024, row chunk of 16); FP64 atomics into y
+        const int id = blockIdx.x - 1;
+        const int cchunk = id / BWD_ROW_CHUNKS, rchunk = id % BWD_ROW_CHUNKS;
+        const int c = cchunk * 1024 + t;
         if (c < k0) {
             double s = 0.0;
-            const double* col = A + (size_t)kn * lda + c;
-#pragma unroll 8
-            for (int j = 0; j < nvn; ++j) s = fma(col[(size_t)j * lda], xs[j], s);
-            A[(size_t)(lda - 1) * lda + c] -= s;
+            const double* col = A + (size_t)(kn + rchunk * RPC) * lda + c;
+#pragma unroll
+            for (int j = 0; j < RPC; ++j) s = fma(col[(size_t)j * lda], xs[rchunk * RPC + j], s);
+            if (s != 0.0) unsafeAtomicAdd(&A[(size_t)(lda - 1) * lda + c], -s);
         }
         return;
     }
     const int nv = min(NB, (lda - 1) - k0);     // rows of this block that belong to the system
+    {   // own update: thread (rchunk, column) = (t >> 7, t & 127)
+        const int rchunk = t >> 7, c = t & 127;
+        double s = 0.0;
+        if (nvn > 0) {
+            const double* col = A + (size_t)(kn + rchunk * RPC) * lda + k0 + c;
+#pragma unroll
+            for (int j = 0; j < RPC; ++j) s = fma(col[(size_t)j * lda], xs[rchunk * RPC + j], s);
+        }
+        part[rchunk][c] = s;
+    }
+    __syncthreads();
     if (t < NB) {
         double yv = (t < nv) ? A[(size_t)(lda - 1) * lda + k0 + t] : 0.0;
-        if (t < nv) {
-            double s = 0.0;
-            const double* col = A + (size_t)kn * lda + k0 + t;
-#pragma unroll 8
-            for (int j = 0; j < nvn; ++j) s = fma(col[(size_t)j * lda], xs[j], s);
-            yv -= s;
-        }
-        ybuf[t] = yv;
+#pragma unroll
+        for (int q = 0; q < BWD_ROW_CHUNKS; ++q) yv -= part[q][t];
+        ybuf[t] = (t < nv) ? yv : 0.0;
     }
-    stage_block_and_inverses<1024>(A, lda, k0, nv, Ld, invd, Gi, t);
-    if (t >= 64) return;
-    const int l = t;
-    double y[2];
-    y[0] = ybuf[l];
-    y[1] = ybuf[l + 64];
+    __syncthreads();
+    // x_i = sum_{j >= i} X[i][j] y_j : 8 threads per row, 16 columns each, shuffle tree
+    const int i = t >> 3, p8 = t & 7;
+    const double* xr = Xinv + (size_t)i * NB + p8 * 16;
+    double s = 0.0;
 #pragma unroll
-    for (int h = 1; h >= 0; --h) {
-#pragma unroll 1
-        for (int Jh = 7; Jh >= 0; --Jh) {
-            const int J = 8 * h + Jh;               // block of unknowns 8J .. 8J+7, owned by lanes 8Jh .. 8Jh+7
-            const int base = 8 * Jh, m = l & 7;
-            // x_m = sum_{k >= m} Gi[J][k][m] * y_k   (transpose of the inverse block)
-            double xm = 0.0;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) xm = fma(Gi[(J * 8 + k) * 8 + m], __shfl(y[h], base + k, 64), xm);
-            if ((l >> 3) == Jh) y[h] = xm;
-            double xv[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) xv[k] = __shfl(y[h], base + k, 64);
-            // remaining unknowns t' < 8J: y_t' -= sum_k L[8J+k][t'] x_k
-            if (h == 1) {
-                double v0 = y[0], v1 = y[1];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const double* rowk = Ld + (8 * J + k) * LDS_LD;
-                    v0 = fma(-rowk[l], xv[k], v0);
-                    if (l + 64 < 8 * J) v1 = fma(-rowk[l + 64], xv[k], v1);
-                }
-                y[0] = v0; y[1] = v1;
-            } else {
-                double v0 = y[0];
-#pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    if (l < 8 * J) v0 = fma(-Ld[(8 * J + k) * LDS_LD + l], xv[k], v0);
-                y[0] = v0;
-            }
-        }
-    }
-    x[k0 + l] = (l < nv) ? y[0] : 0.0;
-    x[k0 + l + 64] = (l + 64 < nv) ? y[1] : 0.0;
+    for (int j = 0; j < 16; ++j) s = fma(xr[j], ybuf[p8 * 16 + j], s);
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 4, 64);
+    if (p8 == 0) x[k0 + i] = (i < nv) ? s : 0.0;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -536,14 +525,20 @@ static int chol_run(double* A, int lda, int n, double* x_dev, int* flag_dev, hip
     if (lda % NB != 0 || lda < n + 1) return fail(STBA_ERR_INVALID_ARGUMENT, "chol: bad padded dimension");
     const int nblk = lda / NB;
     const size_t trsm_lds = sizeof(double) * (NB * LDS_LD + 16 * 64 + NB);
-    const size_t bwd_lds = sizeof(double) * (NB * LDS_LD + 16 * 64 + 3 * NB);
     static bool attr_set = false;
     if (!attr_set) {
         STBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(chol_trsm_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)trsm_lds));
-        STBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(chol_bwd_step_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_lds));
         attr_set = true;
+    }
+    // inverse transposes of the diagonal blocks (written by the panel solve, read by the backward pass)
+    static thread_local double* linv = nullptr;
+    static thread_local int linv_blocks = 0;
+    if (linv_blocks < nblk) {
+        if (linv) (void)hipFree(linv);
+        linv = nullptr; linv_blocks = 0;
+        STBA_HIP(hipMalloc(reinterpret_cast<void**>(&linv), (size_t)nblk * NB * NB * sizeof(double)));
+        linv_blocks = nblk;
     }
     std::vector<hipEvent_t> ev;
     if (prof) {
@@ -561,8 +556,8 @@ static int chol_run(double* A, int lda, int n, double* x_dev, int* flag_dev, hip
             STBA_TRY(mark(4 * (size_t)b + 0));
             hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), 0, st, A, lda, k0, n, flag_dev);
             STBA_TRY(mark(4 * (size_t)b + 1));
-            if (mt > 0)
-                hipLaunchKernelGGL(chol_trsm_kernel, dim3(mt * (NB / TRSM_ROWS)), dim3(256), trsm_lds, st, A, lda, k0);
+            hipLaunchKernelGGL(chol_trsm_kernel, dim3(mt * (NB / TRSM_ROWS) + NB / TRSM_ROWS), dim3(256), trsm_lds, st, A, lda, k0,
+                               mt * (NB / TRSM_ROWS), linv + (size_t)b * NB * NB);
             STBA_TRY(mark(4 * (size_t)b + 2));
             if (mt > 0) launch_syrk(A, lda, k0, 0, mt * (mt + 1) / 2, st);
             STBA_TRY(mark(4 * (size_t)b + 3));
@@ -594,8 +589,8 @@ static int chol_run(double* A, int lda, int n, double* x_dev, int* flag_dev, hip
             evP.push_back(e1); evN.push_back(e2);
         }
         hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), 0, st, A, lda, 0, n, flag_dev);
-        if (nblk > 1)
-            hipLaunchKernelGGL(chol_trsm_kernel, dim3((nblk - 1) * (NB / TRSM_ROWS)), dim3(256), trsm_lds, st, A, lda, 0);
+        hipLaunchKernelGGL(chol_trsm_kernel, dim3((nblk - 1) * (NB / TRSM_ROWS) + NB / TRSM_ROWS), dim3(256), trsm_lds, st, A, lda, 0,
+                           (nblk - 1) * (NB / TRSM_ROWS), linv);
         STBA_HIP(hipEventRecord(evP[0], st));
         // look-ahead only pays while the bulk update is longer than the panel chain (measured on
         // MI355X: cross-stream hand-offs cost ~7-14 us each and the panel is ~65 us under contention)
@@ -612,8 +607,8 @@ static int chol_run(double* A, int lda, int n, double* x_dev, int* flag_dev, hip
             STBA_HIP(hipStreamWaitEvent(st, evN[b], 0));
             const int k1 = k0 + NB;
             hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), 0, st, A, lda, k1, n, flag_dev);
-            if (mt > 1)
-                hipLaunchKernelGGL(chol_trsm_kernel, dim3((mt - 1) * (NB / TRSM_ROWS)), dim3(256), trsm_lds, st, A, lda, k1);
+            hipLaunchKernelGGL(chol_trsm_kernel, dim3((mt - 1) * (NB / TRSM_ROWS) + NB / TRSM_ROWS), dim3(256), trsm_lds, st, A, lda, k1,
+                               (mt - 1) * (NB / TRSM_ROWS), linv + (size_t)(b + 1) * NB * NB);
             STBA_HIP(hipEventRecord(evP[b + 1], st));
         }
         if (b > 0) {
@@ -626,16 +621,16 @@ static int chol_run(double* A, int lda, int n, double* x_dev, int* flag_dev, hip
             launch_syrk(A, lda, k0, 0, mt * (mt + 1) / 2, st);
             const int k1 = k0 + NB;
             hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), 0, st, A, lda, k1, n, flag_dev);
-            if (mt > 1)
-                hipLaunchKernelGGL(chol_trsm_kernel, dim3((mt - 1) * (NB / TRSM_ROWS)), dim3(256), trsm_lds, st, A, lda, k1);
+            hipLaunchKernelGGL(chol_trsm_kernel, dim3((mt - 1) * (NB / TRSM_ROWS) + NB / TRSM_ROWS), dim3(256), trsm_lds, st, A, lda, k1,
+                               (mt - 1) * (NB / TRSM_ROWS), linv + (size_t)(b + 1) * NB * NB);
         }
     }
     STBA_TRY(mark((size_t)nblk * 4));
     for (int b = nblk - 1; b >= 0; --b) {
         const int k0 = b * NB;
         const int has_next = (b < nblk - 1) ? 1 : 0;
-        const int grid = 1 + (has_next ? (k0 + 1023) / 1024 : 0);
-        hipLaunchKernelGGL(chol_bwd_step_kernel, dim3(grid), dim3(1024), bwd_lds, st, A, lda, k0, has_next, x_dev);
+        const int grid = 1 + (has_next ? ((k0 + 1023) / 1024) * BWD_ROW_CHUNKS : 0);
+        hipLaunchKernelGGL(chol_bwd_step_kernel, dim3(grid), dim3(1024), 0, st, A, lda, k0, has_next, linv + (size_t)b * NB * NB, x_dev);
     }
     STBA_TRY(mark((size_t)nblk * 4 + 1));
     STBA_HIP(hipGetLastError());
