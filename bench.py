@@ -29,6 +29,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X FP64 matrix peak (SURVEY.md 8d / AMD datasheet)
+FP64_MFMA_MEASURED_CEILING_TFLOPS = 47.2   # profiles/mfma_f64_microbench.txt (pure-MFMA loop on this chip)
 BYTES_PER_OBS_JAC = 186.5    # materialised residual+Jacobian kernel, 10 obs/landmark
 
 
@@ -154,6 +155,8 @@ def main():
         roof_syrk = {"kernel": "chol_syrk_kernel (v_mfma_f64_16x16x4_f64)", "bound": "mfma", "achieved": syrk_tflops,
                      "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": syrk_tflops / FP64_MFMA_PEAK_TFLOPS,
                      "traffic": None, "ms_per_launch": prof["ms_syrk"] / max(1, prof["syrk_launches"]),
+                     "microbench_ceiling": FP64_MFMA_MEASURED_CEILING_TFLOPS,
+                     "frac_of_microbench_ceiling": syrk_tflops / FP64_MFMA_MEASURED_CEILING_TFLOPS,
                      "launches_per_factorisation": prof["syrk_launches"],
                      "algorithmic_flops_per_factorisation": prof["syrk_flops"],
                      "executed_flops_per_factorisation": prof["syrk_flops_padded"]}
