@@ -118,3 +118,53 @@ def test_reference_call_sites_on_gpu(exe, tmp_path, scenes, O, known):
     cams2 = vec(out, "ba_generic_cams").reshape(-1, 7)
     dq = np.minimum(np.abs(cams2[:, :4] - o2.cams[:, :4]).max(1), np.abs(cams2[:, :4] + o2.cams[:, :4]).max(1)).max()
     assert dq < 1e-6 and np.abs(cams2[:, 4:] - o2.cams[:, 4:]).max() < 1e-5
+
+
+# ---------------------------------------------------------------------------------------------
+# g2o front door: st20-g2o/src/include/test_g2o.h restated on include/stba/g2o.h
+@pytest.fixture(scope="module")
+def exe_g2o(tmp_path_factory):
+    st = importlib.import_module("slam-tricks_amd")
+    if not os.path.exists(st.LIB_PATH):
+        importlib.import_module("slam-tricks_amd.build").build()
+    out = str(tmp_path_factory.mktemp("cpp") / "test_g2o_shim")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "test_g2o_shim.cpp"), "-L", PKG, "-lstba",
+                           f"-Wl,-rpath,{PKG}", "-o", out])
+    return out
+
+
+def test_g2o_shim_compiles_and_fails_loudly_without_device(exe_g2o, tmp_path, scenes):
+    st = importlib.import_module("slam-tricks_amd")
+    s = scenes.st20_scene(n_cams=6, n_pts=40, seed=7, pos_noise=0.05, ang_noise_deg=1.0)
+    f = str(tmp_path / "s.bin")
+    write_scene(f, s)
+    out = run(exe_g2o, f)
+    if st.device_count() == 0:
+        assert out["g2o_iters"].startswith("0 ") and "no CPU fallback" in out["g2o_iters"]
+
+
+@pytest.mark.gpu
+def test_solve_with_g2o_on_gpu(exe_g2o, tmp_path, scenes, O):
+    """SolveWithG2O (test_g2o.h:94-147): no fixed vertex (gauge held by the LM damping), optimize(40),
+    chi2 = 2 x cost.  Noise-free observations: the residual must vanish."""
+    s = scenes.st20_scene()
+    f = str(tmp_path / "s.bin")
+    write_scene(f, s)
+    out = run(exe_g2o, f)
+    toks = out["g2o_iters"].split()
+    iters, chi2 = int(toks[0]), float(toks[2])
+    assert 1 <= iters <= 40, out["g2o_iters"]
+    o = O.BA(s["cams0"], s["pts0"], s["obs_cam"], s["obs_pt"], s["obs_feat"])      # no constant cameras
+    so, _ = o.solve(max_num_iterations=40)
+    assert iters == so.num_iterations
+    assert chi2 < 1e-10 and abs(chi2 - 2 * so.final_cost) < 1e-12
+    cams = vec(out, "g2o_cams").reshape(-1, 7)
+    dq = np.minimum(np.abs(cams[:, :4] - o.cams[:, :4]).max(1), np.abs(cams[:, :4] + o.cams[:, :4]).max(1)).max()
+    assert dq < 1e-7 and np.abs(cams[:, 4:] - o.cams[:, 4:]).max() < 1e-6
+    # with the gauge fixed like the Ceres caller does, the truth is recovered
+    out = run(exe_g2o, f, "fix")
+    cams = vec(out, "g2o_cams").reshape(-1, 7)
+    ct = s["cams_true"]
+    dq = np.minimum(np.abs(cams[:, :4] - ct[:, :4]).max(1), np.abs(cams[:, :4] + ct[:, :4]).max(1)).max()
+    assert dq < 1e-6 and np.abs(cams[:, 4:] - ct[:, 4:]).max() < 1e-5
