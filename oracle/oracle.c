@@ -1265,3 +1265,167 @@ int orc_calib_gauss_newton(int n_views, int n_corners, double* params, const dou
     free(e); free(Ji); free(Jx); free(H); free(g);
     return iter;
 }
+
+/* ======================================================================================
+ * pose graph (C4, build-defined)
+ * ==================================================================================== */
+static void rot_apply(const double* q, const double* v, double* o) {
+    double R[9];
+    orc_quat_to_rot(q, R);
+    for (int i = 0; i < 3; ++i) o[i] = R[i * 3] * v[0] + R[i * 3 + 1] * v[1] + R[i * 3 + 2] * v[2];
+}
+
+void orc_se3_compose(const double* a, const double* b, double* out) {
+    double q[4], t[3];
+    orc_quat_mul(a, b, q);
+    rot_apply(a, b + 4, t);
+    const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    for (int i = 0; i < 4; ++i) out[i] = q[i] / n;
+    for (int i = 0; i < 3; ++i) out[4 + i] = t[i] + a[4 + i];
+}
+
+void orc_se3_inverse(const double* a, double* out) {
+    const double qc[4] = {-a[0], -a[1], -a[2], a[3]};
+    double t[3];
+    rot_apply(qc, a + 4, t);
+    memcpy(out, qc, sizeof qc);
+    for (int i = 0; i < 3; ++i) out[4 + i] = -t[i];
+}
+
+void orc_se3_retract(const double* T, const double* delta, double* out) {
+    double e[7];
+    orc_se3_exp(delta, e, e + 4);
+    orc_se3_compose(T, e, out);
+}
+
+static void mat6_mul(const double* A, const double* B, double* C) {
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j) {
+            double s = 0;
+            for (int k = 0; k < 6; ++k) s += A[i * 6 + k] * B[k * 6 + j];
+            C[i * 6 + j] = s;
+        }
+}
+
+/* ad(xi), xi = [rho, theta]: [[hat(theta), hat(rho)], [0, hat(theta)]] */
+static void se3_ad(const double* xi, double* M) {
+    double Hr[9], Ht[9];
+    hat3(xi, Hr); hat3(xi + 3, Ht);
+    memset(M, 0, sizeof(double) * 36);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            M[i * 6 + j] = Ht[i * 3 + j];
+            M[i * 6 + 3 + j] = Hr[i * 3 + j];
+            M[(3 + i) * 6 + 3 + j] = Ht[i * 3 + j];
+        }
+}
+
+/* Ad(T), T = (R, t): [[R, hat(t) R], [0, R]] */
+static void se3_Ad(const double* T, double* M) {
+    double R[9], Ht[9];
+    orc_quat_to_rot(T, R);
+    hat3(T + 4, Ht);
+    memset(M, 0, sizeof(double) * 36);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double s = 0;
+            for (int k = 0; k < 3; ++k) s += Ht[i * 3 + k] * R[k * 3 + j];
+            M[i * 6 + j] = R[i * 3 + j];
+            M[i * 6 + 3 + j] = s;
+            M[(3 + i) * 6 + 3 + j] = R[i * 3 + j];
+        }
+}
+
+static void pg_edge(const double* Ti, const double* Tj, const double* Z, double* r, double* Ji, double* Jj) {
+    double Zi[7], Tii[7], A[7], E[7];
+    orc_se3_inverse(Z, Zi);
+    orc_se3_inverse(Ti, Tii);
+    orc_se3_compose(Tii, Tj, A);        /* T_i^-1 T_j */
+    orc_se3_compose(Zi, A, E);
+    if (E[3] < 0) for (int k = 0; k < 4; ++k) E[k] = -E[k];   /* shortest rotation */
+    orc_se3_log(E, E + 4, r);
+    if (Ji || Jj) {
+        double ad[36], ad2[36], Jr[36];
+        se3_ad(r, ad);
+        mat6_mul(ad, ad, ad2);
+        for (int k = 0; k < 36; ++k) Jr[k] = 0.5 * ad[k] + ad2[k] / 12.0;
+        for (int k = 0; k < 6; ++k) Jr[k * 7] += 1.0;
+        if (Jj) memcpy(Jj, Jr, sizeof Jr);
+        if (Ji) {
+            double Ainv[7], AdM[36];
+            orc_se3_inverse(A, Ainv);   /* T_j^-1 T_i */
+            se3_Ad(Ainv, AdM);
+            mat6_mul(Jr, AdM, Ji);
+            for (int k = 0; k < 36; ++k) Ji[k] = -Ji[k];
+        }
+    }
+}
+
+double orc_pg_evaluate(const orc_pg_problem* p, double* r, double* Ji, double* Jj) {
+    double cost = 0;
+    for (int e = 0; e < p->n_edges; ++e) {
+        const int i = p->edge_i[e], j = p->edge_j[e];
+        double re[6], ji[36], jj[36];
+        pg_edge(&p->poses[i * 7], &p->poses[j * 7], &p->meas[e * 7], re, (Ji || Jj) ? ji : NULL, (Ji || Jj) ? jj : NULL);
+        if (p->node_fixed) {
+            if (p->node_fixed[i]) memset(ji, 0, sizeof ji);
+            if (p->node_fixed[j]) memset(jj, 0, sizeof jj);
+        }
+        for (int k = 0; k < 6; ++k) cost += re[k] * re[k];
+        if (r) memcpy(&r[(size_t)e * 6], re, sizeof re);
+        if (Ji) memcpy(&Ji[(size_t)e * 36], ji, sizeof ji);
+        if (Jj) memcpy(&Jj[(size_t)e * 36], jj, sizeof jj);
+    }
+    return 0.5 * cost;
+}
+
+double orc_pg_ate(int n, const double* truth, const double* est) {
+    double s = 0;
+    for (int i = 0; i < n; ++i) {
+        double ti[7], d[7], xi[6];
+        orc_se3_inverse(&truth[i * 7], ti);
+        orc_se3_compose(ti, &est[i * 7], d);
+        if (d[3] < 0) for (int k = 0; k < 4; ++k) d[k] = -d[k];
+        orc_se3_log(d, d + 4, xi);
+        for (int k = 0; k < 6; ++k) s += xi[k] * xi[k];
+    }
+    return sqrt(s / n);
+}
+
+typedef struct { orc_pg_problem* p; } pg_ctx;
+
+static int pg_residual_cb(void* user, const double* x, double* r, double* J) {
+    pg_ctx* c = (pg_ctx*)user;
+    orc_pg_problem q = *c->p;
+    q.poses = (double*)x;
+    const int n = 6 * q.n_nodes;
+    if (!J) { orc_pg_evaluate(&q, r, NULL, NULL); return 0; }
+    double* Ji = malloc(sizeof(double) * 36 * q.n_edges);
+    double* Jj = malloc(sizeof(double) * 36 * q.n_edges);
+    orc_pg_evaluate(&q, r, Ji, Jj);
+    memset(J, 0, sizeof(double) * (size_t)6 * q.n_edges * n);
+    for (int e = 0; e < q.n_edges; ++e)
+        for (int a = 0; a < 6; ++a)
+            for (int b = 0; b < 6; ++b) {
+                J[(size_t)(e * 6 + a) * n + q.edge_i[e] * 6 + b] = Ji[(size_t)e * 36 + a * 6 + b];
+                J[(size_t)(e * 6 + a) * n + q.edge_j[e] * 6 + b] = Jj[(size_t)e * 36 + a * 6 + b];
+            }
+    /* fixed nodes: unit regulariser rows are not needed -- their columns are zero and the LM
+     * diagonal (clamped at 1e-6) keeps the system positive definite; the step there is 0 */
+    free(Ji); free(Jj);
+    return 0;
+}
+
+static void pg_plus_cb(void* user, const double* x, const double* d, double* out) {
+    pg_ctx* c = (pg_ctx*)user;
+    for (int i = 0; i < c->p->n_nodes; ++i) {
+        if (c->p->node_fixed && c->p->node_fixed[i]) memcpy(&out[i * 7], &x[i * 7], sizeof(double) * 7);
+        else orc_se3_retract(&x[i * 7], &d[i * 6], &out[i * 7]);
+    }
+}
+
+int orc_pg_solve(orc_pg_problem* p, const orc_lm_options* opt, orc_lm_summary* sum, double* trace) {
+    pg_ctx c = {p};
+    return orc_dense_lm(pg_residual_cb, pg_plus_cb, &c, 7 * p->n_nodes, 6 * p->n_nodes, 6 * p->n_edges, p->poses,
+                        NULL, NULL, opt, sum, trace);
+}

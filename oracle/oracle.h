@@ -188,4 +188,35 @@ int orc_calib_gauss_newton(int n_views, int n_corners, double* params, const dou
 #ifdef __cplusplus
 }
 #endif
+
+/* ---------------- pose graph (BASELINE config C4; build-defined: the reference has no
+ * pose-graph code -- SURVEY.md header fact 3 -- so this part is pinned only by its own numeric
+ * checks: central differences, zero residual at the truth, ATE of st4's absTrajectoryError) -------
+ * node pose T_i = (q, t) world<-body, 7 doubles; edge measurement Z_ij ~ T_i^-1 T_j (q, t);
+ * residual r_ij = log(Z_ij^-1 T_i^-1 T_j) in R^6, Sophus tangent order [rho, theta];
+ * right-multiplicative update T <- T exp(delta)  (st23-lie-group-v2/doc.tex:902-923);
+ * Jacobians: d r/d delta_j = Jr^-1(r), d r/d delta_i = -Jr^-1(r) Ad(T_j^-1 T_i), with
+ * Jr^-1(r) = I + ad(r)/2 + ad(r)^2/12 (series truncated after the quadratic term). */
+#ifdef __cplusplus
+extern "C" {
+#endif
+typedef struct {
+    int n_nodes, n_edges;
+    double* poses;                   /* n_nodes*7 (in/out) */
+    const int* edge_i; const int* edge_j;
+    const double* meas;              /* n_edges*7 */
+    const unsigned char* node_fixed; /* n_nodes or NULL */
+} orc_pg_problem;
+void orc_se3_compose(const double* a, const double* b, double* out);      /* 7-double poses */
+void orc_se3_inverse(const double* a, double* out);
+void orc_se3_retract(const double* T, const double* delta, double* out);  /* T exp(delta) */
+/* r[n_edges*6], Ji/Jj[n_edges*36] row-major 6x6 (any may be NULL); returns cost 1/2 sum r^2 */
+double orc_pg_evaluate(const orc_pg_problem* p, double* r, double* Ji, double* Jj);
+/* LM with the dense (6 n_nodes)^2 normal equations + Cholesky: small graphs only */
+int orc_pg_solve(orc_pg_problem* p, const orc_lm_options* opt, orc_lm_summary* sum, double* trace);
+/* st4 absTrajectoryError (pose_simulation.cpp:198-209): sqrt(mean |log(truth^-1 est)|^2) */
+double orc_pg_ate(int n, const double* truth, const double* est);
+#ifdef __cplusplus
+}
+#endif
 #endif

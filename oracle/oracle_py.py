@@ -315,3 +315,57 @@ def calib_gauss_newton(params, obj, img, max_iter=10):
     tr = np.full(max_iter, np.nan)
     it = lib().orc_calib_gauss_newton(C.c_int(V), C.c_int(Cn), _p(params), _p(obj), _p(img), C.c_int(max_iter), _p(tr))
     return params, it, tr
+
+
+# ---------------------------------------------------------------- pose graph (C4, build-defined)
+class PGProblem(C.Structure):
+    _fields_ = [("n_nodes", C.c_int), ("n_edges", C.c_int), ("poses", C.c_void_p), ("edge_i", C.c_void_p),
+                ("edge_j", C.c_void_p), ("meas", C.c_void_p), ("node_fixed", C.c_void_p)]
+
+
+class PG:
+    def __init__(self, poses, edge_i, edge_j, meas, node_fixed=None):
+        self.poses = f64(poses).copy().reshape(-1, 7)
+        self.edge_i = np.ascontiguousarray(edge_i, dtype=np.int32)
+        self.edge_j = np.ascontiguousarray(edge_j, dtype=np.int32)
+        self.meas = f64(meas).reshape(-1, 7)
+        self.node_fixed = None if node_fixed is None else np.ascontiguousarray(node_fixed, dtype=np.uint8)
+        self.n, self.ne = len(self.poses), len(self.edge_i)
+
+    def _struct(self):
+        return PGProblem(self.n, self.ne, _p(self.poses), _p(self.edge_i), _p(self.edge_j), _p(self.meas), _p(self.node_fixed))
+
+    def evaluate(self, jac=True):
+        lib().orc_pg_evaluate.restype = C.c_double
+        r = np.zeros((self.ne, 6))
+        Ji = np.zeros((self.ne, 6, 6)) if jac else None
+        Jj = np.zeros((self.ne, 6, 6)) if jac else None
+        s = self._struct()
+        cost = lib().orc_pg_evaluate(C.byref(s), _p(r), _p(Ji), _p(Jj))
+        return cost, r, Ji, Jj
+
+    def solve(self, opt=None, **kw):
+        opt = opt or default_options(**kw)
+        trace = np.zeros((opt.max_num_iterations + 1, TRACE_COLS))
+        summ = LMSummary()
+        s = self._struct()
+        lib().orc_pg_solve(C.byref(s), C.byref(opt), C.byref(summ), _p(trace))
+        return summ, trace[: summ.num_iterations + 1]
+
+
+def se3_compose(a, b):
+    o = np.zeros(7); lib().orc_se3_compose(_p(f64(a)), _p(f64(b)), _p(o)); return o
+
+
+def se3_inverse(a):
+    o = np.zeros(7); lib().orc_se3_inverse(_p(f64(a)), _p(o)); return o
+
+
+def se3_retract(T, d):
+    o = np.zeros(7); lib().orc_se3_retract(_p(f64(T)), _p(f64(d)), _p(o)); return o
+
+
+def pg_ate(truth, est):
+    lib().orc_pg_ate.restype = C.c_double
+    truth, est = f64(truth), f64(est)
+    return lib().orc_pg_ate(C.c_int(len(truth)), _p(truth), _p(est))

@@ -370,3 +370,66 @@ def calib_scene(n_views=20, rows=8, cols=11, square=0.028, seed=3, pix_noise=0.3
         xis[v] = se3_log(Rv, t)
     img = calib_forward(intr, xis, obj) + rng.normal(0.0, pix_noise, obj.shape)
     return dict(intr_true=intr, xis_true=xis, obj=obj, img=img, rows=rows, cols=cols, square=square)
+
+
+# --------------------------------------------------------------------------- pose graph (C4)
+def _se3_mul(a, b):
+    """compose 7-double poses (q xyzw, t): a * b, vectorised over the first axis"""
+    ax, ay, az, aw = a[..., 0], a[..., 1], a[..., 2], a[..., 3]
+    bx, by, bz, bw = b[..., 0], b[..., 1], b[..., 2], b[..., 3]
+    q = np.stack([aw * bx + ax * bw + ay * bz - az * by, aw * by - ax * bz + ay * bw + az * bx,
+                  aw * bz + ax * by - ay * bx + az * bw, aw * bw - ax * bx - ay * by - az * bz], -1)
+    q /= np.linalg.norm(q, axis=-1, keepdims=True)
+    t = np.einsum("...ij,...j->...i", rot_from_quat(a[..., :4]), b[..., 4:]) + a[..., 4:]
+    return np.concatenate([q, t], -1)
+
+
+def _se3_inv(a):
+    q = a[..., :4] * np.array([-1.0, -1.0, -1.0, 1.0])
+    t = -np.einsum("...ji,...j->...i", rot_from_quat(a[..., :4]), a[..., 4:])
+    return np.concatenate([q, t], -1)
+
+
+def _se3_exp7(xi):
+    R, t = se3_exp(xi)
+    return np.concatenate([quat_from_rot(R), t])
+
+
+def pose_graph_scene(n_nodes=10000, loops_per_node=3, seed=4, sigma_t=0.01, sigma_r=0.002, radius=10.0, turns=10):
+    """BASELINE config C4 (build-defined; the reference has no pose-graph code).  Nodes on the st4
+    sphere spiral (st4-kalman/src/src/pose_simulation.cpp:21-66: `turns` revolutions while z climbs
+    the sphere, body z-axis towards the sphere centre), n-1 odometry edges plus `loops_per_node`
+    loop closures per node to nodes about one revolution away; measurements
+    Z_ij = T_i^-1 T_j exp(noise); initial poses by integrating the noisy odometry; node 0 fixed."""
+    rng = np.random.default_rng(seed)
+    k = np.arange(n_nodes)
+    theta = 2 * np.pi * turns * k / (n_nodes - 1)
+    z = 0.02 * radius + 1.96 * radius * k / (n_nodes - 1)
+    ri = np.sqrt(np.maximum(radius * radius - (z - radius) ** 2, 1e-12))
+    pos = np.stack([ri * np.cos(theta), ri * np.sin(theta), z], 1)
+    centre = np.array([0.0, 0.0, radius])
+    poses = np.zeros((n_nodes, 7))
+    for i in range(n_nodes):
+        za = centre - pos[i]; za /= np.linalg.norm(za)
+        xa = np.array([-np.sin(theta[i]), np.cos(theta[i]), 0.0])
+        xa = xa - za * (xa @ za); xa /= np.linalg.norm(xa)
+        ya = np.cross(za, xa)
+        poses[i, :4] = quat_from_rot(np.stack([xa, ya, za], 1))
+        poses[i, 4:] = pos[i]
+    ei = list(range(n_nodes - 1)); ej = list(range(1, n_nodes))
+    per_turn = max(2, (n_nodes - 1) // turns)
+    for i in range(n_nodes):
+        for _ in range(loops_per_node):
+            j = i + per_turn + int(rng.integers(-max(1, per_turn // 50), max(2, per_turn // 50 + 1)))
+            if 0 <= j < n_nodes and j != i:
+                ei.append(i); ej.append(j)
+    ei = np.array(ei, np.int32); ej = np.array(ej, np.int32)
+    rel = _se3_mul(_se3_inv(poses[ei]), poses[ej])
+    noise = np.concatenate([rng.normal(0, sigma_t, (len(ei), 3)), rng.normal(0, sigma_r, (len(ei), 3))], 1)
+    meas = np.stack([_se3_mul(rel[e][None], _se3_exp7(noise[e])[None])[0] for e in range(len(ei))])
+    init = np.zeros_like(poses)
+    init[0] = poses[0]
+    for i in range(1, n_nodes):
+        init[i] = _se3_mul(init[i - 1][None], meas[i - 1][None])[0]
+    fixed = np.zeros(n_nodes, np.uint8); fixed[0] = 1
+    return dict(poses_true=poses, poses0=init, edge_i=ei, edge_j=ej, meas=meas, node_fixed=fixed)
