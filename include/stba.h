@@ -197,6 +197,27 @@ int stba_calib_evaluate(int n_views, int n_corners, const double* params, const 
 int stba_calib_gauss_newton(int n_views, int n_corners, double* params, const double* obj, const double* img,
                             int max_iter, double* sse_trace, int* iterations);
 
+/* ================================ pose graph (BASELINE config C4) ======================== */
+/* BUILD-DEFINED: the reference has no pose-graph code (SURVEY.md header fact 3).  Conventions from the
+ * reference's Lie-group notes (st23-lie-group-v2/doc.tex:862-996): node pose T = (qx qy qz qw tx ty tz),
+ * right-multiplicative update T <- T exp(delta), tangent [rho, theta]; edge measurement Z_ij ~ T_i^-1 T_j;
+ * residual r_ij = log(Z_ij^-1 T_i^-1 T_j).  Levenberg-Marquardt with block-Jacobi preconditioned CG. */
+typedef struct stba_pg stba_pg;
+typedef struct {
+    int    max_iterations;       /* 1000 */
+    double relative_tolerance;   /* 1e-12 on |residual| / |rhs| */
+    int    check_every;          /* 20: iterations between host-side convergence checks */
+} stba_pcg_options;
+void stba_pcg_default_options(stba_pcg_options* o);
+int stba_pg_create(stba_pg** out, int n_nodes, int n_edges, const double* poses, const int* edge_i, const int* edge_j,
+                   const double* meas, const unsigned char* node_fixed, void* hip_stream);
+int stba_pg_destroy(stba_pg* pg);
+int stba_pg_get_poses(stba_pg* pg, double* poses);
+/* r[n_edges*6], Ji / Jj [n_edges*36] (6x6 row-major, wrt delta_i / delta_j); any may be NULL */
+int stba_pg_evaluate(stba_pg* pg, double* cost, double* r, double* Ji, double* Jj);
+int stba_pg_solve(stba_pg* pg, const stba_lm_options* opt, const stba_pcg_options* pcg, stba_lm_summary* summary,
+                  double* trace, int* pcg_iterations_total);
+
 /* ================================ small dense LM problems ================================ */
 /* Residual blocks evaluated by a HOST callback (user CostFunction::Evaluate, solver.hpp:168-212;
  * autodiff functors are differentiated on the host by the C++ shim), normal equations + LM

@@ -67,7 +67,8 @@ EXPORTS = ["stba_status_string", "stba_last_error", "stba_version", "stba_device
            "stba_ba_back_substitute", "stba_ba_apply_step", "stba_ba_solve", "stba_ba_lm_iterations",
            "stba_ba_triangulate", "stba_ba_time_linearize", "stba_cholesky_factor", "stba_cholesky_solve",
            "stba_cholesky_time", "stba_cholesky_profile", "stba_calib_evaluate", "stba_calib_gauss_newton",
-           "stba_dense_solve"]
+           "stba_pcg_default_options", "stba_pg_create", "stba_pg_destroy", "stba_pg_get_poses", "stba_pg_evaluate",
+           "stba_pg_solve", "stba_dense_solve"]
 
 
 def lib():
@@ -234,6 +235,60 @@ class BAEngine:
         ms = C.c_double()
         _chk(lib().stba_ba_time_linearize(self._h, int(reps), C.byref(ms)), "stba_ba_time_linearize")
         return ms.value
+
+
+class PCGOptions(C.Structure):
+    _fields_ = [("max_iterations", C.c_int), ("relative_tolerance", C.c_double), ("check_every", C.c_int)]
+
+
+class PGEngine:
+    """Device-resident pose graph (BASELINE config C4, build-defined)."""
+
+    def __init__(self, poses, edge_i, edge_j, meas, node_fixed=None, stream=None):
+        self._h = C.c_void_p()
+        poses = _f64(poses).reshape(-1, 7)
+        ei = np.ascontiguousarray(edge_i, dtype=np.int32); ej = np.ascontiguousarray(edge_j, dtype=np.int32)
+        meas = _f64(meas).reshape(-1, 7)
+        nf = None if node_fixed is None else np.ascontiguousarray(node_fixed, dtype=np.uint8)
+        self.n, self.m = len(poses), len(ei)
+        _chk(lib().stba_pg_create(C.byref(self._h), self.n, self.m, _p(poses), _p(ei), _p(ej), _p(meas), _p(nf),
+                                  C.c_void_p(stream or 0)), "stba_pg_create")
+
+    def close(self):
+        if self._h:
+            lib().stba_pg_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def get_poses(self):
+        out = np.zeros((self.n, 7))
+        _chk(lib().stba_pg_get_poses(self._h, _p(out)), "stba_pg_get_poses")
+        return out
+
+    def evaluate(self, jac=True):
+        cost = C.c_double()
+        r = np.zeros((self.m, 6))
+        Ji = np.zeros((self.m, 6, 6)) if jac else None
+        Jj = np.zeros((self.m, 6, 6)) if jac else None
+        _chk(lib().stba_pg_evaluate(self._h, C.byref(cost), _p(r), _p(Ji), _p(Jj)), "stba_pg_evaluate")
+        return cost.value, r, Ji, Jj
+
+    def solve(self, opt=None, pcg=None, **kw):
+        opt = opt or default_options(**kw)
+        if pcg is None:
+            pcg = PCGOptions()
+            lib().stba_pcg_default_options(C.byref(pcg))
+        trace = np.zeros((opt.max_num_iterations + 1, TRACE_COLS))
+        summ = LMSummary()
+        total = C.c_int()
+        _chk(lib().stba_pg_solve(self._h, C.byref(opt), C.byref(pcg), C.byref(summ), _p(trace), C.byref(total)),
+             "stba_pg_solve")
+        return summ, trace[: summ.num_iterations + 1], total.value
 
 
 def cholesky_factor(A, stream=None):

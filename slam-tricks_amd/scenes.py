@@ -420,7 +420,10 @@ def pose_graph_scene(n_nodes=10000, loops_per_node=3, seed=4, sigma_t=0.01, sigm
     per_turn = max(2, (n_nodes - 1) // turns)
     for i in range(n_nodes):
         for _ in range(loops_per_node):
-            j = i + per_turn + int(rng.integers(-max(1, per_turn // 50), max(2, per_turn // 50 + 1)))
+            jit = int(rng.integers(-max(1, per_turn // 50), max(2, per_turn // 50 + 1)))
+            j = i + per_turn + jit
+            if j >= n_nodes:                      # last revolution: close the loop backwards
+                j = i - per_turn + jit
             if 0 <= j < n_nodes and j != i:
                 ei.append(i); ej.append(j)
     ei = np.array(ei, np.int32); ej = np.array(ej, np.int32)
