@@ -32,7 +32,6 @@
 namespace stba {
 
 constexpr int NB = CHOL_NB;
-constexpr int TRSM_ROWS = 32;
 typedef double double4v __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------------
@@ -82,14 +81,23 @@ __device__ __forceinline__ double sqrt_from_rsqrt(double d, double y) {
 //      tile, operands straight from the scaled panel rows in LDS (2 x 8 B per lane per tile
 //      instead of 32 LDS reads per thread for the same flops on the VALU)
 //   f. the finished panel columns are written back into the accumulators.
+// optional phase timestamps for tools/exp/diag_timing.hip (compiled out of the library)
+#ifdef STBA_DIAG_TS
+__device__ long long g_diag_ts[4][16][6];
+#define DIAG_TS(slot) do { if ((t & 63) == 0) g_diag_ts[t >> 6][2 * Jt + h][slot] = __builtin_readcyclecounter(); } while (0)
+#else
+#define DIAG_TS(slot) do { } while (0)
+#endif
+
 template <int Jt>
-__device__ __forceinline__ void chol_diag_tilecol(double4v (&acc)[2][8], double (*P)[9], double (*Lp)[9], int t, int lr,
+__device__ __forceinline__ void chol_diag_tilecol(double4v (&acc)[2][8], double (*P)[9], double (*Lp)[9], double* rd, int t, int lr,
                                                   int lc, const int (&Irow)[2], int k0, int n_real, int* flag) {
     // tile column Jt is a compile-time constant so that every accumulator index is static (a runtime
     // tile index makes the compiler spill the accumulators to scratch)
 #pragma unroll 1
     for (int h = 0; h < 2; ++h) {
         const int j0 = 16 * Jt + 8 * h;
+        DIAG_TS(0);
         // a. publish the 8 panel columns (lanes with (lc >> 3) == h)
         if ((lc >> 3) == h) {
 #pragma unroll
@@ -100,6 +108,7 @@ __device__ __forceinline__ void chol_diag_tilecol(double4v (&acc)[2][8], double 
                 }
         }
         __syncthreads();
+        DIAG_TS(1);
         // c. one thread per row at or below the block
         if (t < NB && t >= j0) {
             const int i = t;
@@ -125,6 +134,10 @@ __device__ __forceinline__ void chol_diag_tilecol(double4v (&acc)[2][8], double 
                     for (int q = c + 1; q <= r; ++q) D[r][q] = fma(-D[r][c], D[q][c], D[r][q]);
             }
             if (bad && i == j0) atomicCAS(flag, 0, k0 + j0 + 1);
+            if (i == j0) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) rd[j0 + c] = y[c];      // 1 / L[c][c], for the inverse blocks
+            }
             // l G^T = p, right-looking.  Rows INSIDE the 8x8 block take the same path: row r of
             // D = G G^T solves to row r of G in its first r+1 entries; the entries right of the
             // diagonal come out as garbage, but they only ever meet (i) panel-column elements that
@@ -138,7 +151,9 @@ __device__ __forceinline__ void chol_diag_tilecol(double4v (&acc)[2][8], double 
 #pragma unroll
             for (int c = 0; c < 8; ++c) Lp[i][c] = l[c];
         }
+        DIAG_TS(2);
         __syncthreads();
+        DIAG_TS(3);
         // e. rank-8 update of the trailing tiles on the matrix cores (tile columns > Jt, and Jt itself
         //    while its right half is still trailing, i.e. h == 0)
 #pragma unroll
@@ -155,6 +170,7 @@ __device__ __forceinline__ void chol_diag_tilecol(double4v (&acc)[2][8], double 
                     }
             }
         }
+        DIAG_TS(4);
         // f. finished columns of the panel -> accumulators (rows at or below the column)
         if ((lc >> 3) == h) {
 #pragma unroll
@@ -169,13 +185,17 @@ __device__ __forceinline__ void chol_diag_tilecol(double4v (&acc)[2][8], double 
                     }
                 }
         }
+        DIAG_TS(5);
     }
 }
 
 __global__ __launch_bounds__(256) void chol_diag_kernel(double* __restrict__ A, int lda, int k0,
-                                                         int n_real, int* __restrict__ flag) {
+                                                         int n_real, int* __restrict__ flag,
+                                                         double* __restrict__ dinv) {
     __shared__ double P[NB][9];
     __shared__ double Lp[NB][9];
+    __shared__ double rd[NB];
+    __shared__ double Tl[8][16][17];
     const int t = threadIdx.x, lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int lr = lane >> 4, lc = lane & 15;
@@ -194,14 +214,14 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(double* __restrict__ A, 
             tmp[3] = in ? src[(size_t)12 * lda] : 0.0;
             acc[s][J] = tmp;
         }
-    chol_diag_tilecol<0>(acc, P, Lp, t, lr, lc, Irow, k0, n_real, flag);
-    chol_diag_tilecol<1>(acc, P, Lp, t, lr, lc, Irow, k0, n_real, flag);
-    chol_diag_tilecol<2>(acc, P, Lp, t, lr, lc, Irow, k0, n_real, flag);
-    chol_diag_tilecol<3>(acc, P, Lp, t, lr, lc, Irow, k0, n_real, flag);
-    chol_diag_tilecol<4>(acc, P, Lp, t, lr, lc, Irow, k0, n_real, flag);
-    chol_diag_tilecol<5>(acc, P, Lp, t, lr, lc, Irow, k0, n_real, flag);
-    chol_diag_tilecol<6>(acc, P, Lp, t, lr, lc, Irow, k0, n_real, flag);
-    chol_diag_tilecol<7>(acc, P, Lp, t, lr, lc, Irow, k0, n_real, flag);
+    chol_diag_tilecol<0>(acc, P, Lp, rd, t, lr, lc, Irow, k0, n_real, flag);
+    chol_diag_tilecol<1>(acc, P, Lp, rd, t, lr, lc, Irow, k0, n_real, flag);
+    chol_diag_tilecol<2>(acc, P, Lp, rd, t, lr, lc, Irow, k0, n_real, flag);
+    chol_diag_tilecol<3>(acc, P, Lp, rd, t, lr, lc, Irow, k0, n_real, flag);
+    chol_diag_tilecol<4>(acc, P, Lp, rd, t, lr, lc, Irow, k0, n_real, flag);
+    chol_diag_tilecol<5>(acc, P, Lp, rd, t, lr, lc, Irow, k0, n_real, flag);
+    chol_diag_tilecol<6>(acc, P, Lp, rd, t, lr, lc, Irow, k0, n_real, flag);
+    chol_diag_tilecol<7>(acc, P, Lp, rd, t, lr, lc, Irow, k0, n_real, flag);
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -213,120 +233,103 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(double* __restrict__ A, 
                     if (col <= row) A[(size_t)(k0 + row) * lda + k0 + col] = acc[s][J][r];
                 }
             }
-}
-
-// ------------------------------------------------------------------------------------------
-// shared by the panel solve and the backward substitution: stage the 128x128 lower block in LDS
-// (row stride LDS_LD, 16 B aligned rows) and invert its sixteen 8x8 diagonal blocks:
-// Gi[J][k][m] = (L_JJ^-1)[k][m].  Called by all threads of the workgroup; ends with a barrier.
-constexpr int LDS_LD = 130;
-template <int NT>
-__device__ __forceinline__ void stage_block_and_inverses(const double* __restrict__ A, int lda, int k0, int nv,
-                                                         double* __restrict__ Ld, double* __restrict__ invd,
-                                                         double* __restrict__ Gi, int t) {
-    // one 1 KiB row per wave instruction (16 B per lane), all loads of a thread issued back to back
-    constexpr int ITER = NB * (NB / 2) / NT;
-    double2 v[ITER];
+    // inverses of the eight 16x16 diagonal tiles (the panel solve multiplies by them on the matrix
+    // cores): thread (b, m) forward-substitutes column m of tile b's inverse
 #pragma unroll
-    for (int k = 0; k < ITER; ++k) {
-        const int idx = t + k * NT;
-        const int i = idx >> 6, c = (idx & 63) * 2;
-        v[k] = make_double2(0.0, 0.0);
-        if (c <= i && i < nv) v[k] = *reinterpret_cast<const double2*>(&A[(size_t)(k0 + i) * lda + k0 + c]);
-    }
+    for (int s = 0; s < 2; ++s)
 #pragma unroll
-    for (int k = 0; k < ITER; ++k) {
-        const int idx = t + k * NT;
-        const int i = idx >> 6, c = (idx & 63) * 2;
-        double2 w = v[k];
-        if (c + 1 > i) w.y = 0.0;                    // strictly upper element of the pair
-        if (i >= nv) { w.x = (c == i) ? 1.0 : 0.0; w.y = (c + 1 == i) ? 1.0 : 0.0; }
-        *reinterpret_cast<double2*>(&Ld[i * LDS_LD + c]) = w;
-    }
-    __syncthreads();
-    if (t < NB) invd[t] = 1.0 / Ld[t * LDS_LD + t];
+        for (int J = 0; J < 8; ++J)
+            if (J == Irow[s]) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Tl[J][lr + 4 * r][lc] = acc[s][J][r];
+            }
     __syncthreads();
     if (t < NB) {
-        const int J = t >> 3, m = t & 7;
-        double x[8];
+        const int b = t >> 4, m = t & 15;
+        double x[16];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            double s = (k == m) ? 1.0 : 0.0;
+        for (int k = 0; k < 16; ++k) {
+            double sum = (k == m) ? 1.0 : 0.0;
 #pragma unroll
-            for (int q = 0; q < k; ++q) s = fma(-Ld[(8 * J + k) * LDS_LD + 8 * J + q], (q >= m) ? x[q] : 0.0, s);
-            x[k] = (k >= m) ? s * invd[8 * J + k] : 0.0;
-            Gi[(J * 8 + k) * 8 + m] = x[k];
+            for (int q = 0; q < k; ++q) sum = fma(-Tl[b][k][q], x[q], sum);
+            x[k] = (k >= m) ? sum * rd[16 * b + k] : 0.0;
+            dinv[(b * 16 + k) * 16 + m] = x[k];
         }
     }
-    __syncthreads();
 }
 
 // ------------------------------------------------------------------------------------------
-// X = A21 * L11^-T for TRSM_ROWS rows per workgroup, in place, in column blocks of width 8.
-// 256 threads: thread (r, cg) owns row r = t >> 3 and columns cg + 8m (m < 16), i.e. exactly one
-// column of every 8-wide block; the 8 threads of a row are 8 consecutive lanes, so a block step
-// needs only lane shuffles (no LDS hand-off, no barrier):
-//   x = T_J * Gi_J^T (8 shuffles), then columns to the right -= X_J * L11[c, J-block]^T.
-template <int J>
-__device__ __forceinline__ void chol_trsm_block(double (&acc)[16], const double* __restrict__ Ld,
-                                                const double* __restrict__ Gi, int lane, int cg) {
-    const int base = lane & ~7;
-    const double tv = acc[J];
-    double x = 0.0;
-    const double* gi = Gi + (J * 8 + cg) * 8;      // row cg of the inverse block: Gi[J][cg][m]
+// Panel solve X = A21 * L11^-T on the matrix cores, one wave per 16 panel rows, computed in the
+// transposed form  Y = X^T = L11^-1 * A21^T  so that a finished 16x16 tile Y_I, sitting in the
+// accumulator layout, IS the B operand of the next v_mfma_f64_16x16x4_f64 (k-step q <-> register q):
+// no LDS, no shuffles, no barriers.
+//   for I = 0..7:   Y_I  = Inv_II * W_I                      (4 MFMAs; Inv_II from chol_diag_kernel)
+//                   W_J -= L_JI * Y_I   for J > I            (4 MFMAs per tile, independent chains)
+// Row order inside a tile: accumulator register r of lane group g holds LOGICAL row 4g + r (physical
+// MFMA row g + 4r), so a lane's four registers are four consecutive matrix columns of X: one 32 B
+// load/store per lane per tile, and the A operands (L_JI, Inv_II) are one 32 B load per lane too.
+// The last 8 workgroups run the same solve on the rows of the identity: X = I * L11^-T, the
+// inverse transpose of the diagonal block, used by the backward substitution.
+__global__ __launch_bounds__(64) void chol_trsm_kernel(double* __restrict__ A, int lda, int k0, int n_groups,
+                                                       double* __restrict__ Xinv, const double* __restrict__ dinv) {
+    const int lane = threadIdx.x, n = lane & 15, g = lane >> 4;
+    const int pm = 4 * (n & 3) + (n >> 2);          // logical tile row this lane feeds as an A operand
+    const int grp = blockIdx.x;
+    const bool ident = grp >= n_groups;
+    const int e = grp - n_groups;
+    const int nv = ident ? min(NB, (lda - 1) - k0) : NB;   // rows of the block that belong to the system
+    double* rowp = ident ? Xinv + (size_t)(16 * e + n) * NB
+                         : A + (size_t)(k0 + NB + 16 * grp + n) * lda + k0;
+    const double* Lb = A + (size_t)k0 * lda + k0;
+    double4v W[8];
 #pragma unroll
-    for (int m = 0; m < 8; ++m) x = fma(__shfl(tv, base + m, 64), gi[m], x);
-    acc[J] = x;
-    double xs[8];
+    for (int J = 0; J < 8; ++J) {
+        if (ident) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) xs[k] = __shfl(x, base + k, 64);
-#pragma unroll
-    for (int m = J + 1; m < 16; ++m) {
-        const double2* lrow = reinterpret_cast<const double2*>(Ld + (cg + 8 * m) * LDS_LD + 8 * J);
-        double v = acc[m];
-#pragma unroll
-        for (int k2 = 0; k2 < 4; ++k2) {
-            const double2 l2 = lrow[k2];
-            v = fma(-xs[2 * k2], l2.x, v);
-            v = fma(-xs[2 * k2 + 1], l2.y, v);
+            for (int r = 0; r < 4; ++r) W[J][r] = (16 * J + 4 * g + r == 16 * e + n) ? 1.0 : 0.0;
+        } else {
+            W[J] = *reinterpret_cast<const double4v*>(rowp + 16 * J + 4 * g);
         }
-        acc[m] = v;
     }
-}
-
-__global__ __launch_bounds__(256) void chol_trsm_kernel(double* __restrict__ A, int lda, int k0, int n_row_wgs,
-                                                        double* __restrict__ Xinv) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    double* Ld = smem;                          // [128][130]
-    double* Gi = smem + NB * LDS_LD;            // [16][8][8]
-    double* invd = Gi + 16 * 64;                // [128]
-    const int t = threadIdx.x, r = t >> 3, cg = t & 7, lane = t & 63;
-    // the last 4 workgroups run the same solve on the rows of the identity: X = I * L11^-T is the
-    // (upper-triangular) inverse transpose of the diagonal block, used by the backward substitution
-    const bool ident = (int)blockIdx.x >= n_row_wgs;
-    const int rid = ((int)blockIdx.x - n_row_wgs) * TRSM_ROWS + r;
-    const int row = k0 + NB + blockIdx.x * TRSM_ROWS + r;
-    const int nv = min(NB, (lda - 1) - k0);     // rows of the diagonal block that belong to the system
-    double acc[16];
+    auto load_l = [&](int J, int I) -> double4v {
+        const int row = 16 * J + pm;
+        double4v v = *reinterpret_cast<const double4v*>(Lb + (size_t)row * lda + 16 * I + 4 * g);
+        if (row >= nv) v = double4v{0.0, 0.0, 0.0, 0.0};
+        return -v;
+    };
+    auto load_inv = [&](int J) -> double4v {
+        double4v v = *reinterpret_cast<const double4v*>(dinv + (J * 16 + pm) * 16 + 4 * g);
+        if (16 * J + pm >= nv) {
 #pragma unroll
-    for (int m = 0; m < 16; ++m)
-        acc[m] = ident ? ((cg + 8 * m == rid) ? 1.0 : 0.0) : A[(size_t)row * lda + k0 + cg + 8 * m];
-    stage_block_and_inverses<256>(A, lda, k0, ident ? nv : NB, Ld, invd, Gi, t);
-    chol_trsm_block<0>(acc, Ld, Gi, lane, cg);   chol_trsm_block<1>(acc, Ld, Gi, lane, cg);
-    chol_trsm_block<2>(acc, Ld, Gi, lane, cg);   chol_trsm_block<3>(acc, Ld, Gi, lane, cg);
-    chol_trsm_block<4>(acc, Ld, Gi, lane, cg);   chol_trsm_block<5>(acc, Ld, Gi, lane, cg);
-    chol_trsm_block<6>(acc, Ld, Gi, lane, cg);   chol_trsm_block<7>(acc, Ld, Gi, lane, cg);
-    chol_trsm_block<8>(acc, Ld, Gi, lane, cg);   chol_trsm_block<9>(acc, Ld, Gi, lane, cg);
-    chol_trsm_block<10>(acc, Ld, Gi, lane, cg);  chol_trsm_block<11>(acc, Ld, Gi, lane, cg);
-    chol_trsm_block<12>(acc, Ld, Gi, lane, cg);  chol_trsm_block<13>(acc, Ld, Gi, lane, cg);
-    chol_trsm_block<14>(acc, Ld, Gi, lane, cg);  chol_trsm_block<15>(acc, Ld, Gi, lane, cg);
-    if (ident) {
+            for (int q = 0; q < 4; ++q) v[q] = (4 * g + q == pm) ? 1.0 : 0.0;
+        }
+        return v;
+    };
+    double4v Lc[8], Ln[8], iv, ivn;
+    iv = load_inv(0);
 #pragma unroll
-        for (int m = 0; m < 16; ++m) Xinv[(size_t)rid * NB + cg + 8 * m] = acc[m];
-    } else {
+    for (int J = 1; J < 8; ++J) Lc[J] = load_l(J, 0);
 #pragma unroll
-        for (int m = 0; m < 16; ++m) A[(size_t)row * lda + k0 + cg + 8 * m] = acc[m];
+    for (int I = 0; I < 8; ++I) {
+        if (I + 1 < 8) {
+            ivn = load_inv(I + 1);
+#pragma unroll
+            for (int J = I + 2; J < 8; ++J) Ln[J] = load_l(J, I + 1);
+        }
+        double4v y = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) y = __builtin_amdgcn_mfma_f64_16x16x4f64(iv[q], W[I][q], y, 0, 0, 0);
+        W[I] = y;
+#pragma unroll
+        for (int J = I + 1; J < 8; ++J)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) W[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(Lc[J][q], y[q], W[J], 0, 0, 0);
+        iv = ivn;
+#pragma unroll
+        for (int J = I + 2; J < 8; ++J) Lc[J] = Ln[J];
     }
+#pragma unroll
+    for (int J = 0; J < 8; ++J) *reinterpret_cast<double4v*>(rowp + 16 * J + 4 * g) = W[J];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -524,22 +527,28 @@ __global__ __launch_bounds__(1024) void chol_bwd_step_kernel(double* __restrict_
 static int chol_run(double* A, int lda, int n, double* x_dev, int* flag_dev, hipStream_t st, CholProfile* prof) {
     if (lda % NB != 0 || lda < n + 1) return fail(STBA_ERR_INVALID_ARGUMENT, "chol: bad padded dimension");
     const int nblk = lda / NB;
-    const size_t trsm_lds = sizeof(double) * (NB * LDS_LD + 16 * 64 + NB);
-    static bool attr_set = false;
-    if (!attr_set) {
-        STBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(chol_trsm_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)trsm_lds));
-        attr_set = true;
-    }
-    // inverse transposes of the diagonal blocks (written by the panel solve, read by the backward pass)
+    // per diagonal block: its inverse transpose (written by the panel solve, read by the backward pass)
+    // followed by the inverses of its eight 16x16 diagonal tiles (written by the diagonal kernel, read
+    // by the panel solve)
+    constexpr size_t LINV_STRIDE = (size_t)NB * NB + 8 * 256;
     static thread_local double* linv = nullptr;
     static thread_local int linv_blocks = 0;
     if (linv_blocks < nblk) {
         if (linv) (void)hipFree(linv);
         linv = nullptr; linv_blocks = 0;
-        STBA_HIP(hipMalloc(reinterpret_cast<void**>(&linv), (size_t)nblk * NB * NB * sizeof(double)));
+        STBA_HIP(hipMalloc(reinterpret_cast<void**>(&linv), (size_t)nblk * LINV_STRIDE * sizeof(double)));
         linv_blocks = nblk;
     }
+    // panel of block b: diagonal kernel + panel solve of the (nblk - b - 1) * 8 row groups below it
+    auto launch_panel_diag = [&](int b, hipStream_t s_) {
+        double* li = linv + (size_t)b * LINV_STRIDE;
+        hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), 0, s_, A, lda, b * NB, n, flag_dev, li + NB * NB);
+    };
+    auto launch_panel_trsm = [&](int b, hipStream_t s_) {
+        double* li = linv + (size_t)b * LINV_STRIDE;
+        const int groups = (nblk - b - 1) * (NB / 16);
+        hipLaunchKernelGGL(chol_trsm_kernel, dim3(groups + NB / 16), dim3(64), 0, s_, A, lda, b * NB, groups, li, li + NB * NB);
+    };
     std::vector<hipEvent_t> ev;
     if (prof) {
         ev.resize((size_t)nblk * 4 + 2);
@@ -554,10 +563,9 @@ static int chol_run(double* A, int lda, int n, double* x_dev, int* flag_dev, hip
             const int k0 = b * NB;
             const int mt = nblk - b - 1;
             STBA_TRY(mark(4 * (size_t)b + 0));
-            hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), 0, st, A, lda, k0, n, flag_dev);
+            launch_panel_diag(b, st);
             STBA_TRY(mark(4 * (size_t)b + 1));
-            hipLaunchKernelGGL(chol_trsm_kernel, dim3(mt * (NB / TRSM_ROWS) + NB / TRSM_ROWS), dim3(256), trsm_lds, st, A, lda, k0,
-                               mt * (NB / TRSM_ROWS), linv + (size_t)b * NB * NB);
+            launch_panel_trsm(b, st);
             STBA_TRY(mark(4 * (size_t)b + 2));
             if (mt > 0) launch_syrk(A, lda, k0, 0, mt * (mt + 1) / 2, st);
             STBA_TRY(mark(4 * (size_t)b + 3));
@@ -569,60 +577,79 @@ static int chol_run(double* A, int lda, int n, double* x_dev, int* flag_dev, hip
             }
         }
     } else {
-        // look-ahead schedule: the panel of step b+1 (diagonal block + panel solve, on `st`) overlaps
-        // the bulk of the trailing update of step b (on a side stream); only the update of the
-        // next panel's tile column sits on the critical path.
-        static thread_local hipStream_t su = nullptr;
-        static thread_local std::vector<hipEvent_t> evP, evN;
-        static thread_local hipEvent_t evU = nullptr;
-        if (!su) {
-            // bulk trailing updates run at the LOWEST priority so that panel kernels win dispatch slots
-            int lo_prio = 0, hi_prio = 0;
-            STBA_HIP(hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio));
-            STBA_HIP(hipStreamCreateWithPriority(&su, hipStreamNonBlocking, lo_prio));
-            STBA_HIP(hipEventCreateWithFlags(&evU, hipEventDisableTiming));
+        // look-ahead schedule on a partitioned chip.  The panel chain (diagonal block, panel solve,
+        // update of the next panel's tile column) is latency-bound and needs few CUs; the bulk of the
+        // trailing update is throughput-bound.  Two streams with DISJOINT CU masks
+        // (hipExtStreamCreateWithCUMask) keep them from competing for the same CUs: without the
+        // partition a 324-VGPR diagonal-block workgroup cannot start until a CU has drained ALL its
+        // trailing-update workgroups, which serialises the two.  Dependencies:
+        //   sp:  D(0) T(0) | U1(0) D(1) T(1) | [wait bulk(0)] U1(1) D(2) T(2) | ...
+        //   su:             [wait T(0)] U2(0)  [wait T(1)] U2(1) ...
+        // U1(b) = update of tile column b+1 by panel b; U2(b) = the columns right of it.  The only
+        // cross-stream wait on the panel chain is for U2(b-1), which had a whole panel time to finish.
+        static thread_local hipStream_t sp = nullptr, su = nullptr;
+        static thread_local std::vector<hipEvent_t> evP, evU;
+        static thread_local hipEvent_t evStart = nullptr, evEnd = nullptr;
+        static const int PANEL_CUS = [] { const char* e = getenv("STBA_PANEL_CUS"); return e ? atoi(e) : 32; }();
+        static const int SERIAL_MT = [] { const char* e = getenv("STBA_SERIAL_MT"); return e ? atoi(e) : 0; }();
+        if (!sp) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            STBA_HIP(hipGetDevice(&dev));
+            STBA_HIP(hipGetDeviceProperties(&prop, dev));
+            const int ncu = prop.multiProcessorCount;
+            const int words = (ncu + 31) / 32;
+            std::vector<uint32_t> mp((size_t)words, 0u), mu((size_t)words, 0u);
+            for (int c = 0; c < ncu; ++c) {
+                if (c < PANEL_CUS) mp[(size_t)c / 32] |= 1u << (c % 32);
+                else mu[(size_t)c / 32] |= 1u << (c % 32);
+            }
+            if (PANEL_CUS <= 0 || PANEL_CUS >= ncu) {   // no partition: plain streams
+                STBA_HIP(hipStreamCreateWithFlags(&sp, hipStreamNonBlocking));
+                STBA_HIP(hipStreamCreateWithFlags(&su, hipStreamNonBlocking));
+            } else {
+                STBA_HIP(hipExtStreamCreateWithCUMask(&sp, (uint32_t)words, mp.data()));
+                STBA_HIP(hipExtStreamCreateWithCUMask(&su, (uint32_t)words, mu.data()));
+            }
+            STBA_HIP(hipEventCreateWithFlags(&evStart, hipEventDisableTiming));
+            STBA_HIP(hipEventCreateWithFlags(&evEnd, hipEventDisableTiming));
         }
         while ((int)evP.size() < nblk) {
             hipEvent_t e1, e2;
             STBA_HIP(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
             STBA_HIP(hipEventCreateWithFlags(&e2, hipEventDisableTiming));
-            evP.push_back(e1); evN.push_back(e2);
+            evP.push_back(e1); evU.push_back(e2);
         }
-        hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), 0, st, A, lda, 0, n, flag_dev);
-        hipLaunchKernelGGL(chol_trsm_kernel, dim3((nblk - 1) * (NB / TRSM_ROWS) + NB / TRSM_ROWS), dim3(256), trsm_lds, st, A, lda, 0,
-                           (nblk - 1) * (NB / TRSM_ROWS), linv);
-        STBA_HIP(hipEventRecord(evP[0], st));
-        // look-ahead only pays while the bulk update is longer than the panel chain (measured on
-        // MI355X: cross-stream hand-offs cost ~7-14 us each and the panel is ~65 us under contention)
-        static const int LOOKAHEAD_MIN_MT = [] { const char* e = getenv("STBA_LOOKAHEAD_MIN_MT"); return e ? atoi(e) : 36; }();
-        int b = 0;
-        for (; b + 1 < nblk && (nblk - b - 1) >= LOOKAHEAD_MIN_MT; ++b) {
+        STBA_HIP(hipEventRecord(evStart, st));
+        STBA_HIP(hipStreamWaitEvent(sp, evStart, 0));
+        launch_panel_diag(0, sp);
+        launch_panel_trsm(0, sp);
+        STBA_HIP(hipEventRecord(evP[0], sp));
+        int b = 0, last_bulk = -1;
+        for (; b + 1 < nblk && (nblk - b - 1) > SERIAL_MT; ++b) {
             const int k0 = b * NB;
             const int mt = nblk - b - 1;
-            STBA_HIP(hipStreamWaitEvent(su, evP[b], 0));
-            launch_syrk(A, lda, k0, 1, mt, su);
-            STBA_HIP(hipEventRecord(evN[b], su));
-            if (mt > 1)
+            if (last_bulk >= 0) STBA_HIP(hipStreamWaitEvent(sp, evU[last_bulk], 0));
+            launch_syrk(A, lda, k0, 1, mt, sp);
+            if (mt > 1) {
+                STBA_HIP(hipStreamWaitEvent(su, evP[b], 0));
                 launch_syrk(A, lda, k0, 2, mt * (mt - 1) / 2, su);
-            STBA_HIP(hipStreamWaitEvent(st, evN[b], 0));
-            const int k1 = k0 + NB;
-            hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), 0, st, A, lda, k1, n, flag_dev);
-            hipLaunchKernelGGL(chol_trsm_kernel, dim3((mt - 1) * (NB / TRSM_ROWS) + NB / TRSM_ROWS), dim3(256), trsm_lds, st, A, lda, k1,
-                               (mt - 1) * (NB / TRSM_ROWS), linv + (size_t)(b + 1) * NB * NB);
-            STBA_HIP(hipEventRecord(evP[b + 1], st));
+                STBA_HIP(hipEventRecord(evU[b], su));
+                last_bulk = b;
+            }
+            launch_panel_diag(b + 1, sp);
+            launch_panel_trsm(b + 1, sp);
+            STBA_HIP(hipEventRecord(evP[b + 1], sp));
         }
-        if (b > 0) {
-            STBA_HIP(hipEventRecord(evU, su));
-            STBA_HIP(hipStreamWaitEvent(st, evU, 0));
-        }
-        for (; b + 1 < nblk; ++b) {   // serial tail on the caller's stream
+        if (last_bulk >= 0) STBA_HIP(hipStreamWaitEvent(sp, evU[last_bulk], 0));
+        STBA_HIP(hipEventRecord(evEnd, sp));
+        STBA_HIP(hipStreamWaitEvent(st, evEnd, 0));
+        for (; b + 1 < nblk; ++b) {   // serial tail on the caller's stream (whole chip)
             const int k0 = b * NB;
             const int mt = nblk - b - 1;
             launch_syrk(A, lda, k0, 0, mt * (mt + 1) / 2, st);
-            const int k1 = k0 + NB;
-            hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), 0, st, A, lda, k1, n, flag_dev);
-            hipLaunchKernelGGL(chol_trsm_kernel, dim3((mt - 1) * (NB / TRSM_ROWS) + NB / TRSM_ROWS), dim3(256), trsm_lds, st, A, lda, k1,
-                               (mt - 1) * (NB / TRSM_ROWS), linv + (size_t)(b + 1) * NB * NB);
+            launch_panel_diag(b + 1, st);
+            launch_panel_trsm(b + 1, st);
         }
     }
     STBA_TRY(mark((size_t)nblk * 4));
@@ -630,7 +657,7 @@ static int chol_run(double* A, int lda, int n, double* x_dev, int* flag_dev, hip
         const int k0 = b * NB;
         const int has_next = (b < nblk - 1) ? 1 : 0;
         const int grid = 1 + (has_next ? ((k0 + 1023) / 1024) * BWD_ROW_CHUNKS : 0);
-        hipLaunchKernelGGL(chol_bwd_step_kernel, dim3(grid), dim3(1024), 0, st, A, lda, k0, has_next, linv + (size_t)b * NB * NB, x_dev);
+        hipLaunchKernelGGL(chol_bwd_step_kernel, dim3(grid), dim3(1024), 0, st, A, lda, k0, has_next, linv + (size_t)b * LINV_STRIDE, x_dev);
     }
     STBA_TRY(mark((size_t)nblk * 4 + 1));
     STBA_HIP(hipGetLastError());
