@@ -15,7 +15,7 @@ import sys
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libstba.so")
+LIB_PATH = os.environ.get("STBA_LIB") or os.path.join(_HERE, "libstba.so")   # STBA_LIB: kernel experiments only
 TRACE_COLS = 7
 TERM_REASON = {0: "none", 1: "gradient", 2: "function", 3: "parameter", 4: "max_iter",
                5: "min_radius", 6: "solver_fail", 7: "fixed", 8: "user"}

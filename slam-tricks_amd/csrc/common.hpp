@@ -41,7 +41,13 @@ inline int chol_padded_dim(int n) { return ((n + 1 + CHOL_NB - 1) / CHOL_NB) * C
 // A_dev: lda x lda row-major, lda = chol_padded_dim(n).  Rows/cols [n, lda-1) must hold the
 // identity, row lda-1 holds rhs^T in columns [0, n) (and 1 on its diagonal).  On return the
 // lower triangle holds L, row lda-1 holds y = L^-1 rhs, x_dev[0..lda) the solution of A x = rhs.
-// flag_dev: int, set to (row+1) of the first non-positive pivot among real rows.
+// flag_dev: int, set to (row+1) of the first non-positive pivot among real rows, or to
+// CHOL_FLAG_TIMEOUT if the persistent kernel gave up waiting for a dependency (a bug or a lost
+// workgroup; callers turn it into STBA_ERR_HIP through chol_flag_status).
+constexpr int CHOL_FLAG_TIMEOUT = -2147483647;
+inline int chol_flag_status(int flag_h) {
+    return flag_h == CHOL_FLAG_TIMEOUT ? fail(STBA_ERR_HIP, "dense Cholesky: persistent kernel timed out waiting for a dependency") : STBA_OK;
+}
 int chol_factor_solve_dev(double* A_dev, int lda, int n, double* x_dev, int* flag_dev, hipStream_t st);
 struct CholProfile {
     double ms_diag, ms_trsm, ms_syrk, ms_bwd;

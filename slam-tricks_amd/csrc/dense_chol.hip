@@ -25,6 +25,8 @@
 //   backward           one wave per diagonal block (shuffle broadcast, no barriers) + a GEMV
 //                      update of the remaining right-hand side.
 #include <algorithm>
+#include <cstdlib>
+#include <string>
 #include <vector>
 
 #include "common.hpp"
@@ -71,46 +73,103 @@ __device__ __forceinline__ double sqrt_from_rsqrt(double d, double y) {
 }
 
 // ------------------------------------------------------------------------------------------
-// diagonal block: 256 threads = 4 waves, the 128x128 block lives in MFMA accumulator layout
-// (8x8 tiles of 16x16; wave w owns tile rows w and 7-w = 9 lower tiles, balanced), processed in
-// 16 block steps of 8 columns:
+// Global-memory stores.  WT = true: agent-scope relaxed atomic stores, i.e. stores with the sc1 bit,
+// which are written through the XCD-private L2 to memory.  The persistent kernel uses them for
+// FINAL data (finished blocks of L), which workgroups on other XCDs read; everything else in it
+// stays in the L2 of the XCD that owns the tile (see chol_mega_kernel).  No cache-wide
+// buffer_wbl2 / buffer_inv fences anywhere: with one fence pair per task hand-off the factorisation
+// took 14 ms instead of 4.6 ms (every fence flushes and invalidates a whole L2).
+#ifdef STBA_MEGA_PLAIN_FINAL
+constexpr bool MEGA_WT = false;
+#else
+constexpr bool MEGA_WT = true;
+#endif
+#ifdef STBA_MEGA_C_WT
+constexpr bool MEGA_C_WT = true;      // experiment: tiles under update are written through as well
+#else
+constexpr bool MEGA_C_WT = false;
+#endif
+template <bool WT> __device__ __forceinline__ void gst(double* p, double v) {
+    if constexpr (WT && MEGA_WT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+template <bool WT> __device__ __forceinline__ void gst4(double* p, double4v v) {
+    if constexpr (WT && MEGA_WT) { gst<true>(p, v[0]); gst<true>(p + 1, v[1]); gst<true>(p + 2, v[2]); gst<true>(p + 3, v[3]); }
+    else *reinterpret_cast<double4v*>(p) = v;
+}
+__device__ __forceinline__ double4v gld4(const double* p) { return *reinterpret_cast<const double4v*>(p); }
+// loads inside the persistent kernel: F = final data (blocks of L written by other XCDs), C = tiles
+// under update (owned by this XCD).  Experiment switches: -DSTBA_MEGA_F_SC1 / -DSTBA_MEGA_C_SC1 make
+// them agent-scope coherent (sc1) loads.
+#ifdef STBA_MEGA_F_SC1
+constexpr bool MEGA_F_SC1 = true;
+#else
+constexpr bool MEGA_F_SC1 = false;
+#endif
+#ifdef STBA_MEGA_C_SC1
+constexpr bool MEGA_C_SC1 = true;
+#else
+constexpr bool MEGA_C_SC1 = false;
+#endif
+template <bool SC1> __device__ __forceinline__ double mld(const double* p) {
+    if constexpr (SC1) return __hip_atomic_load(const_cast<double*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return *p;
+}
+template <bool SC1> __device__ __forceinline__ double2 mld2(const double* p) {
+    if constexpr (SC1) return make_double2(mld<true>(p), mld<true>(p + 1));
+    else return *reinterpret_cast<const double2*>(p);
+}
+template <bool SC1> __device__ __forceinline__ double4v mld4(const double* p) {
+    if constexpr (SC1) return double4v{mld<true>(p), mld<true>(p + 1), mld<true>(p + 2), mld<true>(p + 3)};
+    else return *reinterpret_cast<const double4v*>(p);
+}
+
+// ------------------------------------------------------------------------------------------
+// Diagonal block: 512 threads = 8 waves, the 128x128 block lives in MFMA accumulator layout
+// (8x8 tiles of 16x16; wave w owns ONE tile row: w for w < 4, 11 - w otherwise, so that the two
+// waves sharing a SIMD own 9 lower tiles together), processed in 16 block steps of 8 columns:
 //   a. lanes holding the 8 panel columns publish them to LDS                     -> barrier
 //   c. 128 row threads factor the 8x8 diagonal mini-block redundantly (right-looking,
 //      division-free v_rsq_f64 + Newton chain) and solve their panel row         -> barrier
 //   e. rank-8 update of the trailing tiles on the matrix cores: two v_mfma_f64_16x16x4_f64 per
-//      tile, operands straight from the scaled panel rows in LDS (2 x 8 B per lane per tile
-//      instead of 32 LDS reads per thread for the same flops on the VALU)
+//      tile, operands straight from the scaled panel rows in LDS
 //   f. the finished panel columns are written back into the accumulators.
+// Finally the inverses of the eight 16x16 diagonal tiles are written to `dinv` (the panel solve
+// multiplies by them on the matrix cores).
+constexpr int DIAG_SMEM_DOUBLES = NB * 9 * 2 + NB + 8 * 16 * 17;   // P, Lp, rd, Tl = 4608
+
 // optional phase timestamps for tools/exp/diag_timing.hip (compiled out of the library)
 #ifdef STBA_DIAG_TS
-__device__ long long g_diag_ts[4][16][6];
+__device__ long long g_diag_ts[8][16][6];
 #define DIAG_TS(slot) do { if ((t & 63) == 0) g_diag_ts[t >> 6][2 * Jt + h][slot] = __builtin_readcyclecounter(); } while (0)
 #else
 #define DIAG_TS(slot) do { } while (0)
 #endif
 
-template <int Jt>
-__device__ __forceinline__ void chol_diag_tilecol(double4v (&acc)[2][8], double (*P)[9], double (*Lp)[9], double* rd, int t, int lr,
-                                                  int lc, const int (&Irow)[2], int k0, int n_real, int* flag) {
+// NT = number of tile columns this wave can own (its tile row index + 1 at most); ROWS = the wave's
+// threads are the row threads of step c.  Waves 0 and 1 (threads 0..127) are the row threads AND own
+// the two shortest tile rows (NT = 2), the other six waves own tile rows 2..7 and skip step c: the
+// register allocation is the maximum over the two code paths instead of their sum (a 512-thread
+// workgroup has 256 registers per lane).
+template <int Jt, int NT, bool ROWS>
+__device__ __forceinline__ void diag_tilecol(double4v (&acc)[NT], double (*P)[9], double (*Lp)[9], double* rd, int t, int lr,
+                                             int lc, int I, int k0, int n_real, int* flag) {
     // tile column Jt is a compile-time constant so that every accumulator index is static (a runtime
     // tile index makes the compiler spill the accumulators to scratch)
+    constexpr int JP = (Jt < NT) ? Jt : NT - 1;     // clamp for the (dead) instantiations Jt >= NT
 #pragma unroll 1
     for (int h = 0; h < 2; ++h) {
         const int j0 = 16 * Jt + 8 * h;
         DIAG_TS(0);
         // a. publish the 8 panel columns (lanes with (lc >> 3) == h)
-        if ((lc >> 3) == h) {
+        if (Jt < NT && (lc >> 3) == h && I >= Jt) {
 #pragma unroll
-            for (int s = 0; s < 2; ++s)
-                if (Irow[s] >= Jt) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) P[16 * Irow[s] + lr + 4 * r][lc & 7] = acc[s][Jt][r];
-                }
+            for (int r = 0; r < 4; ++r) P[16 * I + lr + 4 * r][lc & 7] = acc[JP][r];
         }
         __syncthreads();
         DIAG_TS(1);
         // c. one thread per row at or below the block
-        if (t < NB && t >= j0) {
+        if (ROWS && t >= j0) {
             const int i = t;
             double D[8][8], y[8], p[8], l[8];
 #pragma unroll
@@ -136,7 +195,7 @@ __device__ __forceinline__ void chol_diag_tilecol(double4v (&acc)[2][8], double 
             if (bad && i == j0) atomicCAS(flag, 0, k0 + j0 + 1);
             if (i == j0) {
 #pragma unroll
-                for (int c = 0; c < 8; ++c) rd[j0 + c] = y[c];      // 1 / L[c][c], for the inverse blocks
+                for (int c = 0; c < 8; ++c) rd[j0 + c] = y[c];      // 1 / L[c][c], for the inverse tiles
             }
             // l G^T = p, right-looking.  Rows INSIDE the 8x8 block take the same path: row r of
             // D = G G^T solves to row r of G in its first r+1 entries; the entries right of the
@@ -156,94 +215,87 @@ __device__ __forceinline__ void chol_diag_tilecol(double4v (&acc)[2][8], double 
         DIAG_TS(3);
         // e. rank-8 update of the trailing tiles on the matrix cores (tile columns > Jt, and Jt itself
         //    while its right half is still trailing, i.e. h == 0)
+        if (Jt < NT && (I > Jt || (I == Jt && h == 0))) {
+            const double a0 = -Lp[16 * I + lc][lr], a1 = -Lp[16 * I + lc][4 + lr];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int I = Irow[s];
-            if (I > Jt || (I == Jt && h == 0)) {
-                const double a0 = -Lp[16 * I + lc][lr], a1 = -Lp[16 * I + lc][4 + lr];
-#pragma unroll
-                for (int J = Jt; J < 8; ++J)
-                    if (J <= I && (J > Jt || h == 0)) {
-                        const double b0 = Lp[16 * J + lc][lr], b1 = Lp[16 * J + lc][4 + lr];
-                        acc[s][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[s][J], 0, 0, 0);
-                        acc[s][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[s][J], 0, 0, 0);
-                    }
-            }
+            for (int J = JP; J < NT; ++J)
+                if (J <= I && (J > Jt || h == 0)) {
+                    const double b0 = Lp[16 * J + lc][lr], b1 = Lp[16 * J + lc][4 + lr];
+                    acc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[J], 0, 0, 0);
+                    acc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[J], 0, 0, 0);
+                }
         }
         DIAG_TS(4);
         // f. finished columns of the panel -> accumulators (rows at or below the column)
-        if ((lc >> 3) == h) {
+        if (Jt < NT && (lc >> 3) == h && I >= Jt) {
+            const int col = 16 * Jt + lc;
 #pragma unroll
-            for (int s = 0; s < 2; ++s)
-                if (Irow[s] >= Jt) {
-                    const int col = 16 * Jt + lc;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = 16 * Irow[s] + lr + 4 * r;
-                        const double v = Lp[row][lc & 7];
-                        acc[s][Jt][r] = (row >= col) ? v : acc[s][Jt][r];
-                    }
-                }
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * I + lr + 4 * r;
+                const double v = Lp[row][lc & 7];
+                acc[JP][r] = (row >= col) ? v : acc[JP][r];
+            }
         }
         DIAG_TS(5);
     }
 }
 
-__global__ __launch_bounds__(256) void chol_diag_kernel(double* __restrict__ A, int lda, int k0,
-                                                         int n_real, int* __restrict__ flag,
-                                                         double* __restrict__ dinv) {
-    __shared__ double P[NB][9];
-    __shared__ double Lp[NB][9];
-    __shared__ double rd[NB];
-    __shared__ double Tl[8][16][17];
-    const int t = threadIdx.x, lane = t & 63;
+template <int NT, bool ROWS, bool WT>
+__device__ __forceinline__ void diag_wave_path(double* __restrict__ A, int lda, int k0, int n_real, int* __restrict__ flag,
+                                               double (*P)[9], double (*Lp)[9], double* rd, double (*Tl)[16][17],
+                                               int t, int lr, int lc, int I) {
+    double4v acc[NT];
+#pragma unroll
+    for (int J = 0; J < NT; ++J) {
+        const bool in = (J <= I);
+        const double* src = A + (size_t)(k0 + 16 * I + lr) * lda + k0 + 16 * (in ? J : 0) + lc;
+        double4v tmp;
+        tmp[0] = in ? mld<WT && MEGA_C_SC1>(src) : 0.0;
+        tmp[1] = in ? mld<WT && MEGA_C_SC1>(src + (size_t)4 * lda) : 0.0;
+        tmp[2] = in ? mld<WT && MEGA_C_SC1>(src + (size_t)8 * lda) : 0.0;
+        tmp[3] = in ? mld<WT && MEGA_C_SC1>(src + (size_t)12 * lda) : 0.0;
+        acc[J] = tmp;
+    }
+    diag_tilecol<0, NT, ROWS>(acc, P, Lp, rd, t, lr, lc, I, k0, n_real, flag);
+    diag_tilecol<1, NT, ROWS>(acc, P, Lp, rd, t, lr, lc, I, k0, n_real, flag);
+    diag_tilecol<2, NT, ROWS>(acc, P, Lp, rd, t, lr, lc, I, k0, n_real, flag);
+    diag_tilecol<3, NT, ROWS>(acc, P, Lp, rd, t, lr, lc, I, k0, n_real, flag);
+    diag_tilecol<4, NT, ROWS>(acc, P, Lp, rd, t, lr, lc, I, k0, n_real, flag);
+    diag_tilecol<5, NT, ROWS>(acc, P, Lp, rd, t, lr, lc, I, k0, n_real, flag);
+    diag_tilecol<6, NT, ROWS>(acc, P, Lp, rd, t, lr, lc, I, k0, n_real, flag);
+    diag_tilecol<7, NT, ROWS>(acc, P, Lp, rd, t, lr, lc, I, k0, n_real, flag);
+#pragma unroll
+    for (int J = 0; J < NT; ++J)
+        if (J <= I) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * I + lr + 4 * r, col = 16 * J + lc;
+                if (col <= row) gst<WT>(&A[(size_t)(k0 + row) * lda + k0 + col], acc[J][r]);
+            }
+            if (J == I) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Tl[J][lr + 4 * r][lc] = acc[J][r];
+            }
+        }
+}
+
+// all 512 threads of the workgroup; sm = DIAG_SMEM_DOUBLES doubles of LDS; ends with the results in
+// global memory (no trailing barrier)
+template <bool WT>
+__device__ __forceinline__ void diag_block(double* __restrict__ A, int lda, int k0, int n_real,
+                                           int* __restrict__ flag, double* __restrict__ dinv, double* sm, int t) {
+    double (*P)[9] = reinterpret_cast<double (*)[9]>(sm);
+    double (*Lp)[9] = reinterpret_cast<double (*)[9]>(sm + NB * 9);
+    double* rd = sm + 2 * NB * 9;
+    double (*Tl)[16][17] = reinterpret_cast<double (*)[16][17]>(sm + 2 * NB * 9 + NB);
+    const int lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int lr = lane >> 4, lc = lane & 15;
-    const int Irow[2] = {w, 7 - w};
-    double4v acc[2][8];
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int J = 0; J < 8; ++J) {
-            const bool in = (J <= Irow[s]);
-            const double* src = A + (size_t)(k0 + 16 * Irow[s] + lr) * lda + k0 + 16 * (in ? J : 0) + lc;
-            double4v tmp;
-            tmp[0] = in ? src[0] : 0.0;
-            tmp[1] = in ? src[(size_t)4 * lda] : 0.0;
-            tmp[2] = in ? src[(size_t)8 * lda] : 0.0;
-            tmp[3] = in ? src[(size_t)12 * lda] : 0.0;
-            acc[s][J] = tmp;
-        }
-    chol_diag_tilecol<0>(acc, P, Lp, rd, t, lr, lc, Irow, k0, n_real, flag);
-    chol_diag_tilecol<1>(acc, P, Lp, rd, t, lr, lc, Irow, k0, n_real, flag);
-    chol_diag_tilecol<2>(acc, P, Lp, rd, t, lr, lc, Irow, k0, n_real, flag);
-    chol_diag_tilecol<3>(acc, P, Lp, rd, t, lr, lc, Irow, k0, n_real, flag);
-    chol_diag_tilecol<4>(acc, P, Lp, rd, t, lr, lc, Irow, k0, n_real, flag);
-    chol_diag_tilecol<5>(acc, P, Lp, rd, t, lr, lc, Irow, k0, n_real, flag);
-    chol_diag_tilecol<6>(acc, P, Lp, rd, t, lr, lc, Irow, k0, n_real, flag);
-    chol_diag_tilecol<7>(acc, P, Lp, rd, t, lr, lc, Irow, k0, n_real, flag);
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int J = 0; J < 8; ++J)
-            if (J <= Irow[s]) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = 16 * Irow[s] + lr + 4 * r, col = 16 * J + lc;
-                    if (col <= row) A[(size_t)(k0 + row) * lda + k0 + col] = acc[s][J][r];
-                }
-            }
-    // inverses of the eight 16x16 diagonal tiles (the panel solve multiplies by them on the matrix
-    // cores): thread (b, m) forward-substitutes column m of tile b's inverse
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int J = 0; J < 8; ++J)
-            if (J == Irow[s]) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) Tl[J][lr + 4 * r][lc] = acc[s][J][r];
-            }
+    const int I = (w < 4) ? w : 11 - w;
+    if (w < 2) diag_wave_path<2, true, WT>(A, lda, k0, n_real, flag, P, Lp, rd, Tl, t, lr, lc, I);
+    else diag_wave_path<8, false, WT>(A, lda, k0, n_real, flag, P, Lp, rd, Tl, t, lr, lc, I);
     __syncthreads();
+    // thread (b, m) forward-substitutes column m of tile b's inverse
     if (t < NB) {
         const int b = t >> 4, m = t & 15;
         double x[16];
@@ -253,9 +305,15 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(double* __restrict__ A, 
 #pragma unroll
             for (int q = 0; q < k; ++q) sum = fma(-Tl[b][k][q], x[q], sum);
             x[k] = (k >= m) ? sum * rd[16 * b + k] : 0.0;
-            dinv[(b * 16 + k) * 16 + m] = x[k];
+            gst<WT>(&dinv[(b * 16 + k) * 16 + m], x[k]);
         }
     }
+}
+
+__global__ __launch_bounds__(512) void chol_diag_kernel(double* __restrict__ A, int lda, int k0, int n_real,
+                                                         int* __restrict__ flag, double* __restrict__ dinv) {
+    __shared__ __attribute__((aligned(16))) double sm[DIAG_SMEM_DOUBLES];
+    diag_block<false>(A, lda, k0, n_real, flag, dinv, sm, threadIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -263,42 +321,38 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(double* __restrict__ A, 
 // transposed form  Y = X^T = L11^-1 * A21^T  so that a finished 16x16 tile Y_I, sitting in the
 // accumulator layout, IS the B operand of the next v_mfma_f64_16x16x4_f64 (k-step q <-> register q):
 // no LDS, no shuffles, no barriers.
-//   for I = 0..7:   Y_I  = Inv_II * W_I                      (4 MFMAs; Inv_II from chol_diag_kernel)
+//   for I = 0..7:   Y_I  = Inv_II * W_I                      (4 MFMAs; Inv_II from the diagonal kernel)
 //                   W_J -= L_JI * Y_I   for J > I            (4 MFMAs per tile, independent chains)
 // Row order inside a tile: accumulator register r of lane group g holds LOGICAL row 4g + r (physical
 // MFMA row g + 4r), so a lane's four registers are four consecutive matrix columns of X: one 32 B
 // load/store per lane per tile, and the A operands (L_JI, Inv_II) are one 32 B load per lane too.
-// The last 8 workgroups run the same solve on the rows of the identity: X = I * L11^-T, the
-// inverse transpose of the diagonal block, used by the backward substitution.
-__global__ __launch_bounds__(64) void chol_trsm_kernel(double* __restrict__ A, int lda, int k0, int n_groups,
-                                                       double* __restrict__ Xinv, const double* __restrict__ dinv) {
-    const int lane = threadIdx.x, n = lane & 15, g = lane >> 4;
+// `ident`: the same solve on 16 rows of the identity, X = I * L11^-T = the inverse transpose of the
+// diagonal block (rows >= nv of the block, i.e. the right-hand-side row, count as identity rows);
+// the backward substitution multiplies by it.
+template <bool WT>
+__device__ __forceinline__ void trsm_group(double* __restrict__ rowp, bool ident, int ident_row0, int nv,
+                                           const double* __restrict__ Lb, int lda,
+                                           const double* __restrict__ dinv, int lane) {
+    const int n = lane & 15, g = lane >> 4;
     const int pm = 4 * (n & 3) + (n >> 2);          // logical tile row this lane feeds as an A operand
-    const int grp = blockIdx.x;
-    const bool ident = grp >= n_groups;
-    const int e = grp - n_groups;
-    const int nv = ident ? min(NB, (lda - 1) - k0) : NB;   // rows of the block that belong to the system
-    double* rowp = ident ? Xinv + (size_t)(16 * e + n) * NB
-                         : A + (size_t)(k0 + NB + 16 * grp + n) * lda + k0;
-    const double* Lb = A + (size_t)k0 * lda + k0;
     double4v W[8];
 #pragma unroll
     for (int J = 0; J < 8; ++J) {
         if (ident) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) W[J][r] = (16 * J + 4 * g + r == 16 * e + n) ? 1.0 : 0.0;
+            for (int r = 0; r < 4; ++r) W[J][r] = (16 * J + 4 * g + r == ident_row0 + n) ? 1.0 : 0.0;
         } else {
-            W[J] = *reinterpret_cast<const double4v*>(rowp + 16 * J + 4 * g);
+            W[J] = gld4(rowp + 16 * J + 4 * g);
         }
     }
     auto load_l = [&](int J, int I) -> double4v {
         const int row = 16 * J + pm;
-        double4v v = *reinterpret_cast<const double4v*>(Lb + (size_t)row * lda + 16 * I + 4 * g);
+        double4v v = gld4(Lb + (size_t)row * lda + 16 * I + 4 * g);
         if (row >= nv) v = double4v{0.0, 0.0, 0.0, 0.0};
         return -v;
     };
     auto load_inv = [&](int J) -> double4v {
-        double4v v = *reinterpret_cast<const double4v*>(dinv + (J * 16 + pm) * 16 + 4 * g);
+        double4v v = gld4(dinv + (J * 16 + pm) * 16 + 4 * g);
         if (16 * J + pm >= nv) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] = (4 * g + q == pm) ? 1.0 : 0.0;
@@ -329,7 +383,19 @@ __global__ __launch_bounds__(64) void chol_trsm_kernel(double* __restrict__ A, i
         for (int J = I + 2; J < 8; ++J) Lc[J] = Ln[J];
     }
 #pragma unroll
-    for (int J = 0; J < 8; ++J) *reinterpret_cast<double4v*>(rowp + 16 * J + 4 * g) = W[J];
+    for (int J = 0; J < 8; ++J) gst4<WT>(rowp + 16 * J + 4 * g, W[J]);
+}
+
+// one wave per workgroup: groups [0, n_groups) are the rows below the block, the last 8 the identity
+__global__ __launch_bounds__(64) void chol_trsm_kernel(double* __restrict__ A, int lda, int k0, int n_groups,
+                                                       double* __restrict__ Xinv, const double* __restrict__ dinv) {
+    const int lane = threadIdx.x, grp = blockIdx.x;
+    const bool ident = grp >= n_groups;
+    const int e = grp - n_groups;
+    const int nv = ident ? min(NB, (lda - 1) - k0) : NB;
+    double* rowp = ident ? Xinv + (size_t)(16 * e + (lane & 15)) * NB
+                         : A + (size_t)(k0 + NB + 16 * grp + (lane & 15)) * lda + k0;
+    trsm_group<false>(rowp, ident, 16 * e, nv, A + (size_t)k0 * lda + k0, lda, dinv, lane);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -460,6 +526,478 @@ static void launch_syrk(double* A, int lda, int k0, int tile_mode, int tiles128,
 }
 
 // ------------------------------------------------------------------------------------------
+// The factorisation as ONE persistent kernel: a static task list in dataflow order, executed by one
+// 512-thread workgroup per CU.  Launching the steps as separate kernels costs ~3 us between dependent
+// kernels and ~12 us per cross-stream hand-off (measured), and a diagonal-block workgroup cannot start
+// on a CU that still holds trailing-update workgroups; with 47 dependent steps that was half of the
+// solve time.  Here a workgroup takes the next ticket (atomic counter), waits on the device-side
+// flags of that task's inputs, runs it, publishes its outputs (release fence + flag) and goes on.
+// Tickets are handed out in an order that is a topological order of the task graph, and a workgroup
+// only ever waits for tasks with smaller tickets -- which are finished or held by running
+// workgroups -- so the kernel cannot deadlock whatever the number of resident workgroups.
+//   D(b)          diagonal block b                        needs ver[b][b] == 4b
+//   TU(b, q)      q = 0..3: block row b+1 of the panel solve AND rows 32q.. of the update of the next
+//                 diagonal tile, fused (the critical hand-off D(b) -> D(b+1), see tu_task512)
+//                                                         needs D(b), ver[b+1][b] == ver[b+1][b+1] == 4b
+//   T(b, i)       panel solve of the 128 rows of tile row i > b+1     needs D(b), ver[i][b] == 4b
+//   TI(b)         inverse transpose of block b (for the backward substitution)   needs D(b)
+//   U(b; i, j)    tile (i, j) -= L_ib L_jb^T       needs T(b,i), T(b,j), ver[i][j] == 4b;  ver += 4
+//   Uq(b; i,q,j)  the same for 32 rows of a tile of the NEXT panel's column (j = b+1)       ver += 1
+// XCD ownership.  MI355X has eight XCDs with private, mutually non-coherent L2 caches.  Every tile
+// (i, j) is owned by one XCD (by tile row, see mega_owner), and every task that WRITES the tile runs
+// on a workgroup of that XCD (one ticket queue per XCD; a workgroup reads HW_REG_XCC_ID to find its
+// queue).  A tile under update therefore lives in one L2 only and needs nothing but an L1 invalidate
+// (buffer_inv sc1: agent-scope invalidate, which leaves the L2's local-memory lines alone) per task.  FINAL data -- blocks of L, written once by D / T / TU and never modified
+// again -- is stored write-through (sc1) and may then be cached by every other XCD: no other L2 can
+// hold an older copy, because nobody but the owner ever touched those lines before.  Flags are
+// agent-scope atomics.
+// Order per step b:  TU(b,*)  Uq(b; *, b+1)  D(b+1)  [first DELAY tiles of U(b; cols >= b+2)]
+//                    T(b+1,*) TI(b+1)  [rest of U(b; ...)]:   the panel of step b+1 overlaps the bulk
+//                    of update b.
+enum { TASK_D = 0, TASK_T = 1, TASK_TI = 2, TASK_U = 3, TASK_UQ = 4, TASK_TU = 5 };
+
+struct MegaArgs {
+    double* A; int lda; int n; int nblk;
+    const int4* tasks;      // the per-XCD queues, concatenated
+    int nq;                 // number of queues (= XCDs seen by the probe)
+    int qstart[17];         // queue q holds tasks [qstart[q], qstart[q+1])
+    signed char xcc_queue[16];   // HW_REG_XCC_ID -> queue
+    int* sync;              // [0..16) tickets, [16] abort, then dflag[nblk], tuflag[nblk], tflag[nblk*nblk], ver[nblk*nblk]
+    double* linv; size_t linv_stride;
+    int* flag;
+    int opt;                // experiment switches (STBA_MEGA_OPT)
+    long long* trace;       // optional (STBA_MEGA_TRACE): per task {workgroup, t_ticket, t_ready, t_done}, 100 MHz clock
+};
+constexpr int MEGA_SYNC_HDR = 17;
+constexpr int MEGA_SMEM_BYTES = 128 * 1024;   // X of the TU task: 8 waves x 8 chunks x 2 KB
+
+__device__ __forceinline__ int xcc_id() {
+    unsigned v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    return (int)(v & 15u);
+}
+__global__ void xcc_probe_kernel(int* out) {
+    if (threadIdx.x == 0) out[blockIdx.x] = xcc_id();
+}
+
+// C(TM x 128) -= P_i P_j^T, K = 128 panel columns, 512 threads; smem: 2*(TM+128)*16 doubles
+template <int TM>
+__device__ __forceinline__ void syrk_tile512(double* __restrict__ A, int lda, int k0, int row_i, int row_j,
+                                             double* smem, int t) {
+    constexpr int WR = (TM == 128) ? 2 : 1, WC = 8 / WR;      // wave grid
+    constexpr int MB = TM / (16 * WR);                        // MFMA row blocks per wave: 4 | 2
+    constexpr int NBK = 8 / WC;                               // MFMA col blocks per wave: 2 | 1
+    constexpr int RBA = TM / 16;                              // 16-row blocks of the A tile
+    double* sA = smem;                   // [2][TM * 16]
+    double* sB = smem + 2 * TM * 16;     // [2][2048]
+    const int lane = t & 63, w = t >> 6;
+    const int wr = w / WC, wc = w % WC;
+    double4v acc[MB][NBK];
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int n = 0; n < NBK; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = row_i + wr * (MB * 16) + m * 16 + (lane >> 4) + 4 * r;
+                const int col = row_j + wc * (NBK * 16) + n * 16 + (lane & 15);
+                acc[m][n][r] = mld<MEGA_C_SC1>(&A[(size_t)row * lda + col]);
+            }
+    // staging map: wave w, half h -> row = (lane&15) + 16*w, k = 2*((lane>>4) + 4h)
+    double2 ga[2], gb[2];
+    const int lrow = lane & 15, lkp = lane >> 4;
+    const bool stage_a = (w < RBA);
+    auto gload = [&](int kc) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int row = lrow + 16 * w;
+            const int k = 2 * (lkp + 4 * h);
+            if (stage_a) ga[h] = mld2<MEGA_F_SC1>(&A[(size_t)(row_i + row) * lda + k0 + kc * 16 + k]);
+            gb[h] = mld2<MEGA_F_SC1>(&A[(size_t)(row_j + row) * lda + k0 + kc * 16 + k]);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int k = 2 * (lkp + 4 * h);
+            if (stage_a) {
+                const int posa = (((k >> 2) * RBA + w) << 6) + ((k & 3) << 4) + lrow;
+                sA[buf * TM * 16 + posa] = ga[h].x;
+                sA[buf * TM * 16 + posa + 16] = ga[h].y;      // k+1: (k&3) is even so +1 -> +16
+            }
+            const int posb = (((k >> 2) * 8 + w) << 6) + ((k & 3) << 4) + lrow;
+            sB[buf * 2048 + posb] = gb[h].x;
+            sB[buf * 2048 + posb + 16] = gb[h].y;
+        }
+    };
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    constexpr int KC = NB / 16;
+    for (int kc = 0; kc < KC; ++kc) {
+        const int buf = kc & 1;
+        if (kc + 1 < KC) gload(kc + 1);
+#pragma unroll
+        for (int kq = 0; kq < 4; ++kq) {
+            double a[MB], b[NBK];
+#pragma unroll
+            for (int m = 0; m < MB; ++m) a[m] = -sA[buf * TM * 16 + (((kq * RBA + wr * MB + m) << 6) + lane)];
+#pragma unroll
+            for (int n = 0; n < NBK; ++n) b[n] = sB[buf * 2048 + (((kq * 8 + wc * NBK + n) << 6) + lane)];
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int n = 0; n < NBK; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[n], acc[m][n], 0, 0, 0);
+        }
+        if (kc + 1 < KC) lstore(buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int n = 0; n < NBK; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = row_i + wr * (MB * 16) + m * 16 + (lane >> 4) + 4 * r;
+                const int col = row_j + wc * (NBK * 16) + n * 16 + (lane & 15);
+                gst<MEGA_C_WT>(&A[(size_t)row * lda + col], acc[m][n][r]);
+            }
+}
+
+// Panel solve of 128 rows (8 waves x 16 rows) inside the persistent kernel.  Same algorithm as
+// trsm_group, but the 28 sub-diagonal 16x16 tiles of L11 are staged ONCE per workgroup into LDS, already
+// in A-operand order (56 KB; every lane then reads its 32 B with two ds_read_b128), because coherent
+// (sc1) global loads have ~2 us latency and a per-wave load chain made the task 50 us long.
+// thread 0 only.  Polls with relaxed agent-scope loads; gives up (and raises the abort flag, so that
+// every other workgroup gives up too) after ~2 s instead of hanging the device.
+__device__ __forceinline__ bool mega_wait(const int* p, int target, int* abortf) {
+    if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return true;
+    const long long t0 = wall_clock64();
+    for (;;) {
+        __builtin_amdgcn_s_sleep(1);
+        if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return true;
+        if (__hip_atomic_load(abortf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+        if (wall_clock64() - t0 > 200000000LL) {            // 100 MHz counter
+            __hip_atomic_store(abortf, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+    }
+}
+
+#define PHASE_STAMP(k) do { if (ph && t == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); ph[k] = wall_clock64(); } } while (0)
+// X = W * L11^-T for the 16 rows of this wave (see trsm_group), all 8 waves of the workgroup together:
+// L11's 28 sub-diagonal tiles and the 8 inverse diagonal tiles are staged once into LDS (72 KB) in
+// A-operand order.  W holds X on return.  Starts and ends without a barrier on smem.
+__device__ __forceinline__ void trsm_compute512(double4v (&W)[8], const double* __restrict__ rowp, bool ident,
+                                                int ident_row0, int nv, const double* __restrict__ Lb, int lda,
+                                                const double* __restrict__ dinv, double* smem, int t, long long* ph) {
+    const int lane = t & 63;
+    const int n = lane & 15, g = lane >> 4;
+    // this wave's rows (issued first: they are not needed before the staging is done)
+#pragma unroll
+    for (int J = 0; J < 8; ++J) {
+        if (ident) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) W[J][r] = (16 * J + 4 * g + r == ident_row0 + n) ? 1.0 : 0.0;
+        } else {
+            W[J] = mld4<MEGA_C_SC1>(rowp + 16 * J + 4 * g);
+        }
+    }
+    // stage tile (J, I), J > I, at index 7I - I(I-1)/2 + (J-I-1), then the inverse tiles at 28 + J;
+    // element (r, c) of a tile goes to lane (n = pm(r), g = c >> 2), register c & 3, with
+    // pm(r) = 4 (r & 3) + (r >> 2) (an involution)
+    {
+        double v[18];
+#pragma unroll
+        for (int s2 = 0; s2 < 18; ++s2) {
+            const int e = t + 512 * s2;
+            const int tile = e >> 8, r = (e >> 4) & 15, c = e & 15;
+            if (s2 < 14) {
+                const int I = (tile >= 27) ? 6 : (tile >= 25) ? 5 : (tile >= 22) ? 4 : (tile >= 18) ? 3 : (tile >= 13) ? 2 : (tile >= 7) ? 1 : 0;
+                const int J = tile - (7 * I - I * (I - 1) / 2) + I + 1;
+                const int row = 16 * J + r;
+                v[s2] = -mld<MEGA_F_SC1>(&Lb[(size_t)row * lda + 16 * I + c]);
+                if (row >= nv) v[s2] = 0.0;
+            } else {
+                const int J = tile - 28;
+                v[s2] = mld<MEGA_F_SC1>(&dinv[(J * 16 + r) * 16 + c]);
+                if (16 * J + r >= nv) v[s2] = (c == r) ? 1.0 : 0.0;
+            }
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 18; ++s2) {
+            const int e = t + 512 * s2;
+            const int tile = e >> 8, r = (e >> 4) & 15, c = e & 15;
+            const int nn = 4 * (r & 3) + (r >> 2);
+            smem[tile * 256 + (((c >> 2) << 4) | nn) * 4 + (c & 3)] = v[s2];
+        }
+    }
+    __syncthreads();
+    PHASE_STAMP(0);
+#pragma unroll
+    for (int I = 0; I < 8; ++I) {
+        const double4v iv = *reinterpret_cast<const double4v*>(smem + (28 + I) * 256 + lane * 4);
+        double4v y = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) y = __builtin_amdgcn_mfma_f64_16x16x4f64(iv[q], W[I][q], y, 0, 0, 0);
+        W[I] = y;
+#pragma unroll
+        for (int J = I + 1; J < 8; ++J) {
+            const int tile = 7 * I - I * (I - 1) / 2 + (J - I - 1);
+            const double4v l = *reinterpret_cast<const double4v*>(smem + tile * 256 + lane * 4);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) W[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(l[q], y[q], W[J], 0, 0, 0);
+        }
+    }
+    PHASE_STAMP(1);
+}
+
+// T / TI task: panel solve of 128 rows, result written through to memory (final data)
+__device__ __forceinline__ void trsm_task512(double* __restrict__ rowp, bool ident, int ident_row0, int nv,
+                                             const double* __restrict__ Lb, int lda,
+                                             const double* __restrict__ dinv, double* smem, int t, long long* ph) {
+    double4v W[8];
+    trsm_compute512(W, rowp, ident, ident_row0, nv, Lb, lda, dinv, smem, t, ph);
+    const int g = (t & 63) >> 4;
+#pragma unroll
+    for (int J = 0; J < 8; ++J) gst4<true>(rowp + 16 * J + 4 * g, W[J]);
+    PHASE_STAMP(2);
+}
+
+// TU task (b, q): the critical hand-off D(b) -> D(b+1) in ONE task instead of a panel solve, a flag, and
+// a trailing update.  Each of the four workgroups q = 0..3 solves the WHOLE block row b+1 of the panel
+// (X = A[b+1, b] L_bb^-T, 128 x 128, redundantly), exchanges X between its waves through LDS (a wave's
+// accumulators are already MFMA operand fragments: 128 KB), and applies rows 32q..32q+31 of the update
+// A[b+1, b+1] -= X X^T (lower-triangle tiles only).  Workgroup q also writes rows 32q..32q+31 of X.
+__device__ __forceinline__ bool tu_task512(double* __restrict__ A, int lda, int k0, int rb, int q,
+                                           const double* __restrict__ dinv, double* smem, int t, long long* ph,
+                                           int* loaded, int* abortf, int* s_ok) {
+    const int lane = t & 63, w = t >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    double* rowp = A + (size_t)(rb * NB + 16 * w + n) * lda + k0;
+    double4v W[8];
+    trsm_compute512(W, rowp, false, 0, NB, A + (size_t)k0 * lda + k0, lda, dinv, smem, t, ph);
+    __syncthreads();                          // every wave is done with the L11 tiles in smem and has consumed its rows
+    // the four TU workgroups of this step all READ the whole block row and each WRITES 32 rows of it in
+    // place: count the readers, and store only once all four have their copy (see below)
+    if (t == 0) __hip_atomic_fetch_add(loaded, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int J = 0; J < 8; ++J) *reinterpret_cast<double4v*>(smem + (w * 8 + J) * 256 + lane * 4) = W[J];
+    __syncthreads();
+    // output tiles (m, n'), m in {2q, 2q+1}, n' <= m: 4q + 3 of them, at most two per wave
+    const int ntile = 4 * q + 3;
+    double* Cb = A + (size_t)(rb * NB) * lda + rb * NB;
+#pragma unroll 1
+    for (int e = w; e < ntile; e += 8) {
+        const int m = (e < 2 * q + 1) ? 2 * q : 2 * q + 1;
+        const int np = (e < 2 * q + 1) ? e : e - (2 * q + 1);
+        double4v acc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = mld<MEGA_C_SC1>(&Cb[(size_t)(16 * m + g + 4 * r) * lda + 16 * np + n]);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const double4v fa = *reinterpret_cast<const double4v*>(smem + (m * 8 + c) * 256 + lane * 4);
+            const double4v fb = *reinterpret_cast<const double4v*>(smem + (np * 8 + c) * 256 + lane * 4);
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-fa[qq], fb[qq], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gst<MEGA_C_WT>(&Cb[(size_t)(16 * m + g + 4 * r) * lda + 16 * np + n], acc[r]);
+    }
+    // The three other workgroups hold later tickets of the same queue; they are taken as soon as any
+    // workgroup of this XCD is free (needs >= 4 resident workgroups per XCD, checked on the host).
+    if (t == 0) *s_ok = mega_wait(loaded, 4, abortf) ? 1 : 0;
+    __syncthreads();
+    if (!*s_ok) return false;
+    if ((w >> 1) == q) {
+#pragma unroll
+        for (int J = 0; J < 8; ++J) gst4<true>(rowp + 16 * J + 4 * g, W[J]);
+    }
+    PHASE_STAMP(2);
+    return true;
+}
+
+// C(32 x 128) -= P_i P_j^T for the next panel's tile column: operands straight from global memory
+// into MFMA operand registers (every load of the task is in flight at once: one memory latency
+// instead of eight), wave w -> output columns 16w..16w+15, two 16x16 tiles.
+__device__ __forceinline__ void syrk_q32(double* __restrict__ A, int lda, int k0, int row_i, int row_j, int t, long long* ph) {
+    const int lane = t & 63, w = t >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    const double* pa0 = A + (size_t)(row_i + n) * lda + k0 + 4 * g;
+    const double* pa1 = pa0 + (size_t)16 * lda;
+    const double* pb = A + (size_t)(row_j + 16 * w + n) * lda + k0 + 4 * g;
+    double4v a0[8], a1[8], bb[8], acc[2];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { bb[c] = mld4<MEGA_F_SC1>(pb + 16 * c); a0[c] = mld4<MEGA_F_SC1>(pa0 + 16 * c); a1[c] = mld4<MEGA_F_SC1>(pa1 + 16 * c); }
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[m][r] = mld<MEGA_C_SC1>(&A[(size_t)(row_i + 16 * m + g + 4 * r) * lda + row_j + 16 * w + n]);
+    PHASE_STAMP(0);
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a0[c][q], bb[c][q], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a1[c][q], bb[c][q], acc[1], 0, 0, 0);
+        }
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gst<MEGA_C_WT>(&A[(size_t)(row_i + 16 * m + g + 4 * r) * lda + row_j + 16 * w + n], acc[m][r]);
+    PHASE_STAMP(1);
+}
+
+__global__ __launch_bounds__(512) void chol_mega_kernel(MegaArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];   // MEGA_SMEM_BYTES: SYRK staging | diagonal block | L11 tiles | X
+    __shared__ int s_task, s_ok;
+    const int t = threadIdx.x;
+    const int nblk = a.nblk;
+    int* abortf = a.sync + 16;
+    int* dflag = a.sync + MEGA_SYNC_HDR;
+    int* tuflag = dflag + nblk;
+    int* tflag = tuflag + nblk;
+    int* ver = tflag + nblk * nblk;
+    const int q = a.xcc_queue[xcc_id()];
+    if (q < 0) return;                        // an XCD the probe did not see: no queue, nothing to do
+    int* ticket = a.sync + q;
+    const int qbeg = a.qstart[q], qend = a.qstart[q + 1];
+    int mine = 0;
+    if (t == 0) mine = qbeg + atomicAdd(ticket, 1);
+    for (;;) {
+        if (t == 0) s_task = mine;
+        __syncthreads();
+        const int task = s_task;
+        if (task >= qend) break;
+        const int4 d = a.tasks[task];
+        const int type = d.x, b = d.y, ti = d.z, tj = d.w;
+        const int k0 = b * NB;
+        if (t == 0) {
+            if (a.trace) { a.trace[8 * (size_t)task] = blockIdx.x; a.trace[8 * (size_t)task + 1] = wall_clock64(); }
+            // next ticket; its latency hides behind this task.  Not for TU: a TU task waits for its three
+            // siblings, which hold LATER tickets -- this workgroup must not sit on one of them.
+            if (type != TASK_TU) mine = qbeg + atomicAdd(ticket, 1);
+            bool ok = true;
+            if (type == TASK_D) {
+                ok = mega_wait(&ver[b * nblk + b], 4 * b, abortf);
+            } else if (type == TASK_T) {
+                ok = mega_wait(&dflag[b], 1, abortf) && mega_wait(&ver[ti * nblk + b], 4 * b, abortf);
+            } else if (type == TASK_TI) {
+                ok = mega_wait(&dflag[b], 1, abortf);
+            } else if (type == TASK_TU) {
+                ok = mega_wait(&dflag[b], 1, abortf) && mega_wait(&ver[(b + 1) * nblk + b], 4 * b, abortf) &&
+                     mega_wait(&ver[(b + 1) * nblk + b + 1], 4 * b, abortf);
+            } else {
+                const int i = (type == TASK_UQ) ? (ti >> 2) : ti;
+                ok = mega_wait(&tflag[b * nblk + i], 4, abortf) && mega_wait(&tflag[b * nblk + tj], 4, abortf) &&
+                     mega_wait(&ver[i * nblk + tj], 4 * b, abortf);
+            }
+            // this CU's L1 may hold lines of tiles that other CUs have rewritten since
+            // (buffer_inv sc0 does NOT do it outside threadgroup-split mode: measured, stale L1 hits)
+            asm volatile("buffer_inv sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
+            if (a.trace) a.trace[8 * (size_t)task + 2] = wall_clock64();
+            s_ok = ok ? 1 : 0;
+        }
+        __syncthreads();
+        if (!s_ok) {                            // dependency time-out: make the host see a hard error
+            if (t == 0) atomicExch(a.flag, CHOL_FLAG_TIMEOUT);
+            break;
+        }
+        // a fresh copy of the thread index per task: keeps the compiler from hoisting every task's
+        // lane-dependent address arithmetic out of the ticket loop (that cost 100+ spilled registers)
+        int tt = t;
+        asm volatile("" : "+v"(tt));
+        double* li = a.linv + (size_t)b * a.linv_stride;
+        long long* ph = a.trace ? a.trace + 8 * (size_t)task + 4 : nullptr;
+        if (type == TASK_D) {
+            diag_block<true>(a.A, a.lda, k0, a.n, a.flag, li + NB * NB, smem, tt);
+        } else if (type == TASK_T) {
+            const int lane = tt & 63, w = tt >> 6;
+            double* rowp = a.A + (size_t)(ti * NB + 16 * w + (lane & 15)) * a.lda + k0;
+            trsm_task512(rowp, false, 0, NB, a.A + (size_t)k0 * a.lda + k0, a.lda, li + NB * NB, smem, tt, ph);
+        } else if (type == TASK_TI) {
+            const int lane = tt & 63, w = tt >> 6;
+            const int nv = min(NB, (a.lda - 1) - k0);
+            double* rowp = li + (size_t)(16 * w + (lane & 15)) * NB;
+            trsm_task512(rowp, true, 16 * w, nv, a.A + (size_t)k0 * a.lda + k0, a.lda, li + NB * NB, smem, tt, ph);
+        } else if (type == TASK_U) {
+            syrk_tile512<128>(a.A, a.lda, k0, ti * NB, tj * NB, smem, tt);
+        } else if (type == TASK_TU) {
+            if (!tu_task512(a.A, a.lda, k0, b + 1, ti, li + NB * NB, smem, tt, ph, &tuflag[b], abortf, &s_ok)) {
+                if (t == 0) atomicExch(a.flag, CHOL_FLAG_TIMEOUT);
+                break;
+            }
+        } else {
+            syrk_q32(a.A, a.lda, k0, (ti >> 2) * NB + (ti & 3) * 32, tj * NB, tt, ph);
+        }
+        // release: every wave waits until its stores are acknowledged (by the L2; by memory for the
+        // write-through ones), then the flag is raised with an agent-scope atomic
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t == 0) {
+#ifdef STBA_MEGA_WBL2
+            if (type != TASK_U && type != TASK_UQ) asm volatile("buffer_wbl2 sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
+#endif
+            if (type == TASK_D) __hip_atomic_fetch_add(&dflag[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else if (type == TASK_T) __hip_atomic_fetch_add(&tflag[b * nblk + ti], 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else if (type == TASK_TU) {
+                __hip_atomic_fetch_add(&tflag[b * nblk + b + 1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(&ver[(b + 1) * nblk + b + 1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            else if (type == TASK_U) __hip_atomic_fetch_add(&ver[ti * nblk + tj], 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else if (type == TASK_UQ) __hip_atomic_fetch_add(&ver[(ti >> 2) * nblk + tj], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (a.trace) a.trace[8 * (size_t)task + 3] = wall_clock64();
+            if (type == TASK_TU) mine = qbeg + atomicAdd(ticket, 1);
+        }
+    }
+}
+
+// host side: the task list for nblk block columns (static per size), in one global dataflow order,
+// then split stably into one queue per XCD by the owner of the tile each task writes
+static int mega_owner(const int4& tk, int nq) {
+    // a tile belongs to the XCD of its tile ROW, rows dealt out boustrophedon so that the triangle is
+    // balanced: every task writes tiles of one row only (TU writes (b+1, b) and (b+1, b+1))
+    int row;
+    switch (tk.x) {
+        case TASK_D: case TASK_TI: row = tk.y; break;
+        case TASK_TU: row = tk.y + 1; break;
+        case TASK_T: case TASK_U: row = tk.z; break;
+        default: row = tk.z >> 2; break;
+    }
+    const int m = row % (2 * nq);
+    return m < nq ? m : 2 * nq - 1 - m;
+}
+static void mega_build_tasks(int nblk, int delay, int nq, std::vector<int4>& out, int* qstart) {
+    std::vector<int4> g;
+    auto emit = [&](int type, int b, int i, int j) { g.push_back(make_int4(type, b, i, j)); };
+    emit(TASK_D, 0, 0, 0);
+    for (int i = 2; i < nblk; ++i) emit(TASK_T, 0, i, 0);
+    emit(TASK_TI, 0, 0, 0);
+    for (int b = 0; b + 1 < nblk; ++b) {
+        for (int q = 0; q < 4; ++q) emit(TASK_TU, b, q, 0);
+        for (int i = b + 2; i < nblk; ++i)
+            for (int q = 0; q < 4; ++q) emit(TASK_UQ, b, i * 4 + q, b + 1);
+        emit(TASK_D, b + 1, 0, 0);
+        std::vector<int4> rest;
+        for (int j = b + 2; j < nblk; ++j)
+            for (int i = j; i < nblk; ++i) rest.push_back(make_int4(TASK_U, b, i, j));
+        const size_t first = std::min(rest.size(), (size_t)std::max(0, delay));
+        g.insert(g.end(), rest.begin(), rest.begin() + (long)first);
+        for (int i = b + 3; i < nblk; ++i) emit(TASK_T, b + 1, i, 0);
+        emit(TASK_TI, b + 1, 0, 0);
+        g.insert(g.end(), rest.begin() + (long)first, rest.end());
+    }
+    out.clear();
+    for (int q = 0; q < nq; ++q) {
+        qstart[q] = (int)out.size();
+        for (const int4& tk : g)
+            if (mega_owner(tk, nq) == q) out.push_back(tk);
+    }
+    qstart[nq] = (int)out.size();
+}
+
+// ------------------------------------------------------------------------------------------
 // backward substitution, one launch per 128-unknown block b (from the last block up):
 //   workgroup 0      applies the previous block's solution x_{b+1} to ITS OWN 128 right-hand-side
 //                    entries, then x_b = (L_bb^-T) y_b as a 128x128 GEMV with the inverse transpose
@@ -525,6 +1063,8 @@ __global__ __launch_bounds__(1024) void chol_bwd_step_kernel(double* __restrict_
 
 // ------------------------------------------------------------------------------------------
 static int chol_run(double* A, int lda, int n, double* x_dev, int* flag_dev, hipStream_t st, CholProfile* prof) {
+    static const bool USE_STREAMS = [] { const char* e = getenv("STBA_CHOL_SCHEDULE"); return e && std::string(e) == "streams"; }();
+    static const bool MEGA_CHECK = [] { const char* e = getenv("STBA_MEGA_CHECK"); return e && atoi(e) != 0; }();
     if (lda % NB != 0 || lda < n + 1) return fail(STBA_ERR_INVALID_ARGUMENT, "chol: bad padded dimension");
     const int nblk = lda / NB;
     // per diagonal block: its inverse transpose (written by the panel solve, read by the backward pass)
@@ -542,7 +1082,7 @@ static int chol_run(double* A, int lda, int n, double* x_dev, int* flag_dev, hip
     // panel of block b: diagonal kernel + panel solve of the (nblk - b - 1) * 8 row groups below it
     auto launch_panel_diag = [&](int b, hipStream_t s_) {
         double* li = linv + (size_t)b * LINV_STRIDE;
-        hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), 0, s_, A, lda, b * NB, n, flag_dev, li + NB * NB);
+        hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(512), 0, s_, A, lda, b * NB, n, flag_dev, li + NB * NB);
     };
     auto launch_panel_trsm = [&](int b, hipStream_t s_) {
         double* li = linv + (size_t)b * LINV_STRIDE;
@@ -575,6 +1115,92 @@ static int chol_run(double* A, int lda, int n, double* x_dev, int* flag_dev, hip
                 prof->syrk_flops_padded += (double)(mt * (mt + 1) / 2) * 2.0 * NB * NB * NB;
                 prof->syrk_launches += 1;
             }
+        }
+    } else if (!USE_STREAMS) {
+        // one persistent kernel (see chol_mega_kernel)
+        struct MegaPlan {
+            int nblk = 0, ntasks = 0, nq = 0, ncu = 0;
+            int qstart[17] = {0};
+            signed char xcc_queue[16];
+            int4* tasks = nullptr; int* sync = nullptr; size_t sync_ints = 0;
+        };
+        static thread_local MegaPlan plan;
+        static const int DELAY = [] { const char* e = getenv("STBA_MEGA_DELAY"); return e ? atoi(e) : 384; }();
+        if (plan.nblk != nblk) {
+            if (plan.tasks) (void)hipFree(plan.tasks);
+            if (plan.sync) (void)hipFree(plan.sync);
+            plan = MegaPlan();
+            int dev = 0;
+            hipDeviceProp_t prop;
+            STBA_HIP(hipGetDevice(&dev));
+            STBA_HIP(hipGetDeviceProperties(&prop, dev));
+            plan.ncu = prop.multiProcessorCount;
+            // which XCDs do the workgroups of a ncu-wide launch land on?
+            {
+                int* probe = nullptr;
+                std::vector<int> h((size_t)plan.ncu);
+                STBA_HIP(hipMalloc(reinterpret_cast<void**>(&probe), h.size() * sizeof(int)));
+                hipLaunchKernelGGL(xcc_probe_kernel, dim3(plan.ncu), dim3(512), 0, st, probe);
+                STBA_HIP(hipMemcpyAsync(h.data(), probe, h.size() * sizeof(int), hipMemcpyDeviceToHost, st));
+                STBA_HIP(hipStreamSynchronize(st));
+                (void)hipFree(probe);
+                for (int i = 0; i < 16; ++i) plan.xcc_queue[i] = -1;
+                int per_xcc[16] = {0};
+                for (int x : h) {
+                    if (plan.xcc_queue[x & 15] < 0) plan.xcc_queue[x & 15] = (signed char)plan.nq++;
+                    per_xcc[x & 15]++;
+                }
+                for (int i = 0; i < 16; ++i)
+                    if (plan.xcc_queue[i] >= 0 && per_xcc[i] < 4)
+                        return fail(STBA_ERR_HIP, "chol: fewer than 4 workgroups per XCD (the TU tasks need 4)");
+            }
+            std::vector<int4> tasks;
+            mega_build_tasks(nblk, DELAY, plan.nq, tasks, plan.qstart);
+            STBA_HIP(hipMalloc(reinterpret_cast<void**>(&plan.tasks), tasks.size() * sizeof(int4)));
+            STBA_HIP(hipMemcpy(plan.tasks, tasks.data(), tasks.size() * sizeof(int4), hipMemcpyHostToDevice));
+            plan.sync_ints = MEGA_SYNC_HDR + 2 * (size_t)nblk + 2 * (size_t)nblk * nblk;
+            STBA_HIP(hipMalloc(reinterpret_cast<void**>(&plan.sync), plan.sync_ints * sizeof(int)));
+            plan.ntasks = (int)tasks.size();
+            plan.nblk = nblk;
+        }
+        STBA_HIP(hipMemsetAsync(plan.sync, 0, plan.sync_ints * sizeof(int), st));
+        MegaArgs ma;
+        ma.A = A; ma.lda = lda; ma.n = n; ma.nblk = nblk;
+        ma.tasks = plan.tasks; ma.nq = plan.nq; ma.sync = plan.sync;
+        memcpy(ma.qstart, plan.qstart, sizeof ma.qstart);
+        memcpy(ma.xcc_queue, plan.xcc_queue, sizeof ma.xcc_queue);
+        ma.linv = linv; ma.linv_stride = LINV_STRIDE; ma.flag = flag_dev;
+        static const int OPT = [] { const char* e = getenv("STBA_MEGA_OPT"); return e ? atoi(e) : 0; }();
+        ma.opt = OPT;
+        static const char* TRACE = getenv("STBA_MEGA_TRACE");
+        ma.trace = nullptr;
+        if (TRACE) STBA_HIP(hipMalloc(reinterpret_cast<void**>(&ma.trace), (size_t)plan.ntasks * 8 * sizeof(long long)));
+        static bool attr_set = false;
+        if (!attr_set) {
+            STBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(chol_mega_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, MEGA_SMEM_BYTES));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(chol_mega_kernel, dim3(plan.ncu), dim3(512), MEGA_SMEM_BYTES, st, ma);
+        if (TRACE) {    // debugging aid: dump the task timeline of this factorisation (tools/mega_trace.py)
+            std::vector<long long> h((size_t)plan.ntasks * 8);
+            std::vector<int4> ht((size_t)plan.ntasks);
+            STBA_HIP(hipStreamSynchronize(st));
+            STBA_HIP(hipMemcpy(h.data(), ma.trace, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
+            STBA_HIP(hipMemcpy(ht.data(), plan.tasks, ht.size() * sizeof(int4), hipMemcpyDeviceToHost));
+            (void)hipFree(ma.trace);
+            if (FILE* f = fopen(TRACE, "wb")) {
+                fwrite(&plan.ntasks, sizeof(int), 1, f);
+                fwrite(ht.data(), sizeof(int4), ht.size(), f);
+                fwrite(h.data(), sizeof(long long), h.size(), f);
+                fclose(f);
+            }
+        }
+        if (MEGA_CHECK) {
+            int h = 0;
+            STBA_HIP(hipMemcpyAsync(&h, plan.sync + 16, sizeof h, hipMemcpyDeviceToHost, st));
+            STBA_HIP(hipStreamSynchronize(st));
+            if (h != 0) return fail(STBA_ERR_HIP, "chol: persistent kernel timed out waiting for a dependency");
         }
     } else {
         // look-ahead schedule on a partitioned chip.  The panel chain (diagonal block, panel solve,

@@ -328,6 +328,7 @@ static int ba_run_lm(stba_ba* b, const stba_lm_options* opt_in, int fixed_iterat
         double ts[TS_COUNT];
         STBA_TRY(download(ts, b->trial, TS_COUNT, b->st));
         STBA_TRY(download(&flag_h, b->flag, 1, b->st));
+        STBA_TRY(chol_flag_status(flag_h));
         STBA_HIP(hipStreamSynchronize(b->st));
         if (lin_timing_pending) { (void)hipEventElapsedTime(&ms, ev[0], ev[1]); s.ms_linearize += ms; lin_timing_pending = false; }
         (void)hipEventElapsedTime(&ms, ev[2], ev[3]); s.ms_schur += ms;
@@ -752,6 +753,7 @@ int stba_ba_solve_reduced(stba_ba* b, double* dxc) {
     STBA_TRY(chol_factor_solve_dev(b->S(), b->lda, b->n, b->dxc, b->flag, b->st));
     int flag_h = 0;
     STBA_TRY(download(&flag_h, b->flag, 1, b->st));
+    STBA_TRY(chol_flag_status(flag_h));
     if (dxc) STBA_TRY(download(dxc, b->dxc, (size_t)b->n, b->st));
     STBA_HIP(hipStreamSynchronize(b->st));
     b->have_reduced = false;   // S now holds the factor
@@ -865,6 +867,7 @@ int stba_cholesky_factor(double* A, int n, void* hip_stream) {
     STBA_TRY(chol_factor_solve_dev(w.A, w.lda, n, w.x, w.flag, w.st));
     int flag_h = 0;
     STBA_TRY(download(&flag_h, w.flag, 1, w.st));
+    STBA_TRY(chol_flag_status(flag_h));
     STBA_HIP(hipMemcpy2DAsync(A, (size_t)n * sizeof(double), w.A, (size_t)w.lda * sizeof(double),
                               (size_t)n * sizeof(double), (size_t)n, hipMemcpyDeviceToHost, w.st));
     STBA_HIP(hipStreamSynchronize(w.st));
@@ -881,6 +884,7 @@ int stba_cholesky_solve(const double* A, int n, double* bvec, void* hip_stream) 
     STBA_TRY(chol_factor_solve_dev(w.A, w.lda, n, w.x, w.flag, w.st));
     int flag_h = 0;
     STBA_TRY(download(&flag_h, w.flag, 1, w.st));
+    STBA_TRY(chol_flag_status(flag_h));
     STBA_TRY(download(bvec, w.x, (size_t)n, w.st));
     STBA_HIP(hipStreamSynchronize(w.st));
     if (flag_h) return fail(STBA_ERR_NOT_POSITIVE_DEFINITE, "pivot " + std::to_string(flag_h));
@@ -1070,6 +1074,7 @@ int stba_calib_gauss_newton(int n_views, int n_corners, double* params, const do
         STBA_TRY(chol_factor_solve_dev(c.w.A, c.w.lda, n, c.w.x, c.w.flag, c.w.st));   // H.ldlt().solve(g), :393
         int flag_h = 0;
         STBA_TRY(download(&flag_h, c.w.flag, 1, c.w.st)); STBA_TRY(download(g.data(), c.w.x, (size_t)n, c.w.st));
+        STBA_TRY(chol_flag_status(flag_h));
         STBA_HIP(hipStreamSynchronize(c.w.st));
         if (flag_h) return fail(STBA_ERR_NOT_POSITIVE_DEFINITE, "calibration normal equations: pivot " + std::to_string(flag_h));
         double un = 0.0;
@@ -1162,6 +1167,7 @@ int stba_dense_solve(stba_residual_fn fn, stba_plus_fn plus, void* user, int n_p
         STBA_TRY(chol_factor_solve_dev(w.A, w.lda, n, w.x, w.flag, w.st));
         int flag_h = 0;
         STBA_TRY(download(&flag_h, w.flag, 1, w.st)); STBA_TRY(download(dx.data(), w.x, (size_t)n, w.st));
+        STBA_TRY(chol_flag_status(flag_h));
         STBA_HIP(hipStreamSynchronize(w.st));
         bool ok = (flag_h == 0);
         double model_change = 0.0, new_cost = 0.0, step_norm = 0.0, rho = 0.0, cost_change = 0.0;

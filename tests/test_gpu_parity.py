@@ -323,3 +323,20 @@ def test_calibration_real_fixture(st, O, known):
     assert np.allclose(p[:4], ka["final_intr_dist"][:4], rtol=0, atol=6e-4)
     assert np.allclose(p[4:7], ka["final_intr_dist"][4:7], rtol=2e-6)
     assert abs(it - ka["gn_iterations"]) <= 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1000, 1500, 3000])
+def test_cholesky_persistent_kernel_is_deterministic(st, n):
+    """The persistent (dataflow) factorisation fixes the order of every floating-point operation, so
+    repeated factorisations must agree bit for bit; a difference is a synchronisation or cache-coherence
+    race between workgroups (this test found three).  The matrix is a low-rank product plus a small
+    ridge: every trailing update matters, a stale tile gives a negative pivot."""
+    rng = np.random.default_rng(5)
+    B = rng.standard_normal((n, n // 2))
+    A = B @ B.T + n * 0.01 * np.eye(n)
+    Lref = np.linalg.cholesky(A)
+    L0 = st.cholesky_factor(A)
+    assert np.abs(L0 - Lref).max() <= 1e-12 * np.abs(Lref).max()
+    for _ in range(7):
+        assert np.array_equal(st.cholesky_factor(A), L0)

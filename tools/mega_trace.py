@@ -1,0 +1,49 @@
+"""task timeline of the persistent Cholesky kernel.
+usage: STBA_MEGA_TRACE=/tmp/mega.bin python tools/mega_trace.py run [n];  python tools/mega_trace.py /tmp/mega.bin"""
+import importlib, os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if sys.argv[1] == "run":
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else 6000
+    st = importlib.import_module("slam-tricks_amd")
+    print("chol ms", st.cholesky_time(n, reps=2))
+    sys.exit(0)
+raw = open(sys.argv[1], "rb").read()
+nt = int(np.frombuffer(raw[:4], np.int32)[0])
+tasks = np.frombuffer(raw[4:4 + 16 * nt], np.int32).reshape(nt, 4)
+tr = np.frombuffer(raw[4 + 16 * nt:], np.int64).reshape(nt, 8)
+t0 = tr[:, 1].min()
+us = lambda x: (x - t0) / 100.0
+names = ["D", "T", "TI", "U", "Uq", "TU"]
+print("tasks", nt, "span us", us(tr[:, 3].max()))
+for ty in range(6):
+    m = tasks[:, 0] == ty
+    if m.any():
+        wait = (tr[m, 2] - tr[m, 1]) / 100.0
+        run = (tr[m, 3] - tr[m, 2]) / 100.0
+        print(f"{names[ty]:3s} n={m.sum():6d} wait mean {wait.mean():7.2f} us (sum {wait.sum()/1e3:8.2f} ms)  run mean {run.mean():7.2f} med {np.median(run):7.2f} max {run.max():7.2f} (sum {run.sum()/1e3:8.2f} ms)")
+for ty, nph in ((1, 3), (2, 3), (4, 2), (5, 3)):
+    m = tasks[:, 0] == ty
+    if m.any():
+        prev = tr[m, 2]
+        out = []
+        for k in range(nph):
+            out.append(((tr[m, 4 + k] - prev) / 100.0).mean()); prev = tr[m, 4 + k]
+        out.append(((tr[m, 3] - prev) / 100.0).mean())
+        print(f"{names[ty]:3s} phases (us):", np.round(out, 2))
+nwg = int(tr[:, 0].max()) + 1
+busy = (tr[:, 3] - tr[:, 2]).sum() / 100.0
+print("workgroups", nwg, "busy fraction", busy / (nwg * us(tr[:, 3].max())))
+# critical chain: D(b) start/end
+dm = np.where(tasks[:, 0] == 0)[0]
+print("  b   D.ready   D.done   (ready - prev done)")
+prev = None
+for k in dm[:: max(1, len(dm) // 24)]:
+    b = tasks[k, 1]
+    print(f"{b:3d} {us(tr[k,2]):9.1f} {us(tr[k,3]):9.1f}")
+# per step: time between D(b) done and D(b+1) ready
+d_done = {int(tasks[k, 1]): us(tr[k, 3]) for k in dm}
+d_ready = {int(tasks[k, 1]): us(tr[k, 2]) for k in dm}
+gaps = [d_ready[b + 1] - d_done[b] for b in range(len(dm) - 1)]
+runs = [d_done[b] - d_ready[b] for b in range(len(dm))]
+print("D run mean", np.mean(runs), " gap D(b).done -> D(b+1).ready: mean", np.mean(gaps), "first10", np.round(gaps[:10], 1), "last10", np.round(gaps[-10:], 1))
