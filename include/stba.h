@@ -177,7 +177,12 @@ int stba_cholesky_solve(const double* A, int n, double* b, void* hip_stream);
 /* device-resident timing of factor+solve on an n x n synthetic SPD system, ms per solve */
 int stba_cholesky_time(int n, int reps, double* ms_avg, void* hip_stream);
 
-/* hipEvent time (ms) of one factor+solve per kernel class: ms4 = {diagonal blocks, panel solves,
+/* the same, split by a hipEvent between the factorisation (one persistent kernel, chol_mega_kernel) and
+ * the backward substitution: bench.py's MFMA roofline leg divides the n^3/3 flops by ms_factor. */
+int stba_cholesky_time_split(int n, int reps, double* ms_factor, double* ms_backward, void* hip_stream);
+
+/* hipEvent time (ms) of one factor+solve per kernel class, with the stage-per-kernel schedule (a
+ * diagnostic: the production path runs the stages as tasks of one persistent kernel): ms4 = {diagonal blocks, panel solves,
  * MFMA trailing updates, backward substitution}; algorithmic / executed flops of the trailing
  * updates and their launch count (bench.py MFMA roofline leg). */
 int stba_cholesky_profile(int n, double* ms4, double* syrk_flops, double* syrk_flops_padded,

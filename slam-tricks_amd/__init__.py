@@ -66,7 +66,7 @@ EXPORTS = ["stba_status_string", "stba_last_error", "stba_version", "stba_device
            "stba_ba_cost", "stba_ba_normal_blocks", "stba_ba_reduced_system", "stba_ba_solve_reduced",
            "stba_ba_back_substitute", "stba_ba_apply_step", "stba_ba_solve", "stba_ba_lm_iterations",
            "stba_ba_triangulate", "stba_ba_time_linearize", "stba_cholesky_factor", "stba_cholesky_solve",
-           "stba_cholesky_time", "stba_cholesky_profile", "stba_calib_evaluate", "stba_calib_gauss_newton",
+           "stba_cholesky_time", "stba_cholesky_time_split", "stba_cholesky_profile", "stba_calib_evaluate", "stba_calib_gauss_newton",
            "stba_pcg_default_options", "stba_pg_create", "stba_pg_destroy", "stba_pg_get_poses", "stba_pg_evaluate",
            "stba_pg_solve", "stba_dense_solve"]
 
@@ -307,6 +307,14 @@ def cholesky_time(n, reps=5, stream=None):
     ms = C.c_double()
     _chk(lib().stba_cholesky_time(int(n), int(reps), C.byref(ms), C.c_void_p(stream or 0)), "stba_cholesky_time")
     return ms.value
+
+
+def cholesky_time_split(n, reps=5, stream=None):
+    """(ms_factor, ms_backward) of the production schedule, hipEvent-timed on the device"""
+    a = C.c_double(); b = C.c_double()
+    _chk(lib().stba_cholesky_time_split(int(n), int(reps), C.byref(a), C.byref(b), C.c_void_p(stream or 0)),
+         "stba_cholesky_time_split")
+    return a.value, b.value
 
 
 def cholesky_profile(n, stream=None):

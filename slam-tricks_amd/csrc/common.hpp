@@ -49,6 +49,8 @@ inline int chol_flag_status(int flag_h) {
     return flag_h == CHOL_FLAG_TIMEOUT ? fail(STBA_ERR_HIP, "dense Cholesky: persistent kernel timed out waiting for a dependency") : STBA_OK;
 }
 int chol_factor_solve_dev(double* A_dev, int lda, int n, double* x_dev, int* flag_dev, hipStream_t st);
+// the production schedule with an event recorded between the factorisation and the backward substitution
+int chol_factor_solve_split(double* A_dev, int lda, int n, double* x_dev, int* flag_dev, hipStream_t st, hipEvent_t mid_event);
 struct CholProfile {
     double ms_diag, ms_trsm, ms_syrk, ms_bwd;
     double syrk_flops;          // algorithmic: sum over steps of m(m+1)*128, m = remaining real rows

@@ -12,20 +12,24 @@
 // forward-substituted for free (it ends up holding y = L^-1 rhs).  Only the backward
 // substitution L^T x = y needs its own kernels.
 //
-// Per 128-column step:
-//   chol_diag_kernel   1 workgroup x 1024 threads; the 128x128 diagonal block lives in registers
-//                      (4x4 per thread, 32-cyclic distribution); one LDS column broadcast and one
-//                      barrier per column; sub-blocks left of / above the active column are
-//                      skipped with wave-uniform (compile-time) bounds.
-//   chol_trsm_kernel   one workgroup per 32 rows of the panel (so that a 6000-row panel spreads
-//                      over ~190 CUs); L11 staged in LDS (129-padded), panel rows in registers.
-//   chol_syrk_kernel   128x128 output tiles of the trailing lower triangle, 4 waves x (4x4)
-//                      16x16 MFMA tiles, K = 128 streamed through double-buffered LDS in
-//                      fragment order (conflict-free ds_read_b64 / ds_write_b64).
-//   backward           one wave per diagonal block (shuffle broadcast, no barriers) + a GEMV
-//                      update of the remaining right-hand side.
+// Production schedule: ONE persistent kernel per factorisation (chol_mega_kernel): the four stages of
+// a blocked right-looking Cholesky are tasks of a static dataflow graph, pulled from per-XCD ticket
+// queues by one 512-thread workgroup per CU and synchronised with device-side flags:
+//   D   diag_block     the 128x128 diagonal block in MFMA accumulator layout, 8-column block steps:
+//                      row threads run the sqrt/scale chain, the other waves the rank-8 MFMA updates
+//   T   trsm_task512   panel solve of 128 rows on the matrix cores (transposed form: an accumulator
+//                      tile is the next B operand), L11 staged in LDS in operand order
+//   TU  tu_task512     the critical hand-off: panel solve of block row b+1 fused with the update of
+//                      the next diagonal tile
+//   U   syrk_tile512   128x128 trailing tile -= P_i P_j^T, K = 128 through double-buffered LDS in
+//                      fragment order (conflict-free ds_read_b64 / ds_write_b64); Uq: 32-row pieces
+// Diagnostic schedule (stba_cholesky_profile): the same stages as one kernel each
+// (chol_diag_kernel / chol_trsm_kernel / chol_syrk_kernel), timed per class with hipEvents.
+// Backward substitution: one small kernel per block (GEMV with the inverse transposes the panel
+// solve produced).
 #include <algorithm>
 #include <cstdlib>
+#include <queue>
 #include <string>
 #include <vector>
 
@@ -126,22 +130,21 @@ template <bool SC1> __device__ __forceinline__ double4v mld4(const double* p) {
 
 // ------------------------------------------------------------------------------------------
 // Diagonal block: 512 threads = 8 waves, the 128x128 block lives in MFMA accumulator layout
-// (8x8 tiles of 16x16; wave w owns ONE tile row: w for w < 4, 11 - w otherwise, so that the two
-// waves sharing a SIMD own 9 lower tiles together), processed in 16 block steps of 8 columns:
-//   a. lanes holding the 8 panel columns publish them to LDS                     -> barrier
+// (8x8 tiles of 16x16, one tile row per wave), processed in 16 block steps of 8 columns:
+//   a. lanes holding the 8 panel columns publish them to LDS
 //   c. 128 row threads factor the 8x8 diagonal mini-block redundantly (right-looking,
-//      division-free v_rsq_f64 + Newton chain) and solve their panel row         -> barrier
+//      division-free v_rsq_f64 + Newton chain) and solve their panel row
 //   e. rank-8 update of the trailing tiles on the matrix cores: two v_mfma_f64_16x16x4_f64 per
 //      tile, operands straight from the scaled panel rows in LDS
 //   f. the finished panel columns are written back into the accumulators.
-// Finally the inverses of the eight 16x16 diagonal tiles are written to `dinv` (the panel solve
-// multiplies by them on the matrix cores).
-constexpr int DIAG_SMEM_DOUBLES = NB * 9 * 2 + NB + 8 * 16 * 17;   // P, Lp, rd, Tl = 4608
+// The steps are software-pipelined (see diag_step).  Finally the inverses of the eight 16x16
+// diagonal tiles are written to `dinv` (the panel solve multiplies by them on the matrix cores).
+constexpr int DIAG_SMEM_DOUBLES = NB * 9 * 3 + NB + 8 * 16 * 17;   // P, Lp0, Lp1, rd, Tl = 5760
 
 // optional phase timestamps for tools/exp/diag_timing.hip (compiled out of the library)
 #ifdef STBA_DIAG_TS
 __device__ long long g_diag_ts[8][16][6];
-#define DIAG_TS(slot) do { if ((t & 63) == 0) g_diag_ts[t >> 6][2 * Jt + h][slot] = __builtin_readcyclecounter(); } while (0)
+#define DIAG_TS(slot) do { if ((t & 63) == 0) g_diag_ts[t >> 6][2 * Jt + H][slot] = __builtin_readcyclecounter(); } while (0)
 #else
 #define DIAG_TS(slot) do { } while (0)
 #endif
@@ -151,99 +154,115 @@ __device__ long long g_diag_ts[8][16][6];
 // the two shortest tile rows (NT = 2), the other six waves own tile rows 2..7 and skip step c: the
 // register allocation is the maximum over the two code paths instead of their sum (a 512-thread
 // workgroup has 256 registers per lane).
-template <int Jt, int NT, bool ROWS>
-__device__ __forceinline__ void diag_tilecol(double4v (&acc)[NT], double (*P)[9], double (*Lp)[9], double* rd, int t, int lr,
-                                             int lc, int I, int k0, int n_real, int* flag) {
-    // tile column Jt is a compile-time constant so that every accumulator index is static (a runtime
-    // tile index makes the compiler spill the accumulators to scratch)
-    constexpr int JP = (Jt < NT) ? Jt : NT - 1;     // clamp for the (dead) instantiations Jt >= NT
-#pragma unroll 1
-    for (int h = 0; h < 2; ++h) {
-        const int j0 = 16 * Jt + 8 * h;
-        DIAG_TS(0);
-        // a. publish the 8 panel columns (lanes with (lc >> 3) == h)
-        if (Jt < NT && (lc >> 3) == h && I >= Jt) {
+//
+// One block step (tile column Jt, half h; 8 panel columns), software-pipelined so that the row threads'
+// scalar chain (c) overlaps the other waves' matrix-core update of the PREVIOUS step:
+//     c(s)  on waves 0,1      ||   e2(s-1) on waves 2..7   (trailing tiles right of the next panel)
+//     ---- barrier ----
+//     e1(s): rank-8 update of the tile column holding the NEXT panel;  f(s): finished panel columns ->
+//     accumulators;  a(s+1): publish the next panel's columns to LDS
+//     ---- barrier ----
+// e2(s-1) always covers tile columns > Jt; e1(s) covers tile column Jt (h = 0: the right half of the
+// same tile column comes next) or Jt + 1 (h = 1).  Lp is double-buffered (e2 reads the previous one).
+template <int Jt, int H, int NT, bool ROWS>
+__device__ __forceinline__ void diag_step(double4v (&acc)[NT], double (*P)[9], double (*LpCur)[9], double (*LpPrev)[9],
+                                          double* rd, int t, int lr, int lc, int I, int k0, int n_real, int* flag) {
+    constexpr int h = H;
+    constexpr int j0 = 16 * Jt + 8 * H;
+    constexpr bool FIRST = (Jt == 0 && H == 0);
+    DIAG_TS(0);
+    // e2(s-1): tile columns J > Jt of this wave's tile row, with the previous step's panel
+    if (!FIRST && Jt + 1 < NT && I > Jt) {
+        const double a0 = -LpPrev[16 * I + lc][lr], a1 = -LpPrev[16 * I + lc][4 + lr];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) P[16 * I + lr + 4 * r][lc & 7] = acc[JP][r];
-        }
-        __syncthreads();
-        DIAG_TS(1);
-        // c. one thread per row at or below the block
-        if (ROWS && t >= j0) {
-            const int i = t;
-            double D[8][8], y[8], p[8], l[8];
-#pragma unroll
-            for (int r = 0; r < 8; ++r)
-#pragma unroll
-                for (int c = 0; c <= r; ++c) D[r][c] = P[j0 + r][c];
-#pragma unroll
-            for (int c = 0; c < 8; ++c) p[c] = P[i][c];
-            bool bad = false;
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                double d = D[c][c];
-                if (!(d > 0.0)) { bad = bad || ((k0 + j0 + c) < n_real); d = 1.0; }
-                y[c] = fast_rsqrt(d);
-                D[c][c] = sqrt_from_rsqrt(d, y[c]);
-#pragma unroll
-                for (int r = c + 1; r < 8; ++r) D[r][c] *= y[c];
-#pragma unroll
-                for (int r = c + 1; r < 8; ++r)
-#pragma unroll
-                    for (int q = c + 1; q <= r; ++q) D[r][q] = fma(-D[r][c], D[q][c], D[r][q]);
+        for (int J = Jt + 1; J < NT; ++J)
+            if (J <= I) {
+                const double b0 = LpPrev[16 * J + lc][lr], b1 = LpPrev[16 * J + lc][4 + lr];
+                acc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[J], 0, 0, 0);
+                acc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[J], 0, 0, 0);
             }
-            if (bad && i == j0) atomicCAS(flag, 0, k0 + j0 + 1);
-            if (i == j0) {
-#pragma unroll
-                for (int c = 0; c < 8; ++c) rd[j0 + c] = y[c];      // 1 / L[c][c], for the inverse tiles
-            }
-            // l G^T = p, right-looking.  Rows INSIDE the 8x8 block take the same path: row r of
-            // D = G G^T solves to row r of G in its first r+1 entries; the entries right of the
-            // diagonal come out as garbage, but they only ever meet (i) panel-column elements that
-            // step f overwrites and (ii) strictly-upper elements nobody reads.
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                l[c] = p[c] * y[c];
-#pragma unroll
-                for (int q = c + 1; q < 8; ++q) p[q] = fma(-l[c], D[q][c], p[q]);
-            }
-#pragma unroll
-            for (int c = 0; c < 8; ++c) Lp[i][c] = l[c];
-        }
-        DIAG_TS(2);
-        __syncthreads();
-        DIAG_TS(3);
-        // e. rank-8 update of the trailing tiles on the matrix cores (tile columns > Jt, and Jt itself
-        //    while its right half is still trailing, i.e. h == 0)
-        if (Jt < NT && (I > Jt || (I == Jt && h == 0))) {
-            const double a0 = -Lp[16 * I + lc][lr], a1 = -Lp[16 * I + lc][4 + lr];
-#pragma unroll
-            for (int J = JP; J < NT; ++J)
-                if (J <= I && (J > Jt || h == 0)) {
-                    const double b0 = Lp[16 * J + lc][lr], b1 = Lp[16 * J + lc][4 + lr];
-                    acc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[J], 0, 0, 0);
-                    acc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[J], 0, 0, 0);
-                }
-        }
-        DIAG_TS(4);
-        // f. finished columns of the panel -> accumulators (rows at or below the column)
-        if (Jt < NT && (lc >> 3) == h && I >= Jt) {
-            const int col = 16 * Jt + lc;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = 16 * I + lr + 4 * r;
-                const double v = Lp[row][lc & 7];
-                acc[JP][r] = (row >= col) ? v : acc[JP][r];
-            }
-        }
-        DIAG_TS(5);
     }
+    DIAG_TS(1);
+    // c. one thread per row at or below the block
+    if (ROWS && t >= j0) {
+        const int i = t;
+        double D[8][8], y[8], p[8], l[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+            for (int c = 0; c <= r; ++c) D[r][c] = P[j0 + r][c];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) p[c] = P[i][c];
+        bool bad = false;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            double d = D[c][c];
+            if (!(d > 0.0)) { bad = bad || ((k0 + j0 + c) < n_real); d = 1.0; }
+            y[c] = fast_rsqrt(d);
+            D[c][c] = sqrt_from_rsqrt(d, y[c]);
+#pragma unroll
+            for (int r = c + 1; r < 8; ++r) D[r][c] *= y[c];
+#pragma unroll
+            for (int r = c + 1; r < 8; ++r)
+#pragma unroll
+                for (int q = c + 1; q <= r; ++q) D[r][q] = fma(-D[r][c], D[q][c], D[r][q]);
+        }
+        if (bad && i == j0) atomicCAS(flag, 0, k0 + j0 + 1);
+        if (i == j0) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) rd[j0 + c] = y[c];      // 1 / L[c][c], for the inverse tiles
+        }
+        // l G^T = p, right-looking.  Rows INSIDE the 8x8 block take the same path: row r of
+        // D = G G^T solves to row r of G in its first r+1 entries; the entries right of the
+        // diagonal come out as garbage, but they only ever meet (i) panel-column elements that
+        // step f overwrites and (ii) strictly-upper elements nobody reads.
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            l[c] = p[c] * y[c];
+#pragma unroll
+            for (int q = c + 1; q < 8; ++q) p[q] = fma(-l[c], D[q][c], p[q]);
+        }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) LpCur[i][c] = l[c];
+    }
+    DIAG_TS(2);
+    __syncthreads();
+    DIAG_TS(3);
+    // e1(s): the tile column that holds the next panel
+    constexpr int E1 = Jt + H;
+    if (E1 < NT && I >= E1) {
+        const double a0 = -LpCur[16 * I + lc][lr], a1 = -LpCur[16 * I + lc][4 + lr];
+        const double b0 = LpCur[16 * E1 + lc][lr], b1 = LpCur[16 * E1 + lc][4 + lr];
+        constexpr int EP = (E1 < NT) ? E1 : NT - 1;
+        acc[EP] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[EP], 0, 0, 0);
+        acc[EP] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[EP], 0, 0, 0);
+    }
+    // f. finished columns of the panel -> accumulators (rows at or below the column)
+    constexpr int JP = (Jt < NT) ? Jt : NT - 1;     // clamp for the (dead) instantiations Jt >= NT
+    if (Jt < NT && (lc >> 3) == h && I >= Jt) {
+        const int col = 16 * Jt + lc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * I + lr + 4 * r;
+            const double v = LpCur[row][lc & 7];
+            acc[JP][r] = (row >= col) ? v : acc[JP][r];
+        }
+    }
+    DIAG_TS(4);
+    // a(s+1): publish the next panel's 8 columns (lanes of the other half of tile column E1)
+    if (E1 < NT && E1 < 8 && (lc >> 3) == (1 - h) && I >= E1) {
+        constexpr int EP = (E1 < NT) ? E1 : NT - 1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) P[16 * I + lr + 4 * r][lc & 7] = acc[EP][r];
+    }
+    __syncthreads();
+    DIAG_TS(5);
 }
 
 template <int NT, bool ROWS, bool WT>
 __device__ __forceinline__ void diag_wave_path(double* __restrict__ A, int lda, int k0, int n_real, int* __restrict__ flag,
-                                               double (*P)[9], double (*Lp)[9], double* rd, double (*Tl)[16][17],
-                                               int t, int lr, int lc, int I) {
+                                               double (*P)[9], double (*Lp0)[9], double (*Lp1)[9], double* rd,
+                                               double (*Tl)[16][17], int t, int lr, int lc, int I) {
     double4v acc[NT];
 #pragma unroll
     for (int J = 0; J < NT; ++J) {
@@ -256,14 +275,17 @@ __device__ __forceinline__ void diag_wave_path(double* __restrict__ A, int lda, 
         tmp[3] = in ? mld<WT && MEGA_C_SC1>(src + (size_t)12 * lda) : 0.0;
         acc[J] = tmp;
     }
-    diag_tilecol<0, NT, ROWS>(acc, P, Lp, rd, t, lr, lc, I, k0, n_real, flag);
-    diag_tilecol<1, NT, ROWS>(acc, P, Lp, rd, t, lr, lc, I, k0, n_real, flag);
-    diag_tilecol<2, NT, ROWS>(acc, P, Lp, rd, t, lr, lc, I, k0, n_real, flag);
-    diag_tilecol<3, NT, ROWS>(acc, P, Lp, rd, t, lr, lc, I, k0, n_real, flag);
-    diag_tilecol<4, NT, ROWS>(acc, P, Lp, rd, t, lr, lc, I, k0, n_real, flag);
-    diag_tilecol<5, NT, ROWS>(acc, P, Lp, rd, t, lr, lc, I, k0, n_real, flag);
-    diag_tilecol<6, NT, ROWS>(acc, P, Lp, rd, t, lr, lc, I, k0, n_real, flag);
-    diag_tilecol<7, NT, ROWS>(acc, P, Lp, rd, t, lr, lc, I, k0, n_real, flag);
+    // a(0): publish the first panel (left half of tile column 0)
+    if ((lc >> 3) == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) P[16 * I + lr + 4 * r][lc & 7] = acc[0][r];
+    }
+    __syncthreads();
+#define DIAG_PAIR(JT)                                                                          \
+    diag_step<JT, 0, NT, ROWS>(acc, P, Lp0, Lp1, rd, t, lr, lc, I, k0, n_real, flag);          \
+    diag_step<JT, 1, NT, ROWS>(acc, P, Lp1, Lp0, rd, t, lr, lc, I, k0, n_real, flag);
+    DIAG_PAIR(0) DIAG_PAIR(1) DIAG_PAIR(2) DIAG_PAIR(3) DIAG_PAIR(4) DIAG_PAIR(5) DIAG_PAIR(6) DIAG_PAIR(7)
+#undef DIAG_PAIR
 #pragma unroll
     for (int J = 0; J < NT; ++J)
         if (J <= I) {
@@ -285,15 +307,20 @@ template <bool WT>
 __device__ __forceinline__ void diag_block(double* __restrict__ A, int lda, int k0, int n_real,
                                            int* __restrict__ flag, double* __restrict__ dinv, double* sm, int t) {
     double (*P)[9] = reinterpret_cast<double (*)[9]>(sm);
-    double (*Lp)[9] = reinterpret_cast<double (*)[9]>(sm + NB * 9);
-    double* rd = sm + 2 * NB * 9;
-    double (*Tl)[16][17] = reinterpret_cast<double (*)[16][17]>(sm + 2 * NB * 9 + NB);
+    double (*Lp0)[9] = reinterpret_cast<double (*)[9]>(sm + NB * 9);
+    double (*Lp1)[9] = reinterpret_cast<double (*)[9]>(sm + 2 * NB * 9);
+    double* rd = sm + 3 * NB * 9;
+    double (*Tl)[16][17] = reinterpret_cast<double (*)[16][17]>(sm + 3 * NB * 9 + NB);
     const int lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int lr = lane >> 4, lc = lane & 15;
-    const int I = (w < 4) ? w : 11 - w;
-    if (w < 2) diag_wave_path<2, true, WT>(A, lda, k0, n_real, flag, P, Lp, rd, Tl, t, lr, lc, I);
-    else diag_wave_path<8, false, WT>(A, lda, k0, n_real, flag, P, Lp, rd, Tl, t, lr, lc, I);
+    // tile row of wave w.  Waves w and w + 4 share a SIMD, and FP64 VALU work (step c, waves 0 and 1)
+    // does not overlap FP64 MFMA work on the same SIMD (measured: c slowed from 2200 to 2900 cycles), so
+    // the partners of the row-thread waves get the two shortest remaining tile rows (2, 3) and SIMDs 2, 3
+    // carry rows {4, 7} and {5, 6}
+    const int I = (w < 2) ? w : (w < 4) ? w + 2 : (w < 6) ? w - 2 : 13 - w;
+    if (w < 2) diag_wave_path<2, true, WT>(A, lda, k0, n_real, flag, P, Lp0, Lp1, rd, Tl, t, lr, lc, I);
+    else diag_wave_path<8, false, WT>(A, lda, k0, n_real, flag, P, Lp0, Lp1, rd, Tl, t, lr, lc, I);
     __syncthreads();
     // thread (b, m) forward-substitutes column m of tile b's inverse
     if (t < NB) {
@@ -551,9 +578,7 @@ static void launch_syrk(double* A, int lda, int k0, int tile_mode, int tiles128,
 // again -- is stored write-through (sc1) and may then be cached by every other XCD: no other L2 can
 // hold an older copy, because nobody but the owner ever touched those lines before.  Flags are
 // agent-scope atomics.
-// Order per step b:  TU(b,*)  Uq(b; *, b+1)  D(b+1)  [first DELAY tiles of U(b; cols >= b+2)]
-//                    T(b+1,*) TI(b+1)  [rest of U(b; ...)]:   the panel of step b+1 overlaps the bulk
-//                    of update b.
+// The ticket order comes from a list-scheduling simulation on the host (mega_build_tasks).
 enum { TASK_D = 0, TASK_T = 1, TASK_TI = 2, TASK_U = 3, TASK_UQ = 4, TASK_TU = 5 };
 
 struct MegaArgs {
@@ -968,33 +993,119 @@ static int mega_owner(const int4& tk, int nq) {
     const int m = row % (2 * nq);
     return m < nq ? m : 2 * nq - 1 - m;
 }
-static void mega_build_tasks(int nblk, int delay, int nq, std::vector<int4>& out, int* qstart) {
-    std::vector<int4> g;
-    auto emit = [&](int type, int b, int i, int j) { g.push_back(make_int4(type, b, i, j)); };
-    emit(TASK_D, 0, 0, 0);
-    for (int i = 2; i < nblk; ++i) emit(TASK_T, 0, i, 0);
-    emit(TASK_TI, 0, 0, 0);
-    for (int b = 0; b + 1 < nblk; ++b) {
-        for (int q = 0; q < 4; ++q) emit(TASK_TU, b, q, 0);
-        for (int i = b + 2; i < nblk; ++i)
-            for (int q = 0; q < 4; ++q) emit(TASK_UQ, b, i * 4 + q, b + 1);
-        emit(TASK_D, b + 1, 0, 0);
-        std::vector<int4> rest;
-        for (int j = b + 2; j < nblk; ++j)
-            for (int i = j; i < nblk; ++i) rest.push_back(make_int4(TASK_U, b, i, j));
-        const size_t first = std::min(rest.size(), (size_t)std::max(0, delay));
-        g.insert(g.end(), rest.begin(), rest.begin() + (long)first);
-        for (int i = b + 3; i < nblk; ++i) emit(TASK_T, b + 1, i, 0);
-        emit(TASK_TI, b + 1, 0, 0);
-        g.insert(g.end(), rest.begin() + (long)first, rest.end());
+// The ticket order is produced by LIST SCHEDULING a model of the machine on the host: `wg_per_q`
+// workers per XCD queue, measured task durations, and priorities that put the critical chain
+// D -> TU -> D first, then the panel (T, Uq), then the trailing updates column by column.  Sorting the
+// tasks by their simulated start time gives (i) one global topological order, which the deadlock
+// argument needs, and (ii) per-queue orders in which a workgroup rarely takes a ticket whose inputs
+// are far from ready (an in-order ticket queue has no other notion of priority).
+static void mega_build_tasks(int nblk, int nq, int wg_per_q, std::vector<int4>& out, int* qstart) {
+    struct Node { int4 tk; std::vector<int> succ; int indeg = 0; double dur = 0, prio = 0; int q = 0; double start = 0; };
+    std::vector<Node> nodes;
+    const int NBK = nblk;
+    std::vector<int> idD((size_t)NBK, -1), idTI((size_t)NBK, -1), idTU((size_t)NBK * 4, -1), idT((size_t)NBK * NBK, -1),
+        idUq((size_t)NBK * NBK * 4, -1), idU((size_t)NBK * NBK * NBK, -1);
+    // measured on MI355X (tools/mega_trace.py), microseconds, plus ~2 us of flag latency per hop
+    const double DUR[6] = {35.0, 23.0, 19.0, 25.0, 16.5, 23.5};
+    auto add = [&](int type, int b, int i, int j, double prio) {
+        Node nd; nd.tk = make_int4(type, b, i, j); nd.dur = DUR[type]; nd.prio = prio; nd.q = mega_owner(nd.tk, nq);
+        nodes.push_back(nd);
+        return (int)nodes.size() - 1;
+    };
+    // priorities: smaller = sooner.  The key is the block column a task works towards (10 per column)
+    // plus a class offset, so that everything the NEXT panels need goes before trailing updates of far
+    // columns, whatever step they belong to (an in-step order would bury the update of tile (b+1, b+1)
+    // by panel b-1 behind the whole backlog of panel b-2).
+    for (int b = 0; b < NBK; ++b) {
+        idD[(size_t)b] = add(TASK_D, b, 0, 0, 10.0 * b);
+        idTI[(size_t)b] = add(TASK_TI, b, 0, 0, 10.0 * NBK + b);
+        if (b + 1 < NBK)
+            for (int q = 0; q < 4; ++q) idTU[(size_t)b * 4 + q] = add(TASK_TU, b, q, 0, 10.0 * b + 5);
+        for (int i = b + 2; i < NBK; ++i) {
+            idT[(size_t)b * NBK + i] = add(TASK_T, b, i, 0, 10.0 * b + 6 + 1e-3 * i);
+            for (int q = 0; q < 4; ++q)
+                idUq[((size_t)b * NBK + i) * 4 + q] = add(TASK_UQ, b, i * 4 + q, b + 1, 10.0 * (b + 1) + 2 + 1e-3 * i);
+        }
+        for (int j = b + 2; j < NBK; ++j)
+            for (int i = j; i < NBK; ++i)
+                idU[((size_t)b * NBK + i) * NBK + j] = add(TASK_U, b, i, j, 10.0 * j + 3 + 1e-3 * i + 1e-6 * b);
+    }
+    auto dep = [&](int from, int to) {     // `to` needs `from`
+        if (from < 0 || to < 0) return;
+        nodes[(size_t)from].succ.push_back(to);
+        nodes[(size_t)to].indeg++;
+    };
+    for (int b = 0; b < NBK; ++b) {
+        const int d = idD[(size_t)b];
+        if (b > 0)
+            for (int q = 0; q < 4; ++q) dep(idTU[(size_t)(b - 1) * 4 + q], d);
+        dep(d, idTI[(size_t)b]);
+        if (b + 1 < NBK)
+            for (int q = 0; q < 4; ++q) {
+                const int tu = idTU[(size_t)b * 4 + q];
+                dep(d, tu);
+                if (b > 0) {
+                    for (int q2 = 0; q2 < 4; ++q2) dep(idUq[((size_t)(b - 1) * NBK + (b + 1)) * 4 + q2], tu);
+                    dep(idU[((size_t)(b - 1) * NBK + (b + 1)) * NBK + (b + 1)], tu);
+                }
+            }
+        for (int i = b + 2; i < NBK; ++i) {
+            const int t = idT[(size_t)b * NBK + i];
+            dep(d, t);
+            if (b > 0)
+                for (int q2 = 0; q2 < 4; ++q2) dep(idUq[((size_t)(b - 1) * NBK + i) * 4 + q2], t);
+            for (int q = 0; q < 4; ++q) {
+                const int uq = idUq[((size_t)b * NBK + i) * 4 + q];
+                dep(t, uq);
+                for (int q2 = 0; q2 < 4; ++q2) dep(idTU[(size_t)b * 4 + q2], uq);
+                if (b > 0) dep(idU[((size_t)(b - 1) * NBK + i) * NBK + (b + 1)], uq);
+            }
+        }
+        for (int j = b + 2; j < NBK; ++j)
+            for (int i = j; i < NBK; ++i) {
+                const int u = idU[((size_t)b * NBK + i) * NBK + j];
+                dep(idT[(size_t)b * NBK + i], u);
+                if (j != i) dep(idT[(size_t)b * NBK + j], u);
+                if (b > 0) dep(idU[((size_t)(b - 1) * NBK + i) * NBK + j], u);
+            }
+    }
+    // event-driven list scheduling
+    typedef std::pair<double, int> PI;
+    std::vector<std::priority_queue<PI, std::vector<PI>, std::greater<PI>>> ready((size_t)nq);
+    std::priority_queue<PI, std::vector<PI>, std::greater<PI>> events;
+    std::vector<int> idle((size_t)nq, wg_per_q);
+    for (int k = 0; k < (int)nodes.size(); ++k)
+        if (nodes[(size_t)k].indeg == 0) ready[(size_t)nodes[(size_t)k].q].push(PI(nodes[(size_t)k].prio, k));
+    double now = 0.0;
+    size_t started = 0;
+    std::vector<std::vector<int>> order((size_t)nq);
+    for (;;) {
+        for (int q = 0; q < nq; ++q)
+            while (idle[(size_t)q] > 0 && !ready[(size_t)q].empty()) {
+                const int k = ready[(size_t)q].top().second;
+                ready[(size_t)q].pop();
+                idle[(size_t)q]--;
+                nodes[(size_t)k].start = now;
+                events.push(PI(now + nodes[(size_t)k].dur, k));
+                order[(size_t)q].push_back(k);
+                ++started;
+            }
+        if (events.empty()) break;
+        const PI ev = events.top();
+        events.pop();
+        now = ev.first;
+        const Node& nd = nodes[(size_t)ev.second];
+        idle[(size_t)nd.q]++;
+        for (int sidx : nd.succ)
+            if (--nodes[(size_t)sidx].indeg == 0) ready[(size_t)nodes[(size_t)sidx].q].push(PI(nodes[(size_t)sidx].prio, sidx));
     }
     out.clear();
     for (int q = 0; q < nq; ++q) {
         qstart[q] = (int)out.size();
-        for (const int4& tk : g)
-            if (mega_owner(tk, nq) == q) out.push_back(tk);
+        for (int k : order[(size_t)q]) out.push_back(nodes[(size_t)k].tk);
     }
     qstart[nq] = (int)out.size();
+    (void)started;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1062,8 +1173,8 @@ __global__ __launch_bounds__(1024) void chol_bwd_step_kernel(double* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------
-static int chol_run(double* A, int lda, int n, double* x_dev, int* flag_dev, hipStream_t st, CholProfile* prof) {
-    static const bool USE_STREAMS = [] { const char* e = getenv("STBA_CHOL_SCHEDULE"); return e && std::string(e) == "streams"; }();
+static int chol_run(double* A, int lda, int n, double* x_dev, int* flag_dev, hipStream_t st, CholProfile* prof,
+                    hipEvent_t mid_event = nullptr) {
     static const bool MEGA_CHECK = [] { const char* e = getenv("STBA_MEGA_CHECK"); return e && atoi(e) != 0; }();
     if (lda % NB != 0 || lda < n + 1) return fail(STBA_ERR_INVALID_ARGUMENT, "chol: bad padded dimension");
     const int nblk = lda / NB;
@@ -1116,8 +1227,8 @@ static int chol_run(double* A, int lda, int n, double* x_dev, int* flag_dev, hip
                 prof->syrk_launches += 1;
             }
         }
-    } else if (!USE_STREAMS) {
-        // one persistent kernel (see chol_mega_kernel)
+    } else {
+        // production: one persistent kernel (see chol_mega_kernel)
         struct MegaPlan {
             int nblk = 0, ntasks = 0, nq = 0, ncu = 0;
             int qstart[17] = {0};
@@ -1125,7 +1236,6 @@ static int chol_run(double* A, int lda, int n, double* x_dev, int* flag_dev, hip
             int4* tasks = nullptr; int* sync = nullptr; size_t sync_ints = 0;
         };
         static thread_local MegaPlan plan;
-        static const int DELAY = [] { const char* e = getenv("STBA_MEGA_DELAY"); return e ? atoi(e) : 384; }();
         if (plan.nblk != nblk) {
             if (plan.tasks) (void)hipFree(plan.tasks);
             if (plan.sync) (void)hipFree(plan.sync);
@@ -1155,7 +1265,7 @@ static int chol_run(double* A, int lda, int n, double* x_dev, int* flag_dev, hip
                         return fail(STBA_ERR_HIP, "chol: fewer than 4 workgroups per XCD (the TU tasks need 4)");
             }
             std::vector<int4> tasks;
-            mega_build_tasks(nblk, DELAY, plan.nq, tasks, plan.qstart);
+            mega_build_tasks(nblk, plan.nq, std::max(4, plan.ncu / plan.nq), tasks, plan.qstart);
             STBA_HIP(hipMalloc(reinterpret_cast<void**>(&plan.tasks), tasks.size() * sizeof(int4)));
             STBA_HIP(hipMemcpy(plan.tasks, tasks.data(), tasks.size() * sizeof(int4), hipMemcpyHostToDevice));
             plan.sync_ints = MEGA_SYNC_HDR + 2 * (size_t)nblk + 2 * (size_t)nblk * nblk;
@@ -1202,83 +1312,9 @@ static int chol_run(double* A, int lda, int n, double* x_dev, int* flag_dev, hip
             STBA_HIP(hipStreamSynchronize(st));
             if (h != 0) return fail(STBA_ERR_HIP, "chol: persistent kernel timed out waiting for a dependency");
         }
-    } else {
-        // look-ahead schedule on a partitioned chip.  The panel chain (diagonal block, panel solve,
-        // update of the next panel's tile column) is latency-bound and needs few CUs; the bulk of the
-        // trailing update is throughput-bound.  Two streams with DISJOINT CU masks
-        // (hipExtStreamCreateWithCUMask) keep them from competing for the same CUs: without the
-        // partition a 324-VGPR diagonal-block workgroup cannot start until a CU has drained ALL its
-        // trailing-update workgroups, which serialises the two.  Dependencies:
-        //   sp:  D(0) T(0) | U1(0) D(1) T(1) | [wait bulk(0)] U1(1) D(2) T(2) | ...
-        //   su:             [wait T(0)] U2(0)  [wait T(1)] U2(1) ...
-        // U1(b) = update of tile column b+1 by panel b; U2(b) = the columns right of it.  The only
-        // cross-stream wait on the panel chain is for U2(b-1), which had a whole panel time to finish.
-        static thread_local hipStream_t sp = nullptr, su = nullptr;
-        static thread_local std::vector<hipEvent_t> evP, evU;
-        static thread_local hipEvent_t evStart = nullptr, evEnd = nullptr;
-        static const int PANEL_CUS = [] { const char* e = getenv("STBA_PANEL_CUS"); return e ? atoi(e) : 32; }();
-        static const int SERIAL_MT = [] { const char* e = getenv("STBA_SERIAL_MT"); return e ? atoi(e) : 0; }();
-        if (!sp) {
-            int dev = 0;
-            hipDeviceProp_t prop;
-            STBA_HIP(hipGetDevice(&dev));
-            STBA_HIP(hipGetDeviceProperties(&prop, dev));
-            const int ncu = prop.multiProcessorCount;
-            const int words = (ncu + 31) / 32;
-            std::vector<uint32_t> mp((size_t)words, 0u), mu((size_t)words, 0u);
-            for (int c = 0; c < ncu; ++c) {
-                if (c < PANEL_CUS) mp[(size_t)c / 32] |= 1u << (c % 32);
-                else mu[(size_t)c / 32] |= 1u << (c % 32);
-            }
-            if (PANEL_CUS <= 0 || PANEL_CUS >= ncu) {   // no partition: plain streams
-                STBA_HIP(hipStreamCreateWithFlags(&sp, hipStreamNonBlocking));
-                STBA_HIP(hipStreamCreateWithFlags(&su, hipStreamNonBlocking));
-            } else {
-                STBA_HIP(hipExtStreamCreateWithCUMask(&sp, (uint32_t)words, mp.data()));
-                STBA_HIP(hipExtStreamCreateWithCUMask(&su, (uint32_t)words, mu.data()));
-            }
-            STBA_HIP(hipEventCreateWithFlags(&evStart, hipEventDisableTiming));
-            STBA_HIP(hipEventCreateWithFlags(&evEnd, hipEventDisableTiming));
-        }
-        while ((int)evP.size() < nblk) {
-            hipEvent_t e1, e2;
-            STBA_HIP(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
-            STBA_HIP(hipEventCreateWithFlags(&e2, hipEventDisableTiming));
-            evP.push_back(e1); evU.push_back(e2);
-        }
-        STBA_HIP(hipEventRecord(evStart, st));
-        STBA_HIP(hipStreamWaitEvent(sp, evStart, 0));
-        launch_panel_diag(0, sp);
-        launch_panel_trsm(0, sp);
-        STBA_HIP(hipEventRecord(evP[0], sp));
-        int b = 0, last_bulk = -1;
-        for (; b + 1 < nblk && (nblk - b - 1) > SERIAL_MT; ++b) {
-            const int k0 = b * NB;
-            const int mt = nblk - b - 1;
-            if (last_bulk >= 0) STBA_HIP(hipStreamWaitEvent(sp, evU[last_bulk], 0));
-            launch_syrk(A, lda, k0, 1, mt, sp);
-            if (mt > 1) {
-                STBA_HIP(hipStreamWaitEvent(su, evP[b], 0));
-                launch_syrk(A, lda, k0, 2, mt * (mt - 1) / 2, su);
-                STBA_HIP(hipEventRecord(evU[b], su));
-                last_bulk = b;
-            }
-            launch_panel_diag(b + 1, sp);
-            launch_panel_trsm(b + 1, sp);
-            STBA_HIP(hipEventRecord(evP[b + 1], sp));
-        }
-        if (last_bulk >= 0) STBA_HIP(hipStreamWaitEvent(sp, evU[last_bulk], 0));
-        STBA_HIP(hipEventRecord(evEnd, sp));
-        STBA_HIP(hipStreamWaitEvent(st, evEnd, 0));
-        for (; b + 1 < nblk; ++b) {   // serial tail on the caller's stream (whole chip)
-            const int k0 = b * NB;
-            const int mt = nblk - b - 1;
-            launch_syrk(A, lda, k0, 0, mt * (mt + 1) / 2, st);
-            launch_panel_diag(b + 1, st);
-            launch_panel_trsm(b + 1, st);
-        }
     }
     STBA_TRY(mark((size_t)nblk * 4));
+    if (mid_event) STBA_HIP(hipEventRecord(mid_event, st));     // factorisation | backward substitution
     for (int b = nblk - 1; b >= 0; --b) {
         const int k0 = b * NB;
         const int has_next = (b < nblk - 1) ? 1 : 0;
@@ -1303,6 +1339,10 @@ static int chol_run(double* A, int lda, int n, double* x_dev, int* flag_dev, hip
 
 int chol_factor_solve_dev(double* A, int lda, int n, double* x_dev, int* flag_dev, hipStream_t st) {
     return chol_run(A, lda, n, x_dev, flag_dev, st, nullptr);
+}
+
+int chol_factor_solve_split(double* A, int lda, int n, double* x_dev, int* flag_dev, hipStream_t st, hipEvent_t mid_event) {
+    return chol_run(A, lda, n, x_dev, flag_dev, st, nullptr, mid_event);
 }
 
 int chol_factor_solve_profiled(double* A, int lda, int n, double* x_dev, int* flag_dev, hipStream_t st,

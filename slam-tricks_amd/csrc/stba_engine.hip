@@ -931,6 +931,34 @@ int stba_cholesky_time(int n, int reps, double* ms_avg, void* hip_stream) {
     return STBA_OK;
 }
 
+int stba_cholesky_time_split(int n, int reps, double* ms_factor, double* ms_backward, void* hip_stream) {
+    if (n <= 0 || reps <= 0 || !ms_factor || !ms_backward) return fail(STBA_ERR_INVALID_ARGUMENT, "bad argument");
+    STBA_TRY(require_device());
+    DenseWs w;
+    STBA_TRY(w.init(n, hip_stream));
+    hipEvent_t e0, e1, e2;
+    STBA_HIP(hipEventCreate(&e0)); STBA_HIP(hipEventCreate(&e1)); STBA_HIP(hipEventCreate(&e2));
+    double tf = 0.0, tb = 0.0;
+    const size_t cnt = (size_t)w.lda * w.lda;
+    for (int k = 0; k < reps + 1; ++k) {
+        hipLaunchKernelGGL(synth_spd_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, w.st, w.A, w.lda, n);
+        STBA_HIP(hipMemsetAsync(w.rhs, 0, (size_t)w.lda * sizeof(double), w.st));
+        STBA_TRY(chol_prepare_padding_dev(w.A, w.lda, n, w.rhs, w.st));
+        STBA_HIP(hipEventRecord(e0, w.st));
+        STBA_TRY(chol_factor_solve_split(w.A, w.lda, n, w.x, w.flag, w.st, e1));
+        STBA_HIP(hipEventRecord(e2, w.st));
+        STBA_HIP(hipStreamSynchronize(w.st));
+        float a = 0.f, b = 0.f;
+        STBA_HIP(hipEventElapsedTime(&a, e0, e1));
+        STBA_HIP(hipEventElapsedTime(&b, e1, e2));
+        if (k > 0) { tf += a; tb += b; }
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
+    *ms_factor = tf / reps;
+    *ms_backward = tb / reps;
+    return STBA_OK;
+}
+
 int stba_cholesky_profile(int n, double* ms4, double* syrk_flops, double* syrk_flops_padded, int* syrk_launches,
                           void* hip_stream) {
     if (n <= 0 || !ms4) return fail(STBA_ERR_INVALID_ARGUMENT, "bad argument");

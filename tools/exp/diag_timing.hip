@@ -19,7 +19,7 @@ int main() {
         hipDeviceSynchronize();
         long long w0 = 0, w1 = 0;
         hipEventRecord(e0, 0);
-        hipLaunchKernelGGL(stba::chol_diag_kernel, dim3(1), dim3(256), 0, 0, A, lda, 0, n, flag, dinv);
+        hipLaunchKernelGGL(stba::chol_diag_kernel, dim3(1), dim3(512), 0, 0, A, lda, 0, n, flag, dinv);
         hipEventRecord(e1, 0);
         hipDeviceSynchronize();
         float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -32,11 +32,11 @@ int main() {
         printf("trsm kernel (64 groups) %.2f us\n", ms * 1e3);
         (void)w0; (void)w1;
     }
-    long long ts[4][16][6];
+    long long ts[8][16][6];
     hipMemcpyFromSymbol(ts, HIP_SYMBOL(stba::g_diag_ts), sizeof ts);
     printf("total cycles wave0: %lld\n", ts[0][15][5] - ts[0][0][0]);
-    for (int w = 0; w < 4; ++w) {
-        printf("wave %d\n step:  a+bar   c      bar    e(mfma)  f   | total\n", w);
+    for (int w = 0; w < 8; w += 1) {
+        printf("wave %d\n step:  e2prev   c      bar    e1+f    a+bar | total\n", w);
         for (int s = 0; s < 16; ++s) {
             printf("  %2d: ", s);
             for (int k = 0; k < 5; ++k) printf("%6lld ", ts[w][s][k + 1] - ts[w][s][k]);
