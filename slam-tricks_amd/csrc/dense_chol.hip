@@ -62,14 +62,15 @@ int chol_prepare_padding_dev(double* A_dev, int lda, int n, const double* rhs_de
 }
 
 // ------------------------------------------------------------------------------------------
-// fast reciprocal square root: v_rsq_f64 + two Newton steps (FMA only, ~1 ulp), and sqrt from it.
+// fast reciprocal square root: v_rsq_f64 + ONE third-order (Halley) correction.  With e = 1 - d y0^2,
+// 1/sqrt(d) = y0 (1 - e)^(-1/2) = y0 (1 + e/2 + 3e^2/8 + O(e^3)): four dependent FMA-class operations
+// after the seed instead of six for two Newton steps (this sits on the pivot chain of the diagonal
+// block, 6000 times per factorisation), and cubic convergence takes the >= 2^-20 seed below 2^-60.
 __device__ __forceinline__ double fast_rsqrt(double d) {
-    double y = __builtin_amdgcn_rsq(d);
-    double t = d * y;
-    y = fma(0.5 * y, fma(-t, y, 1.0), y);
-    t = d * y;
-    y = fma(0.5 * y, fma(-t, y, 1.0), y);
-    return y;
+    const double y = __builtin_amdgcn_rsq(d);
+    const double e = fma(-d * y, y, 1.0);
+    const double p = fma(0.375, e, 0.5);
+    return fma(y * e, p, y);
 }
 __device__ __forceinline__ double sqrt_from_rsqrt(double d, double y) {
     double g = d * y;
@@ -714,9 +715,12 @@ __device__ __forceinline__ bool mega_wait(const int* p, int target, int* abortf)
 // X = W * L11^-T for the 16 rows of this wave (see trsm_group), all 8 waves of the workgroup together:
 // L11's 28 sub-diagonal tiles and the 8 inverse diagonal tiles are staged once into LDS (72 KB) in
 // A-operand order.  W holds X on return.  Starts and ends without a barrier on smem.
-__device__ __forceinline__ void trsm_compute512(double4v (&W)[8], const double* __restrict__ rowp, bool ident,
+// `dflag`: the diagonal block's flag is awaited HERE, after the wave's own rows have been requested (they
+// do not depend on it), so their latency hides behind the wait.  Returns false on a wait time-out.
+__device__ __forceinline__ bool trsm_compute512(double4v (&W)[8], const double* __restrict__ rowp, bool ident,
                                                 int ident_row0, int nv, const double* __restrict__ Lb, int lda,
-                                                const double* __restrict__ dinv, double* smem, int t, long long* ph) {
+                                                const double* __restrict__ dinv, double* smem, int t, long long* ph,
+                                                const int* dflag, int* abortf, int* s_ok) {
     const int lane = t & 63;
     const int n = lane & 15, g = lane >> 4;
     // this wave's rows (issued first: they are not needed before the staging is done)
@@ -729,6 +733,12 @@ __device__ __forceinline__ void trsm_compute512(double4v (&W)[8], const double* 
             W[J] = mld4<MEGA_C_SC1>(rowp + 16 * J + 4 * g);
         }
     }
+    if (t == 0) {
+        *s_ok = mega_wait(dflag, 1, abortf) ? 1 : 0;
+        asm volatile("buffer_inv sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    if (!*s_ok) return false;
     // stage tile (J, I), J > I, at index 7I - I(I-1)/2 + (J-I-1), then the inverse tiles at 28 + J;
     // element (r, c) of a tile goes to lane (n = pm(r), g = c >> 2), register c & 3, with
     // pm(r) = 4 (r & 3) + (r >> 2) (an involution)
@@ -776,18 +786,21 @@ __device__ __forceinline__ void trsm_compute512(double4v (&W)[8], const double* 
         }
     }
     PHASE_STAMP(1);
+    return true;
 }
 
 // T / TI task: panel solve of 128 rows, result written through to memory (final data)
-__device__ __forceinline__ void trsm_task512(double* __restrict__ rowp, bool ident, int ident_row0, int nv,
+__device__ __forceinline__ bool trsm_task512(double* __restrict__ rowp, bool ident, int ident_row0, int nv,
                                              const double* __restrict__ Lb, int lda,
-                                             const double* __restrict__ dinv, double* smem, int t, long long* ph) {
+                                             const double* __restrict__ dinv, double* smem, int t, long long* ph,
+                                             const int* dflag, int* abortf, int* s_ok) {
     double4v W[8];
-    trsm_compute512(W, rowp, ident, ident_row0, nv, Lb, lda, dinv, smem, t, ph);
+    if (!trsm_compute512(W, rowp, ident, ident_row0, nv, Lb, lda, dinv, smem, t, ph, dflag, abortf, s_ok)) return false;
     const int g = (t & 63) >> 4;
 #pragma unroll
     for (int J = 0; J < 8; ++J) gst4<true>(rowp + 16 * J + 4 * g, W[J]);
     PHASE_STAMP(2);
+    return true;
 }
 
 // TU task (b, q): the critical hand-off D(b) -> D(b+1) in ONE task instead of a panel solve, a flag, and
@@ -797,12 +810,12 @@ __device__ __forceinline__ void trsm_task512(double* __restrict__ rowp, bool ide
 // A[b+1, b+1] -= X X^T (lower-triangle tiles only).  Workgroup q also writes rows 32q..32q+31 of X.
 __device__ __forceinline__ bool tu_task512(double* __restrict__ A, int lda, int k0, int rb, int q,
                                            const double* __restrict__ dinv, double* smem, int t, long long* ph,
-                                           int* loaded, int* abortf, int* s_ok) {
+                                           int* loaded, const int* dflag, int* abortf, int* s_ok) {
     const int lane = t & 63, w = t >> 6;
     const int n = lane & 15, g = lane >> 4;
     double* rowp = A + (size_t)(rb * NB + 16 * w + n) * lda + k0;
     double4v W[8];
-    trsm_compute512(W, rowp, false, 0, NB, A + (size_t)k0 * lda + k0, lda, dinv, smem, t, ph);
+    if (!trsm_compute512(W, rowp, false, 0, NB, A + (size_t)k0 * lda + k0, lda, dinv, smem, t, ph, dflag, abortf, s_ok)) return false;
     __syncthreads();                          // every wave is done with the L11 tiles in smem and has consumed its rows
     // the four TU workgroups of this step all READ the whole block row and each WRITES 32 rows of it in
     // place: count the readers, and store only once all four have their copy (see below)
@@ -906,12 +919,12 @@ __global__ __launch_bounds__(512) void chol_mega_kernel(MegaArgs a) {
             bool ok = true;
             if (type == TASK_D) {
                 ok = mega_wait(&ver[b * nblk + b], 4 * b, abortf);
-            } else if (type == TASK_T) {
-                ok = mega_wait(&dflag[b], 1, abortf) && mega_wait(&ver[ti * nblk + b], 4 * b, abortf);
+            } else if (type == TASK_T) {          // (the diagonal block's flag is awaited inside the task)
+                ok = mega_wait(&ver[ti * nblk + b], 4 * b, abortf);
             } else if (type == TASK_TI) {
-                ok = mega_wait(&dflag[b], 1, abortf);
+                ok = true;
             } else if (type == TASK_TU) {
-                ok = mega_wait(&dflag[b], 1, abortf) && mega_wait(&ver[(b + 1) * nblk + b], 4 * b, abortf) &&
+                ok = mega_wait(&ver[(b + 1) * nblk + b], 4 * b, abortf) &&
                      mega_wait(&ver[(b + 1) * nblk + b + 1], 4 * b, abortf);
             } else {
                 const int i = (type == TASK_UQ) ? (ti >> 2) : ti;
@@ -940,16 +953,22 @@ __global__ __launch_bounds__(512) void chol_mega_kernel(MegaArgs a) {
         } else if (type == TASK_T) {
             const int lane = tt & 63, w = tt >> 6;
             double* rowp = a.A + (size_t)(ti * NB + 16 * w + (lane & 15)) * a.lda + k0;
-            trsm_task512(rowp, false, 0, NB, a.A + (size_t)k0 * a.lda + k0, a.lda, li + NB * NB, smem, tt, ph);
+            if (!trsm_task512(rowp, false, 0, NB, a.A + (size_t)k0 * a.lda + k0, a.lda, li + NB * NB, smem, tt, ph, &dflag[b], abortf, &s_ok)) {
+                if (t == 0) atomicExch(a.flag, CHOL_FLAG_TIMEOUT);
+                break;
+            }
         } else if (type == TASK_TI) {
             const int lane = tt & 63, w = tt >> 6;
             const int nv = min(NB, (a.lda - 1) - k0);
             double* rowp = li + (size_t)(16 * w + (lane & 15)) * NB;
-            trsm_task512(rowp, true, 16 * w, nv, a.A + (size_t)k0 * a.lda + k0, a.lda, li + NB * NB, smem, tt, ph);
+            if (!trsm_task512(rowp, true, 16 * w, nv, a.A + (size_t)k0 * a.lda + k0, a.lda, li + NB * NB, smem, tt, ph, &dflag[b], abortf, &s_ok)) {
+                if (t == 0) atomicExch(a.flag, CHOL_FLAG_TIMEOUT);
+                break;
+            }
         } else if (type == TASK_U) {
             syrk_tile512<128>(a.A, a.lda, k0, ti * NB, tj * NB, smem, tt);
         } else if (type == TASK_TU) {
-            if (!tu_task512(a.A, a.lda, k0, b + 1, ti, li + NB * NB, smem, tt, ph, &tuflag[b], abortf, &s_ok)) {
+            if (!tu_task512(a.A, a.lda, k0, b + 1, ti, li + NB * NB, smem, tt, ph, &tuflag[b], &dflag[b], abortf, &s_ok)) {
                 if (t == 0) atomicExch(a.flag, CHOL_FLAG_TIMEOUT);
                 break;
             }
@@ -1006,7 +1025,11 @@ static void mega_build_tasks(int nblk, int nq, int wg_per_q, std::vector<int4>& 
     std::vector<int> idD((size_t)NBK, -1), idTI((size_t)NBK, -1), idTU((size_t)NBK * 4, -1), idT((size_t)NBK * NBK, -1),
         idUq((size_t)NBK * NBK * 4, -1), idU((size_t)NBK * NBK * NBK, -1);
     // measured on MI355X (tools/mega_trace.py), microseconds, plus ~2 us of flag latency per hop
-    const double DUR[6] = {35.0, 23.0, 19.0, 25.0, 16.5, 23.5};
+    // Durations are STBA_MEGA_DUR=d,t,ti,u,uq,tu (experiments).  D and TU are entered SHORTER than measured
+    // (33 / 21 us): their tickets then sit a little early in the queues and a workgroup is already
+    // spinning on the flag when the input arrives -- a few idle workgroups buy a tight critical chain.
+    double DUR[6] = {35.0, 23.0, 19.0, 25.0, 16.5, 23.5};
+    if (const char* e = getenv("STBA_MEGA_DUR")) sscanf(e, "%lf,%lf,%lf,%lf,%lf,%lf", &DUR[0], &DUR[1], &DUR[2], &DUR[3], &DUR[4], &DUR[5]);
     auto add = [&](int type, int b, int i, int j, double prio) {
         Node nd; nd.tk = make_int4(type, b, i, j); nd.dur = DUR[type]; nd.prio = prio; nd.q = mega_owner(nd.tk, nq);
         nodes.push_back(nd);
@@ -1315,6 +1338,9 @@ static int chol_run(double* A, int lda, int n, double* x_dev, int* flag_dev, hip
     }
     STBA_TRY(mark((size_t)nblk * 4));
     if (mid_event) STBA_HIP(hipEventRecord(mid_event, st));     // factorisation | backward substitution
+    // backward substitution: one small launch per block.  (A persistent variant -- one chain workgroup plus
+    // GEMV workers synchronised with flags -- was measured at 13.7 us per block against 7.7 us for these
+    // launches: every hand-off through memory costs ~2 us on this part, a dependent launch ~3 us.)
     for (int b = nblk - 1; b >= 0; --b) {
         const int k0 = b * NB;
         const int has_next = (b < nblk - 1) ? 1 : 0;
