@@ -580,7 +580,7 @@ static void launch_syrk(double* A, int lda, int k0, int tile_mode, int tiles128,
 // hold an older copy, because nobody but the owner ever touched those lines before.  Flags are
 // agent-scope atomics.
 // The ticket order comes from a list-scheduling simulation on the host (mega_build_tasks).
-enum { TASK_D = 0, TASK_T = 1, TASK_TI = 2, TASK_U = 3, TASK_UQ = 4, TASK_TU = 5 };
+enum { TASK_D = 0, TASK_T = 1, TASK_TI = 2, TASK_U = 3, TASK_UQ = 4, TASK_TU = 5, TASK_EARLY = 0x100 };
 
 struct MegaArgs {
     double* A; int lda; int n; int nblk;
@@ -810,10 +810,26 @@ __device__ __forceinline__ bool trsm_task512(double* __restrict__ rowp, bool ide
 // A[b+1, b+1] -= X X^T (lower-triangle tiles only).  Workgroup q also writes rows 32q..32q+31 of X.
 __device__ __forceinline__ bool tu_task512(double* __restrict__ A, int lda, int k0, int rb, int q,
                                            const double* __restrict__ dinv, double* smem, int t, long long* ph,
-                                           int* loaded, const int* dflag, int* abortf, int* s_ok) {
+                                           int* loaded, int* ver_diag, const int* dflag, int* abortf, int* s_ok) {
     const int lane = t & 63, w = t >> 6;
     const int n = lane & 15, g = lane >> 4;
     double* rowp = A + (size_t)(rb * NB + 16 * w + n) * lda + k0;
+    // output tiles (m, n') of the diagonal tile, m in {2q, 2q+1}, n' <= m: 4q + 3 of them, at most two
+    // per wave (e = w and w + 8).  Their current values are requested first: they do not depend on D(b).
+    const int ntile = 4 * q + 3;
+    double* Cb = A + (size_t)(rb * NB) * lda + rb * NB;
+    double4v acc[2];
+    int tm[2], tn[2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        const int e = w + 8 * s2;
+        tm[s2] = (e < 2 * q + 1) ? 2 * q : 2 * q + 1;
+        tn[s2] = (e < 2 * q + 1) ? e : e - (2 * q + 1);
+        if (e < ntile) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[s2][r] = mld<MEGA_C_SC1>(&Cb[(size_t)(16 * tm[s2] + g + 4 * r) * lda + 16 * tn[s2] + n]);
+        }
+    }
     double4v W[8];
     if (!trsm_compute512(W, rowp, false, 0, NB, A + (size_t)k0 * lda + k0, lda, dinv, smem, t, ph, dflag, abortf, s_ok)) return false;
     __syncthreads();                          // every wave is done with the L11 tiles in smem and has consumed its rows
@@ -823,29 +839,31 @@ __device__ __forceinline__ bool tu_task512(double* __restrict__ A, int lda, int 
 #pragma unroll
     for (int J = 0; J < 8; ++J) *reinterpret_cast<double4v*>(smem + (w * 8 + J) * 256 + lane * 4) = W[J];
     __syncthreads();
-    // output tiles (m, n'), m in {2q, 2q+1}, n' <= m: 4q + 3 of them, at most two per wave
-    const int ntile = 4 * q + 3;
-    double* Cb = A + (size_t)(rb * NB) * lda + rb * NB;
-#pragma unroll 1
-    for (int e = w; e < ntile; e += 8) {
-        const int m = (e < 2 * q + 1) ? 2 * q : 2 * q + 1;
-        const int np = (e < 2 * q + 1) ? e : e - (2 * q + 1);
-        double4v acc;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] = mld<MEGA_C_SC1>(&Cb[(size_t)(16 * m + g + 4 * r) * lda + 16 * np + n]);
+    for (int s2 = 0; s2 < 2; ++s2) {
+        if (w + 8 * s2 < ntile) {
+            const int m = tm[s2], np = tn[s2];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const double4v fa = *reinterpret_cast<const double4v*>(smem + (m * 8 + c) * 256 + lane * 4);
-            const double4v fb = *reinterpret_cast<const double4v*>(smem + (np * 8 + c) * 256 + lane * 4);
+            for (int c = 0; c < 8; ++c) {
+                const double4v fa = *reinterpret_cast<const double4v*>(smem + (m * 8 + c) * 256 + lane * 4);
+                const double4v fb = *reinterpret_cast<const double4v*>(smem + (np * 8 + c) * 256 + lane * 4);
 #pragma unroll
-            for (int qq = 0; qq < 4; ++qq) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-fa[qq], fb[qq], acc, 0, 0, 0);
+                for (int qq = 0; qq < 4; ++qq) acc[s2] = __builtin_amdgcn_mfma_f64_16x16x4f64(-fa[qq], fb[qq], acc[s2], 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gst<MEGA_C_WT>(&Cb[(size_t)(16 * m + g + 4 * r) * lda + 16 * np + n], acc[s2][r]);
         }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) gst<MEGA_C_WT>(&Cb[(size_t)(16 * m + g + 4 * r) * lda + 16 * np + n], acc[r]);
     }
-    // The three other workgroups hold later tickets of the same queue; they are taken as soon as any
-    // workgroup of this XCD is free (needs >= 4 resident workgroups per XCD, checked on the host).
-    if (t == 0) *s_ok = mega_wait(loaded, 4, abortf) ? 1 : 0;
+    // D(b+1) needs nothing but this tile (it runs on this XCD and finds it in the L2): signal it now, the
+    // panel rows below are off the critical chain
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t == 0) {
+        __hip_atomic_fetch_add(ver_diag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // The three other workgroups hold later tickets of the same queue; they are taken as soon as any
+        // workgroup of this XCD is free (needs >= 4 resident workgroups per XCD, checked on the host).
+        *s_ok = mega_wait(loaded, 4, abortf) ? 1 : 0;
+    }
     __syncthreads();
     if (!*s_ok) return false;
     if ((w >> 1) == q) {
@@ -909,13 +927,15 @@ __global__ __launch_bounds__(512) void chol_mega_kernel(MegaArgs a) {
         const int task = s_task;
         if (task >= qend) break;
         const int4 d = a.tasks[task];
-        const int type = d.x, b = d.y, ti = d.z, tj = d.w;
+        const int type = d.x & 0xff, b = d.y, ti = d.z, tj = d.w;
+        const bool early = (d.x & TASK_EARLY) != 0 || type == TASK_TU || type == TASK_D;
         const int k0 = b * NB;
         if (t == 0) {
             if (a.trace) { a.trace[8 * (size_t)task] = blockIdx.x; a.trace[8 * (size_t)task + 1] = wall_clock64(); }
-            // next ticket; its latency hides behind this task.  Not for TU: a TU task waits for its three
-            // siblings, which hold LATER tickets -- this workgroup must not sit on one of them.
-            if (type != TASK_TU) mine = qbeg + atomicAdd(ticket, 1);
+            // next ticket; its latency hides behind this task.  Not for the chain tasks: their tickets are
+            // taken early (see the gates in mega_build_tasks) and they wait for tasks with LATER tickets (a
+            // TU task also for its three siblings) -- such a workgroup must not sit on one of those.
+            if (!early) mine = qbeg + atomicAdd(ticket, 1);
             bool ok = true;
             if (type == TASK_D) {
                 ok = mega_wait(&ver[b * nblk + b], 4 * b, abortf);
@@ -968,7 +988,7 @@ __global__ __launch_bounds__(512) void chol_mega_kernel(MegaArgs a) {
         } else if (type == TASK_U) {
             syrk_tile512<128>(a.A, a.lda, k0, ti * NB, tj * NB, smem, tt);
         } else if (type == TASK_TU) {
-            if (!tu_task512(a.A, a.lda, k0, b + 1, ti, li + NB * NB, smem, tt, ph, &tuflag[b], &dflag[b], abortf, &s_ok)) {
+            if (!tu_task512(a.A, a.lda, k0, b + 1, ti, li + NB * NB, smem, tt, ph, &tuflag[b], &ver[(b + 1) * nblk + b + 1], &dflag[b], abortf, &s_ok)) {
                 if (t == 0) atomicExch(a.flag, CHOL_FLAG_TIMEOUT);
                 break;
             }
@@ -985,14 +1005,11 @@ __global__ __launch_bounds__(512) void chol_mega_kernel(MegaArgs a) {
 #endif
             if (type == TASK_D) __hip_atomic_fetch_add(&dflag[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             else if (type == TASK_T) __hip_atomic_fetch_add(&tflag[b * nblk + ti], 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else if (type == TASK_TU) {
-                __hip_atomic_fetch_add(&tflag[b * nblk + b + 1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_fetch_add(&ver[(b + 1) * nblk + b + 1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            else if (type == TASK_TU) __hip_atomic_fetch_add(&tflag[b * nblk + b + 1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (ver: inside the task)
             else if (type == TASK_U) __hip_atomic_fetch_add(&ver[ti * nblk + tj], 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             else if (type == TASK_UQ) __hip_atomic_fetch_add(&ver[(ti >> 2) * nblk + tj], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (a.trace) a.trace[8 * (size_t)task + 3] = wall_clock64();
-            if (type == TASK_TU) mine = qbeg + atomicAdd(ticket, 1);
+            if (early) mine = qbeg + atomicAdd(ticket, 1);
         }
     }
 }
@@ -1019,17 +1036,26 @@ static int mega_owner(const int4& tk, int nq) {
 // argument needs, and (ii) per-queue orders in which a workgroup rarely takes a ticket whose inputs
 // are far from ready (an in-order ticket queue has no other notion of priority).
 static void mega_build_tasks(int nblk, int nq, int wg_per_q, std::vector<int4>& out, int* qstart) {
-    struct Node { int4 tk; std::vector<int> succ; int indeg = 0; double dur = 0, prio = 0; int q = 0; double start = 0; };
+    // gate (experiment, STBA_MEGA_GATES=1, off by default): a CHAIN task (D, TU) may be TAKEN as soon as the
+    // gate task has started, long before its inputs are ready, so that a workgroup already spins on the flag
+    // when D(b) finishes (while all workgroups are busy with 23 us trailing tiles the hand-off waits 6..13 us
+    // for a free one).  Measured: no gain -- the tiles (b+1, b) / (b+1, b+1) then arrive late instead (the
+    // T -> Uq chain of the previous panel has only ~6 us of slack), and a static order that deviates from
+    // the simulated one is fragile.  A dynamic chain queue is the proper fix.
+    struct Node { int4 tk; std::vector<int> succ; std::vector<int> gated; std::vector<int> early_succ; int indeg = 0; double dur = 0, prio = 0; int q = 0;
+                  int gate = -1; bool gate_open = false, assigned = false, running = false; };
     std::vector<Node> nodes;
     const int NBK = nblk;
     std::vector<int> idD((size_t)NBK, -1), idTI((size_t)NBK, -1), idTU((size_t)NBK * 4, -1), idT((size_t)NBK * NBK, -1),
         idUq((size_t)NBK * NBK * 4, -1), idU((size_t)NBK * NBK * NBK, -1);
     // measured on MI355X (tools/mega_trace.py), microseconds, plus ~2 us of flag latency per hop
-    // Durations are STBA_MEGA_DUR=d,t,ti,u,uq,tu (experiments).  D and TU are entered SHORTER than measured
-    // (33 / 21 us): their tickets then sit a little early in the queues and a workgroup is already
-    // spinning on the flag when the input arrives -- a few idle workgroups buy a tight critical chain.
-    double DUR[6] = {35.0, 23.0, 19.0, 25.0, 16.5, 23.5};
+    // (STBA_MEGA_DUR=d,t,ti,u,uq,tu overrides them for experiments)
+    double DUR[6] = {33.0, 23.0, 19.0, 25.0, 16.5, 20.0};
     if (const char* e = getenv("STBA_MEGA_DUR")) sscanf(e, "%lf,%lf,%lf,%lf,%lf,%lf", &DUR[0], &DUR[1], &DUR[2], &DUR[3], &DUR[4], &DUR[5]);
+    // LEAD: the TU tickets are placed as if D(b) ended LEAD us early, so that their workgroups are already
+    // inside the task (rows requested, spinning on the flag) when it really ends
+    static const double LEAD = [] { const char* e = getenv("STBA_MEGA_LEAD"); return e ? atof(e) : 0.0; }();
+    static const bool GATES = [] { const char* e = getenv("STBA_MEGA_GATES"); return e && atoi(e) != 0; }();
     auto add = [&](int type, int b, int i, int j, double prio) {
         Node nd; nd.tk = make_int4(type, b, i, j); nd.dur = DUR[type]; nd.prio = prio; nd.q = mega_owner(nd.tk, nq);
         nodes.push_back(nd);
@@ -1066,7 +1092,8 @@ static void mega_build_tasks(int nblk, int nq, int wg_per_q, std::vector<int4>& 
         if (b + 1 < NBK)
             for (int q = 0; q < 4; ++q) {
                 const int tu = idTU[(size_t)b * 4 + q];
-                dep(d, tu);
+                nodes[(size_t)d].early_succ.push_back(tu);      // released LEAD us before D(b) ends (see the simulation)
+                nodes[(size_t)tu].indeg++;
                 if (b > 0) {
                     for (int q2 = 0; q2 < 4; ++q2) dep(idUq[((size_t)(b - 1) * NBK + (b + 1)) * 4 + q2], tu);
                     dep(idU[((size_t)(b - 1) * NBK + (b + 1)) * NBK + (b + 1)], tu);
@@ -1092,43 +1119,73 @@ static void mega_build_tasks(int nblk, int nq, int wg_per_q, std::vector<int4>& 
                 if (b > 0) dep(idU[((size_t)(b - 1) * NBK + i) * NBK + j], u);
             }
     }
+    if (GATES)
+        for (int b = 0; b + 1 < NBK; ++b) {
+            const int d = idD[(size_t)b];
+            for (int q = 0; q < 4; ++q) { nodes[(size_t)idTU[(size_t)b * 4 + q]].gate = d; nodes[(size_t)d].gated.push_back(idTU[(size_t)b * 4 + q]); }
+            nodes[(size_t)idD[(size_t)b + 1]].gate = d;
+            nodes[(size_t)d].gated.push_back(idD[(size_t)b + 1]);
+        }
     // event-driven list scheduling
     typedef std::pair<double, int> PI;
     std::vector<std::priority_queue<PI, std::vector<PI>, std::greater<PI>>> ready((size_t)nq);
     std::priority_queue<PI, std::vector<PI>, std::greater<PI>> events;
     std::vector<int> idle((size_t)nq, wg_per_q);
-    for (int k = 0; k < (int)nodes.size(); ++k)
-        if (nodes[(size_t)k].indeg == 0) ready[(size_t)nodes[(size_t)k].q].push(PI(nodes[(size_t)k].prio, k));
     double now = 0.0;
-    size_t started = 0;
     std::vector<std::vector<int>> order((size_t)nq);
+    auto push_ready = [&](int k) { ready[(size_t)nodes[(size_t)k].q].push(PI(nodes[(size_t)k].prio, k)); };
+    auto start_running = [&](int k) {            // inputs ready AND a workgroup holds the ticket
+        Node& nd = nodes[(size_t)k];
+        nd.running = true;
+        events.push(PI(now + nd.dur, k));
+        if (!nd.early_succ.empty()) events.push(PI(now + std::max(0.0, nd.dur - LEAD), -(k + 1)));
+        for (int g : nd.gated)
+            if (!nodes[(size_t)g].gate_open) { nodes[(size_t)g].gate_open = true; push_ready(g); }
+    };
+    for (int k = 0; k < (int)nodes.size(); ++k)
+        if (nodes[(size_t)k].gate < 0 && nodes[(size_t)k].indeg == 0) push_ready(k);
     for (;;) {
         for (int q = 0; q < nq; ++q)
             while (idle[(size_t)q] > 0 && !ready[(size_t)q].empty()) {
                 const int k = ready[(size_t)q].top().second;
                 ready[(size_t)q].pop();
                 idle[(size_t)q]--;
-                nodes[(size_t)k].start = now;
-                events.push(PI(now + nodes[(size_t)k].dur, k));
+                nodes[(size_t)k].assigned = true;
                 order[(size_t)q].push_back(k);
-                ++started;
+                if (nodes[(size_t)k].indeg == 0) start_running(k);
             }
         if (events.empty()) break;
         const PI ev = events.top();
         events.pop();
         now = ev.first;
+        if (ev.second < 0) {                      // early release: the TU tickets of this diagonal block
+            for (int sidx : nodes[(size_t)(-ev.second - 1)].early_succ) {
+                Node& sn = nodes[(size_t)sidx];
+                if (--sn.indeg != 0) continue;
+                if (sn.gate < 0) push_ready(sidx);
+                else if (sn.assigned && !sn.running) start_running(sidx);
+            }
+            continue;
+        }
         const Node& nd = nodes[(size_t)ev.second];
         idle[(size_t)nd.q]++;
-        for (int sidx : nd.succ)
-            if (--nodes[(size_t)sidx].indeg == 0) ready[(size_t)nodes[(size_t)sidx].q].push(PI(nodes[(size_t)sidx].prio, sidx));
+        for (int sidx : nd.succ) {
+            Node& sn = nodes[(size_t)sidx];
+            if (--sn.indeg != 0) continue;
+            if (sn.gate < 0) push_ready(sidx);
+            else if (sn.assigned && !sn.running) start_running(sidx);   // its workgroup was already spinning
+        }
     }
     out.clear();
     for (int q = 0; q < nq; ++q) {
         qstart[q] = (int)out.size();
-        for (int k : order[(size_t)q]) out.push_back(nodes[(size_t)k].tk);
+        for (int k : order[(size_t)q]) {
+            int4 tk = nodes[(size_t)k].tk;
+            if (nodes[(size_t)k].gate >= 0) tk.x |= TASK_EARLY;      // taken early: must not prefetch the next ticket
+            out.push_back(tk);
+        }
     }
     qstart[nq] = (int)out.size();
-    (void)started;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -10,7 +10,8 @@ if sys.argv[1] == "run":
     sys.exit(0)
 raw = open(sys.argv[1], "rb").read()
 nt = int(np.frombuffer(raw[:4], np.int32)[0])
-tasks = np.frombuffer(raw[4:4 + 16 * nt], np.int32).reshape(nt, 4)
+tasks = np.frombuffer(raw[4:4 + 16 * nt], np.int32).reshape(nt, 4).copy()
+tasks[:, 0] &= 0xff
 tr = np.frombuffer(raw[4 + 16 * nt:], np.int64).reshape(nt, 8)
 t0 = tr[:, 1].min()
 us = lambda x: (x - t0) / 100.0
@@ -47,3 +48,17 @@ d_ready = {int(tasks[k, 1]): us(tr[k, 2]) for k in dm}
 gaps = [d_ready[b + 1] - d_done[b] for b in range(len(dm) - 1)]
 runs = [d_done[b] - d_ready[b] for b in range(len(dm))]
 print("D run mean", np.mean(runs), " gap D(b).done -> D(b+1).ready: mean", np.mean(gaps), "first10", np.round(gaps[:10], 1), "last10", np.round(gaps[-10:], 1))
+# hand-off detail for a few steps: times relative to D(b).done
+for b in (2, 5, 10, 20, 30, 40):
+    if b + 1 >= len(dm):
+        continue
+    kd = [k for k in dm if tasks[k, 1] == b][0]
+    kd1 = [k for k in dm if tasks[k, 1] == b + 1][0]
+    t0b = tr[kd, 3]
+    rel = lambda x: (x - t0b) / 100.0
+    tus = [k for k in np.where(tasks[:, 0] == 5)[0] if tasks[k, 1] == b]
+    line = f"b={b:2d} D.run {(tr[kd,3]-tr[kd,2])/100.0:5.1f} | "
+    for k in tus:
+        line += f"TU{tasks[k,2]} tick {rel(tr[k,1]):7.1f} rdy {rel(tr[k,2]):6.1f} ph {rel(tr[k,4]):5.1f} {rel(tr[k,5]):5.1f} {rel(tr[k,6]):5.1f} done {rel(tr[k,3]):5.1f} | "
+    line += f"D+1 tick {rel(tr[kd1,1]):7.1f} rdy {rel(tr[kd1,2]):6.1f}"
+    print(line)
