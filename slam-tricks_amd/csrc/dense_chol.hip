@@ -130,198 +130,317 @@ template <bool SC1> __device__ __forceinline__ double4v mld4(const double* p) {
 }
 
 // ------------------------------------------------------------------------------------------
-// Diagonal block: 512 threads = 8 waves, the 128x128 block lives in MFMA accumulator layout
-// (8x8 tiles of 16x16, one tile row per wave), processed in 16 block steps of 8 columns:
-//   a. lanes holding the 8 panel columns publish them to LDS
-//   c. 128 row threads factor the 8x8 diagonal mini-block redundantly (right-looking,
-//      division-free v_rsq_f64 + Newton chain) and solve their panel row
-//   e. rank-8 update of the trailing tiles on the matrix cores: two v_mfma_f64_16x16x4_f64 per
-//      tile, operands straight from the scaled panel rows in LDS
-//   f. the finished panel columns are written back into the accumulators.
-// The steps are software-pipelined (see diag_step).  Finally the inverses of the eight 16x16
-// diagonal tiles are written to `dinv` (the panel solve multiplies by them on the matrix cores).
-constexpr int DIAG_SMEM_DOUBLES = NB * 9 * 3 + NB + 8 * 16 * 17;   // P, Lp0, Lp1, rd, Tl = 5760
-
-// optional phase timestamps for tools/exp/diag_timing.hip (compiled out of the library)
+// Diagonal block (128x128), 512 threads.  The pivot chain is sequential (128 columns), so everything is
+// arranged around keeping it short:
+//   * waves 0,1 = 128 ROW THREADS; thread i owns row i of the CURRENT 16-column tile column in
+//     registers.  Per 8 columns: the 8 block rows publish their values (tiny), every row thread factors
+//     the 8x8 mini-block redundantly (right-looking, division-free v_rsq_f64 + Halley) and solves its
+//     own row.  Between the two halves of a tile column each row thread applies the first half's rank-8
+//     update to its own 8 values of the second half (64 FMAs) -- no matrix core, no publish round trip.
+//     Finished columns of L go straight from the row threads to global memory.
+//   * waves 2,3,6,7 = MATRIX-CORE waves; they own the trailing 16x16 tiles (tile rows {1,7}, {2,6}, {4},
+//     {3,5}) in MFMA accumulator layout and apply every finished 8-column panel as a rank-8 update
+//     (two v_mfma_f64_16x16x4_f64 per tile, operands straight from the row threads' panel in LDS), one
+//     half step behind the row threads, then hand the next tile column over through LDS.  FP64 VALU and
+//     FP64 MFMA work do not overlap on one SIMD (measured), so waves 4,5 -- the SIMD partners of the row
+//     threads -- only take part in the barriers.
+// Barriers per tile column: Bp (block rows published) | c0 | B1 (panel 0 in LDS) | local update |
+// Bq (second mini-block published) | c1 ‖ rank-8(panel 0) | B2 | rank-8(panel 1) on the next tile
+// column + hand-over | B3.  The remaining rank-8(panel 1) runs under the next column's c0.
+// Finally the inverses of the eight 16x16 diagonal tiles are written to `dinv` (the panel solve
+// multiplies by them on the matrix cores).
+#define PHASE_STAMP(k) do { if (ph && t == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); ph[k] = wall_clock64(); } } while (0)
+// optional cycle stamps of the row threads for tools/exp/diag_timing.hip (compiled out of the library)
 #ifdef STBA_DIAG_TS
-__device__ long long g_diag_ts[8][16][6];
-#define DIAG_TS(slot) do { if ((t & 63) == 0) g_diag_ts[t >> 6][2 * Jt + H][slot] = __builtin_readcyclecounter(); } while (0)
+__device__ long long g_diag_ts[8][12];
+#define DIAG_TS(slot) do { if (i == 127) g_diag_ts[Jt][slot] = __builtin_readcyclecounter(); } while (0)
+__device__ long long g_diag_ts2[8][8];
+#define DIAG_TS2(slot) do { if (I1 == 7 && lr == 0 && lc == 0) g_diag_ts2[Jt][slot] = __builtin_readcyclecounter(); } while (0)
 #else
+#define DIAG_TS2(slot) do { } while (0)
 #define DIAG_TS(slot) do { } while (0)
 #endif
+struct DiagSmem {
+    double Pn[NB][17];        // next tile column, handed from the matrix-core waves to the row threads
+    double Lp[2][NB][9];      // scaled panel rows of the two half steps
+    double Dd[16][17];        // the 16 block rows of the current tile column
+    double Dd1[8][9];         // second mini-block after the local update
+    double Lb[8][8];          // first-panel rows of the second mini-block (16 B aligned copy for the local update)
+    double rd[NB];            // 1 / L[c][c]
+    double Tl[8][16][17];     // the diagonal 16x16 tiles of L (for the inverses)
+};
+constexpr int DIAG_SMEM_DOUBLES = (int)(sizeof(DiagSmem) / sizeof(double));
 
-// NT = number of tile columns this wave can own (its tile row index + 1 at most); ROWS = the wave's
-// threads are the row threads of step c.  Waves 0 and 1 (threads 0..127) are the row threads AND own
-// the two shortest tile rows (NT = 2), the other six waves own tile rows 2..7 and skip step c: the
-// register allocation is the maximum over the two code paths instead of their sum (a 512-thread
-// workgroup has 256 registers per lane).
-//
-// One block step (tile column Jt, half h; 8 panel columns), software-pipelined so that the row threads'
-// scalar chain (c) overlaps the other waves' matrix-core update of the PREVIOUS step:
-//     c(s)  on waves 0,1      ||   e2(s-1) on waves 2..7   (trailing tiles right of the next panel)
-//     ---- barrier ----
-//     e1(s): rank-8 update of the tile column holding the NEXT panel;  f(s): finished panel columns ->
-//     accumulators;  a(s+1): publish the next panel's columns to LDS
-//     ---- barrier ----
-// e2(s-1) always covers tile columns > Jt; e1(s) covers tile column Jt (h = 0: the right half of the
-// same tile column comes next) or Jt + 1 (h = 1).  Lp is double-buffered (e2 reads the previous one).
-template <int Jt, int H, int NT, bool ROWS>
-__device__ __forceinline__ void diag_step(double4v (&acc)[NT], double (*P)[9], double (*LpCur)[9], double (*LpPrev)[9],
-                                          double* rd, int t, int lr, int lc, int I, int k0, int n_real, int* flag) {
-    constexpr int h = H;
-    constexpr int j0 = 16 * Jt + 8 * H;
-    constexpr bool FIRST = (Jt == 0 && H == 0);
-    DIAG_TS(0);
-    // e2(s-1): tile columns J > Jt of this wave's tile row, with the previous step's panel
-    if (!FIRST && Jt + 1 < NT && I > Jt) {
-        const double a0 = -LpPrev[16 * I + lc][lr], a1 = -LpPrev[16 * I + lc][4 + lr];
+// 8x8 mini-block D (lower, from LDS) and this thread's 8 panel values p: returns l = p G^-T (G G^T = D)
+// and y = 1 / diag(G).  Rows INSIDE the block take the same path: row r of D solves to row r of G in its
+// first r+1 entries; the entries right of the diagonal are garbage that nobody reads.
+template <int LD>
+__device__ __forceinline__ bool mini_chol_solve(const double (*Dsrc)[LD], const double (&p_in)[8], double (&l)[8], double (&y)[8],
+                                                int col0_global, int n_real) {
+    double D[8][8], p[8];
 #pragma unroll
-        for (int J = Jt + 1; J < NT; ++J)
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int c = 0; c <= r; ++c) D[r][c] = Dsrc[r][c];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) p[c] = p_in[c];
+    bool bad = false;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        double d = D[c][c];
+        if (!(d > 0.0)) { bad = bad || ((col0_global + c) < n_real); d = 1.0; }
+        y[c] = fast_rsqrt(d);
+#pragma unroll
+        for (int r = c + 1; r < 8; ++r) D[r][c] *= y[c];
+#pragma unroll
+        for (int r = c + 1; r < 8; ++r)
+#pragma unroll
+            for (int q = c + 1; q <= r; ++q) D[r][q] = fma(-D[r][c], D[q][c], D[r][q]);
+        l[c] = p[c] * y[c];
+#pragma unroll
+        for (int q = c + 1; q < 8; ++q) p[q] = fma(-l[c], D[q][c], p[q]);
+    }
+    return bad;
+}
+
+template <bool WT>
+__device__ __forceinline__ void diag_row_threads(double* __restrict__ A, int lda, int k0, int n_real,
+                                                 int* __restrict__ flag, DiagSmem& sm, int i, long long* ph) {
+    const int t = i;
+    double p[16];
+    {   // tile column 0 straight from global memory (row i, 16 columns)
+        const double* src = A + (size_t)(k0 + i) * lda + k0;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) p[c] = mld<WT && MEGA_C_SC1>(src + c);
+    }
+    PHASE_STAMP(0);
+#pragma unroll 1
+    for (int Jt = 0; Jt < 8; ++Jt) {
+        const int j0 = 16 * Jt;
+        const bool active = (i >= j0);
+        DIAG_TS(0);
+        if (active && i < j0 + 16) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) sm.Dd[i - j0][c] = p[c];
+        }
+        DIAG_TS(1);
+        __syncthreads();                                                  // Bp
+        DIAG_TS(2);
+        double l0[8], l1[8], y[8];
+        if (active) {
+            double pa[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) pa[c] = p[c];
+            const bool bad = mini_chol_solve<17>(sm.Dd, pa, l0, y, k0 + j0, n_real);
+            if (bad && i == j0) atomicCAS(flag, 0, k0 + j0 + 1);
+            if (i == j0) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) sm.rd[j0 + c] = y[c];
+            }
+#pragma unroll
+            for (int c = 0; c < 8; ++c) sm.Lp[0][i][c] = l0[c];
+            if (i >= j0 + 8 && i < j0 + 16) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) sm.Lb[i - j0 - 8][c] = l0[c];
+            }
+        }
+        DIAG_TS(3);
+        __syncthreads();                                                  // B1
+        DIAG_TS(4);
+        const bool active1 = (i >= j0 + 8);
+        if (active1) {
+            // rank-8 update of this row's second-half values with the first-half panel
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                double v = p[8 + c];
+                const double2* lb = reinterpret_cast<const double2*>(&sm.Lb[c][0]);
+#pragma unroll
+                for (int k2 = 0; k2 < 4; ++k2) {
+                    const double2 b2 = lb[k2];
+                    v = fma(-l0[2 * k2], b2.x, v);
+                    v = fma(-l0[2 * k2 + 1], b2.y, v);
+                }
+                p[8 + c] = v;
+            }
+            if (i < j0 + 16) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) sm.Dd1[i - j0 - 8][c] = p[8 + c];
+            }
+        }
+        DIAG_TS(5);
+        __syncthreads();                                                  // Bq
+        DIAG_TS(6);
+        if (active1) {
+            double pa[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) pa[c] = p[8 + c];
+            const bool bad = mini_chol_solve<9>(sm.Dd1, pa, l1, y, k0 + j0 + 8, n_real);
+            if (bad && i == j0 + 8) atomicCAS(flag, 0, k0 + j0 + 8 + 1);
+            if (i == j0 + 8) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) sm.rd[j0 + 8 + c] = y[c];
+            }
+#pragma unroll
+            for (int c = 0; c < 8; ++c) sm.Lp[1][i][c] = l1[c];
+        }
+        DIAG_TS(7);
+        __syncthreads();                                                  // B2
+        DIAG_TS(8);
+        if (active && i < j0 + 16) {
+            // the diagonal tile for the inverses (the finished columns of L are stored to global memory by
+            // the otherwise idle waves 4,5 straight from Lp: diag_store_waves)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                sm.Tl[Jt][i - j0][c] = l0[c];
+                sm.Tl[Jt][i - j0][8 + c] = active1 ? l1[c] : 0.0;
+            }
+        }
+        if (Jt < 7) {
+            DIAG_TS(9);
+            __syncthreads();                                              // B3
+            DIAG_TS(10);
+            if (i >= j0 + 16) {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) p[c] = sm.Pn[i][c];
+            }
+        }
+    }
+}
+
+// waves 4,5: take part in the barriers and, after B2 of every tile column, copy the finished 16 columns of
+// L from the two panels in LDS to global memory, off the critical chain
+// workgroup barrier that waits for this wave's LDS traffic only: __syncthreads() also waits for its
+// outstanding GLOBAL stores (s_waitcnt vmcnt(0)), which would put the store waves' ~1500-cycle global
+// writes back on the row threads' critical chain
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <bool WT>
+__device__ __forceinline__ void diag_store_waves(double* __restrict__ A, int lda, int k0, DiagSmem& sm, int r) {
+    // coalesced: one instruction = 4 rows x 16 columns (128 B per row); thread r -> (row group, column).
+    // The two panels of a tile column are copied LDS -> registers between B2 and B3 (cheap, pipelined) and
+    // written to global memory under the NEXT column's first pivot chain (after its Bp), so that no other
+    // wave ever waits at a barrier for the stores to be issued.
+    const int col = r & 15, h = col >> 3, c = col & 7;
+    const int rbase = (r >> 6) * 64 + ((r >> 4) & 3);                   // wave 4: rows 0..63, wave 5: rows 64..127
+    double v[16];
+    auto store_column = [&](int j0) {
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int row = rbase + 4 * it;
+            if (row >= j0 && j0 + col <= row) gst<WT>(A + (size_t)(k0 + row) * lda + k0 + j0 + col, v[it]);
+        }
+    };
+#pragma unroll 1
+    for (int Jt = 0; Jt < 8; ++Jt) {
+        lds_barrier();                                                    // Bp
+        if (Jt > 0) store_column(16 * (Jt - 1));
+        lds_barrier();                                                    // B1
+        lds_barrier();                                                    // Bq
+        lds_barrier();                                                    // B2
+#pragma unroll
+        for (int it = 0; it < 16; ++it) v[it] = sm.Lp[h][rbase + 4 * it][c];
+        if (Jt < 7) lds_barrier();                                        // B3
+    }
+    store_column(16 * 7);
+}
+
+// rank-8 update of this wave's tiles in tile columns >= JMIN (or == JMIN if ONLY) with the panel Lp
+template <int JMIN, bool ONLY>
+__device__ __forceinline__ void diag_rank8(double4v (&acc)[2][8], const double (*Lp)[9], int lr, int lc, int I0, int I1) {
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        const int I = s2 ? I1 : I0;
+        if (I < JMIN) continue;
+        const double a0 = -Lp[16 * I + lc][lr], a1 = -Lp[16 * I + lc][4 + lr];
+#pragma unroll
+        for (int J = JMIN; J < (ONLY ? JMIN + 1 : 8); ++J) {
+            if (J > 7) continue;
             if (J <= I) {
-                const double b0 = LpPrev[16 * J + lc][lr], b1 = LpPrev[16 * J + lc][4 + lr];
-                acc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[J], 0, 0, 0);
-                acc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[J], 0, 0, 0);
+                const double b0 = Lp[16 * J + lc][lr], b1 = Lp[16 * J + lc][4 + lr];
+                acc[s2][J & 7] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[s2][J & 7], 0, 0, 0);
+                acc[s2][J & 7] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[s2][J & 7], 0, 0, 0);
             }
-    }
-    DIAG_TS(1);
-    // c. one thread per row at or below the block
-    if (ROWS && t >= j0) {
-        const int i = t;
-        double D[8][8], y[8], p[8], l[8];
-#pragma unroll
-        for (int r = 0; r < 8; ++r)
-#pragma unroll
-            for (int c = 0; c <= r; ++c) D[r][c] = P[j0 + r][c];
-#pragma unroll
-        for (int c = 0; c < 8; ++c) p[c] = P[i][c];
-        bool bad = false;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            double d = D[c][c];
-            if (!(d > 0.0)) { bad = bad || ((k0 + j0 + c) < n_real); d = 1.0; }
-            y[c] = fast_rsqrt(d);
-            D[c][c] = sqrt_from_rsqrt(d, y[c]);
-#pragma unroll
-            for (int r = c + 1; r < 8; ++r) D[r][c] *= y[c];
-#pragma unroll
-            for (int r = c + 1; r < 8; ++r)
-#pragma unroll
-                for (int q = c + 1; q <= r; ++q) D[r][q] = fma(-D[r][c], D[q][c], D[r][q]);
-        }
-        if (bad && i == j0) atomicCAS(flag, 0, k0 + j0 + 1);
-        if (i == j0) {
-#pragma unroll
-            for (int c = 0; c < 8; ++c) rd[j0 + c] = y[c];      // 1 / L[c][c], for the inverse tiles
-        }
-        // l G^T = p, right-looking.  Rows INSIDE the 8x8 block take the same path: row r of
-        // D = G G^T solves to row r of G in its first r+1 entries; the entries right of the
-        // diagonal come out as garbage, but they only ever meet (i) panel-column elements that
-        // step f overwrites and (ii) strictly-upper elements nobody reads.
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            l[c] = p[c] * y[c];
-#pragma unroll
-            for (int q = c + 1; q < 8; ++q) p[q] = fma(-l[c], D[q][c], p[q]);
-        }
-#pragma unroll
-        for (int c = 0; c < 8; ++c) LpCur[i][c] = l[c];
-    }
-    DIAG_TS(2);
-    __syncthreads();
-    DIAG_TS(3);
-    // e1(s): the tile column that holds the next panel
-    constexpr int E1 = Jt + H;
-    if (E1 < NT && I >= E1) {
-        const double a0 = -LpCur[16 * I + lc][lr], a1 = -LpCur[16 * I + lc][4 + lr];
-        const double b0 = LpCur[16 * E1 + lc][lr], b1 = LpCur[16 * E1 + lc][4 + lr];
-        constexpr int EP = (E1 < NT) ? E1 : NT - 1;
-        acc[EP] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[EP], 0, 0, 0);
-        acc[EP] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[EP], 0, 0, 0);
-    }
-    // f. finished columns of the panel -> accumulators (rows at or below the column)
-    constexpr int JP = (Jt < NT) ? Jt : NT - 1;     // clamp for the (dead) instantiations Jt >= NT
-    if (Jt < NT && (lc >> 3) == h && I >= Jt) {
-        const int col = 16 * Jt + lc;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = 16 * I + lr + 4 * r;
-            const double v = LpCur[row][lc & 7];
-            acc[JP][r] = (row >= col) ? v : acc[JP][r];
         }
     }
-    DIAG_TS(4);
-    // a(s+1): publish the next panel's 8 columns (lanes of the other half of tile column E1)
-    if (E1 < NT && E1 < 8 && (lc >> 3) == (1 - h) && I >= E1) {
-        constexpr int EP = (E1 < NT) ? E1 : NT - 1;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) P[16 * I + lr + 4 * r][lc & 7] = acc[EP][r];
-    }
-    __syncthreads();
-    DIAG_TS(5);
 }
 
-template <int NT, bool ROWS, bool WT>
-__device__ __forceinline__ void diag_wave_path(double* __restrict__ A, int lda, int k0, int n_real, int* __restrict__ flag,
-                                               double (*P)[9], double (*Lp0)[9], double (*Lp1)[9], double* rd,
-                                               double (*Tl)[16][17], int t, int lr, int lc, int I) {
-    double4v acc[NT];
+template <int Jt>
+__device__ __forceinline__ void diag_mfma_column(double4v (&acc)[2][8], DiagSmem& sm, int lr, int lc, int I0, int I1) {
+    DIAG_TS2(0);
+    __syncthreads();                                                      // Bp
+    DIAG_TS2(1);
+    if (Jt > 0) diag_rank8<Jt + 1, false>(acc, sm.Lp[1], lr, lc, I0, I1); // rest of the previous column's second panel
+    DIAG_TS2(2);
+    __syncthreads();                                                      // B1
+    __syncthreads();                                                      // Bq
+    DIAG_TS2(3);
+    diag_rank8<Jt + 1, false>(acc, sm.Lp[0], lr, lc, I0, I1);             // first panel, all trailing columns
+    DIAG_TS2(4);
+    __syncthreads();                                                      // B2
+    DIAG_TS2(5);
+    if (Jt < 7) {
+        diag_rank8<Jt + 1, true>(acc, sm.Lp[1], lr, lc, I0, I1);          // second panel on the next tile column only
 #pragma unroll
-    for (int J = 0; J < NT; ++J) {
-        const bool in = (J <= I);
-        const double* src = A + (size_t)(k0 + 16 * I + lr) * lda + k0 + 16 * (in ? J : 0) + lc;
-        double4v tmp;
-        tmp[0] = in ? mld<WT && MEGA_C_SC1>(src) : 0.0;
-        tmp[1] = in ? mld<WT && MEGA_C_SC1>(src + (size_t)4 * lda) : 0.0;
-        tmp[2] = in ? mld<WT && MEGA_C_SC1>(src + (size_t)8 * lda) : 0.0;
-        tmp[3] = in ? mld<WT && MEGA_C_SC1>(src + (size_t)12 * lda) : 0.0;
-        acc[J] = tmp;
-    }
-    // a(0): publish the first panel (left half of tile column 0)
-    if ((lc >> 3) == 0) {
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const int I = s2 ? I1 : I0;
+            if (I >= Jt + 1) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) P[16 * I + lr + 4 * r][lc & 7] = acc[0][r];
-    }
-    __syncthreads();
-#define DIAG_PAIR(JT)                                                                          \
-    diag_step<JT, 0, NT, ROWS>(acc, P, Lp0, Lp1, rd, t, lr, lc, I, k0, n_real, flag);          \
-    diag_step<JT, 1, NT, ROWS>(acc, P, Lp1, Lp0, rd, t, lr, lc, I, k0, n_real, flag);
-    DIAG_PAIR(0) DIAG_PAIR(1) DIAG_PAIR(2) DIAG_PAIR(3) DIAG_PAIR(4) DIAG_PAIR(5) DIAG_PAIR(6) DIAG_PAIR(7)
-#undef DIAG_PAIR
-#pragma unroll
-    for (int J = 0; J < NT; ++J)
-        if (J <= I) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = 16 * I + lr + 4 * r, col = 16 * J + lc;
-                if (col <= row) gst<WT>(&A[(size_t)(k0 + row) * lda + k0 + col], acc[J][r]);
-            }
-            if (J == I) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) Tl[J][lr + 4 * r][lc] = acc[J][r];
+                for (int r = 0; r < 4; ++r) sm.Pn[16 * I + lr + 4 * r][lc] = acc[s2][(Jt + 1) & 7][r];
             }
         }
+        DIAG_TS2(6);
+        __syncthreads();                                                  // B3
+        DIAG_TS2(7);
+    }
 }
 
-// all 512 threads of the workgroup; sm = DIAG_SMEM_DOUBLES doubles of LDS; ends with the results in
+template <bool WT>
+__device__ __forceinline__ void diag_mfma_waves(const double* __restrict__ A, int lda, int k0, DiagSmem& sm, int lane, int w) {
+    const int lr = lane >> 4, lc = lane & 15;
+    // tile rows of this wave (-1: none): SIMD 2 = waves 2, 6; SIMD 3 = waves 3, 7
+    const int I0 = (w == 2) ? 1 : (w == 3) ? 2 : (w == 6) ? 4 : (w == 7) ? 3 : -1;
+    const int I1 = (w == 2) ? 7 : (w == 3) ? 6 : (w == 7) ? 5 : -1;
+    double4v acc[2][8];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        const int I = s2 ? I1 : I0;
+#pragma unroll
+        for (int J = 1; J < 8; ++J) {
+            const bool in = (I >= 1 && J <= I);
+            const double* src = A + (size_t)(k0 + 16 * (in ? I : 0) + lr) * lda + k0 + 16 * (in ? J : 0) + lc;
+            double4v tmp;
+            tmp[0] = in ? mld<WT && MEGA_C_SC1>(src) : 0.0;
+            tmp[1] = in ? mld<WT && MEGA_C_SC1>(src + (size_t)4 * lda) : 0.0;
+            tmp[2] = in ? mld<WT && MEGA_C_SC1>(src + (size_t)8 * lda) : 0.0;
+            tmp[3] = in ? mld<WT && MEGA_C_SC1>(src + (size_t)12 * lda) : 0.0;
+            acc[s2][J] = tmp;
+        }
+        acc[s2][0] = double4v{0.0, 0.0, 0.0, 0.0};
+    }
+    diag_mfma_column<0>(acc, sm, lr, lc, I0, I1);
+    diag_mfma_column<1>(acc, sm, lr, lc, I0, I1);
+    diag_mfma_column<2>(acc, sm, lr, lc, I0, I1);
+    diag_mfma_column<3>(acc, sm, lr, lc, I0, I1);
+    diag_mfma_column<4>(acc, sm, lr, lc, I0, I1);
+    diag_mfma_column<5>(acc, sm, lr, lc, I0, I1);
+    diag_mfma_column<6>(acc, sm, lr, lc, I0, I1);
+    diag_mfma_column<7>(acc, sm, lr, lc, I0, I1);
+}
+
+// all 512 threads of the workgroup; smem = DIAG_SMEM_DOUBLES doubles of LDS; ends with the results in
 // global memory (no trailing barrier)
 template <bool WT>
 __device__ __forceinline__ void diag_block(double* __restrict__ A, int lda, int k0, int n_real,
-                                           int* __restrict__ flag, double* __restrict__ dinv, double* sm, int t) {
-    double (*P)[9] = reinterpret_cast<double (*)[9]>(sm);
-    double (*Lp0)[9] = reinterpret_cast<double (*)[9]>(sm + NB * 9);
-    double (*Lp1)[9] = reinterpret_cast<double (*)[9]>(sm + 2 * NB * 9);
-    double* rd = sm + 3 * NB * 9;
-    double (*Tl)[16][17] = reinterpret_cast<double (*)[16][17]>(sm + 3 * NB * 9 + NB);
-    const int lane = t & 63;
+                                           int* __restrict__ flag, double* __restrict__ dinv, double* smem, int t,
+                                           long long* ph = nullptr) {
+    DiagSmem& sm = *reinterpret_cast<DiagSmem*>(smem);
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int lr = lane >> 4, lc = lane & 15;
-    // tile row of wave w.  Waves w and w + 4 share a SIMD, and FP64 VALU work (step c, waves 0 and 1)
-    // does not overlap FP64 MFMA work on the same SIMD (measured: c slowed from 2200 to 2900 cycles), so
-    // the partners of the row-thread waves get the two shortest remaining tile rows (2, 3) and SIMDs 2, 3
-    // carry rows {4, 7} and {5, 6}
-    const int I = (w < 2) ? w : (w < 4) ? w + 2 : (w < 6) ? w - 2 : 13 - w;
-    if (w < 2) diag_wave_path<2, true, WT>(A, lda, k0, n_real, flag, P, Lp0, Lp1, rd, Tl, t, lr, lc, I);
-    else diag_wave_path<8, false, WT>(A, lda, k0, n_real, flag, P, Lp0, Lp1, rd, Tl, t, lr, lc, I);
+    if (w < 2) diag_row_threads<WT>(A, lda, k0, n_real, flag, sm, t, ph);
+    else if (w == 4 || w == 5) diag_store_waves<WT>(A, lda, k0, sm, t - 256);
+    else diag_mfma_waves<WT>(A, lda, k0, sm, t & 63, w);
+    PHASE_STAMP(1);
     __syncthreads();
     // thread (b, m) forward-substitutes column m of tile b's inverse
     if (t < NB) {
@@ -331,8 +450,8 @@ __device__ __forceinline__ void diag_block(double* __restrict__ A, int lda, int 
         for (int k = 0; k < 16; ++k) {
             double sum = (k == m) ? 1.0 : 0.0;
 #pragma unroll
-            for (int q = 0; q < k; ++q) sum = fma(-Tl[b][k][q], x[q], sum);
-            x[k] = (k >= m) ? sum * rd[16 * b + k] : 0.0;
+            for (int q = 0; q < k; ++q) sum = fma(-sm.Tl[b][k][q], x[q], sum);
+            x[k] = (k >= m) ? sum * sm.rd[16 * b + k] : 0.0;
             gst<WT>(&dinv[(b * 16 + k) * 16 + m], x[k]);
         }
     }
@@ -711,7 +830,6 @@ __device__ __forceinline__ bool mega_wait(const int* p, int target, int* abortf)
     }
 }
 
-#define PHASE_STAMP(k) do { if (ph && t == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); ph[k] = wall_clock64(); } } while (0)
 // X = W * L11^-T for the 16 rows of this wave (see trsm_group), all 8 waves of the workgroup together:
 // L11's 28 sub-diagonal tiles and the 8 inverse diagonal tiles are staged once into LDS (72 KB) in
 // A-operand order.  W holds X on return.  Starts and ends without a barrier on smem.
@@ -969,7 +1087,7 @@ __global__ __launch_bounds__(512) void chol_mega_kernel(MegaArgs a) {
         double* li = a.linv + (size_t)b * a.linv_stride;
         long long* ph = a.trace ? a.trace + 8 * (size_t)task + 4 : nullptr;
         if (type == TASK_D) {
-            diag_block<true>(a.A, a.lda, k0, a.n, a.flag, li + NB * NB, smem, tt);
+            diag_block<true>(a.A, a.lda, k0, a.n, a.flag, li + NB * NB, smem, tt, ph);
         } else if (type == TASK_T) {
             const int lane = tt & 63, w = tt >> 6;
             double* rowp = a.A + (size_t)(ti * NB + 16 * w + (lane & 15)) * a.lda + k0;
@@ -1050,7 +1168,7 @@ static void mega_build_tasks(int nblk, int nq, int wg_per_q, std::vector<int4>& 
         idUq((size_t)NBK * NBK * 4, -1), idU((size_t)NBK * NBK * NBK, -1);
     // measured on MI355X (tools/mega_trace.py), microseconds, plus ~2 us of flag latency per hop
     // (STBA_MEGA_DUR=d,t,ti,u,uq,tu overrides them for experiments)
-    double DUR[6] = {33.0, 23.0, 19.0, 25.0, 16.5, 20.0};
+    double DUR[6] = {29.0, 23.0, 19.0, 25.0, 16.5, 20.0};
     if (const char* e = getenv("STBA_MEGA_DUR")) sscanf(e, "%lf,%lf,%lf,%lf,%lf,%lf", &DUR[0], &DUR[1], &DUR[2], &DUR[3], &DUR[4], &DUR[5]);
     // LEAD: the TU tickets are placed as if D(b) ended LEAD us early, so that their workgroups are already
     // inside the task (rows requested, spinning on the flag) when it really ends

@@ -1,5 +1,5 @@
 // Phase timing of chol_diag_kernel (and the panel solve) on one 128x128 block.
-// build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -munsafe-fp-atomics -DSTBA_DIAG_TS -Islam-tricks_amd/csrc tools/exp/diag_timing.hip -o /tmp/diag_timing
+// build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -munsafe-fp-atomics -Islam-tricks_amd/csrc tools/exp/diag_timing.hip -o /tmp/diag_timing
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cmath>
@@ -32,16 +32,21 @@ int main() {
         printf("trsm kernel (64 groups) %.2f us\n", ms * 1e3);
         (void)w0; (void)w1;
     }
-    long long ts[8][16][6];
+    long long ts[8][12];
     hipMemcpyFromSymbol(ts, HIP_SYMBOL(stba::g_diag_ts), sizeof ts);
-    printf("total cycles wave0: %lld\n", ts[0][15][5] - ts[0][0][0]);
-    for (int w = 0; w < 8; w += 1) {
-        printf("wave %d\n step:  e2prev   c      bar    e1+f    a+bar | total\n", w);
-        for (int s = 0; s < 16; ++s) {
-            printf("  %2d: ", s);
-            for (int k = 0; k < 5; ++k) printf("%6lld ", ts[w][s][k + 1] - ts[w][s][k]);
-            printf("| %6lld\n", ts[w][s][5] - ts[w][s][0]);
-        }
+    printf("row thread 127, cycles per tile column:\n Jt  publish  Bp    c0     B1   local    Bq    c1     B2   store    B3   | total\n");
+    for (int J = 0; J < 8; ++J) {
+        printf(" %d ", J);
+        for (int k = 0; k < 10; ++k) printf("%6lld ", ts[J][k + 1] - ts[J][k]);
+        printf("| %6lld\n", ts[J][10] - ts[J][0]);
+    }
+    long long t2[8][8];
+    hipMemcpyFromSymbol(t2, HIP_SYMBOL(stba::g_diag_ts2), sizeof t2);
+    printf("matrix-core wave 2 (tile rows 1,7):\n Jt    Bp  e(prev,1)rest  B1+Bq   e(Jt,0)    B2   e1+publish   B3\n");
+    for (int J = 0; J < 7; ++J) {
+        printf(" %d ", J);
+        for (int k = 0; k < 7; ++k) printf("%7lld ", t2[J][k + 1] - t2[J][k]);
+        printf("\n");
     }
     return 0;
 }
