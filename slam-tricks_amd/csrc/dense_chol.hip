@@ -99,8 +99,14 @@ template <bool WT> __device__ __forceinline__ void gst(double* p, double v) {
     else *p = v;
 }
 template <bool WT> __device__ __forceinline__ void gst4(double* p, double4v v) {
-    if constexpr (WT && MEGA_WT) { gst<true>(p, v[0]); gst<true>(p + 1, v[1]); gst<true>(p + 2, v[2]); gst<true>(p + 3, v[3]); }
-    else *reinterpret_cast<double4v*>(p) = v;
+    if constexpr (WT && MEGA_WT) {
+        // two 16-byte write-through stores (the compiler only emits sc1 on <= 8-byte atomic stores; the
+        // caller's s_waitcnt vmcnt(0) before raising the flag covers these)
+        typedef double double2v __attribute__((ext_vector_type(2)));
+        const double2v lo = {v[0], v[1]}, hi = {v[2], v[3]};
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc1"
+                     :: "v"(p), "v"(lo), "v"(hi) : "memory");
+    } else *reinterpret_cast<double4v*>(p) = v;
 }
 __device__ __forceinline__ double4v gld4(const double* p) { return *reinterpret_cast<const double4v*>(p); }
 // loads inside the persistent kernel: F = final data (blocks of L written by other XCDs), C = tiles
