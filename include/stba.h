@@ -188,6 +188,19 @@ int stba_cholesky_time_split(int n, int reps, double* ms_factor, double* ms_back
 int stba_cholesky_profile(int n, double* ms4, double* syrk_flops, double* syrk_flops_padded,
                           int* syrk_launches, void* hip_stream);
 
+/* ================================ calibration data formats ================== */
+/* Chessboard corner files, st3-calibration/src/src/cbcorner.cpp:34-73: header "rows,cols", then one
+ * "i,j,x,y" line per corner (x, y parsed through float like the reference's std::stof; written with
+ * 3 decimals).  xy: rows*cols*2 doubles, row-major by (i, j); pass xy = NULL to query the size. */
+int stba_corners_read(const char* path, int* rows, int* cols, double* xy, int capacity);
+int stba_corners_write(const char* path, int rows, int cols, const double* xy);
+/* Zhang's closed-form start point of the refinement (st3-calibration/src/src/calib.cpp:55-173):
+ * DLT homographies -> intrinsics (zero skew) -> per-view extrinsics.  obj / img: [V*C*2] board points
+ * (X, Y) / pixels; params out: [alpha beta u0 v0 0 0 0 0 0 | xi_0(6) ..] in stba_calib_* layout;
+ * homographies out (may be NULL): V*9 row-major, unit Frobenius norm, sign as the null vector came out. */
+int stba_zhang_init(int n_views, int n_corners, const double* obj, const double* img, double* params,
+                    double* homographies);
+
 /* ================================ Zhang calibration (st3-calibration) ==================== */
 /* CalibSolver::totalOptimization's residual / Jacobian blocks (st3-calibration/src/src/calib.cpp:311-391,
  * distortNormPt :254-262, normPt2ImgPt :247-252) evaluated by a HIP kernel, one corner per lane.

@@ -68,7 +68,7 @@ EXPORTS = ["stba_status_string", "stba_last_error", "stba_version", "stba_device
            "stba_ba_triangulate", "stba_ba_time_linearize", "stba_cholesky_factor", "stba_cholesky_solve",
            "stba_cholesky_time", "stba_cholesky_time_split", "stba_cholesky_profile", "stba_calib_evaluate", "stba_calib_gauss_newton",
            "stba_pcg_default_options", "stba_pg_create", "stba_pg_destroy", "stba_pg_get_poses", "stba_pg_evaluate",
-           "stba_pg_solve", "stba_dense_solve"]
+           "stba_pg_solve", "stba_dense_solve", "stba_corners_read", "stba_corners_write", "stba_zhang_init"]
 
 
 def lib():
@@ -323,6 +323,29 @@ def cholesky_profile(n, stream=None):
          "stba_cholesky_profile")
     return dict(ms_diag=ms[0], ms_trsm=ms[1], ms_syrk=ms[2], ms_bwd=ms[3], syrk_flops=fl.value,
                 syrk_flops_padded=flp.value, syrk_launches=nl.value)
+
+
+def corners_read(path):
+    """chessboard corner file -> (rows, cols, xy[rows, cols, 2])  (cbcorner.cpp:50-73)"""
+    r = C.c_int(); c = C.c_int()
+    _chk(lib().stba_corners_read(path.encode(), C.byref(r), C.byref(c), None, 0), "stba_corners_read")
+    xy = np.zeros((r.value, c.value, 2))
+    _chk(lib().stba_corners_read(path.encode(), C.byref(r), C.byref(c), _p(xy), r.value * c.value), "stba_corners_read")
+    return r.value, c.value, xy
+
+
+def corners_write(path, xy):
+    xy = _f64(xy)
+    _chk(lib().stba_corners_write(path.encode(), xy.shape[0], xy.shape[1], _p(xy)), "stba_corners_write")
+
+
+def zhang_init(obj, img):
+    """closed-form calibration start (calib.cpp:55-173): obj, img (V, C, 2) -> (params[9 + 6V], H[V, 3, 3])"""
+    obj, img = _f64(obj), _f64(img)
+    V, Cn = obj.shape[0], obj.shape[1]
+    params = np.zeros(9 + 6 * V); H = np.zeros((V, 3, 3))
+    _chk(lib().stba_zhang_init(V, Cn, _p(obj), _p(img), _p(params), _p(H)), "stba_zhang_init")
+    return params, H
 
 
 def calib_evaluate(params, obj, img, jac=True):

@@ -9,7 +9,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["dense_chol.hip", "ba_kernels.hip", "stba_engine.hip", "pg_engine.hip"]
+SOURCES = ["dense_chol.hip", "ba_kernels.hip", "stba_engine.hip", "pg_engine.hip", "calib_io.cpp"]
 HEADERS = ["common.hpp", "ba_kernels.hpp", os.path.join("..", "..", "include", "stba.h")]
 LIB = os.path.join(HERE, "libstba.so")
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-munsafe-fp-atomics", "-Wall",
@@ -31,7 +31,7 @@ def build(force=False, verbose=False):
     objs = []
     procs = []
     for s in SOURCES:
-        o = os.path.join(CSRC, s.replace(".hip", ".o"))
+        o = os.path.join(CSRC, s.replace(".hip", ".o").replace(".cpp", ".o"))
         cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, s), "-o", o]
         if verbose:
             print(" ".join(cmd))

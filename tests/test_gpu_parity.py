@@ -326,6 +326,30 @@ def test_calibration_real_fixture(st, O, known):
 
 
 @pytest.mark.gpu
+def test_calibration_pipeline_from_corner_files(st, known):
+    """C3 end to end through the product only: corner files (stba_corners_read) -> Zhang's closed form
+    (stba_zhang_init) -> Gauss-Newton on the device (stba_calib_gauss_newton) -> the recorded answers"""
+    import os
+    from conftest import GOLDEN
+    ka = known["st3_calibration"]
+    d = os.path.join(GOLDEN, "st3_calib")
+    img = []
+    for f in sorted(x for x in os.listdir(d) if x.endswith(".txt")):
+        rows, cols, xy = st.corners_read(os.path.join(d, f))
+        img.append(xy.reshape(-1, 2))
+    img = np.array(img)
+    jj, ii = np.meshgrid(np.arange(cols), np.arange(rows))
+    board = np.stack([jj.reshape(-1), ii.reshape(-1)], 1) * ka["board_square_m"]       # calib.cpp:28
+    obj = np.repeat(board[None], len(img), 0)
+    p0, _ = st.zhang_init(obj, img)
+    p, it, tr = st.calib_gauss_newton(p0, obj, img, 10)
+    done = tr[~np.isnan(tr)]
+    assert abs(done[0] - ka["sse_first"]) < 5e-4 and abs(done[-1] - ka["sse_last"]) < 5e-4
+    assert np.allclose(p[:4], ka["final_intr_dist"][:4], rtol=0, atol=6e-4)
+    assert abs(it - ka["gn_iterations"]) <= 1
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n", [1000, 1500, 3000])
 def test_cholesky_persistent_kernel_is_deterministic(st, n):
     """The persistent (dataflow) factorisation fixes the order of every floating-point operation, so
