@@ -52,7 +52,8 @@ enum {
     STBA_ERR_NOT_POSITIVE_DEFINITE = -4,
     STBA_ERR_ALLOC = -5,
     STBA_ERR_STATE = -6,
-    STBA_ERR_CALLBACK = -7
+    STBA_ERR_CALLBACK = -7,
+    STBA_ERR_NO_SOLUTION = -8      /* a closed-form initialiser found no (unique) solution */
 };
 
 const char* stba_status_string(int status);
@@ -187,6 +188,20 @@ int stba_cholesky_time_split(int n, int reps, double* ms_factor, double* ms_back
  * updates and their launch count (bench.py MFMA roofline leg). */
 int stba_cholesky_profile(int n, double* ms4, double* syrk_flops, double* syrk_flops_padded,
                           int* syrk_launches, void* hip_stream);
+
+/* ================================ two-view initialiser ====================== */
+/* st22-two-view/src/src/two_view_geometry.cpp:18-126 (FindFunctionalMatrix): fundamental matrix from n >= 8
+ * pixel correspondences (x1^T F x2 = 0, no normalisation), essential matrix with K, the four (R, t)
+ * hypotheses, the cheirality test over ALL points, DLT triangulation.  f1, f2: n*2 pixels; K: 3x3
+ * row-major.  Out: F (9, row-major, unit norm, sign free; may be NULL), R (9) and t (3, unit norm): the
+ * pose of frame 2 in frame 1 (p1 = R p2 + t), pts (n*3 landmarks in frame 1, for the UNIT baseline; may be
+ * NULL), fails (4 counters of points failing the test per hypothesis; their order follows :61-64 but depends
+ * on the sign conventions of the 3x3 SVD; may be NULL).
+ * Returns STBA_ERR_NO_SOLUTION if not exactly one hypothesis passes (the reference returns an empty
+ * optional).  Device: the n x 9 system is reduced to its triangular factor with Givens rotations, the
+ * cheirality test and the triangulation run one correspondence per lane. */
+int stba_two_view_init(int n, const double* f1, const double* f2, const double* K, double* F_out, double* R_out,
+                       double* t_out, double* pts_out, int* fails_out, void* hip_stream);
 
 /* ================================ calibration data formats ================== */
 /* Chessboard corner files, st3-calibration/src/src/cbcorner.cpp:34-73: header "rows,cols", then one

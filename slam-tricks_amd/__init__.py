@@ -68,7 +68,7 @@ EXPORTS = ["stba_status_string", "stba_last_error", "stba_version", "stba_device
            "stba_ba_triangulate", "stba_ba_time_linearize", "stba_cholesky_factor", "stba_cholesky_solve",
            "stba_cholesky_time", "stba_cholesky_time_split", "stba_cholesky_profile", "stba_calib_evaluate", "stba_calib_gauss_newton",
            "stba_pcg_default_options", "stba_pg_create", "stba_pg_destroy", "stba_pg_get_poses", "stba_pg_evaluate",
-           "stba_pg_solve", "stba_dense_solve", "stba_corners_read", "stba_corners_write", "stba_zhang_init"]
+           "stba_pg_solve", "stba_dense_solve", "stba_corners_read", "stba_corners_write", "stba_zhang_init", "stba_two_view_init"]
 
 
 def lib():
@@ -323,6 +323,19 @@ def cholesky_profile(n, stream=None):
          "stba_cholesky_profile")
     return dict(ms_diag=ms[0], ms_trsm=ms[1], ms_syrk=ms[2], ms_bwd=ms[3], syrk_flops=fl.value,
                 syrk_flops_padded=flp.value, syrk_launches=nl.value)
+
+
+def two_view_init(f1, f2, K, points=True, stream=None):
+    """two_view_geometry.cpp:18-126 on the device: pixel pairs (n, 2) x 2 and K -> dict(F, R, t, pts, fails);
+    (R, t) = pose of frame 2 in frame 1, |t| = 1.  Raises StbaError (no solution) like the reference's empty optional."""
+    f1, f2, K = _f64(f1), _f64(f2), _f64(K)
+    n = f1.shape[0]
+    F = np.zeros((3, 3)); R = np.zeros((3, 3)); t = np.zeros(3)
+    pts = np.zeros((n, 3)) if points else None
+    fails = np.zeros(4, dtype=np.int32)
+    _chk(lib().stba_two_view_init(n, _p(f1), _p(f2), _p(K), _p(F), _p(R), _p(t), _p(pts) if points else None,
+                                  fails.ctypes.data_as(C.POINTER(C.c_int)), C.c_void_p(stream or 0)), "stba_two_view_init")
+    return dict(F=F, R=R, t=t, pts=pts, fails=fails)
 
 
 def corners_read(path):

@@ -17,51 +17,10 @@
 #include <vector>
 
 #include "common.hpp"
+#include "small_linalg.hpp"
 
 namespace stba {
 namespace {
-
-// right singular vector of the smallest singular value of A (m x n, row-major, m >= n), one-sided
-// (Hestenes) Jacobi: rotate column pairs until all are mutually orthogonal; V accumulates the rotations
-void smallest_right_singular_vector(std::vector<double> A, int m, int n, double* v_out) {
-    std::vector<double> V((size_t)n * n, 0.0);
-    for (int i = 0; i < n; ++i) V[(size_t)i * n + i] = 1.0;
-    for (int sweep = 0; sweep < 60; ++sweep) {
-        double off = 0.0;
-        for (int p = 0; p < n - 1; ++p)
-            for (int q = p + 1; q < n; ++q) {
-                double app = 0, aqq = 0, apq = 0;
-                for (int r = 0; r < m; ++r) {
-                    const double x = A[(size_t)r * n + p], y = A[(size_t)r * n + q];
-                    app += x * x; aqq += y * y; apq += x * y;
-                }
-                if (apq == 0.0) continue;
-                off = std::max(off, std::fabs(apq) / std::sqrt(std::max(app * aqq, 1e-300)));
-                const double zeta = (aqq - app) / (2.0 * apq);
-                const double t = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
-                const double c = 1.0 / std::sqrt(1.0 + t * t), s = c * t;
-                for (int r = 0; r < m; ++r) {
-                    const double x = A[(size_t)r * n + p], y = A[(size_t)r * n + q];
-                    A[(size_t)r * n + p] = c * x - s * y;
-                    A[(size_t)r * n + q] = s * x + c * y;
-                }
-                for (int r = 0; r < n; ++r) {
-                    const double x = V[(size_t)r * n + p], y = V[(size_t)r * n + q];
-                    V[(size_t)r * n + p] = c * x - s * y;
-                    V[(size_t)r * n + q] = s * x + c * y;
-                }
-            }
-        if (off < 1e-15) break;
-    }
-    int best = 0;
-    double bn = 1e300;
-    for (int j = 0; j < n; ++j) {
-        double nn = 0;
-        for (int r = 0; r < m; ++r) nn += A[(size_t)r * n + j] * A[(size_t)r * n + j];
-        if (nn < bn) { bn = nn; best = j; }
-    }
-    for (int r = 0; r < n; ++r) v_out[r] = V[(size_t)r * n + best];
-}
 
 void mat3_mul_vec(const double* M, const double* v, double* o) {
     for (int i = 0; i < 3; ++i) o[i] = M[i * 3] * v[0] + M[i * 3 + 1] * v[1] + M[i * 3 + 2] * v[2];

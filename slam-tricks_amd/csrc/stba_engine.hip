@@ -450,6 +450,7 @@ const char* stba_status_string(int status) {
         case STBA_ERR_ALLOC: return "device allocation failed";
         case STBA_ERR_STATE: return "call order / state error";
         case STBA_ERR_CALLBACK: return "callback failed";
+        case STBA_ERR_NO_SOLUTION: return "no (unique) solution";
         default: return "unknown";
     }
 }

@@ -253,6 +253,27 @@ def two_view_scene(n_pts=5000, seed=22, pos_noise=0.3, ang_noise_deg=3.0, pix_no
                 obs_feat=obs_feat, cam_fixed=cam_fixed)
 
 
+def two_view_pairs(n_pts=5000, seed=22, pix_noise=0.0):
+    """pixel correspondences of the st22 simulation (two_view_simu.cpp:27-56; same geometry as
+    two_view_scene): returns dict(f1, f2 (n, 2) pixels, K, R_true, t_true = pose of frame 2 in frame 1,
+    pts_f1 = landmarks in frame 1)"""
+    s = two_view_scene(n_pts=n_pts, seed=seed, pix_noise=0.0)
+    K = np.array([[400.0, 0, 300.0], [0, 400.0, 200.0], [0, 0, 1.0]])
+    R = rot_from_quat(s["cams_true"][:, :4])
+    pos = s["cams_true"][:, 4:]
+    pw = s["pts_true"]
+    out = {}
+    for c in range(2):
+        pc = (pw - pos[c]) @ R[c]
+        out[c] = np.stack([K[0, 0] * pc[:, 0] / pc[:, 2] + K[0, 2], K[1, 1] * pc[:, 1] / pc[:, 2] + K[1, 2]], 1)
+    rng = np.random.default_rng(seed + 1000)
+    if pix_noise > 0:
+        out[0] = out[0] + rng.normal(0.0, pix_noise, out[0].shape)
+        out[1] = out[1] + rng.normal(0.0, pix_noise, out[1].shape)
+    return dict(f1=out[0], f2=out[1], K=K, R_true=R[0].T @ R[1], t_true=R[0].T @ (pos[1] - pos[0]),
+                pts_f1=(pw - pos[0]) @ R[0])
+
+
 # --------------------------------------------------------------------------- st17 PnP scene
 def _ypr_pose(yaw, pitch, roll):
     """CameraPose(), st17 main.cpp:14-35; DegreeToRadian is float (scene.h:36-39)."""
