@@ -364,3 +364,54 @@ def test_cholesky_persistent_kernel_is_deterministic(st, n):
     assert np.abs(L0 - Lref).max() <= 1e-12 * np.abs(Lref).max()
     for _ in range(7):
         assert np.array_equal(st.cholesky_factor(A), L0)
+
+
+# ------------------------------------------------------------------------------- full size and edge cases
+def test_c5_full_size_matches_oracle(st, O, scenes):
+    """BASELINE config C5 at FULL size (1 000 cameras, 100 000 landmarks, 1 000 000 observations, the
+    bench.py workload): three LM iterations of the device path against the oracle -- cost trace to 1e-6
+    relative (north_star tolerance on residuals), camera poses to 1e-5."""
+    s = scenes.st20_scene(n_cams=1000, n_pts=100000, max_obs_per_pt=10, seed=20, pix_noise=1e-3)
+    e, o = engine(st, s), oracle(O, s)
+    summ, tr = e.lm_iterations(3)
+    so, tro = o.solve(fixed_iterations=3, num_threads=16)
+    assert tr.shape == tro.shape
+    assert np.allclose(tr[:, 0], tro[:, 0], rtol=1e-6)            # cost after every iteration
+    assert np.array_equal(tr[:, 6], tro[:, 6])                    # same accept / reject decisions
+    cams, pts = e.get_params()
+    dq, dt = pose_err(cams, o.cams)
+    assert dq < 1e-5 and dt < 1e-5
+    assert np.abs(pts - o.pts).max() < 1e-5 * max(1.0, np.abs(o.pts).max())
+
+
+def test_edge_cases(st, O):
+    """shapes the reference's data model allows (sim_data.h:38-63): everything constant, a camera nobody
+    observes through, landmarks seen once, the smallest problem"""
+    rng = np.random.default_rng(2)
+    cams = np.zeros((3, 7)); cams[:, 3] = 1.0; cams[:, 4] = [0.0, 1.0, 2.0]
+    pts = rng.uniform([-1, -1, 4], [1, 1, 6], (6, 3))
+    oc = np.array([0, 1, 0, 1, 0, 1, 0, 1], np.int32)             # camera 2 observes nothing; points 4, 5 unobserved
+    op = np.array([0, 0, 1, 1, 2, 2, 3, 3], np.int32)
+    feat = np.array([(pts[j] - cams[c, 4:])[:2] / (pts[j] - cams[c, 4:])[2] for c, j in zip(oc, op)])
+    # (1) every camera constant: only the observed landmarks move, and they are already at the optimum
+    e = st.BAEngine(cams, pts + 0.01, oc, op, feat, cam_fixed=np.ones((3, 6), np.uint8))
+    summ, _ = e.solve()
+    c2, p2 = e.get_params()
+    assert summ.termination_type == 0 and summ.final_cost < 1e-15
+    assert np.array_equal(c2, cams) and np.allclose(p2[:4], pts[:4], atol=1e-6)
+    assert np.array_equal(p2[4:], pts[4:] + 0.01)                 # unobserved landmarks are left alone
+    # (2) everything constant: nothing to do, nothing changes, no failure
+    e = st.BAEngine(cams, pts, oc, op, feat, cam_fixed=np.ones((3, 6), np.uint8), pt_fixed=np.ones(6, np.uint8))
+    summ, _ = e.solve()
+    c2, p2 = e.get_params()
+    assert summ.termination_type == 0 and np.array_equal(c2, cams) and np.array_equal(p2, pts)
+    # (3) one camera, one landmark, one observation (under-determined: the damping keeps it solvable)
+    e = st.BAEngine(cams[:1], pts[:1], oc[:1] * 0, op[:1] * 0, feat[:1] + 0.01, cam_fixed=np.ones((1, 6), np.uint8))
+    summ, _ = e.solve()
+    assert np.isfinite(summ.final_cost) and summ.final_cost < summ.initial_cost
+    # (4) same inputs through the oracle give the same iteration count and cost (case 1)
+    o = O.BA(cams, pts + 0.01, oc, op, feat, np.ones((3, 6), np.uint8))
+    so, _ = o.solve()
+    e = st.BAEngine(cams, pts + 0.01, oc, op, feat, cam_fixed=np.ones((3, 6), np.uint8))
+    summ, _ = e.solve()
+    assert summ.num_iterations == so.num_iterations and abs(summ.final_cost - so.final_cost) < 1e-15
