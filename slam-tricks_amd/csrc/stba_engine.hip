@@ -93,7 +93,8 @@ struct stba_ba {
     int rank = 0, world = 1;
     bool have_lin = false, have_blocks = false, have_reduced = false, have_dxc = false, have_dxp = false;
     bool scale_init = false;
-    hipEvent_t ev[8] = {};
+    hipEvent_t ev[12] = {};
+    double* lin_pin = nullptr;      // pinned host copy of [scalars (SC_GPMAX0 + world) | gc (n)], read one solve later
 
     double* S() const { return Sbuf; }
     double* ex_diag() const { return Sbuf + (size_t)lda * lda; }
@@ -118,6 +119,7 @@ static void ba_free(stba_ba* b) {
     F(b->task_cam); F(b->task_begin); F(b->task_end); F(b->row_col_ptr); F(b->row_cols); F(b->task_single);
     F(b->cost_partial); F(b->upd_partial_c); F(b->upd_partial_p); F(b->trial); F(b->flag);
     for (auto& e : b->ev) if (e) (void)hipEventDestroy(e);
+    if (b->lin_pin) (void)hipHostFree(b->lin_pin);
     if (b->own_stream && b->st) (void)hipStreamDestroy(b->st);
     delete b;
 }
@@ -276,6 +278,25 @@ static int ba_read_linear_scalars(stba_ba* b, double* cost, double* gmax) {
     return STBA_OK;
 }
 
+// The same read, split: the copies are enqueued behind the reduced-system build into pinned memory and
+// consumed after the NEXT synchronisation (the trial point's), so that the factorisation is enqueued without
+// a host round trip in between (a 115 us bubble per iteration at C5)
+static int ba_request_linear_scalars(stba_ba* b) {
+    const size_t nh = (size_t)SC_GPMAX0 + b->world;
+    if (!b->lin_pin) STBA_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->lin_pin), (nh + (size_t)b->n) * sizeof(double)));
+    STBA_TRY(download(b->lin_pin, b->ex_scalar(), nh, b->st));
+    STBA_TRY(download(b->lin_pin + nh, b->ex_gc(), (size_t)b->n, b->st));
+    return STBA_OK;
+}
+static void ba_finish_linear_scalars(const stba_ba* b, double* cost, double* gmax) {   // after a stream synchronisation
+    const size_t nh = (size_t)SC_GPMAX0 + b->world;
+    *cost = 0.5 * b->lin_pin[SC_COST2];
+    double m = 0.0;
+    for (int k = 0; k < b->world; ++k) m = std::max(m, b->lin_pin[SC_GPMAX0 + k]);
+    for (int k = 0; k < b->n; ++k) m = std::max(m, std::fabs(b->lin_pin[nh + k]));
+    *gmax = m;
+}
+
 static int ba_run_lm(stba_ba* b, const stba_lm_options* opt_in, int fixed_iterations, stba_lm_summary* sum,
                      double* trace, stba_iteration_callback cb, void* cb_user) {
     stba_lm_options opt;
@@ -303,6 +324,11 @@ static int ba_run_lm(stba_ba* b, const stba_lm_options* opt_in, int fixed_iterat
     STBA_TRY(ba_fill_scalar_slots(b, b->trial + TS_COST2));
     bool need_build = true;      // reduced system must be (re)built before the next solve
     bool lin_timing_pending = true;
+
+    // deferred read of (cost, |g|max) of a freshly linearised point: only when nobody watches the iterations
+    const bool deferred_ok = (cb == nullptr) && !opt.minimizer_progress_to_stdout;
+    bool pending = false, pending_accepted = false;
+    int pending_iter = 0;
 
     int iter = 0;
     s.termination_type = STBA_NO_CONVERGENCE;
@@ -358,6 +384,22 @@ static int ba_run_lm(stba_ba* b, const stba_lm_options* opt_in, int fixed_iterat
         STBA_TRY(download(&flag_h, b->flag, 1, b->st));
         STBA_TRY(chol_flag_status(flag_h));
         STBA_HIP(hipStreamSynchronize(b->st));
+        if (pending) {
+            double c2, g2;
+            ba_finish_linear_scalars(b, &c2, &g2);
+            (void)hipEventElapsedTime(&ms, ev[8], ev[9]); s.ms_linearize += ms;
+            (void)hipEventElapsedTime(&ms, ev[10], ev[11]); s.ms_schur += ms;
+            L.gmax = g2;
+            if (pending_accepted) L.cost = c2;
+            if (trace) trace[(size_t)pending_iter * STBA_TRACE_COLS + 2] = g2;
+            pending = false;
+            if (pending_accepted && !fixed && g2 <= opt.gradient_tolerance) {
+                // converged at the previous iteration: the trial step just computed is discarded
+                --iter;
+                s.termination_type = STBA_CONVERGENCE; s.termination_reason = STBA_TERM_GRADIENT;
+                break;
+            }
+        }
         if (lin_timing_pending) { (void)hipEventElapsedTime(&ms, ev[0], ev[1]); s.ms_linearize += ms; lin_timing_pending = false; }
         (void)hipEventElapsedTime(&ms, ev[2], ev[3]); s.ms_schur += ms;
         (void)hipEventElapsedTime(&ms, ev[3], ev[4]); s.ms_solve += ms;
@@ -415,25 +457,33 @@ static int ba_run_lm(stba_ba* b, const stba_lm_options* opt_in, int fixed_iterat
         need_build = true;
         if ((accepted || fixed) && !(fixed && iter >= max_iter)) {
             // re-linearise at the (new) current point
-            STBA_HIP(hipEventRecord(ev[0], b->st));
+            const int e0 = deferred_ok ? 8 : 0, e2 = deferred_ok ? 10 : 2;
+            STBA_HIP(hipEventRecord(ev[e0], b->st));
             STBA_TRY(ba_linearize(b, b->cur, b->trial + TS_COST2));
             STBA_TRY(ba_normal_blocks(b));
-            STBA_HIP(hipEventRecord(ev[1], b->st));
+            STBA_HIP(hipEventRecord(ev[e0 + 1], b->st));
             STBA_TRY(ba_fill_scalar_slots(b, b->trial + TS_COST2));
-            lin_timing_pending = true;
             // gradient of the new point is needed for the convergence test: it arrives with the
             // next reduced-system build (one collective per iteration); build it now.
             dm.radius = L.radius;
-            STBA_HIP(hipEventRecord(ev[2], b->st));
+            STBA_HIP(hipEventRecord(ev[e2], b->st));
             STBA_TRY(ba_build_reduced(b, dm));
-            STBA_HIP(hipEventRecord(ev[3], b->st));
+            STBA_HIP(hipEventRecord(ev[e2 + 1], b->st));
             need_build = false;
-            double c2, g2;
-            STBA_TRY(ba_read_linear_scalars(b, &c2, &g2));
-            (void)hipEventElapsedTime(&ms, ev[0], ev[1]); s.ms_linearize += ms; lin_timing_pending = false;
-            (void)hipEventElapsedTime(&ms, ev[2], ev[3]); s.ms_schur += ms;
-            L.gmax = g2;
-            if (accepted) L.cost = c2;   // same value as new_cost up to summation order
+            lin_timing_pending = false;
+            if (deferred_ok) {
+                // (cost, |g|max) of the new point are consumed after the next synchronisation
+                STBA_TRY(ba_request_linear_scalars(b));
+                pending = true; pending_accepted = accepted; pending_iter = iter;
+                if (accepted) L.cost = new_cost;
+            } else {
+                double c2, g2;
+                STBA_TRY(ba_read_linear_scalars(b, &c2, &g2));
+                (void)hipEventElapsedTime(&ms, ev[0], ev[1]); s.ms_linearize += ms;
+                (void)hipEventElapsedTime(&ms, ev[2], ev[3]); s.ms_schur += ms;
+                L.gmax = g2;
+                if (accepted) L.cost = c2;   // same value as new_cost up to summation order
+            }
         }
         if (trace) { trace[(size_t)iter * STBA_TRACE_COLS + 2] = L.gmax; trace[(size_t)iter * STBA_TRACE_COLS + 5] = L.radius; }
         if (opt.minimizer_progress_to_stdout)
@@ -445,12 +495,24 @@ static int ba_run_lm(stba_ba* b, const stba_lm_options* opt_in, int fixed_iterat
                 break;
             }
         }
-        if (accepted && !fixed && L.gmax <= opt.gradient_tolerance) {
+        if (!pending && accepted && !fixed && L.gmax <= opt.gradient_tolerance) {
             s.termination_type = STBA_CONVERGENCE; s.termination_reason = STBA_TERM_GRADIENT;
             break;
         }
     }
     STBA_HIP(hipStreamSynchronize(b->st));
+    if (pending) {      // the loop ended (iteration / radius limit) before the last linearisation's scalars were read
+        double c2, g2;
+        ba_finish_linear_scalars(b, &c2, &g2);
+        L.gmax = g2;
+        if (pending_accepted) L.cost = c2;
+        if (trace) trace[(size_t)pending_iter * STBA_TRACE_COLS + 2] = g2;
+        if (pending_accepted && !fixed && g2 <= opt.gradient_tolerance &&
+            (s.termination_reason == STBA_TERM_MAX_ITER || s.termination_reason == STBA_TERM_MIN_RADIUS)) {
+            s.termination_type = STBA_CONVERGENCE; s.termination_reason = STBA_TERM_GRADIENT;   // the test comes first
+        }
+        pending = false;
+    }
     s.num_iterations = iter;
     s.final_cost = L.cost;
     s.final_radius = L.radius;
