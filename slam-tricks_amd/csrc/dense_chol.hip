@@ -705,7 +705,7 @@ static void launch_syrk(double* A, int lda, int k0, int tile_mode, int tiles128,
 // hold an older copy, because nobody but the owner ever touched those lines before.  Flags are
 // agent-scope atomics.
 // The ticket order comes from a list-scheduling simulation on the host (mega_build_tasks).
-enum { TASK_D = 0, TASK_T = 1, TASK_TI = 2, TASK_U = 3, TASK_UQ = 4, TASK_TU = 5, TASK_EARLY = 0x100 };
+enum { TASK_D = 0, TASK_T = 1, TASK_TI = 2, TASK_U = 3, TASK_UQ = 4, TASK_TU = 5 };
 
 struct MegaArgs {
     double* A; int lda; int n; int nblk;
@@ -1051,14 +1051,13 @@ __global__ __launch_bounds__(512) void chol_mega_kernel(MegaArgs a) {
         const int task = s_task;
         if (task >= qend) break;
         const int4 d = a.tasks[task];
-        const int type = d.x & 0xff, b = d.y, ti = d.z, tj = d.w;
-        const bool early = (d.x & TASK_EARLY) != 0 || type == TASK_TU || type == TASK_D;
+        const int type = d.x, b = d.y, ti = d.z, tj = d.w;
+        const bool early = (type == TASK_TU);
         const int k0 = b * NB;
         if (t == 0) {
             if (a.trace) { a.trace[8 * (size_t)task] = blockIdx.x; a.trace[8 * (size_t)task + 1] = wall_clock64(); }
-            // next ticket; its latency hides behind this task.  Not for the chain tasks: their tickets are
-            // taken early (see the gates in mega_build_tasks) and they wait for tasks with LATER tickets (a
-            // TU task also for its three siblings) -- such a workgroup must not sit on one of those.
+            // next ticket; its latency hides behind this task.  Not for TU: a TU task waits for its three
+            // siblings, which hold LATER tickets -- this workgroup must not sit on one of them.
             if (!early) mine = qbeg + atomicAdd(ticket, 1);
             bool ok = true;
             if (type == TASK_D) {
@@ -1160,14 +1159,7 @@ static int mega_owner(const int4& tk, int nq) {
 // argument needs, and (ii) per-queue orders in which a workgroup rarely takes a ticket whose inputs
 // are far from ready (an in-order ticket queue has no other notion of priority).
 static void mega_build_tasks(int nblk, int nq, int wg_per_q, std::vector<int4>& out, int* qstart) {
-    // gate (experiment, STBA_MEGA_GATES=1, off by default): a CHAIN task (D, TU) may be TAKEN as soon as the
-    // gate task has started, long before its inputs are ready, so that a workgroup already spins on the flag
-    // when D(b) finishes (while all workgroups are busy with 23 us trailing tiles the hand-off waits 6..13 us
-    // for a free one).  Measured: no gain -- the tiles (b+1, b) / (b+1, b+1) then arrive late instead (the
-    // T -> Uq chain of the previous panel has only ~6 us of slack), and a static order that deviates from
-    // the simulated one is fragile.  A dynamic chain queue is the proper fix.
-    struct Node { int4 tk; std::vector<int> succ; std::vector<int> gated; std::vector<int> early_succ; int indeg = 0; double dur = 0, prio = 0; int q = 0;
-                  int gate = -1; bool gate_open = false, assigned = false, running = false; };
+    struct Node { int4 tk; std::vector<int> succ; int indeg = 0; double dur = 0, prio = 0; int q = 0; };
     std::vector<Node> nodes;
     const int NBK = nblk;
     std::vector<int> idD((size_t)NBK, -1), idTI((size_t)NBK, -1), idTU((size_t)NBK * 4, -1), idT((size_t)NBK * NBK, -1),
@@ -1176,10 +1168,6 @@ static void mega_build_tasks(int nblk, int nq, int wg_per_q, std::vector<int4>& 
     // (STBA_MEGA_DUR=d,t,ti,u,uq,tu overrides them for experiments)
     double DUR[6] = {29.0, 23.0, 19.0, 25.0, 16.5, 20.0};
     if (const char* e = getenv("STBA_MEGA_DUR")) sscanf(e, "%lf,%lf,%lf,%lf,%lf,%lf", &DUR[0], &DUR[1], &DUR[2], &DUR[3], &DUR[4], &DUR[5]);
-    // LEAD: the TU tickets are placed as if D(b) ended LEAD us early, so that their workgroups are already
-    // inside the task (rows requested, spinning on the flag) when it really ends
-    static const double LEAD = [] { const char* e = getenv("STBA_MEGA_LEAD"); return e ? atof(e) : 0.0; }();
-    static const bool GATES = [] { const char* e = getenv("STBA_MEGA_GATES"); return e && atoi(e) != 0; }();
     auto add = [&](int type, int b, int i, int j, double prio) {
         Node nd; nd.tk = make_int4(type, b, i, j); nd.dur = DUR[type]; nd.prio = prio; nd.q = mega_owner(nd.tk, nq);
         nodes.push_back(nd);
@@ -1216,8 +1204,7 @@ static void mega_build_tasks(int nblk, int nq, int wg_per_q, std::vector<int4>& 
         if (b + 1 < NBK)
             for (int q = 0; q < 4; ++q) {
                 const int tu = idTU[(size_t)b * 4 + q];
-                nodes[(size_t)d].early_succ.push_back(tu);      // released LEAD us before D(b) ends (see the simulation)
-                nodes[(size_t)tu].indeg++;
+                dep(d, tu);
                 if (b > 0) {
                     for (int q2 = 0; q2 < 4; ++q2) dep(idUq[((size_t)(b - 1) * NBK + (b + 1)) * 4 + q2], tu);
                     dep(idU[((size_t)(b - 1) * NBK + (b + 1)) * NBK + (b + 1)], tu);
@@ -1243,13 +1230,6 @@ static void mega_build_tasks(int nblk, int nq, int wg_per_q, std::vector<int4>& 
                 if (b > 0) dep(idU[((size_t)(b - 1) * NBK + i) * NBK + j], u);
             }
     }
-    if (GATES)
-        for (int b = 0; b + 1 < NBK; ++b) {
-            const int d = idD[(size_t)b];
-            for (int q = 0; q < 4; ++q) { nodes[(size_t)idTU[(size_t)b * 4 + q]].gate = d; nodes[(size_t)d].gated.push_back(idTU[(size_t)b * 4 + q]); }
-            nodes[(size_t)idD[(size_t)b + 1]].gate = d;
-            nodes[(size_t)d].gated.push_back(idD[(size_t)b + 1]);
-        }
     // event-driven list scheduling
     typedef std::pair<double, int> PI;
     std::vector<std::priority_queue<PI, std::vector<PI>, std::greater<PI>>> ready((size_t)nq);
@@ -1258,56 +1238,30 @@ static void mega_build_tasks(int nblk, int nq, int wg_per_q, std::vector<int4>& 
     double now = 0.0;
     std::vector<std::vector<int>> order((size_t)nq);
     auto push_ready = [&](int k) { ready[(size_t)nodes[(size_t)k].q].push(PI(nodes[(size_t)k].prio, k)); };
-    auto start_running = [&](int k) {            // inputs ready AND a workgroup holds the ticket
-        Node& nd = nodes[(size_t)k];
-        nd.running = true;
-        events.push(PI(now + nd.dur, k));
-        if (!nd.early_succ.empty()) events.push(PI(now + std::max(0.0, nd.dur - LEAD), -(k + 1)));
-        for (int g : nd.gated)
-            if (!nodes[(size_t)g].gate_open) { nodes[(size_t)g].gate_open = true; push_ready(g); }
-    };
     for (int k = 0; k < (int)nodes.size(); ++k)
-        if (nodes[(size_t)k].gate < 0 && nodes[(size_t)k].indeg == 0) push_ready(k);
+        if (nodes[(size_t)k].indeg == 0) push_ready(k);
     for (;;) {
         for (int q = 0; q < nq; ++q)
             while (idle[(size_t)q] > 0 && !ready[(size_t)q].empty()) {
                 const int k = ready[(size_t)q].top().second;
                 ready[(size_t)q].pop();
                 idle[(size_t)q]--;
-                nodes[(size_t)k].assigned = true;
                 order[(size_t)q].push_back(k);
-                if (nodes[(size_t)k].indeg == 0) start_running(k);
+                events.push(PI(now + nodes[(size_t)k].dur, k));
             }
         if (events.empty()) break;
         const PI ev = events.top();
         events.pop();
         now = ev.first;
-        if (ev.second < 0) {                      // early release: the TU tickets of this diagonal block
-            for (int sidx : nodes[(size_t)(-ev.second - 1)].early_succ) {
-                Node& sn = nodes[(size_t)sidx];
-                if (--sn.indeg != 0) continue;
-                if (sn.gate < 0) push_ready(sidx);
-                else if (sn.assigned && !sn.running) start_running(sidx);
-            }
-            continue;
-        }
         const Node& nd = nodes[(size_t)ev.second];
         idle[(size_t)nd.q]++;
-        for (int sidx : nd.succ) {
-            Node& sn = nodes[(size_t)sidx];
-            if (--sn.indeg != 0) continue;
-            if (sn.gate < 0) push_ready(sidx);
-            else if (sn.assigned && !sn.running) start_running(sidx);   // its workgroup was already spinning
-        }
+        for (int sidx : nd.succ)
+            if (--nodes[(size_t)sidx].indeg == 0) push_ready(sidx);
     }
     out.clear();
     for (int q = 0; q < nq; ++q) {
         qstart[q] = (int)out.size();
-        for (int k : order[(size_t)q]) {
-            int4 tk = nodes[(size_t)k].tk;
-            if (nodes[(size_t)k].gate >= 0) tk.x |= TASK_EARLY;      // taken early: must not prefetch the next ticket
-            out.push_back(tk);
-        }
+        for (int k : order[(size_t)q]) out.push_back(nodes[(size_t)k].tk);
     }
     qstart[nq] = (int)out.size();
 }
