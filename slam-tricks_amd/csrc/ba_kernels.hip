@@ -499,11 +499,11 @@ __global__ __launch_bounds__(SCHUR_THREADS) void ba_schur_rows_kernel(SchurRowAr
     const int task = blockIdx.x;
     const int c = a.task_cam[task];
     const int col0 = a.row_col_ptr[c], ncols = a.row_col_ptr[c + 1] - col0;
-    double* acc = smem;                          // [ncols][36]
-    double* racc = smem + (size_t)a.max_cols * 36;   // [8]
+    double* acc = smem;                          // [ncols][SCHUR_BLK_LD]
+    double* racc = smem + (size_t)a.max_cols * SCHUR_BLK_LD;   // [8]
     int* cols = reinterpret_cast<int*>(racc + 8);    // [ncols]
     const int tid = threadIdx.x;
-    for (int e = tid; e < ncols * 36; e += SCHUR_THREADS) acc[e] = 0.0;
+    for (int e = tid; e < ncols * SCHUR_BLK_LD; e += SCHUR_THREADS) acc[e] = 0.0;
     if (tid < 8) racc[tid] = 0.0;
     for (int e = tid; e < ncols; e += SCHUR_THREADS) cols[e] = a.row_cols[col0 + e];
     __syncthreads();
@@ -545,7 +545,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void ba_schur_rows_kernel(SchurRowAr
                 const int mid = (lo + hi) >> 1;
                 if (cols[mid] < c2) lo = mid + 1; else hi = mid;
             }
-            double* blk = acc + (size_t)lo * 36;
+            double* blk = acc + (size_t)lo * SCHUR_BLK_LD;
             double jc2[12], jp2[6];
             load_jc_jp(a.Jc, a.Jp, l, jc2, jp2);
 #pragma unroll
@@ -570,8 +570,105 @@ __global__ __launch_bounds__(SCHUR_THREADS) void ba_schur_rows_kernel(SchurRowAr
         const int c2 = cols[slot];
         if (c2 == c && b > q) continue;
         double* dst = a.S + (size_t)(c * 6 + q) * a.lda + c2 * 6 + b;
-        if (single) *dst = acc[e];
-        else unsafeAtomicAdd(dst, acc[e]);
+        const double v = acc[slot * SCHUR_BLK_LD + k];
+        if (single) *dst = v;
+        else unsafeAtomicAdd(dst, v);
+    }
+    if (tid < 6) {
+        if (single) a.rhs[c * 6 + tid] = racc[tid];
+        else unsafeAtomicAdd(&a.rhs[c * 6 + tid], racc[tid]);
+    }
+}
+
+// -------------------------------------------------------------------------------------------
+// Pair-plan variant of the row-wise Schur kernel.  The row kernel above walks, per observation, the other
+// observations of its landmark in a serial loop of dependent loads (camera index -> binary search -> Jacobian
+// rows): latency-bound, 0.52 ms at C5.  Here the pairs of a camera row are enumerated ON THE HOST once
+// (the structure is static), with the LDS slot of every pair's block resolved; a pre-pass computes
+// E_i = (Jc_i^T Jp_i) Hinv_j and E_i gp_j per observation; then one lane handles one PAIR: two independent
+// 144 B gathers (E_i, J_l), 108 FMAs, 36 LDS atomics -- every iteration of every lane is independent.
+// -------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ba_schur_prep_kernel(int n_obs, const int* __restrict__ obs_pt,
+                                                            const double* __restrict__ Jc, const double* __restrict__ Jp,
+                                                            const double* __restrict__ Hinv6, const double* __restrict__ gp,
+                                                            double* __restrict__ Eb) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_obs) return;
+    const int j = obs_pt[i];
+    double Hi[6], jc[12], jp[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) Hi[k] = Hinv6[(size_t)j * 6 + k];
+    load_jc_jp(Jc, Jp, i, jc, jp);
+    const double g0 = gp[(size_t)j * 3], g1 = gp[(size_t)j * 3 + 1], g2 = gp[(size_t)j * 3 + 2];
+    double* out = Eb + (size_t)i * 24;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        const double w0 = jc[q] * jp[0] + jc[6 + q] * jp[3];
+        const double w1 = jc[q] * jp[1] + jc[6 + q] * jp[4];
+        const double w2 = jc[q] * jp[2] + jc[6 + q] * jp[5];
+        const double e0 = w0 * Hi[0] + w1 * Hi[1] + w2 * Hi[2];
+        const double e1 = w0 * Hi[1] + w1 * Hi[3] + w2 * Hi[4];
+        const double e2 = w0 * Hi[2] + w1 * Hi[4] + w2 * Hi[5];
+        out[q * 3] = e0; out[q * 3 + 1] = e1; out[q * 3 + 2] = e2;
+        out[18 + q] = e0 * g0 + e1 * g1 + e2 * g2;
+    }
+}
+
+__global__ __launch_bounds__(SCHUR_THREADS) void ba_schur_pairs_kernel(SchurRowArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int task = blockIdx.x;
+    const int c = a.task_cam[task];
+    const int col0 = a.row_col_ptr[c], ncols = a.row_col_ptr[c + 1] - col0;
+    double* acc = smem;                          // [ncols][SCHUR_BLK_LD]
+    double* racc = smem + (size_t)a.max_cols * SCHUR_BLK_LD;   // [8]
+    int* cols = reinterpret_cast<int*>(racc + 8);    // [ncols]
+    const int tid = threadIdx.x;
+    for (int e = tid; e < ncols * SCHUR_BLK_LD; e += SCHUR_THREADS) acc[e] = 0.0;
+    if (tid < 8) racc[tid] = 0.0;
+    for (int e = tid; e < ncols; e += SCHUR_THREADS) cols[e] = a.row_cols[col0 + e];
+    __syncthreads();
+    const int ke = a.pair_end[task];
+    for (int k = a.pair_begin[task] + tid; k < ke; k += SCHUR_THREADS) {
+        const int2 il = a.pair_il[k];
+        const unsigned sl = a.pair_slot[k];
+        const double2* pe = reinterpret_cast<const double2*>(a.Eb + (size_t)il.x * 24);
+        double E[18], jc2[12], jp2[6];
+#pragma unroll
+        for (int m = 0; m < 9; ++m) { const double2 v = pe[m]; E[2 * m] = v.x; E[2 * m + 1] = v.y; }
+        load_jc_jp(a.Jc, a.Jp, il.y, jc2, jp2);
+        if (sl & 0x4000u) {                      // l == i: this observation's share of the right-hand side
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                const double v = a.Eb[(size_t)il.x * 24 + 18 + q];
+                if (v != 0.0) unsafeAtomicAdd(&racc[q], v);
+            }
+        }
+        const bool diag = (sl & 0x8000u) != 0;
+        double* blk = acc + (size_t)(sl & 0x3fffu) * SCHUR_BLK_LD;
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+            const double w0 = jc2[b] * jp2[0] + jc2[6 + b] * jp2[3];
+            const double w1 = jc2[b] * jp2[1] + jc2[6 + b] * jp2[4];
+            const double w2 = jc2[b] * jp2[2] + jc2[6 + b] * jp2[5];
+            if (w0 == 0.0 && w1 == 0.0 && w2 == 0.0) continue;   // constant dof of camera c2
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                if (diag && b > q) continue;
+                const double v = E[q * 3] * w0 + E[q * 3 + 1] * w1 + E[q * 3 + 2] * w2;
+                if (v != 0.0) unsafeAtomicAdd(&blk[q * 6 + b], -v);
+            }
+        }
+    }
+    __syncthreads();
+    const bool single = a.task_single[task] != 0;
+    for (int e = tid; e < ncols * 36; e += SCHUR_THREADS) {
+        const int slot = e / 36, k = e - slot * 36, q = k / 6, b = k - q * 6;
+        const int c2 = cols[slot];
+        if (c2 == c && b > q) continue;
+        double* dst = a.S + (size_t)(c * 6 + q) * a.lda + c2 * 6 + b;
+        const double v = acc[slot * SCHUR_BLK_LD + k];
+        if (single) *dst = v;
+        else unsafeAtomicAdd(dst, v);
     }
     if (tid < 6) {
         if (single) a.rhs[c * 6 + tid] = racc[tid];
@@ -580,7 +677,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void ba_schur_rows_kernel(SchurRowAr
 }
 
 size_t schur_rows_lds_bytes(int max_cols) {
-    return ((size_t)max_cols * 36 + 8) * sizeof(double) + (size_t)max_cols * sizeof(int) + 16;
+    return ((size_t)max_cols * SCHUR_BLK_LD + 8) * sizeof(double) + (size_t)max_cols * sizeof(int) + 16;
 }
 
 int launch_schur_rows(const SchurRowArgs& a, int n_tasks, hipStream_t st) {
@@ -590,9 +687,17 @@ int launch_schur_rows(const SchurRowArgs& a, int n_tasks, hipStream_t st) {
     if (lds > attr_lds) {
         STBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_schur_rows_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        STBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_schur_pairs_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_lds = lds;
     }
-    hipLaunchKernelGGL(ba_schur_rows_kernel, dim3(n_tasks), dim3(SCHUR_THREADS), lds, st, a);
+    if (a.pair_il) {
+        hipLaunchKernelGGL(ba_schur_prep_kernel, dim3((a.n_obs + 255) / 256), dim3(256), 0, st, a.n_obs, a.obs_pt, a.Jc, a.Jp,
+                           a.Hinv6, a.gp, a.Eb);
+        hipLaunchKernelGGL(ba_schur_pairs_kernel, dim3(n_tasks), dim3(SCHUR_THREADS), lds, st, a);
+    } else {
+        hipLaunchKernelGGL(ba_schur_rows_kernel, dim3(n_tasks), dim3(SCHUR_THREADS), lds, st, a);
+    }
     STBA_HIP(hipGetLastError());
     return STBA_OK;
 }

@@ -41,8 +41,12 @@ int launch_schur(int n_obs, const int* obs_cam, const int* obs_pt, const int* pt
                  const double* Jp, const double* Hinv6, const double* gp, double* S, int lda, double* rhs,
                  hipStream_t st);
 // row-wise Schur complement with LDS accumulation (plan built on the host at create time)
-constexpr int SCHUR_MAX_COLS = 500;    // non-zero blocks per camera row that fit the LDS accumulator
+constexpr int SCHUR_MAX_COLS = 480;    // non-zero blocks per camera row that fit the LDS accumulator
 constexpr int SCHUR_TASK_OBS = 4096;
+// LDS stride of one 6x6 accumulator block, in doubles: odd, so that the same entry of different blocks falls
+// into different bank pairs (36 = 72 dwords = 8 mod 64 gave 8-way conflicts on every ds_add_f64: measured,
+// the kernel was bound by them)
+constexpr int SCHUR_BLK_LD = 37;
 constexpr int SCHUR_THREADS = 1024;    // one camera row per workgroup: 16 waves hide the L2 gathers   // observations of one camera handled by one workgroup
 struct SchurRowArgs {
     const int* task_cam; const int* task_begin; const int* task_end; const unsigned char* task_single;
@@ -50,6 +54,12 @@ struct SchurRowArgs {
     const int* cam_perm; const int* obs_cam; const int* obs_pt; const int* pt_start;
     const double* Jc; const double* Jp; const double* Hinv6; const double* gp;
     double* S; int lda; double* rhs;
+    // pair plan (optional, built at create time): every (observation i of the row's camera, observation l of
+    // the same landmark with camera(l) <= camera(i)) with the LDS slot of its 6x6 block resolved on the host
+    const int* pair_begin; const int* pair_end;      // per task
+    const int2* pair_il; const unsigned short* pair_slot;   // slot | 0x8000 if diagonal block | 0x4000 if l == i
+    double* Eb;                                      // per observation: E = (Jc^T Jp) Hinv (18) and E gp (6)
+    int n_obs;
 };
 size_t schur_rows_lds_bytes(int max_cols);
 int launch_schur_rows(const SchurRowArgs& a, int n_tasks, hipStream_t st);

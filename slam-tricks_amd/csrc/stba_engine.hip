@@ -77,6 +77,11 @@ struct stba_ba {
     int *task_cam = nullptr, *task_begin = nullptr, *task_end = nullptr, *row_col_ptr = nullptr, *row_cols = nullptr;
     unsigned char* task_single = nullptr;
     int n_tasks = 0, max_cols = 0;
+    // pair plan of the Schur kernel (see ba_schur_pairs_kernel)
+    int *pair_begin = nullptr, *pair_end = nullptr;
+    int2* pair_il = nullptr;
+    unsigned short* pair_slot = nullptr;
+    double* Eb = nullptr;
     unsigned char *cam_fixed = nullptr, *pt_fixed = nullptr;
     double2* r = nullptr;
     double *Jc = nullptr, *Jp = nullptr;
@@ -117,6 +122,7 @@ static void ba_free(stba_ba* b) {
     F(b->pt_fixed); F(b->r); F(b->Jc); F(b->Jp); F(b->Hpp6); F(b->gp); F(b->Hinv6); F(b->dp); F(b->scale_p);
     F(b->Hcc); F(b->gc); F(b->cam_partial); F(b->dc); F(b->scale_c); F(b->Sbuf); F(b->Spack); F(b->dxc); F(b->dxp);
     F(b->task_cam); F(b->task_begin); F(b->task_end); F(b->row_col_ptr); F(b->row_cols); F(b->task_single);
+    F(b->pair_begin); F(b->pair_end); F(b->pair_il); F(b->pair_slot); F(b->Eb);
     F(b->cost_partial); F(b->upd_partial_c); F(b->upd_partial_p); F(b->trial); F(b->flag);
     for (auto& e : b->ev) if (e) (void)hipEventDestroy(e);
     if (b->lin_pin) (void)hipHostFree(b->lin_pin);
@@ -193,6 +199,8 @@ static int ba_build_reduced(stba_ba* b, const Damping& dm) {
         sa.max_cols = b->max_cols; sa.cam_perm = b->cam_perm; sa.obs_cam = b->obs_cam; sa.obs_pt = b->obs_pt;
         sa.pt_start = b->pt_start; sa.Jc = b->Jc; sa.Jp = b->Jp; sa.Hinv6 = b->Hinv6; sa.gp = b->gp;
         sa.S = b->S(); sa.lda = b->lda; sa.rhs = b->rhs();
+        sa.pair_begin = b->pair_begin; sa.pair_end = b->pair_end; sa.pair_il = b->pair_il; sa.pair_slot = b->pair_slot;
+        sa.Eb = b->Eb; sa.n_obs = b->no;
         STBA_TRY(launch_schur_rows(sa, b->n_tasks, b->st));
     } else {
         STBA_TRY(launch_schur(b->no, b->obs_cam, b->obs_pt, b->pt_start, b->Jc, b->Jp, b->Hinv6, b->gp, b->S(),
@@ -663,6 +671,34 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
     const bool row_plan = max_cols <= SCHUR_MAX_COLS;
     b->n_tasks = row_plan ? (int)task_cam.size() : 0;
     b->max_cols = max_cols;
+    // pair plan: (i, l, slot) of every block contribution of every task, in task order
+    std::vector<int> pair_begin, pair_end;
+    std::vector<int2> pair_il;
+    std::vector<unsigned short> pair_slot;
+    static const bool PAIRS = [] { const char* v = getenv("STBA_SCHUR_PAIRS"); return !v || atoi(v) != 0; }();
+    bool pair_plan = PAIRS && row_plan && max_cols < 0x4000;
+    if (pair_plan) {
+        pair_begin.resize(task_cam.size()); pair_end.resize(task_cam.size());
+        for (size_t k = 0; k < task_cam.size() && pair_plan; ++k) {
+            const int c = task_cam[k];
+            const int* cb = row_cols.data() + row_col_ptr[c];
+            const int nco = row_col_ptr[c + 1] - row_col_ptr[c];
+            pair_begin[k] = (int)pair_il.size();
+            for (int p = task_begin[k]; p < task_end[k]; ++p) {
+                const int i = cam_perm[p];
+                const int j = s_pt[i];
+                for (int l = pt_start[j]; l < pt_start[j + 1]; ++l) {
+                    const int c2 = s_cam[l];
+                    if (c2 > c) continue;
+                    const int slot = (int)(std::lower_bound(cb, cb + nco, c2) - cb);
+                    pair_il.push_back(make_int2(i, l));
+                    pair_slot.push_back((unsigned short)(slot | (c2 == c ? 0x8000 : 0) | (l == i ? 0x4000 : 0)));
+                }
+            }
+            pair_end[k] = (int)pair_il.size();
+            if (pair_il.size() > ((size_t)1 << 28)) pair_plan = false;      // > 2.7 GB of plan: keep the row kernel
+        }
+    }
     std::vector<unsigned char> cmask;
     if (cam_fixed) {
         cmask.resize(n_cams);
@@ -688,6 +724,11 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
         A_(dev_alloc(&b->task_cam, task_cam.size())); A_(dev_alloc(&b->task_begin, task_cam.size()));
         A_(dev_alloc(&b->task_end, task_cam.size())); A_(dev_alloc(&b->task_single, task_cam.size()));
         A_(dev_alloc(&b->row_col_ptr, nc + 1)); A_(dev_alloc(&b->row_cols, row_cols.size()));
+        if (pair_plan && !pair_il.empty()) {
+            A_(dev_alloc(&b->pair_begin, pair_begin.size())); A_(dev_alloc(&b->pair_end, pair_end.size()));
+            A_(dev_alloc(&b->pair_il, pair_il.size())); A_(dev_alloc(&b->pair_slot, pair_slot.size()));
+            A_(dev_alloc(&b->Eb, no * 24));
+        }
     }
     if (cam_fixed) A_(dev_alloc(&b->cam_fixed, nc));
     if (pt_fixed) A_(dev_alloc(&b->pt_fixed, np));
@@ -717,6 +758,10 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
         A_(upload(b->task_single, task_single.data(), task_cam.size(), b->st));
         A_(upload(b->row_col_ptr, row_col_ptr.data(), nc + 1, b->st));
         A_(upload(b->row_cols, row_cols.data(), row_cols.size(), b->st));
+        if (b->pair_il) {
+            A_(upload(b->pair_begin, pair_begin.data(), pair_begin.size(), b->st)); A_(upload(b->pair_end, pair_end.data(), pair_end.size(), b->st));
+            A_(upload(b->pair_il, pair_il.data(), pair_il.size(), b->st)); A_(upload(b->pair_slot, pair_slot.data(), pair_slot.size(), b->st));
+        }
     }
     if (cam_fixed) A_(upload(b->cam_fixed, cmask.data(), nc, b->st));
     if (pt_fixed) A_(upload(b->pt_fixed, pt_fixed, np, b->st));
