@@ -155,9 +155,17 @@ def main():
         roof_jac = {"kernel": "ba_linearize_kernel<cams-in-LDS, with-Jacobian>", "bound": "hbm", "achieved": jac_gbs,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": jac_gbs / HBM_PEAK_GBS, "traffic": traffic,
                     "ms_per_launch": ms_jac, "algorithmic_bytes_per_launch": jac_bytes}
+        chol_traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_chol.json")) as f:
+                pc = json.load(f)
+            if nred == 6000:
+                chol_traffic = pc["hbm_bytes_per_launch"]      # PMC passes of tools/pmc_chol.sh, C5 shape only
+        except Exception:
+            pass
         roof_chol = {"kernel": "chol_mega_kernel (persistent dataflow Cholesky, v_mfma_f64_16x16x4_f64)",
                      "bound": "mfma", "achieved": chol_tflops, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": chol_tflops / FP64_MFMA_PEAK_TFLOPS, "traffic": None, "ms_per_launch": ms_factor,
+                     "frac": chol_tflops / FP64_MFMA_PEAK_TFLOPS, "traffic": chol_traffic, "ms_per_launch": ms_factor,
                      "algorithmic_flops_per_launch": chol_flops, "launches_per_lm_iteration": 1,
                      "microbench_ceiling": FP64_MFMA_MEASURED_CEILING_TFLOPS,
                      "frac_of_microbench_ceiling": chol_tflops / FP64_MFMA_MEASURED_CEILING_TFLOPS,
