@@ -84,22 +84,12 @@ __device__ __forceinline__ double sqrt_from_rsqrt(double d, double y) {
 // stays in the L2 of the XCD that owns the tile (see chol_mega_kernel).  No cache-wide
 // buffer_wbl2 / buffer_inv fences anywhere: with one fence pair per task hand-off the factorisation
 // took 14 ms instead of 4.6 ms (every fence flushes and invalidates a whole L2).
-#ifdef STBA_MEGA_PLAIN_FINAL
-constexpr bool MEGA_WT = false;
-#else
-constexpr bool MEGA_WT = true;
-#endif
-#ifdef STBA_MEGA_C_WT
-constexpr bool MEGA_C_WT = true;      // experiment: tiles under update are written through as well
-#else
-constexpr bool MEGA_C_WT = false;
-#endif
 template <bool WT> __device__ __forceinline__ void gst(double* p, double v) {
-    if constexpr (WT && MEGA_WT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if constexpr (WT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else *p = v;
 }
 template <bool WT> __device__ __forceinline__ void gst4(double* p, double4v v) {
-    if constexpr (WT && MEGA_WT) {
+    if constexpr (WT) {
         // two 16-byte write-through stores (the compiler only emits sc1 on <= 8-byte atomic stores; the
         // caller's s_waitcnt vmcnt(0) before raising the flag covers these)
         typedef double double2v __attribute__((ext_vector_type(2)));
@@ -109,32 +99,6 @@ template <bool WT> __device__ __forceinline__ void gst4(double* p, double4v v) {
     } else *reinterpret_cast<double4v*>(p) = v;
 }
 __device__ __forceinline__ double4v gld4(const double* p) { return *reinterpret_cast<const double4v*>(p); }
-// loads inside the persistent kernel: F = final data (blocks of L written by other XCDs), C = tiles
-// under update (owned by this XCD).  Experiment switches: -DSTBA_MEGA_F_SC1 / -DSTBA_MEGA_C_SC1 make
-// them agent-scope coherent (sc1) loads.
-#ifdef STBA_MEGA_F_SC1
-constexpr bool MEGA_F_SC1 = true;
-#else
-constexpr bool MEGA_F_SC1 = false;
-#endif
-#ifdef STBA_MEGA_C_SC1
-constexpr bool MEGA_C_SC1 = true;
-#else
-constexpr bool MEGA_C_SC1 = false;
-#endif
-template <bool SC1> __device__ __forceinline__ double mld(const double* p) {
-    if constexpr (SC1) return __hip_atomic_load(const_cast<double*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else return *p;
-}
-template <bool SC1> __device__ __forceinline__ double2 mld2(const double* p) {
-    if constexpr (SC1) return make_double2(mld<true>(p), mld<true>(p + 1));
-    else return *reinterpret_cast<const double2*>(p);
-}
-template <bool SC1> __device__ __forceinline__ double4v mld4(const double* p) {
-    if constexpr (SC1) return double4v{mld<true>(p), mld<true>(p + 1), mld<true>(p + 2), mld<true>(p + 3)};
-    else return *reinterpret_cast<const double4v*>(p);
-}
-
 // ------------------------------------------------------------------------------------------
 // Diagonal block (128x128), 512 threads.  The pivot chain is sequential (128 columns), so everything is
 // arranged around keeping it short:
@@ -217,7 +181,7 @@ __device__ __forceinline__ void diag_row_threads(double* __restrict__ A, int lda
     {   // tile column 0 straight from global memory (row i, 16 columns)
         const double* src = A + (size_t)(k0 + i) * lda + k0;
 #pragma unroll
-        for (int c = 0; c < 16; ++c) p[c] = mld<WT && MEGA_C_SC1>(src + c);
+        for (int c = 0; c < 16; ++c) p[c] = *(src + c);
     }
     PHASE_STAMP(0);
 #pragma unroll 1
@@ -417,10 +381,10 @@ __device__ __forceinline__ void diag_mfma_waves(const double* __restrict__ A, in
             const bool in = (I >= 1 && J <= I);
             const double* src = A + (size_t)(k0 + 16 * (in ? I : 0) + lr) * lda + k0 + 16 * (in ? J : 0) + lc;
             double4v tmp;
-            tmp[0] = in ? mld<WT && MEGA_C_SC1>(src) : 0.0;
-            tmp[1] = in ? mld<WT && MEGA_C_SC1>(src + (size_t)4 * lda) : 0.0;
-            tmp[2] = in ? mld<WT && MEGA_C_SC1>(src + (size_t)8 * lda) : 0.0;
-            tmp[3] = in ? mld<WT && MEGA_C_SC1>(src + (size_t)12 * lda) : 0.0;
+            tmp[0] = in ? *(src) : 0.0;
+            tmp[1] = in ? *(src + (size_t)4 * lda) : 0.0;
+            tmp[2] = in ? *(src + (size_t)8 * lda) : 0.0;
+            tmp[3] = in ? *(src + (size_t)12 * lda) : 0.0;
             acc[s2][J] = tmp;
         }
         acc[s2][0] = double4v{0.0, 0.0, 0.0, 0.0};
@@ -716,7 +680,6 @@ struct MegaArgs {
     int* sync;              // [0..16) tickets, [16] abort, then dflag[nblk], tuflag[nblk], tflag[nblk*nblk], ver[nblk*nblk]
     double* linv; size_t linv_stride;
     int* flag;
-    int opt;                // experiment switches (STBA_MEGA_OPT)
     long long* trace;       // optional (STBA_MEGA_TRACE): per task {workgroup, t_ticket, t_ready, t_done}, 100 MHz clock
 };
 constexpr int MEGA_SYNC_HDR = 17;
@@ -752,7 +715,7 @@ __device__ __forceinline__ void syrk_tile512(double* __restrict__ A, int lda, in
             for (int r = 0; r < 4; ++r) {
                 const int row = row_i + wr * (MB * 16) + m * 16 + (lane >> 4) + 4 * r;
                 const int col = row_j + wc * (NBK * 16) + n * 16 + (lane & 15);
-                acc[m][n][r] = mld<MEGA_C_SC1>(&A[(size_t)row * lda + col]);
+                acc[m][n][r] = A[(size_t)row * lda + col];
             }
     // staging map: wave w, half h -> row = (lane&15) + 16*w, k = 2*((lane>>4) + 4h)
     double2 ga[2], gb[2];
@@ -763,8 +726,8 @@ __device__ __forceinline__ void syrk_tile512(double* __restrict__ A, int lda, in
         for (int h = 0; h < 2; ++h) {
             const int row = lrow + 16 * w;
             const int k = 2 * (lkp + 4 * h);
-            if (stage_a) ga[h] = mld2<MEGA_F_SC1>(&A[(size_t)(row_i + row) * lda + k0 + kc * 16 + k]);
-            gb[h] = mld2<MEGA_F_SC1>(&A[(size_t)(row_j + row) * lda + k0 + kc * 16 + k]);
+            if (stage_a) ga[h] = *reinterpret_cast<const double2*>(&A[(size_t)(row_i + row) * lda + k0 + kc * 16 + k]);
+            gb[h] = *reinterpret_cast<const double2*>(&A[(size_t)(row_j + row) * lda + k0 + kc * 16 + k]);
         }
     };
     auto lstore = [&](int buf) {
@@ -812,7 +775,7 @@ __device__ __forceinline__ void syrk_tile512(double* __restrict__ A, int lda, in
             for (int r = 0; r < 4; ++r) {
                 const int row = row_i + wr * (MB * 16) + m * 16 + (lane >> 4) + 4 * r;
                 const int col = row_j + wc * (NBK * 16) + n * 16 + (lane & 15);
-                gst<MEGA_C_WT>(&A[(size_t)row * lda + col], acc[m][n][r]);
+                gst<false>(&A[(size_t)row * lda + col], acc[m][n][r]);
             }
 }
 
@@ -854,7 +817,7 @@ __device__ __forceinline__ bool trsm_compute512(double4v (&W)[8], const double* 
 #pragma unroll
             for (int r = 0; r < 4; ++r) W[J][r] = (16 * J + 4 * g + r == ident_row0 + n) ? 1.0 : 0.0;
         } else {
-            W[J] = mld4<MEGA_C_SC1>(rowp + 16 * J + 4 * g);
+            W[J] = gld4(rowp + 16 * J + 4 * g);
         }
     }
     if (t == 0) {
@@ -876,11 +839,11 @@ __device__ __forceinline__ bool trsm_compute512(double4v (&W)[8], const double* 
                 const int I = (tile >= 27) ? 6 : (tile >= 25) ? 5 : (tile >= 22) ? 4 : (tile >= 18) ? 3 : (tile >= 13) ? 2 : (tile >= 7) ? 1 : 0;
                 const int J = tile - (7 * I - I * (I - 1) / 2) + I + 1;
                 const int row = 16 * J + r;
-                v[s2] = -mld<MEGA_F_SC1>(&Lb[(size_t)row * lda + 16 * I + c]);
+                v[s2] = -Lb[(size_t)row * lda + 16 * I + c];
                 if (row >= nv) v[s2] = 0.0;
             } else {
                 const int J = tile - 28;
-                v[s2] = mld<MEGA_F_SC1>(&dinv[(J * 16 + r) * 16 + c]);
+                v[s2] = dinv[(J * 16 + r) * 16 + c];
                 if (16 * J + r >= nv) v[s2] = (c == r) ? 1.0 : 0.0;
             }
         }
@@ -951,7 +914,7 @@ __device__ __forceinline__ bool tu_task512(double* __restrict__ A, int lda, int 
         tn[s2] = (e < 2 * q + 1) ? e : e - (2 * q + 1);
         if (e < ntile) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[s2][r] = mld<MEGA_C_SC1>(&Cb[(size_t)(16 * tm[s2] + g + 4 * r) * lda + 16 * tn[s2] + n]);
+            for (int r = 0; r < 4; ++r) acc[s2][r] = Cb[(size_t)(16 * tm[s2] + g + 4 * r) * lda + 16 * tn[s2] + n];
         }
     }
     double4v W[8];
@@ -975,7 +938,7 @@ __device__ __forceinline__ bool tu_task512(double* __restrict__ A, int lda, int 
                 for (int qq = 0; qq < 4; ++qq) acc[s2] = __builtin_amdgcn_mfma_f64_16x16x4f64(-fa[qq], fb[qq], acc[s2], 0, 0, 0);
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) gst<MEGA_C_WT>(&Cb[(size_t)(16 * m + g + 4 * r) * lda + 16 * np + n], acc[s2][r]);
+            for (int r = 0; r < 4; ++r) gst<false>(&Cb[(size_t)(16 * m + g + 4 * r) * lda + 16 * np + n], acc[s2][r]);
         }
     }
     // D(b+1) needs nothing but this tile (it runs on this XCD and finds it in the L2): signal it now, the
@@ -1009,11 +972,11 @@ __device__ __forceinline__ void syrk_q32(double* __restrict__ A, int lda, int k0
     const double* pb = A + (size_t)(row_j + 16 * w + n) * lda + k0 + 4 * g;
     double4v a0[8], a1[8], bb[8], acc[2];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) { bb[c] = mld4<MEGA_F_SC1>(pb + 16 * c); a0[c] = mld4<MEGA_F_SC1>(pa0 + 16 * c); a1[c] = mld4<MEGA_F_SC1>(pa1 + 16 * c); }
+    for (int c = 0; c < 8; ++c) { bb[c] = gld4(pb + 16 * c); a0[c] = gld4(pa0 + 16 * c); a1[c] = gld4(pa1 + 16 * c); }
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[m][r] = mld<MEGA_C_SC1>(&A[(size_t)(row_i + 16 * m + g + 4 * r) * lda + row_j + 16 * w + n]);
+        for (int r = 0; r < 4; ++r) acc[m][r] = A[(size_t)(row_i + 16 * m + g + 4 * r) * lda + row_j + 16 * w + n];
     PHASE_STAMP(0);
 #pragma unroll
     for (int c = 0; c < 8; ++c)
@@ -1025,7 +988,7 @@ __device__ __forceinline__ void syrk_q32(double* __restrict__ A, int lda, int k0
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) gst<MEGA_C_WT>(&A[(size_t)(row_i + 16 * m + g + 4 * r) * lda + row_j + 16 * w + n], acc[m][r]);
+        for (int r = 0; r < 4; ++r) gst<false>(&A[(size_t)(row_i + 16 * m + g + 4 * r) * lda + row_j + 16 * w + n], acc[m][r]);
     PHASE_STAMP(1);
 }
 
@@ -1123,9 +1086,6 @@ __global__ __launch_bounds__(512) void chol_mega_kernel(MegaArgs a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (t == 0) {
-#ifdef STBA_MEGA_WBL2
-            if (type != TASK_U && type != TASK_UQ) asm volatile("buffer_wbl2 sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
-#endif
             if (type == TASK_D) __hip_atomic_fetch_add(&dflag[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             else if (type == TASK_T) __hip_atomic_fetch_add(&tflag[b * nblk + ti], 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             else if (type == TASK_TU) __hip_atomic_fetch_add(&tflag[b * nblk + b + 1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (ver: inside the task)
@@ -1438,8 +1398,6 @@ static int chol_run(double* A, int lda, int n, double* x_dev, int* flag_dev, hip
         memcpy(ma.qstart, plan.qstart, sizeof ma.qstart);
         memcpy(ma.xcc_queue, plan.xcc_queue, sizeof ma.xcc_queue);
         ma.linv = linv; ma.linv_stride = LINV_STRIDE; ma.flag = flag_dev;
-        static const int OPT = [] { const char* e = getenv("STBA_MEGA_OPT"); return e ? atoi(e) : 0; }();
-        ma.opt = OPT;
         static const char* TRACE = getenv("STBA_MEGA_TRACE");
         ma.trace = nullptr;
         if (TRACE) STBA_HIP(hipMalloc(reinterpret_cast<void**>(&ma.trace), (size_t)plan.ntasks * 8 * sizeof(long long)));
