@@ -626,7 +626,17 @@ __global__ __launch_bounds__(SCHUR_THREADS) void ba_schur_pairs_kernel(SchurRowA
     for (int e = tid; e < ncols * SCHUR_BLK_LD; e += SCHUR_THREADS) acc[e] = 0.0;
     if (tid < 8) racc[tid] = 0.0;
     for (int e = tid; e < ncols; e += SCHUR_THREADS) cols[e] = a.row_cols[col0 + e];
-    __syncthreads();
+    if (a.zero_rows) {
+        // this row's six rows of S are zeroed HERE (up to the end of the diagonal 128-tile; nothing right of it
+        // is ever read) instead of by a 288 MB memset in front of the kernel: the stores drain under the
+        // LDS-atomic-bound pair loop.  (Only when every camera row is a single task.)
+        const int cend = min(a.lda, ((c * 6 + 5) / 128 + 1) * 128);
+        for (int q = 0; q < 6; ++q) {
+            double* row = a.S + (size_t)(c * 6 + q) * a.lda;
+            for (int e = tid; e < cend; e += SCHUR_THREADS) row[e] = 0.0;
+        }
+    }
+    __syncthreads();                             // (also orders the zero stores before the block stores below)
     const int ke = a.pair_end[task];
     for (int k = a.pair_begin[task] + tid; k < ke; k += SCHUR_THREADS) {
         const int2 il = a.pair_il[k];

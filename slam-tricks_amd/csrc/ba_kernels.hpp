@@ -60,6 +60,7 @@ struct SchurRowArgs {
     const int2* pair_il; const unsigned short* pair_slot;   // slot | 0x8000 if diagonal block | 0x4000 if l == i
     double* Eb;                                      // per observation: E = (Jc^T Jp) Hinv (18) and E gp (6)
     int n_obs;
+    int zero_rows;                                   // the pair kernel zeroes its rows of S itself (no memset of S)
 };
 size_t schur_rows_lds_bytes(int max_cols);
 int launch_schur_rows(const SchurRowArgs& a, int n_tasks, hipStream_t st);

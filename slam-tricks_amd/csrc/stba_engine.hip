@@ -82,6 +82,7 @@ struct stba_ba {
     int2* pair_il = nullptr;
     unsigned short* pair_slot = nullptr;
     double* Eb = nullptr;
+    bool all_single = false;            // every camera row is ONE Schur task and every camera has a task
     unsigned char *cam_fixed = nullptr, *pt_fixed = nullptr;
     double2* r = nullptr;
     double *Jc = nullptr, *Jp = nullptr;
@@ -190,8 +191,11 @@ static int ba_build_reduced(stba_ba* b, const Damping& dm) {
         STBA_TRY(launch_lm_diagonal(3 * b->np, 3, 6, 1, b->Hpp6, b->scale_p, init_scale, dm.use_scaling, dm.radius,
                                     dm.dmin, dm.dmax, b->dp, b->st));
     STBA_TRY(launch_point_invert(b->np, b->Hpp6, b->dp, b->pt_fixed, b->Hinv6, b->st));
-    const size_t zero_count = (size_t)b->lda * b->lda + 3 * (size_t)b->lda;   // scalar slots are kept
-    STBA_HIP(hipMemsetAsync(b->Sbuf, 0, zero_count * sizeof(double), b->st));
+    // S is zeroed by the pair-plan Schur kernel itself when every camera row is one task; the three extras
+    // vectors behind it (diag, gc, rhs) always here (the scalar slots are kept)
+    const bool self_zero = b->pair_il != nullptr && b->all_single;
+    if (self_zero) STBA_HIP(hipMemsetAsync(b->Sbuf + (size_t)b->lda * b->lda, 0, 3 * (size_t)b->lda * sizeof(double), b->st));
+    else STBA_HIP(hipMemsetAsync(b->Sbuf, 0, ((size_t)b->lda * b->lda + 3 * (size_t)b->lda) * sizeof(double), b->st));
     if (b->n_tasks > 0) {
         SchurRowArgs sa;
         sa.task_cam = b->task_cam; sa.task_begin = b->task_begin; sa.task_end = b->task_end;
@@ -200,7 +204,7 @@ static int ba_build_reduced(stba_ba* b, const Damping& dm) {
         sa.pt_start = b->pt_start; sa.Jc = b->Jc; sa.Jp = b->Jp; sa.Hinv6 = b->Hinv6; sa.gp = b->gp;
         sa.S = b->S(); sa.lda = b->lda; sa.rhs = b->rhs();
         sa.pair_begin = b->pair_begin; sa.pair_end = b->pair_end; sa.pair_il = b->pair_il; sa.pair_slot = b->pair_slot;
-        sa.Eb = b->Eb; sa.n_obs = b->no;
+        sa.Eb = b->Eb; sa.n_obs = b->no; sa.zero_rows = self_zero ? 1 : 0;
         STBA_TRY(launch_schur_rows(sa, b->n_tasks, b->st));
     } else {
         STBA_TRY(launch_schur(b->no, b->obs_cam, b->obs_pt, b->pt_start, b->Jc, b->Jp, b->Hinv6, b->gp, b->S(),
@@ -671,6 +675,7 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
     const bool row_plan = max_cols <= SCHUR_MAX_COLS;
     b->n_tasks = row_plan ? (int)task_cam.size() : 0;
     b->max_cols = max_cols;
+    b->all_single = row_plan && (int)task_cam.size() == n_cams;     // one task per camera, none split, none missing
     // pair plan: (i, l, slot) of every block contribution of every task, in task order
     std::vector<int> pair_begin, pair_end;
     std::vector<int2> pair_il;
