@@ -245,6 +245,10 @@ void stba_pcg_default_options(stba_pcg_options* o);
 int stba_pg_create(stba_pg** out, int n_nodes, int n_edges, const double* poses, const int* edge_i, const int* edge_j,
                    const double* meas, const unsigned char* node_fixed, void* hip_stream);
 int stba_pg_destroy(stba_pg* pg);
+/* multi-GPU: this engine holds one shard of the EDGES (all nodes replicated); the hook sums the gradient and
+ * diagonal blocks (42 n doubles per linearisation), every matrix-vector product of the PCG (6 n doubles) and
+ * the cost scalars across ranks.  rank 0 owns the once-only damping term. */
+int stba_pg_set_allreduce(stba_pg* pg, stba_allreduce_fn fn, void* user, int rank, int world_size);
 int stba_pg_get_poses(stba_pg* pg, double* poses);
 /* r[n_edges*6], Ji / Jj [n_edges*36] (6x6 row-major, wrt delta_i / delta_j); any may be NULL */
 int stba_pg_evaluate(stba_pg* pg, double* cost, double* r, double* Ji, double* Jj);

@@ -67,7 +67,7 @@ EXPORTS = ["stba_status_string", "stba_last_error", "stba_version", "stba_device
            "stba_ba_back_substitute", "stba_ba_apply_step", "stba_ba_solve", "stba_ba_lm_iterations",
            "stba_ba_triangulate", "stba_ba_time_linearize", "stba_cholesky_factor", "stba_cholesky_solve",
            "stba_cholesky_time", "stba_cholesky_time_split", "stba_cholesky_profile", "stba_calib_evaluate", "stba_calib_gauss_newton",
-           "stba_pcg_default_options", "stba_pg_create", "stba_pg_destroy", "stba_pg_get_poses", "stba_pg_evaluate",
+           "stba_pcg_default_options", "stba_pg_create", "stba_pg_destroy", "stba_pg_set_allreduce", "stba_pg_get_poses", "stba_pg_evaluate",
            "stba_pg_solve", "stba_dense_solve", "stba_corners_read", "stba_corners_write", "stba_zhang_init", "stba_two_view_init"]
 
 
@@ -264,6 +264,11 @@ class PGEngine:
             self.close()
         except Exception:
             pass
+
+    def set_allreduce(self, fn, rank, world):
+        cb = ALLREDUCE_FN(fn)
+        self._keep = getattr(self, "_keep", []) + [cb]
+        _chk(lib().stba_pg_set_allreduce(self._h, cb, None, rank, world), "stba_pg_set_allreduce")
 
     def get_poses(self):
         out = np.zeros((self.n, 7))

@@ -399,15 +399,21 @@ struct stba_pg {
            *part_e = nullptr, *part_a = nullptr, *part_b = nullptr, *part_c = nullptr;
     unsigned char* fixed = nullptr;
     int nb_nodes = 1, nb_vec = 1, nb_edges = 1;
+    // multi-GPU: this engine holds one shard of the EDGES, all nodes are replicated; the hook sums the
+    // gradient | diagonal blocks, every matrix-vector product and the cost across ranks
+    stba_allreduce_fn ar = nullptr;
+    void* ar_user = nullptr;
+    int rank = 0, world = 1;
+    double* scalar = nullptr;           // one device double for the cost sums
 };
 
 namespace stba {
 namespace {
 void pg_free(stba_pg* g) {
     auto F = [](void* p) { if (p) (void)hipFree(p); };
-    F(g->poses[0]); F(g->poses[1]); F(g->ei); F(g->ej); F(g->meas); F(g->r); F(g->Ji); F(g->Jj); F(g->g); F(g->Hd);
+    F(g->poses[0]); F(g->poses[1]); F(g->ei); F(g->ej); F(g->meas); F(g->r); F(g->Ji); F(g->Jj); F(g->g);
     F(g->Minv); F(g->d); F(g->scale); F(g->x); F(g->rr); F(g->z); F(g->p); F(g->q); F(g->part_e); F(g->part_a);
-    F(g->part_b); F(g->part_c); F(g->fixed);
+    F(g->part_b); F(g->part_c); F(g->fixed); F(g->scalar);
     if (g->own && g->st) (void)hipStreamDestroy(g->st);
     delete g;
 }
@@ -428,11 +434,25 @@ int pg_linearize(stba_pg* g, int which, bool jac) {
     return STBA_OK;
 }
 
-// q = (J^T J [+ D]) v
+// q = (J^T J [+ D]) v.  Sharded: every rank applies its edges, rank 0 alone adds the diagonal term, and the
+// hook sums the 6n-vector (the only data-path collective of a PCG iteration: every other vector operation
+// is replicated and bit-identical on all ranks).
 int pg_apply(stba_pg* g, const double* v, double* q, bool with_d) {
-    hipLaunchKernelGGL(pg_diag_mul_kernel, dim3(g->nb_vec), dim3(256), 0, g->st, 6 * g->n, g->d, v, q, with_d ? 1 : 0);
+    hipLaunchKernelGGL(pg_diag_mul_kernel, dim3(g->nb_vec), dim3(256), 0, g->st, 6 * g->n, g->d, v, q,
+                       (with_d && g->rank == 0) ? 1 : 0);
     hipLaunchKernelGGL(pg_matvec_kernel, dim3(g->nb_edges), dim3(256), 0, g->st, g->m, g->ei, g->ej, g->Ji, g->Jj, v, q);
     STBA_HIP(hipGetLastError());
+    if (g->ar && g->ar(g->ar_user, q, (size_t)6 * g->n, g->st) != 0) return fail(STBA_ERR_CALLBACK, "all-reduce hook failed");
+    return STBA_OK;
+}
+
+// sum of a host scalar across ranks (through one device double and the hook)
+int pg_sum_ranks(stba_pg* g, double* v) {
+    if (!g->ar) return STBA_OK;
+    STBA_HIP(hipMemcpyAsync(g->scalar, v, sizeof(double), hipMemcpyHostToDevice, g->st));
+    if (g->ar(g->ar_user, g->scalar, 1, g->st) != 0) return fail(STBA_ERR_CALLBACK, "all-reduce hook failed");
+    STBA_HIP(hipMemcpyAsync(v, g->scalar, sizeof(double), hipMemcpyDeviceToHost, g->st));
+    STBA_HIP(hipStreamSynchronize(g->st));
     return STBA_OK;
 }
 }  // namespace
@@ -468,7 +488,8 @@ int stba_pg_create(stba_pg** out, int n_nodes, int n_edges, const double* poses,
     const size_t n = (size_t)n_nodes, m = (size_t)n_edges;
     A_(dalloc(&g->poses[0], n * 7)); A_(dalloc(&g->poses[1], n * 7)); A_(dalloc(&g->ei, m)); A_(dalloc(&g->ej, m));
     A_(dalloc(&g->meas, m * 7)); A_(dalloc(&g->r, m * 6)); A_(dalloc(&g->Ji, m * 36)); A_(dalloc(&g->Jj, m * 36));
-    A_(dalloc(&g->g, n * 6)); A_(dalloc(&g->Hd, n * 36)); A_(dalloc(&g->Minv, n * 36)); A_(dalloc(&g->d, n * 6));
+    A_(dalloc(&g->g, n * 42)); g->Hd = g->g + n * 6;      // [gradient 6n | diagonal blocks 36n]: one cross-rank sum
+    A_(dalloc(&g->Minv, n * 36)); A_(dalloc(&g->d, n * 6)); A_(dalloc(&g->scalar, 1));
     A_(dalloc(&g->scale, n * 6)); A_(dalloc(&g->x, n * 6)); A_(dalloc(&g->rr, n * 6)); A_(dalloc(&g->z, n * 6));
     A_(dalloc(&g->p, n * 6)); A_(dalloc(&g->q, n * 6));
     const size_t np_ = (size_t)std::max(g->nb_vec, std::max(g->nb_nodes, g->nb_edges)) * 2 + 2;
@@ -483,6 +504,13 @@ int stba_pg_create(stba_pg** out, int n_nodes, int n_edges, const double* poses,
         hipStreamSynchronize(g->st) != hipSuccess)
         return bail(fail(STBA_ERR_HIP, "stba_pg_create: upload failed"));
     *out = g;
+    return STBA_OK;
+}
+
+int stba_pg_set_allreduce(stba_pg* g, stba_allreduce_fn fn, void* user, int rank, int world_size) {
+    if (!g || rank < 0 || world_size < 1 || rank >= world_size) return fail(STBA_ERR_INVALID_ARGUMENT, "bad argument");
+    g->ar = (world_size > 1 || fn) ? fn : nullptr;
+    g->ar_user = user; g->rank = rank; g->world = world_size;
     return STBA_OK;
 }
 
@@ -504,7 +532,8 @@ int stba_pg_evaluate(stba_pg* g, double* cost, double* r, double* Ji, double* Jj
     if (!g) return fail(STBA_ERR_INVALID_ARGUMENT, "null engine");
     STBA_TRY(pg_linearize(g, g->cur, true));
     std::vector<double> buf;
-    const double c2 = host_sum(g->st, g->part_e, g->nb_edges, 1, 0, buf);
+    double c2 = host_sum(g->st, g->part_e, g->nb_edges, 1, 0, buf);
+    STBA_TRY(pg_sum_ranks(g, &c2));
     if (cost) *cost = 0.5 * c2;
     if (r) STBA_HIP(hipMemcpyAsync(r, g->r, (size_t)g->m * 6 * sizeof(double), hipMemcpyDeviceToHost, g->st));
     if (Ji) STBA_HIP(hipMemcpyAsync(Ji, g->Ji, (size_t)g->m * 36 * sizeof(double), hipMemcpyDeviceToHost, g->st));
@@ -529,11 +558,13 @@ int stba_pg_solve(stba_pg* g, const stba_lm_options* opt_in, const stba_pcg_opti
 
     auto linearize_full = [&](double* cost, double* gmax) -> int {
         STBA_TRY(pg_linearize(g, g->cur, true));
-        *cost = 0.5 * host_sum(g->st, g->part_e, g->nb_edges, 1, 0, buf);
-        STBA_HIP(hipMemsetAsync(g->g, 0, (size_t)N * sizeof(double), g->st));
-        STBA_HIP(hipMemsetAsync(g->Hd, 0, (size_t)g->n * 36 * sizeof(double), g->st));
+        double c2 = host_sum(g->st, g->part_e, g->nb_edges, 1, 0, buf);
+        STBA_TRY(pg_sum_ranks(g, &c2));
+        *cost = 0.5 * c2;
+        STBA_HIP(hipMemsetAsync(g->g, 0, (size_t)g->n * 42 * sizeof(double), g->st));
         hipLaunchKernelGGL(pg_accumulate_kernel, dim3((2 * g->m + 255) / 256), dim3(256), 0, g->st, g->m, g->ei, g->ej, g->r,
                            g->Ji, g->Jj, g->g, g->Hd);
+        if (g->ar && g->ar(g->ar_user, g->g, (size_t)g->n * 42, g->st) != 0) return fail(STBA_ERR_CALLBACK, "all-reduce hook failed");
         STBA_TRY(launch_absmax(g->g, (size_t)N, nullptr, 0, g->part_c, g->part_a, g->nb_vec, g->st));
         double gm = 0.0;
         STBA_HIP(hipMemcpyAsync(&gm, g->part_c, sizeof(double), hipMemcpyDeviceToHost, g->st));
@@ -598,7 +629,9 @@ int stba_pg_solve(stba_pg* g, const stba_lm_options* opt_in, const stba_pcg_opti
         const double step2 = host_sum(g->st, part_upd, g->nb_nodes, 2, 0, buf);
         double x2 = 0.0;
         for (int b = 0; b < g->nb_nodes; ++b) x2 += buf[(size_t)b * 2 + 1];
-        const double new_cost = 0.5 * host_sum(g->st, g->part_e, g->nb_edges, 1, 0, buf);
+        double nc2 = host_sum(g->st, g->part_e, g->nb_edges, 1, 0, buf);
+        STBA_TRY(pg_sum_ranks(g, &nc2));
+        const double new_cost = 0.5 * nc2;
         const double model_change = -gx - 0.5 * xhx;
         const double step_norm = std::sqrt(step2), x_norm = std::sqrt(x2);
         ok = ok && model_change > 0.0 && std::isfinite(model_change) && std::isfinite(new_cost);

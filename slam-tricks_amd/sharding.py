@@ -41,6 +41,17 @@ class DeviceVector:
                                          "version": 2, "strides": None}
 
 
+def make_pg_shard(scene, rank, world):
+    """pose graph (BASELINE C4): shard the EDGES into contiguous ranges, replicate the nodes"""
+    m = len(scene["edge_i"])
+    lo, hi = (m * rank) // world, (m * (rank + 1)) // world
+    out = dict(scene)
+    for k in ("edge_i", "edge_j", "meas"):
+        out[k] = scene[k][lo:hi]
+    out["lo"], out["hi"] = lo, hi
+    return out
+
+
 def torch_allreduce_hook(dist, torch):
     """all-reduce hook for BAEngine.set_allreduce: RCCL sum (torch.distributed, backend nccl) of the
     engine-owned device buffer, enqueued on the current stream -- the same stream the engine was

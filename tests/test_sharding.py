@@ -166,6 +166,58 @@ def test_two_shards_on_one_gpu(scenes, O):
 
 
 @pytest.mark.gpu
+def test_pose_graph_two_edge_shards_on_one_gpu(scenes):
+    """BASELINE C4 sharded: two engines hold half of the edges each (all nodes replicated); the hook sums
+    gradient | diagonal blocks, every PCG matrix-vector product and the costs.  Must follow the single engine."""
+    import torch
+    st = importlib.import_module("slam-tricks_amd")
+    sharding = importlib.import_module("slam-tricks_amd.sharding")
+    s = scenes.pose_graph_scene(n_nodes=400, loops_per_node=3, seed=4)
+    world = 2
+    bar = threading.Barrier(world)
+    slots = [None] * world
+    out = [None] * world
+
+    def make_hook(rank):
+        def hook(_u, buf, count, _stream):
+            t = torch.as_tensor(sharding.DeviceVector(buf, count), device="cuda")
+            torch.cuda.synchronize()
+            slots[rank] = t
+            bar.wait()
+            total = slots[0] + slots[1]
+            torch.cuda.synchronize()
+            bar.wait()
+            t.copy_(total)
+            torch.cuda.synchronize()
+            bar.wait()
+            return 0
+        return hook
+
+    def run(rank):
+        sh = sharding.make_pg_shard(s, rank, world)
+        e = st.PGEngine(sh["poses0"], sh["edge_i"], sh["edge_j"], sh["meas"], sh["node_fixed"])
+        e.set_allreduce(make_hook(rank), rank, world)
+        summ, tr, npcg = e.solve(max_num_iterations=6)
+        out[rank] = (summ, tr, npcg, e.get_poses())
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    assert all(o is not None for o in out)
+    e1 = st.PGEngine(s["poses0"], s["edge_i"], s["edge_j"], s["meas"], s["node_fixed"])
+    s1, tr1, n1 = e1.solve(max_num_iterations=6)
+    p1 = e1.get_poses()
+    for rank in range(world):
+        summ, tr, npcg, poses = out[rank]
+        assert summ.num_iterations == s1.num_iterations
+        assert np.allclose(tr[:, 0], tr1[:, 0], rtol=1e-8)
+        assert np.abs(poses - p1).max() < 1e-7
+    assert np.array_equal(out[0][3], out[1][3])             # replicated nodes stay bit-identical across "ranks"
+
+
+@pytest.mark.gpu
 def test_torch_hook_world1(scenes):
     """the production hook (torch view of the engine buffer + all_reduce) on a 1-rank group"""
     import torch
