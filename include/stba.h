@@ -203,6 +203,17 @@ int stba_cholesky_profile(int n, double* ms4, double* syrk_flops, double* syrk_f
 int stba_two_view_init(int n, const double* f1, const double* f2, const double* K, double* F_out, double* R_out,
                        double* t_out, double* pts_out, int* fails_out, void* hip_stream);
 
+/* ================================ trajectories ============================== */
+/* Odometry files, st16-pcl-viewer/src/src/scene.cpp:66-110: "format ascii 1.0", "element odometryInfo N",
+ * property lines, "end_header", then N lines "timeStamp qx qy qz qw x y z" (quaternion normalised on read,
+ * translation parsed through float like the reference's std::stof).  poses: N*7 (qx qy qz qw x y z), the
+ * layout of stba_pg_create; pass stamps = poses = NULL to query N. */
+int stba_odometry_read(const char* path, int* n_poses, double* stamps, double* poses, int capacity);
+int stba_odometry_write(const char* path, int n_poses, const double* stamps, const double* poses);
+/* absolute trajectory error, st4-kalman/src/src/pose_simulation.cpp:198-209:
+ * sqrt(mean |log(T_truth^-1 T_estimate)|^2), 6-vector SE3 logarithm */
+int stba_trajectory_ate(int n_poses, const double* truth, const double* estimate, double* ate);
+
 /* ================================ calibration data formats ================== */
 /* Chessboard corner files, st3-calibration/src/src/cbcorner.cpp:34-73: header "rows,cols", then one
  * "i,j,x,y" line per corner (x, y parsed through float like the reference's std::stof; written with

@@ -68,7 +68,7 @@ EXPORTS = ["stba_status_string", "stba_last_error", "stba_version", "stba_device
            "stba_ba_triangulate", "stba_ba_time_linearize", "stba_cholesky_factor", "stba_cholesky_solve",
            "stba_cholesky_time", "stba_cholesky_time_split", "stba_cholesky_profile", "stba_calib_evaluate", "stba_calib_gauss_newton",
            "stba_pcg_default_options", "stba_pg_create", "stba_pg_destroy", "stba_pg_set_allreduce", "stba_pg_get_poses", "stba_pg_evaluate",
-           "stba_pg_solve", "stba_dense_solve", "stba_corners_read", "stba_corners_write", "stba_zhang_init", "stba_two_view_init"]
+           "stba_pg_solve", "stba_dense_solve", "stba_corners_read", "stba_corners_write", "stba_zhang_init", "stba_two_view_init", "stba_odometry_read", "stba_odometry_write", "stba_trajectory_ate"]
 
 
 def lib():
@@ -341,6 +341,29 @@ def two_view_init(f1, f2, K, points=True, stream=None):
     _chk(lib().stba_two_view_init(n, _p(f1), _p(f2), _p(K), _p(F), _p(R), _p(t), _p(pts) if points else None,
                                   fails.ctypes.data_as(C.POINTER(C.c_int)), C.c_void_p(stream or 0)), "stba_two_view_init")
     return dict(F=F, R=R, t=t, pts=pts, fails=fails)
+
+
+def odometry_read(path):
+    """odometry file (st16 scene.cpp:66-110) -> (stamps[n], poses[n, 7] = qx qy qz qw x y z)"""
+    n = C.c_int()
+    _chk(lib().stba_odometry_read(path.encode(), C.byref(n), None, None, 0), "stba_odometry_read")
+    stamps = np.zeros(n.value); poses = np.zeros((n.value, 7))
+    _chk(lib().stba_odometry_read(path.encode(), C.byref(n), _p(stamps), _p(poses), n.value), "stba_odometry_read")
+    return stamps, poses
+
+
+def odometry_write(path, stamps, poses):
+    poses = _f64(poses).reshape(-1, 7)
+    st_ = None if stamps is None else _f64(stamps)
+    _chk(lib().stba_odometry_write(path.encode(), len(poses), _p(st_), _p(poses)), "stba_odometry_write")
+
+
+def trajectory_ate(truth, estimate):
+    """absolute trajectory error (st4 pose_simulation.cpp:198-209) of two (n, 7) pose sequences"""
+    a, b = _f64(truth).reshape(-1, 7), _f64(estimate).reshape(-1, 7)
+    out = C.c_double()
+    _chk(lib().stba_trajectory_ate(len(a), _p(a), _p(b), C.byref(out)), "stba_trajectory_ate")
+    return out.value
 
 
 def corners_read(path):

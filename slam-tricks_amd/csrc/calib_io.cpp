@@ -185,3 +185,102 @@ int stba_zhang_init(int n_views, int n_corners, const double* obj, const double*
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------------------------
+// Trajectory files and the accuracy metric of the pose-graph path, host C++:
+//   * odometry files, st16-pcl-viewer/src/src/scene.cpp:66-110 (ReadOdom): "format ascii 1.0" /
+//     "element odometryInfo N" / property lines / "end_header", then N lines "timeStamp qx qy qz qw x y z";
+//     the quaternion is normalised, the translation goes through float (std::stof) like in the reference
+//   * absolute trajectory error, st4-kalman/src/src/pose_simulation.cpp:198-209:
+//     sqrt(mean_i |log(T_truth_i^-1 T_est_i)|^2) over the 6-vector SE3 logarithm
+// ------------------------------------------------------------------------------------------------------------
+namespace stba {
+namespace {
+void quat_mul(const double* a, const double* b, double* o) {     // (x, y, z, w)
+    o[0] = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+    o[1] = a[3] * b[1] - a[0] * b[2] + a[1] * b[3] + a[2] * b[0];
+    o[2] = a[3] * b[2] + a[0] * b[1] - a[1] * b[0] + a[2] * b[3];
+    o[3] = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+}
+}  // namespace
+}  // namespace stba
+
+extern "C" {
+
+int stba_odometry_read(const char* path, int* n_poses, double* stamps, double* poses, int capacity) {
+    if (!path || !n_poses) return fail(STBA_ERR_INVALID_ARGUMENT, "null argument");
+    std::ifstream f(path);
+    if (!f) return fail(STBA_ERR_INVALID_ARGUMENT, std::string("cannot open ") + path);
+    std::string line;
+    if (!std::getline(f, line)) return fail(STBA_ERR_INVALID_ARGUMENT, "odometry file: empty");       // format line
+    if (!std::getline(f, line)) return fail(STBA_ERR_INVALID_ARGUMENT, "odometry file: no element line");
+    int n = -1;
+    {
+        char a[64], b[64];
+        if (std::sscanf(line.c_str(), "%63s %63s %d", a, b, &n) != 3 || n < 0)
+            return fail(STBA_ERR_INVALID_ARGUMENT, "odometry file: bad element line");
+    }
+    bool header_done = false;
+    while (std::getline(f, line))
+        if (line.size() >= 10 && line.compare(0, 10, "end_header") == 0) { header_done = true; break; }
+    if (!header_done) return fail(STBA_ERR_INVALID_ARGUMENT, "odometry file: no end_header");
+    *n_poses = n;
+    if (!poses && !stamps) return STBA_OK;                      // size query
+    if (capacity < n) return fail(STBA_ERR_INVALID_ARGUMENT, "odometry buffer too small");
+    for (int i = 0; i < n; ++i) {
+        if (!std::getline(f, line)) return fail(STBA_ERR_INVALID_ARGUMENT, "odometry file: fewer poses than announced");
+        double ts, q[4];
+        float t[3];
+        if (std::sscanf(line.c_str(), "%lf %lf %lf %lf %lf %f %f %f", &ts, &q[0], &q[1], &q[2], &q[3], &t[0], &t[1], &t[2]) != 8)
+            return fail(STBA_ERR_INVALID_ARGUMENT, "odometry file: bad pose line");
+        const double nq = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+        if (!(nq > 0.0)) return fail(STBA_ERR_INVALID_ARGUMENT, "odometry file: zero quaternion");
+        if (stamps) stamps[i] = ts;
+        if (poses) {
+            for (int k = 0; k < 4; ++k) poses[7 * (size_t)i + k] = q[k] / nq;
+            for (int k = 0; k < 3; ++k) poses[7 * (size_t)i + 4 + k] = (double)t[k];
+        }
+    }
+    return STBA_OK;
+}
+
+int stba_odometry_write(const char* path, int n_poses, const double* stamps, const double* poses) {
+    if (!path || n_poses < 0 || !poses) return fail(STBA_ERR_INVALID_ARGUMENT, "bad argument");
+    FILE* f = std::fopen(path, "w");
+    if (!f) return fail(STBA_ERR_INVALID_ARGUMENT, std::string("cannot open ") + path);
+    std::fprintf(f, "format ascii 1.0\nelement odometryInfo %d\nproperty double timeStamp\nproperty double qx\nproperty double qy\n"
+                    "property double qz\nproperty double qw\nproperty double x\nproperty double y\nproperty double z\nend_header\n", n_poses);
+    for (int i = 0; i < n_poses; ++i) {
+        const double* p = poses + 7 * (size_t)i;
+        std::fprintf(f, "%.9f %.10f %.10f %.10f %.10f %.10f %.10f %.10f\n", stamps ? stamps[i] : (double)i, p[0], p[1], p[2], p[3],
+                     p[4], p[5], p[6]);
+    }
+    std::fclose(f);
+    return STBA_OK;
+}
+
+int stba_trajectory_ate(int n_poses, const double* truth, const double* estimate, double* ate) {
+    if (n_poses <= 0 || !truth || !estimate || !ate) return fail(STBA_ERR_INVALID_ARGUMENT, "bad argument");
+    double s = 0.0;
+    for (int i = 0; i < n_poses; ++i) {
+        const double* a = truth + 7 * (size_t)i;
+        const double* b = estimate + 7 * (size_t)i;
+        // D = A^-1 B:  q = conj(qa) qb,  t = Ra^T (tb - ta)
+        const double qc[4] = {-a[0], -a[1], -a[2], a[3]};
+        double q[4], Ra[9], R[9];
+        quat_mul(qc, b, q);
+        if (q[3] < 0) for (double& x : q) x = -x;
+        quat_to_rot(a, Ra);
+        quat_to_rot(q, R);
+        const double d[3] = {b[4] - a[4], b[5] - a[5], b[6] - a[6]};
+        const double t[3] = {Ra[0] * d[0] + Ra[3] * d[1] + Ra[6] * d[2], Ra[1] * d[0] + Ra[4] * d[1] + Ra[7] * d[2],
+                             Ra[2] * d[0] + Ra[5] * d[1] + Ra[8] * d[2]};
+        double xi[6];
+        se3_log_rt(R, t, xi);
+        for (int k = 0; k < 6; ++k) s += xi[k] * xi[k];
+    }
+    *ate = std::sqrt(s / n_poses);
+    return STBA_OK;
+}
+
+}  // extern "C"

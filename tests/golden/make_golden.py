@@ -3,6 +3,7 @@ expected values the reference records for them.  Run once in the build container
 place /root/reference exists); the outputs are committed, this script documents their origin.
 
   st3_calib/1..9.txt     <- st3-calibration/calib/1..9.txt      chessboard corners (data files)
+  st16_odom/odometryInfo.txt <- st16-pcl-viewer/data/odom_lidar/odometryInfo.txt   70 poses (data file)
   st7_ransac/*.csv       <- st7-ransac/data/{good,bad}.csv      parabola samples (data files)
   st6_icp/*.csv          <- st6-icp/log/binding/*.csv           ICP logs (data files)
   known_answers.json     <- values the reference itself publishes:
@@ -22,6 +23,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 def main():
     for i in range(1, 10):
         shutil.copy(f"{REF}/st3-calibration/calib/{i}.txt", f"{HERE}/st3_calib/{i}.txt")
+    os.makedirs(f"{HERE}/st16_odom", exist_ok=True)
+    shutil.copy(f"{REF}/st16-pcl-viewer/data/odom_lidar/odometryInfo.txt", f"{HERE}/st16_odom/odometryInfo.txt")
     for f in ("good.csv", "bad.csv"):
         shutil.copy(f"{REF}/st7-ransac/data/{f}", f"{HERE}/st7_ransac/{f}")
     for f in ("pc1.csv", "pc2.csv", "pc1_prime_1.csv", "pc1_prime_2.csv"):
