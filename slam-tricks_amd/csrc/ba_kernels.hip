@@ -584,36 +584,10 @@ __global__ __launch_bounds__(SCHUR_THREADS) void ba_schur_rows_kernel(SchurRowAr
 // Pair-plan variant of the row-wise Schur kernel.  The row kernel above walks, per observation, the other
 // observations of its landmark in a serial loop of dependent loads (camera index -> binary search -> Jacobian
 // rows): latency-bound, 0.52 ms at C5.  Here the pairs of a camera row are enumerated ON THE HOST once
-// (the structure is static), with the LDS slot of every pair's block resolved; a pre-pass computes
-// E_i = (Jc_i^T Jp_i) Hinv_j and E_i gp_j per observation; then one lane handles one PAIR: two independent
-// 144 B gathers (E_i, J_l), 108 FMAs, 36 LDS atomics -- every iteration of every lane is independent.
+// (the structure is static), with the LDS slot of every pair's block resolved; then one lane handles one
+// PAIR: two independent 144 B gathers (J_i, J_l) plus the landmark's inverse block, ~220 FMAs, 36 LDS
+// atomics -- every iteration of every lane is independent.
 // -------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ba_schur_prep_kernel(int n_obs, const int* __restrict__ obs_pt,
-                                                            const double* __restrict__ Jc, const double* __restrict__ Jp,
-                                                            const double* __restrict__ Hinv6, const double* __restrict__ gp,
-                                                            double* __restrict__ Eb) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n_obs) return;
-    const int j = obs_pt[i];
-    double Hi[6], jc[12], jp[6];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) Hi[k] = Hinv6[(size_t)j * 6 + k];
-    load_jc_jp(Jc, Jp, i, jc, jp);
-    const double g0 = gp[(size_t)j * 3], g1 = gp[(size_t)j * 3 + 1], g2 = gp[(size_t)j * 3 + 2];
-    double* out = Eb + (size_t)i * 24;
-#pragma unroll
-    for (int q = 0; q < 6; ++q) {
-        const double w0 = jc[q] * jp[0] + jc[6 + q] * jp[3];
-        const double w1 = jc[q] * jp[1] + jc[6 + q] * jp[4];
-        const double w2 = jc[q] * jp[2] + jc[6 + q] * jp[5];
-        const double e0 = w0 * Hi[0] + w1 * Hi[1] + w2 * Hi[2];
-        const double e1 = w0 * Hi[1] + w1 * Hi[3] + w2 * Hi[4];
-        const double e2 = w0 * Hi[2] + w1 * Hi[4] + w2 * Hi[5];
-        out[q * 3] = e0; out[q * 3 + 1] = e1; out[q * 3 + 2] = e2;
-        out[18 + q] = e0 * g0 + e1 * g1 + e2 * g2;
-    }
-}
-
 __global__ __launch_bounds__(SCHUR_THREADS) void ba_schur_pairs_kernel(SchurRowArgs a) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int task = blockIdx.x;
@@ -641,18 +615,34 @@ __global__ __launch_bounds__(SCHUR_THREADS) void ba_schur_pairs_kernel(SchurRowA
     for (int k = a.pair_begin[task] + tid; k < ke; k += SCHUR_THREADS) {
         const int2 il = a.pair_il[k];
         const unsigned sl = a.pair_slot[k];
-        const double2* pe = reinterpret_cast<const double2*>(a.Eb + (size_t)il.x * 24);
+        // E_i = (Jc_i^T Jp_i) Hinv_j recomputed per pair (its inputs are cache-resident for the ~5 consecutive
+        // pairs of one observation; the kernel is bound by the LDS atomics, not by this arithmetic)
         double E[18], jc2[12], jp2[6];
+        {
+            const int j = a.obs_pt[il.x];
+            double Hi[6], jc[12], jp[6];
 #pragma unroll
-        for (int m = 0; m < 9; ++m) { const double2 v = pe[m]; E[2 * m] = v.x; E[2 * m + 1] = v.y; }
-        load_jc_jp(a.Jc, a.Jp, il.y, jc2, jp2);
-        if (sl & 0x4000u) {                      // l == i: this observation's share of the right-hand side
+            for (int k2 = 0; k2 < 6; ++k2) Hi[k2] = a.Hinv6[(size_t)j * 6 + k2];
+            load_jc_jp(a.Jc, a.Jp, il.x, jc, jp);
 #pragma unroll
             for (int q = 0; q < 6; ++q) {
-                const double v = a.Eb[(size_t)il.x * 24 + 18 + q];
-                if (v != 0.0) unsafeAtomicAdd(&racc[q], v);
+                const double w0 = jc[q] * jp[0] + jc[6 + q] * jp[3];
+                const double w1 = jc[q] * jp[1] + jc[6 + q] * jp[4];
+                const double w2 = jc[q] * jp[2] + jc[6 + q] * jp[5];
+                E[q * 3 + 0] = w0 * Hi[0] + w1 * Hi[1] + w2 * Hi[2];
+                E[q * 3 + 1] = w0 * Hi[1] + w1 * Hi[3] + w2 * Hi[4];
+                E[q * 3 + 2] = w0 * Hi[2] + w1 * Hi[4] + w2 * Hi[5];
+            }
+            if (sl & 0x4000u) {                  // l == i: this observation's share of the right-hand side
+                const double g0 = a.gp[(size_t)j * 3], g1 = a.gp[(size_t)j * 3 + 1], g2 = a.gp[(size_t)j * 3 + 2];
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
+                    const double v = E[q * 3] * g0 + E[q * 3 + 1] * g1 + E[q * 3 + 2] * g2;
+                    if (v != 0.0) unsafeAtomicAdd(&racc[q], v);
+                }
             }
         }
+        load_jc_jp(a.Jc, a.Jp, il.y, jc2, jp2);
         const bool diag = (sl & 0x8000u) != 0;
         double* blk = acc + (size_t)(sl & 0x3fffu) * SCHUR_BLK_LD;
 #pragma unroll
@@ -702,8 +692,6 @@ int launch_schur_rows(const SchurRowArgs& a, int n_tasks, hipStream_t st) {
         attr_lds = lds;
     }
     if (a.pair_il) {
-        hipLaunchKernelGGL(ba_schur_prep_kernel, dim3((a.n_obs + 255) / 256), dim3(256), 0, st, a.n_obs, a.obs_pt, a.Jc, a.Jp,
-                           a.Hinv6, a.gp, a.Eb);
         hipLaunchKernelGGL(ba_schur_pairs_kernel, dim3(n_tasks), dim3(SCHUR_THREADS), lds, st, a);
     } else {
         hipLaunchKernelGGL(ba_schur_rows_kernel, dim3(n_tasks), dim3(SCHUR_THREADS), lds, st, a);

@@ -58,7 +58,6 @@ struct SchurRowArgs {
     // the same landmark with camera(l) <= camera(i)) with the LDS slot of its 6x6 block resolved on the host
     const int* pair_begin; const int* pair_end;      // per task
     const int2* pair_il; const unsigned short* pair_slot;   // slot | 0x8000 if diagonal block | 0x4000 if l == i
-    double* Eb;                                      // per observation: E = (Jc^T Jp) Hinv (18) and E gp (6)
     int n_obs;
     int zero_rows;                                   // the pair kernel zeroes its rows of S itself (no memset of S)
 };

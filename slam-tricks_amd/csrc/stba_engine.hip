@@ -81,7 +81,6 @@ struct stba_ba {
     int *pair_begin = nullptr, *pair_end = nullptr;
     int2* pair_il = nullptr;
     unsigned short* pair_slot = nullptr;
-    double* Eb = nullptr;
     bool all_single = false;            // every camera row is ONE Schur task and every camera has a task
     unsigned char *cam_fixed = nullptr, *pt_fixed = nullptr;
     double2* r = nullptr;
@@ -123,7 +122,7 @@ static void ba_free(stba_ba* b) {
     F(b->pt_fixed); F(b->r); F(b->Jc); F(b->Jp); F(b->Hpp6); F(b->gp); F(b->Hinv6); F(b->dp); F(b->scale_p);
     F(b->Hcc); F(b->gc); F(b->cam_partial); F(b->dc); F(b->scale_c); F(b->Sbuf); F(b->Spack); F(b->dxc); F(b->dxp);
     F(b->task_cam); F(b->task_begin); F(b->task_end); F(b->row_col_ptr); F(b->row_cols); F(b->task_single);
-    F(b->pair_begin); F(b->pair_end); F(b->pair_il); F(b->pair_slot); F(b->Eb);
+    F(b->pair_begin); F(b->pair_end); F(b->pair_il); F(b->pair_slot);
     F(b->cost_partial); F(b->upd_partial_c); F(b->upd_partial_p); F(b->trial); F(b->flag);
     for (auto& e : b->ev) if (e) (void)hipEventDestroy(e);
     if (b->lin_pin) (void)hipHostFree(b->lin_pin);
@@ -204,7 +203,7 @@ static int ba_build_reduced(stba_ba* b, const Damping& dm) {
         sa.pt_start = b->pt_start; sa.Jc = b->Jc; sa.Jp = b->Jp; sa.Hinv6 = b->Hinv6; sa.gp = b->gp;
         sa.S = b->S(); sa.lda = b->lda; sa.rhs = b->rhs();
         sa.pair_begin = b->pair_begin; sa.pair_end = b->pair_end; sa.pair_il = b->pair_il; sa.pair_slot = b->pair_slot;
-        sa.Eb = b->Eb; sa.n_obs = b->no; sa.zero_rows = self_zero ? 1 : 0;
+        sa.n_obs = b->no; sa.zero_rows = self_zero ? 1 : 0;
         STBA_TRY(launch_schur_rows(sa, b->n_tasks, b->st));
     } else {
         STBA_TRY(launch_schur(b->no, b->obs_cam, b->obs_pt, b->pt_start, b->Jc, b->Jp, b->Hinv6, b->gp, b->S(),
@@ -732,7 +731,6 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
         if (pair_plan && !pair_il.empty()) {
             A_(dev_alloc(&b->pair_begin, pair_begin.size())); A_(dev_alloc(&b->pair_end, pair_end.size()));
             A_(dev_alloc(&b->pair_il, pair_il.size())); A_(dev_alloc(&b->pair_slot, pair_slot.size()));
-            A_(dev_alloc(&b->Eb, no * 24));
         }
     }
     if (cam_fixed) A_(dev_alloc(&b->cam_fixed, nc));
