@@ -1122,6 +1122,7 @@ static void mega_build_tasks(int nblk, int nq, int wg_per_q, std::vector<int4>& 
     struct Node { int4 tk; std::vector<int> succ; int indeg = 0; double dur = 0, prio = 0; int q = 0; };
     std::vector<Node> nodes;
     const int NBK = nblk;
+    static const int QROWS = [] { const char* e = getenv("STBA_MEGA_QROWS"); return e ? atoi(e) : 2; }();
     std::vector<int> idD((size_t)NBK, -1), idTI((size_t)NBK, -1), idTU((size_t)NBK * 4, -1), idT((size_t)NBK * NBK, -1),
         idUq((size_t)NBK * NBK * 4, -1), idU((size_t)NBK * NBK * NBK, -1);
     // measured on MI355X (tools/mega_trace.py), microseconds, plus ~2 us of flag latency per hop
@@ -1144,8 +1145,15 @@ static void mega_build_tasks(int nblk, int nq, int wg_per_q, std::vector<int4>& 
             for (int q = 0; q < 4; ++q) idTU[(size_t)b * 4 + q] = add(TASK_TU, b, q, 0, 10.0 * b + 5);
         for (int i = b + 2; i < NBK; ++i) {
             idT[(size_t)b * NBK + i] = add(TASK_T, b, i, 0, 10.0 * b + 6 + 1e-3 * i);
-            for (int q = 0; q < 4; ++q)
-                idUq[((size_t)b * NBK + i) * 4 + q] = add(TASK_UQ, b, i * 4 + q, b + 1, 10.0 * (b + 1) + 2 + 1e-3 * i);
+            // the next panel's column: 32-row tasks (short latency) only for the rows the second critical chain
+            // needs soon; a quarter task costs 14.5 us of a workgroup against 23.4 us for a whole tile, so the
+            // rows further down take the whole-tile task (their panel solve comes a diagonal block later)
+            if (i <= b + 1 + QROWS) {
+                for (int q = 0; q < 4; ++q)
+                    idUq[((size_t)b * NBK + i) * 4 + q] = add(TASK_UQ, b, i * 4 + q, b + 1, 10.0 * (b + 1) + 2 + 1e-3 * i);
+            } else {
+                idUq[((size_t)b * NBK + i) * 4] = add(TASK_U, b, i, b + 1, 10.0 * (b + 1) + 2 + 1e-3 * i);
+            }
         }
         for (int j = b + 2; j < NBK; ++j)
             for (int i = j; i < NBK; ++i)
@@ -1177,6 +1185,7 @@ static void mega_build_tasks(int nblk, int nq, int wg_per_q, std::vector<int4>& 
                 for (int q2 = 0; q2 < 4; ++q2) dep(idUq[((size_t)(b - 1) * NBK + i) * 4 + q2], t);
             for (int q = 0; q < 4; ++q) {
                 const int uq = idUq[((size_t)b * NBK + i) * 4 + q];
+                if (uq < 0) continue;            // (rows with ONE whole-tile task use slot 0 only)
                 dep(t, uq);
                 for (int q2 = 0; q2 < 4; ++q2) dep(idTU[(size_t)b * 4 + q2], uq);
                 if (b > 0) dep(idU[((size_t)(b - 1) * NBK + i) * NBK + (b + 1)], uq);
