@@ -62,3 +62,27 @@ for b in (2, 5, 10, 20, 30, 40):
         line += f"TU{tasks[k,2]} tick {rel(tr[k,1]):7.1f} rdy {rel(tr[k,2]):6.1f} ph {rel(tr[k,4]):5.1f} {rel(tr[k,5]):5.1f} {rel(tr[k,6]):5.1f} done {rel(tr[k,3]):5.1f} | "
     line += f"D+1 tick {rel(tr[kd1,1]):7.1f} rdy {rel(tr[kd1,2]):6.1f}"
     print(line)
+# full chain table: every time relative to D(b).done
+print("\nchain table (us relative to D(b).done):  step = D(b+1).done - D(b).done")
+print("  b  step | TU tick  rdy  done | Ubb tick  rdy  done | Uq/U(b-1;b+1) tick rdy done | T(b-1,b+1) tick rdy done | D+1 tick rdy")
+key = {}
+for k in range(nt):
+    key[(int(tasks[k, 0]), int(tasks[k, 1]), int(tasks[k, 2]), int(tasks[k, 3]))] = k
+for b in range(1, len(dm) - 1):
+    kd = key[(0, b, 0, 0)]; kd1 = key[(0, b + 1, 0, 0)]
+    t0b = tr[kd, 3]
+    rel = lambda x: (x - t0b) / 100.0
+    tus = [key[(5, b, q, 0)] for q in range(4)]
+    ubb = key.get((3, b - 1, b + 1, b + 1))
+    uqs = [key[(4, b - 1, (b + 1) * 4 + q, b)] for q in range(4) if (4, b - 1, (b + 1) * 4 + q, b) in key]
+    tk = key.get((1, b - 1, b + 1, 0))
+    f = lambda ks, c, fn: fn(rel(tr[k, c]) for k in ks)
+    line = f"{b:3d} {(tr[kd1,3]-tr[kd,3])/100.0:5.1f} | {f(tus,1,max):6.1f} {f(tus,2,max):6.1f} {f(tus,3,max):6.1f} | "
+    if ubb is not None:
+        line += f"{rel(tr[ubb,1]):6.1f} {rel(tr[ubb,2]):6.1f} {rel(tr[ubb,3]):6.1f} | "
+    if uqs:
+        line += f"{f(uqs,1,max):6.1f} {f(uqs,2,max):6.1f} {f(uqs,3,max):6.1f} | "
+    if tk is not None:
+        line += f"{rel(tr[tk,1]):6.1f} {rel(tr[tk,2]):6.1f} {rel(tr[tk,3]):6.1f} | "
+    line += f"{rel(tr[kd1,1]):6.1f} {rel(tr[kd1,2]):6.1f}"
+    print(line)
