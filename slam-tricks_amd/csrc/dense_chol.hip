@@ -1101,18 +1101,38 @@ __global__ __launch_bounds__(512) void chol_mega_kernel(MegaArgs a) {
 
 // host side: the task list for nblk block columns (static per size), in one global dataflow order,
 // then split stably into one queue per XCD by the owner of the tile each task writes
-static int mega_owner(const int4& tk, int nq) {
-    // a tile belongs to the XCD of its tile ROW, rows dealt out boustrophedon so that the triangle is
-    // balanced: every task writes tiles of one row only (TU writes (b+1, b) and (b+1, b+1))
-    int row;
+static int mega_task_row(const int4& tk) {
+    // every task writes tiles of one tile row only (TU writes (b+1, b) and (b+1, b+1))
     switch (tk.x) {
-        case TASK_D: case TASK_TI: row = tk.y; break;
-        case TASK_TU: row = tk.y + 1; break;
-        case TASK_T: case TASK_U: row = tk.z; break;
-        default: row = tk.z >> 2; break;
+        case TASK_D: case TASK_TI: return tk.y;
+        case TASK_TU: return tk.y + 1;
+        case TASK_T: case TASK_U: return tk.z;
+        default: return tk.z >> 2;
     }
-    const int m = row % (2 * nq);
-    return m < nq ? m : 2 * nq - 1 - m;
+}
+// A tile belongs to the XCD of its tile ROW.  Row i carries ~ i^2 / 2 trailing updates, so the rows are
+// dealt out heaviest first, each to the XCD with the least work so far (LPT): the totals differ by < 1 %
+// (a boustrophedon deal leaves 8 % between the heaviest XCD and the mean when nblk is not a multiple
+// of 16, and the heaviest XCD sets the pace of the throughput-bound first half).
+static std::vector<int> mega_row_owner(int nblk, int nq) {
+    std::vector<int> owner((size_t)nblk, 0);
+    static const int MODE = [] { const char* e = getenv("STBA_MEGA_ROWMAP"); return e ? atoi(e) : 1; }();
+    if (MODE == 0) {
+        for (int row = 0; row < nblk; ++row) {
+            const int m = row % (2 * nq);
+            owner[(size_t)row] = m < nq ? m : 2 * nq - 1 - m;
+        }
+        return owner;
+    }
+    std::vector<double> load((size_t)nq, 0.0);
+    for (int row = nblk - 1; row >= 0; --row) {
+        int best = 0;
+        for (int q = 1; q < nq; ++q)
+            if (load[(size_t)q] < load[(size_t)best]) best = q;
+        owner[(size_t)row] = best;
+        load[(size_t)best] += 24.0 * row * (row - 1) / 2.0 + 23.0 * row + 110.0;
+    }
+    return owner;
 }
 // The ticket order is produced by LIST SCHEDULING a model of the machine on the host: `wg_per_q`
 // workers per XCD queue, measured task durations, and priorities that put the critical chain
@@ -1124,6 +1144,7 @@ static void mega_build_tasks(int nblk, int nq, int wg_per_q, std::vector<int4>& 
     struct Node { int4 tk; std::vector<int> succ; int indeg = 0; double dur = 0, prio = 0; int q = 0; };
     std::vector<Node> nodes;
     const int NBK = nblk;
+    const std::vector<int> rowq = mega_row_owner(nblk, nq);
     static const int QROWS = [] { const char* e = getenv("STBA_MEGA_QROWS"); return e ? atoi(e) : 2; }();
     std::vector<int> idD((size_t)NBK, -1), idTI((size_t)NBK, -1), idTU((size_t)NBK * 4, -1), idT((size_t)NBK * NBK, -1),
         idUq((size_t)NBK * NBK * 4, -1), idU((size_t)NBK * NBK * NBK, -1);
@@ -1132,7 +1153,7 @@ static void mega_build_tasks(int nblk, int nq, int wg_per_q, std::vector<int4>& 
     double DUR[6] = {29.0, 23.0, 19.0, 25.0, 16.5, 20.0};
     if (const char* e = getenv("STBA_MEGA_DUR")) sscanf(e, "%lf,%lf,%lf,%lf,%lf,%lf", &DUR[0], &DUR[1], &DUR[2], &DUR[3], &DUR[4], &DUR[5]);
     auto add = [&](int type, int b, int i, int j, double prio) {
-        Node nd; nd.tk = make_int4(type, b, i, j); nd.dur = DUR[type]; nd.prio = prio; nd.q = mega_owner(nd.tk, nq);
+        Node nd; nd.tk = make_int4(type, b, i, j); nd.dur = DUR[type]; nd.prio = prio; nd.q = rowq[(size_t)mega_task_row(nd.tk)];
         nodes.push_back(nd);
         return (int)nodes.size() - 1;
     };
@@ -1200,6 +1221,24 @@ static void mega_build_tasks(int nblk, int nq, int wg_per_q, std::vector<int4>& 
                 if (j != i) dep(idT[(size_t)b * NBK + j], u);
                 if (b > 0) dep(idU[((size_t)(b - 1) * NBK + i) * NBK + j], u);
             }
+    }
+    static const double BLW = [] { const char* e = getenv("STBA_MEGA_BLEVEL"); return e ? atof(e) : 1.0; }();
+    if (BLW > 0.0) {
+        // bottom level (longest path to the end of the graph) as the priority: HLFET list scheduling
+        std::vector<int> indeg2(nodes.size()), topo;
+        topo.reserve(nodes.size());
+        for (size_t k = 0; k < nodes.size(); ++k) { indeg2[k] = nodes[k].indeg; if (indeg2[k] == 0) topo.push_back((int)k); }
+        for (size_t h = 0; h < topo.size(); ++h)
+            for (int sidx : nodes[(size_t)topo[h]].succ)
+                if (--indeg2[(size_t)sidx] == 0) topo.push_back(sidx);
+        std::vector<double> bl(nodes.size(), 0.0);
+        for (size_t h = topo.size(); h-- > 0;) {
+            const int k = topo[h];
+            double m = 0.0;
+            for (int sidx : nodes[(size_t)k].succ) m = std::max(m, bl[(size_t)sidx]);
+            bl[(size_t)k] = nodes[(size_t)k].dur + m;
+        }
+        for (size_t k = 0; k < nodes.size(); ++k) nodes[k].prio = nodes[k].prio * (1.0 - BLW) * 5.0 - BLW * bl[k];
     }
     // event-driven list scheduling
     typedef std::pair<double, int> PI;

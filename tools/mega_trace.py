@@ -86,3 +86,15 @@ for b in range(1, len(dm) - 1):
         line += f"{rel(tr[tk,1]):6.1f} {rel(tr[tk,2]):6.1f} {rel(tr[tk,3]):6.1f} | "
     line += f"{rel(tr[kd1,1]):6.1f} {rel(tr[kd1,2]):6.1f}"
     print(line)
+# queue neighbourhood of the late diagonal-tile updates: who sat in front of them?
+if len(sys.argv) > 2:
+    for b in [int(x) for x in sys.argv[2].split(",")]:
+        k = key.get((3, b - 1, b + 1, b + 1))
+        if k is None:
+            continue
+        t0b = tr[key[(0, b, 0, 0)], 3]
+        rel = lambda x: (x - t0b) / 100.0
+        print(f"\nqueue in front of U({b-1};{b+1},{b+1}) (times rel. D({b}).done): idx type b i j | wg tick rdy done | wait")
+        for kk in range(max(0, k - 70), k + 3):
+            ty, bb, ii, jj = tasks[kk]
+            print(f"{kk:6d} {names[ty]:3s} {bb:3d} {ii:4d} {jj:3d} | {tr[kk,0]:4d} {rel(tr[kk,1]):7.1f} {rel(tr[kk,2]):7.1f} {rel(tr[kk,3]):7.1f} | {(tr[kk,2]-tr[kk,1])/100.0:6.1f}")
