@@ -1140,8 +1140,8 @@ static std::vector<int> mega_row_owner(int nblk, int nq) {
 // tasks by their simulated start time gives (i) one global topological order, which the deadlock
 // argument needs, and (ii) per-queue orders in which a workgroup rarely takes a ticket whose inputs
 // are far from ready (an in-order ticket queue has no other notion of priority).
-static void mega_build_tasks(int nblk, int nq, int wg_per_q, std::vector<int4>& out, int* qstart) {
-    struct Node { int4 tk; std::vector<int> succ; int indeg = 0; double dur = 0, prio = 0; int q = 0; };
+static void mega_build_tasks(int nblk, int nq, int wg_per_q, std::vector<int4>& out, int* qstart, std::vector<float>* sim_start = nullptr) {
+    struct Node { int4 tk; std::vector<int> succ; int indeg = 0; double dur = 0, prio = 0, start = 0; int q = 0; };
     std::vector<Node> nodes;
     const int NBK = nblk;
     const std::vector<int> rowq = mega_row_owner(nblk, nq);
@@ -1257,6 +1257,7 @@ static void mega_build_tasks(int nblk, int nq, int wg_per_q, std::vector<int4>& 
                 ready[(size_t)q].pop();
                 idle[(size_t)q]--;
                 order[(size_t)q].push_back(k);
+                nodes[(size_t)k].start = now;
                 events.push(PI(now + nodes[(size_t)k].dur, k));
             }
         if (events.empty()) break;
@@ -1271,7 +1272,10 @@ static void mega_build_tasks(int nblk, int nq, int wg_per_q, std::vector<int4>& 
     out.clear();
     for (int q = 0; q < nq; ++q) {
         qstart[q] = (int)out.size();
-        for (int k : order[(size_t)q]) out.push_back(nodes[(size_t)k].tk);
+        for (int k : order[(size_t)q]) {
+            out.push_back(nodes[(size_t)k].tk);
+            if (sim_start) sim_start->push_back((float)nodes[(size_t)k].start);
+        }
     }
     qstart[nq] = (int)out.size();
 }
@@ -1402,6 +1406,7 @@ static int chol_run(double* A, int lda, int n, double* x_dev, int* flag_dev, hip
             int qstart[17] = {0};
             signed char xcc_queue[16];
             int4* tasks = nullptr; int* sync = nullptr; size_t sync_ints = 0;
+            std::vector<float> sim_start;     // simulated start time of every task (written to the trace file)
         };
         static thread_local MegaPlan plan;
         if (plan.nblk != nblk) {
@@ -1433,7 +1438,7 @@ static int chol_run(double* A, int lda, int n, double* x_dev, int* flag_dev, hip
                         return fail(STBA_ERR_HIP, "chol: fewer than 4 workgroups per XCD (the TU tasks need 4)");
             }
             std::vector<int4> tasks;
-            mega_build_tasks(nblk, plan.nq, std::max(4, plan.ncu / plan.nq), tasks, plan.qstart);
+            mega_build_tasks(nblk, plan.nq, std::max(4, plan.ncu / plan.nq), tasks, plan.qstart, &plan.sim_start);
             STBA_HIP(hipMalloc(reinterpret_cast<void**>(&plan.tasks), tasks.size() * sizeof(int4)));
             STBA_HIP(hipMemcpy(plan.tasks, tasks.data(), tasks.size() * sizeof(int4), hipMemcpyHostToDevice));
             plan.sync_ints = MEGA_SYNC_HDR + 2 * (size_t)nblk + 2 * (size_t)nblk * nblk;
@@ -1469,6 +1474,7 @@ static int chol_run(double* A, int lda, int n, double* x_dev, int* flag_dev, hip
                 fwrite(&plan.ntasks, sizeof(int), 1, f);
                 fwrite(ht.data(), sizeof(int4), ht.size(), f);
                 fwrite(h.data(), sizeof(long long), h.size(), f);
+                fwrite(plan.sim_start.data(), sizeof(float), plan.sim_start.size(), f);
                 fclose(f);
             }
         }

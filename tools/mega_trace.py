@@ -12,7 +12,8 @@ raw = open(sys.argv[1], "rb").read()
 nt = int(np.frombuffer(raw[:4], np.int32)[0])
 tasks = np.frombuffer(raw[4:4 + 16 * nt], np.int32).reshape(nt, 4).copy()
 tasks[:, 0] &= 0xff
-tr = np.frombuffer(raw[4 + 16 * nt:], np.int64).reshape(nt, 8)
+tr = np.frombuffer(raw[4 + 16 * nt:4 + 16 * nt + 64 * nt], np.int64).reshape(nt, 8)
+sim = np.frombuffer(raw[4 + 80 * nt:4 + 84 * nt], np.float32) if len(raw) >= 4 + 84 * nt else None
 t0 = tr[:, 1].min()
 us = lambda x: (x - t0) / 100.0
 names = ["D", "T", "TI", "U", "Uq", "TU"]
@@ -89,7 +90,7 @@ for b in range(1, len(dm) - 1):
 # queue neighbourhood of the late diagonal-tile updates: who sat in front of them?
 if len(sys.argv) > 2:
     for b in [int(x) for x in sys.argv[2].split(",")]:
-        k = key.get((3, b - 1, b + 1, b + 1))
+        k = key.get((1, b - 1, b + 1, 0)) if os.environ.get("TRACE_T") else key.get((3, b - 1, b + 1, b + 1))
         if k is None:
             continue
         t0b = tr[key[(0, b, 0, 0)], 3]
@@ -98,3 +99,31 @@ if len(sys.argv) > 2:
         for kk in range(max(0, k - 70), k + 3):
             ty, bb, ii, jj = tasks[kk]
             print(f"{kk:6d} {names[ty]:3s} {bb:3d} {ii:4d} {jj:3d} | {tr[kk,0]:4d} {rel(tr[kk,1]):7.1f} {rel(tr[kk,2]):7.1f} {rel(tr[kk,3]):7.1f} | {(tr[kk,2]-tr[kk,1])/100.0:6.1f}")
+
+# drift of the machine against the host's simulation: (real start - simulated start) per 200 us of simulated time
+if sim is not None:
+    real = us(tr[:, 2])
+    print("\nsim window(us)  mean real-sim (us) by task class:   D/TU      T     U(j<=b+2)   U(far)")
+    cls = np.where(np.isin(tasks[:, 0], (0, 5)), 0, np.where(tasks[:, 0] == 1, 1, np.where((tasks[:, 0] == 4) | (tasks[:, 3] <= tasks[:, 1] + 2), 2, 3)))
+    for a0 in np.arange(0, sim.max() + 200, 200.0):
+        m = (sim >= a0) & (sim < a0 + 200)
+        if not m.any(): continue
+        out = []
+        for c in range(4):
+            mm = m & (cls == c)
+            out.append(f"{(real[mm] - sim[mm]).mean():8.1f}" if mm.any() else "       -")
+        print(f"{a0:6.0f}-{a0+200:6.0f}   " + "  ".join(out))
+    print("simulated makespan", sim.max(), "real", real.max())
+if sim is not None:
+    ds = {int(tasks[k, 1]): float(sim[k]) for k in dm}
+    print("simulated step D(b+1).start - D(b).start:", np.round([ds[b + 1] - ds[b] for b in range(len(dm) - 1)], 1))
+    # what delayed the simulated TU / D?  inputs' simulated end times relative to D(b) end
+    DURS = {0: 29.0, 1: 23.0, 2: 19.0, 3: 25.0, 4: 16.5, 5: 20.0}
+    for b in range(1, len(dm) - 1):
+        if ds[b + 1] - ds[b] < 52: continue
+        dend = ds[b] + 29.0
+        tu = [key[(5, b, q, 0)] for q in range(4)]
+        ubb = key.get((3, b - 1, b + 1, b + 1))
+        uqs = [key[(4, b - 1, (b + 1) * 4 + q, b)] for q in range(4) if (4, b - 1, (b + 1) * 4 + q, b) in key]
+        tk = key.get((1, b - 1, b + 1, 0))
+        print(f"  sim b={b}: step {ds[b+1]-ds[b]:.1f}  TU start {max(sim[k] for k in tu)-dend:6.1f}  Ubb start {sim[ubb]-dend:6.1f}  Uq start {max(sim[k] for k in uqs)-dend:6.1f}  T(b-1,b+1) start {sim[tk]-dend:6.1f}  (D(b-1) end {ds[b-1]+29-dend:6.1f})")
