@@ -182,6 +182,11 @@ int stba_cholesky_time(int n, int reps, double* ms_avg, void* hip_stream);
  * the backward substitution: bench.py's MFMA roofline leg divides the n^3/3 flops by ms_factor. */
 int stba_cholesky_time_split(int n, int reps, double* ms_factor, double* ms_backward, void* hip_stream);
 
+/* diagnostic, runs on the host (no GPU): the makespan in microseconds that the host-side scheduling model
+ * predicts for the persistent factorisation kernel of an n x n system on `n_xcd` XCDs with `wg_per_xcd`
+ * workgroups each (MI355X: 8 x 32).  The ticket order of the kernel comes from this model. */
+int stba_cholesky_schedule_model(int n, int n_xcd, int wg_per_xcd, double* makespan_us);
+
 /* hipEvent time (ms) of one factor+solve per kernel class, with the stage-per-kernel schedule (a
  * diagnostic: the production path runs the stages as tasks of one persistent kernel): ms4 = {diagonal blocks, panel solves,
  * MFMA trailing updates, backward substitution}; algorithmic / executed flops of the trailing

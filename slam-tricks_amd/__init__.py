@@ -66,7 +66,7 @@ EXPORTS = ["stba_status_string", "stba_last_error", "stba_version", "stba_device
            "stba_ba_cost", "stba_ba_normal_blocks", "stba_ba_reduced_system", "stba_ba_solve_reduced",
            "stba_ba_back_substitute", "stba_ba_apply_step", "stba_ba_solve", "stba_ba_lm_iterations",
            "stba_ba_triangulate", "stba_ba_time_linearize", "stba_cholesky_factor", "stba_cholesky_solve",
-           "stba_cholesky_time", "stba_cholesky_time_split", "stba_cholesky_profile", "stba_calib_evaluate", "stba_calib_gauss_newton",
+           "stba_cholesky_time", "stba_cholesky_time_split", "stba_cholesky_schedule_model", "stba_cholesky_profile", "stba_calib_evaluate", "stba_calib_gauss_newton",
            "stba_pcg_default_options", "stba_pg_create", "stba_pg_destroy", "stba_pg_set_allreduce", "stba_pg_get_poses", "stba_pg_evaluate",
            "stba_pg_solve", "stba_dense_solve", "stba_corners_read", "stba_corners_write", "stba_zhang_init", "stba_two_view_init", "stba_odometry_read", "stba_odometry_write", "stba_trajectory_ate"]
 
@@ -312,6 +312,13 @@ def cholesky_time(n, reps=5, stream=None):
     ms = C.c_double()
     _chk(lib().stba_cholesky_time(int(n), int(reps), C.byref(ms), C.c_void_p(stream or 0)), "stba_cholesky_time")
     return ms.value
+
+
+def cholesky_schedule_model(n, n_xcd=8, wg_per_xcd=32):
+    """Host-only: makespan (us) the scheduling model predicts for the persistent factorisation kernel."""
+    out = C.c_double()
+    _chk(lib().stba_cholesky_schedule_model(int(n), int(n_xcd), int(wg_per_xcd), C.byref(out)), "stba_cholesky_schedule_model")
+    return out.value
 
 
 def cholesky_time_split(n, reps=5, stream=None):

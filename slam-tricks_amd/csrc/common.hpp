@@ -59,6 +59,8 @@ struct CholProfile {
 };
 int chol_factor_solve_profiled(double* A_dev, int lda, int n, double* x_dev, int* flag_dev, hipStream_t st,
                                CholProfile* prof);
+// host-side scheduling model of the persistent factorisation kernel: predicted makespan (us) for nblk block columns
+double chol_schedule_makespan(int nblk, int nq, int wg_per_q);
 // fills the padding (identity) and the rhs row of a padded system
 int chol_prepare_padding_dev(double* A_dev, int lda, int n, const double* rhs_dev, hipStream_t st);
 

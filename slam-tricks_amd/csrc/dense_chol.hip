@@ -1124,6 +1124,10 @@ static std::vector<int> mega_row_owner(int nblk, int nq) {
         }
         return owner;
     }
+    if (MODE == 2 || MODE == 3) {
+        for (int row = 0; row < nblk; ++row) owner[(size_t)row] = (MODE == 2 ? row : nblk - 1 - row) % nq;
+        return owner;
+    }
     std::vector<double> load((size_t)nq, 0.0);
     for (int row = nblk - 1; row >= 0; --row) {
         int best = 0;
@@ -1140,8 +1144,9 @@ static std::vector<int> mega_row_owner(int nblk, int nq) {
 // tasks by their simulated start time gives (i) one global topological order, which the deadlock
 // argument needs, and (ii) per-queue orders in which a workgroup rarely takes a ticket whose inputs
 // are far from ready (an in-order ticket queue has no other notion of priority).
-static void mega_build_tasks(int nblk, int nq, int wg_per_q, std::vector<int4>& out, int* qstart, std::vector<float>* sim_start = nullptr) {
-    struct Node { int4 tk; std::vector<int> succ; int indeg = 0; double dur = 0, prio = 0, start = 0; int q = 0; };
+static void mega_build_tasks(int nblk, int nq, int wg_per_q, std::vector<int4>& out, int* qstart, std::vector<float>* sim_start = nullptr,
+                             double* makespan_out = nullptr) {
+    struct Node { int4 tk; std::vector<int> succ; int indeg = 0; double dur = 0, prio = 0, start = 0, ready = 0; int q = 0; int last_pred = -1; };
     std::vector<Node> nodes;
     const int NBK = nblk;
     const std::vector<int> rowq = mega_row_owner(nblk, nq);
@@ -1240,44 +1245,121 @@ static void mega_build_tasks(int nblk, int nq, int wg_per_q, std::vector<int4>& 
         }
         for (size_t k = 0; k < nodes.size(); ++k) nodes[k].prio = nodes[k].prio * (1.0 - BLW) * 5.0 - BLW * bl[k];
     }
-    // event-driven list scheduling
+    // Event-driven list scheduling.  A ticket queue replays the model if the tickets are sorted by the time
+    // their worker became FREE (= the moment a workgroup picks its next ticket), not by the task's start:
+    // a workgroup that picks a ticket early parks on it until its inputs arrive.
+    // Liveness: a ticket occupies its model worker from pick to end, so at most wg_per_q - 1 tickets that
+    // come later in the topological (start time) order can precede any ticket in its queue; with at least
+    // wg_per_q real workgroups per XCD one of them always reaches the earliest unfinished task.
+    // The model is faithful (C5: 2.55 ms predicted, 2.53-2.60 ms measured; tools/mega_trace.py prints the
+    // drift), which makes it the place to try policies -- tools/sim_sweep.py, no GPU.  Tried and rejected
+    // there AND on the machine: keeping RES[r] workers of the XCD that owns row b+1+r idle for the tasks of
+    // the critical chains (STBA_MEGA_RES=5,4,2: +2.4 % predicted, +2.3 % measured), boosting the priority
+    // of those rows, cyclic instead of LPT row ownership (+8 %).  What the model says: with 320 workers
+    // instead of 256 the makespan would be 2.36 ms, with unlimited workers 2.30 ms (the chain): the first
+    // 1.6 ms are bound by MFMA capacity (a trailing update runs at 23.4 us, the FP64 MFMA ceiling of one
+    // CU is 22.8 us), the rest by the chain D -> TU -> D.
     typedef std::pair<double, int> PI;
-    std::vector<std::priority_queue<PI, std::vector<PI>, std::greater<PI>>> ready((size_t)nq);
-    std::priority_queue<PI, std::vector<PI>, std::greater<PI>> events;
-    std::vector<int> idle((size_t)nq, wg_per_q);
+    typedef std::priority_queue<PI, std::vector<PI>, std::greater<PI>> Heap;
+    int RES[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (const char* e = getenv("STBA_MEGA_RES")) {
+        for (int& r : RES) r = 0;
+        sscanf(e, "%d,%d,%d,%d,%d,%d,%d,%d", &RES[0], &RES[1], &RES[2], &RES[3], &RES[4], &RES[5], &RES[6], &RES[7]);
+    }
+    int urows = 0;
+    for (int r = 0; r < 8; ++r) if (RES[r] > 0) urows = r + 1;
+    auto is_urgent = [&](const int4& tk) { return tk.x != TASK_TI && mega_task_row(tk) <= tk.y + urows; };
+    std::vector<Heap> ready_u((size_t)nq), ready_b((size_t)nq);
+    Heap events;
+    std::vector<std::vector<double>> idle_since((size_t)nq, std::vector<double>((size_t)wg_per_q, 0.0));   // LIFO
+    std::vector<int> reserve((size_t)nq, 0);
+    int cur_b = -1;
+    auto set_step = [&](int b) {           // the chain has reached diagonal block b: move the reserve
+        cur_b = b;
+        for (int q = 0; q < nq; ++q) reserve[(size_t)q] = 0;
+        for (int r = 0; r < urows; ++r)
+            if (b + 1 + r < NBK) reserve[(size_t)rowq[(size_t)(b + 1 + r)]] += RES[r];
+    };
     double now = 0.0;
-    std::vector<std::vector<int>> order((size_t)nq);
-    auto push_ready = [&](int k) { ready[(size_t)nodes[(size_t)k].q].push(PI(nodes[(size_t)k].prio, k)); };
+    struct Pick { double key, start; int node; };
+    std::vector<std::vector<Pick>> order((size_t)nq);
+    auto push_ready = [&](int k) {
+        Node& nd = nodes[(size_t)k];
+        (is_urgent(nd.tk) ? ready_u : ready_b)[(size_t)nd.q].push(PI(nd.prio, k));
+    };
     for (int k = 0; k < (int)nodes.size(); ++k)
         if (nodes[(size_t)k].indeg == 0) push_ready(k);
+    double makespan = 0.0;
     for (;;) {
-        for (int q = 0; q < nq; ++q)
-            while (idle[(size_t)q] > 0 && !ready[(size_t)q].empty()) {
-                const int k = ready[(size_t)q].top().second;
-                ready[(size_t)q].pop();
-                idle[(size_t)q]--;
-                order[(size_t)q].push_back(k);
-                nodes[(size_t)k].start = now;
-                events.push(PI(now + nodes[(size_t)k].dur, k));
+        for (int q = 0; q < nq; ++q) {
+            std::vector<double>& idl = idle_since[(size_t)q];
+            for (;;) {
+                if (idl.empty()) break;
+                Heap& hu = ready_u[(size_t)q];
+                Heap& hb = ready_b[(size_t)q];
+                const bool bulk_ok = !hb.empty() && (int)idl.size() > reserve[(size_t)q];
+                int k = -1;
+                if (!hu.empty() && (!bulk_ok || hu.top().first <= hb.top().first)) { k = hu.top().second; hu.pop(); }
+                else if (bulk_ok) { k = hb.top().second; hb.pop(); }
+                else break;
+                Node& nd = nodes[(size_t)k];
+                order[(size_t)q].push_back({idl.back(), now, k});
+                idl.pop_back();
+                nd.start = now;
+                events.push(PI(now + nd.dur, k));
+                if (nd.tk.x == TASK_D && nd.tk.y > cur_b) set_step(nd.tk.y);
             }
+        }
         if (events.empty()) break;
         const PI ev = events.top();
         events.pop();
         now = ev.first;
+        makespan = now;
         const Node& nd = nodes[(size_t)ev.second];
-        idle[(size_t)nd.q]++;
+        idle_since[(size_t)nd.q].push_back(now);
         for (int sidx : nd.succ)
-            if (--nodes[(size_t)sidx].indeg == 0) push_ready(sidx);
+            if (--nodes[(size_t)sidx].indeg == 0) { nodes[(size_t)sidx].ready = now; nodes[(size_t)sidx].last_pred = ev.second; push_ready(sidx); }
+    }
+    if (makespan_out) *makespan_out = makespan;
+    if (getenv("STBA_MEGA_SIMDBG")) {
+        static const char* NM[6] = {"D", "T", "TI", "U", "Uq", "TU"};
+        for (int b = 0; b + 1 < NBK; ++b) {
+            const Node& d0 = nodes[(size_t)idD[(size_t)b]];
+            const Node& d1 = nodes[(size_t)idD[(size_t)b + 1]];
+            const Node& tu = nodes[(size_t)idTU[(size_t)b * 4 + 3]];
+            const double e0 = d0.start + d0.dur;
+            fprintf(stderr, "b=%2d step %6.1f | TU ready %+6.1f start %+6.1f | D+1 ready %+6.1f start %+6.1f", b, d1.start - d0.start,
+                    tu.ready - e0, tu.start - e0, d1.ready - e0, d1.start - e0);
+            int k = idTU[(size_t)b * 4 + 3];
+            for (int hop = 0; hop < 4 && k >= 0; ++hop) {       // walk back along the last-arriving inputs
+                const Node& nd = nodes[(size_t)k];
+                fprintf(stderr, " <- %s(%d;%d,%d) rdy %+.1f st %+.1f", NM[nd.tk.x], nd.tk.y, nd.tk.z, nd.tk.w, nd.ready - e0, nd.start - e0);
+                k = nd.last_pred;
+            }
+            fprintf(stderr, "\n");
+        }
     }
     out.clear();
     for (int q = 0; q < nq; ++q) {
+        std::stable_sort(order[(size_t)q].begin(), order[(size_t)q].end(), [](const Pick& x, const Pick& y) {
+            return x.key != y.key ? x.key < y.key : x.start < y.start;
+        });
         qstart[q] = (int)out.size();
-        for (int k : order[(size_t)q]) {
-            out.push_back(nodes[(size_t)k].tk);
-            if (sim_start) sim_start->push_back((float)nodes[(size_t)k].start);
+        for (const Pick& pk : order[(size_t)q]) {
+            out.push_back(nodes[(size_t)pk.node].tk);
+            if (sim_start) sim_start->push_back((float)pk.start);
         }
     }
     qstart[nq] = (int)out.size();
+}
+
+// diagnostics (tools/sim_sweep.py): the simulated makespan of the task graph, no GPU involved
+double chol_schedule_makespan(int nblk, int nq, int wg_per_q) {
+    std::vector<int4> tasks;
+    int qstart[17];
+    double ms = 0.0;
+    mega_build_tasks(nblk, nq, wg_per_q, tasks, qstart, nullptr, &ms);
+    return ms;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -1070,6 +1070,13 @@ int stba_cholesky_time(int n, int reps, double* ms_avg, void* hip_stream) {
     return STBA_OK;
 }
 
+int stba_cholesky_schedule_model(int n, int n_xcd, int wg_per_xcd, double* makespan_us) {
+    if (n <= 0 || n_xcd <= 0 || n_xcd > 16 || wg_per_xcd < 4 || !makespan_us) return fail(STBA_ERR_INVALID_ARGUMENT, "bad argument");
+    const int lda = ((n + 1 + 127) / 128) * 128;      // the padded system carries the right-hand side as one more row
+    *makespan_us = chol_schedule_makespan(lda / 128, n_xcd, wg_per_xcd);
+    return STBA_OK;
+}
+
 int stba_cholesky_time_split(int n, int reps, double* ms_factor, double* ms_backward, void* hip_stream) {
     if (n <= 0 || reps <= 0 || !ms_factor || !ms_backward) return fail(STBA_ERR_INVALID_ARGUMENT, "bad argument");
     STBA_TRY(require_device());
