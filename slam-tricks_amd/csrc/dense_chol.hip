@@ -1367,9 +1367,9 @@ double chol_schedule_makespan(int nblk, int nq, int wg_per_q) {
 //   workgroup 0      applies the previous block's solution x_{b+1} to ITS OWN 128 right-hand-side
 //                    entries, then x_b = (L_bb^-T) y_b as a 128x128 GEMV with the inverse transpose
 //                    the panel-solve kernel produced during the factorisation;
-//   workgroups 1..   apply x_{b+1} to the remaining entries y[0 : k0)   (GEMV with the row panel).
+//   workgroups 1..   apply x_{b+1} to the remaining entries y[0 : k0), 128 entries each (GEMV with the row panel).
 // y lives in row lda-1 (it was forward-substituted for free by the factorisation).
-constexpr int BWD_ROW_CHUNKS = 8;   // the 128 panel rows are split 8 ways so that enough CUs pull the panel
+constexpr int BWD_ROW_CHUNKS = 8;   // the 128 panel rows are split 8 ways over the threads of a workgroup
 __global__ __launch_bounds__(1024) void chol_bwd_step_kernel(double* __restrict__ A, int lda, int k0, int has_next,
                                                              const double* __restrict__ Xinv, double* __restrict__ x) {
     __shared__ double xs[NB];                       // previous block's solution
@@ -1382,16 +1382,23 @@ __global__ __launch_bounds__(1024) void chol_bwd_step_kernel(double* __restrict_
     __syncthreads();
     constexpr int RPC = NB / BWD_ROW_CHUNKS;        // rows per chunk (16)
     if (blockIdx.x > 0) {
-        // update role: workgroup = (column chunk of 1024, row chunk of 16); FP64 atomics into y
-        const int id = blockIdx.x - 1;
-        const int cchunk = id / BWD_ROW_CHUNKS, rchunk = id % BWD_ROW_CHUNKS;
-        const int c = cchunk * 1024 + t;
-        if (c < k0) {
-            double s = 0.0;
-            const double* col = A + (size_t)(kn + rchunk * RPC) * lda + c;
+        // update role: this workgroup OWNS the 128 entries y[c0 .. c0+128) of block column blockIdx.x - 1.
+        // Thread (rchunk, column) = (t >> 7, t & 127) sums 16 panel rows, the 8 partial sums of a column meet
+        // in LDS and are added in a fixed order: no atomics, so the solution is bitwise reproducible (two
+        // ranks that factor the same system get the same step).
+        const int c0 = (blockIdx.x - 1) * NB;
+        const int rchunk = t >> 7, c = t & 127;
+        double s = 0.0;
+        const double* col = A + (size_t)(kn + rchunk * RPC) * lda + c0 + c;
 #pragma unroll
-            for (int j = 0; j < RPC; ++j) s = fma(col[(size_t)j * lda], xs[rchunk * RPC + j], s);
-            if (s != 0.0) unsafeAtomicAdd(&A[(size_t)(lda - 1) * lda + c], -s);
+        for (int j = 0; j < RPC; ++j) s = fma(col[(size_t)j * lda], xs[rchunk * RPC + j], s);
+        part[rchunk][c] = s;
+        __syncthreads();
+        if (t < NB) {
+            double acc = 0.0;
+#pragma unroll
+            for (int q = 0; q < BWD_ROW_CHUNKS; ++q) acc += part[q][t];
+            A[(size_t)(lda - 1) * lda + c0 + t] -= acc;
         }
         return;
     }
@@ -1575,7 +1582,7 @@ static int chol_run(double* A, int lda, int n, double* x_dev, int* flag_dev, hip
     for (int b = nblk - 1; b >= 0; --b) {
         const int k0 = b * NB;
         const int has_next = (b < nblk - 1) ? 1 : 0;
-        const int grid = 1 + (has_next ? ((k0 + 1023) / 1024) * BWD_ROW_CHUNKS : 0);
+        const int grid = 1 + (has_next ? b : 0);       // workgroup 0: this block; workgroup 1 + j: block column j < b
         hipLaunchKernelGGL(chol_bwd_step_kernel, dim3(grid), dim3(1024), 0, st, A, lda, k0, has_next, linv + (size_t)b * LINV_STRIDE, x_dev);
     }
     STBA_TRY(mark((size_t)nblk * 4 + 1));

@@ -109,8 +109,16 @@ struct stba_ba {
     size_t sbuf_count() const { return (size_t)lda * lda + 4 * (size_t)lda; }
     // cross-rank sum: only the lower triangle of the n x n system travels (S is symmetric and only its lower
     // triangle is ever read), followed by the four extras vectors: [tri n(n+1)/2 | ex_diag | ex_gc | rhs | scalars]
+    // When the union over ranks of the non-zero 6x6 blocks is sparse (C5: 14 % of the camera pairs share a
+    // landmark), only those blocks travel: [blocks pk_nz * 36 | extras] -- 20 MB instead of 144 MB at C5.
     double* Spack = nullptr;
-    size_t pack_count() const { return (size_t)n * (n + 1) / 2 + 4 * (size_t)lda; }
+    std::vector<int> h_row_col_ptr, h_row_cols;   // host copy of the local block pattern (lower triangle, by camera)
+    int pk_state = 0;           // 0: not planned yet, 1: triangle, 2: block list
+    int pk_nz = 0;
+    int2* pk_blocks = nullptr;  // (row camera, column camera) of every travelling block
+    size_t pack_count() const {
+        return (pk_state == 2 ? (size_t)pk_nz * 36 : (size_t)n * (n + 1) / 2) + 4 * (size_t)lda;
+    }
 };
 
 namespace stba {
@@ -120,7 +128,7 @@ static void ba_free(stba_ba* b) {
     F(b->cams[0]); F(b->cams[1]); F(b->pts[0]); F(b->pts[1]); F(b->feat); F(b->obs_cam); F(b->obs_pt);
     F(b->pt_start); F(b->cam_perm); F(b->chunk_begin); F(b->chunk_end); F(b->cam_chunk_start); F(b->cam_fixed);
     F(b->pt_fixed); F(b->r); F(b->Jc); F(b->Jp); F(b->Hpp6); F(b->gp); F(b->Hinv6); F(b->dp); F(b->scale_p);
-    F(b->Hcc); F(b->gc); F(b->cam_partial); F(b->dc); F(b->scale_c); F(b->Sbuf); F(b->Spack); F(b->dxc); F(b->dxp);
+    F(b->Hcc); F(b->gc); F(b->cam_partial); F(b->dc); F(b->scale_c); F(b->Sbuf); F(b->Spack); F(b->pk_blocks); F(b->dxc); F(b->dxp);
     F(b->task_cam); F(b->task_begin); F(b->task_end); F(b->row_col_ptr); F(b->row_cols); F(b->task_single);
     F(b->pair_begin); F(b->pair_end); F(b->pair_il); F(b->pair_slot);
     F(b->cost_partial); F(b->upd_partial_c); F(b->upd_partial_p); F(b->trial); F(b->flag);
@@ -184,6 +192,60 @@ __global__ __launch_bounds__(256) void tri_pack_kernel(double* __restrict__ Sbuf
     }
 }
 
+// the travelling 6x6 blocks <-> the packed buffer; the four extras vectors behind S <-> behind the blocks
+__global__ __launch_bounds__(256) void blk_pack_kernel(double* __restrict__ Sbuf, int lda, const int2* __restrict__ blocks, int nz,
+                                                       double* __restrict__ pack, int to_pack) {
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t nel = (size_t)nz * 36;
+    if (e < nel) {
+        const int blk = (int)(e / 36), k = (int)(e % 36);
+        const int2 ij = blocks[blk];
+        double* p = Sbuf + (size_t)(6 * ij.x + k / 6) * lda + 6 * ij.y + k % 6;
+        if (to_pack) pack[e] = *p; else *p = pack[e];
+    } else if (e < nel + 4 * (size_t)lda) {
+        double* p = Sbuf + (size_t)lda * lda + (e - nel);
+        if (to_pack) pack[e] = *p; else *p = pack[e];
+    }
+}
+
+// decides once per engine what travels in the cross-rank sum of the reduced system: the union over ranks of the
+// non-zero blocks (a 0/1 mask of the nc(nc+1)/2 lower blocks, summed with the same hook) if it is sparse
+static int ba_plan_pack(stba_ba* b) {
+    const size_t nb = (size_t)b->nc * (b->nc + 1) / 2;
+    static const bool SPARSE = [] { const char* e = getenv("STBA_PACK_BLOCKS"); return !e || atoi(e) != 0; }();
+    b->pk_state = 1;
+    if (SPARSE && !b->h_row_col_ptr.empty()) {
+        std::vector<double> mask(nb, 0.0);
+        for (int c = 0; c < b->nc; ++c) {
+            mask[(size_t)c * (c + 1) / 2 + c] = 1.0;                 // the diagonal block always travels (Hcc)
+            for (int k = b->h_row_col_ptr[(size_t)c]; k < b->h_row_col_ptr[(size_t)c + 1]; ++k)
+                mask[(size_t)c * (c + 1) / 2 + b->h_row_cols[(size_t)k]] = 1.0;
+        }
+        double* dmask = nullptr;
+        STBA_TRY(dev_alloc(&dmask, nb));
+        int rc = upload(dmask, mask.data(), nb, b->st);
+        if (rc == STBA_OK && b->ar(b->ar_user, dmask, nb, b->st) != 0) rc = fail(STBA_ERR_CALLBACK, "all-reduce hook failed");
+        if (rc == STBA_OK && hipMemcpyAsync(mask.data(), dmask, nb * sizeof(double), hipMemcpyDeviceToHost, b->st) != hipSuccess)
+            rc = fail(STBA_ERR_HIP, "mask download failed");
+        if (rc == STBA_OK && hipStreamSynchronize(b->st) != hipSuccess) rc = fail(STBA_ERR_HIP, "mask download failed");
+        (void)hipFree(dmask);
+        if (rc != STBA_OK) return rc;
+        std::vector<int2> blocks;
+        for (int c = 0; c < b->nc; ++c)
+            for (int c2 = 0; c2 <= c; ++c2)
+                if (mask[(size_t)c * (c + 1) / 2 + c2] > 0.5) blocks.push_back(make_int2(c, c2));
+        if (blocks.size() * 36 * 2 < (size_t)b->n * (b->n + 1) / 2) {      // worth it below 50 % of the triangle
+            STBA_TRY(dev_alloc(&b->pk_blocks, blocks.size()));
+            STBA_TRY(upload(b->pk_blocks, blocks.data(), blocks.size(), b->st));
+            STBA_HIP(hipStreamSynchronize(b->st));
+            b->pk_nz = (int)blocks.size();
+            b->pk_state = 2;
+        }
+    }
+    STBA_TRY(dev_alloc(&b->Spack, b->pack_count()));
+    return STBA_OK;
+}
+
 static int ba_build_reduced(stba_ba* b, const Damping& dm) {
     const int init_scale = b->scale_init ? 0 : 1;
     if (!dm.explicit_d)
@@ -214,11 +276,14 @@ static int ba_build_reduced(stba_ba* b, const Damping& dm) {
     if (b->ar) {
         // pack the lower triangle + extras (half the bytes on the wire: 144 MB instead of 288 MB at C5),
         // sum across ranks, unpack
-        if (!b->Spack) STBA_TRY(dev_alloc(&b->Spack, b->pack_count()));
-        hipLaunchKernelGGL(tri_pack_kernel, dim3(b->n + 1), dim3(256), 0, b->st, b->Sbuf, b->lda, b->n, b->Spack, 1);
+        if (b->pk_state == 0) STBA_TRY(ba_plan_pack(b));
+        const unsigned pgrid = (unsigned)((b->pack_count() + 255) / 256);
+        if (b->pk_state == 2) hipLaunchKernelGGL(blk_pack_kernel, dim3(pgrid), dim3(256), 0, b->st, b->Sbuf, b->lda, b->pk_blocks, b->pk_nz, b->Spack, 1);
+        else hipLaunchKernelGGL(tri_pack_kernel, dim3(b->n + 1), dim3(256), 0, b->st, b->Sbuf, b->lda, b->n, b->Spack, 1);
         if (b->ar(b->ar_user, b->Spack, b->pack_count(), b->st) != 0)
             return fail(STBA_ERR_CALLBACK, "all-reduce hook failed");
-        hipLaunchKernelGGL(tri_pack_kernel, dim3(b->n + 1), dim3(256), 0, b->st, b->Sbuf, b->lda, b->n, b->Spack, 0);
+        if (b->pk_state == 2) hipLaunchKernelGGL(blk_pack_kernel, dim3(pgrid), dim3(256), 0, b->st, b->Sbuf, b->lda, b->pk_blocks, b->pk_nz, b->Spack, 0);
+        else hipLaunchKernelGGL(tri_pack_kernel, dim3(b->n + 1), dim3(256), 0, b->st, b->Sbuf, b->lda, b->n, b->Spack, 0);
         STBA_HIP(hipGetLastError());
     }
     if (!dm.explicit_d)
@@ -759,6 +824,7 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
         A_(upload(b->task_begin, task_begin.data(), task_cam.size(), b->st));
         A_(upload(b->task_end, task_end.data(), task_cam.size(), b->st));
         A_(upload(b->task_single, task_single.data(), task_cam.size(), b->st));
+        b->h_row_col_ptr = row_col_ptr; b->h_row_cols = row_cols;
         A_(upload(b->row_col_ptr, row_col_ptr.data(), nc + 1, b->st));
         A_(upload(b->row_cols, row_cols.data(), row_cols.size(), b->st));
         if (b->pair_il) {
@@ -805,6 +871,10 @@ int stba_ba_set_allreduce(stba_ba* b, stba_allreduce_fn fn, void* user, int rank
     if (!b || world_size < 1 || rank < 0 || rank >= world_size || world_size > SC_MAX_WORLD)
         return fail(STBA_ERR_INVALID_ARGUMENT, "stba_ba_set_allreduce: bad rank/world");
     b->ar = fn; b->ar_user = user; b->rank = rank; b->world = world_size;
+    // what travels is decided again with the new group (the union pattern belongs to the group)
+    b->pk_state = 0; b->pk_nz = 0;
+    if (b->pk_blocks) { (void)hipFree(b->pk_blocks); b->pk_blocks = nullptr; }
+    if (b->Spack) { (void)hipFree(b->Spack); b->Spack = nullptr; }
     return STBA_OK;
 }
 

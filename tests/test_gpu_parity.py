@@ -364,6 +364,13 @@ def test_cholesky_persistent_kernel_is_deterministic(st, n):
     assert np.abs(L0 - Lref).max() <= 1e-12 * np.abs(Lref).max()
     for _ in range(7):
         assert np.array_equal(st.cholesky_factor(A), L0)
+    # the solve too (the backward substitution adds its partial sums in a fixed order, no atomics): every
+    # rank of a sharded run factors the same reduced system and must get the same camera step
+    rhs = rng.standard_normal(n)
+    x0 = st.cholesky_solve(A, rhs)
+    assert np.abs(A @ x0 - rhs).max() <= 1e-9 * np.abs(rhs).max() * np.linalg.cond(A)
+    for _ in range(3):
+        assert np.array_equal(st.cholesky_solve(A, rhs), x0)
 
 
 # ------------------------------------------------------------------------------- full size and edge cases

@@ -113,20 +113,25 @@ def test_two_rank_gloo_step_equals_single_process(scenes, O):
 
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.gpu
-def test_two_shards_on_one_gpu(scenes, O):
+@pytest.mark.parametrize("n_cams,n_pts,max_obs,sparse", [(24, 1500, 8, False), (200, 4000, 3, True)])
+def test_two_shards_on_one_gpu(scenes, O, n_cams, n_pts, max_obs, sparse):
     """two engines = two landmark shards, driven from two threads; the all-reduce hook sums the
-    engines' device buffers in-process.  The sharded LM must follow the single-engine LM."""
+    engines' device buffers in-process.  The sharded LM must follow the single-engine LM.
+    Second case: few cameras per landmark -> most 6x6 blocks of the reduced system are zero on every rank,
+    and only the union of the non-zero blocks may travel (a 0/1 block mask is summed once, first)."""
     import torch
     st = importlib.import_module("slam-tricks_amd")
     sharding = importlib.import_module("slam-tricks_amd.sharding")
-    s = scenes.st20_scene(n_cams=24, n_pts=1500, max_obs_per_pt=8, seed=6, pix_noise=1e-3)
+    s = scenes.st20_scene(n_cams=n_cams, n_pts=n_pts, max_obs_per_pt=max_obs, seed=6, pix_noise=1e-3)
     world = 2
     bar = threading.Barrier(world)
     slots = [None] * world
     out = [None] * world
+    counts = [[] for _ in range(world)]
 
     def make_hook(rank):
         def hook(_u, buf, count, _stream):
+            counts[rank].append(int(count))
             t = torch.as_tensor(sharding.DeviceVector(buf, count), device="cuda")
             torch.cuda.synchronize()
             slots[rank] = t
@@ -163,6 +168,13 @@ def test_two_shards_on_one_gpu(scenes, O):
         assert np.abs(cams - cams1).max() < 1e-9
         assert np.abs(pts - pts1[sh["lo"]:sh["hi"]]).max() < 1e-6      # weakly observed depths amplify round-off
     assert np.array_equal(out[0][2][0], out[1][2][0])       # identical camera blocks on both "ranks"
+    # what travelled: the block mask once, then the packed system (sparse case: far fewer than the triangle)
+    n = 6 * n_cams
+    lda = ((n + 1 + 127) // 128) * 128
+    tri = n * (n + 1) // 2 + 4 * lda
+    big = [c for c in counts[0] if c > 4]
+    assert counts[0] == counts[1] and big[0] == n_cams * (n_cams + 1) // 2
+    assert all((c < tri // 2) == sparse and (c - 4 * lda) % 36 == 0 or (not sparse and c == tri) for c in big[1:])
 
 
 @pytest.mark.gpu
