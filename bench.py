@@ -29,7 +29,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X FP64 matrix peak (SURVEY.md 8d / AMD datasheet)
-FP64_MFMA_MEASURED_CEILING_TFLOPS = 47.2   # profiles/mfma_f64_microbench.txt (pure-MFMA loop on this chip)
+FP64_MFMA_MEASURED_CEILING_TFLOPS = 77.3   # profiles/mfma_f64_microbench.txt (pure-MFMA loop, 512-thread blocks, this chip)
 BYTES_PER_OBS_JAC = 186.5    # materialised residual+Jacobian kernel, 10 obs/landmark
 
 

@@ -1257,8 +1257,8 @@ static void mega_build_tasks(int nblk, int nq, int wg_per_q, std::vector<int4>& 
     // the critical chains (STBA_MEGA_RES=5,4,2: +2.4 % predicted, +2.3 % measured), boosting the priority
     // of those rows, cyclic instead of LPT row ownership (+8 %).  What the model says: with 320 workers
     // instead of 256 the makespan would be 2.36 ms, with unlimited workers 2.30 ms (the chain): the first
-    // 1.6 ms are bound by MFMA capacity (a trailing update runs at 23.4 us, the FP64 MFMA ceiling of one
-    // CU is 22.8 us), the rest by the chain D -> TU -> D.
+    // 1.6 ms are bound by the rate of the trailing-update task (23.4 us per tile; DESIGN.md lists what was
+    // tried inside it), the rest by the chain D -> TU -> D.
     typedef std::pair<double, int> PI;
     typedef std::priority_queue<PI, std::vector<PI>, std::greater<PI>> Heap;
     int RES[8] = {0, 0, 0, 0, 0, 0, 0, 0};
