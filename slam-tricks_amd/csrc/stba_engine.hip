@@ -6,6 +6,7 @@
 // There is no CPU fallback: without a HIP device every compute entry point fails.
 #include <algorithm>
 #include <chrono>
+#include <thread>
 #include <vector>
 
 #include "ba_kernels.hpp"
@@ -59,6 +60,16 @@ enum { TS_COST2 = 0, TS_STEP2 = 1, TS_X2 = 2, TS_MODEL = 3, TS_CAM = 4, TS_COUNT
 }  // namespace stba
 
 using namespace stba;
+
+// host-side plan construction runs on a few threads (the camera rows / Schur tasks are independent)
+template <typename F>
+static void host_parallel_for(int n, F fn) {
+    const int nt = std::max(1, std::min({16, (int)std::thread::hardware_concurrency(), n / 64}));
+    if (nt <= 1) { fn(0, n, 0); return; }
+    std::vector<std::thread> th;
+    for (int k = 0; k < nt; ++k) th.emplace_back([=] { fn((int)((long)n * k / nt), (int)((long)n * (k + 1) / nt), k); });
+    for (auto& t : th) t.join();
+}
 
 struct stba_ba {
     int nc = 0, np = 0, no = 0, n = 0, lda = 0;
@@ -654,6 +665,14 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
     }
     int rc = STBA_OK;
     auto bail = [&](int code) { ba_free(b); return code; };
+    static const bool TIMING = [] { const char* e = getenv("STBA_CREATE_TIMING"); return e && atoi(e) != 0; }();
+    auto tc0 = std::chrono::steady_clock::now();
+    auto tmark = [&](const char* what) {
+        if (!TIMING) return;
+        auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "stba_ba_create: %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t1 - tc0).count());
+        tc0 = t1;
+    };
     for (auto& e : b->ev) {
         if (hipEventCreate(&e) != hipSuccess) return bail(fail(STBA_ERR_HIP, "hipEventCreate"));
     }
@@ -697,22 +716,29 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
     }
     cam_chunk_start[n_cams] = (int)chunk_begin.size();
     b->n_chunks = (int)chunk_begin.size();
+    tmark("regroup observations");
     // ---- row-wise Schur plan: distinct partner cameras c2 <= c of every camera row + tasks
     std::vector<int> row_col_ptr(n_cams + 1, 0), row_cols, task_cam, task_begin, task_end;
     std::vector<unsigned char> task_single;
     int max_cols = 0;
     {
-        std::vector<int> stamp(n_cams, -1), tmp;
-        for (int c = 0; c < n_cams; ++c) {
-            tmp.clear();
-            for (int p = cam_start[c]; p < cam_start[c + 1]; ++p) {
-                const int j = s_pt[cam_perm[p]];
-                for (int l = pt_start[j]; l < pt_start[j + 1]; ++l) {
-                    const int c2 = s_cam[l];
-                    if (c2 <= c && stamp[c2] != c) { stamp[c2] = c; tmp.push_back(c2); }
+        std::vector<std::vector<int>> cols_of((size_t)n_cams);
+        host_parallel_for(n_cams, [&](int c_lo, int c_hi, int) {
+            std::vector<int> stamp(n_cams, -1);
+            for (int c = c_lo; c < c_hi; ++c) {
+                std::vector<int>& tmp = cols_of[(size_t)c];
+                for (int p = cam_start[c]; p < cam_start[c + 1]; ++p) {
+                    const int j = s_pt[cam_perm[p]];
+                    for (int l = pt_start[j]; l < pt_start[j + 1]; ++l) {
+                        const int c2 = s_cam[l];
+                        if (c2 <= c && stamp[c2] != c) { stamp[c2] = c; tmp.push_back(c2); }
+                    }
                 }
+                std::sort(tmp.begin(), tmp.end());
             }
-            std::sort(tmp.begin(), tmp.end());
+        });
+        for (int c = 0; c < n_cams; ++c) {
+            const std::vector<int>& tmp = cols_of[(size_t)c];
             row_cols.insert(row_cols.end(), tmp.begin(), tmp.end());
             row_col_ptr[c + 1] = (int)row_cols.size();
             max_cols = std::max(max_cols, (int)tmp.size());
@@ -736,6 +762,7 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
         auto permute = [&](auto& v) { auto t = v; for (size_t k = 0; k < order.size(); ++k) v[k] = t[order[k]]; };
         permute(task_cam); permute(task_begin); permute(task_end); permute(task_single);
     }
+    tmark("row plan");
     const bool row_plan = max_cols <= SCHUR_MAX_COLS;
     b->n_tasks = row_plan ? (int)task_cam.size() : 0;
     b->max_cols = max_cols;
@@ -747,27 +774,51 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
     static const bool PAIRS = [] { const char* v = getenv("STBA_SCHUR_PAIRS"); return !v || atoi(v) != 0; }();
     bool pair_plan = PAIRS && row_plan && max_cols < 0x4000;
     if (pair_plan) {
-        pair_begin.resize(task_cam.size()); pair_end.resize(task_cam.size());
-        for (size_t k = 0; k < task_cam.size() && pair_plan; ++k) {
-            const int c = task_cam[k];
-            const int* cb = row_cols.data() + row_col_ptr[c];
-            const int nco = row_col_ptr[c + 1] - row_col_ptr[c];
-            pair_begin[k] = (int)pair_il.size();
-            for (int p = task_begin[k]; p < task_end[k]; ++p) {
-                const int i = cam_perm[p];
-                const int j = s_pt[i];
-                for (int l = pt_start[j]; l < pt_start[j + 1]; ++l) {
-                    const int c2 = s_cam[l];
-                    if (c2 > c) continue;
-                    const int slot = (int)(std::lower_bound(cb, cb + nco, c2) - cb);
-                    pair_il.push_back(make_int2(i, l));
-                    pair_slot.push_back((unsigned short)(slot | (c2 == c ? 0x8000 : 0) | (l == i ? 0x4000 : 0)));
+        const int ntask = (int)task_cam.size();
+        pair_begin.resize((size_t)ntask); pair_end.resize((size_t)ntask);
+        // pass 1: pairs per task; pass 2: fill (both over independent tasks, on a few threads)
+        std::vector<size_t> cnt((size_t)ntask + 1, 0);
+        host_parallel_for(ntask, [&](int k_lo, int k_hi, int) {
+            for (int k = k_lo; k < k_hi; ++k) {
+                const int c = task_cam[(size_t)k];
+                size_t m = 0;
+                for (int p = task_begin[(size_t)k]; p < task_end[(size_t)k]; ++p) {
+                    const int j = s_pt[cam_perm[p]];
+                    for (int l = pt_start[j]; l < pt_start[j + 1]; ++l) m += (s_cam[l] <= c) ? 1 : 0;
                 }
+                cnt[(size_t)k + 1] = m;
             }
-            pair_end[k] = (int)pair_il.size();
-            if (pair_il.size() > ((size_t)1 << 28)) pair_plan = false;      // > 2.7 GB of plan: keep the row kernel
+        });
+        for (int k = 0; k < ntask; ++k) cnt[(size_t)k + 1] += cnt[(size_t)k];
+        if (cnt[(size_t)ntask] > ((size_t)1 << 28)) pair_plan = false;          // > 2.7 GB of plan: keep the row kernel
+        if (pair_plan) {
+            pair_il.resize(cnt[(size_t)ntask]); pair_slot.resize(cnt[(size_t)ntask]);
+            host_parallel_for(ntask, [&](int k_lo, int k_hi, int) {
+                std::vector<int> slot_of((size_t)n_cams, 0);
+                for (int k = k_lo; k < k_hi; ++k) {
+                    const int c = task_cam[(size_t)k];
+                    const int* cb = row_cols.data() + row_col_ptr[c];
+                    const int nco = row_col_ptr[c + 1] - row_col_ptr[c];
+                    for (int q = 0; q < nco; ++q) slot_of[(size_t)cb[q]] = q;
+                    size_t w = cnt[(size_t)k];
+                    pair_begin[(size_t)k] = (int)w;
+                    for (int p = task_begin[(size_t)k]; p < task_end[(size_t)k]; ++p) {
+                        const int i = cam_perm[p];
+                        const int j = s_pt[i];
+                        for (int l = pt_start[j]; l < pt_start[j + 1]; ++l) {
+                            const int c2 = s_cam[l];
+                            if (c2 > c) continue;
+                            pair_il[w] = make_int2(i, l);
+                            pair_slot[w] = (unsigned short)(slot_of[(size_t)c2] | (c2 == c ? 0x8000 : 0) | (l == i ? 0x4000 : 0));
+                            ++w;
+                        }
+                    }
+                    pair_end[(size_t)k] = (int)w;
+                }
+            });
         }
     }
+    tmark("pair plan");
     std::vector<unsigned char> cmask;
     if (cam_fixed) {
         cmask.resize(n_cams);
@@ -782,6 +833,7 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
     const int per_cu = std::max(1, std::min(4, (int)((160 * 1024) / std::max<size_t>(lds, 1))));
     b->lin_grid = std::max(1, std::min(n_tiles, num_cu * per_cu));
 
+    tmark("masks");
 #define A_(call) do { rc = (call); if (rc != STBA_OK) return bail(rc); } while (0)
     const size_t no = (size_t)n_obs, np = (size_t)n_pts, nc = (size_t)n_cams;
     for (int k = 0; k < 2; ++k) { A_(dev_alloc(&b->cams[k], nc * 7)); A_(dev_alloc(&b->pts[k], np * 3)); }
@@ -812,6 +864,7 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
     A_(dev_alloc(&b->upd_partial_p, (size_t)((n_pts + 255) / 256 + 1) * 4));
     A_(dev_alloc(&b->trial, (size_t)TS_COUNT)); A_(dev_alloc(&b->flag, 1));
 
+    tmark("device allocations");
     A_(upload(b->cams[0], cams, nc * 7, b->st)); A_(upload(b->pts[0], pts, np * 3, b->st));
     A_(upload(reinterpret_cast<double*>(b->feat), s_feat.data(), no * 2, b->st));
     A_(upload(b->obs_cam, s_cam.data(), no, b->st)); A_(upload(b->obs_pt, s_pt.data(), no, b->st));
@@ -839,6 +892,7 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
         hipStreamSynchronize(b->st) != hipSuccess)
         return bail(fail(STBA_ERR_HIP, "stba_ba_create: initial memset/sync failed"));
 #undef A_
+    tmark("uploads + sync");
     *out = b;
     return STBA_OK;
 }
