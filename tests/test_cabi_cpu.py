@@ -67,3 +67,16 @@ def test_product_never_touches_oracle():
                     if s.startswith(("#", "//", "*", '"""')) or "oracle/" in s and ("never" in s or "no dependency" in s or "Nothing in" in s):
                         continue
                     assert "oracle_py" not in s and "liboracle" not in s and "import oracle" not in s, (f, s)
+
+
+def test_schedule_model_runs_on_the_host():
+    """The scheduling model behind the persistent factorisation kernel is host code (no GPU): its predicted
+    makespan is at least the critical chain (47 block columns x (D + TU) at n = 6000) and at least the work
+    divided by the workers, grows with n, and shrinks when the model gets more workers."""
+    st = importlib.import_module("slam-tricks_amd")
+    m6 = st.cholesky_schedule_model(6000)
+    assert 47 * (29.0 + 20.0) - 1 <= m6 <= 1.25 * 47 * (29.0 + 20.0)
+    assert st.cholesky_schedule_model(3000) < m6 < st.cholesky_schedule_model(9000)
+    assert st.cholesky_schedule_model(6000, 1, 4096) <= 47 * 49.0 + 1e-6 <= st.cholesky_schedule_model(6000, 1, 320) <= m6
+    with pytest.raises(st.StbaError):
+        st.cholesky_schedule_model(0)
