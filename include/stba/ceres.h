@@ -24,9 +24,13 @@
 // Where the work runs.  User CostFunction::Evaluate / autodiff functors are host code and are
 // evaluated on the host (as in the reference); everything else -- normal equations, Schur
 // complement, Cholesky, LM step -- runs in libstba's HIP kernels:
-//   * residual blocks that are all stba_ceres::ReprojectionFactor (the built-in form of
-//     ns_st20::ProjectFactor, test_ceres.h:47-81) -> fully device-resident BA engine (stba_ba_*):
-//     residuals and Jacobians are computed by the HIP kernel too;
+//   * residual blocks that ARE the reprojection factor of test_ceres.h:47-81 -- either the built-in
+//     stba_ceres::ReprojectionFactor or ANY user cost function with blocks {4, 3, 3} -> 2 residuals
+//     (the reference's own ns_st20::ProjectFactor behind DynamicAutoDiffCostFunction, test_ceres.h:111-121)
+//     that is recognised numerically (internal::ProbeReprojection: its value equals
+//     proj(R^T (L - t)) - feature at generic points, its Jet Jacobian equals the closed form)
+//     -> fully device-resident BA engine (stba_ba_*): residuals and Jacobians are computed by the
+//     HIP kernel too, the user functor is never called during the solve;
 //   * any other problem -> the callback path of stba_dense_solve (<= 4096 local parameters).
 // There is no CPU solver behind this header: without a HIP device Solve() reports FAILURE.
 #ifndef STBA_CERES_H
@@ -41,6 +45,8 @@
 #include <memory>
 #include <set>
 #include <string>
+#include <typeindex>
+#include <typeinfo>
 #include <vector>
 
 #include "../stba.h"
@@ -500,7 +506,83 @@ inline void FillSummary(const stba_lm_summary& s, const std::vector<double>& tra
     }
 }
 
-// ---- path 1: every residual block is a built-in ReprojectionFactor --------------------------
+// ---- recognising the reprojection factor behind an arbitrary CostFunction ---------------------
+// The reference's BA call site (st20-g2o/src/include/test_ceres.h:109-121) builds every residual block
+// from its OWN functor (ns_st20::ProjectFactor behind DynamicAutoDiffCostFunction, blocks 4/3/3 -> 2).
+// Such a block runs on the device if it IS the built-in factor: r = proj(conj(q) (L - t)) - feature.
+inline void ReprojectionAt(const double* q, const double* t, const double* L, double* proj, double* pc_out = nullptr) {
+    const double u0 = -q[0], u1 = -q[1], u2 = -q[2], w = q[3];
+    const double v0 = L[0] - t[0], v1 = L[1] - t[1], v2 = L[2] - t[2];
+    const double a0 = 2.0 * (u1 * v2 - u2 * v1), a1 = 2.0 * (u2 * v0 - u0 * v2), a2 = 2.0 * (u0 * v1 - u1 * v0);
+    const double x = v0 + w * a0 + (u1 * a2 - u2 * a1), y = v1 + w * a1 + (u2 * a0 - u0 * a2), z = v2 + w * a2 + (u0 * a1 - u1 * a0);
+    proj[0] = x / z; proj[1] = y / z;
+    if (pc_out) { pc_out[0] = x; pc_out[1] = y; pc_out[2] = z; }
+}
+
+// generic probe points (unit quaternions, landmark well in front of the camera)
+struct ProbePoint { double q[4], t[3], L[3]; };
+inline const ProbePoint* ProbePoints() {
+    static const ProbePoint pts[2] = {
+        {{0.18257418583505536, 0.3651483716701107, 0.5477225575051661, 0.7302967433402214}, {0.3, -0.2, 0.1}, {1.1, 0.7, 2.9}},
+        {{-0.2721655269759087, 0.1360827634879543, 0.4082482904638630, 0.8606629658238704}, {-0.4, 0.25, -0.6}, {0.2, -0.9, 3.3}}};
+    return pts;
+}
+
+// value check of ONE residual block: recovers `feature` at the canonical point (identity rotation, camera at
+// the origin, landmark on the optical axis: proj = 0, so feature = -residual) and requires
+// residual == proj - feature at two generic points.  No Jacobians requested (doubles only: cheap enough to run
+// on every one of the 10^6 blocks of config C5).
+inline bool ProbeReprojectionValue(const CostFunction* cost, double* feature) {
+    const auto& sz = cost->parameter_block_sizes();
+    if (cost->num_residuals() != 2 || sz.size() != 3 || sz[0] != 4 || sz[1] != 3 || sz[2] != 3) return false;
+    const double q0[4] = {0, 0, 0, 1}, t0[3] = {0, 0, 0}, L0[3] = {0, 0, 1};
+    const double* p0[3] = {q0, t0, L0};
+    double r[2] = {0, 0};
+    if (!cost->Evaluate(p0, r, nullptr) || !std::isfinite(r[0]) || !std::isfinite(r[1])) return false;
+    feature[0] = -r[0]; feature[1] = -r[1];
+    const ProbePoint* pp = ProbePoints();
+    for (int k = 0; k < 2; ++k) {
+        const double* p[3] = {pp[k].q, pp[k].t, pp[k].L};
+        double proj[2];
+        ReprojectionAt(pp[k].q, pp[k].t, pp[k].L, proj);
+        if (!cost->Evaluate(p, r, nullptr)) return false;
+        for (int i = 0; i < 2; ++i)
+            if (!(std::fabs(r[i] - (proj[i] - feature[i])) <= 1e-12 * (1.0 + std::fabs(proj[i]) + std::fabs(feature[i])))) return false;
+    }
+    return true;
+}
+
+// derivative check, once per cost-function TYPE: the ambient Jacobians the user's Evaluate returns, composed
+// with the quaternion right-plus chart, must equal the closed form the HIP kernel evaluates
+// (A hat(pInC) | -A R^T | A R^T, A = d proj / d pInC; SURVEY.md header fact 2).
+inline bool ProbeReprojectionJacobian(const CostFunction* cost) {
+    const ProbePoint& P = ProbePoints()[0];
+    const double* p[3] = {P.q, P.t, P.L};
+    double r[2], Jq[8], Jt[6], JL[6];
+    double* J[3] = {Jq, Jt, JL};
+    if (!cost->Evaluate(p, r, J)) return false;
+    double plus[12];
+    QuaternionRightPlus().ComputeJacobian(P.q, plus);
+    double proj[2], pc[3];
+    ReprojectionAt(P.q, P.t, P.L, proj, pc);
+    const double zi = 1.0 / pc[2];
+    const double A[6] = {zi, 0, -pc[0] * zi * zi, 0, zi, -pc[1] * zi * zi};
+    const double H[9] = {0, -pc[2], pc[1], pc[2], 0, -pc[0], -pc[1], pc[0], 0};
+    const double x = P.q[0], y = P.q[1], z = P.q[2], w = P.q[3];
+    const double R[9] = {1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y), 2 * (x * y + w * z), 1 - 2 * (x * x + z * z),
+                         2 * (y * z - w * x), 2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)};
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double rot = 0, exp_rot = 0, exp_L = 0;
+            for (int g = 0; g < 4; ++g) rot += Jq[i * 4 + g] * plus[g * 3 + j];
+            for (int k = 0; k < 3; ++k) { exp_rot += A[i * 3 + k] * H[k * 3 + j]; exp_L += A[i * 3 + k] * R[j * 3 + k]; }   // (A R^T)_ij
+            if (!(std::fabs(rot - exp_rot) <= 1e-9) || !(std::fabs(JL[i * 3 + j] - exp_L) <= 1e-9) ||
+                !(std::fabs(Jt[i * 3 + j] + exp_L) <= 1e-9)) return false;
+        }
+    return true;
+}
+
+// ---- path 1: every residual block is the reprojection factor (built-in or recognised) --------
 struct BaLayout {
     std::vector<int> rot_block, pos_block;   // per camera: Problem block indices
     std::vector<int> pt_block;               // per landmark
@@ -512,9 +594,20 @@ inline bool DetectBa(Problem& p, BaLayout* L) {
     if (p.residuals().empty()) return false;
     std::map<std::pair<int, int>, int> cam_of;   // (rot block, pos block) -> camera index
     std::map<int, int> pt_of;
+    std::set<std::type_index> checked_types;
     for (auto& r : p.residuals()) {
         auto* f = dynamic_cast<ReprojectionFactor*>(r.cost);
-        if (!f) return false;
+        double feature[2];
+        if (f) { feature[0] = f->fx(); feature[1] = f->fy(); }
+        else {
+            // the user's own cost function (test_ceres.h:111-121): accepted iff it IS the reprojection factor
+            if (!ProbeReprojectionValue(r.cost, feature)) return false;
+            const std::type_index ti(typeid(*r.cost));
+            if (!checked_types.count(ti)) {
+                if (!ProbeReprojectionJacobian(r.cost)) return false;
+                checked_types.insert(ti);
+            }
+        }
         const auto& rb = p.blocks()[r.blocks[0]];
         if (!rb.local || !dynamic_cast<QuaternionRightPlus*>(rb.local)) {
             // a user LocalParameterization with the same 4 -> 3 signature is accepted only if it IS the
@@ -533,7 +626,7 @@ inline bool DetectBa(Problem& p, BaLayout* L) {
         if (pi == pt_of.end()) { j = (int)L->pt_block.size(); pt_of[r.blocks[2]] = j; L->pt_block.push_back(r.blocks[2]); }
         else j = pi->second;
         L->obs_cam.push_back(c); L->obs_pt.push_back(j);
-        L->feat.push_back(f->fx()); L->feat.push_back(f->fy());
+        L->feat.push_back(feature[0]); L->feat.push_back(feature[1]);
     }
     // a rotation block must not be shared by two cameras with different position blocks
     std::set<int> rots(L->rot_block.begin(), L->rot_block.end()), poss(L->pos_block.begin(), L->pos_block.end());

@@ -152,7 +152,8 @@ struct VisualCallBack : public ceres::IterationCallback {
     }
 };
 
-// test_ceres.h:47-81 with the user's own functor (generic path)
+// test_ceres.h:47-81: the user's own functor.  Solve() recognises it numerically as the reprojection factor
+// and runs the problem on the device-resident BA engine (execution_path "gpu-ba") -- no source edit.
 struct ProjectFactor {
     double feature[2];
     explicit ProjectFactor(const double* f) { feature[0] = f[0]; feature[1] = f[1]; }
@@ -163,6 +164,22 @@ struct ProjectFactor {
         QuatConjRotate(q, d, pc);
         residuals[0] = pc[0] / pc[2] - T(feature[0]);
         residuals[1] = pc[1] / pc[2] - T(feature[1]);
+        return true;
+    }
+};
+
+// NOT the reprojection factor (residual scaled by 2: same minimiser, different function): must be rejected
+// by the probe and run through the host-callback path.
+struct ScaledProjectFactor {
+    double feature[2];
+    explicit ScaledProjectFactor(const double* f) { feature[0] = f[0]; feature[1] = f[1]; }
+    static auto Create(const double* f) { return new ceres::DynamicAutoDiffCostFunction<ScaledProjectFactor>(new ScaledProjectFactor(f)); }
+    template <typename T> bool operator()(T const* const* parameters, T* residuals) const {
+        const T* q = parameters[0]; const T* t = parameters[1]; const T* L = parameters[2];
+        T d[3] = {L[0] - t[0], L[1] - t[1], L[2] - t[2]}, pc[3];
+        QuatConjRotate(q, d, pc);
+        residuals[0] = T(2.0) * (pc[0] / pc[2] - T(feature[0]));
+        residuals[1] = T(2.0) * (pc[1] / pc[2] - T(feature[1]));
         return true;
     }
 };
@@ -198,16 +215,22 @@ static void print_vec(const char* key, const double* v, int n) {
     std::printf("\n");
 }
 
-// test_ceres.h:98-152 (builtin = ReprojectionFactor -> device-resident path; else the user's functor)
-static void SolveBA(Scene s, bool builtin, const char* tag) {
+// test_ceres.h:98-152.  kind 0: the built-in ReprojectionFactor; 1: the user's ProjectFactor exactly as the
+// reference constructs it (test_ceres.h:109-130); 2: a user functor that is NOT the reprojection factor.
+static void SolveBA(Scene& s, int kind, const char* tag, int max_iterations = 50, int print_cams = -1) {
     ceres::LocalParameterization* localParameterization = new LieLocalParameterization();
     ceres::Problem problem;
     for (int i = 0; i < s.no; ++i) {
         double* so3 = &s.cams[s.oc[i] * 7]; double* pos = so3 + 4; double* lm = &s.pts[s.op[i] * 3];
-        if (builtin) {
+        if (kind == 0) {
             problem.AddResidualBlock(ceres::ReprojectionFactor::Create(&s.feat[i * 2]), nullptr, {so3, pos, lm});
-        } else {
+        } else if (kind == 1) {
             auto costFunc = ProjectFactor::Create(&s.feat[i * 2]);
+            costFunc->AddParameterBlock(4); costFunc->AddParameterBlock(3); costFunc->AddParameterBlock(3);
+            costFunc->SetNumResiduals(2);
+            problem.AddResidualBlock(costFunc, nullptr, {so3, pos, lm});
+        } else {
+            auto costFunc = ScaledProjectFactor::Create(&s.feat[i * 2]);
             costFunc->AddParameterBlock(4); costFunc->AddParameterBlock(3); costFunc->AddParameterBlock(3);
             costFunc->SetNumResiduals(2);
             problem.AddResidualBlock(costFunc, nullptr, {so3, pos, lm});
@@ -218,16 +241,56 @@ static void SolveBA(Scene s, bool builtin, const char* tag) {
     ceres::Solver::Options options;
     options.num_threads = 1;
     options.linear_solver_type = ceres::SPARSE_SCHUR;
+    options.max_num_iterations = max_iterations;
     ceres::Solver::Summary summary;
     ceres::Solve(options, &problem, &summary);
     std::printf("%s_path %s\n%s_report %s\n", tag, summary.execution_path.c_str(), tag, summary.FullReport().c_str());
     std::printf("%s_term %d iters %d initial %.17g final %.17g\n", tag, (int)summary.termination_type,
                 (int)summary.iterations.size() - 1, summary.initial_cost, summary.final_cost);
-    std::string k = std::string(tag) + "_cams"; print_vec(k.c_str(), s.cams.data(), s.nc * 7);
+    std::string k = std::string(tag) + "_costs";
+    std::vector<double> costs;
+    for (auto& it : summary.iterations) costs.push_back(it.cost);
+    print_vec(k.c_str(), costs.data(), (int)costs.size());
+    k = std::string(tag) + "_cams"; print_vec(k.c_str(), s.cams.data(), (print_cams < 0 ? s.nc : std::min(s.nc, print_cams)) * 7);
     k = std::string(tag) + "_pts"; print_vec(k.c_str(), s.pts.data(), std::min(s.np, 50) * 3);
 }
 
+// host-only: what Solve() would dispatch to for each kind of problem (no device needed)
+static void ProbeOnly(Scene& s, int kind, const char* tag) {
+    ceres::LocalParameterization* lp = new LieLocalParameterization();
+    ceres::Problem problem;
+    for (int i = 0; i < s.no; ++i) {
+        double* so3 = &s.cams[s.oc[i] * 7]; double* pos = so3 + 4; double* lm = &s.pts[s.op[i] * 3];
+        ceres::CostFunction* cf;
+        if (kind == 1) { auto c = ProjectFactor::Create(&s.feat[i * 2]); c->AddParameterBlock(4); c->AddParameterBlock(3); c->AddParameterBlock(3); c->SetNumResiduals(2); cf = c; }
+        else { auto c = ScaledProjectFactor::Create(&s.feat[i * 2]); c->AddParameterBlock(4); c->AddParameterBlock(3); c->AddParameterBlock(3); c->SetNumResiduals(2); cf = c; }
+        problem.AddResidualBlock(cf, nullptr, {so3, pos, lm});
+        problem.AddParameterBlock(so3, 4, lp);
+    }
+    ceres::internal::BaLayout L;
+    bool ba = ceres::internal::DetectBa(problem, &L);
+    if (ba) for (int rb : L.rot_block) ba = ba && ceres::internal::UsesQuaternionRightPlus(problem.blocks()[rb].local);
+    double ferr = 0;
+    if (ba) for (int i = 0; i < s.no; ++i) for (int k = 0; k < 2; ++k) ferr = std::fmax(ferr, std::fabs(L.feat[i * 2 + k] - s.feat[i * 2 + k]));
+    std::printf("%s detected %d cams %d pts %d obs %d feature_err %.3g\n", tag, (int)ba, (int)L.rot_block.size(), (int)L.pt_block.size(),
+                (int)L.obs_cam.size(), ferr);
+}
+
 int main(int argc, char** argv) {
+    if (argc >= 3 && std::strcmp(argv[1], "probe") == 0) {
+        Scene s;
+        if (!s.load(argv[2])) { std::printf("scene_load_failed\n"); return 2; }
+        { Scene a = s; ProbeOnly(a, 1, "probe_user"); }
+        { Scene a = s; ProbeOnly(a, 2, "probe_scaled"); }
+        return 0;
+    }
+    // ---- "big <scene> <iterations>": ONLY the reference's unchanged BA call site, at any size (config C5)
+    if (argc >= 4 && std::strcmp(argv[1], "big") == 0) {
+        Scene s;
+        if (!s.load(argv[2])) { std::printf("scene_load_failed\n"); return 2; }
+        SolveBA(s, 1, "ba_user", std::atoi(argv[3]), 1000000);
+        return 0;
+    }
     // ---- ceres_bound.cpp:25-68
     for (int bounded = 0; bounded < 2; ++bounded) {
         ceres::Problem problem;
@@ -314,7 +377,8 @@ int main(int argc, char** argv) {
     // ---- BA: test_ceres.h:98-152
     Scene s;
     if (!s.load(argv[2])) { std::printf("scene_load_failed\n"); return 2; }
-    SolveBA(s, true, "ba_builtin");
-    if (argc > 3) { Scene s2; if (s2.load(argv[3])) SolveBA(s2, false, "ba_generic"); }
+    { Scene a = s; SolveBA(a, 0, "ba_builtin"); }
+    { Scene a = s; SolveBA(a, 1, "ba_user"); }            // the reference's unchanged call site
+    if (argc > 3) { Scene s2; if (s2.load(argv[3])) SolveBA(s2, 2, "ba_generic"); }
     return 0;
 }

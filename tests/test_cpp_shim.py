@@ -66,6 +66,20 @@ def test_shim_compiles_and_fails_loudly_without_device(exe):
         assert abs(float(out["bound_0"].split()[1]) - 3.0) < 1e-8
 
 
+def test_reference_ba_functor_is_recognised_on_the_host(exe, tmp_path, scenes):
+    """Solve()'s dispatch (no device needed): the reference's own ProjectFactor behind DynamicAutoDiffCostFunction
+    (test_ceres.h:47-81,109-121) is recognised as the reprojection factor, every `feature` is recovered exactly
+    enough (1e-15), the observation structure is rebuilt; a functor with another residual is rejected."""
+    s = scenes.st20_scene()
+    f = str(tmp_path / "s.bin")
+    write_scene(f, s)
+    out = run(exe, "probe", f)
+    toks = out["probe_user"].split()
+    assert toks[:8] == ["detected", "1", "cams", str(len(s["cams0"])), "pts", str(len(s["pts0"])), "obs", str(len(s["obs_cam"]))]
+    assert float(toks[-1]) < 1e-15
+    assert out["probe_scaled"].split()[1] == "0"
+
+
 def vec(out, key):
     return np.array([float(x) for x in out[key].split()])
 
@@ -111,13 +125,41 @@ def test_reference_call_sites_on_gpu(exe, tmp_path, scenes, O, known):
     dq = np.minimum(np.abs(cams[:, :4] - o.cams[:, :4]).max(1), np.abs(cams[:, :4] + o.cams[:, :4]).max(1)).max()
     assert dq < 1e-8 and np.abs(cams[:, 4:] - o.cams[:, 4:]).max() < 1e-8
     assert np.all(cams[0] == sc["cams0"][0]) and np.all(cams[-1] == sc["cams0"][-1])
-    # BA, the user's own autodiff functor: callback path, same minimiser
+    # BA, the reference's UNCHANGED call site (user ProjectFactor behind DynamicAutoDiffCostFunction,
+    # test_ceres.h:109-130): recognised numerically, runs on the device-resident engine, bit-identical to
+    # the built-in factor and equal to the oracle's trace
+    assert out["ba_user_path"] == "gpu-ba"
+    assert out["ba_user_term"] == out["ba_builtin_term"]
+    assert np.array_equal(vec(out, "ba_user_cams"), vec(out, "ba_builtin_cams"))
+    assert np.array_equal(vec(out, "ba_user_pts"), vec(out, "ba_builtin_pts"))
+    # BA with a user functor that is NOT the reprojection factor: callback path, same minimiser
     assert out["ba_generic_path"] == "gpu-dense-callback"
     o2 = O.BA(small["cams0"], small["pts0"], small["obs_cam"], small["obs_pt"], small["obs_feat"], small["cam_fixed"])
     o2.solve()
     cams2 = vec(out, "ba_generic_cams").reshape(-1, 7)
     dq = np.minimum(np.abs(cams2[:, :4] - o2.cams[:, :4]).max(1), np.abs(cams2[:, :4] + o2.cams[:, :4]).max(1)).max()
     assert dq < 1e-6 and np.abs(cams2[:, 4:] - o2.cams[:, 4:]).max() < 1e-5
+
+
+@pytest.mark.gpu
+def test_reference_ba_call_site_at_c5_size(exe, tmp_path, scenes, O):
+    """The reference's unchanged Ceres BA call site (test_ceres.h:98-152, one DynamicAutoDiffCostFunction per
+    observation) at BASELINE config C5: 10^6 user cost functions are probed, the problem runs on the
+    device-resident engine ("gpu-ba"; the callback path would refuse it), and three LM iterations match
+    the oracle's cost trace to 1e-6 and its camera poses to 1e-5."""
+    s = scenes.st20_scene(n_cams=1000, n_pts=100000, max_obs_per_pt=10, seed=20, pix_noise=1e-3)
+    f = str(tmp_path / "c5.bin")
+    write_scene(f, s)
+    out = run(exe, "big", f, "3")
+    assert out["ba_user_path"] == "gpu-ba", out["ba_user_report"]
+    o = O.BA(s["cams0"], s["pts0"], s["obs_cam"], s["obs_pt"], s["obs_feat"], s["cam_fixed"])
+    so, tro = o.solve(max_num_iterations=3, num_threads=16)
+    costs = vec(out, "ba_user_costs")
+    assert len(costs) == so.num_iterations + 1
+    assert np.allclose(costs, tro[: len(costs), 0], rtol=1e-6)
+    cams = vec(out, "ba_user_cams").reshape(-1, 7)
+    dq = np.minimum(np.abs(cams[:, :4] - o.cams[:, :4]).max(1), np.abs(cams[:, :4] + o.cams[:, :4]).max(1)).max()
+    assert dq < 1e-5 and np.abs(cams[:, 4:] - o.cams[:, 4:]).max() < 1e-5
 
 
 # ---------------------------------------------------------------------------------------------
