@@ -116,6 +116,24 @@ typedef int (*stba_iteration_callback)(void* user, int iteration, double cost, d
  * (landmark sharding, SURVEY.md 8e: RCCL all-reduce of the reduced camera system).  Return 0. */
 typedef int (*stba_allreduce_fn)(void* user, void* buf_dev, size_t count, void* hip_stream);
 
+/* ================================ native RCCL communicator ================================
+ * One process per GPU.  What a C++ host of the reference (st20-g2o/src/src/test_ceres.cpp:7-19)
+ * uses instead of a Python hook: rank 0 makes the id, hands it to the other ranks over its own side channel,
+ * every rank creates its communicator and gives it to the engines (stba_ba_set_comm / stba_pg_set_comm), which
+ * then call ncclAllReduce(buf, buf, count, ncclDouble, ncclSum, comm, stream) on THEIR stream.  RCCL is bound
+ * lazily (dlopen): hosts that never create a communicator need no librccl.
+ * device < 0: the calling thread's current device. */
+#define STBA_COMM_ID_BYTES 128
+typedef struct stba_comm stba_comm;
+int stba_comm_unique_id(char id[STBA_COMM_ID_BYTES]);
+int stba_comm_create(stba_comm** out, const char id[STBA_COMM_ID_BYTES], int rank, int world_size, int device);
+int stba_comm_destroy(stba_comm* comm);
+int stba_comm_rank(const stba_comm* comm, int* rank, int* world_size);
+/* in-place sum of `count` doubles on the device across all ranks, enqueued on hip_stream */
+int stba_comm_allreduce_sum(stba_comm* comm, void* buf_dev, size_t count, void* hip_stream);
+/* the same as an stba_allreduce_fn (user = stba_comm*) */
+int stba_comm_allreduce_hook(void* user, void* buf_dev, size_t count, void* hip_stream);
+
 /* ================================ bundle-adjustment engine ================================ */
 typedef struct stba_ba stba_ba;
 
@@ -133,6 +151,8 @@ int stba_ba_get_params(stba_ba* ba, double* cams, double* pts);
 /* multi-GPU: this engine holds one landmark shard; all cameras are replicated.  The hook sums
  * the packed reduced system / scalars across ranks.  rank 0 owns the once-only diagonal terms. */
 int stba_ba_set_allreduce(stba_ba* ba, stba_allreduce_fn fn, void* user, int rank, int world_size);
+/* the same with a native communicator (NULL: back to a single rank) */
+int stba_ba_set_comm(stba_ba* ba, stba_comm* comm);
 /* padded order of the dense reduced system (multiple of the factorisation block) */
 int stba_ba_reduced_dim(const stba_ba* ba, int* n, int* n_padded);
 
@@ -265,6 +285,7 @@ int stba_pg_destroy(stba_pg* pg);
  * diagonal blocks (42 n doubles per linearisation), every matrix-vector product of the PCG (6 n doubles) and
  * the cost scalars across ranks.  rank 0 owns the once-only damping term. */
 int stba_pg_set_allreduce(stba_pg* pg, stba_allreduce_fn fn, void* user, int rank, int world_size);
+int stba_pg_set_comm(stba_pg* pg, stba_comm* comm);
 int stba_pg_get_poses(stba_pg* pg, double* poses);
 /* r[n_edges*6], Ji / Jj [n_edges*36] (6x6 row-major, wrt delta_i / delta_j); any may be NULL */
 int stba_pg_evaluate(stba_pg* pg, double* cost, double* r, double* Ji, double* Jj);

@@ -68,7 +68,9 @@ EXPORTS = ["stba_status_string", "stba_last_error", "stba_version", "stba_device
            "stba_ba_triangulate", "stba_ba_time_linearize", "stba_cholesky_factor", "stba_cholesky_solve",
            "stba_cholesky_time", "stba_cholesky_time_split", "stba_cholesky_schedule_model", "stba_cholesky_profile", "stba_calib_evaluate", "stba_calib_gauss_newton",
            "stba_pcg_default_options", "stba_pg_create", "stba_pg_destroy", "stba_pg_set_allreduce", "stba_pg_get_poses", "stba_pg_evaluate",
-           "stba_pg_solve", "stba_dense_solve", "stba_corners_read", "stba_corners_write", "stba_zhang_init", "stba_two_view_init", "stba_odometry_read", "stba_odometry_write", "stba_trajectory_ate"]
+           "stba_pg_solve", "stba_dense_solve", "stba_corners_read", "stba_corners_write", "stba_zhang_init", "stba_two_view_init", "stba_odometry_read", "stba_odometry_write", "stba_trajectory_ate",
+           "stba_comm_unique_id", "stba_comm_create", "stba_comm_destroy", "stba_comm_rank", "stba_comm_allreduce_sum",
+           "stba_comm_allreduce_hook", "stba_ba_set_comm", "stba_pg_set_comm"]
 
 
 def lib():
@@ -120,6 +122,41 @@ def default_options(**kw):
     return o
 
 
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """rank 0: the 128-byte id every rank passes to Comm(...) (ncclGetUniqueId)"""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    _chk(lib().stba_comm_unique_id(buf), "stba_comm_unique_id")
+    return buf.raw
+
+
+class Comm:
+    """Native RCCL communicator (one per process / GPU): the engines all-reduce on their own stream through it,
+    no Python on the data path."""
+
+    def __init__(self, uid, rank, world, device=-1):
+        self._h = C.c_void_p()
+        self.rank, self.world = int(rank), int(world)
+        _chk(lib().stba_comm_create(C.byref(self._h), C.c_char_p(bytes(uid)), self.rank, self.world, int(device)), "stba_comm_create")
+
+    def allreduce_sum(self, ptr, count, stream=None):
+        _chk(lib().stba_comm_allreduce_sum(self._h, C.c_void_p(ptr), C.c_size_t(count), C.c_void_p(stream or 0)),
+             "stba_comm_allreduce_sum")
+
+    def close(self):
+        if self._h:
+            lib().stba_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class BAEngine:
     """Device-resident bundle-adjustment problem (one landmark shard per engine)."""
 
@@ -162,6 +199,11 @@ class BAEngine:
         cb = ALLREDUCE_FN(fn)
         self._keep.append(cb)
         _chk(lib().stba_ba_set_allreduce(self._h, cb, None, rank, world), "stba_ba_set_allreduce")
+
+    def set_comm(self, comm):
+        """landmark shard of a multi-GPU solve: cross-rank sums through a native RCCL communicator"""
+        self._keep.append(comm)
+        _chk(lib().stba_ba_set_comm(self._h, comm._h if comm is not None else None), "stba_ba_set_comm")
 
     def reduced_dim(self):
         n, npad = C.c_int(), C.c_int()

@@ -130,16 +130,16 @@ size_t lin_lds_bytes(int n_cams, bool cams_in_lds, bool with_jac) {
 int launch_linearize(const LinArgs& a, bool with_jac, int grid, hipStream_t st) {
     const bool in_lds = lin_lds_bytes(a.n_cams, true, with_jac) <= LIN_MAX_LDS;
     const size_t lds = lin_lds_bytes(a.n_cams, in_lds, with_jac);
-    static bool attr = false;
-    if (!attr) {
+    static DeviceOnce attr;
+    STBA_TRY(attr.run([]() -> int {
         STBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_linearize_kernel<true, true>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, LIN_MAX_LDS));
         STBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_linearize_kernel<true, false>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, LIN_MAX_LDS));
         STBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_linearize_kernel<false, true>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, LIN_MAX_LDS));
-        attr = true;
-    }
+        return STBA_OK;
+    }));
     if (in_lds && with_jac)
         hipLaunchKernelGGL((ba_linearize_kernel<true, true>), dim3(grid), dim3(LIN_THREADS), lds, st, a);
     else if (in_lds)
@@ -683,14 +683,16 @@ size_t schur_rows_lds_bytes(int max_cols) {
 int launch_schur_rows(const SchurRowArgs& a, int n_tasks, hipStream_t st) {
     if (n_tasks <= 0) return STBA_OK;
     const size_t lds = schur_rows_lds_bytes(a.max_cols);
-    static size_t attr_lds = 0;
-    if (lds > attr_lds) {
+    // the largest plan the engine ever builds (SCHUR_MAX_COLS columns) fixes the limit, once per device
+    static DeviceOnce attr;
+    STBA_TRY(attr.run([]() -> int {
+        const int lim = (int)schur_rows_lds_bytes(SCHUR_MAX_COLS);
         STBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_schur_rows_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, lim));
         STBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_schur_pairs_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_lds = lds;
-    }
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+        return STBA_OK;
+    }));
     if (a.pair_il) {
         hipLaunchKernelGGL(ba_schur_pairs_kernel, dim3(n_tasks), dim3(SCHUR_THREADS), lds, st, a);
     } else {

@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 
 #include "../../include/stba.h"
@@ -33,6 +34,21 @@ inline int fail(int code, const std::string& msg) {
     } while (0)
 
 int require_device();   // STBA_OK or STBA_ERR_NO_DEVICE (there is no CPU fallback)
+
+// runs fn once per DEVICE (function attributes such as the dynamic-LDS limit are per-device state), thread-safe
+struct DeviceOnce {
+    std::mutex m;
+    unsigned long long done = 0;
+    template <class F> int run(F fn) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+        std::lock_guard<std::mutex> g(m);
+        if (dev >= 0 && dev < 64 && ((done >> dev) & 1ull)) return STBA_OK;
+        const int rc = fn();
+        if (rc == STBA_OK && dev >= 0 && dev < 64) done |= 1ull << dev;
+        return rc;
+    }
+};
 
 // ---- dense Cholesky on the device (dense_chol.hip) -----------------------------------------
 constexpr int CHOL_NB = 128;

@@ -29,6 +29,7 @@
 // solve produced).
 #include <algorithm>
 #include <cstdlib>
+#include <map>
 #include <queue>
 #include <string>
 #include <vector>
@@ -1443,8 +1444,22 @@ static int chol_run(double* A, int lda, int n, double* x_dev, int* flag_dev, hip
     // followed by the inverses of its eight 16x16 diagonal tiles (written by the diagonal kernel, read
     // by the panel solve)
     constexpr size_t LINV_STRIDE = (size_t)NB * NB + 8 * 256;
-    static thread_local double* linv = nullptr;
-    static thread_local int linv_blocks = 0;
+    // workspace and task plan are per (host thread, device): a thread that switches devices, or a second GPU in
+    // the same process, must not reuse another device's pointers or XCD probe
+    struct MegaPlan {
+        int nblk = 0, ntasks = 0, nq = 0, ncu = 0;
+        int qstart[17] = {0};
+        signed char xcc_queue[16];
+        int4* tasks = nullptr; int* sync = nullptr; size_t sync_ints = 0;
+        std::vector<float> sim_start;     // simulated start time of every task (written to the trace file)
+    };
+    struct DevWs { double* linv = nullptr; int linv_blocks = 0; MegaPlan plan; };
+    static thread_local std::map<int, DevWs> ws_by_dev;
+    int cur_dev = 0;
+    STBA_HIP(hipGetDevice(&cur_dev));
+    DevWs& ws = ws_by_dev[cur_dev];
+    double*& linv = ws.linv;
+    int& linv_blocks = ws.linv_blocks;
     if (linv_blocks < nblk) {
         if (linv) (void)hipFree(linv);
         linv = nullptr; linv_blocks = 0;
@@ -1490,14 +1505,7 @@ static int chol_run(double* A, int lda, int n, double* x_dev, int* flag_dev, hip
         }
     } else {
         // production: one persistent kernel (see chol_mega_kernel)
-        struct MegaPlan {
-            int nblk = 0, ntasks = 0, nq = 0, ncu = 0;
-            int qstart[17] = {0};
-            signed char xcc_queue[16];
-            int4* tasks = nullptr; int* sync = nullptr; size_t sync_ints = 0;
-            std::vector<float> sim_start;     // simulated start time of every task (written to the trace file)
-        };
-        static thread_local MegaPlan plan;
+        MegaPlan& plan = ws.plan;
         if (plan.nblk != nblk) {
             if (plan.tasks) (void)hipFree(plan.tasks);
             if (plan.sync) (void)hipFree(plan.sync);
@@ -1545,12 +1553,13 @@ static int chol_run(double* A, int lda, int n, double* x_dev, int* flag_dev, hip
         static const char* TRACE = getenv("STBA_MEGA_TRACE");
         ma.trace = nullptr;
         if (TRACE) STBA_HIP(hipMalloc(reinterpret_cast<void**>(&ma.trace), (size_t)plan.ntasks * 8 * sizeof(long long)));
-        static bool attr_set = false;
-        if (!attr_set) {
+        struct TraceGuard { long long*& p; ~TraceGuard() { if (p) { (void)hipFree(p); p = nullptr; } } } trace_guard{ma.trace};
+        static DeviceOnce attr_set;
+        STBA_TRY(attr_set.run([]() -> int {
             STBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(chol_mega_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, MEGA_SMEM_BYTES));
-            attr_set = true;
-        }
+            return STBA_OK;
+        }));
         hipLaunchKernelGGL(chol_mega_kernel, dim3(plan.ncu), dim3(512), MEGA_SMEM_BYTES, st, ma);
         if (TRACE) {    // debugging aid: dump the task timeline of this factorisation (tools/mega_trace.py)
             std::vector<long long> h((size_t)plan.ntasks * 8);
@@ -1558,7 +1567,6 @@ static int chol_run(double* A, int lda, int n, double* x_dev, int* flag_dev, hip
             STBA_HIP(hipStreamSynchronize(st));
             STBA_HIP(hipMemcpy(h.data(), ma.trace, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
             STBA_HIP(hipMemcpy(ht.data(), plan.tasks, ht.size() * sizeof(int4), hipMemcpyDeviceToHost));
-            (void)hipFree(ma.trace);
             if (FILE* f = fopen(TRACE, "wb")) {
                 fwrite(&plan.ntasks, sizeof(int), 1, f);
                 fwrite(ht.data(), sizeof(int4), ht.size(), f);

@@ -509,6 +509,7 @@ int stba_pg_create(stba_pg** out, int n_nodes, int n_edges, const double* poses,
 
 int stba_pg_set_allreduce(stba_pg* g, stba_allreduce_fn fn, void* user, int rank, int world_size) {
     if (!g || rank < 0 || world_size < 1 || rank >= world_size) return fail(STBA_ERR_INVALID_ARGUMENT, "bad argument");
+    if (!fn && world_size > 1) return fail(STBA_ERR_INVALID_ARGUMENT, "stba_pg_set_allreduce: world_size > 1 needs a hook");
     g->ar = (world_size > 1 || fn) ? fn : nullptr;
     g->ar_user = user; g->rank = rank; g->world = world_size;
     return STBA_OK;

@@ -469,8 +469,8 @@ static int ba_run_lm(stba_ba* b, const stba_lm_options* opt_in, int fixed_iterat
         double ts[TS_COUNT];
         STBA_TRY(download(ts, b->trial, TS_COUNT, b->st));
         STBA_TRY(download(&flag_h, b->flag, 1, b->st));
-        STBA_TRY(chol_flag_status(flag_h));
         STBA_HIP(hipStreamSynchronize(b->st));
+        STBA_TRY(chol_flag_status(flag_h));          // (only valid after the synchronisation: the copy is asynchronous)
         if (pending) {
             double c2, g2;
             ba_finish_linear_scalars(b, &c2, &g2);
@@ -924,7 +924,9 @@ int stba_ba_get_params(stba_ba* b, double* cams, double* pts) {
 int stba_ba_set_allreduce(stba_ba* b, stba_allreduce_fn fn, void* user, int rank, int world_size) {
     if (!b || world_size < 1 || rank < 0 || rank >= world_size || world_size > SC_MAX_WORLD)
         return fail(STBA_ERR_INVALID_ARGUMENT, "stba_ba_set_allreduce: bad rank/world");
+    if (!fn && world_size > 1) return fail(STBA_ERR_INVALID_ARGUMENT, "stba_ba_set_allreduce: world_size > 1 needs a hook");
     b->ar = fn; b->ar_user = user; b->rank = rank; b->world = world_size;
+    if (b->lin_pin) { (void)hipHostFree(b->lin_pin); b->lin_pin = nullptr; }     // sized by the world of its first use
     // what travels is decided again with the new group (the union pattern belongs to the group)
     b->pk_state = 0; b->pk_nz = 0;
     if (b->pk_blocks) { (void)hipFree(b->pk_blocks); b->pk_blocks = nullptr; }
@@ -1016,10 +1018,10 @@ int stba_ba_solve_reduced(stba_ba* b, double* dxc) {
     STBA_TRY(chol_factor_solve_dev(b->S(), b->lda, b->n, b->dxc, b->flag, b->st));
     int flag_h = 0;
     STBA_TRY(download(&flag_h, b->flag, 1, b->st));
-    STBA_TRY(chol_flag_status(flag_h));
     if (dxc) STBA_TRY(download(dxc, b->dxc, (size_t)b->n, b->st));
     STBA_HIP(hipStreamSynchronize(b->st));
     b->have_reduced = false;   // S now holds the factor
+    STBA_TRY(chol_flag_status(flag_h));
     if (flag_h != 0) return fail(STBA_ERR_NOT_POSITIVE_DEFINITE, "reduced camera system: pivot " + std::to_string(flag_h));
     b->have_dxc = true;
     return STBA_OK;
@@ -1130,10 +1132,10 @@ int stba_cholesky_factor(double* A, int n, void* hip_stream) {
     STBA_TRY(chol_factor_solve_dev(w.A, w.lda, n, w.x, w.flag, w.st));
     int flag_h = 0;
     STBA_TRY(download(&flag_h, w.flag, 1, w.st));
-    STBA_TRY(chol_flag_status(flag_h));
     STBA_HIP(hipMemcpy2DAsync(A, (size_t)n * sizeof(double), w.A, (size_t)w.lda * sizeof(double),
                               (size_t)n * sizeof(double), (size_t)n, hipMemcpyDeviceToHost, w.st));
     STBA_HIP(hipStreamSynchronize(w.st));
+    STBA_TRY(chol_flag_status(flag_h));
     if (flag_h) return fail(STBA_ERR_NOT_POSITIVE_DEFINITE, "pivot " + std::to_string(flag_h));
     return STBA_OK;
 }
@@ -1147,9 +1149,9 @@ int stba_cholesky_solve(const double* A, int n, double* bvec, void* hip_stream) 
     STBA_TRY(chol_factor_solve_dev(w.A, w.lda, n, w.x, w.flag, w.st));
     int flag_h = 0;
     STBA_TRY(download(&flag_h, w.flag, 1, w.st));
-    STBA_TRY(chol_flag_status(flag_h));
     STBA_TRY(download(bvec, w.x, (size_t)n, w.st));
     STBA_HIP(hipStreamSynchronize(w.st));
+    STBA_TRY(chol_flag_status(flag_h));
     if (flag_h) return fail(STBA_ERR_NOT_POSITIVE_DEFINITE, "pivot " + std::to_string(flag_h));
     return STBA_OK;
 }
@@ -1372,8 +1374,8 @@ int stba_calib_gauss_newton(int n_views, int n_corners, double* params, const do
         STBA_TRY(chol_factor_solve_dev(c.w.A, c.w.lda, n, c.w.x, c.w.flag, c.w.st));   // H.ldlt().solve(g), :393
         int flag_h = 0;
         STBA_TRY(download(&flag_h, c.w.flag, 1, c.w.st)); STBA_TRY(download(g.data(), c.w.x, (size_t)n, c.w.st));
-        STBA_TRY(chol_flag_status(flag_h));
         STBA_HIP(hipStreamSynchronize(c.w.st));
+        STBA_TRY(chol_flag_status(flag_h));
         if (flag_h) return fail(STBA_ERR_NOT_POSITIVE_DEFINITE, "calibration normal equations: pivot " + std::to_string(flag_h));
         double un = 0.0;
         for (int a = 0; a < n; ++a) un += g[a] * g[a];
@@ -1396,6 +1398,8 @@ int stba_dense_solve(stba_residual_fn fn, stba_plus_fn plus, void* user, int n_p
         return fail(STBA_ERR_INVALID_ARGUMENT, "stba_dense_solve: bad argument");
     if ((lower || upper) && plus)
         return fail(STBA_ERR_INVALID_ARGUMENT, "bounds are only supported on Euclidean parameter blocks");
+    if (!plus && n_params != n_local)
+        return fail(STBA_ERR_INVALID_ARGUMENT, "stba_dense_solve: n_params != n_local needs a plus() callback");
     STBA_TRY(require_device());
     stba_lm_options opt;
     if (opt_in) opt = *opt_in; else default_options(&opt);
@@ -1465,8 +1469,8 @@ int stba_dense_solve(stba_residual_fn fn, stba_plus_fn plus, void* user, int n_p
         STBA_TRY(chol_factor_solve_dev(w.A, w.lda, n, w.x, w.flag, w.st));
         int flag_h = 0;
         STBA_TRY(download(&flag_h, w.flag, 1, w.st)); STBA_TRY(download(dx.data(), w.x, (size_t)n, w.st));
-        STBA_TRY(chol_flag_status(flag_h));
         STBA_HIP(hipStreamSynchronize(w.st));
+        STBA_TRY(chol_flag_status(flag_h));
         bool ok = (flag_h == 0);
         double model_change = 0.0, new_cost = 0.0, step_norm = 0.0, rho = 0.0, cost_change = 0.0;
         if (ok) {

@@ -54,10 +54,22 @@ def make_pg_shard(scene, rank, world):
 
 def torch_allreduce_hook(dist, torch):
     """all-reduce hook for BAEngine.set_allreduce: RCCL sum (torch.distributed, backend nccl) of the
-    engine-owned device buffer, enqueued on the current stream -- the same stream the engine was
-    created on, so no extra event is needed for ordering."""
-    def hook(_user, buf, count, _stream):
-        t = torch.as_tensor(DeviceVector(buf, count), device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        return 0
+    engine-owned device buffer, enqueued on the ENGINE's stream (the hook's `stream` argument, wrapped as
+    a torch ExternalStream), so the collective is ordered with the kernels around it without events.
+    Returns nonzero on any failure: a Python exception inside a ctypes callback would otherwise read as
+    success and an unreduced system would be solved silently.  (bench.py uses the native communicator,
+    slam-tricks_amd.Comm; this hook is the fallback and what the gloo CPU tests exercise.)"""
+    def hook(_user, buf, count, stream):
+        try:
+            t = torch.as_tensor(DeviceVector(buf, count), device="cuda")
+            if stream:
+                with torch.cuda.stream(torch.cuda.ExternalStream(int(stream))):
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            else:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            return 0
+        except Exception as e:      # noqa: BLE001
+            import sys
+            print(f"stba all-reduce hook failed: {e!r}", file=sys.stderr, flush=True)
+            return 1
     return hook

@@ -49,6 +49,21 @@ def test_no_device_means_loud_failure(st):
     assert e.value.code == -2
 
 
+def test_native_communicator_needs_a_device(st):
+    """stba_comm_* (the C++-side RCCL collective): exported, and without a device it fails loudly"""
+    if st.device_count() > 0:
+        pytest.skip("a HIP device is present")
+    with pytest.raises(st.StbaError) as e:
+        st.comm_unique_id()
+    assert e.value.code == -2
+    with pytest.raises(st.StbaError) as e:
+        st.Comm(b"\0" * 128, 0, 1)
+    assert e.value.code == -2
+    with pytest.raises(st.StbaError) as e:
+        st.Comm(b"\0" * 128, 2, 2)          # rank out of range
+    assert e.value.code == -1
+
+
 def test_invalid_arguments(st):
     with pytest.raises(st.StbaError) as e:
         st.BAEngine(np.array([[0, 0, 0, 1, 0, 0, 0.0]]), np.array([[0, 0, 5.0]]), [3], [0], [[0.0, 0.0]])

@@ -150,3 +150,26 @@ def test_fixed_iterations_mode(O, scenes):
     ba = make_ba(O, s)
     summ, tr = ba.solve(fixed_iterations=9)
     assert summ.num_iterations == 9 and len(tr) == 10
+
+
+def test_oracle_has_not_drifted_from_its_frozen_traces(O, scenes):
+    """tests/golden/oracle_traces.json (tests/golden/make_oracle_traces.py) freezes the oracle's own LM traces and
+    final parameters on the reference-size scene (29 x 600) and on config C2: a change to oracle/oracle.c that moves
+    them is caught here.  A self-regression fixture, NOT a reference pin (the BA leg stays 'parity unpinned')."""
+    import json
+    import os
+    from conftest import GOLDEN
+    with open(os.path.join(GOLDEN, "oracle_traces.json")) as f:
+        gold = json.load(f)
+    for key, s in (("st20", scenes.st20_scene()), ("c2", scenes.two_view_scene(n_pts=5000))):
+        g = gold[key]
+        o = O.BA(s["cams0"], s["pts0"], s["obs_cam"], s["obs_pt"], s["obs_feat"], s["cam_fixed"])
+        assert (o.nc, o.np_, o.no) == (g["n_cams"], g["n_pts"], g["n_obs"])
+        summ, tr = o.solve()
+        assert summ.num_iterations == g["num_iterations"] and summ.termination_type == g["termination_type"]
+        assert [int(x) for x in tr[:, 6]] == g["accepted"]
+        # the scenes are noise-free: the last costs are round-off (1e-13 .. 1e-21), compared absolutely
+        assert np.allclose(tr[:, 0], g["cost_trace"], rtol=1e-7, atol=1e-12)
+        assert np.allclose(tr[:, 5], g["radius_trace"], rtol=1e-6)
+        assert np.abs(o.cams.reshape(-1) - np.array(g["final_cams"])).max() < 1e-9
+        assert np.abs(o.pts[:20].reshape(-1) - np.array(g["final_pts_head"])).max() < 1e-8

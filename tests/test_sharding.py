@@ -240,8 +240,8 @@ def test_torch_hook_world1(scenes):
     if not dist.is_initialized():
         dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29731", rank=0, world_size=1)
     try:
-        stream = torch.cuda.current_stream().cuda_stream
-        e = st.BAEngine(s["cams0"], s["pts0"], s["obs_cam"], s["obs_pt"], s["obs_feat"], s["cam_fixed"], stream=stream)
+        stream_obj = torch.cuda.Stream()              # explicit non-default stream: the hook enqueues on it
+        e = st.BAEngine(s["cams0"], s["pts0"], s["obs_cam"], s["obs_pt"], s["obs_feat"], s["cam_fixed"], stream=stream_obj.cuda_stream)
         e.set_allreduce(sharding.torch_allreduce_hook(dist, torch), 0, 1)
         summ, tr = e.solve()
         e2 = st.BAEngine(s["cams0"], s["pts0"], s["obs_cam"], s["obs_pt"], s["obs_feat"], s["cam_fixed"])
@@ -250,3 +250,107 @@ def test_torch_hook_world1(scenes):
         assert np.allclose(tr[:, 0], tr2[:, 0], rtol=1e-12)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_native_rccl_communicator_world1(scenes, tmp_path):
+    """stba_comm_* (ncclAllReduce behind the C ABI, no Python on the data path) on a 1-rank communicator:
+    from Python (slam-tricks_amd.Comm) and from a C++ host (tests/cpp/test_comm.cpp), as the reference's
+    callers are C++ executables (st20-g2o/src/src/test_ceres.cpp:7-19)."""
+    import subprocess
+    import torch
+    from conftest import ROOT
+    from test_cpp_shim import write_scene
+    st = importlib.import_module("slam-tricks_amd")
+    s = scenes.st20_scene(n_cams=12, n_pts=300, seed=5, pix_noise=1e-3)
+    comm = st.Comm(st.comm_unique_id(), 0, 1)
+    x = torch.arange(1000, dtype=torch.float64, device="cuda")
+    comm.allreduce_sum(x.data_ptr(), x.numel(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert torch.equal(x.cpu(), torch.arange(1000, dtype=torch.float64))
+    e = st.BAEngine(s["cams0"], s["pts0"], s["obs_cam"], s["obs_pt"], s["obs_feat"], s["cam_fixed"])
+    e.set_comm(comm)
+    summ, tr = e.solve()
+    e2 = st.BAEngine(s["cams0"], s["pts0"], s["obs_cam"], s["obs_pt"], s["obs_feat"], s["cam_fixed"])
+    s2, tr2 = e2.solve()
+    assert summ.num_iterations == s2.num_iterations and np.allclose(tr[:, 0], tr2[:, 0], rtol=1e-9)
+    e.close(); comm.close()
+    # the same from C++
+    pkg = os.path.join(ROOT, "slam-tricks_amd")
+    exe = str(tmp_path / "test_comm")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include",
+                           os.path.join(ROOT, "tests", "cpp", "test_comm.cpp"), "-L", pkg, "-lstba", "-L", "/opt/rocm/lib", "-lamdhip64",
+                           f"-Wl,-rpath,{pkg}", "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    f = str(tmp_path / "s.bin")
+    write_scene(f, s)
+    p = subprocess.run([exe, f], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    out = dict(l.split(" ", 1) for l in p.stdout.splitlines())
+    assert out["unique_id"].startswith("rc 0") and out["create"].startswith("rc 0") and out["rank"] == "0 world 1"
+    assert out["allreduce"].split()[1] == "0" and float(out["allreduce"].split()[3]) == 0.0
+    toks = out["solve"].split()
+    assert toks[1] == "0" and toks[2] == "0" and toks[4] == toks[5] and int(toks[4]) == s2.num_iterations
+    assert float(toks[-1]) < 1e-9 and out["destroy"] == "rc 0"
+
+
+def _proc_worker(rank, world, port, q):
+    """one PROCESS per landmark shard, the product engine in each (both on GPU 0 of this box: RCCL refuses two
+    ranks on one device, so the cross-process sum goes device -> host -> gloo -> device)"""
+    import torch
+    import torch.distributed as dist
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    st = importlib.import_module("slam-tricks_amd")
+    scenes = importlib.import_module("slam-tricks_amd.scenes")
+    sharding = importlib.import_module("slam-tricks_amd.sharding")
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    s = scenes.st20_scene(n_cams=24, n_pts=1500, max_obs_per_pt=8, seed=6, pix_noise=1e-3)
+    sh = sharding.make_shard(s, rank, world)
+    stream_obj = torch.cuda.Stream()
+
+    def hook(_u, buf, count, stream):
+        try:
+            t = torch.as_tensor(sharding.DeviceVector(buf, count), device="cuda")
+            with torch.cuda.stream(torch.cuda.ExternalStream(int(stream))):
+                h = t.cpu()
+                dist.all_reduce(h)
+                t.copy_(h.cuda())
+            return 0
+        except Exception as e:      # noqa: BLE001
+            print("hook failed", repr(e), flush=True)
+            return 1
+    e = st.BAEngine(sh["cams0"], sh["pts0"], sh["obs_cam"], sh["obs_pt"], sh["obs_feat"], sh["cam_fixed"], stream=stream_obj.cuda_stream)
+    e.set_allreduce(hook, rank, world)
+    summ, tr = e.solve()
+    cams, pts = e.get_params()
+    q.put((rank, summ.num_iterations, summ.termination_type, tr[:, 0].copy(), cams, pts, sh["lo"], sh["hi"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_processes_two_shards_product_engine(scenes):
+    """the PRODUCT across processes: two processes, one landmark shard each, the HIP engine in
+    both, a real cross-process collective between them; must follow the single-engine solve."""
+    import torch.multiprocessing as mp
+    st = importlib.import_module("slam-tricks_amd")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 400) + 400
+    procs = [ctx.Process(target=_proc_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in range(2)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+    s = scenes.st20_scene(n_cams=24, n_pts=1500, max_obs_per_pt=8, seed=6, pix_noise=1e-3)
+    e1 = st.BAEngine(s["cams0"], s["pts0"], s["obs_cam"], s["obs_pt"], s["obs_feat"], s["cam_fixed"])
+    s1, tr1 = e1.solve()
+    cams1, pts1 = e1.get_params()
+    for rank, iters, term, costs, cams, pts, lo, hi in res:
+        assert iters == s1.num_iterations and term == 0
+        assert np.allclose(costs, tr1[:, 0], rtol=1e-9)
+        assert np.abs(cams - cams1).max() < 1e-9
+        assert np.abs(pts - pts1[lo:hi]).max() < 1e-6
+    assert np.array_equal(res[0][4], res[1][4])             # both processes hold bit-identical cameras
