@@ -428,6 +428,378 @@ __device__ __forceinline__ void diag_block(double* __restrict__ A, int lda, int 
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Diagonal block, second design ("D2"): everything on the matrix cores, 4 columns per step, no barriers.
+//
+// Measured on MI355X (tools/exp/lat_f64.hip): a dependent v_fma_f64 costs 4.2 cycles (= its issue time), the whole
+// pivot step rsq + Halley + scale + update 50 cycles, a dependent v_mfma_f64_16x16x4 66-81 cycles, an LDS round
+// trip 130-260.  The first design spent 250 cycles per pivot because every row thread factored an 8x8 mini-block
+// redundantly (FP64 latency = issue time, so redundant work IS latency) and because FP64 MFMAs of the SIMD partner
+// stall a wave's FP64 VALU.  Here:
+//   * the 128x128 block is 8x8 tiles of 16x16, lower tiles only, each tile in the accumulator layout of
+//     v_mfma_f64_16x16x4_f64 holding the TRANSPOSE: lane (n, g) register r = M[n][4r + g].  Register s of a tile
+//     is then directly the B operand "columns 4s..4s+3 of the tile" (lane (n, g) = M[n][4s + g]).
+//   * per 4-column step the FACTOR wave broadcasts the 4x4 pivot block of its diagonal tile with v_readlane,
+//     factors it and inverts the factor on the VALU (uniform in all lanes, branch-free), forms the operand
+//     Gp = [Ginv; 0] (lane (n, g) = Ginv[n][g], n < 4) and then
+//                l = mfma(Gp, tile.reg[s])[0]        lane (n, g) = L[n][4s + g]   (panel: 1 MFMA)
+//                tile = mfma(-l, l, tile)             rank-4 update                (1 MFMA)
+//     Every other tile (I, J') does the same two MFMAs with Gp and the l operands of rows I and J' taken from LDS:
+//     tile(I, J') = mfma(-l_J', l_I, tile(I, J')).
+//   * every Gp and every l has its own slot in LDS, written once (no ring, no back-pressure) and pre-set to a
+//     NaN sentinel: a consumer polls the slot itself, one LDS round trip per operand, no barriers in the loop.
+//   * roles (waves w and w + 4 share a SIMD):
+//       waves 0, 1   factor waves for the even / odd tile rows.  While wave 1 factors row J+1's predecessor,
+//                    wave 0 ... i.e. the wave that factors row I next follows the current factor wave through tile
+//                    column I-1 (panel + update of its two tiles (I, I-1), (I, I)), then factors.  Nothing else
+//                    runs FP64 MFMAs on their SIMDs while they factor.
+//       waves 4, 5   their SIMD mates: the inverses of the finished 16x16 diagonal tiles (the same two MFMAs on an
+//                    identity tile; the panel-solve tasks multiply by them) and ALL global stores.
+//       waves 2,3,6,7  bulk: tile rows 7 | 6 | 4,2 | 5,3 through tile column I-2; the two tiles of row I that the
+//                    factor wave needs then migrate to it through LDS, a whole tile column ahead of their use.
+constexpr unsigned long long D2_SENTINEL = 0x7FFDEAD0BEEF0001ull;    // a NaN payload no computation produces
+struct Diag2Smem {
+    double Lsl[36][4][64];          // l operands: tile (I, J) at I(I+1)/2 + J, step s, lane
+    double Gp[32][64];              // Gp operands: global step 4J + s, lane
+    double Mig[8][2][4][64];        // tiles (I, I-1) and (I, I) on their way to the factor wave: register r, lane
+    unsigned int abortf;            // a poll gave up (a bug): results are garbage, the caller reports a time-out
+};
+constexpr int DIAG2_SMEM_DOUBLES = (int)((sizeof(Diag2Smem) + 7) / sizeof(double));
+static_assert(sizeof(Diag2Smem) <= 128 * 1024, "D2 must fit the persistent kernel's LDS");
+
+#ifdef STBA_DIAG_TS
+// event trace: (code, time) per wave; the clock read takes the value it follows as an input, so it cannot move ahead of it
+__device__ long long g_d2_ev[8][160][2];
+__device__ int g_d2_nev[8];
+__device__ __forceinline__ long long d2_clock_after(double dep) { long long c; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(c) : "v"(dep) : "memory"); return c; }
+#define D2EV(code, dep) do { const long long c_ = d2_clock_after(dep); if (lane == 0 && d2_nev < 160) { g_d2_ev[d2_w][d2_nev][0] = (code); g_d2_ev[d2_w][d2_nev][1] = c_; } ++d2_nev; } while (0)
+#define D2EV_DECL(w) int d2_nev = 0; const int d2_w = (w)
+#define D2EV_END() do { if (lane == 0) g_d2_nev[d2_w] = d2_nev; } while (0)
+#else
+#define D2EV(code, dep) do { } while (0)
+#define D2EV_DECL(w) do { } while (0)
+#define D2EV_END() do { } while (0)
+#endif
+#define D2F(I, k) do { } while (0)
+
+// LDS accesses by 32-bit LDS address (low half of the generic pointer), as inline asm: the polls must not be
+// hoisted or merged, and must not wait for this wave's global stores
+__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(size_t)p; }
+__device__ __forceinline__ void lds_store_b32(void* p, unsigned v) { asm volatile("ds_write_b32 %0, %1" :: "v"(lds_addr(p)), "v"(v) : "memory"); }
+__device__ __forceinline__ unsigned long long lds_load_b64(const void* p) {
+    unsigned long long v;
+    asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(lds_addr(p)) : "memory");
+    return v;
+}
+// volatile LDS load through an explicit LDS-address-space pointer: the compiler issues consecutive ones back to back
+// and waits once (s_waitcnt lgkmcnt), which is what the batched polls below need
+typedef const volatile unsigned long long __attribute__((address_space(3))) * lds_cvu64p;
+__device__ __forceinline__ unsigned long long lds_vload_b64(const void* p) { return *(lds_cvu64p)(size_t)lds_addr(p); }
+// this lane's slot, once every lane of the wave sees a published value (a 64-lane LDS store is not atomic)
+__device__ __forceinline__ double d2_take(const double* slot, unsigned int* abortf) {
+    for (int spin = 0;; ++spin) {
+        const unsigned long long v = lds_load_b64(slot);
+        if (__builtin_amdgcn_ballot_w64(v == D2_SENTINEL) == 0ull) return __longlong_as_double((long long)v);
+        if (spin > (1 << 21)) { lds_store_b32(abortf, 1u); return 0.0; }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+__device__ __forceinline__ double readlane_f64(double x, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), lane), hi = __builtin_amdgcn_readlane(__double2hiint(x), lane);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double mfma_l(double gp, double b) {       // l = (Gp . tile.reg[s])[0]
+    const double4v z = {0.0, 0.0, 0.0, 0.0};
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(gp, b, z, 0, 0, 0)[0];
+}
+__device__ __forceinline__ int d2_tix(int I, int J) { return I * (I + 1) / 2 + J; }
+
+// tile (I, J) of the block -> registers; the diagonal tiles are made symmetric from their lower triangle
+__device__ __forceinline__ double4v d2_load_tile(const double* __restrict__ Ab, int lda, int I, int J, int n, int g) {
+    double4v v;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int c = 4 * r + g;
+        const int row = (I == J && c > n) ? c : n, col = (I == J && c > n) ? n : c;
+        v[r] = Ab[(size_t)(16 * I + row) * lda + 16 * J + col];
+    }
+    return v;
+}
+
+// final L tile (I, J): LDS slots -> global, 32 contiguous bytes per lane (lane (n, g') writes L[n][4g' .. 4g'+3])
+template <bool WT>
+__device__ __forceinline__ void d2_store_tile(double* __restrict__ A, int lda, int k0, Diag2Smem& sm, int I, int J, int lane) {
+    const int n = lane & 15, gq = lane >> 4;
+    const int tix = d2_tix(I, J);
+    (void)d2_take(&sm.Lsl[tix][3][lane], &sm.abortf);        // the tile's last step is published (the earlier ones then are, too)
+    double4v v;
+#pragma unroll
+    for (int gg = 0; gg < 4; ++gg) {
+        v[gg] = sm.Lsl[tix][gq][n + 16 * gg];
+        if (I == J && 4 * gq + gg > n) v[gg] = 0.0;          // right of the diagonal: not part of L
+    }
+    gst4<WT>(A + (size_t)(k0 + 16 * I + n) * lda + k0 + 16 * J + 4 * gq, v);
+}
+
+// one 4-column step (tile column J, step s) of a row that is not being factored.  The row's tiles sit in a shift
+// register: acc[0] is tile (I, J) of the CURRENT tile column, acc[k] is tile (I, J + k), cnt = I - J of them are live
+// (the registers are shifted down after every tile column, so the code is the same for every J and every row: the
+// whole task must fit the instruction cache).  Panel value of tile (I, J), then the rank-4 update of the live tiles
+// and of the diagonal tile.  The l operands of the rows above are requested from LDS together and awaited once
+// (one round trip, not one per tile: an LDS round trip costs 130-260 cycles).
+// part 1: panel value, published at once (nobody's l waits for another l), and the update of the diagonal tile
+template <int NT>
+__device__ __forceinline__ double d2_row_panel(Diag2Smem& sm, int I, int J, int s, double gp, const double4v (&acc)[NT], double4v& accD, int lane) {
+    const double l = mfma_l(gp, acc[0][s]);
+    sm.Lsl[d2_tix(I, J)][s][lane] = l;
+    accD = __builtin_amdgcn_mfma_f64_16x16x4f64(-l, l, accD, 0, 0, 0);
+    return l;
+}
+// part 2: the l operands of the rows above, then the rank-4 updates of the live tiles
+template <int NT>
+__device__ __forceinline__ void d2_row_update(Diag2Smem& sm, int I, int J, int s, double l, double4v (&acc)[NT], int lane) {
+    const int cnt = I - J;
+    const int k0 = (s == 3) ? 1 : 0;            // (the finished tile needs no last update)
+    unsigned long long lj[NT];
+    for (int spin = 0;; ++spin) {
+        bool missing = false;
+#pragma unroll
+        for (int k = 0; k < NT; ++k)
+            if (k >= k0 && k < cnt) lj[k] = lds_vload_b64(&sm.Lsl[d2_tix(J + k, J)][s][lane]);
+#pragma unroll
+        for (int k = 0; k < NT; ++k)
+            if (k >= k0 && k < cnt) missing = missing || (lj[k] == D2_SENTINEL);
+        if (__builtin_amdgcn_ballot_w64(missing) == 0ull) break;
+        if (spin > (1 << 21)) { lds_store_b32(&sm.abortf, 1u); break; }
+        __builtin_amdgcn_s_sleep(1);
+    }
+#pragma unroll
+    for (int k = 0; k < NT; ++k)
+        if (k >= k0 && k < cnt)
+            acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(-__longlong_as_double((long long)lj[k]), l, acc[k], 0, 0, 0);
+}
+
+// bulk wave: tile rows RA and RB (RB < 0: none; RB < RA) through tile column row-2, then the hand-over of the two
+// tiles (I, I-1), (I, I) to the factor wave.  One code path for all four bulk waves (the rows are run-time values).
+__device__ __forceinline__ void d2_bulk_wave(const double* __restrict__ Ab, int lda, Diag2Smem& sm, int lane, int RA, int RB, int wave_id) {
+    const int n = lane & 15, g = lane >> 4;
+    double4v accA[7], accAD, accB[3], accBD;
+#pragma unroll
+    for (int J = 0; J < 7; ++J) if (J < RA) accA[J] = d2_load_tile(Ab, lda, RA, J, n, g);
+    accAD = d2_load_tile(Ab, lda, RA, RA, n, g);
+#pragma unroll
+    for (int J = 0; J < 3; ++J) if (J < RB) accB[J] = d2_load_tile(Ab, lda, RB, J, n, g);
+    if (RB > 0) accBD = d2_load_tile(Ab, lda, RB, RB, n, g);
+    __syncthreads();                       // the slots carry their sentinels
+    D2EV_DECL(wave_id);
+    D2EV(900, accAD[0]);
+#pragma unroll 1
+    for (int J = 0; J <= RA - 2; ++J) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const double gp = d2_take(&sm.Gp[4 * J + s][lane], &sm.abortf);
+            D2EV(100 + 4 * J + s, gp);
+            const bool hasB = J <= RB - 2;
+            double lB = 0.0;
+            if (hasB) lB = d2_row_panel<3>(sm, RB, J, s, gp, accB, accBD, lane);
+            const double lA = d2_row_panel<7>(sm, RA, J, s, gp, accA, accAD, lane);
+            if (hasB) d2_row_update<3>(sm, RB, J, s, lB, accB, lane);                   // (the row that is needed sooner first)
+            d2_row_update<7>(sm, RA, J, s, lA, accA, lane);
+            D2EV(200 + 4 * J + s, accAD[0]);
+        }
+        if (J == RB - 2) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { sm.Mig[RB][0][r][lane] = accB[1][r]; sm.Mig[RB][1][r][lane] = accBD[r]; }
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) accA[k] = accA[k + 1];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) accB[k] = accB[k + 1];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { sm.Mig[RA][0][r][lane] = accA[0][r]; sm.Mig[RA][1][r][lane] = accAD[r]; }
+    D2EV(999, accAD[0]);
+    D2EV_END();
+    (void)wave_id;
+}
+
+// one factor step on the diagonal tile accD (see above): pivot block s -> Gp operand, panel values l, rank-4 update
+__device__ __forceinline__ double d2_factor_gp(const double4v& accD, int s, const double (&mk)[10], int& badv, int col0, int n_real) {
+    const double b = accD[s];
+    // the 4x4 pivot block M[4s+a][4s+c] sits in lane (n = 4s+a, g = c), register s
+    const double a00 = readlane_f64(b, 4 * s + 0);
+    const double a10 = readlane_f64(b, 4 * s + 1), a11 = readlane_f64(b, 4 * s + 1 + 16);
+    const double a20 = readlane_f64(b, 4 * s + 2), a21 = readlane_f64(b, 4 * s + 2 + 16), a22 = readlane_f64(b, 4 * s + 2 + 32);
+    const double a30 = readlane_f64(b, 4 * s + 3), a31 = readlane_f64(b, 4 * s + 3 + 16), a32 = readlane_f64(b, 4 * s + 3 + 32),
+                 a33 = readlane_f64(b, 4 * s + 3 + 48);
+    // a failed pivot of a real column is recorded (reported at the end) and replaced by 1; no branches
+    auto pivot = [&](double d, int c) -> double {
+        const bool ok = d > 0.0;
+        badv = (!ok && col0 + c < n_real && badv == 0) ? col0 + c + 1 : badv;
+        return fast_rsqrt(ok ? d : 1.0);
+    };
+    const double y0 = pivot(a00, 0);
+    const double g10 = a10 * y0, g20 = a20 * y0, g30 = a30 * y0;
+    const double y1 = pivot(fma(-g10, g10, a11), 1);
+    const double g21 = fma(-g20, g10, a21) * y1, g31 = fma(-g30, g10, a31) * y1;
+    const double y2 = pivot(fma(-g21, g21, fma(-g20, g20, a22)), 2);
+    const double g32 = fma(-g31, g21, fma(-g30, g20, a32)) * y2;
+    const double y3 = pivot(fma(-g32, g32, fma(-g31, g31, fma(-g30, g30, a33))), 3);
+    // inverse of the 4x4 factor
+    const double i10 = -(g10 * y0) * y1, i21 = -(g21 * y1) * y2, i32 = -(g32 * y2) * y3;
+    const double i20 = -fma(g21, i10, g20 * y0) * y2, i31 = -fma(g32, i21, g31 * y1) * y3;
+    const double i30 = -fma(g32, i20, fma(g31, i10, g30 * y0)) * y3;
+    // Gp: lane (n, g) = Ginv[n][g] (n < 4), as a sum with per-lane 0/1 weights (exact; no divergent code),
+    // the entries that depend on the last pivot last
+    double gp = mk[0] * y0;
+    gp = fma(mk[1], i10, gp); gp = fma(mk[2], y1, gp); gp = fma(mk[3], i20, gp); gp = fma(mk[4], i21, gp);
+    gp = fma(mk[5], y2, gp); gp = fma(mk[6], i30, gp); gp = fma(mk[7], i31, gp); gp = fma(mk[8], i32, gp);
+    gp = fma(mk[9], y3, gp);
+    return gp;
+}
+__device__ __forceinline__ double d2_factor_update(double4v& accD, int s, double gp) {
+    const double l = mfma_l(gp, accD[s]);
+    if (s < 3) accD = __builtin_amdgcn_mfma_f64_16x16x4f64(-l, l, accD, 0, 0, 0);
+    return l;
+}
+
+// factor wave F (0: even rows, 1: odd rows); one code path for both
+__device__ __forceinline__ void d2_factor_wave(const double* __restrict__ Ab, int lda, int k0, int n_real, int* __restrict__ flag,
+                                               Diag2Smem& sm, int lane, int F) {
+    const int n = lane & 15, g = lane >> 4;
+    double4v accS, accD;
+    accD = d2_load_tile(Ab, lda, F, F, n, g);
+    accS = d2_load_tile(Ab, lda, 1, 0, n, g);          // (only the odd wave uses it)
+    double mk[10];          // 0/1 weights of the ten entries of the 4x4 inverse for this lane's operand slot
+    {
+        const int idx = (n < 4 && g <= n) ? n * (n + 1) / 2 + g : -1;
+#pragma unroll
+        for (int e = 0; e < 10; ++e) mk[e] = (idx == e) ? 1.0 : 0.0;
+    }
+    int badv = 0;
+    __syncthreads();                       // the slots carry their sentinels
+    D2EV_DECL(F);
+    D2EV(900, accD[0]);
+#pragma unroll 1
+    for (int k = 0; k < 4; ++k) {
+        const int I = F + 2 * k;
+        if (I >= 2) {                      // the two tiles of this row arrive from the bulk wave that carried them so far
+            unsigned long long m[8];
+            for (int spin = 0;; ++spin) {
+                bool missing = false;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) m[r] = lds_vload_b64(&sm.Mig[I][r >> 2][r & 3][lane]);
+#pragma unroll
+                for (int r = 0; r < 8; ++r) missing = missing || (m[r] == D2_SENTINEL);
+                if (__builtin_amdgcn_ballot_w64(missing) == 0ull) break;
+                if (spin > (1 << 21)) { lds_store_b32(&sm.abortf, 1u); break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { accS[r] = __longlong_as_double((long long)m[r]); accD[r] = __longlong_as_double((long long)m[4 + r]); }
+            D2EV(300 + I, accD[0]);
+        }
+        if (I >= 1) {                      // follow the other factor wave through tile column I-1
+            const int J = I - 1;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const double gp = d2_take(&sm.Gp[4 * J + s][lane], &sm.abortf);
+                const double l = mfma_l(gp, accS[s]);
+                sm.Lsl[d2_tix(I, J)][s][lane] = l;
+                accD = __builtin_amdgcn_mfma_f64_16x16x4f64(-l, l, accD, 0, 0, 0);
+                if (s < 3) {
+                    const double lj = d2_take(&sm.Lsl[d2_tix(J, J)][s][lane], &sm.abortf);
+                    accS = __builtin_amdgcn_mfma_f64_16x16x4f64(-lj, l, accS, 0, 0, 0);
+                }
+                D2EV(400 + 4 * J + s, accD[0]);
+            }
+        }
+        // ---- factor the diagonal tile (I, I)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const double gp = d2_factor_gp(accD, s, mk, badv, k0 + 16 * I + 4 * s, n_real);
+            sm.Gp[4 * I + s][lane] = gp;
+            const double l = d2_factor_update(accD, s, gp);
+            sm.Lsl[d2_tix(I, I)][s][lane] = l;
+            D2EV(500 + 4 * I + s, l);
+        }
+    }
+    D2EV_END();
+    if (badv != 0 && lane == 0) atomicCAS(flag, 0, badv);
+}
+
+// mate of factor wave F: inverse of every finished diagonal tile of its rows (the same two MFMAs on an identity
+// tile below it: its panel values are X = L_II^-T, lane (n, g) of step s = X[n][4s+g] = Inv[4s+g][n]), and the
+// global stores of the tile columns J = F, F+2, ..
+template <bool WT>
+__device__ __forceinline__ void d2_mate_wave(double* __restrict__ A, int lda, int k0, double* __restrict__ dinv, Diag2Smem& sm, int lane, int F) {
+    const int n = lane & 15, g = lane >> 4;
+    __syncthreads();                       // the slots carry their sentinels
+    D2EV_DECL(4 + F);
+#pragma unroll 1
+    for (int k = 0; k < 4; ++k) {
+        const int I = F + 2 * k;
+        double4v accE;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) accE[r] = (n == 4 * r + g) ? 1.0 : 0.0;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const double gp = d2_take(&sm.Gp[4 * I + s][lane], &sm.abortf);
+            const double le = mfma_l(gp, accE[s]);
+            gst<WT>(&dinv[(I * 16 + 4 * s + g) * 16 + n], le);
+            if (s < 3) {
+                const double li = d2_take(&sm.Lsl[d2_tix(I, I)][s][lane], &sm.abortf);
+                accE = __builtin_amdgcn_mfma_f64_16x16x4f64(-li, le, accE, 0, 0, 0);
+            }
+        }
+        D2EV(600 + I, accE[0]);
+#pragma unroll 1
+        for (int Ip = I; Ip < 8; ++Ip) d2_store_tile<WT>(A, lda, k0, sm, Ip, I, lane);      // tile column I
+        D2EV(700 + I, accE[0]);
+    }
+    D2EV_END();
+}
+
+// all 512 threads of the workgroup; smem = sizeof(Diag2Smem); ends with the results in flight to global memory
+// (the caller waits for them: s_waitcnt vmcnt(0) + barrier)
+template <bool WT>
+__device__ __forceinline__ void diag_block2(double* __restrict__ A, int lda, int k0, int n_real,
+                                            int* __restrict__ flag, double* __restrict__ dinv, double* smem, int t,
+                                            long long* ph = nullptr) {
+    Diag2Smem& sm = *reinterpret_cast<Diag2Smem*>(smem);
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
+    const double* Ab = A + (size_t)k0 * lda + k0;
+    // sentinels (the global loads of the tiles are issued first by every role, so this hides behind them)
+    {
+        unsigned long long* p = reinterpret_cast<unsigned long long*>(smem);
+        constexpr int NSENT = (int)((sizeof(double) * (36 * 4 * 64 + 32 * 64 + 8 * 2 * 4 * 64)) / 8);
+        for (int e = t; e < NSENT; e += 512) p[e] = D2_SENTINEL;
+        if (t == 0) sm.abortf = 0u;
+    }
+    if (w < 2) d2_factor_wave(Ab, lda, k0, n_real, flag, sm, lane, w);
+    else if (w == 4 || w == 5) d2_mate_wave<WT>(A, lda, k0, dinv, sm, lane, w - 4);
+    else d2_bulk_wave(Ab, lda, sm, lane, w == 2 ? 7 : w == 3 ? 6 : w == 6 ? 4 : 5, w == 6 ? 2 : w == 7 ? 3 : -1, w);
+    PHASE_STAMP(1);
+    if (lane == 0 && sm.abortf != 0u) atomicExch(flag, CHOL_FLAG_TIMEOUT);
+}
+
+// (warm_k0 >= 0: the task is first run on another diagonal block of the matrix, so that the timed run finds its code
+// in the instruction cache as it does inside the persistent kernel; diagnostics only)
+__global__ __launch_bounds__(512) void chol_diag2_kernel(double* __restrict__ A, int lda, int k0, int n_real,
+                                                          int* __restrict__ flag, double* __restrict__ dinv, int warm_k0, long long* cycles) {
+    extern __shared__ __attribute__((aligned(16))) double sm2[];
+    if (warm_k0 >= 0) {
+        diag_block2<false>(A, lda, warm_k0, n_real, flag, dinv + 2048, sm2, threadIdx.x);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    const long long c0 = wall_clock64();
+    diag_block2<false>(A, lda, k0, n_real, flag, dinv, sm2, threadIdx.x);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (cycles && threadIdx.x == 0) cycles[0] = wall_clock64() - c0;      // 100 MHz
+}
+
 __global__ __launch_bounds__(512) void chol_diag_kernel(double* __restrict__ A, int lda, int k0, int n_real,
                                                          int* __restrict__ flag, double* __restrict__ dinv) {
     __shared__ __attribute__((aligned(16))) double sm[DIAG_SMEM_DOUBLES];
