@@ -1050,8 +1050,9 @@ struct MegaArgs {
     int nq;                 // number of queues (= XCDs seen by the probe)
     int qstart[17];         // queue q holds tasks [qstart[q], qstart[q+1])
     signed char xcc_queue[16];   // HW_REG_XCC_ID -> queue
-    int* sync;              // [0..16) tickets, [16] abort, then dflag[nblk], tuflag[nblk], tflag[nblk*nblk], ver[nblk*nblk]
+    int* sync;              // [0..16) tickets, [16] abort, then dflag[nblk], tuflag[nblk], tflag[nblk*nrow], ver[nrow*nblk], nrow = nblk + 4 nwide
     double* linv; size_t linv_stride;
+    double* vbuf; int nwide;   // inverse transposes of the 512 x 512 diagonal blocks 0 .. nwide-1 (row-major, ld 512): see below
     int* flag;
     long long* trace;       // optional (STBA_MEGA_TRACE): per task {workgroup, t_ticket, t_ready, t_done}, 100 MHz clock
 };
@@ -1067,6 +1068,7 @@ __global__ void xcc_probe_kernel(int* out) {
     if (threadIdx.x == 0) out[blockIdx.x] = xcc_id();
 }
 
+// C(TM x 128) -= P_i P_j^T, K = 128 panel columns, 512 threads; smem: 2*(TM+128)*16 doubles
 // C(TM x 128) -= P_i P_j^T, K = 128 panel columns, 512 threads; smem: 2*(TM+128)*16 doubles
 template <int TM>
 __device__ __forceinline__ void syrk_tile512(double* __restrict__ A, int lda, int k0, int row_i, int row_j,
@@ -1149,6 +1151,94 @@ __device__ __forceinline__ void syrk_tile512(double* __restrict__ A, int lda, in
                 const int row = row_i + wr * (MB * 16) + m * 16 + (lane >> 4) + 4 * r;
                 const int col = row_j + wc * (NBK * 16) + n * 16 + (lane & 15);
                 gst<false>(&A[(size_t)row * lda + col], acc[m][n][r]);
+            }
+}
+
+// The same with the three operands anywhere (tiles of the wide inverse blocks live outside A; the hot task above keeps
+// the single base + offsets form: the general one costs 1.6 us more per tile in address arithmetic).
+// C (TM x 128) -= Pi Pj^T with K = 128: C at Cb (leading dimension ldc), Pi rows at Pi (ldi), Pj rows at Pj (ldj).
+// c_zero: C counts as zero on entry (the first update of a tile of an inverse block, see the wide inverse blocks).
+template <int TM>
+__device__ __forceinline__ void syrk_tile512_gen(double* __restrict__ Cb, int ldc, const double* __restrict__ Pi, int ldi,
+                                             const double* __restrict__ Pj, int ldj, bool c_zero, double* smem, int t) {
+    constexpr int WR = (TM == 128) ? 2 : 1, WC = 8 / WR;      // wave grid
+    constexpr int MB = TM / (16 * WR);                        // MFMA row blocks per wave: 4 | 2
+    constexpr int NBK = 8 / WC;                               // MFMA col blocks per wave: 2 | 1
+    constexpr int RBA = TM / 16;                              // 16-row blocks of the A tile
+    double* sA = smem;                   // [2][TM * 16]
+    double* sB = smem + 2 * TM * 16;     // [2][2048]
+    const int lane = t & 63, w = t >> 6;
+    const int wr = w / WC, wc = w % WC;
+    double4v acc[MB][NBK];
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int n = 0; n < NBK; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wr * (MB * 16) + m * 16 + (lane >> 4) + 4 * r;
+                const int col = wc * (NBK * 16) + n * 16 + (lane & 15);
+                acc[m][n][r] = c_zero ? 0.0 : Cb[(size_t)row * ldc + col];
+            }
+    // staging map: wave w, half h -> row = (lane&15) + 16*w, k = 2*((lane>>4) + 4h)
+    double2 ga[2], gb[2];
+    const int lrow = lane & 15, lkp = lane >> 4;
+    const bool stage_a = (w < RBA);
+    auto gload = [&](int kc) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int row = lrow + 16 * w;
+            const int k = 2 * (lkp + 4 * h);
+            if (stage_a) ga[h] = *reinterpret_cast<const double2*>(&Pi[(size_t)row * ldi + kc * 16 + k]);
+            gb[h] = *reinterpret_cast<const double2*>(&Pj[(size_t)row * ldj + kc * 16 + k]);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int k = 2 * (lkp + 4 * h);
+            if (stage_a) {
+                const int posa = (((k >> 2) * RBA + w) << 6) + ((k & 3) << 4) + lrow;
+                sA[buf * TM * 16 + posa] = ga[h].x;
+                sA[buf * TM * 16 + posa + 16] = ga[h].y;      // k+1: (k&3) is even so +1 -> +16
+            }
+            const int posb = (((k >> 2) * 8 + w) << 6) + ((k & 3) << 4) + lrow;
+            sB[buf * 2048 + posb] = gb[h].x;
+            sB[buf * 2048 + posb + 16] = gb[h].y;
+        }
+    };
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    constexpr int KC = NB / 16;
+    for (int kc = 0; kc < KC; ++kc) {
+        const int buf = kc & 1;
+        if (kc + 1 < KC) gload(kc + 1);
+#pragma unroll
+        for (int kq = 0; kq < 4; ++kq) {
+            double a[MB], b[NBK];
+#pragma unroll
+            for (int m = 0; m < MB; ++m) a[m] = -sA[buf * TM * 16 + (((kq * RBA + wr * MB + m) << 6) + lane)];
+#pragma unroll
+            for (int n = 0; n < NBK; ++n) b[n] = sB[buf * 2048 + (((kq * 8 + wc * NBK + n) << 6) + lane)];
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int n = 0; n < NBK; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[n], acc[m][n], 0, 0, 0);
+        }
+        if (kc + 1 < KC) lstore(buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int n = 0; n < NBK; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wr * (MB * 16) + m * 16 + (lane >> 4) + 4 * r;
+                const int col = wc * (NBK * 16) + n * 16 + (lane & 15);
+                gst<false>(&Cb[(size_t)row * ldc + col], acc[m][n][r]);
             }
 }
 
@@ -1373,8 +1463,21 @@ __global__ __launch_bounds__(512) void chol_mega_kernel(MegaArgs a) {
     int* abortf = a.sync + 16;
     int* dflag = a.sync + MEGA_SYNC_HDR;
     int* tuflag = dflag + nblk;
-    int* tflag = tuflag + nblk;
-    int* ver = tflag + nblk * nblk;
+    // Block rows >= nblk are VIRTUAL: row nblk + p is the identity block under panel p of a wide (4-panel) diagonal
+    // block; carried through the panel solves and updates of the panels p .. 4q+3 of its wide block q = p / 4 it
+    // becomes block row p - 4q of the inverse transpose of that 512 x 512 diagonal block, which the backward
+    // substitution multiplies by (12 dependent steps instead of 47).  Its tiles live in a.vbuf, not in A.
+    const int nrow = nblk + 4 * a.nwide;
+    int* tflag = tuflag + nblk;                 // [panel b][row i], i < nrow
+    int* ver = tflag + nblk * nrow;             // [row i][panel j]
+    // row i, column panel j: address of the tile's first element and its leading dimension
+    auto tile_ptr = [&](int i, int j, int& ld) -> double* {
+        if (i < nblk) { ld = a.lda; return a.A + (size_t)i * NB * a.lda + (size_t)j * NB; }
+        const int p = i - nblk, qw = p >> 2;
+        ld = 4 * NB;
+        return a.vbuf + (size_t)qw * (4 * NB) * (4 * NB) + (size_t)(p & 3) * NB * (4 * NB) + (size_t)(j - 4 * qw) * NB;
+    };
+    auto first_panel = [&](int i) { return i < nblk ? 0 : i - nblk; };      // the first panel that updates row i
     const int q = a.xcc_queue[xcc_id()];
     if (q < 0) return;                        // an XCD the probe did not see: no queue, nothing to do
     int* ticket = a.sync + q;
@@ -1396,7 +1499,7 @@ __global__ __launch_bounds__(512) void chol_mega_kernel(MegaArgs a) {
             if (type == TASK_D) {
                 ok = mega_wait(&ver[b * nblk + b], 4 * b, abortf);
             } else if (type == TASK_T) {          // (the diagonal block's flag is awaited inside the task)
-                ok = mega_wait(&ver[ti * nblk + b], 4 * b, abortf);
+                ok = mega_wait(&ver[ti * nblk + b], 4 * (b - first_panel(ti)), abortf);
             } else if (type == TASK_TI) {
                 ok = true;
             } else if (type == TASK_TU) {
@@ -1404,8 +1507,8 @@ __global__ __launch_bounds__(512) void chol_mega_kernel(MegaArgs a) {
                      mega_wait(&ver[(b + 1) * nblk + b + 1], 4 * b, abortf);
             } else {
                 const int i = (type == TASK_UQ) ? (ti >> 2) : ti;
-                ok = mega_wait(&tflag[b * nblk + i], 4, abortf) && mega_wait(&tflag[b * nblk + tj], 4, abortf) &&
-                     mega_wait(&ver[i * nblk + tj], 4 * b, abortf);
+                ok = mega_wait(&tflag[b * nrow + i], 4, abortf) && mega_wait(&tflag[b * nrow + tj], 4, abortf) &&
+                     mega_wait(&ver[i * nblk + tj], 4 * (b - first_panel(i)), abortf);
             }
             // this CU's L1 may hold lines of tiles that other CUs have rewritten since
             // (buffer_inv sc0 does NOT do it outside threadgroup-split mode: measured, stale L1 hits)
@@ -1433,7 +1536,8 @@ __global__ __launch_bounds__(512) void chol_mega_kernel(MegaArgs a) {
             diag_block<true>(a.A, a.lda, k0, a.n, a.flag, li + NB * NB, smem, tt, ph);
         } else if (type == TASK_T) {
             const int lane = tt & 63, w = tt >> 6;
-            double* rowp = a.A + (size_t)(ti * NB + 16 * w + (lane & 15)) * a.lda + k0;
+            int ldr;
+            double* rowp = tile_ptr(ti, b, ldr) + (size_t)(16 * w + (lane & 15)) * ldr;
             if (!trsm_task512(rowp, false, 0, NB, a.A + (size_t)k0 * a.lda + k0, a.lda, li + NB * NB, smem, tt, ph, &dflag[b], abortf, &s_ok)) {
                 if (t == 0) atomicExch(a.flag, CHOL_FLAG_TIMEOUT);
                 break;
@@ -1441,13 +1545,25 @@ __global__ __launch_bounds__(512) void chol_mega_kernel(MegaArgs a) {
         } else if (type == TASK_TI) {
             const int lane = tt & 63, w = tt >> 6;
             const int nv = min(NB, (a.lda - 1) - k0);
-            double* rowp = li + (size_t)(16 * w + (lane & 15)) * NB;
+            // inverse transpose of block b: into its wide block's diagonal tile, or (tail blocks) into linv
+            int ldr = NB;
+            double* base = li;
+            if (b < 4 * a.nwide) base = tile_ptr(nblk + b, b, ldr);
+            double* rowp = base + (size_t)(16 * w + (lane & 15)) * ldr;
             if (!trsm_task512(rowp, true, 16 * w, nv, a.A + (size_t)k0 * a.lda + k0, a.lda, li + NB * NB, smem, tt, ph, &dflag[b], abortf, &s_ok)) {
                 if (t == 0) atomicExch(a.flag, CHOL_FLAG_TIMEOUT);
                 break;
             }
         } else if (type == TASK_U) {
-            syrk_tile512<128>(a.A, a.lda, k0, ti * NB, tj * NB, smem, tt);
+            if (ti < nblk) {
+                syrk_tile512<128>(a.A, a.lda, k0, ti * NB, tj * NB, smem, tt);
+            } else {
+                int ldc, ldi, ldj;
+                double* Cb = tile_ptr(ti, tj, ldc);
+                const double* Pi = tile_ptr(ti, b, ldi);
+                const double* Pj = tile_ptr(tj, b, ldj);
+                syrk_tile512_gen<128>(Cb, ldc, Pi, ldi, Pj, ldj, b == first_panel(ti), smem, tt);
+            }
         } else if (type == TASK_TU) {
             if (!tu_task512(a.A, a.lda, k0, b + 1, ti, li + NB * NB, smem, tt, ph, &tuflag[b], &ver[(b + 1) * nblk + b + 1], &dflag[b], abortf, &s_ok)) {
                 if (t == 0) atomicExch(a.flag, CHOL_FLAG_TIMEOUT);
@@ -1462,8 +1578,9 @@ __global__ __launch_bounds__(512) void chol_mega_kernel(MegaArgs a) {
         __syncthreads();
         if (t == 0) {
             if (type == TASK_D) __hip_atomic_fetch_add(&dflag[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else if (type == TASK_T) __hip_atomic_fetch_add(&tflag[b * nblk + ti], 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else if (type == TASK_TU) __hip_atomic_fetch_add(&tflag[b * nblk + b + 1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (ver: inside the task)
+            else if (type == TASK_T) __hip_atomic_fetch_add(&tflag[b * nrow + ti], 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else if (type == TASK_TI) { if (b < 4 * a.nwide) __hip_atomic_fetch_add(&tflag[b * nrow + nblk + b], 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            else if (type == TASK_TU) __hip_atomic_fetch_add(&tflag[b * nrow + b + 1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (ver: inside the task)
             else if (type == TASK_U) __hip_atomic_fetch_add(&ver[ti * nblk + tj], 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             else if (type == TASK_UQ) __hip_atomic_fetch_add(&ver[(ti >> 2) * nblk + tj], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (a.trace) a.trace[8 * (size_t)task + 3] = wall_clock64();
@@ -1487,8 +1604,9 @@ static int mega_task_row(const int4& tk) {
 // dealt out heaviest first, each to the XCD with the least work so far (LPT): the totals differ by < 1 %
 // (a boustrophedon deal leaves 8 % between the heaviest XCD and the mean when nblk is not a multiple
 // of 16, and the heaviest XCD sets the pace of the throughput-bound first half).
-static std::vector<int> mega_row_owner(int nblk, int nq) {
-    std::vector<int> owner((size_t)nblk, 0);
+static std::vector<int> mega_row_owner(int nblk, int nq, int nvirt = 0) {
+    std::vector<int> owner((size_t)(nblk + nvirt), 0);
+    for (int v = 0; v < nvirt; ++v) owner[(size_t)(nblk + v)] = v % nq;      // virtual rows (inverse blocks): a few light tasks each
     static const int MODE = [] { const char* e = getenv("STBA_MEGA_ROWMAP"); return e ? atoi(e) : 1; }();
     if (MODE == 0) {
         for (int row = 0; row < nblk; ++row) {
@@ -1518,11 +1636,11 @@ static std::vector<int> mega_row_owner(int nblk, int nq) {
 // argument needs, and (ii) per-queue orders in which a workgroup rarely takes a ticket whose inputs
 // are far from ready (an in-order ticket queue has no other notion of priority).
 static void mega_build_tasks(int nblk, int nq, int wg_per_q, std::vector<int4>& out, int* qstart, std::vector<float>* sim_start = nullptr,
-                             double* makespan_out = nullptr) {
+                             double* makespan_out = nullptr, int nwide = 0) {
     struct Node { int4 tk; std::vector<int> succ; int indeg = 0; double dur = 0, prio = 0, start = 0, ready = 0; int q = 0; int last_pred = -1; };
     std::vector<Node> nodes;
     const int NBK = nblk;
-    const std::vector<int> rowq = mega_row_owner(nblk, nq);
+    const std::vector<int> rowq = mega_row_owner(nblk, nq, 4 * nwide);
     static const int QROWS = [] { const char* e = getenv("STBA_MEGA_QROWS"); return e ? atoi(e) : 2; }();
     std::vector<int> idD((size_t)NBK, -1), idTI((size_t)NBK, -1), idTU((size_t)NBK * 4, -1), idT((size_t)NBK * NBK, -1),
         idUq((size_t)NBK * NBK * 4, -1), idU((size_t)NBK * NBK * NBK, -1);
@@ -1600,6 +1718,31 @@ static void mega_build_tasks(int nblk, int nq, int wg_per_q, std::vector<int4>& 
                 if (b > 0) dep(idU[((size_t)(b - 1) * NBK + i) * NBK + j], u);
             }
     }
+    // wide inverse blocks: the identity block under panel p = 4q + v of wide block q (virtual row nblk + p) is carried
+    // through panels p .. 4q+3: TI(p) makes its diagonal tile, then per later panel bj of the block the updates
+    // U(k; row, bj), k = p .. bj-1, and the panel solve T(bj; row)
+    for (int qw = 0; qw < nwide; ++qw)
+        for (int v = 0; v < 4; ++v) {
+            const int pnl = 4 * qw + v, iv = NBK + pnl;
+            std::vector<int> xdone(4, -1);            // task that finishes tile (iv, 4qw + j)
+            xdone[(size_t)v] = idTI[(size_t)pnl];
+            for (int j = v + 1; j < 4; ++j) {
+                const int bj = 4 * qw + j;
+                int prev = -1;
+                for (int k = pnl; k < bj; ++k) {
+                    const int u = add(TASK_U, k, iv, bj, 10.0 * NBK + bj);
+                    dep(xdone[(size_t)(k - 4 * qw)], u);
+                    if (bj == k + 1) { for (int q2 = 0; q2 < 4; ++q2) dep(idTU[(size_t)k * 4 + q2], u); }
+                    else dep(idT[(size_t)k * NBK + bj], u);
+                    dep(prev, u);
+                    prev = u;
+                }
+                const int tv = add(TASK_T, bj, iv, 0, 10.0 * NBK + bj);
+                dep(idD[(size_t)bj], tv);
+                dep(prev, tv);
+                xdone[(size_t)j] = tv;
+            }
+        }
     static const double BLW = [] { const char* e = getenv("STBA_MEGA_BLEVEL"); return e ? atof(e) : 1.0; }();
     if (BLW > 0.0) {
         // bottom level (longest path to the end of the graph) as the priority: HLFET list scheduling
@@ -1743,6 +1886,9 @@ double chol_schedule_makespan(int nblk, int nq, int wg_per_q) {
 //   workgroups 1..   apply x_{b+1} to the remaining entries y[0 : k0), 128 entries each (GEMV with the row panel).
 // y lives in row lda-1 (it was forward-substituted for free by the factorisation).
 constexpr int BWD_ROW_CHUNKS = 8;   // the 128 panel rows are split 8 ways over the threads of a workgroup
+// Every launch is one dependent step of 47, so what counts is its latency: the panel block of L and (workgroup 0) the
+// inverse transpose do NOT depend on the previous step's solution and are requested first, together; only the 1 KB
+// of x_{b+1} is read behind the kernel boundary.  One memory round trip per step instead of three (7.9 -> ~4 us).
 __global__ __launch_bounds__(1024) void chol_bwd_step_kernel(double* __restrict__ A, int lda, int k0, int has_next,
                                                              const double* __restrict__ Xinv, double* __restrict__ x) {
     __shared__ double xs[NB];                       // previous block's solution
@@ -1751,59 +1897,124 @@ __global__ __launch_bounds__(1024) void chol_bwd_step_kernel(double* __restrict_
     const int t = threadIdx.x;
     const int kn = k0 + NB;                                  // first row of the previous (next-lower) block
     const int nvn = has_next ? min(NB, (lda - 1) - kn) : 0;   // its rows that belong to the system
-    if (t < NB) xs[t] = (t < nvn) ? x[kn + t] : 0.0;
-    __syncthreads();
     constexpr int RPC = NB / BWD_ROW_CHUNKS;        // rows per chunk (16)
-    if (blockIdx.x > 0) {
-        // update role: this workgroup OWNS the 128 entries y[c0 .. c0+128) of block column blockIdx.x - 1.
-        // Thread (rchunk, column) = (t >> 7, t & 127) sums 16 panel rows, the 8 partial sums of a column meet
-        // in LDS and are added in a fixed order: no atomics, so the solution is bitwise reproducible (two
-        // ranks that factor the same system get the same step).
-        const int c0 = (blockIdx.x - 1) * NB;
-        const int rchunk = t >> 7, c = t & 127;
-        double s = 0.0;
+    const int rchunk = t >> 7, c = t & 127;
+    // ---- requests that do not depend on x: 16 panel values per thread (+ 16 of the inverse transpose and y)
+    const int c0 = (blockIdx.x > 0) ? (blockIdx.x - 1) * NB : k0;
+    double lv[RPC];
+#pragma unroll
+    for (int j = 0; j < RPC; ++j) lv[j] = 0.0;
+    if (has_next) {
         const double* col = A + (size_t)(kn + rchunk * RPC) * lda + c0 + c;
 #pragma unroll
-        for (int j = 0; j < RPC; ++j) s = fma(col[(size_t)j * lda], xs[rchunk * RPC + j], s);
-        part[rchunk][c] = s;
-        __syncthreads();
+        for (int j = 0; j < RPC; ++j) lv[j] = col[(size_t)j * lda];
+    }
+    const int i = t >> 3, p8 = t & 7;
+    double xv[16];
+    double y_own = 0.0;
+    const int nv = min(NB, (lda - 1) - k0);         // rows of this block that belong to the system
+    if (blockIdx.x == 0) {
+        const double* xr = Xinv + (size_t)i * NB + p8 * 16;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) xv[j] = xr[j];
+        if (t < NB) y_own = (t < nv) ? A[(size_t)(lda - 1) * lda + k0 + t] : 0.0;
+    }
+    double y_upd = 0.0;
+    if (blockIdx.x > 0 && t < NB) y_upd = A[(size_t)(lda - 1) * lda + c0 + t];
+    // ---- the previous block's solution
+    if (t < NB) xs[t] = (t < nvn) ? x[kn + t] : 0.0;
+    __syncthreads();
+    double s = 0.0;
+#pragma unroll
+    for (int j = 0; j < RPC; ++j) s = fma(lv[j], xs[rchunk * RPC + j], s);
+    part[rchunk][c] = s;
+    __syncthreads();
+    if (blockIdx.x > 0) {
+        // update role: this workgroup OWNS the 128 entries y[c0 .. c0+128) of block column blockIdx.x - 1.
+        // Thread (rchunk, column) summed 16 panel rows, the 8 partial sums of a column meet in LDS and are added
+        // in a fixed order: no atomics, so the solution is bitwise reproducible (two ranks that factor the same
+        // system get the same step).
         if (t < NB) {
             double acc = 0.0;
 #pragma unroll
             for (int q = 0; q < BWD_ROW_CHUNKS; ++q) acc += part[q][t];
-            A[(size_t)(lda - 1) * lda + c0 + t] -= acc;
+            A[(size_t)(lda - 1) * lda + c0 + t] = y_upd - acc;
         }
         return;
     }
-    const int nv = min(NB, (lda - 1) - k0);     // rows of this block that belong to the system
-    {   // own update: thread (rchunk, column) = (t >> 7, t & 127)
-        const int rchunk = t >> 7, c = t & 127;
-        double s = 0.0;
-        if (nvn > 0) {
-            const double* col = A + (size_t)(kn + rchunk * RPC) * lda + k0 + c;
-#pragma unroll
-            for (int j = 0; j < RPC; ++j) s = fma(col[(size_t)j * lda], xs[rchunk * RPC + j], s);
-        }
-        part[rchunk][c] = s;
-    }
-    __syncthreads();
     if (t < NB) {
-        double yv = (t < nv) ? A[(size_t)(lda - 1) * lda + k0 + t] : 0.0;
+        double yv = y_own;
 #pragma unroll
         for (int q = 0; q < BWD_ROW_CHUNKS; ++q) yv -= part[q][t];
         ybuf[t] = (t < nv) ? yv : 0.0;
     }
     __syncthreads();
     // x_i = sum_{j >= i} X[i][j] y_j : 8 threads per row, 16 columns each, shuffle tree
-    const int i = t >> 3, p8 = t & 7;
-    const double* xr = Xinv + (size_t)i * NB + p8 * 16;
+    double r = 0.0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) r = fma(xv[j], ybuf[p8 * 16 + j], r);
+    r += __shfl_xor(r, 1, 64);
+    r += __shfl_xor(r, 2, 64);
+    r += __shfl_xor(r, 4, 64);
+    if (p8 == 0) x[k0 + i] = (i < nv) ? r : 0.0;
+}
+
+// Wide backward steps.  With the inverse transposes V_q of the 512 x 512 diagonal blocks (built by extra tasks of the
+// persistent kernel, see chol_mega_kernel) a step covers four panels:  x_B = V_q y_B  (solve), then
+// y[0 : row0) -= L[B, 0 : row0)^T x_B  (apply).  Both are GEMVs spread over many workgroups, partial sums are added in a
+// fixed order (no atomics: bitwise reproducible).
+// apply: workgroup g owns the 32 entries y[32 g .. 32 g + 32); thread (rc, c) = (t >> 5, t & 31) sums RPC source rows
+template <int RPC>
+__global__ __launch_bounds__(1024) void chol_bwd_apply_kernel(double* __restrict__ A, int lda, int src_row0, const double* __restrict__ x) {
+    __shared__ double xs[32 * RPC];
+    __shared__ double part[32][33];
+    const int t = threadIdx.x, rc = t >> 5, c = t & 31;
+    const int c0 = blockIdx.x * 32;
+    const double* col = A + (size_t)(src_row0 + rc * RPC) * lda + c0 + c;
+    double lv[RPC];
+#pragma unroll
+    for (int j = 0; j < RPC; ++j) lv[j] = col[(size_t)j * lda];
+    for (int e = t; e < 32 * RPC; e += 1024) xs[e] = x[src_row0 + e];
+    double yv = 0.0;
+    if (t < 32) yv = A[(size_t)(lda - 1) * lda + c0 + t];
+    __syncthreads();
     double s = 0.0;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) s = fma(xr[j], ybuf[p8 * 16 + j], s);
+    for (int j = 0; j < RPC; ++j) s = fma(lv[j], xs[rc * RPC + j], s);
+    part[rc][c] = s;
+    __syncthreads();
+    if (t < 32) {
+        double acc = 0.0;
+#pragma unroll
+        for (int q = 0; q < 32; ++q) acc += part[q][t];
+        A[(size_t)(lda - 1) * lda + c0 + t] = yv - acc;
+    }
+}
+// solve: workgroup g owns rows 32 g .. 32 g + 31 of the block; thread (r, cc) = (t >> 5, t & 31) takes 16 columns
+__global__ __launch_bounds__(1024) void chol_bwd_wide_solve_kernel(const double* __restrict__ A, int lda, const double* __restrict__ V, int row0,
+                                                                   double* __restrict__ x) {
+    __shared__ double ys[4 * NB];
+    const int t = threadIdx.x, r = blockIdx.x * 32 + (t >> 5), cc = t & 31;
+    const bool live = (cc >> 3) >= (r >> 7);            // tiles left of the block diagonal are zero (and never written)
+    double v[16];
+    if (live) {
+        const double* vr = V + (size_t)r * (4 * NB) + 16 * cc;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = vr[j];
+    }
+    if (t < 4 * NB) ys[t] = A[(size_t)(lda - 1) * lda + row0 + t];
+    __syncthreads();
+    double s = 0.0;
+    if (live) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) s = fma(v[j], ys[16 * cc + j], s);
+    }
     s += __shfl_xor(s, 1, 64);
     s += __shfl_xor(s, 2, 64);
     s += __shfl_xor(s, 4, 64);
-    if (p8 == 0) x[k0 + i] = (i < nv) ? s : 0.0;
+    s += __shfl_xor(s, 8, 64);
+    s += __shfl_xor(s, 16, 64);
+    if (cc == 0) x[row0 + r] = s;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1819,13 +2030,13 @@ static int chol_run(double* A, int lda, int n, double* x_dev, int* flag_dev, hip
     // workspace and task plan are per (host thread, device): a thread that switches devices, or a second GPU in
     // the same process, must not reuse another device's pointers or XCD probe
     struct MegaPlan {
-        int nblk = 0, ntasks = 0, nq = 0, ncu = 0;
+        int nblk = 0, nwide = -1, ntasks = 0, nq = 0, ncu = 0;
         int qstart[17] = {0};
         signed char xcc_queue[16];
         int4* tasks = nullptr; int* sync = nullptr; size_t sync_ints = 0;
         std::vector<float> sim_start;     // simulated start time of every task (written to the trace file)
     };
-    struct DevWs { double* linv = nullptr; int linv_blocks = 0; MegaPlan plan; };
+    struct DevWs { double* linv = nullptr; int linv_blocks = 0; double* vbuf = nullptr; int vbuf_blocks = 0; MegaPlan plan; };
     static thread_local std::map<int, DevWs> ws_by_dev;
     int cur_dev = 0;
     STBA_HIP(hipGetDevice(&cur_dev));
@@ -1837,6 +2048,16 @@ static int chol_run(double* A, int lda, int n, double* x_dev, int* flag_dev, hip
         linv = nullptr; linv_blocks = 0;
         STBA_HIP(hipMalloc(reinterpret_cast<void**>(&linv), (size_t)nblk * LINV_STRIDE * sizeof(double)));
         linv_blocks = nblk;
+    }
+    // wide (4-panel) inverse blocks for the backward substitution: every panel but the last 1..4 (the tail keeps
+    // single-panel steps, so that no inverse-block task runs behind the last diagonal block)
+    static const bool WIDE = [] { const char* e = getenv("STBA_BWD_WIDE"); return !e || atoi(e) != 0; }();
+    const int nwide = (WIDE && !prof) ? (nblk - 1) / 4 : 0;
+    if (ws.vbuf_blocks < nwide) {
+        if (ws.vbuf) (void)hipFree(ws.vbuf);
+        ws.vbuf = nullptr; ws.vbuf_blocks = 0;
+        STBA_HIP(hipMalloc(reinterpret_cast<void**>(&ws.vbuf), (size_t)nwide * 16 * NB * NB * sizeof(double)));
+        ws.vbuf_blocks = nwide;
     }
     // panel of block b: diagonal kernel + panel solve of the (nblk - b - 1) * 8 row groups below it
     auto launch_panel_diag = [&](int b, hipStream_t s_) {
@@ -1878,7 +2099,7 @@ static int chol_run(double* A, int lda, int n, double* x_dev, int* flag_dev, hip
     } else {
         // production: one persistent kernel (see chol_mega_kernel)
         MegaPlan& plan = ws.plan;
-        if (plan.nblk != nblk) {
+        if (plan.nblk != nblk || plan.nwide != nwide) {
             if (plan.tasks) (void)hipFree(plan.tasks);
             if (plan.sync) (void)hipFree(plan.sync);
             plan = MegaPlan();
@@ -1907,13 +2128,13 @@ static int chol_run(double* A, int lda, int n, double* x_dev, int* flag_dev, hip
                         return fail(STBA_ERR_HIP, "chol: fewer than 4 workgroups per XCD (the TU tasks need 4)");
             }
             std::vector<int4> tasks;
-            mega_build_tasks(nblk, plan.nq, std::max(4, plan.ncu / plan.nq), tasks, plan.qstart, &plan.sim_start);
+            mega_build_tasks(nblk, plan.nq, std::max(4, plan.ncu / plan.nq), tasks, plan.qstart, &plan.sim_start, nullptr, nwide);
             STBA_HIP(hipMalloc(reinterpret_cast<void**>(&plan.tasks), tasks.size() * sizeof(int4)));
             STBA_HIP(hipMemcpy(plan.tasks, tasks.data(), tasks.size() * sizeof(int4), hipMemcpyHostToDevice));
-            plan.sync_ints = MEGA_SYNC_HDR + 2 * (size_t)nblk + 2 * (size_t)nblk * nblk;
+            plan.sync_ints = MEGA_SYNC_HDR + 2 * (size_t)nblk + 2 * (size_t)nblk * (nblk + 4 * nwide);
             STBA_HIP(hipMalloc(reinterpret_cast<void**>(&plan.sync), plan.sync_ints * sizeof(int)));
             plan.ntasks = (int)tasks.size();
-            plan.nblk = nblk;
+            plan.nblk = nblk; plan.nwide = nwide;
         }
         STBA_HIP(hipMemsetAsync(plan.sync, 0, plan.sync_ints * sizeof(int), st));
         MegaArgs ma;
@@ -1922,6 +2143,7 @@ static int chol_run(double* A, int lda, int n, double* x_dev, int* flag_dev, hip
         memcpy(ma.qstart, plan.qstart, sizeof ma.qstart);
         memcpy(ma.xcc_queue, plan.xcc_queue, sizeof ma.xcc_queue);
         ma.linv = linv; ma.linv_stride = LINV_STRIDE; ma.flag = flag_dev;
+        ma.vbuf = ws.vbuf; ma.nwide = nwide;
         static const char* TRACE = getenv("STBA_MEGA_TRACE");
         ma.trace = nullptr;
         if (TRACE) STBA_HIP(hipMalloc(reinterpret_cast<void**>(&ma.trace), (size_t)plan.ntasks * 8 * sizeof(long long)));
@@ -1959,11 +2181,18 @@ static int chol_run(double* A, int lda, int n, double* x_dev, int* flag_dev, hip
     // backward substitution: one small launch per block.  (A persistent variant -- one chain workgroup plus
     // GEMV workers synchronised with flags -- was measured at 13.7 us per block against 7.7 us for these
     // launches: every hand-off through memory costs ~2 us on this part, a dependent launch ~3 us.)
-    for (int b = nblk - 1; b >= 0; --b) {
+    for (int b = nblk - 1; b >= 4 * nwide; --b) {
         const int k0 = b * NB;
         const int has_next = (b < nblk - 1) ? 1 : 0;
         const int grid = 1 + (has_next ? b : 0);       // workgroup 0: this block; workgroup 1 + j: block column j < b
         hipLaunchKernelGGL(chol_bwd_step_kernel, dim3(grid), dim3(1024), 0, st, A, lda, k0, has_next, linv + (size_t)b * LINV_STRIDE, x_dev);
+    }
+    // wide steps: apply the solution found last to everything above it, then solve four panels at once
+    for (int qw = nwide - 1; qw >= 0; --qw) {
+        const int row0 = qw * 4 * NB;
+        if (qw == nwide - 1) hipLaunchKernelGGL(chol_bwd_apply_kernel<4>, dim3((row0 + 4 * NB) / 32), dim3(1024), 0, st, A, lda, row0 + 4 * NB, x_dev);
+        else hipLaunchKernelGGL(chol_bwd_apply_kernel<16>, dim3((row0 + 4 * NB) / 32), dim3(1024), 0, st, A, lda, row0 + 4 * NB, x_dev);
+        hipLaunchKernelGGL(chol_bwd_wide_solve_kernel, dim3(16), dim3(1024), 0, st, A, lda, ws.vbuf + (size_t)qw * 16 * NB * NB, row0, x_dev);
     }
     STBA_TRY(mark((size_t)nblk * 4 + 1));
     STBA_HIP(hipGetLastError());
