@@ -40,7 +40,9 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X FP64 matrix peak (SURVEY.md 8d / AMD datasheet)
 FP64_MFMA_MEASURED_CEILING_TFLOPS = 77.3   # profiles/mfma_f64_microbench.txt (pure-MFMA loop, 512-thread blocks, this chip)
-BYTES_PER_OBS_JAC = 186.5    # materialised residual+Jacobian kernel, 10 obs/landmark
+BYTES_PER_OBS_JAC = 106.5    # residual + COMPACT Jacobian kernel at 10 obs/landmark: read 24 B (feature, 2 indices) + 24 B / 10 (landmark)
+                             # + 0.06 B (camera table); write 16 B (r) + 64 B ({xn, yn, P 2x3}: the 2x6 | 2x3 form of SURVEY.md 8d, 186.5 B,
+                             # carries 80 redundant bytes per observation -- DESIGN.md 4)
 
 
 def load_scene(args, rank):
@@ -260,9 +262,9 @@ def main():
                 traffic = pj["hbm_bytes_per_launch"]
         except Exception:
             pass
-        roof_jac = {"kernel": "ba_linearize_kernel<cams-in-LDS, with-Jacobian>", "bound": "hbm", "achieved": jac_gbs,
+        roof_jac = {"kernel": "ba_linearize_kernel<cams-in-LDS, with-Jacobian> (residual + compact 64 B Jacobian per observation)", "bound": "hbm", "achieved": jac_gbs,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": jac_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                    "ms_per_launch": ms_jac, "algorithmic_bytes_per_launch": jac_bytes}
+                    "ms_per_launch": ms_jac, "algorithmic_bytes_per_launch": jac_bytes, "algorithmic_bytes_per_observation": BYTES_PER_OBS_JAC}
         chol_traffic = None
         try:
             with open(os.path.join(ROOT, "profiles", "pmc_chol.json")) as f:

@@ -12,7 +12,10 @@
 //   cams   [n_cams][7]   qx qy qz qw tx ty tz          (56 B/camera; staged into LDS per workgroup)
 //   pts    [n_pts][3]
 //   obs    landmark-major: feat double2[n_obs], obs_cam int[n_obs], obs_pt int[n_obs]
-//   r      double2[n_obs];  Jc [n_obs][12] (2x6 row-major: d/dtheta | d/dt);  Jp [n_obs][6] (2x3)
+//   r      double2[n_obs];  J8 [n_obs][8] = {xn, yn, P (2x3 row-major)} with P = A R^T, A = d proj / d pInC: the
+//          COMPACT Jacobian.  The 2x6 camera block is [A hat(pInC) | -P] and its first part depends on (xn, yn)
+//          only, the 2x3 landmark block is P: 64 B per observation instead of 144 B, expanded in registers where it
+//          is used (expand_j8); constant dofs / landmarks are a per-observation mask byte (omask), not stored zeros
 //   Hpp6   [n_pts][6] (xx xy xz yy yz zz), gp [n_pts][3], Hinv6 [n_pts][6]
 //   Hcc    [n_cams][36], gc [n_cams][6]
 //   S      [lda][lda] dense reduced camera system (lower triangle), lda = padded 6*n_cams
@@ -25,17 +28,16 @@ namespace stba {
 // ===========================================================================================
 // residual + Jacobian, one observation per lane.
 // Algorithmic HBM traffic per observation: 24 B (feature + 2 indices) + landmark 24 B / (obs per
-// landmark) read; 16 B (r) + 96 B (Jc) + 48 B (Jp) written = 186.5 B at 10 obs/landmark
-// (SURVEY.md 8d).  Camera blocks are staged once per workgroup in LDS; the per-lane 96 B / 48 B
-// Jacobian rows are transposed through LDS so that every global store instruction writes
-// 16 B x 64 contiguous lanes.
+// landmark) read; 16 B (r) + 64 B (compact Jacobian) written = 106.5 B at 10 obs/landmark (the
+// materialised 2x6 | 2x3 form of SURVEY.md 8d would be 186.5 B: 80 B of it are redundant).  Camera
+// blocks are staged once per workgroup in LDS; the per-lane 64 B Jacobian rows are transposed through LDS
+// so that every global store instruction writes 16 B x 64 contiguous lanes.
 // ===========================================================================================
 template <bool CAMS_IN_LDS, bool WITH_JAC>
 __global__ __launch_bounds__(LIN_THREADS) void ba_linearize_kernel(LinArgs a) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    double* s_jc = smem;                                   // [LIN_THREADS][13]
-    double* s_jp = smem + (WITH_JAC ? LIN_THREADS * 13 : 0);   // [LIN_THREADS][7]
-    double* s_cam = s_jp + (WITH_JAC ? LIN_THREADS * 7 : 0);   // [n_cams][7]
+    double* s_j8 = smem;                                   // [LIN_THREADS][9]
+    double* s_cam = smem + (WITH_JAC ? LIN_THREADS * 9 : 0);   // [n_cams][7]
     const int tid = threadIdx.x;
     if (CAMS_IN_LDS) {
         for (int i = tid; i < a.n_cams * 7; i += LIN_THREADS) s_cam[i] = a.cams[i];
@@ -65,45 +67,26 @@ __global__ __launch_bounds__(LIN_THREADS) void ba_linearize_kernel(LinArgs a) {
             if (a.r) a.r[i] = make_double2(r0, r1);
             cost += r0 * r0 + r1 * r1;
             if (WITH_JAC) {
-                // A = [[iz,0,-xn iz],[0,iz,-yn iz]];  A*hat(pInC) in closed form
-                const unsigned cm = a.cam_fixed ? a.cam_fixed[c] : 0u;
-                const bool pf = a.pt_fixed ? (a.pt_fixed[j] != 0) : false;
-                double* jc = s_jc + tid * 13;
-                double* jp = s_jp + tid * 7;
-                jc[0] = (cm & 1u) ? 0.0 : xn * yn;
-                jc[1] = (cm & 2u) ? 0.0 : -(1.0 + xn * xn);
-                jc[2] = (cm & 4u) ? 0.0 : yn;
-                jc[6] = (cm & 1u) ? 0.0 : 1.0 + yn * yn;
-                jc[7] = (cm & 2u) ? 0.0 : -xn * yn;
-                jc[8] = (cm & 4u) ? 0.0 : -xn;
+                // A = [[iz,0,-xn iz],[0,iz,-yn iz]];  P = A R^T;  (A hat(pInC) is a function of xn, yn: expand_j8)
+                double* j8 = s_j8 + tid * 9;
+                j8[0] = xn; j8[1] = yn;
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     // (A R^T)_{0k} = iz*R[k][0] - xn*iz*R[k][2];  row 1 with R[k][1], yn
-                    const double p0 = iz * (R[k * 3 + 0] - xn * R[k * 3 + 2]);
-                    const double p1 = iz * (R[k * 3 + 1] - yn * R[k * 3 + 2]);
-                    const bool fx = (cm >> (3 + k)) & 1u;
-                    jc[3 + k] = fx ? 0.0 : -p0;
-                    jc[9 + k] = fx ? 0.0 : -p1;
-                    jp[k] = pf ? 0.0 : p0;
-                    jp[3 + k] = pf ? 0.0 : p1;
+                    j8[2 + k] = iz * (R[k * 3 + 0] - xn * R[k * 3 + 2]);
+                    j8[5 + k] = iz * (R[k * 3 + 1] - yn * R[k * 3 + 2]);
                 }
             }
         }
         if (WITH_JAC) {
             __syncthreads();
             const int n_here = min(LIN_THREADS, a.n_obs - base);
-            // Jc: n_here*12 doubles, written as double2 (16 B per lane, contiguous across lanes)
-            double* gjc = a.Jc + (size_t)base * 12;
-            for (int e = tid; e < n_here * 6; e += LIN_THREADS) {
-                const int o = e / 6, k = (e - o * 6) * 2;
-                const double* s = s_jc + o * 13 + k;
-                *reinterpret_cast<double2*>(gjc + 2 * (size_t)e) = make_double2(s[0], s[1]);
-            }
-            double* gjp = a.Jp + (size_t)base * 6;
-            for (int e = tid; e < n_here * 3; e += LIN_THREADS) {
-                const int o = e / 3, k = (e - o * 3) * 2;
-                const double* s = s_jp + o * 7 + k;
-                *reinterpret_cast<double2*>(gjp + 2 * (size_t)e) = make_double2(s[0], s[1]);
+            // n_here*8 doubles, written as double2 (16 B per lane, contiguous across lanes)
+            double* gj = a.J8 + (size_t)base * 8;
+            for (int e = tid; e < n_here * 4; e += LIN_THREADS) {
+                const int o = e >> 2, k = (e & 3) * 2;
+                const double* sj = s_j8 + o * 9 + k;
+                *reinterpret_cast<double2*>(gj + 2 * (size_t)e) = make_double2(sj[0], sj[1]);
             }
             __syncthreads();
         }
@@ -122,7 +105,7 @@ __global__ __launch_bounds__(LIN_THREADS) void ba_linearize_kernel(LinArgs a) {
 
 size_t lin_lds_bytes(int n_cams, bool cams_in_lds, bool with_jac) {
     size_t d = 0;
-    if (with_jac) d += (size_t)LIN_THREADS * 20;
+    if (with_jac) d += (size_t)LIN_THREADS * 9;
     if (cams_in_lds) d += (size_t)n_cams * 7;
     return d * sizeof(double) + 16;
 }
@@ -222,11 +205,55 @@ int launch_absmax(const double* v, size_t n, const double* v2, size_t n2, double
     return STBA_OK;
 }
 
+// compact Jacobian of observation i -> the 2x6 camera block (d/dtheta | d/dt) and the 2x3 landmark block; columns of
+// constant dofs (mask bits 0..5) and of constant landmarks (bit 6) are zero, as the stored form used to have them
+__device__ inline void load_jc_jp(const double* __restrict__ J8, const unsigned char* __restrict__ omask, int i,
+                                  double jc[12], double jp[6]) {
+    const double2* pj = reinterpret_cast<const double2*>(J8 + (size_t)i * 8);
+    const double2 v0 = pj[0], v1 = pj[1], v2 = pj[2], v3 = pj[3];
+    const unsigned m = omask ? omask[i] : 0u;
+    const double xn = v0.x, yn = v0.y;
+    const double P[6] = {v1.x, v1.y, v2.x, v2.y, v3.x, v3.y};
+    jc[0] = (m & 1u) ? 0.0 : xn * yn;
+    jc[1] = (m & 2u) ? 0.0 : -(1.0 + xn * xn);
+    jc[2] = (m & 4u) ? 0.0 : yn;
+    jc[6] = (m & 1u) ? 0.0 : 1.0 + yn * yn;
+    jc[7] = (m & 2u) ? 0.0 : -xn * yn;
+    jc[8] = (m & 4u) ? 0.0 : -xn;
+    const bool pf = (m & 64u) != 0u;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const bool fx = (m >> (3 + k)) & 1u;
+        jc[3 + k] = fx ? 0.0 : -P[k];
+        jc[9 + k] = fx ? 0.0 : -P[3 + k];
+        jp[k] = pf ? 0.0 : P[k];
+        jp[3 + k] = pf ? 0.0 : P[3 + k];
+    }
+}
+
+// stage entry points (stba_ba_evaluate) hand out the expanded form
+__global__ __launch_bounds__(256) void ba_expand_jacobian_kernel(int n_obs, const double* __restrict__ J8,
+                                                                 const unsigned char* __restrict__ omask,
+                                                                 double* __restrict__ Jc, double* __restrict__ Jp) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_obs) return;
+    double jc[12], jp[6];
+    load_jc_jp(J8, omask, i, jc, jp);
+    if (Jc) for (int k = 0; k < 12; ++k) Jc[(size_t)i * 12 + k] = jc[k];
+    if (Jp) for (int k = 0; k < 6; ++k) Jp[(size_t)i * 6 + k] = jp[k];
+}
+int launch_expand_jacobian(int n_obs, const double* J8, const unsigned char* omask, double* Jc, double* Jp, hipStream_t st) {
+    if (n_obs > 0) hipLaunchKernelGGL(ba_expand_jacobian_kernel, dim3((n_obs + 255) / 256), dim3(256), 0, st, n_obs, J8, omask, Jc, Jp);
+    STBA_HIP(hipGetLastError());
+    return STBA_OK;
+}
+
 // ===========================================================================================
 // point blocks: Hpp_j = sum Jp^T Jp, gp_j = sum Jp^T r over the landmark's observation segment
 // ===========================================================================================
 __global__ __launch_bounds__(256) void ba_point_blocks_kernel(int n_pts, const int* __restrict__ pt_start,
-                                                              const double* __restrict__ Jp,
+                                                              const double* __restrict__ J8,
+                                                              const unsigned char* __restrict__ omask,
                                                               const double2* __restrict__ r,
                                                               double* __restrict__ Hpp6, double* __restrict__ gp) {
     const int j = blockIdx.x * 256 + threadIdx.x;
@@ -234,8 +261,9 @@ __global__ __launch_bounds__(256) void ba_point_blocks_kernel(int n_pts, const i
     double h0 = 0, h1 = 0, h2 = 0, h3 = 0, h4 = 0, h5 = 0, g0 = 0, g1 = 0, g2 = 0;
     const int e = pt_start[j + 1];
     for (int i = pt_start[j]; i < e; ++i) {
-        const double2* p = reinterpret_cast<const double2*>(Jp + (size_t)i * 6);
-        const double2 a = p[0], b = p[1], c = p[2];   // a.x a.y b.x | b.y c.x c.y
+        if (omask && (omask[i] & 64u)) continue;                   // constant landmark: zero block
+        const double2* p = reinterpret_cast<const double2*>(J8 + (size_t)i * 8);
+        const double2 a = p[1], b = p[2], c = p[3];   // a.x a.y b.x | b.y c.x c.y
         const double2 ri = r[i];
         const double j00 = a.x, j01 = a.y, j02 = b.x, j10 = b.y, j11 = c.x, j12 = c.y;
         h0 += j00 * j00 + j10 * j10; h1 += j00 * j01 + j10 * j11; h2 += j00 * j02 + j10 * j12;
@@ -248,10 +276,10 @@ __global__ __launch_bounds__(256) void ba_point_blocks_kernel(int n_pts, const i
     g[0] = g0; g[1] = g1; g[2] = g2;
 }
 
-int launch_point_blocks(int n_pts, const int* pt_start, const double* Jp, const double2* r, double* Hpp6,
-                        double* gp, hipStream_t st) {
+int launch_point_blocks(int n_pts, const int* pt_start, const double* J8, const unsigned char* omask, const double2* r,
+                        double* Hpp6, double* gp, hipStream_t st) {
     hipLaunchKernelGGL(ba_point_blocks_kernel, dim3((n_pts + 255) / 256), dim3(256), 0, st, n_pts, pt_start,
-                       Jp, r, Hpp6, gp);
+                       J8, omask, r, Hpp6, gp);
     STBA_HIP(hipGetLastError());
     return STBA_OK;
 }
@@ -266,7 +294,8 @@ int launch_point_blocks(int n_pts, const int* pt_start, const double* Jp, const 
 __global__ __launch_bounds__(256) void ba_camera_partial_kernel(int n_chunks, const int* __restrict__ chunk_begin,
                                                                 const int* __restrict__ chunk_end,
                                                                 const int* __restrict__ cam_perm,
-                                                                const double* __restrict__ Jc,
+                                                                const double* __restrict__ J8,
+                                                                const unsigned char* __restrict__ omask,
                                                                 const double2* __restrict__ r,
                                                                 double* __restrict__ partial) {
     const int lane = threadIdx.x & 63;
@@ -278,10 +307,8 @@ __global__ __launch_bounds__(256) void ba_camera_partial_kernel(int n_chunks, co
     const int e = chunk_end[ch];
     for (int p = chunk_begin[ch] + lane; p < e; p += 64) {
         const int i = cam_perm[p];
-        const double2* pj = reinterpret_cast<const double2*>(Jc + (size_t)i * 12);
-        double j[12];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) { const double2 v = pj[k]; j[2 * k] = v.x; j[2 * k + 1] = v.y; }
+        double j[12], jpu[6];
+        load_jc_jp(J8, omask, i, j, jpu);
         const double2 ri = r[i];
         int idx = 0;
 #pragma unroll
@@ -324,11 +351,11 @@ __global__ __launch_bounds__(256) void ba_camera_final_kernel(int n_cams, const 
 }
 
 int launch_camera_blocks(int n_cams, int n_chunks, const int* chunk_begin, const int* chunk_end,
-                         const int* cam_chunk_start, const int* cam_perm, const double* Jc, const double2* r,
-                         double* partial, double* Hcc, double* gc, hipStream_t st) {
+                         const int* cam_chunk_start, const int* cam_perm, const double* J8, const unsigned char* omask,
+                         const double2* r, double* partial, double* Hcc, double* gc, hipStream_t st) {
     if (n_chunks > 0)
         hipLaunchKernelGGL(ba_camera_partial_kernel, dim3((n_chunks + 3) / 4), dim3(256), 0, st, n_chunks,
-                           chunk_begin, chunk_end, cam_perm, Jc, r, partial);
+                           chunk_begin, chunk_end, cam_perm, J8, omask, r, partial);
     hipLaunchKernelGGL(ba_camera_final_kernel, dim3((n_cams * 27 + 255) / 256), dim3(256), 0, st, n_cams,
                        cam_chunk_start, partial, Hcc, gc);
     STBA_HIP(hipGetLastError());
@@ -408,20 +435,10 @@ int launch_point_invert(int n_pts, const double* Hpp6, const double* dp, const u
 // (lower block triangle; within a diagonal block only a >= b).  FP64 hardware atomics
 // (global_atomic_add_f64) into the dense S.
 // ===========================================================================================
-__device__ inline void load_jc_jp(const double* __restrict__ Jc, const double* __restrict__ Jp, int i,
-                                  double jc[12], double jp[6]) {
-    const double2* pc = reinterpret_cast<const double2*>(Jc + (size_t)i * 12);
-#pragma unroll
-    for (int k = 0; k < 6; ++k) { const double2 v = pc[k]; jc[2 * k] = v.x; jc[2 * k + 1] = v.y; }
-    const double2* pp = reinterpret_cast<const double2*>(Jp + (size_t)i * 6);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { const double2 v = pp[k]; jp[2 * k] = v.x; jp[2 * k + 1] = v.y; }
-}
-
 __global__ __launch_bounds__(256) void ba_schur_kernel(int n_obs, const int* __restrict__ obs_cam,
                                                        const int* __restrict__ obs_pt,
                                                        const int* __restrict__ pt_start,
-                                                       const double* __restrict__ Jc, const double* __restrict__ Jp,
+                                                       const double* __restrict__ Jc, const unsigned char* __restrict__ Jp,
                                                        const double* __restrict__ Hinv6, const double* __restrict__ gp,
                                                        double* __restrict__ S, int lda, double* __restrict__ rhs) {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -477,7 +494,7 @@ __global__ __launch_bounds__(256) void ba_schur_kernel(int n_obs, const int* __r
 }
 
 int launch_schur(int n_obs, const int* obs_cam, const int* obs_pt, const int* pt_start, const double* Jc,
-                 const double* Jp, const double* Hinv6, const double* gp, double* S, int lda, double* rhs,
+                 const unsigned char* Jp, const double* Hinv6, const double* gp, double* S, int lda, double* rhs,
                  hipStream_t st) {
     if (n_obs > 0)
         hipLaunchKernelGGL(ba_schur_kernel, dim3((n_obs + 255) / 256), dim3(256), 0, st, n_obs, obs_cam, obs_pt,
@@ -592,7 +609,9 @@ __global__ __launch_bounds__(SCHUR_THREADS) void ba_schur_pairs_kernel(SchurRowA
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int task = blockIdx.x;
     const int c = a.task_cam[task];
-    const int col0 = a.row_col_ptr[c], ncols = a.row_col_ptr[c + 1] - col0;
+    const int row_ncols = a.row_col_ptr[c + 1] - a.row_col_ptr[c];
+    const int clo = a.task_col_lo[task], chi = a.task_col_hi[task];       // this task's slice of the row's blocks
+    const int col0 = a.row_col_ptr[c] + clo, ncols = chi - clo;
     double* acc = smem;                          // [ncols][SCHUR_BLK_LD]
     double* racc = smem + (size_t)a.max_cols * SCHUR_BLK_LD;   // [8]
     int* cols = reinterpret_cast<int*>(racc + 8);    // [ncols]
@@ -605,44 +624,44 @@ __global__ __launch_bounds__(SCHUR_THREADS) void ba_schur_pairs_kernel(SchurRowA
         // is ever read) instead of by a 288 MB memset in front of the kernel: the stores drain under the
         // LDS-atomic-bound pair loop.  (Only when every camera row is a single task.)
         const int cend = min(a.lda, ((c * 6 + 5) / 128 + 1) * 128);
+        // (a split row: every piece zeroes from its first block to the next piece's first block)
+        const int z0 = (clo == 0) ? 0 : 6 * a.row_cols[col0];
+        const int z1 = (chi == row_ncols) ? cend : 6 * a.row_cols[col0 + ncols];
         for (int q = 0; q < 6; ++q) {
             double* row = a.S + (size_t)(c * 6 + q) * a.lda;
-            for (int e = tid; e < cend; e += SCHUR_THREADS) row[e] = 0.0;
+            for (int e = z0 + tid; e < z1; e += SCHUR_THREADS) row[e] = 0.0;
         }
     }
     __syncthreads();                             // (also orders the zero stores before the block stores below)
+    // One pair per lane and trip.  The record carries (i, l, landmark, slot), so all gathers of a pair are one level
+    // deep.  (Two pairs in flight per lane -- the second pair's gathers requested before the first is computed -- was
+    // measured 7 % slower: the kernel is not bound by the gather latency.)
     const int ke = a.pair_end[task];
-    for (int k = a.pair_begin[task] + tid; k < ke; k += SCHUR_THREADS) {
-        const int2 il = a.pair_il[k];
-        const unsigned sl = a.pair_slot[k];
-        // E_i = (Jc_i^T Jp_i) Hinv_j recomputed per pair (its inputs are cache-resident for the ~5 consecutive
-        // pairs of one observation; the kernel is bound by the LDS atomics, not by this arithmetic)
-        double E[18], jc2[12], jp2[6];
-        {
-            const int j = a.obs_pt[il.x];
-            double Hi[6], jc[12], jp[6];
+    auto gather = [&](const int4& rc, double (&Hi)[6], double (&jc)[12], double (&jp)[6], double (&jc2)[12], double (&jp2)[6]) {
 #pragma unroll
-            for (int k2 = 0; k2 < 6; ++k2) Hi[k2] = a.Hinv6[(size_t)j * 6 + k2];
-            load_jc_jp(a.Jc, a.Jp, il.x, jc, jp);
+        for (int k2 = 0; k2 < 6; ++k2) Hi[k2] = a.Hinv6[(size_t)rc.z * 6 + k2];
+        load_jc_jp(a.Jc, a.Jp, rc.x, jc, jp);
+        load_jc_jp(a.Jc, a.Jp, rc.y, jc2, jp2);
+    };
+    auto accumulate = [&](const int4& rc, const double (&Hi)[6], const double (&jc)[12], const double (&jp)[6],
+                          const double (&jc2)[12], const double (&jp2)[6]) {
+        const unsigned sl = (unsigned)rc.w;
+        // E_i = (Jc_i^T Jp_i) Hinv_j recomputed per pair (cheaper than a pre-pass that stores it)
+        double E[18];
 #pragma unroll
-            for (int q = 0; q < 6; ++q) {
-                const double w0 = jc[q] * jp[0] + jc[6 + q] * jp[3];
-                const double w1 = jc[q] * jp[1] + jc[6 + q] * jp[4];
-                const double w2 = jc[q] * jp[2] + jc[6 + q] * jp[5];
-                E[q * 3 + 0] = w0 * Hi[0] + w1 * Hi[1] + w2 * Hi[2];
-                E[q * 3 + 1] = w0 * Hi[1] + w1 * Hi[3] + w2 * Hi[4];
-                E[q * 3 + 2] = w0 * Hi[2] + w1 * Hi[4] + w2 * Hi[5];
-            }
-            if (sl & 0x4000u) {                  // l == i: this observation's share of the right-hand side
-                const double g0 = a.gp[(size_t)j * 3], g1 = a.gp[(size_t)j * 3 + 1], g2 = a.gp[(size_t)j * 3 + 2];
-#pragma unroll
-                for (int q = 0; q < 6; ++q) {
-                    const double v = E[q * 3] * g0 + E[q * 3 + 1] * g1 + E[q * 3 + 2] * g2;
-                    if (v != 0.0) unsafeAtomicAdd(&racc[q], v);
-                }
-            }
+        for (int q = 0; q < 6; ++q) {
+            const double w0 = jc[q] * jp[0] + jc[6 + q] * jp[3];
+            const double w1 = jc[q] * jp[1] + jc[6 + q] * jp[4];
+            const double w2 = jc[q] * jp[2] + jc[6 + q] * jp[5];
+            E[q * 3 + 0] = w0 * Hi[0] + w1 * Hi[1] + w2 * Hi[2];
+            E[q * 3 + 1] = w0 * Hi[1] + w1 * Hi[3] + w2 * Hi[4];
+            E[q * 3 + 2] = w0 * Hi[2] + w1 * Hi[4] + w2 * Hi[5];
         }
-        load_jc_jp(a.Jc, a.Jp, il.y, jc2, jp2);
+        if (sl & 0x4000u) {                  // l == i: this observation's share of the right-hand side
+            const double g0 = a.gp[(size_t)rc.z * 3], g1 = a.gp[(size_t)rc.z * 3 + 1], g2 = a.gp[(size_t)rc.z * 3 + 2];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) unsafeAtomicAdd(&racc[q], E[q * 3] * g0 + E[q * 3 + 1] * g1 + E[q * 3 + 2] * g2);
+        }
         const bool diag = (sl & 0x8000u) != 0;
         double* blk = acc + (size_t)(sl & 0x3fffu) * SCHUR_BLK_LD;
 #pragma unroll
@@ -650,14 +669,19 @@ __global__ __launch_bounds__(SCHUR_THREADS) void ba_schur_pairs_kernel(SchurRowA
             const double w0 = jc2[b] * jp2[0] + jc2[6 + b] * jp2[3];
             const double w1 = jc2[b] * jp2[1] + jc2[6 + b] * jp2[4];
             const double w2 = jc2[b] * jp2[2] + jc2[6 + b] * jp2[5];
-            if (w0 == 0.0 && w1 == 0.0 && w2 == 0.0) continue;   // constant dof of camera c2
+            // (no tests for zero contributions of constant dofs: adding a zero is harmless)
 #pragma unroll
             for (int q = 0; q < 6; ++q) {
-                if (diag && b > q) continue;
-                const double v = E[q * 3] * w0 + E[q * 3 + 1] * w1 + E[q * 3 + 2] * w2;
-                if (v != 0.0) unsafeAtomicAdd(&blk[q * 6 + b], -v);
+                if (b > q) { if (!diag) unsafeAtomicAdd(&blk[q * 6 + b], -(E[q * 3] * w0 + E[q * 3 + 1] * w1 + E[q * 3 + 2] * w2)); }
+                else unsafeAtomicAdd(&blk[q * 6 + b], -(E[q * 3] * w0 + E[q * 3 + 1] * w1 + E[q * 3 + 2] * w2));
             }
         }
+    };
+    for (int k = a.pair_begin[task] + tid; k < ke; k += SCHUR_THREADS) {
+        const int4 r0 = a.pair_rec[k];
+        double Hi0[6], jc0[12], jp0[6], jcl0[12], jpl0[6];
+        gather(r0, Hi0, jc0, jp0, jcl0, jpl0);
+        accumulate(r0, Hi0, jc0, jp0, jcl0, jpl0);
     }
     __syncthreads();
     const bool single = a.task_single[task] != 0;
@@ -670,7 +694,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void ba_schur_pairs_kernel(SchurRowA
         if (single) *dst = v;
         else unsafeAtomicAdd(dst, v);
     }
-    if (tid < 6) {
+    if (tid < 6 && chi == row_ncols) {           // (the piece with the diagonal block carries the right-hand side)
         if (single) a.rhs[c * 6 + tid] = racc[tid];
         else unsafeAtomicAdd(&a.rhs[c * 6 + tid], racc[tid]);
     }
@@ -693,7 +717,7 @@ int launch_schur_rows(const SchurRowArgs& a, int n_tasks, hipStream_t st) {
                                      hipFuncAttributeMaxDynamicSharedMemorySize, lim));
         return STBA_OK;
     }));
-    if (a.pair_il) {
+    if (a.pair_rec) {
         hipLaunchKernelGGL(ba_schur_pairs_kernel, dim3(n_tasks), dim3(SCHUR_THREADS), lds, st, a);
     } else {
         hipLaunchKernelGGL(ba_schur_rows_kernel, dim3(n_tasks), dim3(SCHUR_THREADS), lds, st, a);
@@ -758,7 +782,7 @@ int launch_reduced_damp(int n, const double* dc, const unsigned char* cam_fixed,
 // ===========================================================================================
 __global__ __launch_bounds__(256) void ba_backsub_kernel(int n_pts, const int* __restrict__ pt_start,
                                                          const int* __restrict__ obs_cam,
-                                                         const double* __restrict__ Jc, const double* __restrict__ Jp,
+                                                         const double* __restrict__ Jc, const unsigned char* __restrict__ Jp,
                                                          const double* __restrict__ Hinv6, const double* __restrict__ gp,
                                                          const double* __restrict__ dxc, double* __restrict__ dxp) {
     const int j = blockIdx.x * 256 + threadIdx.x;
@@ -782,7 +806,7 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(int n_pts, const int* _
     dxp[(size_t)j * 3 + 2] = Hi[2] * v0 + Hi[4] * v1 + Hi[5] * v2;
 }
 
-int launch_backsub(int n_pts, const int* pt_start, const int* obs_cam, const double* Jc, const double* Jp,
+int launch_backsub(int n_pts, const int* pt_start, const int* obs_cam, const double* Jc, const unsigned char* Jp,
                    const double* Hinv6, const double* gp, const double* dxc, double* dxp, hipStream_t st) {
     hipLaunchKernelGGL(ba_backsub_kernel, dim3((n_pts + 255) / 256), dim3(256), 0, st, n_pts, pt_start, obs_cam, Jc,
                        Jp, Hinv6, gp, dxc, dxp);

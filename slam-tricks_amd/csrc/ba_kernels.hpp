@@ -18,8 +18,7 @@ struct LinArgs {
     const unsigned char* cam_fixed;  // [n_cams] bitmask (bit a = dof a constant) or null
     const unsigned char* pt_fixed;   // [n_pts] or null
     double2* r;                      // [n_obs]
-    double* Jc;                      // [n_obs][12]
-    double* Jp;                      // [n_obs][6]
+    double* J8;                      // [n_obs][8] compact Jacobian {xn, yn, P 2x3} (see ba_kernels.hip)
     double* cost_partial;            // [grid]
 };
 
@@ -28,36 +27,41 @@ int launch_linearize(const LinArgs& a, bool with_jac, int grid, hipStream_t st);
 int launch_sum_partials(const double* partial, int n, int stride, int K, double* out, hipStream_t st);
 int launch_absmax(const double* v, size_t n, const double* v2, size_t n2, double* out, double* partial, int n_partial,
                   hipStream_t st);
-int launch_point_blocks(int n_pts, const int* pt_start, const double* Jp, const double2* r, double* Hpp6,
-                        double* gp, hipStream_t st);
+// (J8: compact Jacobian [n_obs][8]; omask: per-observation mask byte of constant dofs / landmarks, or null)
+int launch_expand_jacobian(int n_obs, const double* J8, const unsigned char* omask, double* Jc, double* Jp, hipStream_t st);
+int launch_point_blocks(int n_pts, const int* pt_start, const double* J8, const unsigned char* omask, const double2* r,
+                        double* Hpp6, double* gp, hipStream_t st);
 int launch_camera_blocks(int n_cams, int n_chunks, const int* chunk_begin, const int* chunk_end,
-                         const int* cam_chunk_start, const int* cam_perm, const double* Jc, const double2* r,
-                         double* partial, double* Hcc, double* gc, hipStream_t st);
+                         const int* cam_chunk_start, const int* cam_perm, const double* J8, const unsigned char* omask,
+                         const double2* r, double* partial, double* Hcc, double* gc, hipStream_t st);
 int launch_lm_diagonal(int n, int bs, int bstride, int kind, const double* H, double* scale, int init_scale,
                        int use_scaling, double radius, double dmin, double dmax, double* d, hipStream_t st);
 int launch_point_invert(int n_pts, const double* Hpp6, const double* dp, const unsigned char* pt_fixed,
                         double* Hinv6, hipStream_t st);
-int launch_schur(int n_obs, const int* obs_cam, const int* obs_pt, const int* pt_start, const double* Jc,
-                 const double* Jp, const double* Hinv6, const double* gp, double* S, int lda, double* rhs,
+int launch_schur(int n_obs, const int* obs_cam, const int* obs_pt, const int* pt_start, const double* J8,
+                 const unsigned char* omask, const double* Hinv6, const double* gp, double* S, int lda, double* rhs,
                  hipStream_t st);
 // row-wise Schur complement with LDS accumulation (plan built on the host at create time)
 constexpr int SCHUR_MAX_COLS = 480;    // non-zero blocks per camera row that fit the LDS accumulator
 constexpr int SCHUR_TASK_OBS = 4096;
+constexpr int SCHUR_SPLIT_COLS = 256;  // camera rows with more non-zero blocks are split by column range (two workgroups per CU)
 // LDS stride of one 6x6 accumulator block, in doubles: odd, so that the same entry of different blocks falls
 // into different bank pairs (36 = 72 dwords = 8 mod 64 gave 8-way conflicts on every ds_add_f64: measured,
 // the kernel was bound by them)
 constexpr int SCHUR_BLK_LD = 37;
-constexpr int SCHUR_THREADS = 1024;    // one camera row per workgroup: 16 waves hide the L2 gathers   // observations of one camera handled by one workgroup
+constexpr int SCHUR_THREADS = 512;    // one camera row per workgroup: 16 waves hide the L2 gathers   // observations of one camera handled by one workgroup
 struct SchurRowArgs {
     const int* task_cam; const int* task_begin; const int* task_end; const unsigned char* task_single;
+    const int* task_col_lo; const int* task_col_hi;  // the task's slice of its row's column list (the whole row unless split)
     const int* row_col_ptr; const int* row_cols; int max_cols;
     const int* cam_perm; const int* obs_cam; const int* obs_pt; const int* pt_start;
-    const double* Jc; const double* Jp; const double* Hinv6; const double* gp;
+    const double* Jc; const unsigned char* Jp;       // compact Jacobian [n_obs][8] | per-observation mask byte (or null)
+    const double* Hinv6; const double* gp;
     double* S; int lda; double* rhs;
     // pair plan (optional, built at create time): every (observation i of the row's camera, observation l of
     // the same landmark with camera(l) <= camera(i)) with the LDS slot of its 6x6 block resolved on the host
     const int* pair_begin; const int* pair_end;      // per task
-    const int2* pair_il; const unsigned short* pair_slot;   // slot | 0x8000 if diagonal block | 0x4000 if l == i
+    const int4* pair_rec;                            // (i, l, landmark, slot | 0x8000 if diagonal block | 0x4000 if l == i)
     int n_obs;
     int zero_rows;                                   // the pair kernel zeroes its rows of S itself (no memset of S)
 };
@@ -67,7 +71,7 @@ int launch_reduced_add_camera(int n_cams, const double* Hcc, const double* gc, d
                               double* ex_diag, double* ex_gc, hipStream_t st);
 int launch_reduced_damp(int n, const double* dc, const unsigned char* cam_fixed, double* S, int lda, double* rhs,
                         hipStream_t st);
-int launch_backsub(int n_pts, const int* pt_start, const int* obs_cam, const double* Jc, const double* Jp,
+int launch_backsub(int n_pts, const int* pt_start, const int* obs_cam, const double* J8, const unsigned char* omask,
                    const double* Hinv6, const double* gp, const double* dxc, double* dxp, hipStream_t st);
 int launch_update(int n_cams, int n_pts, const double* cams, const double* pts, const double* dxc,
                   const double* dxp, const unsigned char* cam_fixed, const unsigned char* pt_fixed,

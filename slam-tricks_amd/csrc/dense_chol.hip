@@ -464,7 +464,7 @@ struct Diag2Smem {
     double Mig[8][2][4][64];        // tiles (I, I-1) and (I, I) on their way to the factor wave: register r, lane
     unsigned int abortf;            // a poll gave up (a bug): results are garbage, the caller reports a time-out
 };
-constexpr int DIAG2_SMEM_DOUBLES = (int)((sizeof(Diag2Smem) + 7) / sizeof(double));
+
 static_assert(sizeof(Diag2Smem) <= 128 * 1024, "D2 must fit the persistent kernel's LDS");
 
 #ifdef STBA_DIAG_TS

@@ -86,16 +86,17 @@ struct stba_ba {
     int n_chunks = 0;
     // row-wise Schur plan (empty => global-atomic fallback kernel)
     int *task_cam = nullptr, *task_begin = nullptr, *task_end = nullptr, *row_col_ptr = nullptr, *row_cols = nullptr;
+    int *task_col_lo = nullptr, *task_col_hi = nullptr;      // a task's slice [lo, hi) of its camera row's column list
     unsigned char* task_single = nullptr;
     int n_tasks = 0, max_cols = 0;
     // pair plan of the Schur kernel (see ba_schur_pairs_kernel)
     int *pair_begin = nullptr, *pair_end = nullptr;
-    int2* pair_il = nullptr;
-    unsigned short* pair_slot = nullptr;
+    int4* pair_rec = nullptr;           // (i, l, landmark, slot | flags)
     bool all_single = false;            // every camera row is ONE Schur task and every camera has a task
     unsigned char *cam_fixed = nullptr, *pt_fixed = nullptr;
     double2* r = nullptr;
-    double *Jc = nullptr, *Jp = nullptr;
+    double* J8 = nullptr;            // compact Jacobian [n_obs][8] (ba_kernels.hip)
+    unsigned char* omask = nullptr;  // per observation: constant dofs of its camera (bits 0..5) | constant landmark (bit 6); null if none
     double *Hpp6 = nullptr, *gp = nullptr, *Hinv6 = nullptr, *dp = nullptr, *scale_p = nullptr;
     double *Hcc = nullptr, *gc = nullptr, *cam_partial = nullptr, *dc = nullptr, *scale_c = nullptr;
     double* Sbuf = nullptr;   // [S lda*lda | ex_diag lda | ex_gc lda | rhs lda | ex_scalar lda]
@@ -138,10 +139,10 @@ static void ba_free(stba_ba* b) {
     auto F = [](void* p) { if (p) (void)hipFree(p); };
     F(b->cams[0]); F(b->cams[1]); F(b->pts[0]); F(b->pts[1]); F(b->feat); F(b->obs_cam); F(b->obs_pt);
     F(b->pt_start); F(b->cam_perm); F(b->chunk_begin); F(b->chunk_end); F(b->cam_chunk_start); F(b->cam_fixed);
-    F(b->pt_fixed); F(b->r); F(b->Jc); F(b->Jp); F(b->Hpp6); F(b->gp); F(b->Hinv6); F(b->dp); F(b->scale_p);
+    F(b->pt_fixed); F(b->r); F(b->J8); F(b->omask); F(b->Hpp6); F(b->gp); F(b->Hinv6); F(b->dp); F(b->scale_p);
     F(b->Hcc); F(b->gc); F(b->cam_partial); F(b->dc); F(b->scale_c); F(b->Sbuf); F(b->Spack); F(b->pk_blocks); F(b->dxc); F(b->dxp);
-    F(b->task_cam); F(b->task_begin); F(b->task_end); F(b->row_col_ptr); F(b->row_cols); F(b->task_single);
-    F(b->pair_begin); F(b->pair_end); F(b->pair_il); F(b->pair_slot);
+    F(b->task_cam); F(b->task_begin); F(b->task_end); F(b->task_col_lo); F(b->task_col_hi); F(b->row_col_ptr); F(b->row_cols); F(b->task_single);
+    F(b->pair_begin); F(b->pair_end); F(b->pair_rec);
     F(b->cost_partial); F(b->upd_partial_c); F(b->upd_partial_p); F(b->trial); F(b->flag);
     for (auto& e : b->ev) if (e) (void)hipEventDestroy(e);
     if (b->lin_pin) (void)hipHostFree(b->lin_pin);
@@ -155,7 +156,7 @@ static LinArgs lin_args(stba_ba* b, int which, bool store_r) {
     a.cams = b->cams[which]; a.pts = b->pts[which];
     a.feat = b->feat; a.obs_cam = b->obs_cam; a.obs_pt = b->obs_pt;
     a.cam_fixed = b->cam_fixed; a.pt_fixed = b->pt_fixed;
-    a.r = store_r ? b->r : nullptr; a.Jc = b->Jc; a.Jp = b->Jp; a.cost_partial = b->cost_partial;
+    a.r = store_r ? b->r : nullptr; a.J8 = b->J8; a.cost_partial = b->cost_partial;
     return a;
 }
 
@@ -172,9 +173,9 @@ static int ba_cost_only(stba_ba* b, int which, double* cost2_dev) {
 }
 
 static int ba_normal_blocks(stba_ba* b) {
-    STBA_TRY(launch_point_blocks(b->np, b->pt_start, b->Jp, b->r, b->Hpp6, b->gp, b->st));
+    STBA_TRY(launch_point_blocks(b->np, b->pt_start, b->J8, b->omask, b->r, b->Hpp6, b->gp, b->st));
     return launch_camera_blocks(b->nc, b->n_chunks, b->chunk_begin, b->chunk_end, b->cam_chunk_start, b->cam_perm,
-                                b->Jc, b->r, b->cam_partial, b->Hcc, b->gc, b->st);
+                                b->J8, b->omask, b->r, b->cam_partial, b->Hcc, b->gc, b->st);
 }
 
 struct Damping {
@@ -265,21 +266,22 @@ static int ba_build_reduced(stba_ba* b, const Damping& dm) {
     STBA_TRY(launch_point_invert(b->np, b->Hpp6, b->dp, b->pt_fixed, b->Hinv6, b->st));
     // S is zeroed by the pair-plan Schur kernel itself when every camera row is one task; the three extras
     // vectors behind it (diag, gc, rhs) always here (the scalar slots are kept)
-    const bool self_zero = b->pair_il != nullptr && b->all_single;
+    const bool self_zero = b->pair_rec != nullptr && b->all_single;
     if (self_zero) STBA_HIP(hipMemsetAsync(b->Sbuf + (size_t)b->lda * b->lda, 0, 3 * (size_t)b->lda * sizeof(double), b->st));
     else STBA_HIP(hipMemsetAsync(b->Sbuf, 0, ((size_t)b->lda * b->lda + 3 * (size_t)b->lda) * sizeof(double), b->st));
     if (b->n_tasks > 0) {
         SchurRowArgs sa;
         sa.task_cam = b->task_cam; sa.task_begin = b->task_begin; sa.task_end = b->task_end;
+        sa.task_col_lo = b->task_col_lo; sa.task_col_hi = b->task_col_hi;
         sa.task_single = b->task_single; sa.row_col_ptr = b->row_col_ptr; sa.row_cols = b->row_cols;
         sa.max_cols = b->max_cols; sa.cam_perm = b->cam_perm; sa.obs_cam = b->obs_cam; sa.obs_pt = b->obs_pt;
-        sa.pt_start = b->pt_start; sa.Jc = b->Jc; sa.Jp = b->Jp; sa.Hinv6 = b->Hinv6; sa.gp = b->gp;
+        sa.pt_start = b->pt_start; sa.Jc = b->J8; sa.Jp = b->omask; sa.Hinv6 = b->Hinv6; sa.gp = b->gp;
         sa.S = b->S(); sa.lda = b->lda; sa.rhs = b->rhs();
-        sa.pair_begin = b->pair_begin; sa.pair_end = b->pair_end; sa.pair_il = b->pair_il; sa.pair_slot = b->pair_slot;
+        sa.pair_begin = b->pair_begin; sa.pair_end = b->pair_end; sa.pair_rec = b->pair_rec;
         sa.n_obs = b->no; sa.zero_rows = self_zero ? 1 : 0;
         STBA_TRY(launch_schur_rows(sa, b->n_tasks, b->st));
     } else {
-        STBA_TRY(launch_schur(b->no, b->obs_cam, b->obs_pt, b->pt_start, b->Jc, b->Jp, b->Hinv6, b->gp, b->S(),
+        STBA_TRY(launch_schur(b->no, b->obs_cam, b->obs_pt, b->pt_start, b->J8, b->omask, b->Hinv6, b->gp, b->S(),
                               b->lda, b->rhs(), b->st));
     }
     STBA_TRY(launch_reduced_add_camera(b->nc, b->Hcc, b->gc, b->S(), b->lda, b->rhs(), b->ex_diag(), b->ex_gc(),
@@ -462,7 +464,7 @@ static int ba_run_lm(stba_ba* b, const stba_lm_options* opt_in, int fixed_iterat
         int flag_h = 0;
         STBA_TRY(chol_factor_solve_dev(b->S(), b->lda, b->n, b->dxc, b->flag, b->st));
         STBA_HIP(hipEventRecord(ev[4], b->st));
-        STBA_TRY(launch_backsub(b->np, b->pt_start, b->obs_cam, b->Jc, b->Jp, b->Hinv6, b->gp, b->dxc, b->dxp, b->st));
+        STBA_TRY(launch_backsub(b->np, b->pt_start, b->obs_cam, b->J8, b->omask, b->Hinv6, b->gp, b->dxc, b->dxp, b->st));
         STBA_HIP(hipEventRecord(ev[5], b->st));
         STBA_TRY(ba_trial(b));
         STBA_HIP(hipEventRecord(ev[6], b->st));
@@ -718,9 +720,15 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
     b->n_chunks = (int)chunk_begin.size();
     tmark("regroup observations");
     // ---- row-wise Schur plan: distinct partner cameras c2 <= c of every camera row + tasks
-    std::vector<int> row_col_ptr(n_cams + 1, 0), row_cols, task_cam, task_begin, task_end;
+    std::vector<int> row_col_ptr(n_cams + 1, 0), row_cols, task_cam, task_begin, task_end, task_col_lo, task_col_hi;
     std::vector<unsigned char> task_single;
-    int max_cols = 0;
+    int max_cols = 0, task_max_cols = 0;
+    bool every_cam_exclusive = true;                  // every camera row is covered by tasks that own their blocks alone
+    // the pair plan (one (i, l) pair per lane, see ba_schur_pairs_kernel) is used unless it would be huge
+    static const bool PAIRS = [] { const char* v = getenv("STBA_SCHUR_PAIRS"); return !v || atoi(v) != 0; }();
+    size_t total_pairs = 0;
+    for (int j = 0; j < n_pts; ++j) { const size_t k = (size_t)(pt_start[j + 1] - pt_start[j]); total_pairs += k * (k + 1) / 2; }
+    bool pair_plan = PAIRS && total_pairs <= ((size_t)1 << 27);          // > 2 GB of plan: keep the row kernel
     {
         std::vector<std::vector<int>> cols_of((size_t)n_cams);
         host_parallel_for(n_cams, [&](int c_lo, int c_hi, int) {
@@ -741,38 +749,46 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
             const std::vector<int>& tmp = cols_of[(size_t)c];
             row_cols.insert(row_cols.end(), tmp.begin(), tmp.end());
             row_col_ptr[c + 1] = (int)row_cols.size();
-            max_cols = std::max(max_cols, (int)tmp.size());
+            const int ncols_c = (int)tmp.size();
+            max_cols = std::max(max_cols, ncols_c);
             const int nobs_c = cam_start[c + 1] - cam_start[c];
             const int nt = (nobs_c + SCHUR_TASK_OBS - 1) / SCHUR_TASK_OBS;
-            for (int k = 0; k < nt; ++k) {
-                task_cam.push_back(c);
-                task_begin.push_back(cam_start[c] + k * SCHUR_TASK_OBS);
-                task_end.push_back(std::min(cam_start[c] + (k + 1) * SCHUR_TASK_OBS, cam_start[c + 1]));
-                task_single.push_back(nt == 1 ? 1 : 0);
-            }
+            if (nt != 1) every_cam_exclusive = false;
+            // a wide row is split by COLUMN range (pair plan only): each piece owns its blocks alone, and its LDS
+            // accumulator is small enough for two workgroups per CU (the kernel is bound by LDS atomics and by the
+            // barrier behind them: one workgroup per CU leaves the CU idle a third of the time)
+            const int nsplit = (pair_plan && nt == 1 && ncols_c > SCHUR_SPLIT_COLS) ? (ncols_c + SCHUR_SPLIT_COLS - 1) / SCHUR_SPLIT_COLS : 1;
+            for (int k = 0; k < nt; ++k)
+                for (int sp = 0; sp < nsplit; ++sp) {
+                    task_cam.push_back(c);
+                    task_begin.push_back(cam_start[c] + k * SCHUR_TASK_OBS);
+                    task_end.push_back(std::min(cam_start[c] + (k + 1) * SCHUR_TASK_OBS, cam_start[c + 1]));
+                    task_single.push_back(nt == 1 ? 1 : 0);
+                    task_col_lo.push_back((int)((long)ncols_c * sp / nsplit));
+                    task_col_hi.push_back((int)((long)ncols_c * (sp + 1) / nsplit));
+                    task_max_cols = std::max(task_max_cols, task_col_hi.back() - task_col_lo.back());
+                }
         }
-        // heaviest rows first (more partners, more observations) for a better tail
+        // heaviest tasks first (more partners, more observations) for a better tail
         std::vector<int> order(task_cam.size());
         for (size_t k = 0; k < order.size(); ++k) order[k] = (int)k;
         std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
-            const long wx = (long)(task_end[x] - task_begin[x]) * (row_col_ptr[task_cam[x] + 1] - row_col_ptr[task_cam[x]]);
-            const long wy = (long)(task_end[y] - task_begin[y]) * (row_col_ptr[task_cam[y] + 1] - row_col_ptr[task_cam[y]]);
+            const long wx = (long)(task_end[x] - task_begin[x]) * (task_col_hi[x] - task_col_lo[x]);
+            const long wy = (long)(task_end[y] - task_begin[y]) * (task_col_hi[y] - task_col_lo[y]);
             return wx > wy;
         });
         auto permute = [&](auto& v) { auto t = v; for (size_t k = 0; k < order.size(); ++k) v[k] = t[order[k]]; };
-        permute(task_cam); permute(task_begin); permute(task_end); permute(task_single);
+        permute(task_cam); permute(task_begin); permute(task_end); permute(task_single); permute(task_col_lo); permute(task_col_hi);
     }
     tmark("row plan");
-    const bool row_plan = max_cols <= SCHUR_MAX_COLS;
+    const bool row_plan = task_max_cols <= SCHUR_MAX_COLS;
     b->n_tasks = row_plan ? (int)task_cam.size() : 0;
-    b->max_cols = max_cols;
-    b->all_single = row_plan && (int)task_cam.size() == n_cams;     // one task per camera, none split, none missing
-    // pair plan: (i, l, slot) of every block contribution of every task, in task order
+    b->max_cols = task_max_cols;
+    b->all_single = row_plan && every_cam_exclusive;     // every block of S has exactly one writer: the Schur kernel can zero its rows itself
+    // pair plan: (i, l, landmark, slot) of every block contribution of every task, in task order
     std::vector<int> pair_begin, pair_end;
-    std::vector<int2> pair_il;
-    std::vector<unsigned short> pair_slot;
-    static const bool PAIRS = [] { const char* v = getenv("STBA_SCHUR_PAIRS"); return !v || atoi(v) != 0; }();
-    bool pair_plan = PAIRS && row_plan && max_cols < 0x4000;
+    std::vector<int4> pair_rec;
+    pair_plan = pair_plan && row_plan && task_max_cols < 0x4000;
     if (pair_plan) {
         const int ntask = (int)task_cam.size();
         pair_begin.resize((size_t)ntask); pair_end.resize((size_t)ntask);
@@ -781,18 +797,20 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
         host_parallel_for(ntask, [&](int k_lo, int k_hi, int) {
             for (int k = k_lo; k < k_hi; ++k) {
                 const int c = task_cam[(size_t)k];
+                // the task's column slice is a range of partner cameras [c2_lo, c2_hi]
+                const int* cb = row_cols.data() + row_col_ptr[c];
+                const int c2_lo = cb[task_col_lo[(size_t)k]], c2_hi = cb[task_col_hi[(size_t)k] - 1];
                 size_t m = 0;
                 for (int p = task_begin[(size_t)k]; p < task_end[(size_t)k]; ++p) {
                     const int j = s_pt[cam_perm[p]];
-                    for (int l = pt_start[j]; l < pt_start[j + 1]; ++l) m += (s_cam[l] <= c) ? 1 : 0;
+                    for (int l = pt_start[j]; l < pt_start[j + 1]; ++l) m += (s_cam[l] >= c2_lo && s_cam[l] <= c2_hi) ? 1 : 0;
                 }
                 cnt[(size_t)k + 1] = m;
             }
         });
         for (int k = 0; k < ntask; ++k) cnt[(size_t)k + 1] += cnt[(size_t)k];
-        if (cnt[(size_t)ntask] > ((size_t)1 << 28)) pair_plan = false;          // > 2.7 GB of plan: keep the row kernel
         if (pair_plan) {
-            pair_il.resize(cnt[(size_t)ntask]); pair_slot.resize(cnt[(size_t)ntask]);
+            pair_rec.resize(cnt[(size_t)ntask]);
             host_parallel_for(ntask, [&](int k_lo, int k_hi, int) {
                 std::vector<int> slot_of((size_t)n_cams, 0);
                 for (int k = k_lo; k < k_hi; ++k) {
@@ -800,6 +818,7 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
                     const int* cb = row_cols.data() + row_col_ptr[c];
                     const int nco = row_col_ptr[c + 1] - row_col_ptr[c];
                     for (int q = 0; q < nco; ++q) slot_of[(size_t)cb[q]] = q;
+                    const int slo = task_col_lo[(size_t)k], shi = task_col_hi[(size_t)k];
                     size_t w = cnt[(size_t)k];
                     pair_begin[(size_t)k] = (int)w;
                     for (int p = task_begin[(size_t)k]; p < task_end[(size_t)k]; ++p) {
@@ -808,12 +827,15 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
                         for (int l = pt_start[j]; l < pt_start[j + 1]; ++l) {
                             const int c2 = s_cam[l];
                             if (c2 > c) continue;
-                            pair_il[w] = make_int2(i, l);
-                            pair_slot[w] = (unsigned short)(slot_of[(size_t)c2] | (c2 == c ? 0x8000 : 0) | (l == i ? 0x4000 : 0));
+                            const int sl = slot_of[(size_t)c2];
+                            if (sl < slo || sl >= shi) continue;
+                            pair_rec[w] = make_int4(i, l, j, (sl - slo) | (c2 == c ? 0x8000 : 0) | (l == i ? 0x4000 : 0));
                             ++w;
                         }
                     }
                     pair_end[(size_t)k] = (int)w;
+                    // (dealing the records out so that every 32 consecutive ones hit 32 different LDS bank pairs was measured:
+                    // the bank conflicts it removes cost less than the locality of the landmark-major order it destroys)
                 }
             });
         }
@@ -844,15 +866,17 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
     if (b->n_tasks > 0) {
         A_(dev_alloc(&b->task_cam, task_cam.size())); A_(dev_alloc(&b->task_begin, task_cam.size()));
         A_(dev_alloc(&b->task_end, task_cam.size())); A_(dev_alloc(&b->task_single, task_cam.size()));
+        A_(dev_alloc(&b->task_col_lo, task_cam.size())); A_(dev_alloc(&b->task_col_hi, task_cam.size()));
         A_(dev_alloc(&b->row_col_ptr, nc + 1)); A_(dev_alloc(&b->row_cols, row_cols.size()));
-        if (pair_plan && !pair_il.empty()) {
+        if (pair_plan && !pair_rec.empty()) {
             A_(dev_alloc(&b->pair_begin, pair_begin.size())); A_(dev_alloc(&b->pair_end, pair_end.size()));
-            A_(dev_alloc(&b->pair_il, pair_il.size())); A_(dev_alloc(&b->pair_slot, pair_slot.size()));
+            A_(dev_alloc(&b->pair_rec, pair_rec.size()));
         }
     }
     if (cam_fixed) A_(dev_alloc(&b->cam_fixed, nc));
     if (pt_fixed) A_(dev_alloc(&b->pt_fixed, np));
-    A_(dev_alloc(&b->r, no)); A_(dev_alloc(&b->Jc, no * 12)); A_(dev_alloc(&b->Jp, no * 6));
+    A_(dev_alloc(&b->r, no)); A_(dev_alloc(&b->J8, no * 8));
+    if (cam_fixed || pt_fixed) A_(dev_alloc(&b->omask, no));
     A_(dev_alloc(&b->Hpp6, np * 6)); A_(dev_alloc(&b->gp, np * 3)); A_(dev_alloc(&b->Hinv6, np * 6));
     A_(dev_alloc(&b->dp, np * 3)); A_(dev_alloc(&b->scale_p, np * 3));
     A_(dev_alloc(&b->Hcc, nc * 36)); A_(dev_alloc(&b->gc, nc * 6)); A_(dev_alloc(&b->cam_partial, (size_t)b->n_chunks * 28));
@@ -877,15 +901,24 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
         A_(upload(b->task_begin, task_begin.data(), task_cam.size(), b->st));
         A_(upload(b->task_end, task_end.data(), task_cam.size(), b->st));
         A_(upload(b->task_single, task_single.data(), task_cam.size(), b->st));
+        A_(upload(b->task_col_lo, task_col_lo.data(), task_cam.size(), b->st));
+        A_(upload(b->task_col_hi, task_col_hi.data(), task_cam.size(), b->st));
         b->h_row_col_ptr = row_col_ptr; b->h_row_cols = row_cols;
         A_(upload(b->row_col_ptr, row_col_ptr.data(), nc + 1, b->st));
         A_(upload(b->row_cols, row_cols.data(), row_cols.size(), b->st));
-        if (b->pair_il) {
+        if (b->pair_rec) {
             A_(upload(b->pair_begin, pair_begin.data(), pair_begin.size(), b->st)); A_(upload(b->pair_end, pair_end.data(), pair_end.size(), b->st));
-            A_(upload(b->pair_il, pair_il.data(), pair_il.size(), b->st)); A_(upload(b->pair_slot, pair_slot.data(), pair_slot.size(), b->st));
+            A_(upload(b->pair_rec, pair_rec.data(), pair_rec.size(), b->st));
         }
     }
     if (cam_fixed) A_(upload(b->cam_fixed, cmask.data(), nc, b->st));
+    std::vector<unsigned char> omask;
+    if (b->omask) {
+        omask.resize(no);
+        for (size_t p2 = 0; p2 < no; ++p2)
+            omask[p2] = (unsigned char)((cam_fixed ? cmask[(size_t)s_cam[p2]] : 0u) | ((pt_fixed && pt_fixed[(size_t)s_pt[p2]]) ? 64u : 0u));
+        A_(upload(b->omask, omask.data(), no, b->st));
+    }
     if (pt_fixed) A_(upload(b->pt_fixed, pt_fixed, np, b->st));
     if (hipMemsetAsync(b->dxc, 0, (size_t)b->lda * sizeof(double), b->st) != hipSuccess ||
         hipMemsetAsync(b->Sbuf, 0, b->sbuf_count() * sizeof(double), b->st) != hipSuccess ||
@@ -949,8 +982,15 @@ int stba_ba_evaluate(stba_ba* b, double* cost, double* r, double* Jc, double* Jp
     const size_t no = (size_t)b->no;
     std::vector<double> tr, tjc, tjp;
     if (r) { tr.resize(no * 2); STBA_TRY(download(tr.data(), reinterpret_cast<double*>(b->r), no * 2, b->st)); }
-    if (Jc) { tjc.resize(no * 12); STBA_TRY(download(tjc.data(), b->Jc, no * 12, b->st)); }
-    if (Jp) { tjp.resize(no * 6); STBA_TRY(download(tjp.data(), b->Jp, no * 6, b->st)); }
+    double *djc = nullptr, *djp = nullptr;     // the device holds the compact Jacobian; the 2x6 | 2x3 form is expanded for the caller
+    struct TmpGuard { double*& a; double*& c; ~TmpGuard() { if (a) (void)hipFree(a); if (c) (void)hipFree(c); } } tmp_guard{djc, djp};
+    if (Jc || Jp) {
+        if (Jc) STBA_TRY(dev_alloc(&djc, no * 12));
+        if (Jp) STBA_TRY(dev_alloc(&djp, no * 6));
+        STBA_TRY(launch_expand_jacobian(b->no, b->J8, b->omask, djc, djp, b->st));
+        if (Jc) { tjc.resize(no * 12); STBA_TRY(download(tjc.data(), djc, no * 12, b->st)); }
+        if (Jp) { tjp.resize(no * 6); STBA_TRY(download(tjp.data(), djp, no * 6, b->st)); }
+    }
     STBA_HIP(hipStreamSynchronize(b->st));
     for (size_t p = 0; p < no; ++p) {   // back to the caller's observation order
         const size_t i = (size_t)b->perm[p];
@@ -1030,7 +1070,7 @@ int stba_ba_solve_reduced(stba_ba* b, double* dxc) {
 int stba_ba_back_substitute(stba_ba* b, double* dxp) {
     if (!b) return fail(STBA_ERR_INVALID_ARGUMENT, "null engine");
     if (!b->have_dxc) return fail(STBA_ERR_STATE, "stba_ba_back_substitute needs stba_ba_solve_reduced first");
-    STBA_TRY(launch_backsub(b->np, b->pt_start, b->obs_cam, b->Jc, b->Jp, b->Hinv6, b->gp, b->dxc, b->dxp, b->st));
+    STBA_TRY(launch_backsub(b->np, b->pt_start, b->obs_cam, b->J8, b->omask, b->Hinv6, b->gp, b->dxc, b->dxp, b->st));
     if (dxp) STBA_TRY(download(dxp, b->dxp, (size_t)b->np * 3, b->st));
     STBA_HIP(hipStreamSynchronize(b->st));
     b->have_dxp = true;
