@@ -429,13 +429,13 @@ __device__ __forceinline__ void diag_block(double* __restrict__ A, int lda, int 
 }
 
 // ------------------------------------------------------------------------------------------
-// Diagonal block, second design ("D2"): everything on the matrix cores, 4 columns per step, no barriers.
+// Diagonal block, second design ("D2"): everything on the matrix cores, 4 columns per step.
 //
 // Measured on MI355X (tools/exp/lat_f64.hip): a dependent v_fma_f64 costs 4.2 cycles (= its issue time), the whole
-// pivot step rsq + Halley + scale + update 50 cycles, a dependent v_mfma_f64_16x16x4 66-81 cycles, an LDS round
-// trip 130-260.  The first design spent 250 cycles per pivot because every row thread factored an 8x8 mini-block
-// redundantly (FP64 latency = issue time, so redundant work IS latency) and because FP64 MFMAs of the SIMD partner
-// stall a wave's FP64 VALU.  Here:
+// pivot step rsq + Halley + scale + update 50 cycles, a dependent v_mfma_f64_16x16x4 66-81 cycles, an LDS write ->
+// barrier -> read hand-off 150-190, a POLLED LDS hand-off 250-500.  The first design spent 250 cycles per pivot
+// because every row thread factored an 8x8 mini-block redundantly (FP64 latency = issue time, so redundant work IS
+// latency) and because FP64 MFMAs of the SIMD partner stall a wave's FP64 VALU.  Here:
 //   * the 128x128 block is 8x8 tiles of 16x16, lower tiles only, each tile in the accumulator layout of
 //     v_mfma_f64_16x16x4_f64 holding the TRANSPOSE: lane (n, g) register r = M[n][4r + g].  Register s of a tile
 //     is then directly the B operand "columns 4s..4s+3 of the tile" (lane (n, g) = M[n][4s + g]).
@@ -446,64 +446,38 @@ __device__ __forceinline__ void diag_block(double* __restrict__ A, int lda, int 
 //                tile = mfma(-l, l, tile)             rank-4 update                (1 MFMA)
 //     Every other tile (I, J') does the same two MFMAs with Gp and the l operands of rows I and J' taken from LDS:
 //     tile(I, J') = mfma(-l_J', l_I, tile(I, J')).
-//   * every Gp and every l has its own slot in LDS, written once (no ring, no back-pressure) and pre-set to a
-//     NaN sentinel: a consumer polls the slot itself, one LDS round trip per operand, no barriers in the loop.
+//   * every Gp and every l has its own slot in LDS, written once.  A step has three phases separated by two
+//     s_barriers: (1) the factor wave makes Gp | (2) every row computes and publishes its l | (3) trailing updates.
+//     The updates of step t overlap the factor wave's VALU work of step t + 1.
 //   * roles (waves w and w + 4 share a SIMD):
-//       waves 0, 1   factor waves for the even / odd tile rows.  While wave 1 factors row J+1's predecessor,
-//                    wave 0 ... i.e. the wave that factors row I next follows the current factor wave through tile
-//                    column I-1 (panel + update of its two tiles (I, I-1), (I, I)), then factors.  Nothing else
-//                    runs FP64 MFMAs on their SIMDs while they factor.
-//       waves 4, 5   their SIMD mates: the inverses of the finished 16x16 diagonal tiles (the same two MFMAs on an
-//                    identity tile; the panel-solve tasks multiply by them) and ALL global stores.
-//       waves 2,3,6,7  bulk: tile rows 7 | 6 | 4,2 | 5,3 through tile column I-2; the two tiles of row I that the
-//                    factor wave needs then migrate to it through LDS, a whole tile column ahead of their use.
-constexpr unsigned long long D2_SENTINEL = 0x7FFDEAD0BEEF0001ull;    // a NaN payload no computation produces
+//       wave 0   the factor wave.  Nothing else runs FP64 MFMAs on its SIMD: wave 4 only moves the finished tile columns
+//                of L from LDS to memory.
+//       wave 1   the FOLLOWER: it carries the two tiles (J+1, J), (J+1, J+1) of the next row through tile column J and
+//                hands the finished diagonal tile to wave 0 through LDS.
+//       waves 5 | 2, 6 | 3, 7   bulk: tile rows {5, 2} | {7}, {3} | {6}, {4} through tile column I-2 (14 MFMAs per step
+//                and SIMD in the first tile column, fewer later); the two tiles of row I that the follower needs then
+//                migrate to it through LDS.  Waves 6 / 7 also compute the inverses of the finished diagonal tiles of the
+//                even / odd rows (the same two MFMAs on an identity tile; the panel-solve tasks multiply by them).
+#ifndef STBA_DIAG_V2
+#define STBA_DIAG_V2 1
+#endif
 struct Diag2Smem {
     double Lsl[36][4][64];          // l operands: tile (I, J) at I(I+1)/2 + J, step s, lane
     double Gp[32][64];              // Gp operands: global step 4J + s, lane
-    double Mig[8][2][4][64];        // tiles (I, I-1) and (I, I) on their way to the factor wave: register r, lane
-    unsigned int abortf;            // a poll gave up (a bug): results are garbage, the caller reports a time-out
+    double Mig[2][2][4][64];        // tiles (I, I-1) and (I, I) of row I on their way to the follower, slot I & 1: register r, lane
+    double Dg[4][64];               // the next diagonal tile on its way from the follower to the factor wave
 };
-
 static_assert(sizeof(Diag2Smem) <= 128 * 1024, "D2 must fit the persistent kernel's LDS");
 
 #ifdef STBA_DIAG_TS
-// event trace: (code, time) per wave; the clock read takes the value it follows as an input, so it cannot move ahead of it
 __device__ long long g_d2_ev[8][160][2];
 __device__ int g_d2_nev[8];
 __device__ __forceinline__ long long d2_clock_after(double dep) { long long c; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(c) : "v"(dep) : "memory"); return c; }
-#define D2EV(code, dep) do { const long long c_ = d2_clock_after(dep); if (lane == 0 && d2_nev < 160) { g_d2_ev[d2_w][d2_nev][0] = (code); g_d2_ev[d2_w][d2_nev][1] = c_; } ++d2_nev; } while (0)
-#define D2EV_DECL(w) int d2_nev = 0; const int d2_w = (w)
-#define D2EV_END() do { if (lane == 0) g_d2_nev[d2_w] = d2_nev; } while (0)
+#define D2EV(code, dep) do { const long long c_ = d2_clock_after(dep); if (lane == 0 && d2_nev < 160) { g_d2_ev[w][d2_nev][0] = (code); g_d2_ev[w][d2_nev][1] = c_; } ++d2_nev; } while (0)
 #else
 #define D2EV(code, dep) do { } while (0)
-#define D2EV_DECL(w) do { } while (0)
-#define D2EV_END() do { } while (0)
 #endif
-#define D2F(I, k) do { } while (0)
 
-// LDS accesses by 32-bit LDS address (low half of the generic pointer), as inline asm: the polls must not be
-// hoisted or merged, and must not wait for this wave's global stores
-__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(size_t)p; }
-__device__ __forceinline__ void lds_store_b32(void* p, unsigned v) { asm volatile("ds_write_b32 %0, %1" :: "v"(lds_addr(p)), "v"(v) : "memory"); }
-__device__ __forceinline__ unsigned long long lds_load_b64(const void* p) {
-    unsigned long long v;
-    asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(lds_addr(p)) : "memory");
-    return v;
-}
-// volatile LDS load through an explicit LDS-address-space pointer: the compiler issues consecutive ones back to back
-// and waits once (s_waitcnt lgkmcnt), which is what the batched polls below need
-typedef const volatile unsigned long long __attribute__((address_space(3))) * lds_cvu64p;
-__device__ __forceinline__ unsigned long long lds_vload_b64(const void* p) { return *(lds_cvu64p)(size_t)lds_addr(p); }
-// this lane's slot, once every lane of the wave sees a published value (a 64-lane LDS store is not atomic)
-__device__ __forceinline__ double d2_take(const double* slot, unsigned int* abortf) {
-    for (int spin = 0;; ++spin) {
-        const unsigned long long v = lds_load_b64(slot);
-        if (__builtin_amdgcn_ballot_w64(v == D2_SENTINEL) == 0ull) return __longlong_as_double((long long)v);
-        if (spin > (1 << 21)) { lds_store_b32(abortf, 1u); return 0.0; }
-        __builtin_amdgcn_s_sleep(1);
-    }
-}
 __device__ __forceinline__ double readlane_f64(double x, int lane) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(x), lane), hi = __builtin_amdgcn_readlane(__double2hiint(x), lane);
     return __hiloint2double(hi, lo);
@@ -528,10 +502,9 @@ __device__ __forceinline__ double4v d2_load_tile(const double* __restrict__ Ab, 
 
 // final L tile (I, J): LDS slots -> global, 32 contiguous bytes per lane (lane (n, g') writes L[n][4g' .. 4g'+3])
 template <bool WT>
-__device__ __forceinline__ void d2_store_tile(double* __restrict__ A, int lda, int k0, Diag2Smem& sm, int I, int J, int lane) {
+__device__ __forceinline__ void d2_store_tile(double* __restrict__ A, int lda, int k0, const Diag2Smem& sm, int I, int J, int lane) {
     const int n = lane & 15, gq = lane >> 4;
     const int tix = d2_tix(I, J);
-    (void)d2_take(&sm.Lsl[tix][3][lane], &sm.abortf);        // the tile's last step is published (the earlier ones then are, too)
     double4v v;
 #pragma unroll
     for (int gg = 0; gg < 4; ++gg) {
@@ -541,89 +514,7 @@ __device__ __forceinline__ void d2_store_tile(double* __restrict__ A, int lda, i
     gst4<WT>(A + (size_t)(k0 + 16 * I + n) * lda + k0 + 16 * J + 4 * gq, v);
 }
 
-// one 4-column step (tile column J, step s) of a row that is not being factored.  The row's tiles sit in a shift
-// register: acc[0] is tile (I, J) of the CURRENT tile column, acc[k] is tile (I, J + k), cnt = I - J of them are live
-// (the registers are shifted down after every tile column, so the code is the same for every J and every row: the
-// whole task must fit the instruction cache).  Panel value of tile (I, J), then the rank-4 update of the live tiles
-// and of the diagonal tile.  The l operands of the rows above are requested from LDS together and awaited once
-// (one round trip, not one per tile: an LDS round trip costs 130-260 cycles).
-// part 1: panel value, published at once (nobody's l waits for another l), and the update of the diagonal tile
-template <int NT>
-__device__ __forceinline__ double d2_row_panel(Diag2Smem& sm, int I, int J, int s, double gp, const double4v (&acc)[NT], double4v& accD, int lane) {
-    const double l = mfma_l(gp, acc[0][s]);
-    sm.Lsl[d2_tix(I, J)][s][lane] = l;
-    accD = __builtin_amdgcn_mfma_f64_16x16x4f64(-l, l, accD, 0, 0, 0);
-    return l;
-}
-// part 2: the l operands of the rows above, then the rank-4 updates of the live tiles
-template <int NT>
-__device__ __forceinline__ void d2_row_update(Diag2Smem& sm, int I, int J, int s, double l, double4v (&acc)[NT], int lane) {
-    const int cnt = I - J;
-    const int k0 = (s == 3) ? 1 : 0;            // (the finished tile needs no last update)
-    unsigned long long lj[NT];
-    for (int spin = 0;; ++spin) {
-        bool missing = false;
-#pragma unroll
-        for (int k = 0; k < NT; ++k)
-            if (k >= k0 && k < cnt) lj[k] = lds_vload_b64(&sm.Lsl[d2_tix(J + k, J)][s][lane]);
-#pragma unroll
-        for (int k = 0; k < NT; ++k)
-            if (k >= k0 && k < cnt) missing = missing || (lj[k] == D2_SENTINEL);
-        if (__builtin_amdgcn_ballot_w64(missing) == 0ull) break;
-        if (spin > (1 << 21)) { lds_store_b32(&sm.abortf, 1u); break; }
-        __builtin_amdgcn_s_sleep(1);
-    }
-#pragma unroll
-    for (int k = 0; k < NT; ++k)
-        if (k >= k0 && k < cnt)
-            acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(-__longlong_as_double((long long)lj[k]), l, acc[k], 0, 0, 0);
-}
-
-// bulk wave: tile rows RA and RB (RB < 0: none; RB < RA) through tile column row-2, then the hand-over of the two
-// tiles (I, I-1), (I, I) to the factor wave.  One code path for all four bulk waves (the rows are run-time values).
-__device__ __forceinline__ void d2_bulk_wave(const double* __restrict__ Ab, int lda, Diag2Smem& sm, int lane, int RA, int RB, int wave_id) {
-    const int n = lane & 15, g = lane >> 4;
-    double4v accA[7], accAD, accB[3], accBD;
-#pragma unroll
-    for (int J = 0; J < 7; ++J) if (J < RA) accA[J] = d2_load_tile(Ab, lda, RA, J, n, g);
-    accAD = d2_load_tile(Ab, lda, RA, RA, n, g);
-#pragma unroll
-    for (int J = 0; J < 3; ++J) if (J < RB) accB[J] = d2_load_tile(Ab, lda, RB, J, n, g);
-    if (RB > 0) accBD = d2_load_tile(Ab, lda, RB, RB, n, g);
-    __syncthreads();                       // the slots carry their sentinels
-    D2EV_DECL(wave_id);
-    D2EV(900, accAD[0]);
-#pragma unroll 1
-    for (int J = 0; J <= RA - 2; ++J) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const double gp = d2_take(&sm.Gp[4 * J + s][lane], &sm.abortf);
-            D2EV(100 + 4 * J + s, gp);
-            const bool hasB = J <= RB - 2;
-            double lB = 0.0;
-            if (hasB) lB = d2_row_panel<3>(sm, RB, J, s, gp, accB, accBD, lane);
-            const double lA = d2_row_panel<7>(sm, RA, J, s, gp, accA, accAD, lane);
-            if (hasB) d2_row_update<3>(sm, RB, J, s, lB, accB, lane);                   // (the row that is needed sooner first)
-            d2_row_update<7>(sm, RA, J, s, lA, accA, lane);
-            D2EV(200 + 4 * J + s, accAD[0]);
-        }
-        if (J == RB - 2) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { sm.Mig[RB][0][r][lane] = accB[1][r]; sm.Mig[RB][1][r][lane] = accBD[r]; }
-        }
-#pragma unroll
-        for (int k = 0; k < 6; ++k) accA[k] = accA[k + 1];
-#pragma unroll
-        for (int k = 0; k < 2; ++k) accB[k] = accB[k + 1];
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { sm.Mig[RA][0][r][lane] = accA[0][r]; sm.Mig[RA][1][r][lane] = accAD[r]; }
-    D2EV(999, accAD[0]);
-    D2EV_END();
-    (void)wave_id;
-}
-
-// one factor step on the diagonal tile accD (see above): pivot block s -> Gp operand, panel values l, rank-4 update
+// one factor step on the diagonal tile accD (see above): pivot block s -> Gp operand
 __device__ __forceinline__ double d2_factor_gp(const double4v& accD, int s, const double (&mk)[10], int& badv, int col0, int n_real) {
     const double b = accD[s];
     // the 4x4 pivot block M[4s+a][4s+c] sits in lane (n = 4s+a, g = c), register s
@@ -657,19 +548,23 @@ __device__ __forceinline__ double d2_factor_gp(const double4v& accD, int s, cons
     gp = fma(mk[9], y3, gp);
     return gp;
 }
-__device__ __forceinline__ double d2_factor_update(double4v& accD, int s, double gp) {
-    const double l = mfma_l(gp, accD[s]);
-    if (s < 3) accD = __builtin_amdgcn_mfma_f64_16x16x4f64(-l, l, accD, 0, 0, 0);
-    return l;
-}
 
-// factor wave F (0: even rows, 1: odd rows); one code path for both
+// Every role runs the same schedule of barriers: ONE per 4-column step.  Behind barrier t = (tile column J, step s):
+//   * the factor wave, whose Gp(t) was published before the barrier, computes its panel values l(t), updates its
+//     tile and goes straight on to the pivot block of step t + 1 (published before barrier t + 1);
+//   * every other row first applies the rank-4 update of step t - 1 (all its operands were published before this
+//     barrier), then computes and publishes l(t) = mfma(Gp(t), tile.reg[s]).
+// So the updates run one step behind, no wave ever needs a second barrier inside a step, and the factor wave's
+// chain per step is: panel MFMA, update MFMA, pivot block on the VALU, one LDS store, one barrier.
+// (One function per role: their registers are allocated independently; a single loop with all roles inside needed
+// 256 registers and spilled.)
+#define D2_BARRIER() lds_barrier()      // LDS traffic only: a wave's global stores must not hold the barrier up
+
+// the factor wave
 __device__ __forceinline__ void d2_factor_wave(const double* __restrict__ Ab, int lda, int k0, int n_real, int* __restrict__ flag,
-                                               Diag2Smem& sm, int lane, int F) {
+                                               Diag2Smem& sm, int lane, long long* ph) {
     const int n = lane & 15, g = lane >> 4;
-    double4v accS, accD;
-    accD = d2_load_tile(Ab, lda, F, F, n, g);
-    accS = d2_load_tile(Ab, lda, 1, 0, n, g);          // (only the odd wave uses it)
+    double4v accD = d2_load_tile(Ab, lda, 0, 0, n, g);
     double mk[10];          // 0/1 weights of the ten entries of the 4x4 inverse for this lane's operand slot
     {
         const int idx = (n < 4 && g <= n) ? n * (n + 1) / 2 + g : -1;
@@ -677,87 +572,208 @@ __device__ __forceinline__ void d2_factor_wave(const double* __restrict__ Ab, in
         for (int e = 0; e < 10; ++e) mk[e] = (idx == e) ? 1.0 : 0.0;
     }
     int badv = 0;
-    __syncthreads();                       // the slots carry their sentinels
-    D2EV_DECL(F);
-    D2EV(900, accD[0]);
+#ifdef STBA_DIAG_TS
+    int d2_nev = 0; const int w = 0;
+#endif
+    double gp = d2_factor_gp(accD, 0, mk, badv, k0, n_real);
+    sm.Gp[0][lane] = gp;
+    if (ph && lane == 0) ph[1] = wall_clock64();
 #pragma unroll 1
-    for (int k = 0; k < 4; ++k) {
-        const int I = F + 2 * k;
-        if (I >= 2) {                      // the two tiles of this row arrive from the bulk wave that carried them so far
-            unsigned long long m[8];
-            for (int spin = 0;; ++spin) {
-                bool missing = false;
-#pragma unroll
-                for (int r = 0; r < 8; ++r) m[r] = lds_vload_b64(&sm.Mig[I][r >> 2][r & 3][lane]);
-#pragma unroll
-                for (int r = 0; r < 8; ++r) missing = missing || (m[r] == D2_SENTINEL);
-                if (__builtin_amdgcn_ballot_w64(missing) == 0ull) break;
-                if (spin > (1 << 21)) { lds_store_b32(&sm.abortf, 1u); break; }
-                __builtin_amdgcn_s_sleep(1);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { accS[r] = __longlong_as_double((long long)m[r]); accD[r] = __longlong_as_double((long long)m[4 + r]); }
-            D2EV(300 + I, accD[0]);
-        }
-        if (I >= 1) {                      // follow the other factor wave through tile column I-1
-            const int J = I - 1;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const double gp = d2_take(&sm.Gp[4 * J + s][lane], &sm.abortf);
-                const double l = mfma_l(gp, accS[s]);
-                sm.Lsl[d2_tix(I, J)][s][lane] = l;
-                accD = __builtin_amdgcn_mfma_f64_16x16x4f64(-l, l, accD, 0, 0, 0);
-                if (s < 3) {
-                    const double lj = d2_take(&sm.Lsl[d2_tix(J, J)][s][lane], &sm.abortf);
-                    accS = __builtin_amdgcn_mfma_f64_16x16x4f64(-lj, l, accS, 0, 0, 0);
-                }
-                D2EV(400 + 4 * J + s, accD[0]);
-            }
-        }
-        // ---- factor the diagonal tile (I, I)
+    for (int J = 0; J < 8; ++J) {
+        if (ph && lane == 0 && (J == 1 || J == 4)) ph[J == 1 ? 2 : 3] = wall_clock64();
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const double gp = d2_factor_gp(accD, s, mk, badv, k0 + 16 * I + 4 * s, n_real);
-            sm.Gp[4 * I + s][lane] = gp;
-            const double l = d2_factor_update(accD, s, gp);
-            sm.Lsl[d2_tix(I, I)][s][lane] = l;
-            D2EV(500 + 4 * I + s, l);
+            const int tt = 4 * J + s;
+            D2_BARRIER();
+            D2EV(200 + tt, gp);
+            const double l = mfma_l(gp, accD[s]);
+            sm.Lsl[d2_tix(J, J)][s][lane] = l;
+            if (s < 3) {
+                accD = __builtin_amdgcn_mfma_f64_16x16x4f64(-l, l, accD, 0, 0, 0);
+                gp = d2_factor_gp(accD, s + 1, mk, badv, k0 + 16 * J + 4 * (s + 1), n_real);
+                sm.Gp[tt + 1][lane] = gp;
+                D2EV(100 + tt + 1, gp);
+            }
+        }
+        if (J < 7) {
+            D2_BARRIER();                               // X: the follower has published the next diagonal tile
+#pragma unroll
+            for (int r = 0; r < 4; ++r) accD[r] = sm.Dg[r][lane];
+            gp = d2_factor_gp(accD, 0, mk, badv, k0 + 16 * (J + 1), n_real);
+            sm.Gp[4 * J + 4][lane] = gp;
+            D2EV(100 + 4 * J + 4, gp);
         }
     }
-    D2EV_END();
+    D2_BARRIER();                                       // (the panel values of the last step are published)
     if (badv != 0 && lane == 0) atomicCAS(flag, 0, badv);
+#ifdef STBA_DIAG_TS
+    if (lane == 0) g_d2_nev[w] = d2_nev;
+#endif
 }
 
-// mate of factor wave F: inverse of every finished diagonal tile of its rows (the same two MFMAs on an identity
-// tile below it: its panel values are X = L_II^-T, lane (n, g) of step s = X[n][4s+g] = Inv[4s+g][n]), and the
-// global stores of the tile columns J = F, F+2, ..
-template <bool WT>
-__device__ __forceinline__ void d2_mate_wave(double* __restrict__ A, int lda, int k0, double* __restrict__ dinv, Diag2Smem& sm, int lane, int F) {
+// the follower: row J + 1 through tile column J
+__device__ __forceinline__ void d2_follower_wave(const double* __restrict__ Ab, int lda, Diag2Smem& sm, int lane) {
     const int n = lane & 15, g = lane >> 4;
-    __syncthreads();                       // the slots carry their sentinels
-    D2EV_DECL(4 + F);
+    double4v accS = d2_load_tile(Ab, lda, 1, 0, n, g), accD = d2_load_tile(Ab, lda, 1, 1, n, g);
+    double lprev = 0.0;
 #pragma unroll 1
-    for (int k = 0; k < 4; ++k) {
-        const int I = F + 2 * k;
-        double4v accE;
+    for (int J = 0; J < 8; ++J) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int tt = 4 * J + s;
+            D2_BARRIER();
+            if (J < 7) {
+                if (s == 0 && J >= 1) {
+                    // the two tiles of row J + 1 arrive from the bulk wave that carried them, with every update but the
+                    // last one of the previous tile column: that one is applied here (lprev: row J's values of step
+                    // (J-1, 3), this wave's own)
+                    const double li = sm.Lsl[d2_tix(J + 1, J - 1)][3][lane];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { accS[r] = sm.Mig[(J + 1) & 1][0][r][lane]; accD[r] = sm.Mig[(J + 1) & 1][1][r][lane]; }
+                    accS = __builtin_amdgcn_mfma_f64_16x16x4f64(-lprev, li, accS, 0, 0, 0);
+                    accD = __builtin_amdgcn_mfma_f64_16x16x4f64(-li, li, accD, 0, 0, 0);
+                }
+                if (s >= 1) accS = __builtin_amdgcn_mfma_f64_16x16x4f64(-sm.Lsl[d2_tix(J, J)][s - 1][lane], lprev, accS, 0, 0, 0);
+                const double l = mfma_l(sm.Gp[tt][lane], accS[s]);
+                sm.Lsl[d2_tix(J + 1, J)][s][lane] = l;
+                accD = __builtin_amdgcn_mfma_f64_16x16x4f64(-l, l, accD, 0, 0, 0);
+                lprev = l;
+                if (s == 3) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sm.Dg[r][lane] = accD[r];
+                }
+            }
+        }
+        if (J < 7) D2_BARRIER();                        // X
+    }
+    D2_BARRIER();
+}
+
+// Bulk rows.  A wave carries ONE tile row R with its tiles indexed by their distance from the diagonal: acc[d] = tile
+// (R, R - d).  In tile column J = R - C the live tiles are d = 0 .. C and the leading tile is acc[C]: with C a template
+// parameter every register index is static, so a tile column is straight-line code with C + 2 MFMAs per step and not
+// one branch; the code of the columns C = 7 .. 2 is shared by all rows (row R enters at C = R and leaves after C = 2,
+// when its last two tiles migrate to the follower).  Per step, behind the barrier:
+//   * all LDS operands are fetched in one batch (the loads must not sit behind the wave's own LDS stores, which the
+//     compiler cannot tell apart from them);
+//   * the LEADING tile gets the previous step's update first, and the row's panel values of this step are published
+//     at once (every row below waits for them at the next barrier);
+//   * then the rest of the previous step's update (nothing waits for it before the next step).
+template <int C>
+__device__ __forceinline__ void d2_bulk_column(Diag2Smem& sm, int R, double4v (&acc)[8], double& lprev, int lane) {
+    const int J = R - C;
+    // LDS slots of the operands: l of row R - d in the current tile column (for steps 1..3) and in the previous one
+    const double* ljp[C + 1];
+#pragma unroll
+    for (int d = 1; d <= C; ++d) ljp[d] = &sm.Lsl[d2_tix(R - d, J)][0][lane];
+    double* mine = &sm.Lsl[d2_tix(R, J)][0][lane];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        D2_BARRIER();
+        const bool upd = s > 0 || J > 0;        // (the very first step has no previous one)
+        double lj[C + 1];
+        const double gp = sm.Gp[4 * J + s][lane];
+        if (upd) {
+#pragma unroll
+            for (int d = C; d >= 1; --d) lj[d] = (s > 0) ? ljp[d][(s - 1) * 64] : ljp[d][3 * 64 - 4 * 64];   // (previous column: one tile slot back)
+            acc[C] = __builtin_amdgcn_mfma_f64_16x16x4f64(-lj[C], lprev, acc[C], 0, 0, 0);
+        }
+        const double l = mfma_l(gp, acc[C][s]);
+        mine[s * 64] = l;
+        if (s == 3) D2_BARRIER();               // X (early: the factor wave works on the next pivot block meanwhile)
+        if (upd) {
+#pragma unroll
+            for (int d = C - 1; d >= 1; --d) acc[d] = __builtin_amdgcn_mfma_f64_16x16x4f64(-lj[d], lprev, acc[d], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(-lprev, lprev, acc[0], 0, 0, 0);
+        }
+        lprev = l;
+    }
+    if (C == 2) {
+        // the row's last bulk column: its two remaining tiles leave for the follower WITHOUT the update of step 3, which
+        // the follower applies itself
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { sm.Mig[R & 1][0][r][lane] = acc[1][r]; sm.Mig[R & 1][1][r][lane] = acc[0][r]; }
+    }
+}
+
+// tile row R (2 .. 7) through the tile columns 0 .. R - 2; R + 1 barriers short of ... no: 5 barriers per tile column
+__device__ __forceinline__ void d2_bulk_row(const double* __restrict__ Ab, int lda, Diag2Smem& sm, int lane, int R) {
+    const int n = lane & 15, g = lane >> 4;
+    double4v acc[8];
+#pragma unroll
+    for (int d = 0; d < 8; ++d) if (d <= R) acc[d] = d2_load_tile(Ab, lda, R, R - d, n, g);
+    double lprev = 0.0;
+    switch (R) {
+        case 7: d2_bulk_column<7>(sm, R, acc, lprev, lane); [[fallthrough]];
+        case 6: d2_bulk_column<6>(sm, R, acc, lprev, lane); [[fallthrough]];
+        case 5: d2_bulk_column<5>(sm, R, acc, lprev, lane); [[fallthrough]];
+        case 4: d2_bulk_column<4>(sm, R, acc, lprev, lane); [[fallthrough]];
+        case 3: d2_bulk_column<3>(sm, R, acc, lprev, lane); [[fallthrough]];
+        default: d2_bulk_column<2>(sm, R, acc, lprev, lane);
+    }
+}
+
+// bulk wave: its row, then -- idle otherwise -- the inverses of finished diagonal tiles: the same two MFMAs on an identity
+// tile below the diagonal tile; its panel values are X = L^-T, lane (n, g) of step s = X[n][4s+g] = Inv[4s+g][n].
+// einv 0: the inverse of row J - 1 during every tile column J the wave is idle in (rows 1 .. 6 for tile row 3);
+// einv 1: row 0 during the first idle column, row 7 at the end.
+template <bool WT>
+__device__ __forceinline__ void d2_bulk_wave(const double* __restrict__ Ab, int lda, Diag2Smem& sm, int lane, int R, int einv,
+                                             double* __restrict__ dinv) {
+    const int n = lane & 15, g = lane >> 4;
+    d2_bulk_row(Ab, lda, sm, lane, R);
+    double4v accE;
+    auto inverse_step = [&](int I, int s) {
+        const double le = mfma_l(sm.Gp[4 * I + s][lane], accE[s]);
+        gst<WT>(&dinv[(I * 16 + 4 * s + g) * 16 + n], le);
+        if (s < 3) accE = __builtin_amdgcn_mfma_f64_16x16x4f64(-sm.Lsl[d2_tix(I, I)][s][lane], le, accE, 0, 0, 0);
+    };
+#pragma unroll 1
+    for (int J = R - 1; J < 8; ++J) {
+        const int Ie = einv == 0 ? J - 1 : (einv == 1 && J == R - 1) ? 0 : -1;
+        if (Ie >= 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) accE[r] = (n == 4 * r + g) ? 1.0 : 0.0;
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            D2_BARRIER();
+            if (Ie >= 0) inverse_step(Ie, s);
+        }
+        if (J < 7) D2_BARRIER();                        // X
+    }
+    D2_BARRIER();
+    if (einv == 1) {                            // the last diagonal tile's inverse (row 7)
 #pragma unroll
         for (int r = 0; r < 4; ++r) accE[r] = (n == 4 * r + g) ? 1.0 : 0.0;
 #pragma unroll
+        for (int s = 0; s < 4; ++s) inverse_step(7, s);
+    }
+}
+
+// wave 4, the SIMD mate of the factor wave: tile row 2 during the first tile column (4 MFMAs per step next to the
+// factor wave, which is not the bottleneck there), then all global stores of L.  The tile column finished one column
+// ago goes to memory two tiles per step (all at once would make this wave late for the next barrier, and every wave
+// waits there).
+template <bool WT>
+__device__ __forceinline__ void d2_store_wave(double* __restrict__ A, const double* __restrict__ Ab, int lda, int k0, Diag2Smem& sm, int lane) {
+    d2_bulk_row(Ab, lda, sm, lane, 2);
+#pragma unroll 1
+    for (int J = 1; J < 8; ++J) {
+#pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const double gp = d2_take(&sm.Gp[4 * I + s][lane], &sm.abortf);
-            const double le = mfma_l(gp, accE[s]);
-            gst<WT>(&dinv[(I * 16 + 4 * s + g) * 16 + n], le);
-            if (s < 3) {
-                const double li = d2_take(&sm.Lsl[d2_tix(I, I)][s][lane], &sm.abortf);
-                accE = __builtin_amdgcn_mfma_f64_16x16x4f64(-li, le, accE, 0, 0, 0);
+            D2_BARRIER();
+            // (behind barrier (J, 0) every panel value of tile column J - 1 has been published)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int Ip = (J - 1) + 2 * s + h;
+                if (Ip < 8) d2_store_tile<WT>(A, lda, k0, sm, Ip, J - 1, lane);
             }
         }
-        D2EV(600 + I, accE[0]);
-#pragma unroll 1
-        for (int Ip = I; Ip < 8; ++Ip) d2_store_tile<WT>(A, lda, k0, sm, Ip, I, lane);      // tile column I
-        D2EV(700 + I, accE[0]);
+        if (J < 7) D2_BARRIER();                        // X
     }
-    D2EV_END();
+    D2_BARRIER();
+    d2_store_tile<WT>(A, lda, k0, sm, 7, 7, lane);      // the last tile column
 }
 
 // all 512 threads of the workgroup; smem = sizeof(Diag2Smem); ends with the results in flight to global memory
@@ -769,18 +785,11 @@ __device__ __forceinline__ void diag_block2(double* __restrict__ A, int lda, int
     Diag2Smem& sm = *reinterpret_cast<Diag2Smem*>(smem);
     const int w = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
     const double* Ab = A + (size_t)k0 * lda + k0;
-    // sentinels (the global loads of the tiles are issued first by every role, so this hides behind them)
-    {
-        unsigned long long* p = reinterpret_cast<unsigned long long*>(smem);
-        constexpr int NSENT = (int)((sizeof(double) * (36 * 4 * 64 + 32 * 64 + 8 * 2 * 4 * 64)) / 8);
-        for (int e = t; e < NSENT; e += 512) p[e] = D2_SENTINEL;
-        if (t == 0) sm.abortf = 0u;
-    }
-    if (w < 2) d2_factor_wave(Ab, lda, k0, n_real, flag, sm, lane, w);
-    else if (w == 4 || w == 5) d2_mate_wave<WT>(A, lda, k0, dinv, sm, lane, w - 4);
-    else d2_bulk_wave(Ab, lda, sm, lane, w == 2 ? 7 : w == 3 ? 6 : w == 6 ? 4 : 5, w == 6 ? 2 : w == 7 ? 3 : -1, w);
-    PHASE_STAMP(1);
-    if (lane == 0 && sm.abortf != 0u) atomicExch(flag, CHOL_FLAG_TIMEOUT);
+    PHASE_STAMP(0);
+    if (w == 0) d2_factor_wave(Ab, lda, k0, n_real, flag, sm, lane, ph);
+    else if (w == 1) d2_follower_wave(Ab, lda, sm, lane);
+    else if (w == 4) d2_store_wave<WT>(A, Ab, lda, k0, sm, lane);
+    else d2_bulk_wave<WT>(Ab, lda, sm, lane, w == 5 ? 5 : w == 2 ? 7 : w == 6 ? 3 : w == 3 ? 6 : 4, w == 6 ? 0 : w == 7 ? 1 : -1, dinv);
 }
 
 // (warm_k0 >= 0: the task is first run on another diagonal block of the matrix, so that the timed run finds its code
@@ -1533,7 +1542,11 @@ __global__ __launch_bounds__(512) void chol_mega_kernel(MegaArgs a) {
         double* li = a.linv + (size_t)b * a.linv_stride;
         long long* ph = a.trace ? a.trace + 8 * (size_t)task + 4 : nullptr;
         if (type == TASK_D) {
+#if STBA_DIAG_V2
+            diag_block2<true>(a.A, a.lda, k0, a.n, a.flag, li + NB * NB, smem, tt, ph);
+#else
             diag_block<true>(a.A, a.lda, k0, a.n, a.flag, li + NB * NB, smem, tt, ph);
+#endif
         } else if (type == TASK_T) {
             const int lane = tt & 63, w = tt >> 6;
             int ldr;

@@ -6,103 +6,7 @@
 #include <vector>
 #include "../../slam-tricks_amd/csrc/dense_chol.hip"
 namespace stba { thread_local std::string g_last_error; }
-// ---- micro-kernels: the factor wave alone, and factor wave + follower, on synthetic tiles (timing only)
-namespace stba {
-__device__ __forceinline__ long long mk_clock(double dep) { long long c; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(c) : "v"(dep) : "memory"); return c; }
-__global__ __launch_bounds__(512) void d2_micro_kernel(long long* out, int mode) {
-    extern __shared__ __attribute__((aligned(16))) double sm2[];
-    Diag2Smem& sm = *reinterpret_cast<Diag2Smem*>(sm2);
-    const int t = threadIdx.x, w = t >> 6, lane = t & 63, n = lane & 15, g = lane >> 4;
-    {
-        unsigned long long* p = reinterpret_cast<unsigned long long*>(sm2);
-        constexpr int NSENT = 36 * 4 * 64 + 32 * 64 + 8 * 2 * 4 * 64;
-        for (int e = t; e < NSENT; e += 512) p[e] = D2_SENTINEL;
-        if (t == 0) sm.abortf = 0u;
-    }
-    __syncthreads();
-    double mk[10];
-    { const int idx = (n < 4 && g <= n) ? n * (n + 1) / 2 + g : -1;
-#pragma unroll
-      for (int e = 0; e < 10; ++e) mk[e] = (idx == e) ? 1.0 : 0.0; }
-    int badv = 0;
-    if (w == 0) {
-        // factor wave: 8 well-conditioned diagonal tiles in a row (fresh tile per row, as after a hand-over)
-        double chk = 0.0;
-        long long t0 = mk_clock(chk), tt[9];
-        tt[0] = t0;
-#pragma unroll
-        for (int I = 0; I < 8; ++I) {
-            double4v accD;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) accD[r] = ((n == 4 * r + g) ? 50.0 + I : 0.01 * (n + 4 * r + g)) + chk * 1e-30;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const double gp = d2_factor_gp(accD, s, mk, badv, 0, 1 << 30);
-                sm.Gp[4 * I + s][lane] = gp;
-                const double l = d2_factor_update(accD, s, gp);
-                sm.Lsl[d2_tix(I, I)][s][lane] = l;
-                chk += l;
-            }
-            tt[I + 1] = mk_clock(chk);
-        }
-        if (lane == 0) { for (int I = 0; I < 9; ++I) out[I] = tt[I] - t0; out[20] = (long long)chk + badv; }
-    } else if (w == 1 && mode >= 1) {
-        // follower: for every tile column J the two tiles of row J+1
-        double chk = 0.0;
-        long long tt[9];
-        tt[0] = mk_clock(chk);
-#pragma unroll
-        for (int J = 0; J < 8; ++J) {
-            double4v accS, accD;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { accS[r] = 0.01 * (n - g + r) + chk * 1e-30; accD[r] = (n == 4 * r + g) ? 60.0 : 0.02; }
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const double gp = d2_take(&sm.Gp[4 * J + s][lane], &sm.abortf);
-                const double l = mfma_l(gp, accS[s]);
-                sm.Lsl[d2_tix(7, J == 7 ? 6 : J)][s][lane] = l;       // (any free slot: row 7's)
-                accD = __builtin_amdgcn_mfma_f64_16x16x4f64(-l, l, accD, 0, 0, 0);
-                if (s < 3) {
-                    const double lj = d2_take(&sm.Lsl[d2_tix(J, J)][s][lane], &sm.abortf);
-                    accS = __builtin_amdgcn_mfma_f64_16x16x4f64(-lj, l, accS, 0, 0, 0);
-                }
-            }
-            chk += accD[0] + accD[1] + accD[2] + accD[3];
-            tt[J + 1] = mk_clock(chk);
-        }
-        if (lane == 0) { for (int I = 0; I < 9; ++I) out[32 + I] = tt[I]; out[52] = (long long)chk; }
-    } else if (mode >= 2 && w >= 2) {
-        // pollers: the other six waves poll a slot that is published last (LDS polling traffic as in the real task)
-        (void)d2_take(&sm.Lsl[d2_tix(7, 7)][3][lane], &sm.abortf);
-    }
-    if (w == 0 && lane == 0) out[31] = 0;
-}
-}
 int main() {
-    {
-        long long* out; hipMalloc((void**)&out, 64 * 8);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(stba::d2_micro_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-        for (int mode = 0; mode < 3; ++mode) {
-            long long h[64];
-            for (int rep = 0; rep < 2; ++rep) {
-                hipMemset(out, 0, 64 * 8);
-                hipLaunchKernelGGL(stba::d2_micro_kernel, dim3(1), dim3(512), sizeof(stba::Diag2Smem) + 64, 0, out, mode);
-                hipDeviceSynchronize();
-            }
-            hipMemcpy(h, out, sizeof h, hipMemcpyDeviceToHost);
-            printf("micro mode %d (0: factor wave alone, 1: + follower, 2: + six pollers): factor-wave cycles per tile:", mode);
-            for (int I = 0; I < 8; ++I) printf(" %lld", h[I + 1] - h[I]);
-            printf("  total %lld\n", h[8]);
-            if (mode >= 1) {
-                printf("   follower column end minus factor-wave tile end:");
-                // both clocks are s_memtime: compare absolute values (factor wave's t0 unknown here -> print follower deltas)
-                for (int J = 0; J < 8; ++J) printf(" %lld", h[32 + J + 1] - h[32 + J]);
-                printf("\n");
-            }
-        }
-        hipFree(out);
-    }
-
     const int lda = 1024, n = 1000;
     std::vector<double> h((size_t)lda * lda, 0.0);
     // SPD-ish 128x128 leading block: diagonally dominant with structure
@@ -160,14 +64,22 @@ int main() {
         static long long ev[8][160][2]; int nev[8];
         hipMemcpyFromSymbol(ev, HIP_SYMBOL(stba::g_d2_ev), sizeof ev);
         hipMemcpyFromSymbol(nev, HIP_SYMBOL(stba::g_d2_nev), sizeof nev);
-        long long t0 = 1LL << 62;
-        for (int w = 0; w < 8; ++w) for (int k = 0; k < nev[w] && k < 160; ++k) t0 = ev[w][k][1] < t0 ? ev[w][k][1] : t0;
-        printf("event trace (cycles since the first event).  codes: 900 start, 1xx bulk got Gp(step), 2xx bulk step done, 999 bulk handed over,\n"
-               "  3II migrated tiles of row II received, 4xx follower step done, 5xx factor step done (l there), 6II inverse tile of row II done, 7II tile column stored\n");
-        for (int w = 0; w < 8; ++w) {
-            printf("wave %d:", w);
-            for (int k = 0; k < nev[w] && k < 160; ++k) printf(" %lld@%lld", ev[w][k][0], ev[w][k][1] - t0);
-            printf("\n");
+        // merge the two factor waves: per step tt: Gp made (1tt), behind the barrier (2tt)
+        long long T[33][2] = {{0}}, t0 = 1LL << 62;
+        for (int w = 0; w < 2; ++w) for (int k = 0; k < nev[w] && k < 160; ++k) {
+            const long long c = ev[w][k][0];
+            if (c >= 100 && c < 300) T[c % 100][c / 100 - 1] = ev[w][k][1];
+            if (ev[w][k][1] < t0) t0 = ev[w][k][1];
+        }
+        printf("factor chain (cycles): step | Gp made -> behind the barrier | barrier -> next Gp made\n");
+        for (int tt = 1; tt < 32; ++tt) printf(" %2d | %5lld | %5lld\n", tt, T[tt][1] - T[tt][0], tt < 31 ? T[tt + 1][0] - T[tt][1] : 0LL);
+        printf("chain total %lld cycles\n", T[31][1] - T[1][0]);
+        // bulk waves: per step, relative to the factor wave's time behind the barrier: behind the barrier | updates done | step done
+        for (int w : {2, 6, 5}) {
+            printf("bulk wave %d: step | behind barrier | updates done | step done   (relative to the factor wave behind the barrier)\n", w);
+            long long B[32][3] = {{0}};
+            for (int k = 0; k < nev[w] && k < 160; ++k) { const long long c = ev[w][k][0]; if (c >= 300 && c < 600) B[c % 100][c / 100 - 3] = ev[w][k][1]; }
+            for (int tt = 0; tt < 12; ++tt) printf(" %2d | %5lld | %5lld | %5lld\n", tt, B[tt][0] - T[tt][1], B[tt][1] - T[tt][1], B[tt][2] - T[tt][1]);
         }
     }
 #endif

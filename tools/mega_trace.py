@@ -24,7 +24,7 @@ for ty in range(6):
         wait = (tr[m, 2] - tr[m, 1]) / 100.0
         run = (tr[m, 3] - tr[m, 2]) / 100.0
         print(f"{names[ty]:3s} n={m.sum():6d} wait mean {wait.mean():7.2f} us (sum {wait.sum()/1e3:8.2f} ms)  run mean {run.mean():7.2f} med {np.median(run):7.2f} max {run.max():7.2f} (sum {run.sum()/1e3:8.2f} ms)")
-for ty, nph in ((0, 2), (1, 3), (2, 3), (4, 2), (5, 3)):
+for ty, nph in ((0, 4), (1, 3), (2, 3), (4, 2), (5, 3)):
     m = tasks[:, 0] == ty
     if m.any():
         prev = tr[m, 2]
