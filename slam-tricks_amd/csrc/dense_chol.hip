@@ -1057,15 +1057,17 @@ struct MegaArgs {
     double* A; int lda; int n; int nblk;
     const int4* tasks;      // the per-XCD queues, concatenated
     int nq;                 // number of queues (= XCDs seen by the probe)
-    int qstart[17];         // queue q holds tasks [qstart[q], qstart[q+1])
+    int qstart[17];         // queue q holds tasks [qstart[q], qstart[q+1]): first its bulk tasks, taken in order, ...
+    int hstart[16];         // ... then, from hstart[q] on, its URGENT tasks (the critical chains), taken as soon as they are ready
     signed char xcc_queue[16];   // HW_REG_XCC_ID -> queue
-    int* sync;              // [0..16) tickets, [16] abort, then dflag[nblk], tuflag[nblk], tflag[nblk*nrow], ver[nrow*nblk], nrow = nblk + 4 nwide
+    int* sync;              // [0..16) tickets, [16] abort, [17..33) heads of the urgent lists, [33..49) their hint words, then dflag[nblk], tuflag[nblk],
+                            // tflag[nblk*nrow], ver[nrow*nblk] (nrow = nblk + 4 nwide), claim[ntasks]
     double* linv; size_t linv_stride;
     double* vbuf; int nwide;   // inverse transposes of the 512 x 512 diagonal blocks 0 .. nwide-1 (row-major, ld 512): see below
     int* flag;
     long long* trace;       // optional (STBA_MEGA_TRACE): per task {workgroup, t_ticket, t_ready, t_done}, 100 MHz clock
 };
-constexpr int MEGA_SYNC_HDR = 17;
+constexpr int MEGA_SYNC_HDR = 49;
 constexpr int MEGA_SMEM_BYTES = 128 * 1024;   // X of the TU task: 8 waves x 8 chunks x 2 KB
 
 __device__ __forceinline__ int xcc_id() {
@@ -1466,7 +1468,8 @@ __device__ __forceinline__ void syrk_q32(double* __restrict__ A, int lda, int k0
 
 __global__ __launch_bounds__(512) void chol_mega_kernel(MegaArgs a) {
     extern __shared__ __attribute__((aligned(16))) double smem[];   // MEGA_SMEM_BYTES: SYRK staging | diagonal block | L11 tiles | X
-    __shared__ int s_task, s_ok;
+    __shared__ int s_task, s_ok, s_hc;
+    __shared__ int4 s_hd[64];              // the urgent list's window [s_hc, s_hc + 64) as wave 0 saw it last
     const int t = threadIdx.x;
     const int nblk = a.nblk;
     int* abortf = a.sync + 16;
@@ -1489,52 +1492,147 @@ __global__ __launch_bounds__(512) void chol_mega_kernel(MegaArgs a) {
     auto first_panel = [&](int i) { return i < nblk ? 0 : i - nblk; };      // the first panel that updates row i
     const int q = a.xcc_queue[xcc_id()];
     if (q < 0) return;                        // an XCD the probe did not see: no queue, nothing to do
+    // One in-order list per XCD: a workgroup draws the next ticket while its current task starts (the atomic's latency
+    // hides behind the task), reads the descriptor afterwards and PARKS on it, polling the task's input flags; it starts
+    // the instant the last one flips.  (TU and T tasks go on waiting for the diagonal block inside, with their operands
+    // loaded.)
+    // Optionally (STBA_MEGA_HI, an experiment that LOST -- numbers at mega_build_tasks) the tasks of the critical chains
+    // form a second, URGENT list per XCD, [hstart, qstart[q+1]): any workgroup that is free, or waiting for its bulk
+    // task's inputs, claims the first urgent entry that is ready.
+    // No deadlock: the earliest unexecuted task of the global (simulated-start) order has all its inputs done or
+    // running; if urgent it is at the head of its list, if bulk its ticket is the lowest one not executed, which is
+    // either held by a polling workgroup or the next one handed out.
     int* ticket = a.sync + q;
-    const int qbeg = a.qstart[q], qend = a.qstart[q + 1];
-    int mine = 0;
-    if (t == 0) mine = qbeg + atomicAdd(ticket, 1);
+    int* hhead = a.sync + 17 + q;
+    int* claim = ver + nrow * nblk;
+    const int qbeg = a.qstart[q], qend = a.hstart[q], hbeg = a.hstart[q], hend = a.qstart[q + 1];
+    auto ldf = [](const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    auto ready = [&](const int4 d, bool urgent) -> bool {
+        const int type = d.x & 0xff, b = d.y, ti = d.z, tj = d.w;
+        if (type == TASK_D) return ldf(&ver[b * nblk + b]) >= 4 * b;
+        if (type == TASK_T) {       // (an urgent one awaits the diagonal block inside the task, with its rows loaded)
+            const int v = ldf(&ver[ti * nblk + b]), df = urgent ? 1 : ldf(&dflag[b]);
+            return (v >= 4 * (b - first_panel(ti))) & (df >= 1);
+        }
+        if (type == TASK_TI) return ldf(&dflag[b]) >= 1;
+        if (type == TASK_TU) {
+            const int v0 = ldf(&ver[(b + 1) * nblk + b]), v1 = ldf(&ver[(b + 1) * nblk + b + 1]);
+            return (v0 >= 4 * b) & (v1 >= 4 * b);
+        }
+        const int i = (type == TASK_UQ) ? (ti >> 2) : ti;
+        const int f0 = ldf(&tflag[b * nrow + i]), f1 = ldf(&tflag[b * nrow + tj]), v = ldf(&ver[i * nblk + tj]);
+        return (f0 >= 4) & (f1 >= 4) & (v >= 4 * (b - first_panel(i)));
+    };
+    // Wave 0 polls.  The urgent list (if there is one) is examined one entry per lane (the 64 entries behind its head,
+    // their descriptors cached in LDS between polls), but only when there can be something new in it: right after a task
+    // that FEEDS urgent tasks (bit 8 of its type word), when the list's hint word says that ready entries were left
+    // behind by the last scan, and while the workgroup has nothing else to do.
+    int mine = -1;                  // wave 0, uniform: the bulk ticket held (-1: none)
+    int4 md = make_int4(0, 0, 0, 0);
+    bool lo_done = false;           // the bulk list is exhausted
+    int m_raw = 0;                  // lane 0: the ticket drawn when the previous task started (its latency hides behind that task)
+    bool m_pending = false;
+    bool fed = true;                // the task just finished feeds urgent tasks
+    int* hint = a.sync + 33 + q;
+    if (t == 0) s_hc = -1;
     for (;;) {
-        if (t == 0) s_task = mine;
-        __syncthreads();
-        const int task = s_task;
-        if (task >= qend) break;
-        const int4 d = a.tasks[task];
-        const int type = d.x, b = d.y, ti = d.z, tj = d.w;
-        const bool early = (type == TASK_TU);
-        const int k0 = b * NB;
-        if (t == 0) {
-            if (a.trace) { a.trace[8 * (size_t)task] = blockIdx.x; a.trace[8 * (size_t)task + 1] = wall_clock64(); }
+        if (t < 64) {
+            const int lane = t;
+            const long long t_poll = a.trace ? wall_clock64() : 0;
+            const long long t0 = wall_clock64();
+            int pick = -1;
             bool ok = true;
-            if (type == TASK_D) {
-                ok = mega_wait(&ver[b * nblk + b], 4 * b, abortf);
-            } else if (type == TASK_T) {          // (the diagonal block's flag is awaited inside the task)
-                ok = mega_wait(&ver[ti * nblk + b], 4 * (b - first_panel(ti)), abortf);
-            } else if (type == TASK_TI) {
-                ok = true;
-            } else if (type == TASK_TU) {
-                ok = mega_wait(&ver[(b + 1) * nblk + b], 4 * b, abortf) &&
-                     mega_wait(&ver[(b + 1) * nblk + b + 1], 4 * b, abortf);
-            } else {
-                const int i = (type == TASK_UQ) ? (ti >> 2) : ti;
-                ok = mega_wait(&tflag[b * nrow + i], 4, abortf) && mega_wait(&tflag[b * nrow + tj], 4, abortf) &&
-                     mega_wait(&ver[i * nblk + tj], 4 * (b - first_panel(i)), abortf);
+            if (mine < 0 && !lo_done) {
+                if (!m_pending && lane == 0) m_raw = qbeg + atomicAdd(ticket, 1);
+                m_pending = false;
+                mine = __builtin_amdgcn_readfirstlane(m_raw);
+                if (mine >= qend) { mine = -1; lo_done = true; }
+                else md = a.tasks[mine];
             }
+            int hc = s_hc;
+            int4 hd = s_hd[lane];
+            bool idle = false;              // a poll has found nothing to run
+            for (;;) {
+                const bool lr = mine >= 0 && ready(md, false);
+                const int hn = ldf(hint);
+                if (hbeg < hend && (fed || idle || hn != 0)) {
+                    // scan the window
+                    const int idx = hbeg + hc + lane;
+                    const bool hv = hc >= 0 && idx < hend;
+                    const int cl = hv ? ldf(&claim[idx]) : 1;
+                    const bool hr = hv && ready(hd, true);
+                    const int h = ldf(hhead);
+                    if (h != hc) {                          // the head has moved: fetch the new window, test again
+                        hc = h;
+                        hd = (hbeg + hc + lane < hend) ? a.tasks[hbeg + hc + lane] : make_int4(TASK_TI, 0, 0, 0);
+                        continue;
+                    }
+                    const unsigned long long rm = __ballot(hr && cl == 0);
+                    int win = -1;
+                    const int nready = __builtin_popcountll(rm);
+                    if (nready > 0) {
+                        // (not always the first ready entry: the workgroups that see four tasks become ready together must
+                        // not all go for the same one)
+                        unsigned long long m2 = rm;
+                        for (int r = (int)(blockIdx.x % (unsigned)nready); r > 0; --r) m2 &= m2 - 1;
+                        win = __builtin_ctzll(m2);
+                        const bool got = lane == win && atomicCAS(&claim[idx], 0, 1) == 0;
+                        if (__ballot(got) == 0ull) continue;        // another workgroup was faster
+                        pick = hbeg + hc + win;
+                    }
+                    // move the head past the leading claimed entries; tell the others whether ready entries are left
+                    const unsigned long long cm = __ballot(hv && (cl != 0 || lane == win));
+                    const int lead = (~cm == 0ull) ? 64 : __builtin_ctzll(~cm);
+                    if (lane == 0) {
+                        if (lead > 0) atomicMax(hhead, hc + lead);
+                        const int left = nready > 1 ? 1 : 0;
+                        if (left != hn) __hip_atomic_store(hint, left, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    fed = false;
+                    if (pick >= 0) break;
+                }
+                if (lr) { pick = mine; mine = -1; break; }
+                if (lo_done && mine < 0 && (hbeg >= hend || (hc >= 0 && hbeg + hc >= hend))) { pick = -2; break; }      // nothing left for this XCD
+                if (ldf(abortf) != 0) { ok = false; break; }
+                if (wall_clock64() - t0 > 200000000LL) {            // 100 MHz counter
+                    __hip_atomic_store(abortf, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = false;
+                    break;
+                }
+                idle = true;
+                __builtin_amdgcn_s_sleep(8);
+            }
+            s_hd[lane] = hd;
             // this CU's L1 may hold lines of tiles that other CUs have rewritten since
             // (buffer_inv sc0 does NOT do it outside threadgroup-split mode: measured, stale L1 hits)
             asm volatile("buffer_inv sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
-            // next ticket; its latency hides behind this task.  Taken only NOW: a ticket held while this
-            // one waits for its inputs could be a critical one (measured: +3 % LM iterations/s).  Not for
-            // TU: a TU task waits for its three siblings, which hold LATER tickets -- this workgroup must
-            // not sit on one of them.
-            if (!early) mine = qbeg + atomicAdd(ticket, 1);
-            if (a.trace) a.trace[8 * (size_t)task + 2] = wall_clock64();
-            s_ok = ok ? 1 : 0;
+            if (pick >= 0) fed = (a.tasks[pick].x >> 8) != 0;
+            if (lane == 0) {
+                if (a.trace && pick >= 0) {
+                    a.trace[8 * (size_t)pick] = blockIdx.x; a.trace[8 * (size_t)pick + 1] = t_poll;
+                    a.trace[8 * (size_t)pick + 2] = wall_clock64();
+                }
+                s_hc = hc;
+                s_task = pick;
+                s_ok = ok ? 1 : 0;
+            }
+            // draw the next bulk ticket now, look at it after the task.  Not before a TU task: it waits for its three
+            // siblings, which hold LATER tickets -- this workgroup must not sit on one of them.
+            if (mine < 0 && !lo_done && pick >= 0 && (a.tasks[pick].x & 0xff) != TASK_TU) {
+                if (lane == 0) m_raw = qbeg + atomicAdd(ticket, 1);
+                m_pending = true;
+            }
         }
         __syncthreads();
         if (!s_ok) {                            // dependency time-out: make the host see a hard error
             if (t == 0) atomicExch(a.flag, CHOL_FLAG_TIMEOUT);
             break;
         }
+        const int task = s_task;
+        if (task < 0) break;
+        const int4 d = a.tasks[task];
+        const int type = d.x & 0xff, b = d.y, ti = d.z, tj = d.w;
+        const int k0 = b * NB;
         // a fresh copy of the thread index per task: keeps the compiler from hoisting every task's
         // lane-dependent address arithmetic out of the ticket loop (that cost 100+ spilled registers)
         int tt = t;
@@ -1597,7 +1695,8 @@ __global__ __launch_bounds__(512) void chol_mega_kernel(MegaArgs a) {
             else if (type == TASK_U) __hip_atomic_fetch_add(&ver[ti * nblk + tj], 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             else if (type == TASK_UQ) __hip_atomic_fetch_add(&ver[(ti >> 2) * nblk + tj], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (a.trace) a.trace[8 * (size_t)task + 3] = wall_clock64();
-            if (early) mine = qbeg + atomicAdd(ticket, 1);
+            // (the scan that follows a feeding task must see this flag: wait until the L2 has it)
+            if (fed) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
     }
 }
@@ -1648,7 +1747,7 @@ static std::vector<int> mega_row_owner(int nblk, int nq, int nvirt = 0) {
 // tasks by their simulated start time gives (i) one global topological order, which the deadlock
 // argument needs, and (ii) per-queue orders in which a workgroup rarely takes a ticket whose inputs
 // are far from ready (an in-order ticket queue has no other notion of priority).
-static void mega_build_tasks(int nblk, int nq, int wg_per_q, std::vector<int4>& out, int* qstart, std::vector<float>* sim_start = nullptr,
+static void mega_build_tasks(int nblk, int nq, int wg_per_q, std::vector<int4>& out, int* qstart, int* hstart, std::vector<float>* sim_start = nullptr,
                              double* makespan_out = nullptr, int nwide = 0) {
     struct Node { int4 tk; std::vector<int> succ; int indeg = 0; double dur = 0, prio = 0, start = 0, ready = 0; int q = 0; int last_pred = -1; };
     std::vector<Node> nodes;
@@ -1797,7 +1896,21 @@ static void mega_build_tasks(int nblk, int nq, int wg_per_q, std::vector<int4>& 
     }
     int urows = 0;
     for (int r = 0; r < 8; ++r) if (RES[r] > 0) urows = r + 1;
-    auto is_urgent = [&](const int4& tk) { return tk.x != TASK_TI && mega_task_row(tk) <= tk.y + urows; };
+    // URGENT tasks (STBA_MEGA_HI=r, an EXPERIMENT, off by default): the diagonal blocks, the fused panel-solve + diagonal
+    // update of the next tile row, and every panel solve / trailing update that writes one of the next r tile rows get
+    // their own list per XCD, from which any free workgroup takes the first READY entry (see the kernel).  Measured on
+    // MI355X, 6000 unknowns, factorisation + substitution: in-order lists 2.74 ms; r = 1: 2.90, 2: 2.95, 3: 2.99,
+    // 4..6: 3.05, 8: 3.17, 12: 3.31.  A workgroup parked on the ticket of a critical task starts it the moment its last
+    // input flag flips and has its operands loaded by then; a dynamically claimed task pays 2-5 us per hand-over (flag
+    // round trips, the claim, the cold descriptor), four hand-overs per diagonal block.  Idle workgroups are plentiful
+    // (a third of the machine-time), so parking them costs nothing.
+    static const int HI_ROWS = [] { const char* e = getenv("STBA_MEGA_HI"); return e ? atoi(e) : 0; }();
+    auto is_urgent = [&](const int4& tk) {
+        if (HI_ROWS <= 0) return tk.x != TASK_TI && mega_task_row(tk) <= tk.y + urows;
+        if (tk.x == TASK_D || tk.x == TASK_TU) return true;
+        const int row = mega_task_row(tk);
+        return tk.x != TASK_TI && row < NBK && row <= tk.y + HI_ROWS;
+    };
     std::vector<Heap> ready_u((size_t)nq), ready_b((size_t)nq);
     Heap events;
     std::vector<std::vector<double>> idle_since((size_t)nq, std::vector<double>((size_t)wg_per_q, 0.0));   // LIFO
@@ -1828,7 +1941,7 @@ static void mega_build_tasks(int nblk, int nq, int wg_per_q, std::vector<int4>& 
                 Heap& hb = ready_b[(size_t)q];
                 const bool bulk_ok = !hb.empty() && (int)idl.size() > reserve[(size_t)q];
                 int k = -1;
-                if (!hu.empty() && (!bulk_ok || hu.top().first <= hb.top().first)) { k = hu.top().second; hu.pop(); }
+                if (!hu.empty() && (HI_ROWS > 0 || !bulk_ok || hu.top().first <= hb.top().first)) { k = hu.top().second; hu.pop(); }
                 else if (bulk_ok) { k = hb.top().second; hb.pop(); }
                 else break;
                 Node& nd = nodes[(size_t)k];
@@ -1874,9 +1987,25 @@ static void mega_build_tasks(int nblk, int nq, int wg_per_q, std::vector<int4>& 
             return x.key != y.key ? x.key < y.key : x.start < y.start;
         });
         qstart[q] = (int)out.size();
-        for (const Pick& pk : order[(size_t)q]) {
-            out.push_back(nodes[(size_t)pk.node].tk);
+        // bit 8 of the type word: the task's output can be an input of an urgent task (see the kernel's polling)
+        auto emit = [&](const Pick& pk) {
+            int4 tk = nodes[(size_t)pk.node].tk;
+            const int row = mega_task_row(tk);
+            if (HI_ROWS > 0 && (is_urgent(tk) || (tk.x != TASK_TI && row < NBK && row <= tk.y + HI_ROWS + 1))) tk.x |= 0x100;
+            out.push_back(tk);
             if (sim_start) sim_start->push_back((float)pk.start);
+        };
+        for (const Pick& pk : order[(size_t)q]) {
+            if (HI_ROWS > 0 && is_urgent(nodes[(size_t)pk.node].tk)) continue;
+            emit(pk);
+        }
+        // the urgent list, by simulated start (a topological order: a task starts after its inputs have ended)
+        hstart[q] = (int)out.size();
+        if (HI_ROWS > 0) {
+            std::vector<Pick> hi;
+            for (const Pick& pk : order[(size_t)q]) if (is_urgent(nodes[(size_t)pk.node].tk)) hi.push_back(pk);
+            std::stable_sort(hi.begin(), hi.end(), [](const Pick& x, const Pick& y) { return x.start < y.start; });
+            for (const Pick& pk : hi) emit(pk);
         }
     }
     qstart[nq] = (int)out.size();
@@ -1885,9 +2014,9 @@ static void mega_build_tasks(int nblk, int nq, int wg_per_q, std::vector<int4>& 
 // diagnostics (tools/sim_sweep.py): the simulated makespan of the task graph, no GPU involved
 double chol_schedule_makespan(int nblk, int nq, int wg_per_q) {
     std::vector<int4> tasks;
-    int qstart[17];
+    int qstart[17], hstart[16];
     double ms = 0.0;
-    mega_build_tasks(nblk, nq, wg_per_q, tasks, qstart, nullptr, &ms);
+    mega_build_tasks(nblk, nq, wg_per_q, tasks, qstart, hstart, nullptr, &ms);
     return ms;
 }
 
@@ -2044,7 +2173,7 @@ static int chol_run(double* A, int lda, int n, double* x_dev, int* flag_dev, hip
     // the same process, must not reuse another device's pointers or XCD probe
     struct MegaPlan {
         int nblk = 0, nwide = -1, ntasks = 0, nq = 0, ncu = 0;
-        int qstart[17] = {0};
+        int qstart[17] = {0}, hstart[16] = {0};
         signed char xcc_queue[16];
         int4* tasks = nullptr; int* sync = nullptr; size_t sync_ints = 0;
         std::vector<float> sim_start;     // simulated start time of every task (written to the trace file)
@@ -2141,10 +2270,10 @@ static int chol_run(double* A, int lda, int n, double* x_dev, int* flag_dev, hip
                         return fail(STBA_ERR_HIP, "chol: fewer than 4 workgroups per XCD (the TU tasks need 4)");
             }
             std::vector<int4> tasks;
-            mega_build_tasks(nblk, plan.nq, std::max(4, plan.ncu / plan.nq), tasks, plan.qstart, &plan.sim_start, nullptr, nwide);
+            mega_build_tasks(nblk, plan.nq, std::max(4, plan.ncu / plan.nq), tasks, plan.qstart, plan.hstart, &plan.sim_start, nullptr, nwide);
             STBA_HIP(hipMalloc(reinterpret_cast<void**>(&plan.tasks), tasks.size() * sizeof(int4)));
             STBA_HIP(hipMemcpy(plan.tasks, tasks.data(), tasks.size() * sizeof(int4), hipMemcpyHostToDevice));
-            plan.sync_ints = MEGA_SYNC_HDR + 2 * (size_t)nblk + 2 * (size_t)nblk * (nblk + 4 * nwide);
+            plan.sync_ints = MEGA_SYNC_HDR + 2 * (size_t)nblk + 2 * (size_t)nblk * (nblk + 4 * nwide) + tasks.size();
             STBA_HIP(hipMalloc(reinterpret_cast<void**>(&plan.sync), plan.sync_ints * sizeof(int)));
             plan.ntasks = (int)tasks.size();
             plan.nblk = nblk; plan.nwide = nwide;
@@ -2154,6 +2283,7 @@ static int chol_run(double* A, int lda, int n, double* x_dev, int* flag_dev, hip
         ma.A = A; ma.lda = lda; ma.n = n; ma.nblk = nblk;
         ma.tasks = plan.tasks; ma.nq = plan.nq; ma.sync = plan.sync;
         memcpy(ma.qstart, plan.qstart, sizeof ma.qstart);
+        memcpy(ma.hstart, plan.hstart, sizeof ma.hstart);
         memcpy(ma.xcc_queue, plan.xcc_queue, sizeof ma.xcc_queue);
         ma.linv = linv; ma.linv_stride = LINV_STRIDE; ma.flag = flag_dev;
         ma.vbuf = ws.vbuf; ma.nwide = nwide;

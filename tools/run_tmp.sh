@@ -1,3 +1,3 @@
 export TMPDIR=/tmp
-timeout 60 ./tools/exp/diag2_test.bin > gpurun_out/diag2_test.txt
-timeout 60 ./tools/exp/diag2_test_nots.bin | tee gpurun_out/diag2_test_nots.txt
+timeout 900 python -m pytest tests -x -q -m gpu > gpurun_out/pytest_tmp.txt 2>&1
+tail -3 gpurun_out/pytest_tmp.txt
