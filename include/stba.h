@@ -207,6 +207,17 @@ int stba_cholesky_time_split(int n, int reps, double* ms_factor, double* ms_back
  * workgroups each (MI355X: 8 x 32).  The ticket order of the kernel comes from this model. */
 int stba_cholesky_schedule_model(int n, int n_xcd, int wg_per_xcd, double* makespan_us);
 
+/* design study, runs on the host (no GPU): the same task graph spread over `n_gpus` GPUs (the reduced
+ * camera system as the next thing to shard).  Tile rows are dealt to the GPUs block-cyclically, `rows_per_group`
+ * consecutive 128-row tile rows at a time (0: one per XCD, i.e. n_xcd rows); a task runs on the GPU that owns the tile
+ * row it writes; a dependency that crosses GPUs costs `hop_us` (flag over xGMI) plus the transfer of one 128 x 128
+ * FP64 tile (128 KiB) at `link_gb_per_s`.  Link contention is NOT modelled; remote_tiles_busiest_gpu (x 128 KiB) is
+ * the ingress volume to hold against the aggregate xGMI bandwidth.  DESIGN.md tabulates it for 1/2/4/8 GPUs.
+ * stba_cholesky_shard_owner returns the distribution (tile row -> GPU) the model uses. */
+int stba_cholesky_shard_model(int n, int n_gpus, int n_xcd, int wg_per_xcd, int rows_per_group, double hop_us, double link_gb_per_s,
+                              double* makespan_us, double* cross_gpu_dependencies, double* remote_tiles_busiest_gpu);
+int stba_cholesky_shard_owner(int n_block_rows, int n_gpus, int rows_per_group, int* owner_gpu);
+
 /* hipEvent time (ms) of one factor+solve per kernel class, with the stage-per-kernel schedule (a
  * diagnostic: the production path runs the stages as tasks of one persistent kernel): ms4 = {diagonal blocks, panel solves,
  * MFMA trailing updates, backward substitution}; algorithmic / executed flops of the trailing

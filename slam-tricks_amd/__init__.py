@@ -66,7 +66,7 @@ EXPORTS = ["stba_status_string", "stba_last_error", "stba_version", "stba_device
            "stba_ba_cost", "stba_ba_normal_blocks", "stba_ba_reduced_system", "stba_ba_solve_reduced",
            "stba_ba_back_substitute", "stba_ba_apply_step", "stba_ba_solve", "stba_ba_lm_iterations",
            "stba_ba_triangulate", "stba_ba_time_linearize", "stba_cholesky_factor", "stba_cholesky_solve",
-           "stba_cholesky_time", "stba_cholesky_time_split", "stba_cholesky_schedule_model", "stba_cholesky_profile", "stba_calib_evaluate", "stba_calib_gauss_newton",
+           "stba_cholesky_time", "stba_cholesky_time_split", "stba_cholesky_schedule_model", "stba_cholesky_shard_model", "stba_cholesky_shard_owner", "stba_cholesky_profile", "stba_calib_evaluate", "stba_calib_gauss_newton",
            "stba_pcg_default_options", "stba_pg_create", "stba_pg_destroy", "stba_pg_set_allreduce", "stba_pg_get_poses", "stba_pg_evaluate",
            "stba_pg_solve", "stba_dense_solve", "stba_corners_read", "stba_corners_write", "stba_zhang_init", "stba_two_view_init", "stba_odometry_read", "stba_odometry_write", "stba_trajectory_ate",
            "stba_comm_unique_id", "stba_comm_create", "stba_comm_destroy", "stba_comm_rank", "stba_comm_allreduce_sum",
@@ -361,6 +361,23 @@ def cholesky_schedule_model(n, n_xcd=8, wg_per_xcd=32):
     out = C.c_double()
     _chk(lib().stba_cholesky_schedule_model(int(n), int(n_xcd), int(wg_per_xcd), C.byref(out)), "stba_cholesky_schedule_model")
     return out.value
+
+
+def cholesky_shard_model(n, n_gpus, n_xcd=8, wg_per_xcd=32, rows_per_group=0, hop_us=3.0, link_gb_per_s=48.0):
+    """Host-only design study: (makespan us, cross-GPU dependencies, remote 128x128 tiles fetched by the busiest GPU)
+    of the factorisation's task graph spread block-cyclically over n_gpus GPUs (include/stba.h)."""
+    ms = C.c_double(); ce = C.c_double(); ti = C.c_double()
+    _chk(lib().stba_cholesky_shard_model(int(n), int(n_gpus), int(n_xcd), int(wg_per_xcd), int(rows_per_group), C.c_double(hop_us),
+                                         C.c_double(link_gb_per_s), C.byref(ms), C.byref(ce), C.byref(ti)), "stba_cholesky_shard_model")
+    return ms.value, ce.value, ti.value
+
+
+def cholesky_shard_owner(n_block_rows, n_gpus, rows_per_group):
+    """tile row -> GPU of the block-cyclic distribution of the sharded-solve design"""
+    out = np.zeros(int(n_block_rows), np.int32)
+    _chk(lib().stba_cholesky_shard_owner(int(n_block_rows), int(n_gpus), int(rows_per_group), out.ctypes.data_as(C.POINTER(C.c_int))),
+         "stba_cholesky_shard_owner")
+    return out
 
 
 def cholesky_time_split(n, reps=5, stream=None):

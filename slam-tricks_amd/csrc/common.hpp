@@ -77,6 +77,8 @@ int chol_factor_solve_profiled(double* A_dev, int lda, int n, double* x_dev, int
                                CholProfile* prof);
 // host-side scheduling model of the persistent factorisation kernel: predicted makespan (us) for nblk block columns
 double chol_schedule_makespan(int nblk, int nq, int wg_per_q);
+void chol_shard_model(int nblk, int n_gpus, int n_xcd, int wg_per_q, int rows_per_group, double hop_us, double tile_us, double* out3);
+int chol_shard_row_owner(int row, int n_gpus, int rows_per_group);
 // fills the padding (identity) and the rhs row of a padded system
 int chol_prepare_padding_dev(double* A_dev, int lda, int n, const double* rhs_dev, hipStream_t st);
 

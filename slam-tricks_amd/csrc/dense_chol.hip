@@ -1747,12 +1747,30 @@ static std::vector<int> mega_row_owner(int nblk, int nq, int nvirt = 0) {
 // tasks by their simulated start time gives (i) one global topological order, which the deadlock
 // argument needs, and (ii) per-queue orders in which a workgroup rarely takes a ticket whose inputs
 // are far from ready (an in-order ticket queue has no other notion of priority).
+struct MegaShardModel {          // what-if: the queues are spread over several GPUs (design study, DESIGN.md "sharded reduced solve")
+    int n_gpus = 1;              // queue q belongs to GPU q / (nq / n_gpus)
+    int rows_per_group = 0;      // tile rows are dealt to the GPUs in groups of this many consecutive rows (0: one XCD-round, nq / n_gpus)
+    double hop_us = 0.0;         // flag latency of a dependency that crosses GPUs
+    double tile_us = 0.0;        // + transfer time of the 128 x 128 tile it carries (128 KiB over one xGMI link)
+    double cross_edges = 0.0;    // out: dependencies that crossed GPUs
+    double tiles_in_max = 0.0;   // out: distinct remote tiles fetched by the busiest GPU
+};
 static void mega_build_tasks(int nblk, int nq, int wg_per_q, std::vector<int4>& out, int* qstart, int* hstart, std::vector<float>* sim_start = nullptr,
-                             double* makespan_out = nullptr, int nwide = 0) {
-    struct Node { int4 tk; std::vector<int> succ; int indeg = 0; double dur = 0, prio = 0, start = 0, ready = 0; int q = 0; int last_pred = -1; };
+                             double* makespan_out = nullptr, int nwide = 0, MegaShardModel* shard = nullptr) {
+    struct Node { int4 tk; std::vector<int> succ; int indeg = 0; double dur = 0, prio = 0, start = 0, ready = 0, avail = 0; int q = 0; int last_pred = -1; };
     std::vector<Node> nodes;
     const int NBK = nblk;
-    const std::vector<int> rowq = mega_row_owner(nblk, nq, 4 * nwide);
+    std::vector<int> rowq = mega_row_owner(nblk, nq, 4 * nwide);
+    const int n_gpus = shard ? shard->n_gpus : 1, q_per_gpu = nq / std::max(1, n_gpus);
+    if (shard && n_gpus > 1) {
+        // block-cyclic over the GPUs, cyclic over a GPU's XCDs: rows [g R, (g+1) R) of every round of n_gpus R rows go to GPU g
+        const int R = shard->rows_per_group > 0 ? shard->rows_per_group : q_per_gpu;
+        for (int row = 0; row < nblk; ++row) {
+            const int local = (row / (R * n_gpus)) * R + row % R;        // index among the rows of its GPU
+            rowq[(size_t)row] = ((row / R) % n_gpus) * q_per_gpu + local % q_per_gpu;
+        }
+    }
+    auto gpu_of = [&](int q) { return n_gpus > 1 ? q / q_per_gpu : 0; };
     static const int QROWS = [] { const char* e = getenv("STBA_MEGA_QROWS"); return e ? atoi(e) : 2; }();
     std::vector<int> idD((size_t)NBK, -1), idTI((size_t)NBK, -1), idTU((size_t)NBK * 4, -1), idT((size_t)NBK * NBK, -1),
         idUq((size_t)NBK * NBK * 4, -1), idU((size_t)NBK * NBK * NBK, -1);
@@ -1932,6 +1950,7 @@ static void mega_build_tasks(int nblk, int nq, int wg_per_q, std::vector<int4>& 
     for (int k = 0; k < (int)nodes.size(); ++k)
         if (nodes[(size_t)k].indeg == 0) push_ready(k);
     double makespan = 0.0;
+    std::vector<double> tiles_in((size_t)std::max(1, n_gpus), 0.0);
     for (;;) {
         for (int q = 0; q < nq; ++q) {
             std::vector<double>& idl = idle_since[(size_t)q];
@@ -1956,13 +1975,35 @@ static void mega_build_tasks(int nblk, int nq, int wg_per_q, std::vector<int4>& 
         const PI ev = events.top();
         events.pop();
         now = ev.first;
+        if (ev.second < 0) {                    // (sharded model) the last remote input of a task has arrived
+            const int k = -(ev.second + 1);
+            nodes[(size_t)k].ready = now;
+            push_ready(k);
+            continue;
+        }
         makespan = now;
         const Node& nd = nodes[(size_t)ev.second];
         idle_since[(size_t)nd.q].push_back(now);
-        for (int sidx : nd.succ)
-            if (--nodes[(size_t)sidx].indeg == 0) { nodes[(size_t)sidx].ready = now; nodes[(size_t)sidx].last_pred = ev.second; push_ready(sidx); }
+        const int g0 = gpu_of(nd.q);
+        unsigned sent_to = 0;                   // GPUs this task's output tile has been shipped to
+        for (int sidx : nd.succ) {
+            Node& sn = nodes[(size_t)sidx];
+            double at = now;
+            const int g1 = gpu_of(sn.q);
+            if (g1 != g0) {
+                at += shard->hop_us + shard->tile_us;
+                shard->cross_edges += 1.0;
+                if (!(sent_to >> g1 & 1u)) { sent_to |= 1u << g1; tiles_in[(size_t)g1] += 1.0; }
+            }
+            if (at > sn.avail) { sn.avail = at; sn.last_pred = ev.second; }
+            if (--sn.indeg == 0) {
+                if (sn.avail <= now) { sn.ready = now; push_ready(sidx); }
+                else events.push(PI(sn.avail, -(sidx + 1)));
+            }
+        }
     }
     if (makespan_out) *makespan_out = makespan;
+    if (shard) shard->tiles_in_max = *std::max_element(tiles_in.begin(), tiles_in.end());
     if (getenv("STBA_MEGA_SIMDBG")) {
         static const char* NM[6] = {"D", "T", "TI", "U", "Uq", "TU"};
         for (int b = 0; b + 1 < NBK; ++b) {
@@ -2019,6 +2060,22 @@ double chol_schedule_makespan(int nblk, int nq, int wg_per_q) {
     mega_build_tasks(nblk, nq, wg_per_q, tasks, qstart, hstart, nullptr, &ms);
     return ms;
 }
+
+// the same task graph on n_gpus x n_xcd queues: tile rows block-cyclic over the GPUs, a dependency that crosses GPUs
+// costs hop_us + tile_us (see MegaShardModel); out3 = {makespan us, cross-GPU dependencies, remote tiles fetched by the
+// busiest GPU}
+void chol_shard_model(int nblk, int n_gpus, int n_xcd, int wg_per_q, int rows_per_group, double hop_us, double tile_us, double* out3) {
+    std::vector<int4> tasks;
+    std::vector<int> qstart((size_t)n_gpus * n_xcd + 1), hstart((size_t)n_gpus * n_xcd);
+    MegaShardModel sh;
+    sh.n_gpus = n_gpus; sh.rows_per_group = rows_per_group; sh.hop_us = hop_us; sh.tile_us = tile_us;
+    double ms = 0.0;
+    mega_build_tasks(nblk, n_gpus * n_xcd, wg_per_q, tasks, qstart.data(), hstart.data(), nullptr, &ms, 0, &sh);
+    out3[0] = ms; out3[1] = sh.cross_edges; out3[2] = sh.tiles_in_max;
+}
+
+// tile row -> GPU of the block-cyclic distribution the model uses
+int chol_shard_row_owner(int row, int n_gpus, int rows_per_group) { return (row / std::max(1, rows_per_group)) % std::max(1, n_gpus); }
 
 // ------------------------------------------------------------------------------------------
 // backward substitution, one launch per 128-unknown block b (from the last block up):

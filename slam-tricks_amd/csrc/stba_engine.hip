@@ -1243,6 +1243,26 @@ int stba_cholesky_schedule_model(int n, int n_xcd, int wg_per_xcd, double* makes
     return STBA_OK;
 }
 
+int stba_cholesky_shard_model(int n, int n_gpus, int n_xcd, int wg_per_xcd, int rows_per_group, double hop_us, double link_gb_per_s,
+                              double* makespan_us, double* cross_gpu_dependencies, double* remote_tiles_busiest_gpu) {
+    if (n <= 0 || n_gpus < 1 || n_gpus > 32 || n_xcd <= 0 || n_xcd > 16 || wg_per_xcd < 4 || rows_per_group < 0 || hop_us < 0 ||
+        !(link_gb_per_s > 0) || !makespan_us)
+        return fail(STBA_ERR_INVALID_ARGUMENT, "bad argument");
+    const int lda = ((n + 1 + 127) / 128) * 128;
+    double out3[3];
+    chol_shard_model(lda / 128, n_gpus, n_xcd, wg_per_xcd, rows_per_group, hop_us, 128.0 * 128.0 * 8.0 / (link_gb_per_s * 1e3), out3);
+    *makespan_us = out3[0];
+    if (cross_gpu_dependencies) *cross_gpu_dependencies = out3[1];
+    if (remote_tiles_busiest_gpu) *remote_tiles_busiest_gpu = out3[2];
+    return STBA_OK;
+}
+
+int stba_cholesky_shard_owner(int n_block_rows, int n_gpus, int rows_per_group, int* owner_gpu) {
+    if (n_block_rows <= 0 || n_gpus < 1 || rows_per_group < 1 || !owner_gpu) return fail(STBA_ERR_INVALID_ARGUMENT, "bad argument");
+    for (int r = 0; r < n_block_rows; ++r) owner_gpu[r] = chol_shard_row_owner(r, n_gpus, rows_per_group);
+    return STBA_OK;
+}
+
 int stba_cholesky_time_split(int n, int reps, double* ms_factor, double* ms_backward, void* hip_stream) {
     if (n <= 0 || reps <= 0 || !ms_factor || !ms_backward) return fail(STBA_ERR_INVALID_ARGUMENT, "bad argument");
     STBA_TRY(require_device());
