@@ -989,69 +989,65 @@ int launch_triangulate(int n_pts, const int* pt_start, const int* obs_cam, const
 //   e = predicted - measured pixel (calib.cpp:334)
 //   Ji (2x9): d e / d(intrinsics, distortion)   (:337-348)
 //   Jx (2x6): d e / d(left perturbation of the view pose), [I | -hat(P')] chain (:352-380)
-// Optionally also scatters the rows into a dense row-major Jacobian Jd [2*V*C][9+6V] (zero elsewhere).
 // ===========================================================================================
+// one corner of one view: residual e (2) and, if want_j, Ji (2x9) and Jx (2x6)
+__device__ __forceinline__ void calib_corner(const double* __restrict__ params, int v, double X, double Y, double u, double w,
+                                             bool want_j, double e[2], double ji[18], double jx[12]) {
+    const double alpha = params[0], beta = params[1], u0 = params[2], v0 = params[3];
+    const double k1 = params[4], k2 = params[5], k3 = params[6], p1 = params[7], p2 = params[8];
+    double xi[6], R[9], t[3];
+    for (int k = 0; k < 6; ++k) xi[k] = params[9 + v * 6 + k];
+    se3_exp_rt(xi, R, t);
+    const double Xp = R[0] * X + R[1] * Y + t[0], Yp = R[3] * X + R[4] * Y + t[1], Zp = R[6] * X + R[7] * Y + t[2];
+    const double iz = 1.0 / Zp, xn = Xp * iz, yn = Yp * iz;
+    const double r2 = xn * xn + yn * yn, r4 = r2 * r2, r6 = r4 * r2;
+    const double rad = 1.0 + k1 * r2 + k2 * r4 + k3 * r6;
+    const double xd = xn * rad + 2.0 * p1 * xn * yn + p2 * (r2 + 2.0 * xn * xn);
+    const double yd = yn * rad + 2.0 * p2 * xn * yn + p1 * (r2 + 2.0 * yn * yn);
+    e[0] = alpha * xd + u0 - u;
+    e[1] = beta * yd + v0 - w;
+    if (!want_j) return;
+    const double jt[18] = {xd, 0, 1, 0, alpha * xn * r2, alpha * xn * r4, alpha * xn * r6, 2.0 * alpha * xn * yn,
+                           alpha * (r2 + 2.0 * xn * xn),
+                           0, yd, 0, 1, beta * yn * r2, beta * yn * r4, beta * yn * r6, beta * (r2 + 2.0 * yn * yn),
+                           2.0 * beta * xn * yn};
+    for (int k = 0; k < 18; ++k) ji[k] = jt[k];
+    const double dx = 2.0 * k1 * xn + 4.0 * k2 * r2 * xn + 6.0 * k3 * r4 * xn;
+    const double dy = 2.0 * k1 * yn + 4.0 * k2 * r2 * yn + 6.0 * k3 * r4 * yn;
+    const double d00 = rad + xn * dx + 2.0 * p1 * yn + 6.0 * p2 * xn;
+    const double d01 = xn * dy + 2.0 * p1 * xn + 2.0 * p2 * yn;
+    const double d10 = yn * dx + 2.0 * p1 * xn + 2.0 * p2 * yn;
+    const double d11 = rad + yn * dy + 2.0 * p2 * xn + 6.0 * p1 * yn;
+    const double N[6] = {iz, 0, -Xp * iz * iz, 0, iz, -Yp * iz * iz};
+    double M[6];
+    for (int b = 0; b < 3; ++b) {
+        M[b] = alpha * (d00 * N[b] + d01 * N[3 + b]);
+        M[3 + b] = beta * (d10 * N[b] + d11 * N[3 + b]);
+    }
+    // [I | -hat(P')]:  -hat(P') = [[0, Zp, -Yp], [-Zp, 0, Xp], [Yp, -Xp, 0]]
+    const double nH[9] = {0, Zp, -Yp, -Zp, 0, Xp, Yp, -Xp, 0};
+    for (int a = 0; a < 2; ++a)
+        for (int b = 0; b < 3; ++b) {
+            jx[a * 6 + b] = M[a * 3 + b];
+            jx[a * 6 + 3 + b] = M[a * 3] * nH[b] + M[a * 3 + 1] * nH[3 + b] + M[a * 3 + 2] * nH[6 + b];
+        }
+}
+
 __global__ __launch_bounds__(256) void calib_linearize_kernel(int n_views, int n_corners, const double* __restrict__ params,
                                                               const double* __restrict__ obj, const double* __restrict__ img,
                                                               double* __restrict__ e, double* __restrict__ Ji,
-                                                              double* __restrict__ Jx, double* __restrict__ Jd,
-                                                              double* __restrict__ sse_partial) {
+                                                              double* __restrict__ Jx, double* __restrict__ sse_partial) {
     const int o = blockIdx.x * 256 + threadIdx.x;
     const int total = n_views * n_corners;
     double sq = 0.0;
     if (o < total) {
-        const int v = o / n_corners;
-        const double alpha = params[0], beta = params[1], u0 = params[2], v0 = params[3];
-        const double k1 = params[4], k2 = params[5], k3 = params[6], p1 = params[7], p2 = params[8];
-        double xi[6], R[9], t[3];
-        for (int k = 0; k < 6; ++k) xi[k] = params[9 + v * 6 + k];
-        se3_exp_rt(xi, R, t);
-        const double X = obj[(size_t)o * 2], Y = obj[(size_t)o * 2 + 1];
-        const double Xp = R[0] * X + R[1] * Y + t[0], Yp = R[3] * X + R[4] * Y + t[1], Zp = R[6] * X + R[7] * Y + t[2];
-        const double iz = 1.0 / Zp, xn = Xp * iz, yn = Yp * iz;
-        const double r2 = xn * xn + yn * yn, r4 = r2 * r2, r6 = r4 * r2;
-        const double rad = 1.0 + k1 * r2 + k2 * r4 + k3 * r6;
-        const double xd = xn * rad + 2.0 * p1 * xn * yn + p2 * (r2 + 2.0 * xn * xn);
-        const double yd = yn * rad + 2.0 * p2 * xn * yn + p1 * (r2 + 2.0 * yn * yn);
-        const double e0 = alpha * xd + u0 - img[(size_t)o * 2], e1 = beta * yd + v0 - img[(size_t)o * 2 + 1];
-        sq = e0 * e0 + e1 * e1;
-        if (e) { e[(size_t)o * 2] = e0; e[(size_t)o * 2 + 1] = e1; }
-        if (Ji || Jx || Jd) {
-            double ji[18] = {xd, 0, 1, 0, alpha * xn * r2, alpha * xn * r4, alpha * xn * r6, 2.0 * alpha * xn * yn,
-                             alpha * (r2 + 2.0 * xn * xn),
-                             0, yd, 0, 1, beta * yn * r2, beta * yn * r4, beta * yn * r6, beta * (r2 + 2.0 * yn * yn),
-                             2.0 * beta * xn * yn};
-            const double dx = 2.0 * k1 * xn + 4.0 * k2 * r2 * xn + 6.0 * k3 * r4 * xn;
-            const double dy = 2.0 * k1 * yn + 4.0 * k2 * r2 * yn + 6.0 * k3 * r4 * yn;
-            const double d00 = rad + xn * dx + 2.0 * p1 * yn + 6.0 * p2 * xn;
-            const double d01 = xn * dy + 2.0 * p1 * xn + 2.0 * p2 * yn;
-            const double d10 = yn * dx + 2.0 * p1 * xn + 2.0 * p2 * yn;
-            const double d11 = rad + yn * dy + 2.0 * p2 * xn + 6.0 * p1 * yn;
-            const double N[6] = {iz, 0, -Xp * iz * iz, 0, iz, -Yp * iz * iz};
-            double M[6];
-            for (int b = 0; b < 3; ++b) {
-                M[b] = alpha * (d00 * N[b] + d01 * N[3 + b]);
-                M[3 + b] = beta * (d10 * N[b] + d11 * N[3 + b]);
-            }
-            // [I | -hat(P')]:  -hat(P') = [[0, Zp, -Yp], [-Zp, 0, Xp], [Yp, -Xp, 0]]
-            const double nH[9] = {0, Zp, -Yp, -Zp, 0, Xp, Yp, -Xp, 0};
-            double jx[12];
-            for (int a = 0; a < 2; ++a)
-                for (int b = 0; b < 3; ++b) {
-                    jx[a * 6 + b] = M[a * 3 + b];
-                    jx[a * 6 + 3 + b] = M[a * 3] * nH[b] + M[a * 3 + 1] * nH[3 + b] + M[a * 3 + 2] * nH[6 + b];
-                }
-            if (Ji) for (int k = 0; k < 18; ++k) Ji[(size_t)o * 18 + k] = ji[k];
-            if (Jx) for (int k = 0; k < 12; ++k) Jx[(size_t)o * 12 + k] = jx[k];
-            if (Jd) {
-                const int n = 9 + 6 * n_views;
-                for (int a = 0; a < 2; ++a) {
-                    double* row = Jd + (size_t)(2 * o + a) * n;
-                    for (int k = 0; k < 9; ++k) row[k] = ji[a * 9 + k];
-                    for (int k = 0; k < 6; ++k) row[9 + v * 6 + k] = jx[a * 6 + k];
-                }
-            }
-        }
+        double ee[2], ji[18], jx[12];
+        calib_corner(params, o / n_corners, obj[(size_t)o * 2], obj[(size_t)o * 2 + 1], img[(size_t)o * 2], img[(size_t)o * 2 + 1],
+                     Ji || Jx, ee, ji, jx);
+        sq = ee[0] * ee[0] + ee[1] * ee[1];
+        if (e) { e[(size_t)o * 2] = ee[0]; e[(size_t)o * 2 + 1] = ee[1]; }
+        if (Ji) for (int k = 0; k < 18; ++k) Ji[(size_t)o * 18 + k] = ji[k];
+        if (Jx) for (int k = 0; k < 12; ++k) Jx[(size_t)o * 12 + k] = jx[k];
     }
     __shared__ double s_red[4];
     for (int off = 32; off > 0; off >>= 1) sq += __shfl_down(sq, off, 64);
@@ -1060,11 +1056,206 @@ __global__ __launch_bounds__(256) void calib_linearize_kernel(int n_views, int n
     if (threadIdx.x == 0) sse_partial[blockIdx.x] = s_red[0] + s_red[1] + s_red[2] + s_red[3];
 }
 
+// ---- Gauss-Newton with the ARROW structure of the calibration's normal equations --------------------------------
+// The unknowns are the 9 intrinsics (shared by all corners) and one 6-dof pose per view (touched by that view's
+// corners only): H = [A B; B^T C] with C block-diagonal.  The reference builds the dense (9+6V)^2 matrix from
+// full-width Jacobian rows and calls ldlt() (calib.cpp:383-393); here neither exists:
+//   calib_view_gram_kernel   per view: the Gram matrix of the corner rows [Ji (9) | Jx (6) | e], 16 x 16 symmetric =
+//                            136 sums = {A_v, B_v, C_v, b_v, c_v, sse_v}; the rows never leave the workgroup's LDS;
+//   calib_arrow_step_kernel  one workgroup: per view C_v = L L^T, Y_v = C_v^-1 B_v^T, z_v = C_v^-1 c_v; the 9 x 9 Schur
+//                            complement S = sum A_v - B_v Y_v, its right-hand side, the intrinsics step; per view the
+//                            pose step, the left-multiplicative pose update (calib.cpp:397-402); the iteration's record
+//                            (sse, |step|, stop test).  Parameters, blocks and the iteration state stay on the device:
+//                            the host enqueues max_iter iteration pairs and reads the result once.
+// Every sum runs in a fixed order (bitwise reproducible).
+// ================================================================================================================
+constexpr int CALIB_GRAM = 136;          // pairs (p <= q) of the 16-vector [ji(9) | jx(6) | e]
+constexpr int CALIB_CHUNK = 128;         // corners staged per pass
+
+__global__ __launch_bounds__(256) void calib_view_gram_kernel(int n_corners, const double* __restrict__ params,
+                                                              const double* __restrict__ obj, const double* __restrict__ img,
+                                                              const int* __restrict__ state, double* __restrict__ gram) {
+    if (state[1] != 0) return;                          // converged (or failed) earlier: the remaining launches are empty
+    __shared__ double s_rows[CALIB_CHUNK][2][17];       // (padded: 17)
+    const int v = blockIdx.x, t = threadIdx.x;
+    // this thread's pair (p, q), p <= q, in row-major order of the upper triangle
+    int p = 0, q = 0;
+    if (t < CALIB_GRAM) {
+        int k = t;
+        while (k >= 16 - p) { k -= 16 - p; ++p; }
+        q = p + k;
+    }
+    double acc = 0.0;
+    for (int c0 = 0; c0 < n_corners; c0 += CALIB_CHUNK) {
+        const int nc = min(CALIB_CHUNK, n_corners - c0);
+        if (t < nc) {
+            const size_t o = (size_t)v * n_corners + c0 + t;
+            double e[2], ji[18], jx[12];
+            calib_corner(params, v, obj[o * 2], obj[o * 2 + 1], img[o * 2], img[o * 2 + 1], true, e, ji, jx);
+            for (int a = 0; a < 2; ++a) {
+                for (int k = 0; k < 9; ++k) s_rows[t][a][k] = ji[a * 9 + k];
+                for (int k = 0; k < 6; ++k) s_rows[t][a][9 + k] = jx[a * 6 + k];
+                s_rows[t][a][15] = e[a];
+            }
+        }
+        __syncthreads();
+        if (t < CALIB_GRAM)
+            for (int c = 0; c < nc; ++c) acc += s_rows[c][0][p] * s_rows[c][0][q] + s_rows[c][1][p] * s_rows[c][1][q];
+        __syncthreads();
+    }
+    if (t < CALIB_GRAM) gram[(size_t)v * CALIB_GRAM + t] = acc;
+}
+
+__device__ __forceinline__ int calib_gram_index(int p, int q) {      // p <= q
+    return p * 16 - p * (p - 1) / 2 + (q - p);
+}
+
+// state: {iterations completed, done, failed pivot (1-based unknown) }; scratch: per view Y (6x9) | z (6) | B Y (45) | B z (9)
+__global__ __launch_bounds__(256) void calib_arrow_step_kernel(int n_views, const double* __restrict__ gram, double* __restrict__ params,
+                                                               double* __restrict__ scratch, int* __restrict__ state,
+                                                               double* __restrict__ sse_trace) {
+    if (state[1] != 0) return;
+    constexpr int SCR = 54 + 6 + 45 + 9;
+    __shared__ double s_S[45], s_rhs[9], s_di[9], s_un[256], s_sse;
+    const int t = threadIdx.x;
+    for (int v = t; v < n_views; v += 256) {
+        const double* G = gram + (size_t)v * CALIB_GRAM;
+        double* sc = scratch + (size_t)v * SCR;
+        // C_v = L L^T (6 x 6, unknowns 9..14 of the 16-vector)
+        double L[21];
+        bool ok = true;
+        for (int i = 0; i < 6; ++i)
+            for (int j = 0; j <= i; ++j) {
+                double sum = G[calib_gram_index(9 + j, 9 + i)];
+                for (int k = 0; k < j; ++k) sum -= L[i * (i + 1) / 2 + k] * L[j * (j + 1) / 2 + k];
+                if (i == j) { if (!(sum > 0.0)) { ok = false; sum = 1.0; } L[i * (i + 1) / 2 + i] = sqrt(sum); }
+                else L[i * (i + 1) / 2 + j] = sum / L[j * (j + 1) / 2 + j];
+            }
+        if (!ok) atomicCAS(&state[2], 0, 9 + 6 * v + 1);
+        auto solve6 = [&](double* x) {                 // x <- C_v^-1 x
+            for (int i = 0; i < 6; ++i) {
+                double sum = x[i];
+                for (int k = 0; k < i; ++k) sum -= L[i * (i + 1) / 2 + k] * x[k];
+                x[i] = sum / L[i * (i + 1) / 2 + i];
+            }
+            for (int i = 5; i >= 0; --i) {
+                double sum = x[i];
+                for (int k = i + 1; k < 6; ++k) sum -= L[k * (k + 1) / 2 + i] * x[k];
+                x[i] = sum / L[i * (i + 1) / 2 + i];
+            }
+        };
+        double Y[54];                                   // Y[k][a] = (C^-1 B^T)[k][a], k < 6, a < 9
+        for (int a = 0; a < 9; ++a) {
+            double x[6];
+            for (int k = 0; k < 6; ++k) x[k] = G[calib_gram_index(a, 9 + k)];
+            solve6(x);
+            for (int k = 0; k < 6; ++k) Y[k * 9 + a] = x[k];
+        }
+        double z[6];
+        for (int k = 0; k < 6; ++k) z[k] = G[calib_gram_index(9 + k, 15)];
+        solve6(z);
+        for (int k = 0; k < 54; ++k) sc[k] = Y[k];
+        for (int k = 0; k < 6; ++k) sc[54 + k] = z[k];
+        int idx = 0;
+        for (int a = 0; a < 9; ++a)
+            for (int b = a; b < 9; ++b, ++idx) {
+                double sum = 0.0;
+                for (int k = 0; k < 6; ++k) sum += G[calib_gram_index(a, 9 + k)] * Y[k * 9 + b];
+                sc[60 + idx] = sum;
+            }
+        for (int a = 0; a < 9; ++a) {
+            double sum = 0.0;
+            for (int k = 0; k < 6; ++k) sum += G[calib_gram_index(a, 9 + k)] * z[k];
+            sc[105 + a] = sum;
+        }
+    }
+    __syncthreads();
+    // Schur complement of the pose blocks and its right-hand side: S = sum_v (A_v - B_v Y_v), rhs = -(sum_v b_v - B_v z_v)
+    if (t < 45) {
+        int a = 0, k = t;
+        while (k >= 9 - a) { k -= 9 - a; ++a; }
+        const int b = a + k;
+        double sum = 0.0;
+        for (int v = 0; v < n_views; ++v) sum += gram[(size_t)v * CALIB_GRAM + calib_gram_index(a, b)] - scratch[(size_t)v * SCR + 60 + t];
+        s_S[t] = sum;
+    } else if (t < 54) {
+        const int a = t - 45;
+        double sum = 0.0;
+        for (int v = 0; v < n_views; ++v) sum += gram[(size_t)v * CALIB_GRAM + calib_gram_index(a, 15)] - scratch[(size_t)v * SCR + 105 + a];
+        s_rhs[a] = -sum;
+    } else if (t == 54) {
+        double sum = 0.0;
+        for (int v = 0; v < n_views; ++v) sum += gram[(size_t)v * CALIB_GRAM + calib_gram_index(15, 15)];
+        s_sse = sum;
+    }
+    __syncthreads();
+    if (t == 0) {                                       // 9 x 9 Cholesky solve
+        double L[45], x[9];
+        auto at = [](int i, int j) { return j * 9 - j * (j - 1) / 2 + (i - j); };      // (i >= j) in the upper-triangle order of s_S
+        bool ok = true;
+        for (int i = 0; i < 9; ++i)
+            for (int j = 0; j <= i; ++j) {
+                double sum = s_S[at(i, j)];
+                for (int k = 0; k < j; ++k) sum -= L[i * (i + 1) / 2 + k] * L[j * (j + 1) / 2 + k];
+                if (i == j) { if (!(sum > 0.0)) { if (ok) atomicCAS(&state[2], 0, i + 1); ok = false; sum = 1.0; } L[i * (i + 1) / 2 + i] = sqrt(sum); }
+                else L[i * (i + 1) / 2 + j] = sum / L[j * (j + 1) / 2 + j];
+            }
+        for (int i = 0; i < 9; ++i) {
+            double sum = s_rhs[i];
+            for (int k = 0; k < i; ++k) sum -= L[i * (i + 1) / 2 + k] * x[k];
+            x[i] = sum / L[i * (i + 1) / 2 + i];
+        }
+        for (int i = 8; i >= 0; --i) {
+            double sum = x[i];
+            for (int k = i + 1; k < 9; ++k) sum -= L[k * (k + 1) / 2 + i] * x[k];
+            x[i] = sum / L[i * (i + 1) / 2 + i];
+        }
+        for (int i = 0; i < 9; ++i) s_di[i] = x[i];
+    }
+    __syncthreads();
+    // pose steps dx_v = -z_v - Y_v di, left-multiplicative update
+    double un = 0.0;
+    for (int v = t; v < n_views; v += 256) {
+        const double* sc = scratch + (size_t)v * SCR;
+        double d[6];
+        for (int k = 0; k < 6; ++k) {
+            double sum = -sc[54 + k];
+            for (int a = 0; a < 9; ++a) sum -= sc[k * 9 + a] * s_di[a];
+            d[k] = sum;
+            un += sum * sum;
+        }
+        double xi[6];
+        for (int k = 0; k < 6; ++k) xi[k] = params[9 + v * 6 + k];
+        se3_left_update(d, xi);
+        for (int k = 0; k < 6; ++k) params[9 + v * 6 + k] = xi[k];
+    }
+    s_un[t] = un;
+    __syncthreads();
+    if (t == 0) {
+        double tot = 0.0;
+        for (int k = 0; k < 256; ++k) tot += s_un[k];
+        for (int a = 0; a < 9; ++a) { tot += s_di[a] * s_di[a]; params[a] += s_di[a]; }     // calib.cpp:394
+        const int it = state[0];
+        sse_trace[it] = s_sse;
+        if (state[2] != 0) state[1] = 2;                // failed pivot: stop
+        else if (sqrt(tot) < 1e-8) state[1] = 1;        // calib.cpp:404 (the iteration counter is not advanced on the break)
+        else state[0] = it + 1;
+    }
+}
+
+int launch_calib_arrow_iteration(int n_views, int n_corners, double* params, const double* obj, const double* img, double* gram,
+                                 double* scratch, int* state, double* sse_trace, hipStream_t st) {
+    hipLaunchKernelGGL(calib_view_gram_kernel, dim3(n_views), dim3(256), 0, st, n_corners, params, obj, img, state, gram);
+    hipLaunchKernelGGL(calib_arrow_step_kernel, dim3(1), dim3(256), 0, st, n_views, gram, params, scratch, state, sse_trace);
+    STBA_HIP(hipGetLastError());
+    return STBA_OK;
+}
+
 int launch_calib_linearize(int n_views, int n_corners, const double* params, const double* obj, const double* img,
-                           double* e, double* Ji, double* Jx, double* Jd, double* sse_partial, hipStream_t st) {
+                           double* e, double* Ji, double* Jx, double* sse_partial, hipStream_t st) {
     const int total = n_views * n_corners;
     hipLaunchKernelGGL(calib_linearize_kernel, dim3((total + 255) / 256), dim3(256), 0, st, n_views, n_corners, params, obj,
-                       img, e, Ji, Jx, Jd, sse_partial);
+                       img, e, Ji, Jx, sse_partial);
     STBA_HIP(hipGetLastError());
     return STBA_OK;
 }

@@ -80,7 +80,10 @@ int launch_update(int n_cams, int n_pts, const double* cams, const double* pts, 
 int launch_triangulate(int n_pts, const int* pt_start, const int* obs_cam, const double2* feat, const double* cams,
                        double* pts, const unsigned char* pt_fixed, int max_iter, hipStream_t st);
 int launch_calib_linearize(int n_views, int n_corners, const double* params, const double* obj, const double* img,
-                           double* e, double* Ji, double* Jx, double* Jd, double* sse_partial, hipStream_t st);
+                           double* e, double* Ji, double* Jx, double* sse_partial, hipStream_t st);
+constexpr int CALIB_GRAM_DOUBLES = 136, CALIB_SCRATCH_DOUBLES = 114;      // per view
+int launch_calib_arrow_iteration(int n_views, int n_corners, double* params, const double* obj, const double* img, double* gram,
+                                 double* scratch, int* state, double* sse_trace, hipStream_t st);
 int launch_dense_normal(int n_res, int n, const double* J, const double* r, double* H, int ldh, double* g,
                         hipStream_t st);
 

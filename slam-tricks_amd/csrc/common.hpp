@@ -144,6 +144,54 @@ __host__ __device__ inline void se3_exp_rt(const double xi[6], double R[9], doub
     }
 }
 
+// Sophus-style SE3 helpers for the left-multiplicative pose update of the calibration (calib.cpp:397-402)
+__host__ __device__ inline void quat_mul(const double* a, const double* b, double* o) {
+    o[0] = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+    o[1] = a[3] * b[1] - a[0] * b[2] + a[1] * b[3] + a[2] * b[0];
+    o[2] = a[3] * b[2] + a[0] * b[1] - a[1] * b[0] + a[2] * b[3];
+    o[3] = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+}
+__host__ __device__ inline void so3_log(const double* q, double* w) {
+    const double n2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2];
+    double k;
+    if (n2 < 1e-20) k = 2.0 / q[3] - (2.0 / 3.0) * n2 / (q[3] * q[3] * q[3]);
+    else { const double nn = sqrt(n2); k = 2.0 * ((q[3] < 0) ? atan2(-nn, -q[3]) : atan2(nn, q[3])) / nn; }
+    w[0] = k * q[0]; w[1] = k * q[1]; w[2] = k * q[2];
+}
+__host__ __device__ inline void so3_left_jacobian(const double* w, double* Vm) {
+    const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+    double a, b;
+    if (th2 < 1e-20) { a = 0.5 - th2 / 24.0; b = 1.0 / 6.0 - th2 / 120.0; }
+    else { const double th = sqrt(th2); a = (1.0 - cos(th)) / th2; b = (th - sin(th)) / (th2 * th); }
+    const double K[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            const double k2 = K[i * 3] * K[j] + K[i * 3 + 1] * K[3 + j] + K[i * 3 + 2] * K[6 + j];
+            Vm[i * 3 + j] = (i == j ? 1.0 : 0.0) + a * K[i * 3 + j] + b * k2;
+        }
+}
+// xi <- log(exp(d) * exp(xi))
+__host__ __device__ inline void se3_left_update(const double* d, double* xi) {
+    double qa[4], qb[4], qc[4], Ra[9], ta[3], Rb[9], tb[3], tc[3];
+    so3_exp(d + 3, qa); so3_exp(xi + 3, qb);
+    se3_exp_rt(d, Ra, ta); se3_exp_rt(xi, Rb, tb);
+    quat_mul(qa, qb, qc);
+    const double nn = sqrt(qc[0] * qc[0] + qc[1] * qc[1] + qc[2] * qc[2] + qc[3] * qc[3]);
+    for (int k = 0; k < 4; ++k) qc[k] /= nn;
+    for (int i = 0; i < 3; ++i) tc[i] = Ra[i * 3] * tb[0] + Ra[i * 3 + 1] * tb[1] + Ra[i * 3 + 2] * tb[2] + ta[i];
+    double w[3], Vm[9];
+    so3_log(qc, w);
+    so3_left_jacobian(w, Vm);
+    // rho = V^-1 t (3x3 solve by Cramer)
+    const double a = Vm[0], b = Vm[1], c = Vm[2], dd = Vm[3], ee = Vm[4], f = Vm[5], g = Vm[6], h = Vm[7], i9 = Vm[8];
+    const double C0 = ee * i9 - f * h, C1 = f * g - dd * i9, C2 = dd * h - ee * g;
+    const double inv = 1.0 / (a * C0 + b * C1 + c * C2);
+    xi[0] = inv * (C0 * tc[0] + (c * h - b * i9) * tc[1] + (b * f - c * ee) * tc[2]);
+    xi[1] = inv * (C1 * tc[0] + (a * i9 - c * g) * tc[1] + (c * dd - a * f) * tc[2]);
+    xi[2] = inv * (C2 * tc[0] + (b * g - a * h) * tc[1] + (a * ee - b * dd) * tc[2]);
+    xi[3] = w[0]; xi[4] = w[1]; xi[5] = w[2];
+}
+
 // inverse of the symmetric 3x3 given as (xx,xy,xz,yy,yz,zz); returns false if not SPD-ish
 __host__ __device__ inline bool inv3_sym6(const double A[6], double Ai[6]) {
     const double a = A[0], b = A[1], c = A[2], d = A[3], e = A[4], f = A[5];

@@ -1323,71 +1323,31 @@ namespace {
 struct CalibWs {
     int V = 0, C = 0, n = 0;
     size_t no = 0;
-    double *params = nullptr, *obj = nullptr, *img = nullptr, *e = nullptr, *Ji = nullptr, *Jx = nullptr, *Jd = nullptr,
-           *H = nullptr, *g = nullptr, *part = nullptr, *sse = nullptr;
-    DenseWs w;
-    ~CalibWs() { for (double* p : {params, obj, img, e, Ji, Jx, Jd, H, g, part, sse}) if (p) (void)hipFree(p); }
-    int init(int n_views, int n_corners, const double* h_obj, const double* h_img, bool dense) {
+    double *params = nullptr, *obj = nullptr, *img = nullptr, *e = nullptr, *Ji = nullptr, *Jx = nullptr,
+           *gram = nullptr, *scratch = nullptr, *trace = nullptr, *part = nullptr, *sse = nullptr;
+    int* state = nullptr;
+    hipStream_t st = nullptr;
+    ~CalibWs() {
+        for (double* p : {params, obj, img, e, Ji, Jx, gram, scratch, trace, part, sse}) if (p) (void)hipFree(p);
+        if (state) (void)hipFree(state);
+    }
+    // arrow: the Gauss-Newton buffers (per-view Gram blocks, step scratch, iteration state, cost trace) instead of the
+    // per-corner outputs of stba_calib_evaluate
+    int init(int n_views, int n_corners, const double* h_obj, const double* h_img, bool arrow, int max_iter) {
         V = n_views; C = n_corners; n = 9 + 6 * V; no = (size_t)V * C;
-        STBA_TRY(w.init(n, nullptr));
         STBA_TRY(dev_alloc(&params, (size_t)n)); STBA_TRY(dev_alloc(&obj, no * 2)); STBA_TRY(dev_alloc(&img, no * 2));
-        STBA_TRY(dev_alloc(&e, no * 2)); STBA_TRY(dev_alloc(&Ji, no * 18)); STBA_TRY(dev_alloc(&Jx, no * 12));
-        STBA_TRY(dev_alloc(&part, (no + 255) / 256)); STBA_TRY(dev_alloc(&sse, (size_t)1));
-        if (dense) {
-            STBA_TRY(dev_alloc(&Jd, no * 2 * (size_t)n)); STBA_TRY(dev_alloc(&H, (size_t)n * n)); STBA_TRY(dev_alloc(&g, (size_t)n));
+        if (arrow) {
+            STBA_TRY(dev_alloc(&gram, (size_t)V * CALIB_GRAM_DOUBLES)); STBA_TRY(dev_alloc(&scratch, (size_t)V * CALIB_SCRATCH_DOUBLES));
+            STBA_TRY(dev_alloc(&trace, (size_t)max_iter)); STBA_TRY(dev_alloc(&state, (size_t)4));
+        } else {
+            STBA_TRY(dev_alloc(&e, no * 2)); STBA_TRY(dev_alloc(&Ji, no * 18)); STBA_TRY(dev_alloc(&Jx, no * 12));
+            STBA_TRY(dev_alloc(&part, (no + 255) / 256)); STBA_TRY(dev_alloc(&sse, (size_t)1));
         }
-        STBA_TRY(upload(obj, h_obj, no * 2, w.st)); STBA_TRY(upload(img, h_img, no * 2, w.st));
+        STBA_TRY(upload(obj, h_obj, no * 2, st)); STBA_TRY(upload(img, h_img, no * 2, st));
         return STBA_OK;
     }
 };
 
-// host Sophus-style SE3 helpers for the left-multiplicative pose update (calib.cpp:397-402)
-void quat_mul_h(const double* a, const double* b, double* o) {
-    o[0] = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
-    o[1] = a[3] * b[1] - a[0] * b[2] + a[1] * b[3] + a[2] * b[0];
-    o[2] = a[3] * b[2] + a[0] * b[1] - a[1] * b[0] + a[2] * b[3];
-    o[3] = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
-}
-void so3_log_h(const double* q, double* w) {
-    const double n2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2];
-    double k;
-    if (n2 < 1e-20) k = 2.0 / q[3] - (2.0 / 3.0) * n2 / (q[3] * q[3] * q[3]);
-    else { const double nn = std::sqrt(n2); k = 2.0 * ((q[3] < 0) ? std::atan2(-nn, -q[3]) : std::atan2(nn, q[3])) / nn; }
-    w[0] = k * q[0]; w[1] = k * q[1]; w[2] = k * q[2];
-}
-void left_jac_h(const double* w, double* Vm) {
-    const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
-    double a, b;
-    if (th2 < 1e-20) { a = 0.5 - th2 / 24.0; b = 1.0 / 6.0 - th2 / 120.0; }
-    else { const double th = std::sqrt(th2); a = (1.0 - std::cos(th)) / th2; b = (th - std::sin(th)) / (th2 * th); }
-    const double K[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) {
-            const double k2 = K[i * 3] * K[j] + K[i * 3 + 1] * K[3 + j] + K[i * 3 + 2] * K[6 + j];
-            Vm[i * 3 + j] = (i == j ? 1.0 : 0.0) + a * K[i * 3 + j] + b * k2;
-        }
-}
-// xi <- log(exp(d) * exp(xi))
-void se3_left_update_h(const double* d, double* xi) {
-    double qa[4], qb[4], qc[4], Ra[9], ta[3], Rb[9], tb[3], tc[3];
-    so3_exp(d + 3, qa); so3_exp(xi + 3, qb);
-    se3_exp_rt(d, Ra, ta); se3_exp_rt(xi, Rb, tb);
-    quat_mul_h(qa, qb, qc);
-    const double nn = std::sqrt(qc[0] * qc[0] + qc[1] * qc[1] + qc[2] * qc[2] + qc[3] * qc[3]);
-    for (double& v : qc) v /= nn;
-    for (int i = 0; i < 3; ++i) tc[i] = Ra[i * 3] * tb[0] + Ra[i * 3 + 1] * tb[1] + Ra[i * 3 + 2] * tb[2] + ta[i];
-    double w[3], Vm[9];
-    so3_log_h(qc, w);
-    left_jac_h(w, Vm);
-    // rho = V^-1 t (3x3 solve by Cramer)
-    const double a = Vm[0], b = Vm[1], c = Vm[2], dd = Vm[3], ee = Vm[4], f = Vm[5], g = Vm[6], h = Vm[7], i9 = Vm[8];
-    const double C0 = ee * i9 - f * h, C1 = f * g - dd * i9, C2 = dd * h - ee * g;
-    const double inv = 1.0 / (a * C0 + b * C1 + c * C2);
-    xi[0] = inv * (C0 * tc[0] + (c * h - b * i9) * tc[1] + (b * f - c * ee) * tc[2]);
-    xi[1] = inv * (C1 * tc[0] + (a * i9 - c * g) * tc[1] + (c * dd - a * f) * tc[2]);
-    xi[2] = inv * (C2 * tc[0] + (b * g - a * h) * tc[1] + (a * ee - b * dd) * tc[2]);
-    xi[3] = w[0]; xi[4] = w[1]; xi[5] = w[2];
-}
 }  // namespace
 
 int stba_calib_evaluate(int n_views, int n_corners, const double* params, const double* obj, const double* img,
@@ -1395,55 +1355,44 @@ int stba_calib_evaluate(int n_views, int n_corners, const double* params, const 
     if (n_views <= 0 || n_corners <= 0 || !params || !obj || !img) return fail(STBA_ERR_INVALID_ARGUMENT, "bad argument");
     STBA_TRY(require_device());
     CalibWs c;
-    STBA_TRY(c.init(n_views, n_corners, obj, img, false));
-    STBA_TRY(upload(c.params, params, (size_t)c.n, c.w.st));
-    STBA_TRY(launch_calib_linearize(c.V, c.C, c.params, c.obj, c.img, c.e, c.Ji, c.Jx, nullptr, c.part, c.w.st));
-    STBA_TRY(launch_sum_partials(c.part, (int)((c.no + 255) / 256), 1, 1, c.sse, c.w.st));
-    if (sse) STBA_TRY(download(sse, c.sse, 1, c.w.st));
-    if (e) STBA_TRY(download(e, c.e, c.no * 2, c.w.st));
-    if (Ji) STBA_TRY(download(Ji, c.Ji, c.no * 18, c.w.st));
-    if (Jx) STBA_TRY(download(Jx, c.Jx, c.no * 12, c.w.st));
-    STBA_HIP(hipStreamSynchronize(c.w.st));
+    STBA_TRY(c.init(n_views, n_corners, obj, img, false, 0));
+    STBA_TRY(upload(c.params, params, (size_t)c.n, c.st));
+    STBA_TRY(launch_calib_linearize(c.V, c.C, c.params, c.obj, c.img, c.e, c.Ji, c.Jx, c.part, c.st));
+    STBA_TRY(launch_sum_partials(c.part, (int)((c.no + 255) / 256), 1, 1, c.sse, c.st));
+    if (sse) STBA_TRY(download(sse, c.sse, 1, c.st));
+    if (e) STBA_TRY(download(e, c.e, c.no * 2, c.st));
+    if (Ji) STBA_TRY(download(Ji, c.Ji, c.no * 18, c.st));
+    if (Jx) STBA_TRY(download(Jx, c.Jx, c.no * 12, c.st));
+    STBA_HIP(hipStreamSynchronize(c.st));
     return STBA_OK;
 }
 
+// CalibSolver::totalOptimization (calib.cpp:282-422) with the arrow structure of its normal equations exploited and
+// everything resident on the device (ba_kernels.hip, "Gauss-Newton with the ARROW structure"): per iteration one kernel
+// forms the per-view 16 x 16 Gram blocks, one solves the 9 x 9 Schur complement, back-substitutes the poses, applies the
+// update and records {cost, stop test}.  The host enqueues max_iter iterations (the ones behind the stop are empty
+// launches) and reads parameters, trace and state once.
 int stba_calib_gauss_newton(int n_views, int n_corners, double* params, const double* obj, const double* img,
                             int max_iter, double* sse_trace, int* iterations) {
     if (n_views <= 0 || n_corners <= 0 || !params || !obj || !img || max_iter <= 0)
         return fail(STBA_ERR_INVALID_ARGUMENT, "bad argument");
     STBA_TRY(require_device());
     CalibWs c;
-    STBA_TRY(c.init(n_views, n_corners, obj, img, true));
-    const int n = c.n;
-    std::vector<double> H((size_t)n * n), g(n);
-    int iter = 0;
-    for (; iter != max_iter; ++iter) {                                    // calib.cpp:303
-        STBA_TRY(upload(c.params, params, (size_t)n, c.w.st));
-        STBA_HIP(hipMemsetAsync(c.Jd, 0, c.no * 2 * (size_t)n * sizeof(double), c.w.st));
-        STBA_TRY(launch_calib_linearize(c.V, c.C, c.params, c.obj, c.img, c.e, nullptr, nullptr, c.Jd, c.part, c.w.st));
-        STBA_TRY(launch_sum_partials(c.part, (int)((c.no + 255) / 256), 1, 1, c.sse, c.w.st));
-        STBA_HIP(hipMemsetAsync(c.H, 0, (size_t)n * n * sizeof(double), c.w.st));
-        STBA_TRY(launch_dense_normal((int)(c.no * 2), n, c.Jd, c.e, c.H, n, c.g, c.w.st));   // H += J J^T, :383-389
-        double sse = 0.0;
-        STBA_TRY(download(&sse, c.sse, 1, c.w.st));
-        STBA_TRY(download(H.data(), c.H, H.size(), c.w.st)); STBA_TRY(download(g.data(), c.g, g.size(), c.w.st));
-        STBA_HIP(hipStreamSynchronize(c.w.st));
-        if (sse_trace) sse_trace[iter] = sse;
-        for (double& v : g) v = -v;                                       // g -= J e
-        STBA_TRY(c.w.load(H.data(), g.data()));
-        STBA_TRY(chol_factor_solve_dev(c.w.A, c.w.lda, n, c.w.x, c.w.flag, c.w.st));   // H.ldlt().solve(g), :393
-        int flag_h = 0;
-        STBA_TRY(download(&flag_h, c.w.flag, 1, c.w.st)); STBA_TRY(download(g.data(), c.w.x, (size_t)n, c.w.st));
-        STBA_HIP(hipStreamSynchronize(c.w.st));
-        STBA_TRY(chol_flag_status(flag_h));
-        if (flag_h) return fail(STBA_ERR_NOT_POSITIVE_DEFINITE, "calibration normal equations: pivot " + std::to_string(flag_h));
-        double un = 0.0;
-        for (int a = 0; a < n; ++a) un += g[a] * g[a];
-        for (int a = 0; a < 9; ++a) params[a] += g[a];                    // :394
-        for (int v = 0; v < n_views; ++v) se3_left_update_h(&g[9 + v * 6], &params[9 + v * 6]);   // :397-402
-        if (std::sqrt(un) < 1e-8) break;                                  // :404
-    }
-    if (iterations) *iterations = iter;
+    STBA_TRY(c.init(n_views, n_corners, obj, img, true, max_iter));
+    STBA_TRY(upload(c.params, params, (size_t)c.n, c.st));
+    STBA_HIP(hipMemsetAsync(c.state, 0, 4 * sizeof(int), c.st));
+    for (int iter = 0; iter != max_iter; ++iter)                           // calib.cpp:303
+        STBA_TRY(launch_calib_arrow_iteration(c.V, c.C, c.params, c.obj, c.img, c.gram, c.scratch, c.state, c.trace, c.st));
+    int state[4] = {0, 0, 0, 0};
+    std::vector<double> tr((size_t)max_iter);
+    STBA_TRY(download(state, c.state, 4, c.st));
+    STBA_TRY(download(tr.data(), c.trace, tr.size(), c.st));
+    STBA_TRY(download(params, c.params, (size_t)c.n, c.st));
+    STBA_HIP(hipStreamSynchronize(c.st));
+    const int executed = std::min(max_iter, state[0] + (state[1] != 0 ? 1 : 0));
+    if (sse_trace) for (int k = 0; k < executed; ++k) sse_trace[k] = tr[(size_t)k];
+    if (iterations) *iterations = state[0];
+    if (state[2] != 0) return fail(STBA_ERR_NOT_POSITIVE_DEFINITE, "calibration normal equations: pivot " + std::to_string(state[2]));
     return STBA_OK;
 }
 
