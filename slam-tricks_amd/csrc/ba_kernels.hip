@@ -769,6 +769,74 @@ int launch_reduced_add_camera(int n_cams, const double* Hcc, const double* gc, d
     return STBA_OK;
 }
 
+// One rank: the four small steps between the Schur complement and the factorisation in ONE launch --
+// ba_reduced_add_camera_kernel (S += Hcc blocks, rhs -= gc, the diagonal and gc copied out), lm_diagonal_kernel on the
+// camera diagonal, ba_reduced_damp_kernel and the padding of the factorisation (rows [n, lda): identity; the last row
+// carries the right-hand side).  Same arithmetic in the same order as the four kernels (bit-identical); with several
+// ranks the cross-rank sum sits between the first and the second step, and the separate kernels are used.
+__global__ __launch_bounds__(256) void ba_reduced_finalize_kernel(int n_cams, int n, const double* __restrict__ Hcc,
+                                                                  const double* __restrict__ gc, const unsigned char* __restrict__ cam_fixed,
+                                                                  double* __restrict__ S, int lda, double* __restrict__ rhs,
+                                                                  double* __restrict__ ex_diag, double* __restrict__ ex_gc,
+                                                                  double* __restrict__ scale, int init_scale, int use_scaling,
+                                                                  double radius, double dmin, double dmax, double* __restrict__ dc,
+                                                                  int blocks_cam) {
+    if ((int)blockIdx.x >= blocks_cam) {
+        // padding rows (chol_pad_kernel); the first n entries of the last row are written by the diagonal threads below
+        const int r = n + ((int)blockIdx.x - blocks_cam);
+        if (r >= lda) return;
+        double* row = S + (size_t)r * lda;
+        const bool last = (r == lda - 1);
+        for (int c = threadIdx.x; c < lda; c += 256) {
+            if (last && c < n) continue;
+            row[c] = (c == r) ? 1.0 : 0.0;
+        }
+        return;
+    }
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    const int c = gid / 36, k = gid - c * 36;
+    if (c >= n_cams) return;
+    const int a = k / 6, b = k - a * 6;
+    const double h = Hcc[(size_t)c * 36 + k];
+    if (a != b) {
+        if (b < a) S[(size_t)(c * 6 + a) * lda + c * 6 + b] += h;
+        return;
+    }
+    const int i = c * 6 + a;
+    double sd = S[(size_t)i * lda + i] + h;
+    ex_diag[i] = h;
+    const double g = gc[i];
+    ex_gc[i] = g;
+    double rv = rhs[i] - g;
+    // lm_diagonal_kernel, kind 2
+    double sc = 1.0;
+    if (use_scaling) {
+        if (init_scale) { sc = 1.0 / (1.0 + sqrt(h)); scale[i] = sc; }
+        else sc = scale[i];
+    } else if (init_scale) scale[i] = 1.0;
+    const double s2 = sc * sc;
+    const double v = fmin(fmax(h * s2, dmin), dmax);
+    const double d = v / radius / s2;
+    dc[i] = d;
+    // ba_reduced_damp_kernel
+    const bool fx = cam_fixed ? ((cam_fixed[c] >> a) & 1u) : false;
+    if (fx) { sd += 1.0; rv = 0.0; }
+    else sd += d;
+    S[(size_t)i * lda + i] = sd;
+    rhs[i] = rv;
+    S[(size_t)(lda - 1) * lda + i] = rv;
+}
+
+int launch_reduced_finalize(int n_cams, int n, const double* Hcc, const double* gc, const unsigned char* cam_fixed, double* S, int lda,
+                            double* rhs, double* ex_diag, double* ex_gc, double* scale, int init_scale, int use_scaling,
+                            double radius, double dmin, double dmax, double* dc, hipStream_t st) {
+    const int blocks_cam = (n_cams * 36 + 255) / 256;
+    hipLaunchKernelGGL(ba_reduced_finalize_kernel, dim3(blocks_cam + (lda - n)), dim3(256), 0, st, n_cams, n, Hcc, gc, cam_fixed, S, lda,
+                       rhs, ex_diag, ex_gc, scale, init_scale, use_scaling, radius, dmin, dmax, dc, blocks_cam);
+    STBA_HIP(hipGetLastError());
+    return STBA_OK;
+}
+
 int launch_reduced_damp(int n, const double* dc, const unsigned char* cam_fixed, double* S, int lda, double* rhs,
                         hipStream_t st) {
     hipLaunchKernelGGL(ba_reduced_damp_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, dc, cam_fixed, S, lda,

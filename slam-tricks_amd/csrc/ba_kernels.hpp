@@ -69,6 +69,9 @@ size_t schur_rows_lds_bytes(int max_cols);
 int launch_schur_rows(const SchurRowArgs& a, int n_tasks, hipStream_t st);
 int launch_reduced_add_camera(int n_cams, const double* Hcc, const double* gc, double* S, int lda, double* rhs,
                               double* ex_diag, double* ex_gc, hipStream_t st);
+int launch_reduced_finalize(int n_cams, int n, const double* Hcc, const double* gc, const unsigned char* cam_fixed, double* S, int lda,
+                            double* rhs, double* ex_diag, double* ex_gc, double* scale, int init_scale, int use_scaling,
+                            double radius, double dmin, double dmax, double* dc, hipStream_t st);
 int launch_reduced_damp(int n, const double* dc, const unsigned char* cam_fixed, double* S, int lda, double* rhs,
                         hipStream_t st);
 int launch_backsub(int n_pts, const int* pt_start, const int* obs_cam, const double* J8, const unsigned char* omask,

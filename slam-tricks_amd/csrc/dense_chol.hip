@@ -2354,7 +2354,22 @@ static int chol_run(double* A, int lda, int n, double* x_dev, int* flag_dev, hip
                                          hipFuncAttributeMaxDynamicSharedMemorySize, MEGA_SMEM_BYTES));
             return STBA_OK;
         }));
-        hipLaunchKernelGGL(chol_mega_kernel, dim3(plan.ncu), dim3(512), MEGA_SMEM_BYTES, st, ma);
+        // Two persistent kernels must not share the device: each needs four workgroups of one XCD at the same time (the
+        // TU tasks), and with the CUs split unevenly between two of them each can starve the other on a different XCD
+        // (seen as a dependency time-out with two engines driven from two threads).  Factorisations of one process are
+        // therefore chained on the device, stream to stream, through an event; the host does not wait.
+        {
+            struct Chain { std::mutex m; hipEvent_t last = nullptr; };
+            static std::mutex chains_m;
+            static std::map<int, Chain> chains;
+            Chain* ch;
+            { std::lock_guard<std::mutex> g(chains_m); ch = &chains[cur_dev]; }
+            std::lock_guard<std::mutex> g(ch->m);
+            if (!ch->last) STBA_HIP(hipEventCreateWithFlags(&ch->last, hipEventDisableTiming));
+            else STBA_HIP(hipStreamWaitEvent(st, ch->last, 0));
+            hipLaunchKernelGGL(chol_mega_kernel, dim3(plan.ncu), dim3(512), MEGA_SMEM_BYTES, st, ma);
+            STBA_HIP(hipEventRecord(ch->last, st));
+        }
         if (TRACE) {    // debugging aid: dump the task timeline of this factorisation (tools/mega_trace.py)
             std::vector<long long> h((size_t)plan.ntasks * 8);
             std::vector<int4> ht((size_t)plan.ntasks);

@@ -55,7 +55,8 @@ static int download(T* dst, const T* src, size_t count, hipStream_t st) {
 // scalar slots in the extras region behind S (summed across ranks together with S)
 enum { SC_COST2 = 0, SC_GPMAX0 = 8, SC_MAX_WORLD = 64 };
 // trial-point scalars: [0..3] summed across ranks (landmark shards), [4..6] camera terms
-enum { TS_COST2 = 0, TS_STEP2 = 1, TS_X2 = 2, TS_MODEL = 3, TS_CAM = 4, TS_COUNT = 8 };
+enum { TS_COST2 = 0, TS_STEP2 = 1, TS_X2 = 2, TS_MODEL = 3, TS_CAM = 4, TS_COUNT = 8,
+       TS_SPEC_COST2 = 8 };      // (behind the trial block: cost of the speculative linearisation at the trial point)
 
 }  // namespace stba
 
@@ -102,7 +103,9 @@ struct stba_ba {
     double* Sbuf = nullptr;   // [S lda*lda | ex_diag lda | ex_gc lda | rhs lda | ex_scalar lda]
     double *dxc = nullptr, *dxp = nullptr;
     double *cost_partial = nullptr, *upd_partial_c = nullptr, *upd_partial_p = nullptr;
-    double* trial = nullptr;   // TS_COUNT doubles
+    double* trial = nullptr;   // TS_COUNT + 1 doubles
+    double* ts_host = nullptr;   // mapped pinned host memory: the trial block + the factorisation flag, written by a kernel
+    double* ts_host_dev = nullptr;
     int* flag = nullptr;
     int lin_grid = 1;
     stba_allreduce_fn ar = nullptr;
@@ -110,8 +113,9 @@ struct stba_ba {
     int rank = 0, world = 1;
     bool have_lin = false, have_blocks = false, have_reduced = false, have_dxc = false, have_dxp = false;
     bool scale_init = false;
-    hipEvent_t ev[12] = {};
+    hipEvent_t ev[15] = {};     // [12]: the trial block has reached the host; [13], [14]: second pair for the speculative linearisation
     double* lin_pin = nullptr;      // pinned host copy of [scalars (SC_GPMAX0 + world) | gc (n)], read one solve later
+    double* lin_pin_dev = nullptr;  // (its device address)
 
     double* S() const { return Sbuf; }
     double* ex_diag() const { return Sbuf + (size_t)lda * lda; }
@@ -146,6 +150,7 @@ static void ba_free(stba_ba* b) {
     F(b->cost_partial); F(b->upd_partial_c); F(b->upd_partial_p); F(b->trial); F(b->flag);
     for (auto& e : b->ev) if (e) (void)hipEventDestroy(e);
     if (b->lin_pin) (void)hipHostFree(b->lin_pin);
+    if (b->ts_host) (void)hipHostFree(b->ts_host);
     if (b->own_stream && b->st) (void)hipStreamDestroy(b->st);
     delete b;
 }
@@ -284,6 +289,13 @@ static int ba_build_reduced(stba_ba* b, const Damping& dm) {
         STBA_TRY(launch_schur(b->no, b->obs_cam, b->obs_pt, b->pt_start, b->J8, b->omask, b->Hinv6, b->gp, b->S(),
                               b->lda, b->rhs(), b->st));
     }
+    if (!b->ar && !dm.explicit_d && b->n == 6 * b->nc) {
+        // one rank: camera blocks, LM diagonal, damping and padding in one launch
+        STBA_TRY(launch_reduced_finalize(b->nc, b->n, b->Hcc, b->gc, b->cam_fixed, b->S(), b->lda, b->rhs(), b->ex_diag(), b->ex_gc(),
+                                         b->scale_c, init_scale, dm.use_scaling, dm.radius, dm.dmin, dm.dmax, b->dc, b->st));
+        b->scale_init = true;
+        return STBA_OK;
+    }
     STBA_TRY(launch_reduced_add_camera(b->nc, b->Hcc, b->gc, b->S(), b->lda, b->rhs(), b->ex_diag(), b->ex_gc(),
                                        b->st));
     if (b->ar) {
@@ -331,6 +343,14 @@ static int ba_trial(stba_ba* b) {
     return STBA_OK;
 }
 
+// the trial block and the factorisation's flag, written straight into mapped host memory: the host waits for an event
+// behind this kernel instead of a device-to-host copy + stream synchronisation, and the stream can go on
+__global__ void export_trial_kernel(const double* __restrict__ trial, const int* __restrict__ flag, double* __restrict__ out) {
+    const int k = threadIdx.x;
+    if (k < TS_COUNT) out[k] = trial[k];
+    else if (k == TS_COUNT) out[k] = (double)flag[0];
+}
+
 struct LMState {
     double cost = 0, gmax = 0, radius = 0, decrease = 2.0, x_norm = 0;
 };
@@ -370,11 +390,24 @@ static int ba_read_linear_scalars(stba_ba* b, double* cost, double* gmax) {
 // The same read, split: the copies are enqueued behind the reduced-system build into pinned memory and
 // consumed after the NEXT synchronisation (the trial point's), so that the factorisation is enqueued without
 // a host round trip in between (a 115 us bubble per iteration at C5)
+__global__ __launch_bounds__(256) void export_linear_kernel(const double* __restrict__ scalars, int nh, const double* __restrict__ gc,
+                                                            int n, double* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < nh) out[i] = scalars[i];
+    else if (i < nh + n) out[i] = gc[i - nh];
+}
+// (written by a kernel into mapped host memory: two device-to-host copies here cost ~30 us of idle GPU between the
+// compute queue and the copy engine, in front of every factorisation)
 static int ba_request_linear_scalars(stba_ba* b) {
     const size_t nh = (size_t)SC_GPMAX0 + b->world;
-    if (!b->lin_pin) STBA_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->lin_pin), (nh + (size_t)b->n) * sizeof(double)));
-    STBA_TRY(download(b->lin_pin, b->ex_scalar(), nh, b->st));
-    STBA_TRY(download(b->lin_pin + nh, b->ex_gc(), (size_t)b->n, b->st));
+    if (!b->lin_pin) {
+        STBA_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->lin_pin), (nh + (size_t)b->n) * sizeof(double), hipHostMallocMapped));
+        STBA_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&b->lin_pin_dev), b->lin_pin, 0));
+    }
+    const int total = (int)nh + b->n;
+    hipLaunchKernelGGL(export_linear_kernel, dim3((total + 255) / 256), dim3(256), 0, b->st, b->ex_scalar(), (int)nh, b->ex_gc(), b->n,
+                       b->lin_pin_dev);
+    STBA_HIP(hipGetLastError());
     return STBA_OK;
 }
 static void ba_finish_linear_scalars(const stba_ba* b, double* cost, double* gmax) {   // after a stream synchronisation
@@ -414,10 +447,11 @@ static int ba_run_lm(stba_ba* b, const stba_lm_options* opt_in, int fixed_iterat
     bool need_build = true;      // reduced system must be (re)built before the next solve
     bool lin_timing_pending = true;
 
+    static const bool SPECULATE = [] { const char* e = getenv("STBA_LM_SPECULATE"); return !e || atoi(e) != 0; }();
     // deferred read of (cost, |g|max) of a freshly linearised point: only when nobody watches the iterations
     const bool deferred_ok = (cb == nullptr) && !opt.minimizer_progress_to_stdout;
     bool pending = false, pending_accepted = false;
-    int pending_iter = 0;
+    int pending_iter = 0, pending_lin_ev = 8, spec_ev = 13;
 
     int iter = 0;
     s.termination_type = STBA_NO_CONVERGENCE;
@@ -469,14 +503,42 @@ static int ba_run_lm(stba_ba* b, const stba_lm_options* opt_in, int fixed_iterat
         STBA_TRY(ba_trial(b));
         STBA_HIP(hipEventRecord(ev[6], b->st));
         double ts[TS_COUNT];
-        STBA_TRY(download(ts, b->trial, TS_COUNT, b->st));
-        STBA_TRY(download(&flag_h, b->flag, 1, b->st));
-        STBA_HIP(hipStreamSynchronize(b->st));
+        // Nobody watches the iterations and there is one rank: the host learns the trial point's scalars through mapped
+        // memory and an event, and meanwhile the stream already linearises AT THE TRIAL POINT -- a step is accepted far
+        // more often than not, and the host's round trip (wake-up, decision, enqueue: ~35 us) would otherwise be a
+        // bubble on the GPU in every iteration.  A rejected step costs one linearisation at the old point (below).
+        const bool fast = deferred_ok && !b->ar && SPECULATE;
+        bool speculated = false;
+        if (fast) {
+            if (!b->ts_host) {
+                STBA_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->ts_host), (TS_COUNT + 1) * sizeof(double), hipHostMallocMapped));
+                STBA_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&b->ts_host_dev), b->ts_host, 0));
+            }
+            hipLaunchKernelGGL(export_trial_kernel, dim3(1), dim3(64), 0, b->st, b->trial, b->flag, b->ts_host_dev);
+            STBA_HIP(hipEventRecord(ev[12], b->st));
+            if (!(fixed && iter >= max_iter)) {
+                // (its own pair of events, alternating: the previous linearisation's pair is read behind the synchronisation below)
+                spec_ev = (spec_ev == 8) ? 13 : 8;
+                STBA_HIP(hipEventRecord(ev[spec_ev], b->st));
+                STBA_TRY(ba_linearize(b, b->cur ^ 1, b->trial + TS_SPEC_COST2));
+                STBA_TRY(ba_normal_blocks(b));
+                STBA_HIP(hipEventRecord(ev[spec_ev + 1], b->st));
+                STBA_TRY(ba_fill_scalar_slots(b, b->trial + TS_SPEC_COST2));
+                speculated = true;
+            }
+            STBA_HIP(hipEventSynchronize(ev[12]));
+            for (int k = 0; k < TS_COUNT; ++k) ts[k] = b->ts_host[k];
+            flag_h = (int)b->ts_host[TS_COUNT];
+        } else {
+            STBA_TRY(download(ts, b->trial, TS_COUNT, b->st));
+            STBA_TRY(download(&flag_h, b->flag, 1, b->st));
+            STBA_HIP(hipStreamSynchronize(b->st));
+        }
         STBA_TRY(chol_flag_status(flag_h));          // (only valid after the synchronisation: the copy is asynchronous)
         if (pending) {
             double c2, g2;
             ba_finish_linear_scalars(b, &c2, &g2);
-            (void)hipEventElapsedTime(&ms, ev[8], ev[9]); s.ms_linearize += ms;
+            (void)hipEventElapsedTime(&ms, ev[pending_lin_ev], ev[pending_lin_ev + 1]); s.ms_linearize += ms;
             (void)hipEventElapsedTime(&ms, ev[10], ev[11]); s.ms_schur += ms;
             L.gmax = g2;
             if (pending_accepted) L.cost = c2;
@@ -545,13 +607,15 @@ static int ba_run_lm(stba_ba* b, const stba_lm_options* opt_in, int fixed_iterat
         }
         need_build = true;
         if ((accepted || fixed) && !(fixed && iter >= max_iter)) {
-            // re-linearise at the (new) current point
+            // re-linearise at the (new) current point -- unless the stream has done so already
             const int e0 = deferred_ok ? 8 : 0, e2 = deferred_ok ? 10 : 2;
-            STBA_HIP(hipEventRecord(ev[e0], b->st));
-            STBA_TRY(ba_linearize(b, b->cur, b->trial + TS_COST2));
-            STBA_TRY(ba_normal_blocks(b));
-            STBA_HIP(hipEventRecord(ev[e0 + 1], b->st));
-            STBA_TRY(ba_fill_scalar_slots(b, b->trial + TS_COST2));
+            if (!(speculated && accepted)) {
+                STBA_HIP(hipEventRecord(ev[e0], b->st));
+                STBA_TRY(ba_linearize(b, b->cur, b->trial + TS_COST2));
+                STBA_TRY(ba_normal_blocks(b));
+                STBA_HIP(hipEventRecord(ev[e0 + 1], b->st));
+                STBA_TRY(ba_fill_scalar_slots(b, b->trial + TS_COST2));
+            }
             // gradient of the new point is needed for the convergence test: it arrives with the
             // next reduced-system build (one collective per iteration); build it now.
             dm.radius = L.radius;
@@ -564,6 +628,7 @@ static int ba_run_lm(stba_ba* b, const stba_lm_options* opt_in, int fixed_iterat
                 // (cost, |g|max) of the new point are consumed after the next synchronisation
                 STBA_TRY(ba_request_linear_scalars(b));
                 pending = true; pending_accepted = accepted; pending_iter = iter;
+                pending_lin_ev = (speculated && accepted) ? spec_ev : 8;
                 if (accepted) L.cost = new_cost;
             } else {
                 double c2, g2;
@@ -573,6 +638,12 @@ static int ba_run_lm(stba_ba* b, const stba_lm_options* opt_in, int fixed_iterat
                 L.gmax = g2;
                 if (accepted) L.cost = c2;   // same value as new_cost up to summation order
             }
+        }
+        else if (speculated && !accepted) {
+            // the speculative linearisation overwrote the residuals, Jacobians and blocks of the current point
+            STBA_TRY(ba_linearize(b, b->cur, b->trial + TS_COST2));
+            STBA_TRY(ba_normal_blocks(b));
+            STBA_TRY(ba_fill_scalar_slots(b, b->trial + TS_COST2));
         }
         if (trace) { trace[(size_t)iter * STBA_TRACE_COLS + 2] = L.gmax; trace[(size_t)iter * STBA_TRACE_COLS + 5] = L.radius; }
         if (opt.minimizer_progress_to_stdout)
@@ -886,7 +957,7 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
     A_(dev_alloc(&b->cost_partial, (size_t)b->lin_grid));
     A_(dev_alloc(&b->upd_partial_c, (size_t)((n_cams + 255) / 256) * 4));
     A_(dev_alloc(&b->upd_partial_p, (size_t)((n_pts + 255) / 256 + 1) * 4));
-    A_(dev_alloc(&b->trial, (size_t)TS_COUNT)); A_(dev_alloc(&b->flag, 1));
+    A_(dev_alloc(&b->trial, (size_t)TS_COUNT + 1)); A_(dev_alloc(&b->flag, 1));
 
     tmark("device allocations");
     A_(upload(b->cams[0], cams, nc * 7, b->st)); A_(upload(b->pts[0], pts, np * 3, b->st));
