@@ -205,6 +205,60 @@ int launch_absmax(const double* v, size_t n, const double* v2, size_t n2, double
     return STBA_OK;
 }
 
+// |gp|max of this rank and the cost into their slots of the scalar block behind S, the rest of the block zeroed: the second
+// stage of launch_absmax, the memset and the one-double copy of the separate path in one launch
+__global__ __launch_bounds__(256) void scalar_slots_final_kernel(const double* __restrict__ partial, int n, const double* __restrict__ cost2,
+                                                                 double* __restrict__ slots, int n_slots, int cost_slot, int max_slot) {
+    __shared__ double s[256];
+    double m = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) m = fmax(m, partial[i]);
+    s[threadIdx.x] = m;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) s[threadIdx.x] = fmax(s[threadIdx.x], s[threadIdx.x + off]);
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < n_slots; i += 256) slots[i] = (i == cost_slot) ? cost2[0] : (i == max_slot) ? s[0] : 0.0;
+}
+
+int launch_scalar_slots(const double* v, size_t n, const double* cost2, double* slots, int n_slots, int cost_slot, int max_slot,
+                        double* partial, int n_partial, hipStream_t st) {
+    int grid = (int)std::min<size_t>((size_t)n_partial, std::max<size_t>(1, (n + 2047) / 2048));
+    hipLaunchKernelGGL(absmax_partial_kernel, dim3(grid), dim3(256), 0, st, v, n, (const double*)nullptr, (size_t)0, partial);
+    hipLaunchKernelGGL(scalar_slots_final_kernel, dim3(1), dim3(256), 0, st, partial, grid, cost2, slots, n_slots, cost_slot, max_slot);
+    STBA_HIP(hipGetLastError());
+    return STBA_OK;
+}
+
+// the trial block of one LM iteration: the three sums of the landmark update's partials into out[1..3], the three of the
+// camera update's into out[4..6] (same summation order as sum_partials_kernel), out[0] and out[7] zeroed -- the memset
+// and the two single-block sums of the separate path in one launch
+__global__ __launch_bounds__(256) void trial_sums_kernel(const double* __restrict__ part_p, int n_p, const double* __restrict__ part_c,
+                                                         int n_c, double* __restrict__ out) {
+    __shared__ double s[256];
+    for (int q = 0; q < 6; ++q) {
+        const double* partial = q < 3 ? part_p : part_c;
+        const int n = q < 3 ? n_p : n_c, k = q < 3 ? q : q - 3;
+        double v = 0.0;
+        for (int i = threadIdx.x; i < n; i += 256) v += partial[(size_t)i * 4 + k];
+        s[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) {
+            if (threadIdx.x < off) s[threadIdx.x] += s[threadIdx.x + off];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) out[1 + q] = s[0];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out[0] = 0.0; out[7] = 0.0; }
+}
+
+int launch_trial_sums(const double* part_p, int n_p, const double* part_c, int n_c, double* out, hipStream_t st) {
+    hipLaunchKernelGGL(trial_sums_kernel, dim3(1), dim3(256), 0, st, part_p, n_p, part_c, n_c, out);
+    STBA_HIP(hipGetLastError());
+    return STBA_OK;
+}
+
 // compact Jacobian of observation i -> the 2x6 camera block (d/dtheta | d/dt) and the 2x3 landmark block; columns of
 // constant dofs (mask bits 0..5) and of constant landmarks (bit 6) are zero, as the stored form used to have them
 __device__ inline void load_jc_jp(const double* __restrict__ J8, const unsigned char* __restrict__ omask, int i,
@@ -418,6 +472,51 @@ __global__ __launch_bounds__(256) void ba_point_invert_kernel(int n_pts, const d
     }
 #pragma unroll
     for (int k = 0; k < 6; ++k) Hinv6[(size_t)j * 6 + k] = Hi[k];
+}
+
+// the same with the landmark's LM diagonal computed on the way (lm_diagonal_kernel, kind 1: diagonal of the packed 3x3
+// block) and stored in dp / scale_p as the separate kernel does
+__global__ __launch_bounds__(256) void ba_point_damp_invert_kernel(int n_pts, const double* __restrict__ Hpp6,
+                                                                   const unsigned char* __restrict__ pt_fixed,
+                                                                   double* __restrict__ scale, int init_scale, int use_scaling,
+                                                                   double radius, double dmin, double dmax, double* __restrict__ dp,
+                                                                   double* __restrict__ Hinv6) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n_pts) return;
+    double H[6], Hi[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 6; ++k) H[k] = Hpp6[(size_t)j * 6 + k];
+    const int dg[3] = {0, 3, 5};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const size_t i = (size_t)j * 3 + k;
+        const double h = H[dg[k]];
+        double s = 1.0;
+        if (use_scaling) {
+            if (init_scale) { s = 1.0 / (1.0 + sqrt(h)); scale[i] = s; }
+            else s = scale[i];
+        } else if (init_scale) scale[i] = 1.0;
+        const double s2 = s * s;
+        const double v = fmin(fmax(h * s2, dmin), dmax);
+        const double d = v / radius / s2;
+        dp[i] = d;
+        H[dg[k]] = h + d;
+    }
+    const bool fixed = pt_fixed ? (pt_fixed[j] != 0) : false;
+    if (fixed || !inv3_sym6(H, Hi)) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) Hi[k] = 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) Hinv6[(size_t)j * 6 + k] = Hi[k];
+}
+
+int launch_point_damp_invert(int n_pts, const double* Hpp6, const unsigned char* pt_fixed, double* scale, int init_scale,
+                             int use_scaling, double radius, double dmin, double dmax, double* dp, double* Hinv6, hipStream_t st) {
+    hipLaunchKernelGGL(ba_point_damp_invert_kernel, dim3((n_pts + 255) / 256), dim3(256), 0, st, n_pts, Hpp6, pt_fixed, scale,
+                       init_scale, use_scaling, radius, dmin, dmax, dp, Hinv6);
+    STBA_HIP(hipGetLastError());
+    return STBA_OK;
 }
 
 int launch_point_invert(int n_pts, const double* Hpp6, const double* dp, const unsigned char* pt_fixed,

@@ -36,6 +36,11 @@ int launch_camera_blocks(int n_cams, int n_chunks, const int* chunk_begin, const
                          const double2* r, double* partial, double* Hcc, double* gc, hipStream_t st);
 int launch_lm_diagonal(int n, int bs, int bstride, int kind, const double* H, double* scale, int init_scale,
                        int use_scaling, double radius, double dmin, double dmax, double* d, hipStream_t st);
+int launch_point_damp_invert(int n_pts, const double* Hpp6, const unsigned char* pt_fixed, double* scale, int init_scale,
+                             int use_scaling, double radius, double dmin, double dmax, double* dp, double* Hinv6, hipStream_t st);
+int launch_scalar_slots(const double* v, size_t n, const double* cost2, double* slots, int n_slots, int cost_slot, int max_slot,
+                        double* partial, int n_partial, hipStream_t st);
+int launch_trial_sums(const double* part_p, int n_p, const double* part_c, int n_c, double* out, hipStream_t st);
 int launch_point_invert(int n_pts, const double* Hpp6, const double* dp, const unsigned char* pt_fixed,
                         double* Hinv6, hipStream_t st);
 int launch_schur(int n_obs, const int* obs_cam, const int* obs_pt, const int* pt_start, const double* J8,

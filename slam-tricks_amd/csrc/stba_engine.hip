@@ -266,9 +266,10 @@ static int ba_plan_pack(stba_ba* b) {
 static int ba_build_reduced(stba_ba* b, const Damping& dm) {
     const int init_scale = b->scale_init ? 0 : 1;
     if (!dm.explicit_d)
-        STBA_TRY(launch_lm_diagonal(3 * b->np, 3, 6, 1, b->Hpp6, b->scale_p, init_scale, dm.use_scaling, dm.radius,
-                                    dm.dmin, dm.dmax, b->dp, b->st));
-    STBA_TRY(launch_point_invert(b->np, b->Hpp6, b->dp, b->pt_fixed, b->Hinv6, b->st));
+        STBA_TRY(launch_point_damp_invert(b->np, b->Hpp6, b->pt_fixed, b->scale_p, init_scale, dm.use_scaling, dm.radius, dm.dmin,
+                                          dm.dmax, b->dp, b->Hinv6, b->st));
+    else
+        STBA_TRY(launch_point_invert(b->np, b->Hpp6, b->dp, b->pt_fixed, b->Hinv6, b->st));
     // S is zeroed by the pair-plan Schur kernel itself when every camera row is one task; the three extras
     // vectors behind it (diag, gc, rhs) always here (the scalar slots are kept)
     const bool self_zero = b->pair_rec != nullptr && b->all_single;
@@ -321,10 +322,8 @@ static int ba_build_reduced(stba_ba* b, const Damping& dm) {
 
 // cost slot + per-rank |gp|_inf slot, filled before the reduced system is built
 static int ba_fill_scalar_slots(stba_ba* b, const double* cost2_dev) {
-    STBA_HIP(hipMemsetAsync(b->ex_scalar(), 0, (size_t)b->lda * sizeof(double), b->st));
-    STBA_HIP(hipMemcpyAsync(b->ex_scalar() + SC_COST2, cost2_dev, sizeof(double), hipMemcpyDeviceToDevice, b->st));
-    return launch_absmax(b->gp, (size_t)3 * b->np, nullptr, 0, b->ex_scalar() + SC_GPMAX0 + b->rank, b->upd_partial_p,
-                         (b->np + 255) / 256 + 1, b->st);
+    return launch_scalar_slots(b->gp, (size_t)3 * b->np, cost2_dev, b->ex_scalar(), b->lda, SC_COST2, SC_GPMAX0 + b->rank,
+                               b->upd_partial_p, (b->np + 255) / 256 + 1, b->st);
 }
 
 static int ba_trial(stba_ba* b) {
@@ -333,9 +332,8 @@ static int ba_trial(stba_ba* b) {
     STBA_TRY(launch_update(b->nc, b->np, b->cams[cur], b->pts[cur], b->dxc, b->dxp, b->cam_fixed, b->pt_fixed,
                            b->ex_gc(), b->dc, b->gp, b->dp, b->cams[nxt], b->pts[nxt], b->upd_partial_c,
                            b->upd_partial_p, b->st));
-    STBA_HIP(hipMemsetAsync(b->trial, 0, TS_COUNT * sizeof(double), b->st));
-    if (b->np > 0) STBA_TRY(launch_sum_partials(b->upd_partial_p, pb, 4, 3, b->trial + TS_STEP2, b->st));
-    STBA_TRY(launch_sum_partials(b->upd_partial_c, cb, 4, 3, b->trial + TS_CAM, b->st));
+    static_assert(TS_STEP2 == 1 && TS_X2 == 2 && TS_MODEL == 3 && TS_CAM == 4 && TS_COUNT == 8, "trial_sums_kernel writes this layout");
+    STBA_TRY(launch_trial_sums(b->upd_partial_p, b->np > 0 ? pb : 0, b->upd_partial_c, cb, b->trial, b->st));
     STBA_TRY(ba_cost_only(b, nxt, b->trial + TS_COST2));
     if (b->ar) {
         if (b->ar(b->ar_user, b->trial, 4, b->st) != 0) return fail(STBA_ERR_CALLBACK, "all-reduce hook failed");
