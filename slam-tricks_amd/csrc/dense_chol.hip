@@ -489,13 +489,45 @@ __device__ __forceinline__ double mfma_l(double gp, double b) {       // l = (Gp
 __device__ __forceinline__ int d2_tix(int I, int J) { return I * (I + 1) / 2 + J; }
 
 // tile (I, J) of the block -> registers; the diagonal tiles are made symmetric from their lower triangle
-__device__ __forceinline__ double4v d2_load_tile(const double* __restrict__ Ab, int lda, int I, int J, int n, int g) {
+// The block enters through LDS.  Read tile by tile straight into the accumulator layout, a load instruction touches 16
+// rows at 32 bytes each and every 128-byte line four times: the factor wave, its own tile long loaded, stood 3.1 us at
+// the first barrier waiting for the bulk rows' 32 such instructions per lane (tools/mega_trace.py, stamps behind the
+// first two barriers).  Here all 512 threads fetch the lower-triangle tiles with full-line requests (8 lanes x 16 B per
+// row) and drop them into the -- still empty -- slots of the panel values, tile (I, J) at Lsl[tix(I, J)], element
+// (row a, column c) at c * 16 + (a + c') mod 16, c' = c with bit 0 cleared: the accumulator layout then reads as four
+// contiguous 512-byte rows per tile (each rotated by a constant: conflict-free), and the rotation spreads the staging
+// writes, whose lanes differ in c' by multiples of two, over the banks.
+__device__ __forceinline__ void d2_stage_block(const double* __restrict__ Ab, int lda, Diag2Smem& sm, int t) {
+    const int h = t & 7, a8 = (t >> 3) & 7, w = t >> 6;            // 16-byte piece of the row, row within the half tile
+    double2 v[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const int item = k * 8 + w;                                // 72 half tiles over 8 waves
+        const int tile = item >> 1, a = (item & 1) * 8 + a8;
+        int I = 0;
+        while ((I + 1) * (I + 2) / 2 <= tile) ++I;
+        const int J = tile - I * (I + 1) / 2;
+        v[k] = *reinterpret_cast<const double2*>(&Ab[(size_t)(16 * I + a) * lda + 16 * J + 2 * h]);
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const int item = k * 8 + w;
+        const int tile = item >> 1, a = (item & 1) * 8 + a8;
+        double* dst = &sm.Lsl[tile][0][0];
+        dst[(2 * h) * 16 + ((a + 2 * h) & 15)] = v[k].x;
+        dst[(2 * h + 1) * 16 + ((a + 2 * h) & 15)] = v[k].y;
+    }
+}
+
+// tile (I, J) of the staged block -> registers; the diagonal tiles are made symmetric from their lower triangle
+__device__ __forceinline__ double4v d2_load_tile(const Diag2Smem& sm, int I, int J, int n, int g) {
+    const double* src = &sm.Lsl[d2_tix(I, J)][0][0];
     double4v v;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int c = 4 * r + g;
         const int row = (I == J && c > n) ? c : n, col = (I == J && c > n) ? n : c;
-        v[r] = Ab[(size_t)(16 * I + row) * lda + 16 * J + col];
+        v[r] = src[col * 16 + ((row + (col & ~1)) & 15)];
     }
     return v;
 }
@@ -564,7 +596,7 @@ __device__ __forceinline__ double d2_factor_gp(const double4v& accD, int s, cons
 __device__ __forceinline__ void d2_factor_wave(const double* __restrict__ Ab, int lda, int k0, int n_real, int* __restrict__ flag,
                                                Diag2Smem& sm, int lane, long long* ph) {
     const int n = lane & 15, g = lane >> 4;
-    double4v accD = d2_load_tile(Ab, lda, 0, 0, n, g);
+    double4v accD = d2_load_tile(sm, 0, 0, n, g);
     double mk[10];          // 0/1 weights of the ten entries of the 4x4 inverse for this lane's operand slot
     {
         const int idx = (n < 4 && g <= n) ? n * (n + 1) / 2 + g : -1;
@@ -614,7 +646,7 @@ __device__ __forceinline__ void d2_factor_wave(const double* __restrict__ Ab, in
 // the follower: row J + 1 through tile column J
 __device__ __forceinline__ void d2_follower_wave(const double* __restrict__ Ab, int lda, Diag2Smem& sm, int lane) {
     const int n = lane & 15, g = lane >> 4;
-    double4v accS = d2_load_tile(Ab, lda, 1, 0, n, g), accD = d2_load_tile(Ab, lda, 1, 1, n, g);
+    double4v accS = d2_load_tile(sm, 1, 0, n, g), accD = d2_load_tile(sm, 1, 1, n, g);
     double lprev = 0.0;
 #pragma unroll 1
     for (int J = 0; J < 8; ++J) {
@@ -701,7 +733,7 @@ __device__ __forceinline__ void d2_bulk_row(const double* __restrict__ Ab, int l
     const int n = lane & 15, g = lane >> 4;
     double4v acc[8];
 #pragma unroll
-    for (int d = 0; d < 8; ++d) if (d <= R) acc[d] = d2_load_tile(Ab, lda, R, R - d, n, g);
+    for (int d = 0; d < 8; ++d) if (d <= R) acc[d] = d2_load_tile(sm, R, R - d, n, g);
     double lprev = 0.0;
     switch (R) {
         case 7: d2_bulk_column<7>(sm, R, acc, lprev, lane); [[fallthrough]];
@@ -786,6 +818,8 @@ __device__ __forceinline__ void diag_block2(double* __restrict__ A, int lda, int
     const int w = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
     const double* Ab = A + (size_t)k0 * lda + k0;
     PHASE_STAMP(0);
+    d2_stage_block(Ab, lda, sm, t);
+    D2_BARRIER();
     if (w == 0) d2_factor_wave(Ab, lda, k0, n_real, flag, sm, lane, ph);
     else if (w == 1) d2_follower_wave(Ab, lda, sm, lane);
     else if (w == 4) d2_store_wave<WT>(A, Ab, lda, k0, sm, lane);
