@@ -373,6 +373,33 @@ def test_cholesky_persistent_kernel_is_deterministic(st, n):
         assert np.array_equal(st.cholesky_solve(A, rhs), x0)
 
 
+def test_rejected_steps_follow_the_oracle(st, O, scenes):
+    """A badly initialised scene: the first three steps are REJECTED (the trust region shrinks), then the solve
+    recovers.  The device loop linearises speculatively at the trial point while the host decides; a rejected step
+    must put the linearisation of the old point back, in the free-running solve and in the fixed-work variant."""
+    s = scenes.st20_scene(n_cams=12, n_pts=150, seed=3, pos_noise=0.6, ang_noise_deg=8.0, pix_noise=1e-3)
+    o = oracle(O, s)
+    so, tro = o.solve(max_num_iterations=12)
+    flags = tro[: so.num_iterations + 1, 6]
+    assert (flags[1:4] == 0).all() and flags[4:].all()                       # the situation this test is about
+    e = engine(st, s)
+    summ, tr = e.solve(max_num_iterations=12)
+    assert summ.num_iterations == so.num_iterations
+    assert np.array_equal(tr[: summ.num_iterations + 1, 6], flags)
+    assert np.allclose(tr[: summ.num_iterations + 1, 0], tro[: so.num_iterations + 1, 0], rtol=1e-6)
+    assert np.allclose(tr[: summ.num_iterations + 1, 5], tro[: so.num_iterations + 1, 5], rtol=1e-9)     # radius
+    dq, dt = pose_err(e.get_params()[0], o.cams)
+    assert dq < 1e-6 and dt < 1e-6
+    # fixed-work variant (bench.py's): rejected steps re-linearise at the unchanged point
+    e2, o2 = engine(st, s), oracle(O, s)
+    summ2, tr2 = e2.lm_iterations(8)
+    so2, tro2 = o2.solve(fixed_iterations=8)
+    assert np.array_equal(tr2[:, 6], tro2[:, 6]) and (tr2[1:4, 6] == 0).all()
+    assert np.allclose(tr2[:, 0], tro2[:, 0], rtol=1e-6)
+    dq, dt = pose_err(e2.get_params()[0], o2.cams)
+    assert dq < 1e-6 and dt < 1e-6
+
+
 # ------------------------------------------------------------------------------- full size and edge cases
 def test_c5_full_size_matches_oracle(st, O, scenes):
     """BASELINE config C5 at FULL size (1 000 cameras, 100 000 landmarks, 1 000 000 observations, the
