@@ -1806,6 +1806,9 @@ static void mega_build_tasks(int nblk, int nq, int wg_per_q, std::vector<int4>& 
     }
     auto gpu_of = [&](int q) { return n_gpus > 1 ? q / q_per_gpu : 0; };
     static const int QROWS = [] { const char* e = getenv("STBA_MEGA_QROWS"); return e ? atoi(e) : 2; }();
+    // from panel QFROM on (the chain-bound part of the factorisation, where workgroups are idle) every row's tile in the next
+    // panel column is updated by four quarter tasks: the row sweeps T -> U -> T get shorter
+    static const int QFROM = [] { const char* e = getenv("STBA_MEGA_QFROM"); return e ? atoi(e) : 1 << 30; }();
     std::vector<int> idD((size_t)NBK, -1), idTI((size_t)NBK, -1), idTU((size_t)NBK * 4, -1), idT((size_t)NBK * NBK, -1),
         idUq((size_t)NBK * NBK * 4, -1), idU((size_t)NBK * NBK * NBK, -1);
     // measured on MI355X (tools/mega_trace.py), microseconds, plus ~2 us of flag latency per hop
@@ -1831,7 +1834,7 @@ static void mega_build_tasks(int nblk, int nq, int wg_per_q, std::vector<int4>& 
             // the next panel's column: 32-row tasks (short latency) only for the rows the second critical chain
             // needs soon; a quarter task costs 14.5 us of a workgroup against 23.4 us for a whole tile, so the
             // rows further down take the whole-tile task (their panel solve comes a diagonal block later)
-            if (i <= b + 1 + QROWS) {
+            if (i <= b + 1 + QROWS || b >= QFROM) {
                 for (int q = 0; q < 4; ++q)
                     idUq[((size_t)b * NBK + i) * 4 + q] = add(TASK_UQ, b, i * 4 + q, b + 1, 10.0 * (b + 1) + 2 + 1e-3 * i);
             } else {
