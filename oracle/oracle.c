@@ -388,6 +388,14 @@ static inline int pt_is_fixed(const orc_ba_problem* p, int j) { return p->pt_fix
 
 static int g_threads = 1;   /* set by orc_ba_solve from options->num_threads */
 
+/* Optional external dense solver for the reduced camera system (bench.py's cpu_baseline leg: LAPACK dpotrf/dpotrs of
+ * the OpenBLAS that numpy/scipy ship, installed from oracle_py.use_lapack()).  fn(S, n, x): S row-major, lower triangle
+ * valid, may be overwritten; x holds the right-hand side on entry and the solution on return; returns 0, or k > 0 if
+ * the leading minor of order k is not positive definite.  NULL: the blocked C factorisation above. */
+typedef int (*orc_dense_solver_fn)(double* S, int n, double* x);
+static orc_dense_solver_fn g_dense_solver = 0;
+void orc_set_dense_solver(orc_dense_solver_fn fn) { g_dense_solver = fn; }
+
 double orc_ba_evaluate(const orc_ba_problem* p, double* r, double* Jc, double* Jp) {
     double cost = 0;
 #pragma omp parallel for schedule(static) reduction(+ : cost) num_threads(g_threads)
@@ -724,11 +732,19 @@ int orc_ba_solve(orc_ba_problem* p, const orc_lm_options* opt, orc_lm_summary* s
         orc_ba_reduced_system(p, w.Jc, w.Jp, w.r, w.dc, w.dp, 0, np, w.S, w.rhs);
         sum->seconds_schur += now_s() - t0;
         t0 = now_s();
-        int bad = orc_cholesky_lower(w.S, n, nt);
+        int bad;
+        if (g_dense_solver) {
+            memcpy(w.dxc, w.rhs, sizeof(double) * n);
+            bad = g_dense_solver(w.S, n, w.dxc);
+        } else {
+            bad = orc_cholesky_lower(w.S, n, nt);
+        }
         int step_ok = (bad == 0);
         if (step_ok) {
-            memcpy(w.dxc, w.rhs, sizeof(double) * n);
-            chol_solve_big(w.S, n, w.dxc);
+            if (!g_dense_solver) {
+                memcpy(w.dxc, w.rhs, sizeof(double) * n);
+                chol_solve_big(w.S, n, w.dxc);
+            }
             for (int c = 0; c < nc; ++c)
                 for (int a = 0; a < 6; ++a)
                     if (cam_dof_fixed(p, c, a)) w.dxc[c * 6 + a] = 0;

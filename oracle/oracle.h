@@ -144,6 +144,9 @@ void orc_ba_reduced_system(const orc_ba_problem* p, const double* Jc, const doub
 
 /* dense SPD solve helpers (in place, row-major, lower).  return 0 ok / k>0 first bad pivot */
 int  orc_cholesky_lower(double* A, int n, int num_threads);
+/* optional external dense solver used by orc_ba_solve for the reduced camera system (NULL: orc_cholesky_lower);
+ * fn(S row-major lower, n, x = rhs in / solution out) -> 0 or the order of the failing minor */
+void orc_set_dense_solver(int (*fn)(double* S, int n, double* x));
 void orc_cholesky_solve(const double* L, int n, double* b);
 
 /* Full LM with point-block Schur elimination + dense Cholesky on the reduced system.

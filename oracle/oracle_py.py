@@ -88,6 +88,54 @@ def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
+_DENSE_CB = None      # (keeps the ctypes callback alive)
+
+
+def use_lapack(on=True, threads=None):
+    """bench.py's cpu_baseline leg: let the LM solve of the oracle factor the reduced camera system with LAPACK
+    (dpotrf / dpotrs of the OpenBLAS that scipy ships) instead of the blocked C loop of orc_cholesky_lower --
+    the fair CPU opponent for a dense 6000 x 6000 FP64 Cholesky.  Returns a description of the BLAS in use, or None
+    if scipy's LAPACK is not importable.  use_lapack(False) restores the C factorisation."""
+    global _DENSE_CB
+    L = lib()
+    L.orc_set_dense_solver.argtypes = [C.c_void_p]
+    if not on:
+        L.orc_set_dense_solver(None)
+        _DENSE_CB = None
+        return None
+    try:
+        from scipy.linalg import lapack
+    except Exception:
+        return None
+    info = "scipy LAPACK"
+    try:
+        import threadpoolctl
+        if threads:
+            threadpoolctl.threadpool_limits(limits=int(threads), user_api="blas")
+        for d in threadpoolctl.threadpool_info():
+            if d.get("user_api") == "blas" and "scipy" in os.path.basename(d.get("filepath", "")) and "scipy.libs" in d.get("filepath", ""):
+                info = f"{d.get('internal_api')} {d.get('version')} ({d.get('architecture')}), {d.get('num_threads')} threads"
+    except Exception:
+        pass
+
+    def solve(S_ptr, n, x_ptr):
+        # the row-major lower triangle is the column-major UPPER triangle of the same memory: factor S^T = U^T U in place
+        S = np.ctypeslib.as_array(C.cast(S_ptr, C.POINTER(C.c_double)), shape=(n, n)).T
+        x = np.ctypeslib.as_array(C.cast(x_ptr, C.POINTER(C.c_double)), shape=(n,))
+        c, bad = lapack.dpotrf(S, lower=0, clean=0, overwrite_a=1)
+        if bad != 0:
+            return int(bad) if bad > 0 else n
+        sol, bad = lapack.dpotrs(c, x, lower=0)
+        if bad != 0:
+            return n
+        x[:] = sol
+        return 0
+
+    _DENSE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p)(solve)
+    L.orc_set_dense_solver(C.cast(_DENSE_CB, C.c_void_p))
+    return info
+
+
 def f64(a):
     return np.ascontiguousarray(a, dtype=np.float64)
 

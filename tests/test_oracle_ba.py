@@ -173,3 +173,24 @@ def test_oracle_has_not_drifted_from_its_frozen_traces(O, scenes):
         assert np.allclose(tr[:, 5], g["radius_trace"], rtol=1e-6)
         assert np.abs(o.cams.reshape(-1) - np.array(g["final_cams"])).max() < 1e-9
         assert np.abs(o.pts[:20].reshape(-1) - np.array(g["final_pts_head"])).max() < 1e-8
+
+
+def test_lapack_backed_reduced_solve_follows_the_c_factorisation(O, scenes):
+    """bench.py's cpu_baseline leg may factor the reduced camera system with LAPACK (oracle_py.use_lapack): same
+    iterations, same decisions, same answer as the blocked C factorisation"""
+    s = scenes.st20_scene(n_cams=40, n_pts=800, max_obs_per_pt=6, seed=9, pix_noise=1e-3)
+    def run():
+        ba = O.BA(s["cams0"], s["pts0"], s["obs_cam"], s["obs_pt"], s["obs_feat"], s["cam_fixed"])
+        so, tr = ba.solve(fixed_iterations=4)
+        return so, tr, ba.cams.copy(), ba.pts.copy()
+    so0, tr0, c0, p0 = run()
+    info = O.use_lapack(True, threads=2)
+    if info is None:
+        pytest.skip("scipy LAPACK not importable")
+    try:
+        so1, tr1, c1, p1 = run()
+    finally:
+        O.use_lapack(False)
+    assert np.array_equal(tr0[:, 6], tr1[:, 6])
+    assert np.allclose(tr0[:, 0], tr1[:, 0], rtol=1e-10)
+    assert np.abs(c0 - c1).max() < 1e-10 and np.abs(p0 - p1).max() < 1e-9
