@@ -1115,9 +1115,10 @@ __global__ void xcc_probe_kernel(int* out) {
 
 // C(TM x 128) -= P_i P_j^T, K = 128 panel columns, 512 threads; smem: 2*(TM+128)*16 doubles
 // C(TM x 128) -= P_i P_j^T, K = 128 panel columns, 512 threads; smem: 2*(TM+128)*16 doubles
+// (kchunks 16-column chunks of K: 8 for one panel; a batched trailing update runs several panels in one pass)
 template <int TM>
 __device__ __forceinline__ void syrk_tile512(double* __restrict__ A, int lda, int k0, int row_i, int row_j,
-                                             double* smem, int t) {
+                                             double* smem, int t, int kchunks = NB / 16) {
     constexpr int WR = (TM == 128) ? 2 : 1, WC = 8 / WR;      // wave grid
     constexpr int MB = TM / (16 * WR);                        // MFMA row blocks per wave: 4 | 2
     constexpr int NBK = 8 / WC;                               // MFMA col blocks per wave: 2 | 1
@@ -1167,7 +1168,7 @@ __device__ __forceinline__ void syrk_tile512(double* __restrict__ A, int lda, in
     gload(0);
     lstore(0);
     __syncthreads();
-    constexpr int KC = NB / 16;
+    const int KC = kchunks;
     for (int kc = 0; kc < KC; ++kc) {
         const int buf = kc & 1;
         if (kc + 1 < KC) gload(kc + 1);
@@ -1554,8 +1555,9 @@ __global__ __launch_bounds__(512) void chol_mega_kernel(MegaArgs a) {
             return (v0 >= 4 * b) & (v1 >= 4 * b);
         }
         const int i = (type == TASK_UQ) ? (ti >> 2) : ti;
+        const int nbp = max(1, (d.x >> 16) & 0xff);            // panels in this task (a batched trailing update: b is its last one)
         const int f0 = ldf(&tflag[b * nrow + i]), f1 = ldf(&tflag[b * nrow + tj]), v = ldf(&ver[i * nblk + tj]);
-        return (f0 >= 4) & (f1 >= 4) & (v >= 4 * (b - first_panel(i)));
+        return (f0 >= 4) & (f1 >= 4) & (v >= 4 * (b - nbp + 1 - first_panel(i)));
     };
     // Wave 0 polls.  The urgent list (if there is one) is examined one entry per lane (the 64 entries behind its head,
     // their descriptors cached in LDS between polls), but only when there can be something new in it: right after a task
@@ -1701,7 +1703,8 @@ __global__ __launch_bounds__(512) void chol_mega_kernel(MegaArgs a) {
             }
         } else if (type == TASK_U) {
             if (ti < nblk) {
-                syrk_tile512<128>(a.A, a.lda, k0, ti * NB, tj * NB, smem, tt);
+                const int nbp = max(1, (d.x >> 16) & 0xff);
+                syrk_tile512<128>(a.A, a.lda, k0 - (nbp - 1) * NB, ti * NB, tj * NB, smem, tt, nbp * (NB / 16));
             } else {
                 int ldc, ldi, ldj;
                 double* Cb = tile_ptr(ti, tj, ldc);
@@ -1726,7 +1729,7 @@ __global__ __launch_bounds__(512) void chol_mega_kernel(MegaArgs a) {
             else if (type == TASK_T) __hip_atomic_fetch_add(&tflag[b * nrow + ti], 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             else if (type == TASK_TI) { if (b < 4 * a.nwide) __hip_atomic_fetch_add(&tflag[b * nrow + nblk + b], 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
             else if (type == TASK_TU) __hip_atomic_fetch_add(&tflag[b * nrow + b + 1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (ver: inside the task)
-            else if (type == TASK_U) __hip_atomic_fetch_add(&ver[ti * nblk + tj], 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else if (type == TASK_U) __hip_atomic_fetch_add(&ver[ti * nblk + tj], 4 * max(1, (d.x >> 16) & 0xff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             else if (type == TASK_UQ) __hip_atomic_fetch_add(&ver[(ti >> 2) * nblk + tj], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (a.trace) a.trace[8 * (size_t)task + 3] = wall_clock64();
             // (the scan that follows a feeding task must see this flag: wait until the L2 has it)
@@ -1739,7 +1742,7 @@ __global__ __launch_bounds__(512) void chol_mega_kernel(MegaArgs a) {
 // then split stably into one queue per XCD by the owner of the tile each task writes
 static int mega_task_row(const int4& tk) {
     // every task writes tiles of one tile row only (TU writes (b+1, b) and (b+1, b+1))
-    switch (tk.x) {
+    switch (tk.x & 0xff) {
         case TASK_D: case TASK_TI: return tk.y;
         case TASK_TU: return tk.y + 1;
         case TASK_T: case TASK_U: return tk.z;
@@ -1814,6 +1817,9 @@ static void mega_build_tasks(int nblk, int nq, int wg_per_q, std::vector<int4>& 
     // measured on MI355X (tools/mega_trace.py), microseconds, plus ~2 us of flag latency per hop
     // (STBA_MEGA_DUR=d,t,ti,u,uq,tu overrides them for experiments)
     double DUR[6] = {29.0, 23.0, 19.0, 25.0, 16.5, 20.0};
+    const double DUR_K = 18.0;     // one more panel (K += 128) inside a batched trailing update (measured: 24 us for one panel, 42 for two)
+    static const int BATCH = [] { const char* e = getenv("STBA_MEGA_BATCH"); return e ? std::max(1, std::min(16, atoi(e))) : 2; }();
+    static const int BLAG = [] { const char* e = getenv("STBA_MEGA_BLAG"); return e ? std::max(0, atoi(e)) : 3; }();
     if (const char* e = getenv("STBA_MEGA_DUR")) sscanf(e, "%lf,%lf,%lf,%lf,%lf,%lf", &DUR[0], &DUR[1], &DUR[2], &DUR[3], &DUR[4], &DUR[5]);
     auto add = [&](int type, int b, int i, int j, double prio) {
         Node nd; nd.tk = make_int4(type, b, i, j); nd.dur = DUR[type]; nd.prio = prio; nd.q = rowq[(size_t)mega_task_row(nd.tk)];
@@ -1841,9 +1847,34 @@ static void mega_build_tasks(int nblk, int nq, int wg_per_q, std::vector<int4>& 
                 idUq[((size_t)b * NBK + i) * 4] = add(TASK_U, b, i, b + 1, 10.0 * (b + 1) + 2 + 1e-3 * i);
             }
         }
-        for (int j = b + 2; j < NBK; ++j)
-            for (int i = j; i < NBK; ++i)
-                idU[((size_t)b * NBK + i) * NBK + j] = add(TASK_U, b, i, j, 10.0 * j + 3 + 1e-3 * i + 1e-6 * b);
+        // Trailing updates of the tiles beyond the next panel column.  Tile (i, j) needs the panels 0 .. j-2 at some point
+        // before its last update (panel j-1, above: the latency-critical one); they are applied BATCH panels at a time in
+        // one pass over the tile, K = 128 BATCH: the tile is read and written once per batch instead of once per panel and
+        // the task's fixed costs (waiting for the first operands and the tile, the stores, the hand-over: ~10 of 24 us) are
+        // paid once per batch.  The task of a batch carries its LAST panel in .y and the panel count in bits 16..23 of .x;
+        // the MFMAs run on the same accumulators in the same order as panel-by-panel, so the result is bit-identical.
+        if (BATCH <= 1) {
+            for (int j = b + 2; j < NBK; ++j)
+                for (int i = j; i < NBK; ++i)
+                    idU[((size_t)b * NBK + i) * NBK + j] = add(TASK_U, b, i, j, 10.0 * j + 3 + 1e-3 * i + 1e-6 * b);
+        } else {
+            for (int j = b + 2; j < NBK; ++j) {
+                // panels 0 .. j-2 of column j in batches [0, BATCH), [BATCH, 2 BATCH), ...: this panel closes a batch if it
+                // is the last of its group or the last one of the column
+                // (the last BLAG panels before the final one stay single tasks: a long batch there would sit on the path to
+                // the tile's panel solve)
+                const int lim = j - 2 - BLAG;
+                const int b0 = b > lim ? b : (b / BATCH) * BATCH, last = b > lim ? b : std::min(b0 + BATCH - 1, lim);
+                if (b != last) continue;
+                const int nb = b - b0 + 1;
+                for (int i = j; i < NBK; ++i) {
+                    const int id = add(TASK_U, b, i, j, 10.0 * j + 3 + 1e-3 * i + 1e-6 * b);
+                    nodes[(size_t)id].tk.x |= nb << 16;
+                    nodes[(size_t)id].dur = DUR[TASK_U] + (nb - 1) * DUR_K;
+                    for (int bb = b0; bb <= b; ++bb) idU[((size_t)bb * NBK + i) * NBK + j] = id;
+                }
+            }
+        }
     }
     auto dep = [&](int from, int to) {     // `to` needs `from`
         if (from < 0 || to < 0) return;
@@ -1880,9 +1911,11 @@ static void mega_build_tasks(int nblk, int nq, int wg_per_q, std::vector<int4>& 
         for (int j = b + 2; j < NBK; ++j)
             for (int i = j; i < NBK; ++i) {
                 const int u = idU[((size_t)b * NBK + i) * NBK + j];
+                if (nodes[(size_t)u].tk.y != b) continue;          // (a batch: its dependencies hang on its last panel)
                 dep(idT[(size_t)b * NBK + i], u);
                 if (j != i) dep(idT[(size_t)b * NBK + j], u);
-                if (b > 0) dep(idU[((size_t)(b - 1) * NBK + i) * NBK + j], u);
+                const int nbp = std::max(1, (nodes[(size_t)u].tk.x >> 16) & 0xff);
+                if (b - nbp >= 0) dep(idU[((size_t)(b - nbp) * NBK + i) * NBK + j], u);
             }
     }
     // wide inverse blocks: the identity block under panel p = 4q + v of wide block q (virtual row nblk + p) is carried
@@ -2053,7 +2086,7 @@ static void mega_build_tasks(int nblk, int nq, int wg_per_q, std::vector<int4>& 
             int k = idTU[(size_t)b * 4 + 3];
             for (int hop = 0; hop < 4 && k >= 0; ++hop) {       // walk back along the last-arriving inputs
                 const Node& nd = nodes[(size_t)k];
-                fprintf(stderr, " <- %s(%d;%d,%d) rdy %+.1f st %+.1f", NM[nd.tk.x], nd.tk.y, nd.tk.z, nd.tk.w, nd.ready - e0, nd.start - e0);
+                fprintf(stderr, " <- %s(%d;%d,%d) rdy %+.1f st %+.1f", NM[nd.tk.x & 0xff], nd.tk.y, nd.tk.z, nd.tk.w, nd.ready - e0, nd.start - e0);
                 k = nd.last_pred;
             }
             fprintf(stderr, "\n");
