@@ -1098,6 +1098,7 @@ struct MegaArgs {
                             // tflag[nblk*nrow], ver[nrow*nblk] (nrow = nblk + 4 nwide), claim[ntasks]
     double* linv; size_t linv_stride;
     double* vbuf; int nwide;   // inverse transposes of the 512 x 512 diagonal blocks 0 .. nwide-1 (row-major, ld 512): see below
+    int predraw_nb;         // the next ticket is drawn at the start of a task only if the task spans at most this many panels
     int* flag;
     long long* trace;       // optional (STBA_MEGA_TRACE): per task {workgroup, t_ticket, t_ready, t_done}, 100 MHz clock
 };
@@ -1654,7 +1655,7 @@ __global__ __launch_bounds__(512) void chol_mega_kernel(MegaArgs a) {
             }
             // draw the next bulk ticket now, look at it after the task.  Not before a TU task: it waits for its three
             // siblings, which hold LATER tickets -- this workgroup must not sit on one of them.
-            if (mine < 0 && !lo_done && pick >= 0 && (a.tasks[pick].x & 0xff) != TASK_TU) {
+            if (mine < 0 && !lo_done && pick >= 0 && (a.tasks[pick].x & 0xff) != TASK_TU && ((a.tasks[pick].x >> 16) & 0xff) <= a.predraw_nb) {
                 if (lane == 0) m_raw = qbeg + atomicAdd(ticket, 1);
                 m_pending = true;
             }
@@ -2414,6 +2415,8 @@ static int chol_run(double* A, int lda, int n, double* x_dev, int* flag_dev, hip
         memcpy(ma.xcc_queue, plan.xcc_queue, sizeof ma.xcc_queue);
         ma.linv = linv; ma.linv_stride = LINV_STRIDE; ma.flag = flag_dev;
         ma.vbuf = ws.vbuf; ma.nwide = nwide;
+        static const int PREDRAW = [] { const char* e = getenv("STBA_MEGA_PREDRAW"); return e ? atoi(e) : 2; }();
+        ma.predraw_nb = PREDRAW;
         static const char* TRACE = getenv("STBA_MEGA_TRACE");
         ma.trace = nullptr;
         if (TRACE) STBA_HIP(hipMalloc(reinterpret_cast<void**>(&ma.trace), (size_t)plan.ntasks * 8 * sizeof(long long)));

@@ -1,11 +1,8 @@
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests -x -q -m gpu > gpurun_out/pytest_tmp.txt 2>&1
-grep -E "passed|failed" gpurun_out/pytest_tmp.txt
-timeout 300 python tools/mega_stress.py 3000 10 1 2>&1 | tail -1
-timeout 300 python tools/mega_stress.py 1500 20 2 2>&1 | tail -1
-timeout 300 python bench.py --reps 3 --steps 50 --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/bench_d3.json; python - <<'PY'
-import json
-d=json.loads(open('gpurun_out/bench_d3.json').read())
-print('it/s', round(d['value'],2), 'ms/step', round(d['ms_per_step'],3), d['reps_ms_per_step'])
-print(d['cholesky_ms']['factor_persistent_kernel'], d['roofline']['frac'])
-PY
+for rep in 1 2 3; do
+for cfg in "2 3 2" "2 3 1" "4 5 1" "4 5 2" "8 5 1" "4 8 1"; do
+set -- $cfg
+echo "BATCH $1 BLAG $2 PRE $3"
+STBA_MEGA_PREDRAW=$3 STBA_MEGA_BATCH=$1 STBA_MEGA_BLAG=$2 timeout 300 python tools/mega_trace.py run 6000
+done
+done
