@@ -1,8 +1,12 @@
 export TMPDIR=/tmp
-for rep in 1 2 3; do
-for cfg in "2 3 2" "2 3 1" "4 5 1" "4 5 2" "8 5 1" "4 8 1"; do
-set -- $cfg
-echo "BATCH $1 BLAG $2 PRE $3"
-STBA_MEGA_PREDRAW=$3 STBA_MEGA_BATCH=$1 STBA_MEGA_BLAG=$2 timeout 300 python tools/mega_trace.py run 6000
-done
-done
+bash tools/pmc_chol.sh r2_e > gpurun_out/pmc_chol_r2_e.log 2>&1
+tail -1 gpurun_out/pmc_chol_r2_e.log | cut -c1-300
+bash tools/gpu_prof.sh r2_e > gpurun_out/prof_r2_e.log 2>&1
+cd $GRAFT_REPO_ROOT
+timeout 900 python bench.py > gpurun_out/bench_r2_e_full.json 2> gpurun_out/bench_r2_e_full.err
+python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/bench_r2_e_full.json').read().strip().splitlines()[-1])
+print('it/s', d['value'], 'ms', d['ms_per_step'], d['reps_ms_per_step'])
+print(d['phase_ms_per_step']); print(d['cholesky_ms']); print(d['roofline']['frac'], d['roofline_jacobian']['frac']); print(d['cpu_baseline']['value'], d['speedup_vs_cpu_port'], d['matched_result_gate']['passed'])
+PY
