@@ -1547,6 +1547,12 @@ __global__ __launch_bounds__(512) void chol_mega_kernel(MegaArgs a) {
         const int type = d.x & 0xff, b = d.y, ti = d.z, tj = d.w;
         if (type == TASK_D) return ldf(&ver[b * nblk + b]) >= 4 * b;
         if (type == TASK_T) {       // (an urgent one awaits the diagonal block inside the task, with its rows loaded)
+            if ((d.x >> 24) & 1) {
+                // fused with the last update of its tile (by panel b-1): needs that panel's tiles of the rows ti and b and the
+                // tile through panel b-2; the diagonal block b is awaited inside, behind the update
+                const int v = ldf(&ver[ti * nblk + b]), f0 = ldf(&tflag[(b - 1) * nrow + ti]), f1 = ldf(&tflag[(b - 1) * nrow + b]);
+                return (v >= 4 * (b - 1 - first_panel(ti))) & (f0 >= 4) & (f1 >= 4);
+            }
             const int v = ldf(&ver[ti * nblk + b]), df = urgent ? 1 : ldf(&dflag[b]);
             return (v >= 4 * (b - first_panel(ti))) & (df >= 1);
         }
@@ -1683,6 +1689,14 @@ __global__ __launch_bounds__(512) void chol_mega_kernel(MegaArgs a) {
             diag_block<true>(a.A, a.lda, k0, a.n, a.flag, li + NB * NB, smem, tt, ph);
 #endif
         } else if (type == TASK_T) {
+            if ((d.x >> 24) & 1) {
+                // the tile's last update first; the panel solve below reads the tile back through the L2 (this CU's L1 holds
+                // the lines the update loaded)
+                syrk_tile512<128>(a.A, a.lda, k0 - NB, ti * NB, k0, smem, tt);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                asm volatile("buffer_inv sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
+            }
             const int lane = tt & 63, w = tt >> 6;
             int ldr;
             double* rowp = tile_ptr(ti, b, ldr) + (size_t)(16 * w + (lane & 15)) * ldr;
@@ -1795,7 +1809,7 @@ struct MegaShardModel {          // what-if: the queues are spread over several 
 };
 static void mega_build_tasks(int nblk, int nq, int wg_per_q, std::vector<int4>& out, int* qstart, int* hstart, std::vector<float>* sim_start = nullptr,
                              double* makespan_out = nullptr, int nwide = 0, MegaShardModel* shard = nullptr) {
-    struct Node { int4 tk; std::vector<int> succ; int indeg = 0; double dur = 0, prio = 0, start = 0, ready = 0, avail = 0; int q = 0; int last_pred = -1; };
+    struct Node { int4 tk; std::vector<int> succ; int indeg = 0; double dur = 0, prio = 0, start = 0, ready = 0, avail = 0; int q = 0; int last_pred = -1; bool noemit = false; };
     std::vector<Node> nodes;
     const int NBK = nblk;
     std::vector<int> rowq = mega_row_owner(nblk, nq, 4 * nwide);
@@ -1820,6 +1834,9 @@ static void mega_build_tasks(int nblk, int nq, int wg_per_q, std::vector<int4>& 
     double DUR[6] = {29.0, 23.0, 19.0, 25.0, 16.5, 20.0};
     const double DUR_K = 18.0;     // one more panel (K += 128) inside a batched trailing update (measured: 24 us for one panel, 42 for two)
     static const int BATCH = [] { const char* e = getenv("STBA_MEGA_BATCH"); return e ? std::max(1, std::min(16, atoi(e))) : 2; }();
+    // (STBA_MEGA_FUSET=1, an experiment, off: correct and deterministic, predicted -55 us by the model, measured 2.69-2.73 ms
+    // with and without -- the row sweeps are not what binds the machine)
+    static const int FUSET = [] { const char* e = getenv("STBA_MEGA_FUSET"); return e ? atoi(e) : 0; }();
     static const int BLAG = [] { const char* e = getenv("STBA_MEGA_BLAG"); return e ? std::max(0, atoi(e)) : 3; }();
     if (const char* e = getenv("STBA_MEGA_DUR")) sscanf(e, "%lf,%lf,%lf,%lf,%lf,%lf", &DUR[0], &DUR[1], &DUR[2], &DUR[3], &DUR[4], &DUR[5]);
     auto add = [&](int type, int b, int i, int j, double prio) {
@@ -1838,10 +1855,24 @@ static void mega_build_tasks(int nblk, int nq, int wg_per_q, std::vector<int4>& 
             for (int q = 0; q < 4; ++q) idTU[(size_t)b * 4 + q] = add(TASK_TU, b, q, 0, 10.0 * b + 5);
         for (int i = b + 2; i < NBK; ++i) {
             idT[(size_t)b * NBK + i] = add(TASK_T, b, i, 0, 10.0 * b + 6 + 1e-3 * i);
+            if (FUSET && b >= 1 && i >= b + 2) {        // second half of the fused task emitted with the previous panel
+                nodes[(size_t)idT[(size_t)b * NBK + i]].noemit = true;
+                nodes[(size_t)idT[(size_t)b * NBK + i]].dur = DUR[TASK_T] - 2.0;
+            }
             // the next panel's column: 32-row tasks (short latency) only for the rows the second critical chain
             // needs soon; a quarter task costs 14.5 us of a workgroup against 23.4 us for a whole tile, so the
             // rows further down take the whole-tile task (their panel solve comes a diagonal block later)
-            if (i <= b + 1 + QROWS || b >= QFROM) {
+            if (FUSET && i >= b + 3) {
+                // The last update of tile (i, b+1) -- by this panel -- belongs to the panel solve T(b+1; i) that consumes the
+                // tile: ONE task, emitted here (it can start as soon as this panel's tiles of the rows i and b+1 are there,
+                // i.e. while the diagonal block b+1 is still being factored), whose second half (the solve proper, the node
+                // T(b+1; i) created in the next round, not emitted) waits for that diagonal block inside.  Saves a tile round
+                // trip and a hand-over per tile row and panel: the row sweeps T -> U -> T were the longest chain.
+                const int ua = add(TASK_T, b + 1, i, 0, 10.0 * (b + 1) + 2 + 1e-3 * i);
+                nodes[(size_t)ua].tk.x |= 1 << 24;
+                nodes[(size_t)ua].dur = DUR_K;
+                idUq[((size_t)b * NBK + i) * 4] = ua;
+            } else if (i <= b + 1 + QROWS || b >= QFROM) {
                 for (int q = 0; q < 4; ++q)
                     idUq[((size_t)b * NBK + i) * 4 + q] = add(TASK_UQ, b, i * 4 + q, b + 1, 10.0 * (b + 1) + 2 + 1e-3 * i);
             } else {
@@ -2108,6 +2139,7 @@ static void mega_build_tasks(int nblk, int nq, int wg_per_q, std::vector<int4>& 
             if (sim_start) sim_start->push_back((float)pk.start);
         };
         for (const Pick& pk : order[(size_t)q]) {
+            if (nodes[(size_t)pk.node].noemit) continue;
             if (HI_ROWS > 0 && is_urgent(nodes[(size_t)pk.node].tk)) continue;
             emit(pk);
         }
@@ -2115,7 +2147,7 @@ static void mega_build_tasks(int nblk, int nq, int wg_per_q, std::vector<int4>& 
         hstart[q] = (int)out.size();
         if (HI_ROWS > 0) {
             std::vector<Pick> hi;
-            for (const Pick& pk : order[(size_t)q]) if (is_urgent(nodes[(size_t)pk.node].tk)) hi.push_back(pk);
+            for (const Pick& pk : order[(size_t)q]) if (!nodes[(size_t)pk.node].noemit && is_urgent(nodes[(size_t)pk.node].tk)) hi.push_back(pk);
             std::stable_sort(hi.begin(), hi.end(), [](const Pick& x, const Pick& y) { return x.start < y.start; });
             for (const Pick& pk : hi) emit(pk);
         }

@@ -1,12 +1,12 @@
 export TMPDIR=/tmp
-bash tools/pmc_chol.sh r2_e > gpurun_out/pmc_chol_r2_e.log 2>&1
-tail -1 gpurun_out/pmc_chol_r2_e.log | cut -c1-300
-bash tools/gpu_prof.sh r2_e > gpurun_out/prof_r2_e.log 2>&1
-cd $GRAFT_REPO_ROOT
-timeout 900 python bench.py > gpurun_out/bench_r2_e_full.json 2> gpurun_out/bench_r2_e_full.err
-python - <<'PY'
-import json
-d=json.loads(open('gpurun_out/bench_r2_e_full.json').read().strip().splitlines()[-1])
-print('it/s', d['value'], 'ms', d['ms_per_step'], d['reps_ms_per_step'])
-print(d['phase_ms_per_step']); print(d['cholesky_ms']); print(d['roofline']['frac'], d['roofline_jacobian']['frac']); print(d['cpu_baseline']['value'], d['speedup_vs_cpu_port'], d['matched_result_gate']['passed'])
-PY
+for rep in 1 2 3; do
+for f in 0 1; do
+echo "FUSET $f"
+STBA_MEGA_FUSET=$f timeout 300 python tools/mega_trace.py run 6000
+done
+done
+timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu 2>&1 | grep -E "passed|failed"
+timeout 300 python tools/mega_stress.py 3000 10 1 2>&1 | tail -1
+timeout 300 python tools/mega_stress.py 1500 20 2 2>&1 | tail -1
+STBA_MEGA_TRACE=/tmp/mega.bin timeout 300 python tools/mega_trace.py run 6000
+timeout 100 python tools/mega_trace.py /tmp/mega.bin > gpurun_out/mega_trace_d3.txt
