@@ -1831,7 +1831,7 @@ static void mega_build_tasks(int nblk, int nq, int wg_per_q, std::vector<int4>& 
         idUq((size_t)NBK * NBK * 4, -1), idU((size_t)NBK * NBK * NBK, -1);
     // measured on MI355X (tools/mega_trace.py), microseconds, plus ~2 us of flag latency per hop
     // (STBA_MEGA_DUR=d,t,ti,u,uq,tu overrides them for experiments)
-    double DUR[6] = {29.0, 23.0, 19.0, 25.0, 16.5, 20.0};
+    double DUR[6] = {23.0, 23.0, 19.0, 25.0, 16.5, 20.0};      // (D: 21.3 us since round 2)
     const double DUR_K = 18.0;     // one more panel (K += 128) inside a batched trailing update (measured: 24 us for one panel, 42 for two)
     static const int BATCH = [] { const char* e = getenv("STBA_MEGA_BATCH"); return e ? std::max(1, std::min(16, atoi(e))) : 2; }();
     // (STBA_MEGA_FUSET=1, an experiment, off: correct and deterministic, predicted -55 us by the model, measured 2.69-2.73 ms

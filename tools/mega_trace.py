@@ -118,12 +118,12 @@ if sim is not None:
     ds = {int(tasks[k, 1]): float(sim[k]) for k in dm}
     print("simulated step D(b+1).start - D(b).start:", np.round([ds[b + 1] - ds[b] for b in range(len(dm) - 1)], 1))
     # what delayed the simulated TU / D?  inputs' simulated end times relative to D(b) end
-    DURS = {0: 29.0, 1: 23.0, 2: 19.0, 3: 25.0, 4: 16.5, 5: 20.0}
+    DURS = {0: 23.0, 1: 23.0, 2: 19.0, 3: 25.0, 4: 16.5, 5: 20.0}
     for b in range(1, len(dm) - 1):
         if ds[b + 1] - ds[b] < 52: continue
-        dend = ds[b] + 29.0
+        dend = ds[b] + 23.0
         tu = [key[(5, b, q, 0)] for q in range(4)]
         ubb = key.get((3, b - 1, b + 1, b + 1))
         uqs = [key[(4, b - 1, (b + 1) * 4 + q, b)] for q in range(4) if (4, b - 1, (b + 1) * 4 + q, b) in key]
         tk = key.get((1, b - 1, b + 1, 0))
-        print(f"  sim b={b}: step {ds[b+1]-ds[b]:.1f}  TU start {max(sim[k] for k in tu)-dend:6.1f}  Ubb start {sim[ubb]-dend:6.1f}  Uq start {max(sim[k] for k in uqs)-dend:6.1f}  T(b-1,b+1) start {sim[tk]-dend:6.1f}  (D(b-1) end {ds[b-1]+29-dend:6.1f})")
+        print(f"  sim b={b}: step {ds[b+1]-ds[b]:.1f}  TU start {max(sim[k] for k in tu)-dend:6.1f}  Ubb start {sim[ubb]-dend:6.1f}  Uq start {max(sim[k] for k in uqs)-dend:6.1f}  T(b-1,b+1) start {sim[tk]-dend:6.1f}  (D(b-1) end {ds[b-1]+23-dend:6.1f})")
