@@ -1,16 +1,15 @@
 export TMPDIR=/tmp
-run() { echo -n "$1 : "; env $1 timeout 300 python tools/mega_trace.py run 6000 2>/dev/null | grep "chol ms"; }
-for rep in 1 2; do
-run "X=0"
-run "STBA_MEGA_QROWS=1"
-run "STBA_MEGA_QROWS=3"
-run "STBA_MEGA_QROWS=4"
-run "STBA_MEGA_ROWMAP=2"
-run "STBA_MEGA_ROWMAP=0"
-run "STBA_MEGA_DUR=23,23,19,25,16.5,20"
-run "STBA_MEGA_DUR=23,21,19,24,16,18"
-run "STBA_MEGA_DUR=29,23,19,27,16.5,20"
-run "STBA_MEGA_RES=2,2"
-run "STBA_MEGA_BLEVEL=0.5"
-run "STBA_MEGA_BLEVEL=2"
-done
+timeout 900 python -m pytest tests -x -q -m gpu > gpurun_out/pytest_tmp.txt 2>&1
+grep -E "passed|failed" gpurun_out/pytest_tmp.txt
+python __graft_entry__.py smoke 2>&1 | tail -1
+timeout 300 python tools/mega_stress.py 6000 6 1 2>&1 | tail -1
+timeout 300 python tools/mega_stress.py 1500 20 2 2>&1 | tail -1
+bash tools/gpu_prof.sh r2_f > gpurun_out/prof_r2_f.log 2>&1
+cd $GRAFT_REPO_ROOT
+timeout 900 python bench.py > gpurun_out/bench_r2_f_full.json 2> gpurun_out/bench_r2_f_full.err
+python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/bench_r2_f_full.json').read().strip().splitlines()[-1])
+print('it/s', d['value'], 'ms', d['ms_per_step'], d['reps_ms_per_step'])
+print(d['phase_ms_per_step']); print(d['cholesky_ms']['factor_persistent_kernel'], d['cholesky_ms']['backward']); print(d['roofline']['frac'], d['roofline']['traffic'], d['roofline_jacobian']['frac']); print(d['cpu_baseline']['value'], d['speedup_vs_cpu_port'], d['matched_result_gate']['passed'])
+PY
