@@ -1317,7 +1317,7 @@ __device__ __forceinline__ bool mega_wait(const int* p, int target, int* abortf)
 __device__ __forceinline__ bool trsm_compute512(double4v (&W)[8], const double* __restrict__ rowp, bool ident,
                                                 int ident_row0, int nv, const double* __restrict__ Lb, int lda,
                                                 const double* __restrict__ dinv, double* smem, int t, long long* ph,
-                                                const int* dflag, int* abortf, int* s_ok) {
+                                                const int* dflag, int* abortf, int* s_ok, bool flag_known = false) {
     const int lane = t & 63;
     const int n = lane & 15, g = lane >> 4;
     // this wave's rows (issued first: they are not needed before the staging is done)
@@ -1330,12 +1330,16 @@ __device__ __forceinline__ bool trsm_compute512(double4v (&W)[8], const double* 
             W[J] = gld4(rowp + 16 * J + 4 * g);
         }
     }
-    if (t == 0) {
-        *s_ok = mega_wait(dflag, 1, abortf) ? 1 : 0;
-        asm volatile("buffer_inv sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
+    // (flag_known: the caller has SEEN the diagonal block's flag set -- in the same poll that found the task ready --, so the
+    // factor's tiles are requested right behind the rows: one memory round trip in front of the first MFMA instead of two)
+    if (!flag_known) {
+        if (t == 0) {
+            *s_ok = mega_wait(dflag, 1, abortf) ? 1 : 0;
+            asm volatile("buffer_inv sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        if (!*s_ok) return false;
     }
-    __syncthreads();
-    if (!*s_ok) return false;
     // stage tile (J, I), J > I, at index 7I - I(I-1)/2 + (J-I-1), then the inverse tiles at 28 + J;
     // element (r, c) of a tile goes to lane (n = pm(r), g = c >> 2), register c & 3, with
     // pm(r) = 4 (r & 3) + (r >> 2) (an involution)
@@ -1390,9 +1394,9 @@ __device__ __forceinline__ bool trsm_compute512(double4v (&W)[8], const double* 
 __device__ __forceinline__ bool trsm_task512(double* __restrict__ rowp, bool ident, int ident_row0, int nv,
                                              const double* __restrict__ Lb, int lda,
                                              const double* __restrict__ dinv, double* smem, int t, long long* ph,
-                                             const int* dflag, int* abortf, int* s_ok) {
+                                             const int* dflag, int* abortf, int* s_ok, bool flag_known = false) {
     double4v W[8];
-    if (!trsm_compute512(W, rowp, ident, ident_row0, nv, Lb, lda, dinv, smem, t, ph, dflag, abortf, s_ok)) return false;
+    if (!trsm_compute512(W, rowp, ident, ident_row0, nv, Lb, lda, dinv, smem, t, ph, dflag, abortf, s_ok, flag_known)) return false;
     const int g = (t & 63) >> 4;
 #pragma unroll
     for (int J = 0; J < 8; ++J) gst4<true>(rowp + 16 * J + 4 * g, W[J]);
@@ -1407,7 +1411,7 @@ __device__ __forceinline__ bool trsm_task512(double* __restrict__ rowp, bool ide
 // A[b+1, b+1] -= X X^T (lower-triangle tiles only).  Workgroup q also writes rows 32q..32q+31 of X.
 __device__ __forceinline__ bool tu_task512(double* __restrict__ A, int lda, int k0, int rb, int q,
                                            const double* __restrict__ dinv, double* smem, int t, long long* ph,
-                                           int* loaded, int* ver_diag, const int* dflag, int* abortf, int* s_ok) {
+                                           int* loaded, int* ver_diag, const int* dflag, int* abortf, int* s_ok, bool flag_known = false) {
     const int lane = t & 63, w = t >> 6;
     const int n = lane & 15, g = lane >> 4;
     double* rowp = A + (size_t)(rb * NB + 16 * w + n) * lda + k0;
@@ -1428,7 +1432,7 @@ __device__ __forceinline__ bool tu_task512(double* __restrict__ A, int lda, int 
         }
     }
     double4v W[8];
-    if (!trsm_compute512(W, rowp, false, 0, NB, A + (size_t)k0 * lda + k0, lda, dinv, smem, t, ph, dflag, abortf, s_ok)) return false;
+    if (!trsm_compute512(W, rowp, false, 0, NB, A + (size_t)k0 * lda + k0, lda, dinv, smem, t, ph, dflag, abortf, s_ok, flag_known)) return false;
     __syncthreads();                          // every wave is done with the L11 tiles in smem and has consumed its rows
     // the four TU workgroups of this step all READ the whole block row and each WRITES 32 rows of it in
     // place: count the readers, and store only once all four have their copy (see below)
@@ -1504,7 +1508,7 @@ __device__ __forceinline__ void syrk_q32(double* __restrict__ A, int lda, int k0
 
 __global__ __launch_bounds__(512) void chol_mega_kernel(MegaArgs a) {
     extern __shared__ __attribute__((aligned(16))) double smem[];   // MEGA_SMEM_BYTES: SYRK staging | diagonal block | L11 tiles | X
-    __shared__ int s_task, s_ok, s_hc;
+    __shared__ int s_task, s_ok, s_hc, s_dset;
     __shared__ int4 s_hd[64];              // the urgent list's window [s_hc, s_hc + 64) as wave 0 saw it last
     const int t = threadIdx.x;
     const int nblk = a.nblk;
@@ -1543,6 +1547,7 @@ __global__ __launch_bounds__(512) void chol_mega_kernel(MegaArgs a) {
     int* claim = ver + nrow * nblk;
     const int qbeg = a.qstart[q], qend = a.hstart[q], hbeg = a.hstart[q], hend = a.qstart[q + 1];
     auto ldf = [](const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    bool tu_dset = false;
     auto ready = [&](const int4 d, bool urgent) -> bool {
         const int type = d.x & 0xff, b = d.y, ti = d.z, tj = d.w;
         if (type == TASK_D) return ldf(&ver[b * nblk + b]) >= 4 * b;
@@ -1558,7 +1563,8 @@ __global__ __launch_bounds__(512) void chol_mega_kernel(MegaArgs a) {
         }
         if (type == TASK_TI) return ldf(&dflag[b]) >= 1;
         if (type == TASK_TU) {
-            const int v0 = ldf(&ver[(b + 1) * nblk + b]), v1 = ldf(&ver[(b + 1) * nblk + b + 1]);
+            const int v0 = ldf(&ver[(b + 1) * nblk + b]), v1 = ldf(&ver[(b + 1) * nblk + b + 1]), df = ldf(&dflag[b]);
+            tu_dset = df >= 1;      // (is the diagonal block there already?  then the task fetches its factor at once)
             return (v0 >= 4 * b) & (v1 >= 4 * b);
         }
         const int i = (type == TASK_UQ) ? (ti >> 2) : ti;
@@ -1656,6 +1662,7 @@ __global__ __launch_bounds__(512) void chol_mega_kernel(MegaArgs a) {
                     a.trace[8 * (size_t)pick + 2] = wall_clock64();
                 }
                 s_hc = hc;
+                s_dset = tu_dset ? 1 : 0;
                 s_task = pick;
                 s_ok = ok ? 1 : 0;
             }
@@ -1700,7 +1707,9 @@ __global__ __launch_bounds__(512) void chol_mega_kernel(MegaArgs a) {
             const int lane = tt & 63, w = tt >> 6;
             int ldr;
             double* rowp = tile_ptr(ti, b, ldr) + (size_t)(16 * w + (lane & 15)) * ldr;
-            if (!trsm_task512(rowp, false, 0, NB, a.A + (size_t)k0 * a.lda + k0, a.lda, li + NB * NB, smem, tt, ph, &dflag[b], abortf, &s_ok)) {
+            // (a bulk panel solve is only started once its diagonal block is there: see ready())
+            if (!trsm_task512(rowp, false, 0, NB, a.A + (size_t)k0 * a.lda + k0, a.lda, li + NB * NB, smem, tt, ph, &dflag[b], abortf, &s_ok,
+                              hbeg >= hend && !((d.x >> 24) & 1))) {
                 if (t == 0) atomicExch(a.flag, CHOL_FLAG_TIMEOUT);
                 break;
             }
@@ -1712,7 +1721,7 @@ __global__ __launch_bounds__(512) void chol_mega_kernel(MegaArgs a) {
             double* base = li;
             if (b < 4 * a.nwide) base = tile_ptr(nblk + b, b, ldr);
             double* rowp = base + (size_t)(16 * w + (lane & 15)) * ldr;
-            if (!trsm_task512(rowp, true, 16 * w, nv, a.A + (size_t)k0 * a.lda + k0, a.lda, li + NB * NB, smem, tt, ph, &dflag[b], abortf, &s_ok)) {
+            if (!trsm_task512(rowp, true, 16 * w, nv, a.A + (size_t)k0 * a.lda + k0, a.lda, li + NB * NB, smem, tt, ph, &dflag[b], abortf, &s_ok, true)) {
                 if (t == 0) atomicExch(a.flag, CHOL_FLAG_TIMEOUT);
                 break;
             }
@@ -1728,7 +1737,8 @@ __global__ __launch_bounds__(512) void chol_mega_kernel(MegaArgs a) {
                 syrk_tile512_gen<128>(Cb, ldc, Pi, ldi, Pj, ldj, b == first_panel(ti), smem, tt);
             }
         } else if (type == TASK_TU) {
-            if (!tu_task512(a.A, a.lda, k0, b + 1, ti, li + NB * NB, smem, tt, ph, &tuflag[b], &ver[(b + 1) * nblk + b + 1], &dflag[b], abortf, &s_ok)) {
+            if (!tu_task512(a.A, a.lda, k0, b + 1, ti, li + NB * NB, smem, tt, ph, &tuflag[b], &ver[(b + 1) * nblk + b + 1], &dflag[b], abortf, &s_ok,
+                            s_dset != 0)) {
                 if (t == 0) atomicExch(a.flag, CHOL_FLAG_TIMEOUT);
                 break;
             }

@@ -1,15 +1,13 @@
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests -x -q -m gpu > gpurun_out/pytest_tmp.txt 2>&1
-grep -E "passed|failed" gpurun_out/pytest_tmp.txt
-python __graft_entry__.py smoke 2>&1 | tail -1
-timeout 300 python tools/mega_stress.py 6000 6 1 2>&1 | tail -1
+for rep in 1 2 3 4; do timeout 300 python tools/mega_trace.py run 6000; done
+timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_sharding.py -x -q -m gpu 2>&1 | grep -E "passed|failed"
+timeout 300 python tools/mega_stress.py 3000 10 1 2>&1 | tail -1
 timeout 300 python tools/mega_stress.py 1500 20 2 2>&1 | tail -1
-bash tools/gpu_prof.sh r2_f > gpurun_out/prof_r2_f.log 2>&1
-cd $GRAFT_REPO_ROOT
-timeout 900 python bench.py > gpurun_out/bench_r2_f_full.json 2> gpurun_out/bench_r2_f_full.err
-python - <<'PY'
+STBA_MEGA_TRACE=/tmp/mega.bin timeout 300 python tools/mega_trace.py run 6000
+timeout 100 python tools/mega_trace.py /tmp/mega.bin > gpurun_out/mega_trace_d3.txt
+timeout 300 python bench.py --reps 3 --steps 50 --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/bench_d3.json; python - <<'PY'
 import json
-d=json.loads(open('gpurun_out/bench_r2_f_full.json').read().strip().splitlines()[-1])
-print('it/s', d['value'], 'ms', d['ms_per_step'], d['reps_ms_per_step'])
-print(d['phase_ms_per_step']); print(d['cholesky_ms']['factor_persistent_kernel'], d['cholesky_ms']['backward']); print(d['roofline']['frac'], d['roofline']['traffic'], d['roofline_jacobian']['frac']); print(d['cpu_baseline']['value'], d['speedup_vs_cpu_port'], d['matched_result_gate']['passed'])
+d=json.loads(open('gpurun_out/bench_d3.json').read())
+print('it/s', round(d['value'],2), 'ms/step', round(d['ms_per_step'],3), d['reps_ms_per_step'])
+print(d['cholesky_ms']['factor_persistent_kernel'])
 PY
