@@ -1,5 +1,5 @@
 export TMPDIR=/tmp
-for rep in 1 2 3 4; do timeout 300 python tools/mega_trace.py run 6000; done
-timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu 2>&1 | grep -E "passed|failed"
-bash tools/pmc_chol.sh r2_nt > gpurun_out/pmc_chol_r2_nt.log 2>&1
-tail -1 gpurun_out/pmc_chol_r2_nt.log | cut -c1-200
+for kv in "STBA_MEGA_HI=3" "STBA_MEGA_FUSET=1" "STBA_MEGA_QFROM=24" "STBA_MEGA_BATCH=4 STBA_MEGA_BLAG=5 STBA_MEGA_PREDRAW=1" "STBA_MEGA_BATCH=1" "STBA_BWD_WIDE=0" "STBA_LM_SPECULATE=0"; do
+echo "== $kv"
+env $kv timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "cholesky or c5_full or st20_reference" 2>&1 | grep -E "passed|failed"
+done
