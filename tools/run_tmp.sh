@@ -1,5 +1,10 @@
 export TMPDIR=/tmp
-for kv in "STBA_MEGA_HI=3" "STBA_MEGA_FUSET=1" "STBA_MEGA_QFROM=24" "STBA_MEGA_BATCH=4 STBA_MEGA_BLAG=5 STBA_MEGA_PREDRAW=1" "STBA_MEGA_BATCH=1" "STBA_BWD_WIDE=0" "STBA_LM_SPECULATE=0"; do
-echo "== $kv"
-env $kv timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "cholesky or c5_full or st20_reference" 2>&1 | grep -E "passed|failed"
+timeout 900 python -m pytest tests -x -q -m gpu 2>&1 | grep -E "passed|failed"
+timeout 300 python tools/mega_stress.py 1500 20 2 2>&1 | tail -1
+for f in 0 1 0 1; do
+STBA_BWD_FUSED=$f timeout 300 python bench.py --reps 3 --steps 50 --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/bench_d3.json; python - $f <<'PY'
+import json,sys
+d=json.loads(open('gpurun_out/bench_d3.json').read())
+print('FUSED', sys.argv[1], 'it/s', round(d['value'],2), 'ms/step', round(d['ms_per_step'],3), 'bwd', round(d['cholesky_ms']['backward'],4), 'factor', round(d['cholesky_ms']['factor_persistent_kernel'],3))
+PY
 done
