@@ -1,10 +1,16 @@
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests -x -q -m gpu 2>&1 | grep -E "passed|failed"
-timeout 300 python tools/mega_stress.py 1500 20 2 2>&1 | tail -1
-for f in 0 1 0 1; do
-STBA_BWD_FUSED=$f timeout 300 python bench.py --reps 3 --steps 50 --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/bench_d3.json; python - $f <<'PY'
-import json,sys
-d=json.loads(open('gpurun_out/bench_d3.json').read())
-print('FUSED', sys.argv[1], 'it/s', round(d['value'],2), 'ms/step', round(d['ms_per_step'],3), 'bwd', round(d['cholesky_ms']['backward'],4), 'factor', round(d['cholesky_ms']['factor_persistent_kernel'],3))
+cd /tmp
+rocprofv3 --list-avail 2>/dev/null | grep -o "TCC_[A-Z_a-z0-9]*" | sort -u | tr '\n' ' ' | cut -c1-1500
+echo
+OUT=/tmp/tcc; rm -rf $OUT; mkdir -p $OUT
+timeout 600 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA_RDREQ_sum TCC_EA_RDREQ_32B_sum --output-format csv -d $OUT -- python $GRAFT_REPO_ROOT/tools/chol_trace.py run 6000 > $OUT/log.txt 2>&1
+python - <<'PY'
+import csv, glob, collections
+acc = collections.defaultdict(list)
+for f in glob.glob("/tmp/tcc/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "chol_mega_kernel" in r.get("Kernel_Name",""):
+            acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k,v in acc.items(): print(k, sum(v)/len(v), len(v))
 PY
-done
+tail -2 $OUT/log.txt
