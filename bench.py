@@ -166,14 +166,19 @@ def main():
         if world > 1 and args.backend == "gloo":
             # launch-path check on a box without GPUs: rendezvous, sharding, the max-over-ranks reduction and the
             # JSON line are exercised; the product has no CPU fallback, so there is nothing to time
-            counts = torch.tensor([float(len(sh["obs_cam"]))], dtype=torch.float64)
+            counts = torch.zeros(world, dtype=torch.float64)
+            counts[rank] = float(len(sh["obs_cam"]))
             dist.all_reduce(counts)
             dist.barrier()
             if rank == 0:
+                # (the keys that explain an N > 1 line are present, without values: nothing ran)
                 print(json.dumps({"metric": "LM iterations/sec + residuals/sec, 1k-cam/100k-pt BA", "value": None,
                                   "unit": "LM iterations/s", "n_gpus": world, "ranks": dist.get_world_size(),
                                   "skipped": "no HIP device: libstba has no CPU fallback",
-                                  "sharded_observations": int(counts.item()), "n_obs": n_obs}), flush=True)
+                                  "sharded_observations": int(counts.sum().item()), "n_obs": n_obs,
+                                  "observations_per_rank": [int(v) for v in counts.tolist()],
+                                  "phase_ms_per_step": None, "allreduce_ms": None, "allreduce_bytes": None,
+                                  "allreduce_calls_per_step": None}), flush=True)
             dist.destroy_process_group()
             return
         raise SystemExit("bench.py needs an MI355X: libstba has no CPU fallback")
@@ -186,15 +191,36 @@ def main():
     comm = None
     if world > 1:
         if args.hook == "native":
-            try:
-                box = [st.comm_unique_id() if rank == 0 else None]
-                dist.broadcast_object_list(box, src=0)
-                comm = st.Comm(box[0], rank, world, device=local_rank)
+            # the decision native communicator | torch hook is COLLECTIVE: rank 0 always broadcasts (the id or None), and after
+            # the communicator is created the ranks agree on whether every one of them succeeded -- a rank that fell back
+            # alone would leave the others blocked in ncclCommInitRank or issue mismatched collectives
+            uid = None
+            if rank == 0:
+                try:
+                    uid = st.comm_unique_id()
+                except Exception as e:      # noqa: BLE001
+                    print(f"[rank 0] native communicator: no unique id ({e!r})", file=sys.stderr, flush=True)
+            box = [uid]
+            dist.broadcast_object_list(box, src=0)
+            ok = 0.0
+            if box[0] is not None:
+                try:
+                    comm = st.Comm(box[0], rank, world, device=local_rank)
+                    ok = 1.0
+                except Exception as e:      # noqa: BLE001
+                    print(f"[rank {rank}] native communicator failed ({e!r})", file=sys.stderr, flush=True)
+                    comm = None
+            agree = torch.tensor([ok], dtype=torch.float64, device="cuda" if (have_gpu and args.backend == "nccl") else "cpu")
+            dist.all_reduce(agree, op=dist.ReduceOp.MIN)
+            if float(agree.item()) >= 1.0:
                 eng.set_comm(comm)
                 collective = "native RCCL (ncclAllReduce on the engine stream, stba_comm)"
-            except Exception as e:      # noqa: BLE001
-                print(f"[rank {rank}] native communicator failed ({e!r}); falling back to the torch hook", file=sys.stderr, flush=True)
+            else:
+                if comm is not None:
+                    comm.close()
                 comm = None
+                if rank == 0:
+                    print("native communicator not available on every rank: all ranks use the torch hook", file=sys.stderr, flush=True)
         if comm is None:
             eng.set_allreduce(sharding.torch_allreduce_hook(dist, torch), rank, world)
             collective = "torch.distributed all_reduce (RCCL) through the Python hook"
@@ -235,10 +261,29 @@ def main():
                                "st20 spiral/cube scene seed 20, pixel noise 1e-3",
                    "parallelism": f"landmark-shard x{world}" if world > 1 else "single GPU",
                    "collective": collective, "n_cams": n_cams, "n_pts": n_pts, "n_obs": n_obs},
-        "phase_ms_per_step": {k: getattr(summ, k) / args.steps for k in
-                              ("ms_linearize", "ms_schur", "ms_solve", "ms_backsub", "ms_cost")},
         "final_cost": summ.final_cost,
     }
+    # device time per phase of the LAST repetition (hipEvents on the engine's stream), per step; with several ranks the
+    # MAXIMUM over ranks, plus what explains an N > 1 line: the cross-rank sum's device time and bytes per step and the
+    # observations each rank holds (the Cholesky of the reduced system is replicated on every rank: DESIGN.md 6)
+    phase_keys = ("ms_linearize", "ms_schur", "ms_solve", "ms_backsub", "ms_cost", "ms_allreduce")
+    phases = np.array([getattr(summ, k) / args.steps for k in phase_keys], dtype=np.float64)
+    local_counts = np.zeros(world, dtype=np.float64)
+    local_counts[rank] = float(len(sh["obs_cam"]))
+    if world > 1:
+        dev = "cuda" if (have_gpu and args.backend == "nccl") else "cpu"
+        tp = torch.tensor(phases, dtype=torch.float64, device=dev)
+        dist.all_reduce(tp, op=dist.ReduceOp.MAX)
+        phases = tp.cpu().numpy()
+        tc = torch.tensor(local_counts, dtype=torch.float64, device=dev)
+        dist.all_reduce(tc)
+        local_counts = tc.cpu().numpy()
+    out["phase_ms_per_step"] = {k: float(v) for k, v in zip(phase_keys[:5], phases[:5])}
+    out["phase_ms_per_step"]["timing"] = "hipEvents on the engine stream, last repetition" + (", max over ranks" if world > 1 else "")
+    out["allreduce_ms"] = float(phases[5])                      # per step, inside ms_schur
+    out["allreduce_bytes"] = float(summ.allreduce_bytes / max(1, summ.allreduce_calls))      # per call and rank
+    out["allreduce_calls_per_step"] = float(summ.allreduce_calls / args.steps)
+    out["observations_per_rank"] = [int(v) for v in local_counts]
 
     if rank == 0:
         # ---- roofline legs, measured live with hipEvents on the engine's stream
@@ -264,6 +309,7 @@ def main():
             pass
         roof_jac = {"kernel": "ba_linearize_kernel<cams-in-LDS, with-Jacobian> (residual + compact 64 B Jacobian per observation)", "bound": "hbm", "achieved": jac_gbs,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": jac_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                    "traffic_source": "profiles/pmc_jacobian.json (PMC passes of tools/pmc_jacobian.sh on the C5 shape; a recorded figure, not measured in this run)",
                     "ms_per_launch": ms_jac, "algorithmic_bytes_per_launch": jac_bytes, "algorithmic_bytes_per_observation": BYTES_PER_OBS_JAC}
         chol_traffic = None
         try:
@@ -275,7 +321,9 @@ def main():
             pass
         roof_chol = {"kernel": "chol_mega_kernel (persistent dataflow Cholesky, v_mfma_f64_16x16x4_f64)",
                      "bound": "mfma", "achieved": chol_tflops, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": chol_tflops / FP64_MFMA_PEAK_TFLOPS, "traffic": chol_traffic, "ms_per_launch": ms_factor,
+                     "frac": chol_tflops / FP64_MFMA_PEAK_TFLOPS, "traffic": chol_traffic,
+                     "traffic_source": "profiles/pmc_chol.json (PMC passes of tools/pmc_chol.sh at n = 6000; a recorded figure, not measured in this run)",
+                     "ms_per_launch": ms_factor,
                      "algorithmic_flops_per_launch": chol_flops, "launches_per_lm_iteration": 1,
                      "microbench_ceiling": FP64_MFMA_MEASURED_CEILING_TFLOPS,
                      "frac_of_microbench_ceiling": chol_tflops / FP64_MFMA_MEASURED_CEILING_TFLOPS}
@@ -297,21 +345,30 @@ def main():
             def fresh():
                 return O.BA(s["cams0"], s["pts0"], s["obs_cam"], s["obs_pt"], s["obs_feat"], s["cam_fixed"])
 
-            # ---- matched-result gate: same start, same fixed iteration count, GPU leg vs CPU leg
-            n_gate = 3
+            # ---- matched-result gate: same start, both legs run to CONVERGENCE (Ceres' default stopping rules,
+            # test_ceres.h:148; north_star: "same converged parameters"); the oracle factors with LAPACK here so that the
+            # ~30 iterations take seconds
             ob = fresh()
+            gate_blas = O.use_lapack(True, threads=min(ncpu, 16))
             tg = time.perf_counter()
-            so, tro = ob.solve(fixed_iterations=n_gate, num_threads=min(ncpu, 16))
+            try:
+                so, tro = ob.solve(num_threads=min(ncpu, 16))
+            finally:
+                O.use_lapack(False)
             t_gate = time.perf_counter() - tg
             eng.set_params(s["cams0"], s["pts0"])
-            sg, trg = eng.lm_iterations(n_gate)
+            sg, trg = eng.solve()
+            n_gate = int(so.num_iterations)
             cams_g, _ = eng.get_params()
             rel_cost = abs(sg.final_cost - so.final_cost) / max(abs(so.final_cost), 1e-300)
             dq, dtp = pose_err(cams_g, ob.cams)
-            matched = bool(rel_cost <= 1e-6 and dq <= 1e-5 and dtp <= 1e-5 and np.array_equal(trg[:, 6], tro[:, 6]))
-            out["matched_result_gate"] = {"iterations": n_gate, "gpu_final_cost": sg.final_cost, "cpu_final_cost": so.final_cost,
+            same_seq = bool(sg.num_iterations == n_gate and np.array_equal(trg[: n_gate + 1, 6], tro[: n_gate + 1, 6]))
+            matched = bool(rel_cost <= 1e-6 and dq <= 1e-5 and dtp <= 1e-5 and same_seq and sg.termination_type == 0 and so.termination_type == 0)
+            out["matched_result_gate"] = {"run": "to convergence on both legs", "iterations_gpu": int(sg.num_iterations), "iterations_cpu": n_gate,
+                                          "gpu_final_cost": sg.final_cost, "cpu_final_cost": so.final_cost,
                                           "relative_cost_difference": rel_cost, "pose_dq": dq, "pose_dt": dtp,
-                                          "same_accept_reject_sequence": bool(np.array_equal(trg[:, 6], tro[:, 6])),
+                                          "same_accept_reject_sequence": same_seq, "gpu_solve_seconds": sg.seconds_total,
+                                          "cpu_solve_seconds": t_gate, "cpu_dense_solver": gate_blas or "oracle C Cholesky",
                                           "tolerances": {"cost_rel": 1e-6, "pose": 1e-5}, "passed": matched}
 
             def time_oracle(threads, budget_s, runs):
@@ -385,7 +442,6 @@ def main():
             except Exception:
                 scene_file = None
             out["ceres_baseline"] = ceres_row(scene_file, n_gate) if scene_file else ceres_row("", n_gate)
-            _ = t_gate
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define STBA_VERSION 1
+#define STBA_VERSION 2
 
 /* status codes */
 enum {
@@ -101,6 +101,10 @@ typedef struct {
     double seconds_total;
     /* device time per phase, milliseconds, summed over iterations (hipEvent) */
     double ms_linearize, ms_schur, ms_solve, ms_backsub, ms_cost;
+    /* several ranks: the cross-rank sums of the reduced camera system of this run -- device time between
+     * events around the collective (part of ms_schur), bytes handed to it per rank, number of calls; 0 on one rank */
+    double ms_allreduce, allreduce_bytes;
+    int    allreduce_calls;
 } stba_lm_summary;
 
 /* iteration trace row: cost, cost_change, gradient_max_norm, step_norm, relative_decrease,

@@ -39,6 +39,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <initializer_list>
 #include <map>
@@ -425,6 +426,7 @@ public:
                min_relative_decrease = 1e-3, min_lm_diagonal = 1e-6, max_lm_diagonal = 1e32,
                function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
         bool jacobi_scaling = true;
+        bool force_callback_path = false;   // (not in Ceres) never replace user cost functions by the built-in device factor: see Solve()
     };
     struct Summary {
         TerminationType termination_type = FAILURE;
@@ -522,9 +524,12 @@ inline void ReprojectionAt(const double* q, const double* t, const double* L, do
 // generic probe points (unit quaternions, landmark well in front of the camera)
 struct ProbePoint { double q[4], t[3], L[3]; };
 inline const ProbePoint* ProbePoints() {
-    static const ProbePoint pts[2] = {
+    // (the third point has a different geometry: a rotation of more than 90 degrees and a landmark that projects far off
+    // the optical axis, |x/z| ~ 1.9: a cost that clamps or guards large image coordinates differs here)
+    static const ProbePoint pts[3] = {
         {{0.18257418583505536, 0.3651483716701107, 0.5477225575051661, 0.7302967433402214}, {0.3, -0.2, 0.1}, {1.1, 0.7, 2.9}},
-        {{-0.2721655269759087, 0.1360827634879543, 0.4082482904638630, 0.8606629658238704}, {-0.4, 0.25, -0.6}, {0.2, -0.9, 3.3}}};
+        {{-0.2721655269759087, 0.1360827634879543, 0.4082482904638630, 0.8606629658238704}, {-0.4, 0.25, -0.6}, {0.2, -0.9, 3.3}},
+        {{0.0, 0.8, 0.0, 0.6}, {0.5, 0.1, -0.2}, {1.035, -0.775, -2.83}}};
     return pts;
 }
 
@@ -541,7 +546,7 @@ inline bool ProbeReprojectionValue(const CostFunction* cost, double* feature) {
     if (!cost->Evaluate(p0, r, nullptr) || !std::isfinite(r[0]) || !std::isfinite(r[1])) return false;
     feature[0] = -r[0]; feature[1] = -r[1];
     const ProbePoint* pp = ProbePoints();
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < 3; ++k) {
         const double* p[3] = {pp[k].q, pp[k].t, pp[k].L};
         double proj[2];
         ReprojectionAt(pp[k].q, pp[k].t, pp[k].L, proj);
@@ -820,7 +825,14 @@ inline bool SolveDense(const Solver::Options& o, Problem* p, Solver::Summary* su
 inline void Solve(const Solver::Options& options, Problem* problem, Solver::Summary* summary) {
     *summary = Solver::Summary();
     internal::BaLayout L;
-    bool ba = internal::DetectBa(*problem, &L);
+    // CONTRACT of the recognition (DetectBa): a user cost function is replaced by the built-in device factor if it equals
+    // proj(conj(q)(L - t)) - feature at three probe points (1e-12) and, once per C++ type, its Jacobian equals the closed form
+    // at one of them (1e-9).  A cost that agrees there and differs elsewhere (a guard that only fires behind the camera, say)
+    // would be replaced silently: Solver::Options::force_callback_path = true (or STBA_CERES_FORCE_CALLBACK=1 in the
+    // environment) keeps every block on the generic path, where the user's Evaluate is what runs.
+    const char* fe = std::getenv("STBA_CERES_FORCE_CALLBACK");
+    const bool force_cb = options.force_callback_path || (fe && *fe && *fe != '0');
+    bool ba = !force_cb && internal::DetectBa(*problem, &L);
     if (ba)
         for (int rb : L.rot_block) ba = ba && internal::UsesQuaternionRightPlus(problem->blocks()[rb].local);
     if (ba) { summary->execution_path = "gpu-ba"; internal::SolveBa(options, problem, L, summary); }

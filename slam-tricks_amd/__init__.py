@@ -45,7 +45,8 @@ class LMSummary(C.Structure):
                 ("initial_cost", C.c_double), ("final_cost", C.c_double), ("final_radius", C.c_double),
                 ("final_gradient_max_norm", C.c_double), ("seconds_total", C.c_double),
                 ("ms_linearize", C.c_double), ("ms_schur", C.c_double), ("ms_solve", C.c_double),
-                ("ms_backsub", C.c_double), ("ms_cost", C.c_double)]
+                ("ms_backsub", C.c_double), ("ms_cost", C.c_double),
+                ("ms_allreduce", C.c_double), ("allreduce_bytes", C.c_double), ("allreduce_calls", C.c_int)]
 
     def as_dict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_}

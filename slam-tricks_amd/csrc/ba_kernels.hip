@@ -1284,6 +1284,7 @@ __global__ __launch_bounds__(256) void calib_arrow_step_kernel(int n_views, cons
     if (state[1] != 0) return;
     constexpr int SCR = 54 + 6 + 45 + 9;
     __shared__ double s_S[45], s_rhs[9], s_di[9], s_un[256], s_sse;
+    __shared__ int s_fail;
     const int t = threadIdx.x;
     for (int v = t; v < n_views; v += 256) {
         const double* G = gram + (size_t)v * CALIB_GRAM;
@@ -1378,8 +1379,13 @@ __global__ __launch_bounds__(256) void calib_arrow_step_kernel(int n_views, cons
             x[i] = sum / L[i * (i + 1) / 2 + i];
         }
         for (int i = 0; i < 9; ++i) s_di[i] = x[i];
+        s_fail = atomicAdd(&state[2], 0);               // a failed pivot of any view block or of the 9 x 9 complement
     }
     __syncthreads();
+    if (s_fail != 0) {                                  // the parameters stay as they were (the caller gets them back untouched)
+        if (t == 0) { sse_trace[state[0]] = s_sse; state[1] = 2; }
+        return;
+    }
     // pose steps dx_v = -z_v - Y_v di, left-multiplicative update
     double un = 0.0;
     for (int v = t; v < n_views; v += 256) {
@@ -1404,8 +1410,7 @@ __global__ __launch_bounds__(256) void calib_arrow_step_kernel(int n_views, cons
         for (int a = 0; a < 9; ++a) { tot += s_di[a] * s_di[a]; params[a] += s_di[a]; }     // calib.cpp:394
         const int it = state[0];
         sse_trace[it] = s_sse;
-        if (state[2] != 0) state[1] = 2;                // failed pivot: stop
-        else if (sqrt(tot) < 1e-8) state[1] = 1;        // calib.cpp:404 (the iteration counter is not advanced on the break)
+        if (sqrt(tot) < 1e-8) state[1] = 1;        // calib.cpp:404 (the iteration counter is not advanced on the break)
         else state[0] = it + 1;
     }
 }

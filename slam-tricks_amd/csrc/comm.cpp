@@ -37,12 +37,15 @@ Rccl& rccl() {
     static std::once_flag once;
     std::call_once(once, [] {
         const char* names[] = {getenv("STBA_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        std::string why;
         for (const char* n : names) {
             if (!n || !*n) continue;
             r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
             if (r.handle) break;
+            const char* e = dlerror();            // (one call: dlerror() clears the message it returns)
+            if (why.empty() && e) why = e;
         }
-        if (!r.handle) { r.error = std::string("librccl not found: ") + (dlerror() ? dlerror() : "?"); return; }
+        if (!r.handle) { r.error = std::string("librccl not found: ") + (why.empty() ? "?" : why); return; }
         auto sym = [&](const char* s) { void* p = dlsym(r.handle, s); if (!p) r.error = std::string("librccl lacks ") + s; return p; };
         r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
         r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));

@@ -113,6 +113,9 @@ struct stba_ba {
     int rank = 0, world = 1;
     bool have_lin = false, have_blocks = false, have_reduced = false, have_dxc = false, have_dxp = false;
     bool scale_init = false;
+    hipEvent_t ev_ar[2] = {};   // around the cross-rank sum of the reduced system (several ranks only)
+    bool ar_timing_pending = false;
+    double ar_ms = 0.0, ar_bytes = 0.0; int ar_calls = 0;   // accumulated over one LM run
     hipEvent_t ev[15] = {};     // [12]: the trial block has reached the host; [13], [14]: second pair for the speculative linearisation
     double* lin_pin = nullptr;      // pinned host copy of [scalars (SC_GPMAX0 + world) | gc (n)], read one solve later
     double* lin_pin_dev = nullptr;  // (its device address)
@@ -149,6 +152,7 @@ static void ba_free(stba_ba* b) {
     F(b->pair_begin); F(b->pair_end); F(b->pair_rec);
     F(b->cost_partial); F(b->upd_partial_c); F(b->upd_partial_p); F(b->trial); F(b->flag);
     for (auto& e : b->ev) if (e) (void)hipEventDestroy(e);
+    for (auto& e : b->ev_ar) if (e) (void)hipEventDestroy(e);
     if (b->lin_pin) (void)hipHostFree(b->lin_pin);
     if (b->ts_host) (void)hipHostFree(b->ts_host);
     if (b->own_stream && b->st) (void)hipStreamDestroy(b->st);
@@ -263,6 +267,15 @@ static int ba_plan_pack(stba_ba* b) {
     return STBA_OK;
 }
 
+// device time of the last cross-rank sum of the reduced system: read once its events have completed (after a
+// synchronisation of the stream; a pair still in flight is waited for -- only on the multi-rank path)
+static void ba_collect_allreduce_time(stba_ba* b) {
+    if (!b->ar_timing_pending) return;
+    float ms = 0.f;
+    if (hipEventSynchronize(b->ev_ar[1]) == hipSuccess && hipEventElapsedTime(&ms, b->ev_ar[0], b->ev_ar[1]) == hipSuccess) b->ar_ms += ms;
+    b->ar_timing_pending = false;
+}
+
 static int ba_build_reduced(stba_ba* b, const Damping& dm) {
     const int init_scale = b->scale_init ? 0 : 1;
     if (!dm.explicit_d)
@@ -306,8 +319,15 @@ static int ba_build_reduced(stba_ba* b, const Damping& dm) {
         const unsigned pgrid = (unsigned)((b->pack_count() + 255) / 256);
         if (b->pk_state == 2) hipLaunchKernelGGL(blk_pack_kernel, dim3(pgrid), dim3(256), 0, b->st, b->Sbuf, b->lda, b->pk_blocks, b->pk_nz, b->Spack, 1);
         else hipLaunchKernelGGL(tri_pack_kernel, dim3(b->n + 1), dim3(256), 0, b->st, b->Sbuf, b->lda, b->n, b->Spack, 1);
+        ba_collect_allreduce_time(b);                     // (a previous build's pair, if nobody has read it yet)
+        if (!b->ev_ar[0]) { STBA_HIP(hipEventCreate(&b->ev_ar[0])); STBA_HIP(hipEventCreate(&b->ev_ar[1])); }
+        STBA_HIP(hipEventRecord(b->ev_ar[0], b->st));
         if (b->ar(b->ar_user, b->Spack, b->pack_count(), b->st) != 0)
             return fail(STBA_ERR_CALLBACK, "all-reduce hook failed");
+        STBA_HIP(hipEventRecord(b->ev_ar[1], b->st));
+        b->ar_timing_pending = true;
+        b->ar_bytes += (double)b->pack_count() * sizeof(double);
+        b->ar_calls += 1;
         if (b->pk_state == 2) hipLaunchKernelGGL(blk_pack_kernel, dim3(pgrid), dim3(256), 0, b->st, b->Sbuf, b->lda, b->pk_blocks, b->pk_nz, b->Spack, 0);
         else hipLaunchKernelGGL(tri_pack_kernel, dim3(b->n + 1), dim3(256), 0, b->st, b->Sbuf, b->lda, b->n, b->Spack, 0);
         STBA_HIP(hipGetLastError());
@@ -431,6 +451,7 @@ static int ba_run_lm(stba_ba* b, const stba_lm_options* opt_in, int fixed_iterat
     hipEvent_t* ev = b->ev;
 
     b->scale_init = false;
+    b->ar_ms = 0.0; b->ar_bytes = 0.0; b->ar_calls = 0; b->ar_timing_pending = false;
     Damping dm;
     dm.dmin = opt.min_lm_diagonal; dm.dmax = opt.max_lm_diagonal; dm.use_scaling = opt.jacobi_scaling;
     LMState L;
@@ -536,8 +557,8 @@ static int ba_run_lm(stba_ba* b, const stba_lm_options* opt_in, int fixed_iterat
         if (pending) {
             double c2, g2;
             ba_finish_linear_scalars(b, &c2, &g2);
-            (void)hipEventElapsedTime(&ms, ev[pending_lin_ev], ev[pending_lin_ev + 1]); s.ms_linearize += ms;
-            (void)hipEventElapsedTime(&ms, ev[10], ev[11]); s.ms_schur += ms;
+            if (hipEventElapsedTime(&ms, ev[pending_lin_ev], ev[pending_lin_ev + 1]) == hipSuccess) s.ms_linearize += ms;
+            if (hipEventElapsedTime(&ms, ev[10], ev[11]) == hipSuccess) s.ms_schur += ms;
             L.gmax = g2;
             if (pending_accepted) L.cost = c2;
             if (trace) trace[(size_t)pending_iter * STBA_TRACE_COLS + 2] = g2;
@@ -606,7 +627,9 @@ static int ba_run_lm(stba_ba* b, const stba_lm_options* opt_in, int fixed_iterat
         need_build = true;
         if ((accepted || fixed) && !(fixed && iter >= max_iter)) {
             // re-linearise at the (new) current point -- unless the stream has done so already
-            const int e0 = deferred_ok ? 8 : 0, e2 = deferred_ok ? 10 : 2;
+            // (event pair of a non-speculated re-linearisation: the pair the speculation used LAST -- the next iteration's
+            // speculation records into the other one, so the pair is still intact when the host reads it one solve later)
+            const int e0 = deferred_ok ? spec_ev : 0, e2 = deferred_ok ? 10 : 2;
             if (!(speculated && accepted)) {
                 STBA_HIP(hipEventRecord(ev[e0], b->st));
                 STBA_TRY(ba_linearize(b, b->cur, b->trial + TS_COST2));
@@ -626,7 +649,7 @@ static int ba_run_lm(stba_ba* b, const stba_lm_options* opt_in, int fixed_iterat
                 // (cost, |g|max) of the new point are consumed after the next synchronisation
                 STBA_TRY(ba_request_linear_scalars(b));
                 pending = true; pending_accepted = accepted; pending_iter = iter;
-                pending_lin_ev = (speculated && accepted) ? spec_ev : 8;
+                pending_lin_ev = spec_ev;
                 if (accepted) L.cost = new_cost;
             } else {
                 double c2, g2;
@@ -671,6 +694,8 @@ static int ba_run_lm(stba_ba* b, const stba_lm_options* opt_in, int fixed_iterat
         }
         pending = false;
     }
+    ba_collect_allreduce_time(b);
+    s.ms_allreduce = b->ar_ms; s.allreduce_bytes = b->ar_bytes; s.allreduce_calls = b->ar_calls;
     s.num_iterations = iter;
     s.final_cost = L.cost;
     s.final_radius = L.radius;

@@ -29,6 +29,12 @@ def test_bench_gpus_2_launches_two_ranks(tmp_path):
     if not st_has_gpu:
         assert d["value"] is None and "no CPU fallback" in d["skipped"]
         assert d["sharded_observations"] == d["n_obs"]    # the two landmark shards cover every observation once
+    # what explains an N > 1 line: per-rank observation counts, the collective's time and bytes,
+    # the phases as the maximum over ranks
+    for key in ("observations_per_rank", "phase_ms_per_step", "allreduce_ms", "allreduce_bytes", "allreduce_calls_per_step"):
+        assert key in d, key
+    assert len(d["observations_per_rank"]) == 2 and sum(d["observations_per_rank"]) == d["n_obs"]
+    assert min(d["observations_per_rank"]) > 0.4 * d["n_obs"]          # balanced by observation count
 
 
 def test_bench_refuses_a_rank_count_that_is_not_gpus(tmp_path):

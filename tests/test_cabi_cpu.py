@@ -27,7 +27,7 @@ def test_header_symbols_are_exported(st):
     L = st.lib()
     for name in declared:
         assert hasattr(L, name), name
-    assert L.stba_version() == 1
+    assert L.stba_version() == 2
 
 
 def test_default_options_are_ceres_defaults(st):

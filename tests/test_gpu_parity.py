@@ -418,6 +418,34 @@ def test_c5_full_size_matches_oracle(st, O, scenes):
     assert np.abs(pts - o.pts).max() < 1e-5 * max(1.0, np.abs(o.pts).max())
 
 
+def test_c5_converges_like_the_oracle(st, O, scenes):
+    """north_star: "the same CONVERGED parameters ... within 1e-6 relative on residuals and 1e-5 on pose".  BASELINE
+    config C5 at full size run to TERMINATION on both sides (Ceres' default stopping rules, test_ceres.h:148): same
+    iteration count, same accept / reject sequence, same termination reason, final cost to 1e-6 relative, camera
+    poses and landmarks to 1e-5.  The oracle factors its reduced system with LAPACK here (seconds per solve instead
+    of minutes); its own blocked C Cholesky is the one pinned by the three-iteration test above."""
+    s = scenes.st20_scene(n_cams=1000, n_pts=100000, max_obs_per_pt=10, seed=20, pix_noise=1e-3)
+    e, o = engine(st, s), oracle(O, s)
+    blas = O.use_lapack(True, threads=16)
+    try:
+        so, tro = o.solve(num_threads=16)
+    finally:
+        O.use_lapack(False)
+    summ, tr = e.solve()
+    n = so.num_iterations
+    assert so.termination_type == 0 and n >= 5, (so.as_dict(), blas)
+    assert summ.termination_type == 0 and summ.num_iterations == n, (summ.as_dict(), so.as_dict())
+    assert summ.termination_reason == so.termination_reason
+    assert np.array_equal(tr[: n + 1, 6], tro[: n + 1, 6])                 # accept / reject sequence
+    assert np.allclose(tr[: n + 1, 0], tro[: n + 1, 0], rtol=1e-6)          # cost after every iteration
+    assert abs(summ.final_cost - so.final_cost) <= 1e-6 * so.final_cost
+    cams, pts = e.get_params()
+    dq, dt = pose_err(cams, o.cams)
+    assert dq < 1e-5 and dt < 1e-5, (dq, dt)
+    assert np.abs(pts - o.pts).max() < 1e-5 * max(1.0, np.abs(o.pts).max())
+    print(f"C5 to convergence: {n} iterations, final cost {summ.final_cost:.9e} (oracle {so.final_cost:.9e}), dq {dq:.2e} dt {dt:.2e}")
+
+
 def test_edge_cases(st, O):
     """shapes the reference's data model allows (sim_data.h:38-63): everything constant, a camera nobody
     observes through, landmarks seen once, the smallest problem"""
