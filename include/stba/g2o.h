@@ -27,6 +27,7 @@
 #include <iosfwd>
 #include <memory>
 #include <string>
+#include <typeinfo>
 #include <utility>
 #include <vector>
 
@@ -163,8 +164,17 @@ public:
             if (a < 0 || b < 0 || cam_of[a] < 0 || pt_of[b] < 0) { _message = "edge does not connect (pose, landmark)"; return 0; }
             oc[k] = cam_of[a]; op[k] = pt_of[b];
             e->measurement_raw(&feat[(size_t)k * 2]);
+            // EVERY edge must be the reprojection residual (a graph with one edge of another type must not be treated as pure
+            // bundle adjustment): one computeError per edge at its current estimates, host work, no device involved
+            if (!probe_edge(e, k)) return 0;
         }
-        if (!probe_semantics(cams[0], pts[0])) return 0;
+        // the manifold updates: once per vertex CLASS (typeid) that occurs in the graph
+        {
+            std::vector<const std::type_info*> seen;
+            auto fresh = [&](Vertex* v) { for (auto* t : seen) if (*t == typeid(*v)) return false; seen.push_back(&typeid(*v)); return true; };
+            for (Vertex* v : cams) if (fresh(v) && !probe_pose_oplus(v)) return 0;
+            for (Vertex* v : pts) if (fresh(v) && !probe_landmark_oplus(v)) return 0;
+        }
         const int nc = (int)cams.size(), np = (int)pts.size();
         std::vector<double> c7((size_t)nc * 7), p3((size_t)np * 3);
         std::vector<unsigned char> cfix((size_t)nc * 6, 0), pfix((size_t)np, 0);
@@ -201,7 +211,7 @@ public:
 
 private:
     // the user's oplus / computeError must be the built-in manifold update and reprojection residual
-    bool probe_semantics(Vertex* cam, Vertex* pt) {
+    bool probe_pose_oplus(Vertex* cam) {
         const double d[6] = {0.011, -0.017, 0.005, 0.03, -0.02, 0.04};
         double before[7], after[7];
         cam->get_raw(before);
@@ -215,11 +225,17 @@ private:
         double et = 0;
         for (int i = 0; i < 3; ++i) et = std::fmax(et, std::fabs(after[4 + i] - (before[4 + i] + d[3 + i])));
         if (std::fmin(e1, e2) > 1e-12 || et > 1e-12) { _message = "pose vertex oplusImpl is not (SO3 right-plus, translation add): unsupported on the device"; return false; }
+        return true;
+    }
+    bool probe_landmark_oplus(Vertex* pt) {
+        const double d[3] = {0.011, -0.017, 0.005};
         double pb[3], pa[3];
         pt->get_raw(pb); pt->push(); pt->oplus(d); pt->get_raw(pa); pt->pop();
         for (int i = 0; i < 3; ++i) if (std::fabs(pa[i] - (pb[i] + d[i])) > 1e-12) { _message = "landmark vertex oplusImpl is not additive"; return false; }
-        // one edge: computeError == proj(R^T (L - t)) - z
-        Edge* e = _edges[0];
+        return true;
+    }
+    // edge k: computeError == proj(R^T (L - t)) - z at the current estimates of its two vertices
+    bool probe_edge(Edge* e, int k) {
         e->computeError();
         double err[2], z[2], c[7], L[3];
         e->error_raw(err); e->measurement_raw(z);
@@ -230,8 +246,9 @@ private:
         const double dd[3] = {L[0] - c[4], L[1] - c[5], L[2] - c[6]};
         const double px = R[0] * dd[0] + R[3] * dd[1] + R[6] * dd[2], py = R[1] * dd[0] + R[4] * dd[1] + R[7] * dd[2],
                      pz = R[2] * dd[0] + R[5] * dd[1] + R[8] * dd[2];
-        if (std::fabs(err[0] - (px / pz - z[0])) > 1e-10 || std::fabs(err[1] - (py / pz - z[1])) > 1e-10) {
-            _message = "edge computeError is not the reprojection residual proj(R^T (L - t)) - z: unsupported on the device";
+        const double ex = px / pz - z[0], ey = py / pz - z[1];
+        if (!(std::fabs(err[0] - ex) <= 1e-10 * (1.0 + std::fabs(ex))) || !(std::fabs(err[1] - ey) <= 1e-10 * (1.0 + std::fabs(ey)))) {
+            _message = "edge " + std::to_string(k) + ": computeError is not the reprojection residual proj(R^T (L - t)) - z: unsupported on the device";
             return false;
         }
         return true;

@@ -1159,6 +1159,59 @@ int orc_parabola_gauss_newton(int n, const float* xy, int iters, float abc[3]) {
 }
 
 /* ======================================================================================
+ * st6: planar point-to-point alignment with known correspondences -- Gauss-Newton on SE2 with a LEFT
+ * multiplicative update, FLOAT arithmetic as the reference (st6-icp/src/include/icp.hpp:28-50).  The
+ * reference holds the iterates of this loop after 1 and 2 iterations on a recorded 10-point pair
+ * (st6-icp/log/binding/pc1_prime_{1,2}.csv): the only per-iteration trace of a manifold Gauss-Newton in the
+ * repository.  T = {cos, sin, tx, ty}: p' = R p + t.
+ * ==================================================================================== */
+static void se2_exp_f(const float d[3], float T[4]) {
+    /* Sophus::SE2f::exp: tangent (upsilon_x, upsilon_y, theta); translation = V(theta) upsilon */
+    const float th = d[2];
+    const float c = cosf(th), s = sinf(th);
+    float sbt, omcbt;                                  /* sin(theta)/theta, (1 - cos(theta))/theta */
+    if (fabsf(th) < 1e-10f) {                          /* Sophus: Constants<float>::epsilon() */
+        const float th2 = th * th;
+        sbt = 1.0f - (1.0f / 6.0f) * th2;
+        omcbt = 0.5f * th - (1.0f / 24.0f) * th * th2;
+    } else {
+        sbt = s / th;
+        omcbt = (1.0f - c) / th;
+    }
+    T[0] = c; T[1] = s;
+    T[2] = sbt * d[0] - omcbt * d[1];
+    T[3] = omcbt * d[0] + sbt * d[1];
+}
+
+int orc_icp_se2_gauss_newton(int n, const float* pc1, const float* pc2, int iters, float T[4]) {
+    T[0] = 1.0f; T[1] = 0.0f; T[2] = 0.0f; T[3] = 0.0f;      /* icp.hpp:30: identity */
+    int it = 0;
+    for (; it != iters; ++it) {
+        float H[9] = {0}, g[3] = {0};
+        for (int i = 0; i < n; ++i) {
+            const float x = pc1[i * 2], y = pc1[i * 2 + 1];
+            const float px = T[0] * x - T[1] * y + T[2], py = T[1] * x + T[0] * y + T[3];   /* :37 */
+            const float ex = px - pc2[i * 2], ey = py - pc2[i * 2 + 1];                     /* :38 */
+            const float J[2][3] = {{1.0f, 0.0f, -py}, {0.0f, 1.0f, px}};                    /* :40-41 */
+            for (int a = 0; a < 3; ++a) {
+                for (int b = 0; b < 3; ++b) H[a * 3 + b] += J[0][a] * J[0][b] + J[1][a] * J[1][b];
+                g[a] -= J[0][a] * ex + J[1][a] * ey;                                          /* :43 */
+            }
+        }
+        float d[3];
+        if (solve3f(H, g, d)) break;                                                          /* :45 (ldlt) */
+        float E[4];
+        se2_exp_f(d, E);
+        /* T <- exp(delta) * T  (:46) */
+        const float c = E[0] * T[0] - E[1] * T[1], s = E[1] * T[0] + E[0] * T[1];
+        const float tx = E[0] * T[2] - E[1] * T[3] + E[2], ty = E[1] * T[2] + E[0] * T[3] + E[3];
+        const float nrm = sqrtf(c * c + s * s);                                               /* SO2 stays normalised */
+        T[0] = c / nrm; T[1] = s / nrm; T[2] = tx; T[3] = ty;
+    }
+    return it;
+}
+
+/* ======================================================================================
  * st3: calibration (calib.cpp:247-262, 282-422)
  * ==================================================================================== */
 double orc_calib_evaluate(int n_views, int n_corners, const double* params, const double* obj,

@@ -175,6 +175,8 @@ int orc_pnp_gauss_newton(int n, const double* pts_w, const double* feats, double
 /* ---------------- st7 parabola (float arithmetic, parabola.hpp:98-130) ---------------- */
 void orc_parabola_least_square(int n, const float* xy, float abc[3]);
 int  orc_parabola_gauss_newton(int n, const float* xy, int iters, float abc[3]);
+/* ---------------- st6 SE2 alignment (float arithmetic, st6-icp/src/include/icp.hpp:28-50) ---------------- */
+int  orc_icp_se2_gauss_newton(int n, const float* pc1, const float* pc2, int iters, float T[4]);
 
 /* ---------------- st3 calibration (calib.cpp:247-262, 282-422) ---------------- */
 /* params: [alpha beta u0 v0 k1 k2 k3 p1 p2 | xi_0(6) ... xi_{V-1}(6)], xi = se3 [rho,theta].

@@ -346,6 +346,15 @@ def parabola_gauss_newton(xy, iters=10):
     return o, it
 
 
+def icp_se2_gauss_newton(pc1, pc2, iters=10):
+    """st6-icp/src/include/icp.hpp:28-50 in float: returns T21 = (cos, sin, tx, ty) after `iters` iterations"""
+    pc1 = np.ascontiguousarray(pc1, dtype=np.float32)
+    pc2 = np.ascontiguousarray(pc2, dtype=np.float32)
+    T = np.zeros(4, dtype=np.float32)
+    lib().orc_icp_se2_gauss_newton(C.c_int(len(pc1)), _p(pc1), _p(pc2), C.c_int(iters), _p(T))
+    return T
+
+
 def calib_evaluate(params, obj, img, jac=True):
     obj, img = f64(obj), f64(img)
     V, Cn = obj.shape[0], obj.shape[1]

@@ -5,6 +5,7 @@
 // with the user-side classes (LieLocalParameterization, functors, callbacks) written against the
 // mirrored API exactly as the reference writes them against Ceres.  Sophus/Eigen are replaced by
 // a few templated helpers.  Prints "key value..." lines that tests/test_cpp_shim.py checks.
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -184,6 +185,31 @@ struct ScaledProjectFactor {
     }
 };
 
+// sim_data.h:165-194: the per-landmark triangulation factor of the scene generator.  NOTE the residual's sign,
+// feature - proj (sim_data.h:191), the opposite of ProjectFactor's; WtoC is the INVERSE camera pose (sim_data.cpp:303).
+struct Triangulation {
+    double q_wc[4], p_wc[3], feature[2];       // WtoC.SO3 (as a quaternion), WtoC.POS
+    Triangulation(const double* cam_q, const double* cam_t, const double* f) {
+        q_wc[0] = -cam_q[0]; q_wc[1] = -cam_q[1]; q_wc[2] = -cam_q[2]; q_wc[3] = cam_q[3];        // inverse rotation
+        double mt[3] = {-cam_t[0], -cam_t[1], -cam_t[2]};
+        QuatConjRotate(cam_q, mt, p_wc);                                                          // -R^T t
+        feature[0] = f[0]; feature[1] = f[1];
+    }
+    static auto Create(const double* cam_q, const double* cam_t, const double* f) {
+        return new ceres::AutoDiffCostFunction<Triangulation, 2, 3>(new Triangulation(cam_q, cam_t, f));
+    }
+    template <typename T> bool operator()(const T* const pInW, T* residuals) const {
+        // pInC = WtoC.SO3 * p + WtoC.POS: rotate by q_wc = conj-rotate by its conjugate
+        const T qc[4] = {T(-q_wc[0]), T(-q_wc[1]), T(-q_wc[2]), T(q_wc[3])};
+        T pc[3];
+        QuatConjRotate(qc, pInW, pc);
+        pc[0] = pc[0] + T(p_wc[0]); pc[1] = pc[1] + T(p_wc[1]); pc[2] = pc[2] + T(p_wc[2]);
+        residuals[0] = T(feature[0]) - pc[0] / pc[2];
+        residuals[1] = T(feature[1]) - pc[1] / pc[2];
+        return true;
+    }
+};
+
 // ceres_bound.cpp:8-23
 struct DemoFunctor {
     static auto Create() { return new ceres::DynamicAutoDiffCostFunction<DemoFunctor>(new DemoFunctor()); }
@@ -282,6 +308,37 @@ int main(int argc, char** argv) {
         if (!s.load(argv[2])) { std::printf("scene_load_failed\n"); return 2; }
         { Scene a = s; ProbeOnly(a, 1, "probe_user"); }
         { Scene a = s; ProbeOnly(a, 2, "probe_scaled"); }
+        return 0;
+    }
+    // ---- "tri <scene>": sim_data.cpp:298-311 -- one ceres::Problem PER LANDMARK (cameras fixed: they are not parameter
+    // blocks at all), default options, AutoDiffCostFunction<Triangulation, 2, 3> per observation
+    if (argc >= 3 && std::strcmp(argv[1], "tri") == 0) {
+        Scene s;
+        if (!s.load(argv[2])) { std::printf("scene_load_failed\n"); return 2; }
+        std::vector<std::vector<int>> obs_of(s.np);
+        for (int k = 0; k < s.no; ++k) obs_of[s.op[k]].push_back(k);
+        const auto t0 = std::chrono::steady_clock::now();
+        int n_solved = 0, n_conv = 0, iters = 0;
+        std::string path;
+        for (int j = 0; j < s.np; ++j) {
+            if (obs_of[j].empty()) continue;
+            ceres::Problem problem;
+            for (int k : obs_of[j]) {
+                const double* cam = &s.cams[s.oc[k] * 7];
+                auto costFunc = Triangulation::Create(cam, cam + 4, &s.feat[k * 2]);
+                problem.AddResidualBlock(costFunc, nullptr, &s.pts[j * 3]);
+            }
+            ceres::Solver::Options options;
+            ceres::Solver::Summary summary;
+            ceres::Solve(options, &problem, &summary);
+            ++n_solved;
+            n_conv += summary.termination_type == ceres::CONVERGENCE ? 1 : 0;
+            iters += (int)summary.iterations.size() - 1;
+            path = summary.execution_path;
+        }
+        const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        std::printf("tri_summary problems %d converged %d iterations %d seconds %.6f path %s\n", n_solved, n_conv, iters, secs, path.c_str());
+        print_vec("tri_pts", s.pts.data(), s.np * 3);
         return 0;
     }
     // ---- "big <scene> <iterations>": ONLY the reference's unchanged BA call site, at any size (config C5)

@@ -74,6 +74,11 @@ struct EdgeProject : public g2o::BaseBinaryEdge<2, Vec2, VertexCamera, VertexLan
     bool write(ostream&) const override { return true; }
 };
 
+// NOT the reference's edge: a residual of another kind hidden among the projection edges (negative test of the probe)
+struct EdgeProjectScaled : public EdgeProject {
+    void computeError() override { EdgeProject::computeError(); _error.v[0] *= 2.0; _error.v[1] *= 2.0; }
+};
+
 int main(int argc, char** argv) {
     if (argc < 2) return 1;
     std::ifstream f(argv[1], std::ios::binary);
@@ -97,7 +102,7 @@ int main(int argc, char** argv) {
         auto cameraVertex = new VertexCamera();
         cameraVertex->setId(i);
         cameraVertex->setEstimate(camera);
-        if (argc > 2 && fixed[i]) cameraVertex->setFixed(true);       // (the reference fixes none; optional here)
+        if (argc > 2 && std::strcmp(argv[2], "fix") == 0 && fixed[i]) cameraVertex->setFixed(true);       // (the reference fixes none; optional here)
         optimizer.addVertex(cameraVertex);
         cameraVertexVec.push_back(cameraVertex);
     }
@@ -112,7 +117,8 @@ int main(int argc, char** argv) {
         optimizer.addVertex(landmarkVertex);
         landmarkVertexVec.push_back(landmarkVertex);
         for (int k : obs_of[i]) {
-            auto* e = new EdgeProject;
+            // ("odd": ONE edge in the middle of the graph is of another type)
+            EdgeProject* e = (argc > 2 && std::strcmp(argv[2], "odd") == 0 && k == no / 2) ? new EdgeProjectScaled : new EdgeProject;
             e->setVertex(0, cameraVertexVec.at(oc[k]));
             e->setVertex(1, landmarkVertex);
             Vec2 z; z.v[0] = feat[k * 2]; z.v[1] = feat[k * 2 + 1];

@@ -5,6 +5,7 @@ place /root/reference exists); the outputs are committed, this script documents 
   st3_calib/1..9.txt     <- st3-calibration/calib/1..9.txt      chessboard corners (data files)
   st16_odom/odometryInfo.txt <- st16-pcl-viewer/data/odom_lidar/odometryInfo.txt   70 poses (data file)
   st7_ransac/*.csv       <- st7-ransac/data/{good,bad}.csv      parabola samples (data files)
+  st6_icp/*.csv          <- st6-icp/log/binding/{pc1,pc2,pc1_prime_1,pc1_prime_2}.csv   inputs and recorded iterates (data files)
   known_answers.json     <- values the reference itself publishes:
        st7-ransac/pyDraw/drawerResult.py:12-16, st17-ceres/img/{release,debug}.png (transcribed
        in BASELINE.md), st17-ceres/src/ceres_bound.cpp:26-65, SURVEY.md section 4 (calibration
@@ -26,6 +27,9 @@ def main():
     shutil.copy(f"{REF}/st16-pcl-viewer/data/odom_lidar/odometryInfo.txt", f"{HERE}/st16_odom/odometryInfo.txt")
     for f in ("good.csv", "bad.csv"):
         shutil.copy(f"{REF}/st7-ransac/data/{f}", f"{HERE}/st7_ransac/{f}")
+    os.makedirs(f"{HERE}/st6_icp", exist_ok=True)
+    for f in ("pc1.csv", "pc2.csv", "pc1_prime_1.csv", "pc1_prime_2.csv"):
+        shutil.copy(f"{REF}/st6-icp/log/binding/{f}", f"{HERE}/st6_icp/{f}")
     ka = {
         "st7_parabola": {
             "source": "st7-ransac/pyDraw/drawerResult.py:12-16",

@@ -168,6 +168,43 @@ def test_reference_ba_call_site_at_c5_size(exe, tmp_path, scenes, O):
     assert dq < 1e-5 and np.abs(cams[:, 4:] - o.cams[:, 4:]).max() < 1e-5
 
 
+@pytest.mark.gpu
+def test_reference_triangulation_call_site_on_gpu(exe, tmp_path, scenes, O):
+    """sim_data.cpp:298-311: the scene generator triangulates every landmark with its OWN ceres::Problem (cameras are
+    not parameter blocks; AutoDiffCostFunction<Triangulation, 2, 3> per observation, sim_data.h:165-194, residual
+    feature - proj).  The restated call site runs at the reference's size (29 cameras, 600 landmarks) through the
+    generic callback path of the shim; the landmarks must equal the bulk kernel's (stba_ba_triangulate, one landmark
+    per lane) and the oracle's to 1e-6 (same minimiser, different stopping rules).  The wall time of the 600 tiny
+    solves is printed next to the bulk kernel's: INTEGRATION.md 2 quotes the ratio."""
+    import time
+    st = importlib.import_module("slam-tricks_amd")
+    s = scenes.st20_scene(retriangulate=False)                          # landmarks NOT triangulated yet
+    f = str(tmp_path / "tri.bin")
+    write_scene(f, s)
+    out = run(exe, "tri", f)
+    toks = out["tri_summary"].split()
+    n_prob, n_conv, secs = int(toks[1]), int(toks[3]), float(toks[7])
+    assert toks[9] == "gpu-dense-callback"
+    n_seen = len(np.unique(s["obs_pt"]))
+    assert n_prob == n_seen and n_conv == n_prob
+    pts = vec(out, "tri_pts").reshape(-1, 3)
+    e = st.BAEngine(s["cams0"], s["pts0"], s["obs_cam"], s["obs_pt"], s["obs_feat"], s["cam_fixed"])
+    e.triangulate()                                                     # (warm-up: module load, allocations)
+    e.set_params(s["cams0"], s["pts0"])
+    t0 = time.perf_counter()
+    e.triangulate()
+    _, pts_bulk = e.get_params()
+    t_bulk = time.perf_counter() - t0
+    o = O.BA(s["cams0"], s["pts0"], s["obs_cam"], s["obs_pt"], s["obs_feat"], s["cam_fixed"])
+    o.triangulate()
+    seen = np.zeros(len(pts), bool); seen[s["obs_pt"]] = True
+    assert np.abs(pts[seen] - pts_bulk[seen]).max() < 1e-6
+    assert np.abs(pts[seen] - o.pts[seen]).max() < 1e-6
+    assert np.array_equal(pts[~seen], s["pts0"][~seen])
+    print(f"triangulation call site: {n_prob} per-landmark Solve() calls {secs * 1e3:.1f} ms "
+          f"({secs / n_prob * 1e6:.0f} us each), bulk stba_ba_triangulate {t_bulk * 1e3:.2f} ms incl. read-back: ratio {secs / t_bulk:.0f}x")
+
+
 # ---------------------------------------------------------------------------------------------
 # g2o front door (SURVEY 8f f2): st20-g2o/src/include/test_g2o.h restated on include/stba/g2o.h
 @pytest.fixture(scope="module")
@@ -190,6 +227,17 @@ def test_g2o_shim_compiles_and_fails_loudly_without_device(exe_g2o, tmp_path, sc
     out = run(exe_g2o, f)
     if st.device_count() == 0:
         assert out["g2o_iters"].startswith("0 ") and "no CPU fallback" in out["g2o_iters"]
+
+
+def test_g2o_probe_rejects_a_graph_with_one_foreign_edge(exe_g2o, tmp_path, scenes):
+    """the front door checks EVERY edge's computeError (host work, before any device call): one edge of another
+    type among the projection edges and optimize() refuses, naming the edge"""
+    s = scenes.st20_scene(n_cams=6, n_pts=40, seed=7, pos_noise=0.05, ang_noise_deg=1.0)
+    f = str(tmp_path / "s.bin")
+    write_scene(f, s)
+    out = run(exe_g2o, f, "odd")
+    assert out["g2o_iters"].startswith("0 ")
+    assert f"edge {len(s['obs_cam']) // 2}: computeError is not the reprojection residual" in out["g2o_iters"]
 
 
 @pytest.mark.gpu

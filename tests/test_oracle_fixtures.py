@@ -25,6 +25,23 @@ def test_parabola_known_answers(O, known):
     assert np.allclose(b, ka["gaussNewton_bad_10"], rtol=2e-5)
 
 
+def test_se2_gauss_newton_iterates_of_the_icp_demo(O):
+    """st6-icp/log/binding: the reference's recorded inputs (pc1, pc2) and its iterates after ONE and TWO Gauss-Newton
+    steps on SE2 with the left-multiplicative update T <- exp(delta) T (icp.hpp:28-50; binding.cpp applies the estimate
+    to pc1 and writes pc1_prime_k.csv).  The only reference-held per-iteration trace of a manifold Gauss-Newton: the
+    oracle's float restatement reproduces both iterates to the 6 digits the files carry."""
+    pc1, pc2 = _csv("st6_icp/pc1.csv"), _csv("st6_icp/pc2.csv")
+    assert pc1.shape == (10, 2) and pc2.shape == (10, 2)
+    for k in (1, 2):
+        want = _csv(f"st6_icp/pc1_prime_{k}.csv")
+        c, s, tx, ty = (float(v) for v in O.icp_se2_gauss_newton(pc1, pc2, k))
+        got = pc1 @ np.array([[c, s], [-s, c]]) + np.array([tx, ty])
+        assert np.abs(got - want).max() < 5e-5 * max(1.0, np.abs(want).max()), (k, np.abs(got - want).max())
+    # and the loop converges to the transformation the demo was generated with (pi/4, (2, 2)) up to its 0.1 noise
+    c, s, tx, ty = (float(v) for v in O.icp_se2_gauss_newton(pc1, pc2, 10))
+    assert abs(np.arctan2(s, c) - np.pi / 4) < 0.02 and abs(tx - 2.0) < 0.15 and abs(ty - 2.0) < 0.15
+
+
 def test_parabola_through_dense_lm(O, known):
     """the same fit through the LM driver (FP64) lands on the same answer"""
     good = _csv("st7_ransac/good.csv")
