@@ -210,6 +210,13 @@ int stba_cholesky_time_split(int n, int reps, double* ms_factor, double* ms_back
  * predicts for the persistent factorisation kernel of an n x n system on `n_xcd` XCDs with `wg_per_xcd`
  * workgroups each (MI355X: 8 x 32).  The ticket order of the kernel comes from this model. */
 int stba_cholesky_schedule_model(int n, int n_xcd, int wg_per_xcd, double* makespan_us);
+/* how often, in this process, the persistent factorisation gave up waiting for a dependency (its workgroups were not all
+ * resident: the device is shared with another process) and the stage kernels -- one launch per stage and panel, nothing
+ * resident -- took over */
+int stba_cholesky_timeout_count(void);
+/* how long a workgroup of the persistent factorisation waits for a dependency before the program gives up (microseconds;
+ * 0 restores the automatic bound, max(100 ms, 40 x the predicted makespan)).  Process-wide. */
+int stba_cholesky_set_timeout_us(double us);
 
 /* design study, runs on the host (no GPU): the same task graph spread over `n_gpus` GPUs (the reduced
  * camera system as the next thing to shard).  Tile rows are dealt to the GPUs block-cyclically, `rows_per_group`

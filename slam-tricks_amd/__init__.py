@@ -67,7 +67,7 @@ EXPORTS = ["stba_status_string", "stba_last_error", "stba_version", "stba_device
            "stba_ba_cost", "stba_ba_normal_blocks", "stba_ba_reduced_system", "stba_ba_solve_reduced",
            "stba_ba_back_substitute", "stba_ba_apply_step", "stba_ba_solve", "stba_ba_lm_iterations",
            "stba_ba_triangulate", "stba_ba_time_linearize", "stba_cholesky_factor", "stba_cholesky_solve",
-           "stba_cholesky_time", "stba_cholesky_time_split", "stba_cholesky_schedule_model", "stba_cholesky_shard_model", "stba_cholesky_shard_owner", "stba_cholesky_profile", "stba_calib_evaluate", "stba_calib_gauss_newton",
+           "stba_cholesky_time", "stba_cholesky_time_split", "stba_cholesky_schedule_model", "stba_cholesky_timeout_count", "stba_cholesky_set_timeout_us", "stba_cholesky_shard_model", "stba_cholesky_shard_owner", "stba_cholesky_profile", "stba_calib_evaluate", "stba_calib_gauss_newton",
            "stba_pcg_default_options", "stba_pg_create", "stba_pg_destroy", "stba_pg_set_allreduce", "stba_pg_get_poses", "stba_pg_evaluate",
            "stba_pg_solve", "stba_dense_solve", "stba_corners_read", "stba_corners_write", "stba_zhang_init", "stba_two_view_init", "stba_odometry_read", "stba_odometry_write", "stba_trajectory_ate",
            "stba_comm_unique_id", "stba_comm_create", "stba_comm_destroy", "stba_comm_rank", "stba_comm_allreduce_sum",
@@ -362,6 +362,16 @@ def cholesky_schedule_model(n, n_xcd=8, wg_per_xcd=32):
     out = C.c_double()
     _chk(lib().stba_cholesky_schedule_model(int(n), int(n_xcd), int(wg_per_xcd), C.byref(out)), "stba_cholesky_schedule_model")
     return out.value
+
+
+def cholesky_set_timeout_us(us):
+    """bound on a workgroup's wait for a dependency inside the persistent factorisation (0: automatic)"""
+    _chk(lib().stba_cholesky_set_timeout_us(C.c_double(us)), "stba_cholesky_set_timeout_us")
+
+
+def cholesky_timeout_count():
+    """how often the persistent factorisation gave up (shared device) and the stage kernels took over, in this process"""
+    return int(lib().stba_cholesky_timeout_count())
 
 
 def cholesky_shard_model(n, n_gpus, n_xcd=8, wg_per_xcd=32, rows_per_group=0, hop_us=3.0, link_gb_per_s=48.0):

@@ -16,6 +16,12 @@ FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-munsafe-fp-ato
          "-Wno-unused-function", "-Wno-unused-result"]
 
 
+# STBA_DEBUG_KNOBS=1 in the environment of the BUILD compiles the scheduling-experiment knobs in (environment variables read
+# by dense_chol.hip; tools/mega_trace.py, tools/sim_sweep.py); the product build reads none
+if os.environ.get("STBA_DEBUG_KNOBS", "0") not in ("", "0"):
+    FLAGS.append("-DSTBA_DEBUG_KNOBS")
+
+
 def _stale():
     if not os.path.exists(LIB):
         return True

@@ -62,9 +62,18 @@ inline int chol_padded_dim(int n) { return ((n + 1 + CHOL_NB - 1) / CHOL_NB) * C
 // workgroup; callers turn it into STBA_ERR_HIP through chol_flag_status).
 constexpr int CHOL_FLAG_TIMEOUT = -2147483647;
 inline int chol_flag_status(int flag_h) {
-    return flag_h == CHOL_FLAG_TIMEOUT ? fail(STBA_ERR_HIP, "dense Cholesky: persistent kernel timed out waiting for a dependency") : STBA_OK;
+    return flag_h == CHOL_FLAG_TIMEOUT ? fail(STBA_ERR_HIP, "dense Cholesky: the persistent program timed out waiting for a dependency and the caller has no way to rebuild the matrix") : STBA_OK;
 }
 int chol_factor_solve_dev(double* A_dev, int lda, int n, double* x_dev, int* flag_dev, hipStream_t st);
+// the same factorisation + solve through the stage kernels (one launch per stage and panel): the fallback when the
+// persistent program reports CHOL_FLAG_TIMEOUT -- the matrix must be rebuilt first, the aborted run leaves it half factored
+int chol_factor_solve_stages(double* A_dev, int lda, int n, double* x_dev, int* flag_dev, hipStream_t st);
+// a caller that has SEEN CHOL_FLAG_TIMEOUT reports it: the device's next 64 factorisations take the stage kernels without
+// trying the persistent program again (the device is shared with somebody), and the process-wide count goes up
+void chol_note_timeout();
+void chol_set_spin_limit_us(double us);    // how long a workgroup waits for a dependency before it gives up; 0: automatic
+int chol_timeout_count();
+
 // the production schedule with an event recorded between the factorisation and the backward substitution
 int chol_factor_solve_split(double* A_dev, int lda, int n, double* x_dev, int* flag_dev, hipStream_t st, hipEvent_t mid_event);
 struct CholProfile {

@@ -28,6 +28,7 @@
 // Backward substitution: one small kernel per block (GEMV with the inverse transposes the panel
 // solve produced).
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <map>
 #include <queue>
@@ -101,335 +102,18 @@ template <bool WT> __device__ __forceinline__ void gst4(double* p, double4v v) {
 }
 __device__ __forceinline__ double4v gld4(const double* p) { return *reinterpret_cast<const double4v*>(p); }
 // ------------------------------------------------------------------------------------------
-// Diagonal block (128x128), 512 threads.  The pivot chain is sequential (128 columns), so everything is
-// arranged around keeping it short:
-//   * waves 0,1 = 128 ROW THREADS; thread i owns row i of the CURRENT 16-column tile column in
-//     registers.  Per 8 columns: the 8 block rows publish their values (tiny), every row thread factors
-//     the 8x8 mini-block redundantly (right-looking, division-free v_rsq_f64 + Halley) and solves its
-//     own row.  Between the two halves of a tile column each row thread applies the first half's rank-8
-//     update to its own 8 values of the second half (64 FMAs) -- no matrix core, no publish round trip.
-//     Finished columns of L go straight from the row threads to global memory.
-//   * waves 2,3,6,7 = MATRIX-CORE waves; they own the trailing 16x16 tiles (tile rows {1,7}, {2,6}, {4},
-//     {3,5}) in MFMA accumulator layout and apply every finished 8-column panel as a rank-8 update
-//     (two v_mfma_f64_16x16x4_f64 per tile, operands straight from the row threads' panel in LDS), one
-//     half step behind the row threads, then hand the next tile column over through LDS.  FP64 VALU and
-//     FP64 MFMA work do not overlap on one SIMD (measured), so waves 4,5 -- the SIMD partners of the row
-//     threads -- only take part in the barriers.
-// Barriers per tile column: Bp (block rows published) | c0 | B1 (panel 0 in LDS) | local update |
-// Bq (second mini-block published) | c1 ‖ rank-8(panel 0) | B2 | rank-8(panel 1) on the next tile
-// column + hand-over | B3.  The remaining rank-8(panel 1) runs under the next column's c0.
-// Finally the inverses of the eight 16x16 diagonal tiles are written to `dinv` (the panel solve
-// multiplies by them on the matrix cores).
 #define PHASE_STAMP(k) do { if (ph && t == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); ph[k] = wall_clock64(); } } while (0)
-// optional cycle stamps of the row threads for tools/exp/diag_timing.hip (compiled out of the library)
-#ifdef STBA_DIAG_TS
-__device__ long long g_diag_ts[8][12];
-#define DIAG_TS(slot) do { if (i == 127) g_diag_ts[Jt][slot] = __builtin_readcyclecounter(); } while (0)
-__device__ long long g_diag_ts2[8][8];
-#define DIAG_TS2(slot) do { if (I1 == 7 && lr == 0 && lc == 0) g_diag_ts2[Jt][slot] = __builtin_readcyclecounter(); } while (0)
-#else
-#define DIAG_TS2(slot) do { } while (0)
-#define DIAG_TS(slot) do { } while (0)
-#endif
-struct DiagSmem {
-    double Pn[NB][17];        // next tile column, handed from the matrix-core waves to the row threads
-    double Lp[2][NB][9];      // scaled panel rows of the two half steps
-    double Dd[16][17];        // the 16 block rows of the current tile column
-    double Dd1[8][9];         // second mini-block after the local update
-    double Lb[8][8];          // first-panel rows of the second mini-block (16 B aligned copy for the local update)
-    double rd[NB];            // 1 / L[c][c]
-    double Tl[8][16][17];     // the diagonal 16x16 tiles of L (for the inverses)
-};
-constexpr int DIAG_SMEM_DOUBLES = (int)(sizeof(DiagSmem) / sizeof(double));
-
-// 8x8 mini-block D (lower, from LDS) and this thread's 8 panel values p: returns l = p G^-T (G G^T = D)
-// and y = 1 / diag(G).  Rows INSIDE the block take the same path: row r of D solves to row r of G in its
-// first r+1 entries; the entries right of the diagonal are garbage that nobody reads.
-template <int LD>
-__device__ __forceinline__ bool mini_chol_solve(const double (*Dsrc)[LD], const double (&p_in)[8], double (&l)[8], double (&y)[8],
-                                                int col0_global, int n_real) {
-    double D[8][8], p[8];
-#pragma unroll
-    for (int r = 0; r < 8; ++r)
-#pragma unroll
-        for (int c = 0; c <= r; ++c) D[r][c] = Dsrc[r][c];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) p[c] = p_in[c];
-    bool bad = false;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        double d = D[c][c];
-        if (!(d > 0.0)) { bad = bad || ((col0_global + c) < n_real); d = 1.0; }
-        y[c] = fast_rsqrt(d);
-#pragma unroll
-        for (int r = c + 1; r < 8; ++r) D[r][c] *= y[c];
-#pragma unroll
-        for (int r = c + 1; r < 8; ++r)
-#pragma unroll
-            for (int q = c + 1; q <= r; ++q) D[r][q] = fma(-D[r][c], D[q][c], D[r][q]);
-        l[c] = p[c] * y[c];
-#pragma unroll
-        for (int q = c + 1; q < 8; ++q) p[q] = fma(-l[c], D[q][c], p[q]);
-    }
-    return bad;
-}
-
-template <bool WT>
-__device__ __forceinline__ void diag_row_threads(double* __restrict__ A, int lda, int k0, int n_real,
-                                                 int* __restrict__ flag, DiagSmem& sm, int i, long long* ph) {
-    const int t = i;
-    double p[16];
-    {   // tile column 0 straight from global memory (row i, 16 columns)
-        const double* src = A + (size_t)(k0 + i) * lda + k0;
-#pragma unroll
-        for (int c = 0; c < 16; ++c) p[c] = *(src + c);
-    }
-    PHASE_STAMP(0);
-#pragma unroll 1
-    for (int Jt = 0; Jt < 8; ++Jt) {
-        const int j0 = 16 * Jt;
-        const bool active = (i >= j0);
-        DIAG_TS(0);
-        if (active && i < j0 + 16) {
-#pragma unroll
-            for (int c = 0; c < 16; ++c) sm.Dd[i - j0][c] = p[c];
-        }
-        DIAG_TS(1);
-        __syncthreads();                                                  // Bp
-        DIAG_TS(2);
-        double l0[8], l1[8], y[8];
-        if (active) {
-            double pa[8];
-#pragma unroll
-            for (int c = 0; c < 8; ++c) pa[c] = p[c];
-            const bool bad = mini_chol_solve<17>(sm.Dd, pa, l0, y, k0 + j0, n_real);
-            if (bad && i == j0) atomicCAS(flag, 0, k0 + j0 + 1);
-            if (i == j0) {
-#pragma unroll
-                for (int c = 0; c < 8; ++c) sm.rd[j0 + c] = y[c];
-            }
-#pragma unroll
-            for (int c = 0; c < 8; ++c) sm.Lp[0][i][c] = l0[c];
-            if (i >= j0 + 8 && i < j0 + 16) {
-#pragma unroll
-                for (int c = 0; c < 8; ++c) sm.Lb[i - j0 - 8][c] = l0[c];
-            }
-        }
-        DIAG_TS(3);
-        __syncthreads();                                                  // B1
-        DIAG_TS(4);
-        const bool active1 = (i >= j0 + 8);
-        if (active1) {
-            // rank-8 update of this row's second-half values with the first-half panel
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                double v = p[8 + c];
-                const double2* lb = reinterpret_cast<const double2*>(&sm.Lb[c][0]);
-#pragma unroll
-                for (int k2 = 0; k2 < 4; ++k2) {
-                    const double2 b2 = lb[k2];
-                    v = fma(-l0[2 * k2], b2.x, v);
-                    v = fma(-l0[2 * k2 + 1], b2.y, v);
-                }
-                p[8 + c] = v;
-            }
-            if (i < j0 + 16) {
-#pragma unroll
-                for (int c = 0; c < 8; ++c) sm.Dd1[i - j0 - 8][c] = p[8 + c];
-            }
-        }
-        DIAG_TS(5);
-        __syncthreads();                                                  // Bq
-        DIAG_TS(6);
-        if (active1) {
-            double pa[8];
-#pragma unroll
-            for (int c = 0; c < 8; ++c) pa[c] = p[8 + c];
-            const bool bad = mini_chol_solve<9>(sm.Dd1, pa, l1, y, k0 + j0 + 8, n_real);
-            if (bad && i == j0 + 8) atomicCAS(flag, 0, k0 + j0 + 8 + 1);
-            if (i == j0 + 8) {
-#pragma unroll
-                for (int c = 0; c < 8; ++c) sm.rd[j0 + 8 + c] = y[c];
-            }
-#pragma unroll
-            for (int c = 0; c < 8; ++c) sm.Lp[1][i][c] = l1[c];
-        }
-        DIAG_TS(7);
-        __syncthreads();                                                  // B2
-        DIAG_TS(8);
-        if (active && i < j0 + 16) {
-            // the diagonal tile for the inverses (the finished columns of L are stored to global memory by
-            // the otherwise idle waves 4,5 straight from Lp: diag_store_waves)
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                sm.Tl[Jt][i - j0][c] = l0[c];
-                sm.Tl[Jt][i - j0][8 + c] = active1 ? l1[c] : 0.0;
-            }
-        }
-        if (Jt < 7) {
-            DIAG_TS(9);
-            __syncthreads();                                              // B3
-            DIAG_TS(10);
-            if (i >= j0 + 16) {
-#pragma unroll
-                for (int c = 0; c < 16; ++c) p[c] = sm.Pn[i][c];
-            }
-        }
-    }
-}
-
-// waves 4,5: take part in the barriers and, after B2 of every tile column, copy the finished 16 columns of
-// L from the two panels in LDS to global memory, off the critical chain
 // workgroup barrier that waits for this wave's LDS traffic only: __syncthreads() also waits for its
-// outstanding GLOBAL stores (s_waitcnt vmcnt(0)), which would put the store waves' ~1500-cycle global
-// writes back on the row threads' critical chain
+// outstanding GLOBAL stores (s_waitcnt vmcnt(0)), which would put a store wave's ~1500-cycle global
+// writes on the critical chain of the waves that wait for it at the barrier
 __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <bool WT>
-__device__ __forceinline__ void diag_store_waves(double* __restrict__ A, int lda, int k0, DiagSmem& sm, int r) {
-    // coalesced: one instruction = 4 rows x 16 columns (128 B per row); thread r -> (row group, column).
-    // The two panels of a tile column are copied LDS -> registers between B2 and B3 (cheap, pipelined) and
-    // written to global memory under the NEXT column's first pivot chain (after its Bp), so that no other
-    // wave ever waits at a barrier for the stores to be issued.
-    const int col = r & 15, h = col >> 3, c = col & 7;
-    const int rbase = (r >> 6) * 64 + ((r >> 4) & 3);                   // wave 4: rows 0..63, wave 5: rows 64..127
-    double v[16];
-    auto store_column = [&](int j0) {
-#pragma unroll
-        for (int it = 0; it < 16; ++it) {
-            const int row = rbase + 4 * it;
-            if (row >= j0 && j0 + col <= row) gst<WT>(A + (size_t)(k0 + row) * lda + k0 + j0 + col, v[it]);
-        }
-    };
-#pragma unroll 1
-    for (int Jt = 0; Jt < 8; ++Jt) {
-        lds_barrier();                                                    // Bp
-        if (Jt > 0) store_column(16 * (Jt - 1));
-        lds_barrier();                                                    // B1
-        lds_barrier();                                                    // Bq
-        lds_barrier();                                                    // B2
-#pragma unroll
-        for (int it = 0; it < 16; ++it) v[it] = sm.Lp[h][rbase + 4 * it][c];
-        if (Jt < 7) lds_barrier();                                        // B3
-    }
-    store_column(16 * 7);
-}
-
-// rank-8 update of this wave's tiles in tile columns >= JMIN (or == JMIN if ONLY) with the panel Lp
-template <int JMIN, bool ONLY>
-__device__ __forceinline__ void diag_rank8(double4v (&acc)[2][8], const double (*Lp)[9], int lr, int lc, int I0, int I1) {
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-        const int I = s2 ? I1 : I0;
-        if (I < JMIN) continue;
-        const double a0 = -Lp[16 * I + lc][lr], a1 = -Lp[16 * I + lc][4 + lr];
-#pragma unroll
-        for (int J = JMIN; J < (ONLY ? JMIN + 1 : 8); ++J) {
-            if (J > 7) continue;
-            if (J <= I) {
-                const double b0 = Lp[16 * J + lc][lr], b1 = Lp[16 * J + lc][4 + lr];
-                acc[s2][J & 7] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[s2][J & 7], 0, 0, 0);
-                acc[s2][J & 7] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[s2][J & 7], 0, 0, 0);
-            }
-        }
-    }
-}
-
-template <int Jt>
-__device__ __forceinline__ void diag_mfma_column(double4v (&acc)[2][8], DiagSmem& sm, int lr, int lc, int I0, int I1) {
-    DIAG_TS2(0);
-    __syncthreads();                                                      // Bp
-    DIAG_TS2(1);
-    if (Jt > 0) diag_rank8<Jt + 1, false>(acc, sm.Lp[1], lr, lc, I0, I1); // rest of the previous column's second panel
-    DIAG_TS2(2);
-    __syncthreads();                                                      // B1
-    __syncthreads();                                                      // Bq
-    DIAG_TS2(3);
-    diag_rank8<Jt + 1, false>(acc, sm.Lp[0], lr, lc, I0, I1);             // first panel, all trailing columns
-    DIAG_TS2(4);
-    __syncthreads();                                                      // B2
-    DIAG_TS2(5);
-    if (Jt < 7) {
-        diag_rank8<Jt + 1, true>(acc, sm.Lp[1], lr, lc, I0, I1);          // second panel on the next tile column only
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            const int I = s2 ? I1 : I0;
-            if (I >= Jt + 1) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) sm.Pn[16 * I + lr + 4 * r][lc] = acc[s2][(Jt + 1) & 7][r];
-            }
-        }
-        DIAG_TS2(6);
-        __syncthreads();                                                  // B3
-        DIAG_TS2(7);
-    }
-}
-
-template <bool WT>
-__device__ __forceinline__ void diag_mfma_waves(const double* __restrict__ A, int lda, int k0, DiagSmem& sm, int lane, int w) {
-    const int lr = lane >> 4, lc = lane & 15;
-    // tile rows of this wave (-1: none): SIMD 2 = waves 2, 6; SIMD 3 = waves 3, 7
-    const int I0 = (w == 2) ? 1 : (w == 3) ? 2 : (w == 6) ? 4 : (w == 7) ? 3 : -1;
-    const int I1 = (w == 2) ? 7 : (w == 3) ? 6 : (w == 7) ? 5 : -1;
-    double4v acc[2][8];
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-        const int I = s2 ? I1 : I0;
-#pragma unroll
-        for (int J = 1; J < 8; ++J) {
-            const bool in = (I >= 1 && J <= I);
-            const double* src = A + (size_t)(k0 + 16 * (in ? I : 0) + lr) * lda + k0 + 16 * (in ? J : 0) + lc;
-            double4v tmp;
-            tmp[0] = in ? *(src) : 0.0;
-            tmp[1] = in ? *(src + (size_t)4 * lda) : 0.0;
-            tmp[2] = in ? *(src + (size_t)8 * lda) : 0.0;
-            tmp[3] = in ? *(src + (size_t)12 * lda) : 0.0;
-            acc[s2][J] = tmp;
-        }
-        acc[s2][0] = double4v{0.0, 0.0, 0.0, 0.0};
-    }
-    diag_mfma_column<0>(acc, sm, lr, lc, I0, I1);
-    diag_mfma_column<1>(acc, sm, lr, lc, I0, I1);
-    diag_mfma_column<2>(acc, sm, lr, lc, I0, I1);
-    diag_mfma_column<3>(acc, sm, lr, lc, I0, I1);
-    diag_mfma_column<4>(acc, sm, lr, lc, I0, I1);
-    diag_mfma_column<5>(acc, sm, lr, lc, I0, I1);
-    diag_mfma_column<6>(acc, sm, lr, lc, I0, I1);
-    diag_mfma_column<7>(acc, sm, lr, lc, I0, I1);
-}
-
-// all 512 threads of the workgroup; smem = DIAG_SMEM_DOUBLES doubles of LDS; ends with the results in
-// global memory (no trailing barrier)
-template <bool WT>
-__device__ __forceinline__ void diag_block(double* __restrict__ A, int lda, int k0, int n_real,
-                                           int* __restrict__ flag, double* __restrict__ dinv, double* smem, int t,
-                                           long long* ph = nullptr) {
-    DiagSmem& sm = *reinterpret_cast<DiagSmem*>(smem);
-    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-    if (w < 2) diag_row_threads<WT>(A, lda, k0, n_real, flag, sm, t, ph);
-    else if (w == 4 || w == 5) diag_store_waves<WT>(A, lda, k0, sm, t - 256);
-    else diag_mfma_waves<WT>(A, lda, k0, sm, t & 63, w);
-    PHASE_STAMP(1);
-    __syncthreads();
-    // thread (b, m) forward-substitutes column m of tile b's inverse
-    if (t < NB) {
-        const int b = t >> 4, m = t & 15;
-        double x[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            double sum = (k == m) ? 1.0 : 0.0;
-#pragma unroll
-            for (int q = 0; q < k; ++q) sum = fma(-sm.Tl[b][k][q], x[q], sum);
-            x[k] = (k >= m) ? sum * sm.rd[16 * b + k] : 0.0;
-            gst<WT>(&dinv[(b * 16 + k) * 16 + m], x[k]);
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------
-// Diagonal block, second design ("D2"): everything on the matrix cores, 4 columns per step.
+// Diagonal block (128 x 128, 512 threads): everything on the matrix cores, 4 columns per step.  (A first design -- 128 row
+// threads factoring 8 x 8 mini-blocks redundantly on the VALU, four waves of rank-8 MFMA updates -- took 27.8 us inside the
+// persistent kernel against 21.3 us for this one and is gone; DESIGN.md 4 has its anatomy.)
 //
 // Measured on MI355X (tools/exp/lat_f64.hip): a dependent v_fma_f64 costs 4.2 cycles (= its issue time), the whole
 // pivot step rsq + Halley + scale + update 50 cycles, a dependent v_mfma_f64_16x16x4 66-81 cycles, an LDS write ->
@@ -458,9 +142,6 @@ __device__ __forceinline__ void diag_block(double* __restrict__ A, int lda, int 
 //                and SIMD in the first tile column, fewer later); the two tiles of row I that the follower needs then
 //                migrate to it through LDS.  Waves 6 / 7 also compute the inverses of the finished diagonal tiles of the
 //                even / odd rows (the same two MFMAs on an identity tile; the panel-solve tasks multiply by them).
-#ifndef STBA_DIAG_V2
-#define STBA_DIAG_V2 1
-#endif
 struct Diag2Smem {
     double Lsl[36][4][64];          // l operands: tile (I, J) at I(I+1)/2 + J, step s, lane
     double Gp[32][64];              // Gp operands: global step 4J + s, lane
@@ -469,14 +150,6 @@ struct Diag2Smem {
 };
 static_assert(sizeof(Diag2Smem) <= 128 * 1024, "D2 must fit the persistent kernel's LDS");
 
-#ifdef STBA_DIAG_TS
-__device__ long long g_d2_ev[8][160][2];
-__device__ int g_d2_nev[8];
-__device__ __forceinline__ long long d2_clock_after(double dep) { long long c; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(c) : "v"(dep) : "memory"); return c; }
-#define D2EV(code, dep) do { const long long c_ = d2_clock_after(dep); if (lane == 0 && d2_nev < 160) { g_d2_ev[w][d2_nev][0] = (code); g_d2_ev[w][d2_nev][1] = c_; } ++d2_nev; } while (0)
-#else
-#define D2EV(code, dep) do { } while (0)
-#endif
 
 __device__ __forceinline__ double readlane_f64(double x, int lane) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(x), lane), hi = __builtin_amdgcn_readlane(__double2hiint(x), lane);
@@ -604,9 +277,6 @@ __device__ __forceinline__ void d2_factor_wave(const double* __restrict__ Ab, in
         for (int e = 0; e < 10; ++e) mk[e] = (idx == e) ? 1.0 : 0.0;
     }
     int badv = 0;
-#ifdef STBA_DIAG_TS
-    int d2_nev = 0; const int w = 0;
-#endif
     double gp = d2_factor_gp(accD, 0, mk, badv, k0, n_real);
     sm.Gp[0][lane] = gp;
     if (ph && lane == 0) ph[1] = wall_clock64();
@@ -617,14 +287,12 @@ __device__ __forceinline__ void d2_factor_wave(const double* __restrict__ Ab, in
         for (int s = 0; s < 4; ++s) {
             const int tt = 4 * J + s;
             D2_BARRIER();
-            D2EV(200 + tt, gp);
             const double l = mfma_l(gp, accD[s]);
             sm.Lsl[d2_tix(J, J)][s][lane] = l;
             if (s < 3) {
                 accD = __builtin_amdgcn_mfma_f64_16x16x4f64(-l, l, accD, 0, 0, 0);
                 gp = d2_factor_gp(accD, s + 1, mk, badv, k0 + 16 * J + 4 * (s + 1), n_real);
                 sm.Gp[tt + 1][lane] = gp;
-                D2EV(100 + tt + 1, gp);
             }
         }
         if (J < 7) {
@@ -633,14 +301,10 @@ __device__ __forceinline__ void d2_factor_wave(const double* __restrict__ Ab, in
             for (int r = 0; r < 4; ++r) accD[r] = sm.Dg[r][lane];
             gp = d2_factor_gp(accD, 0, mk, badv, k0 + 16 * (J + 1), n_real);
             sm.Gp[4 * J + 4][lane] = gp;
-            D2EV(100 + 4 * J + 4, gp);
         }
     }
     D2_BARRIER();                                       // (the panel values of the last step are published)
     if (badv != 0 && lane == 0) atomicCAS(flag, 0, badv);
-#ifdef STBA_DIAG_TS
-    if (lane == 0) g_d2_nev[w] = d2_nev;
-#endif
 }
 
 // the follower: row J + 1 through tile column J
@@ -826,27 +490,11 @@ __device__ __forceinline__ void diag_block2(double* __restrict__ A, int lda, int
     else d2_bulk_wave<WT>(Ab, lda, sm, lane, w == 5 ? 5 : w == 2 ? 7 : w == 6 ? 3 : w == 3 ? 6 : 4, w == 6 ? 0 : w == 7 ? 1 : -1, dinv);
 }
 
-// (warm_k0 >= 0: the task is first run on another diagonal block of the matrix, so that the timed run finds its code
-// in the instruction cache as it does inside the persistent kernel; diagnostics only)
-__global__ __launch_bounds__(512) void chol_diag2_kernel(double* __restrict__ A, int lda, int k0, int n_real,
-                                                          int* __restrict__ flag, double* __restrict__ dinv, int warm_k0, long long* cycles) {
-    extern __shared__ __attribute__((aligned(16))) double sm2[];
-    if (warm_k0 >= 0) {
-        diag_block2<false>(A, lda, warm_k0, n_real, flag, dinv + 2048, sm2, threadIdx.x);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    }
-    const long long c0 = wall_clock64();
-    diag_block2<false>(A, lda, k0, n_real, flag, dinv, sm2, threadIdx.x);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (cycles && threadIdx.x == 0) cycles[0] = wall_clock64() - c0;      // 100 MHz
-}
-
+// the diagonal-block task as a kernel of its own (stage-kernel schedule); dynamic LDS: sizeof(Diag2Smem)
 __global__ __launch_bounds__(512) void chol_diag_kernel(double* __restrict__ A, int lda, int k0, int n_real,
                                                          int* __restrict__ flag, double* __restrict__ dinv) {
-    __shared__ __attribute__((aligned(16))) double sm[DIAG_SMEM_DOUBLES];
-    diag_block<false>(A, lda, k0, n_real, flag, dinv, sm, threadIdx.x);
+    extern __shared__ __attribute__((aligned(16))) double sm2[];
+    diag_block2<false>(A, lda, k0, n_real, flag, dinv, sm2, threadIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1051,23 +699,22 @@ __global__ __launch_bounds__(256) void chol_syrk_kernel(double* __restrict__ A, 
 
 // picks the tile shape by grid size (tiles128 = number of 128x128 tiles of the launch)
 static void launch_syrk(double* A, int lda, int k0, int tile_mode, int tiles128, hipStream_t st) {
-    static const int force = [] { const char* e = getenv("STBA_SYRK_TM"); return e ? atoi(e) : 0; }();
-    static const int big = [] { const char* e = getenv("STBA_SYRK_BIG"); return e ? atoi(e) : 1000000; }();
-    const bool use64 = force == 64 || (force != 128 && tiles128 < big);
+    // (TM = 64 for every grid size met so far: measured; TM = 128 pays from ~1000 tiles per launch)
+    const bool use64 = tiles128 < 1000000;
     if (use64) hipLaunchKernelGGL(chol_syrk_kernel<64>, dim3(2 * tiles128), dim3(256), 0, st, A, lda, k0, tile_mode);
     else hipLaunchKernelGGL(chol_syrk_kernel<128>, dim3(tiles128), dim3(256), 0, st, A, lda, k0, tile_mode);
 }
 
 // ------------------------------------------------------------------------------------------
-// The factorisation as ONE persistent kernel: a static task list in dataflow order, executed by one
-// 512-thread workgroup per CU.  Launching the steps as separate kernels costs ~3 us between dependent
-// kernels and ~12 us per cross-stream hand-off (measured), and a diagonal-block workgroup cannot start
-// on a CU that still holds trailing-update workgroups; with 47 dependent steps that was half of the
-// solve time.  Here a workgroup takes the next ticket (atomic counter), waits on the device-side
-// flags of that task's inputs, runs it, publishes its outputs (release fence + flag) and goes on.
-// Tickets are handed out in an order that is a topological order of the task graph, and a workgroup
-// only ever waits for tasks with smaller tickets -- which are finished or held by running
-// workgroups -- so the kernel cannot deadlock whatever the number of resident workgroups.
+// The factorisation as a persistent DATAFLOW program: a static task list in dataflow order, executed by workgroups that
+// stay resident for the whole factorisation.  Launching the steps as separate kernels costs ~3 us between dependent
+// kernels and ~12 us per cross-stream hand-off (measured), and a diagonal-block workgroup cannot start on a CU that still
+// holds trailing-update workgroups; with 47 dependent steps that was half of the solve time.  Here a workgroup takes the
+// next ticket of its list (atomic counter), waits on the device-side flags of that task's inputs, runs it, publishes its
+// outputs (release fence + flag) and goes on.  Tickets are handed out in an order that is a topological order of the task
+// graph, and a workgroup only ever waits for tasks that come earlier in that order -- which are finished, held by a
+// resident workgroup, or the next ticket of some list -- so the program cannot deadlock as long as every list has a
+// resident workgroup (4 for the lists that carry the TU tasks).
 //   D(b)          diagonal block b                        needs ver[b][b] == 4b
 //   TU(b, q)      q = 0..3: block row b+1 of the panel solve AND rows 32q.. of the update of the next
 //                 diagonal tile, fused (the critical hand-off D(b) -> D(b+1), see tu_task512)
@@ -1076,40 +723,50 @@ static void launch_syrk(double* A, int lda, int k0, int tile_mode, int tiles128,
 //   TI(b)         inverse transpose of block b (for the backward substitution)   needs D(b)
 //   U(b; i, j)    tile (i, j) -= L_ib L_jb^T       needs T(b,i), T(b,j), ver[i][j] == 4b;  ver += 4
 //   Uq(b; i,q,j)  the same for 32 rows of a tile of the NEXT panel's column (j = b+1)       ver += 1
+// (Round 3 tried TWO CLASSES of workgroups -- 512-thread "chain" workgroups on a few CUs of every XCD for D / TU / T / Uq, and
+// 256-thread trailing-update workgroups, two per CU, on all the others, the device split with CU-masked streams.  It ran,
+// bit-exact, and LOST: 2.61-2.96 ms against 2.44 ms, whatever the split.  Two update workgroups on a CU each take 45 us
+// per 128-column pass against 24 us alone: the update task is bound by what the memory system delivers to ALL CUs
+// together (~5.5 TB/s past the L2s at 8.2 flop/B), not by exposed latency inside one CU, so a second workgroup adds
+// nothing, and the critical updates queue behind far ones in the in-order bulk lists.  DESIGN.md 4 has the table.)
 // XCD ownership.  MI355X has eight XCDs with private, mutually non-coherent L2 caches.  Every tile
-// (i, j) is owned by one XCD (by tile row, see mega_owner), and every task that WRITES the tile runs
-// on a workgroup of that XCD (one ticket queue per XCD; a workgroup reads HW_REG_XCC_ID to find its
-// queue).  A tile under update therefore lives in one L2 only and needs nothing but an L1 invalidate
-// (buffer_inv sc1: agent-scope invalidate, which leaves the L2's local-memory lines alone) per task.  FINAL data -- blocks of L, written once by D / T / TU and never modified
+// (i, j) is owned by one XCD (by tile row, see mega_row_owner), and every task that WRITES the tile runs
+// on a workgroup of that XCD (a workgroup reads HW_REG_XCC_ID to find its lists).  A tile under update therefore lives
+// in one L2 only and needs nothing but an L1 invalidate (buffer_inv sc1: agent-scope invalidate, which leaves the L2's
+// local-memory lines alone) per task.  FINAL data -- blocks of L, written once by D / T / TU and never modified
 // again -- is stored write-through (sc1) and may then be cached by every other XCD: no other L2 can
 // hold an older copy, because nobody but the owner ever touched those lines before.  Flags are
 // agent-scope atomics.
 // The ticket order comes from a list-scheduling simulation on the host (mega_build_tasks).
 enum { TASK_D = 0, TASK_T = 1, TASK_TI = 2, TASK_U = 3, TASK_UQ = 4, TASK_TU = 5 };
 
+constexpr int MEGA_MAX_Q = 16;         // XCDs
 struct MegaArgs {
     double* A; int lda; int n; int nblk;
-    const int4* tasks;      // the per-XCD queues, concatenated
-    int nq;                 // number of queues (= XCDs seen by the probe)
-    int qstart[17];         // queue q holds tasks [qstart[q], qstart[q+1]): first its bulk tasks, taken in order, ...
-    int hstart[16];         // ... then, from hstart[q] on, its URGENT tasks (the critical chains), taken as soon as they are ready
+    const int4* tasks;      // the ticket lists, concatenated
+    int nq;                 // number of XCD queues (= XCDs seen by the probe)
+    int lstart[MEGA_MAX_Q + 1];   // list q (one per XCD) holds tasks [lstart[q], lstart[q+1]), taken in order
     signed char xcc_queue[16];   // HW_REG_XCC_ID -> queue
-    int* sync;              // [0..16) tickets, [16] abort, [17..33) heads of the urgent lists, [33..49) their hint words, then dflag[nblk], tuflag[nblk],
-                            // tflag[nblk*nrow], ver[nrow*nblk] (nrow = nblk + 4 nwide), claim[ntasks]
+    int* sync;              // [0..16) tickets of the lists, [16] abort, then dflag[nblk], tuflag[nblk],
+                            // tflag[nblk*nrow], ver[nrow*nblk] (nrow = nblk + 4 nwide)
     double* linv; size_t linv_stride;
     double* vbuf; int nwide;   // inverse transposes of the 512 x 512 diagonal blocks 0 .. nwide-1 (row-major, ld 512): see below
-    int predraw_nb;         // the next ticket is drawn at the start of a task only if the task spans at most this many panels
+    long long spin_limit;   // give up waiting for a dependency after this many ticks of the 100 MHz clock
     int* flag;
     long long* trace;       // optional (STBA_MEGA_TRACE): per task {workgroup, t_ticket, t_ready, t_done}, 100 MHz clock
 };
-constexpr int MEGA_SYNC_HDR = 49;
+constexpr int MEGA_SYNC_HDR = MEGA_MAX_Q + 1;
+constexpr int MEGA_ABORT = MEGA_MAX_Q;
 constexpr int MEGA_SMEM_BYTES = 128 * 1024;   // X of the TU task: 8 waves x 8 chunks x 2 KB
+constexpr int MEGA_PREDRAW_NB = 2;            // the next ticket is drawn at the start of a task only if the task spans at most
+                                              // this many panels (a ticket held for 60-80 us can be a critical one: measured -12 %)
 
 __device__ __forceinline__ int xcc_id() {
     unsigned v;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
     return (int)(v & 15u);
 }
+// which XCD does every workgroup of a launch land on (plan construction)
 __global__ void xcc_probe_kernel(int* out) {
     if (threadIdx.x == 0) out[blockIdx.x] = xcc_id();
 }
@@ -1294,15 +951,17 @@ __device__ __forceinline__ void syrk_tile512_gen(double* __restrict__ Cb, int ld
 // in A-operand order (56 KB; every lane then reads its 32 B with two ds_read_b128), because coherent
 // (sc1) global loads have ~2 us latency and a per-wave load chain made the task 50 us long.
 // thread 0 only.  Polls with relaxed agent-scope loads; gives up (and raises the abort flag, so that
-// every other workgroup gives up too) after ~2 s instead of hanging the device.
-__device__ __forceinline__ bool mega_wait(const int* p, int target, int* abortf) {
+// every other workgroup gives up too) after `limit` ticks of the 100 MHz clock instead of hanging the device
+// (MegaArgs::spin_limit: a multiple of the predicted makespan; the host then reruns the factorisation through the
+// stage kernels, see chol_run).
+__device__ __forceinline__ bool mega_wait(const int* p, int target, int* abortf, long long limit) {
     if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return true;
     const long long t0 = wall_clock64();
     for (;;) {
         __builtin_amdgcn_s_sleep(1);
         if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return true;
         if (__hip_atomic_load(abortf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
-        if (wall_clock64() - t0 > 200000000LL) {            // 100 MHz counter
+        if (wall_clock64() - t0 > limit) {
             __hip_atomic_store(abortf, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return false;
         }
@@ -1317,7 +976,7 @@ __device__ __forceinline__ bool mega_wait(const int* p, int target, int* abortf)
 __device__ __forceinline__ bool trsm_compute512(double4v (&W)[8], const double* __restrict__ rowp, bool ident,
                                                 int ident_row0, int nv, const double* __restrict__ Lb, int lda,
                                                 const double* __restrict__ dinv, double* smem, int t, long long* ph,
-                                                const int* dflag, int* abortf, int* s_ok, bool flag_known = false) {
+                                                const int* dflag, int* abortf, int* s_ok, long long spin_limit, bool flag_known = false) {
     const int lane = t & 63;
     const int n = lane & 15, g = lane >> 4;
     // this wave's rows (issued first: they are not needed before the staging is done)
@@ -1334,7 +993,7 @@ __device__ __forceinline__ bool trsm_compute512(double4v (&W)[8], const double* 
     // factor's tiles are requested right behind the rows: one memory round trip in front of the first MFMA instead of two)
     if (!flag_known) {
         if (t == 0) {
-            *s_ok = mega_wait(dflag, 1, abortf) ? 1 : 0;
+            *s_ok = mega_wait(dflag, 1, abortf, spin_limit) ? 1 : 0;
             asm volatile("buffer_inv sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
         }
         __syncthreads();
@@ -1394,9 +1053,9 @@ __device__ __forceinline__ bool trsm_compute512(double4v (&W)[8], const double* 
 __device__ __forceinline__ bool trsm_task512(double* __restrict__ rowp, bool ident, int ident_row0, int nv,
                                              const double* __restrict__ Lb, int lda,
                                              const double* __restrict__ dinv, double* smem, int t, long long* ph,
-                                             const int* dflag, int* abortf, int* s_ok, bool flag_known = false) {
+                                             const int* dflag, int* abortf, int* s_ok, long long spin_limit, bool flag_known = false) {
     double4v W[8];
-    if (!trsm_compute512(W, rowp, ident, ident_row0, nv, Lb, lda, dinv, smem, t, ph, dflag, abortf, s_ok, flag_known)) return false;
+    if (!trsm_compute512(W, rowp, ident, ident_row0, nv, Lb, lda, dinv, smem, t, ph, dflag, abortf, s_ok, spin_limit, flag_known)) return false;
     const int g = (t & 63) >> 4;
 #pragma unroll
     for (int J = 0; J < 8; ++J) gst4<true>(rowp + 16 * J + 4 * g, W[J]);
@@ -1411,7 +1070,8 @@ __device__ __forceinline__ bool trsm_task512(double* __restrict__ rowp, bool ide
 // A[b+1, b+1] -= X X^T (lower-triangle tiles only).  Workgroup q also writes rows 32q..32q+31 of X.
 __device__ __forceinline__ bool tu_task512(double* __restrict__ A, int lda, int k0, int rb, int q,
                                            const double* __restrict__ dinv, double* smem, int t, long long* ph,
-                                           int* loaded, int* ver_diag, const int* dflag, int* abortf, int* s_ok, bool flag_known = false) {
+                                           int* loaded, int* ver_diag, const int* dflag, int* abortf, int* s_ok, long long spin_limit,
+                                           bool flag_known = false) {
     const int lane = t & 63, w = t >> 6;
     const int n = lane & 15, g = lane >> 4;
     double* rowp = A + (size_t)(rb * NB + 16 * w + n) * lda + k0;
@@ -1432,7 +1092,7 @@ __device__ __forceinline__ bool tu_task512(double* __restrict__ A, int lda, int 
         }
     }
     double4v W[8];
-    if (!trsm_compute512(W, rowp, false, 0, NB, A + (size_t)k0 * lda + k0, lda, dinv, smem, t, ph, dflag, abortf, s_ok, flag_known)) return false;
+    if (!trsm_compute512(W, rowp, false, 0, NB, A + (size_t)k0 * lda + k0, lda, dinv, smem, t, ph, dflag, abortf, s_ok, spin_limit, flag_known)) return false;
     __syncthreads();                          // every wave is done with the L11 tiles in smem and has consumed its rows
     // the four TU workgroups of this step all READ the whole block row and each WRITES 32 rows of it in
     // place: count the readers, and store only once all four have their copy (see below)
@@ -1463,7 +1123,7 @@ __device__ __forceinline__ bool tu_task512(double* __restrict__ A, int lda, int 
         __hip_atomic_fetch_add(ver_diag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // The three other workgroups hold later tickets of the same queue; they are taken as soon as any
         // workgroup of this XCD is free (needs >= 4 resident workgroups per XCD, checked on the host).
-        *s_ok = mega_wait(loaded, 4, abortf) ? 1 : 0;
+        *s_ok = mega_wait(loaded, 4, abortf, spin_limit) ? 1 : 0;
     }
     __syncthreads();
     if (!*s_ok) return false;
@@ -1506,22 +1166,105 @@ __device__ __forceinline__ void syrk_q32(double* __restrict__ A, int lda, int k0
     PHASE_STAMP(1);
 }
 
-__global__ __launch_bounds__(512) void chol_mega_kernel(MegaArgs a) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];   // MEGA_SMEM_BYTES: SYRK staging | diagonal block | L11 tiles | X
-    __shared__ int s_task, s_ok, s_hc, s_dset;
-    __shared__ int4 s_hd[64];              // the urgent list's window [s_hc, s_hc + 64) as wave 0 saw it last
-    const int t = threadIdx.x;
-    const int nblk = a.nblk;
-    int* abortf = a.sync + 16;
-    int* dflag = a.sync + MEGA_SYNC_HDR;
-    int* tuflag = dflag + nblk;
+// ---- the flag arrays behind the header of MegaArgs::sync, and the readiness test of a task ----
+struct MegaView {
+    int nblk, nrow;
+    int* abortf; int* dflag; int* tuflag; int* tflag; int* ver;
+};
+__device__ __forceinline__ MegaView mega_view(const MegaArgs& a) {
+    MegaView v;
+    v.nblk = a.nblk;
     // Block rows >= nblk are VIRTUAL: row nblk + p is the identity block under panel p of a wide (4-panel) diagonal
     // block; carried through the panel solves and updates of the panels p .. 4q+3 of its wide block q = p / 4 it
     // becomes block row p - 4q of the inverse transpose of that 512 x 512 diagonal block, which the backward
     // substitution multiplies by (12 dependent steps instead of 47).  Its tiles live in a.vbuf, not in A.
-    const int nrow = nblk + 4 * a.nwide;
-    int* tflag = tuflag + nblk;                 // [panel b][row i], i < nrow
-    int* ver = tflag + nblk * nrow;             // [row i][panel j]
+    v.nrow = a.nblk + 4 * a.nwide;
+    v.abortf = a.sync + MEGA_ABORT;
+    v.dflag = a.sync + MEGA_SYNC_HDR;
+    v.tuflag = v.dflag + a.nblk;
+    v.tflag = v.tuflag + a.nblk;                // [panel b][row i], i < nrow
+    v.ver = v.tflag + a.nblk * v.nrow;          // [row i][panel j]
+    return v;
+}
+__device__ __forceinline__ int mega_ldf(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// (tu_dset: for a TU task, whether its diagonal block was there already -- then the task fetches the factor at once)
+__device__ __forceinline__ bool mega_ready(const MegaView& v, const int4 d, bool& tu_dset) {
+    const int type = d.x & 0xff, b = d.y, ti = d.z, tj = d.w;
+    const int nblk = v.nblk, nrow = v.nrow;
+    auto first_panel = [&](int i) { return i < nblk ? 0 : i - nblk; };      // the first panel that updates row i
+    if (type == TASK_D) return mega_ldf(&v.ver[b * nblk + b]) >= 4 * b;
+    if (type == TASK_T) {       // (a panel solve is only started once its diagonal block is there; starting it earlier, with its
+                                // rows requested before the wait, measured the same: 2.465 against 2.463 ms)
+        const int ve = mega_ldf(&v.ver[ti * nblk + b]), df = mega_ldf(&v.dflag[b]);
+        return (ve >= 4 * (b - first_panel(ti))) & (df >= 1);
+    }
+    if (type == TASK_TI) return mega_ldf(&v.dflag[b]) >= 1;
+    if (type == TASK_TU) {
+        const int v0 = mega_ldf(&v.ver[(b + 1) * nblk + b]), v1 = mega_ldf(&v.ver[(b + 1) * nblk + b + 1]), df = mega_ldf(&v.dflag[b]);
+        tu_dset = df >= 1;
+        return (v0 >= 4 * b) & (v1 >= 4 * b);
+    }
+    const int i = (type == TASK_UQ) ? (ti >> 2) : ti;
+    const int nbp = max(1, (d.x >> 16) & 0xff);            // panels in this task (a batched trailing update: b is its last one)
+    const int f0 = mega_ldf(&v.tflag[b * nrow + i]), f1 = mega_ldf(&v.tflag[b * nrow + tj]), ve = mega_ldf(&v.ver[i * nblk + tj]);
+    return (f0 >= 4) & (f1 >= 4) & (ve >= 4 * (b - nbp + 1 - first_panel(i)));
+}
+
+// Wave 0 of a workgroup: the next task of ticket list [lbeg, lend).  One in-order list per XCD: a workgroup
+// draws the next ticket while its current task starts (the atomic's latency hides behind the task), reads the
+// descriptor afterwards and PARKS on it, polling the task's input flags; it starts the instant the last one flips.
+// (TU tasks go on waiting for the diagonal block inside, with their operands loaded.)  Returns the task index, -2 when
+// the list is exhausted, -1 on a time-out / abort (ok = false).
+struct MegaTicket {
+    int mine = -1;          // the ticket held (-1: none), wave-uniform
+    int4 md;
+    bool done = false;      // the list is exhausted
+    int m_raw = 0;          // lane 0: the ticket drawn when the previous task started
+    bool m_pending = false;
+};
+__device__ __forceinline__ int mega_next_task(const MegaArgs& a, const MegaView& v, MegaTicket& tk, int* ticket, int lbeg, int lend, int lane,
+                                              bool& ok, bool& tu_dset, long long& t_poll) {
+    t_poll = a.trace ? wall_clock64() : 0;
+    ok = true;
+    if (tk.mine < 0 && !tk.done) {
+        if (!tk.m_pending && lane == 0) tk.m_raw = lbeg + atomicAdd(ticket, 1);
+        tk.m_pending = false;
+        tk.mine = __builtin_amdgcn_readfirstlane(tk.m_raw);
+        if (tk.mine >= lend) { tk.mine = -1; tk.done = true; }
+        else tk.md = a.tasks[tk.mine];
+    }
+    int pick = -2;                          // nothing left for this workgroup
+    if (tk.mine >= 0) {
+        const long long t0 = wall_clock64();
+        for (;;) {
+            if (mega_ready(v, tk.md, tu_dset)) { pick = tk.mine; tk.mine = -1; break; }
+            if (mega_ldf(v.abortf) != 0) { ok = false; pick = -1; break; }
+            if (wall_clock64() - t0 > a.spin_limit) {            // 100 MHz counter
+                __hip_atomic_store(v.abortf, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = false; pick = -1;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    // this CU's L1 may hold lines of tiles that other CUs have rewritten since
+    // (buffer_inv sc0 does NOT do it outside threadgroup-split mode: measured, stale L1 hits)
+    asm volatile("buffer_inv sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
+    return pick;
+}
+
+__global__ __launch_bounds__(512) void chol_mega_kernel(MegaArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];   // MEGA_SMEM_BYTES: SYRK staging | diagonal block | L11 tiles | X
+    __shared__ int s_task, s_ok, s_dset;
+    const int t = threadIdx.x;
+    const int nblk = a.nblk;
+    const MegaView v = mega_view(a);
+    int* abortf = v.abortf;
+    int* dflag = v.dflag;
+    int* tuflag = v.tuflag;
+    const int nrow = v.nrow;
+    int* tflag = v.tflag;
+    int* ver = v.ver;
     // row i, column panel j: address of the tile's first element and its leading dimension
     auto tile_ptr = [&](int i, int j, int& ld) -> double* {
         if (i < nblk) { ld = a.lda; return a.A + (size_t)i * NB * a.lda + (size_t)j * NB; }
@@ -1531,150 +1274,33 @@ __global__ __launch_bounds__(512) void chol_mega_kernel(MegaArgs a) {
     };
     auto first_panel = [&](int i) { return i < nblk ? 0 : i - nblk; };      // the first panel that updates row i
     const int q = a.xcc_queue[xcc_id()];
-    if (q < 0) return;                        // an XCD the probe did not see: no queue, nothing to do
-    // One in-order list per XCD: a workgroup draws the next ticket while its current task starts (the atomic's latency
-    // hides behind the task), reads the descriptor afterwards and PARKS on it, polling the task's input flags; it starts
-    // the instant the last one flips.  (TU and T tasks go on waiting for the diagonal block inside, with their operands
-    // loaded.)
-    // Optionally (STBA_MEGA_HI, an experiment that LOST -- numbers at mega_build_tasks) the tasks of the critical chains
-    // form a second, URGENT list per XCD, [hstart, qstart[q+1]): any workgroup that is free, or waiting for its bulk
-    // task's inputs, claims the first urgent entry that is ready.
-    // No deadlock: the earliest unexecuted task of the global (simulated-start) order has all its inputs done or
-    // running; if urgent it is at the head of its list, if bulk its ticket is the lowest one not executed, which is
-    // either held by a polling workgroup or the next one handed out.
+    if (q < 0) return;                        // an XCD the probe did not see: no list, nothing to do
     int* ticket = a.sync + q;
-    int* hhead = a.sync + 17 + q;
-    int* claim = ver + nrow * nblk;
-    const int qbeg = a.qstart[q], qend = a.hstart[q], hbeg = a.hstart[q], hend = a.qstart[q + 1];
-    auto ldf = [](const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-    bool tu_dset = false;
-    auto ready = [&](const int4 d, bool urgent) -> bool {
-        const int type = d.x & 0xff, b = d.y, ti = d.z, tj = d.w;
-        if (type == TASK_D) return ldf(&ver[b * nblk + b]) >= 4 * b;
-        if (type == TASK_T) {       // (an urgent one awaits the diagonal block inside the task, with its rows loaded)
-            if ((d.x >> 24) & 1) {
-                // fused with the last update of its tile (by panel b-1): needs that panel's tiles of the rows ti and b and the
-                // tile through panel b-2; the diagonal block b is awaited inside, behind the update
-                const int v = ldf(&ver[ti * nblk + b]), f0 = ldf(&tflag[(b - 1) * nrow + ti]), f1 = ldf(&tflag[(b - 1) * nrow + b]);
-                return (v >= 4 * (b - 1 - first_panel(ti))) & (f0 >= 4) & (f1 >= 4);
-            }
-            const int v = ldf(&ver[ti * nblk + b]), df = urgent ? 1 : ldf(&dflag[b]);
-            return (v >= 4 * (b - first_panel(ti))) & (df >= 1);
-        }
-        if (type == TASK_TI) return ldf(&dflag[b]) >= 1;
-        if (type == TASK_TU) {
-            const int v0 = ldf(&ver[(b + 1) * nblk + b]), v1 = ldf(&ver[(b + 1) * nblk + b + 1]), df = ldf(&dflag[b]);
-            tu_dset = df >= 1;      // (is the diagonal block there already?  then the task fetches its factor at once)
-            return (v0 >= 4 * b) & (v1 >= 4 * b);
-        }
-        const int i = (type == TASK_UQ) ? (ti >> 2) : ti;
-        const int nbp = max(1, (d.x >> 16) & 0xff);            // panels in this task (a batched trailing update: b is its last one)
-        const int f0 = ldf(&tflag[b * nrow + i]), f1 = ldf(&tflag[b * nrow + tj]), v = ldf(&ver[i * nblk + tj]);
-        return (f0 >= 4) & (f1 >= 4) & (v >= 4 * (b - nbp + 1 - first_panel(i)));
-    };
-    // Wave 0 polls.  The urgent list (if there is one) is examined one entry per lane (the 64 entries behind its head,
-    // their descriptors cached in LDS between polls), but only when there can be something new in it: right after a task
-    // that FEEDS urgent tasks (bit 8 of its type word), when the list's hint word says that ready entries were left
-    // behind by the last scan, and while the workgroup has nothing else to do.
-    int mine = -1;                  // wave 0, uniform: the bulk ticket held (-1: none)
-    int4 md = make_int4(0, 0, 0, 0);
-    bool lo_done = false;           // the bulk list is exhausted
-    int m_raw = 0;                  // lane 0: the ticket drawn when the previous task started (its latency hides behind that task)
-    bool m_pending = false;
-    bool fed = true;                // the task just finished feeds urgent tasks
-    int* hint = a.sync + 33 + q;
-    if (t == 0) s_hc = -1;
+    const int lbeg = a.lstart[q], lend = a.lstart[q + 1];
+    MegaTicket tk;
     for (;;) {
         if (t < 64) {
-            const int lane = t;
-            const long long t_poll = a.trace ? wall_clock64() : 0;
-            const long long t0 = wall_clock64();
-            int pick = -1;
-            bool ok = true;
-            if (mine < 0 && !lo_done) {
-                if (!m_pending && lane == 0) m_raw = qbeg + atomicAdd(ticket, 1);
-                m_pending = false;
-                mine = __builtin_amdgcn_readfirstlane(m_raw);
-                if (mine >= qend) { mine = -1; lo_done = true; }
-                else md = a.tasks[mine];
-            }
-            int hc = s_hc;
-            int4 hd = s_hd[lane];
-            bool idle = false;              // a poll has found nothing to run
-            for (;;) {
-                const bool lr = mine >= 0 && ready(md, false);
-                const int hn = ldf(hint);
-                if (hbeg < hend && (fed || idle || hn != 0)) {
-                    // scan the window
-                    const int idx = hbeg + hc + lane;
-                    const bool hv = hc >= 0 && idx < hend;
-                    const int cl = hv ? ldf(&claim[idx]) : 1;
-                    const bool hr = hv && ready(hd, true);
-                    const int h = ldf(hhead);
-                    if (h != hc) {                          // the head has moved: fetch the new window, test again
-                        hc = h;
-                        hd = (hbeg + hc + lane < hend) ? a.tasks[hbeg + hc + lane] : make_int4(TASK_TI, 0, 0, 0);
-                        continue;
-                    }
-                    const unsigned long long rm = __ballot(hr && cl == 0);
-                    int win = -1;
-                    const int nready = __builtin_popcountll(rm);
-                    if (nready > 0) {
-                        // (not always the first ready entry: the workgroups that see four tasks become ready together must
-                        // not all go for the same one)
-                        unsigned long long m2 = rm;
-                        for (int r = (int)(blockIdx.x % (unsigned)nready); r > 0; --r) m2 &= m2 - 1;
-                        win = __builtin_ctzll(m2);
-                        const bool got = lane == win && atomicCAS(&claim[idx], 0, 1) == 0;
-                        if (__ballot(got) == 0ull) continue;        // another workgroup was faster
-                        pick = hbeg + hc + win;
-                    }
-                    // move the head past the leading claimed entries; tell the others whether ready entries are left
-                    const unsigned long long cm = __ballot(hv && (cl != 0 || lane == win));
-                    const int lead = (~cm == 0ull) ? 64 : __builtin_ctzll(~cm);
-                    if (lane == 0) {
-                        if (lead > 0) atomicMax(hhead, hc + lead);
-                        const int left = nready > 1 ? 1 : 0;
-                        if (left != hn) __hip_atomic_store(hint, left, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                    fed = false;
-                    if (pick >= 0) break;
-                }
-                if (lr) { pick = mine; mine = -1; break; }
-                if (lo_done && mine < 0 && (hbeg >= hend || (hc >= 0 && hbeg + hc >= hend))) { pick = -2; break; }      // nothing left for this XCD
-                if (ldf(abortf) != 0) { ok = false; break; }
-                if (wall_clock64() - t0 > 200000000LL) {            // 100 MHz counter
-                    __hip_atomic_store(abortf, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ok = false;
-                    break;
-                }
-                idle = true;
-                __builtin_amdgcn_s_sleep(8);
-            }
-            s_hd[lane] = hd;
-            // this CU's L1 may hold lines of tiles that other CUs have rewritten since
-            // (buffer_inv sc0 does NOT do it outside threadgroup-split mode: measured, stale L1 hits)
-            asm volatile("buffer_inv sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
-            if (pick >= 0) fed = (a.tasks[pick].x >> 8) != 0;
-            if (lane == 0) {
+            bool ok, tu_dset = false;
+            long long t_poll;
+            const int pick = mega_next_task(a, v, tk, ticket, lbeg, lend, t, ok, tu_dset, t_poll);
+            if (t == 0) {
                 if (a.trace && pick >= 0) {
                     a.trace[8 * (size_t)pick] = blockIdx.x; a.trace[8 * (size_t)pick + 1] = t_poll;
                     a.trace[8 * (size_t)pick + 2] = wall_clock64();
                 }
-                s_hc = hc;
                 s_dset = tu_dset ? 1 : 0;
                 s_task = pick;
                 s_ok = ok ? 1 : 0;
             }
-            // draw the next bulk ticket now, look at it after the task.  Not before a TU task: it waits for its three
+            // draw the next ticket now, look at it after the task.  Not before a TU task: it waits for its three
             // siblings, which hold LATER tickets -- this workgroup must not sit on one of them.
-            if (mine < 0 && !lo_done && pick >= 0 && (a.tasks[pick].x & 0xff) != TASK_TU && ((a.tasks[pick].x >> 16) & 0xff) <= a.predraw_nb) {
-                if (lane == 0) m_raw = qbeg + atomicAdd(ticket, 1);
-                m_pending = true;
+            if (!tk.done && pick >= 0 && (tk.md.x & 0xff) != TASK_TU && ((tk.md.x >> 16) & 0xff) <= MEGA_PREDRAW_NB) {
+                if (t == 0) tk.m_raw = lbeg + atomicAdd(ticket, 1);
+                tk.m_pending = true;
             }
         }
         __syncthreads();
-        if (!s_ok) {                            // dependency time-out: make the host see a hard error
+        if (!s_ok) {                            // dependency time-out: make the host see it (it reruns the stage kernels)
             if (t == 0) atomicExch(a.flag, CHOL_FLAG_TIMEOUT);
             break;
         }
@@ -1690,26 +1316,14 @@ __global__ __launch_bounds__(512) void chol_mega_kernel(MegaArgs a) {
         double* li = a.linv + (size_t)b * a.linv_stride;
         long long* ph = a.trace ? a.trace + 8 * (size_t)task + 4 : nullptr;
         if (type == TASK_D) {
-#if STBA_DIAG_V2
             diag_block2<true>(a.A, a.lda, k0, a.n, a.flag, li + NB * NB, smem, tt, ph);
-#else
-            diag_block<true>(a.A, a.lda, k0, a.n, a.flag, li + NB * NB, smem, tt, ph);
-#endif
         } else if (type == TASK_T) {
-            if ((d.x >> 24) & 1) {
-                // the tile's last update first; the panel solve below reads the tile back through the L2 (this CU's L1 holds
-                // the lines the update loaded)
-                syrk_tile512<128>(a.A, a.lda, k0 - NB, ti * NB, k0, smem, tt);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                asm volatile("buffer_inv sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
-            }
             const int lane = tt & 63, w = tt >> 6;
             int ldr;
             double* rowp = tile_ptr(ti, b, ldr) + (size_t)(16 * w + (lane & 15)) * ldr;
-            // (a bulk panel solve is only started once its diagonal block is there: see ready())
+            // (a panel solve is only started once its diagonal block is there: see mega_ready)
             if (!trsm_task512(rowp, false, 0, NB, a.A + (size_t)k0 * a.lda + k0, a.lda, li + NB * NB, smem, tt, ph, &dflag[b], abortf, &s_ok,
-                              hbeg >= hend && !((d.x >> 24) & 1))) {
+                              a.spin_limit, true)) {
                 if (t == 0) atomicExch(a.flag, CHOL_FLAG_TIMEOUT);
                 break;
             }
@@ -1721,7 +1335,8 @@ __global__ __launch_bounds__(512) void chol_mega_kernel(MegaArgs a) {
             double* base = li;
             if (b < 4 * a.nwide) base = tile_ptr(nblk + b, b, ldr);
             double* rowp = base + (size_t)(16 * w + (lane & 15)) * ldr;
-            if (!trsm_task512(rowp, true, 16 * w, nv, a.A + (size_t)k0 * a.lda + k0, a.lda, li + NB * NB, smem, tt, ph, &dflag[b], abortf, &s_ok, true)) {
+            if (!trsm_task512(rowp, true, 16 * w, nv, a.A + (size_t)k0 * a.lda + k0, a.lda, li + NB * NB, smem, tt, ph, &dflag[b], abortf, &s_ok,
+                              a.spin_limit, true)) {
                 if (t == 0) atomicExch(a.flag, CHOL_FLAG_TIMEOUT);
                 break;
             }
@@ -1738,7 +1353,7 @@ __global__ __launch_bounds__(512) void chol_mega_kernel(MegaArgs a) {
             }
         } else if (type == TASK_TU) {
             if (!tu_task512(a.A, a.lda, k0, b + 1, ti, li + NB * NB, smem, tt, ph, &tuflag[b], &ver[(b + 1) * nblk + b + 1], &dflag[b], abortf, &s_ok,
-                            s_dset != 0)) {
+                            a.spin_limit, s_dset != 0)) {
                 if (t == 0) atomicExch(a.flag, CHOL_FLAG_TIMEOUT);
                 break;
             }
@@ -1757,8 +1372,6 @@ __global__ __launch_bounds__(512) void chol_mega_kernel(MegaArgs a) {
             else if (type == TASK_U) __hip_atomic_fetch_add(&ver[ti * nblk + tj], 4 * max(1, (d.x >> 16) & 0xff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             else if (type == TASK_UQ) __hip_atomic_fetch_add(&ver[(ti >> 2) * nblk + tj], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (a.trace) a.trace[8 * (size_t)task + 3] = wall_clock64();
-            // (the scan that follows a feeding task must see this flag: wait until the L2 has it)
-            if (fed) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
     }
 }
@@ -1781,18 +1394,7 @@ static int mega_task_row(const int4& tk) {
 static std::vector<int> mega_row_owner(int nblk, int nq, int nvirt = 0) {
     std::vector<int> owner((size_t)(nblk + nvirt), 0);
     for (int v = 0; v < nvirt; ++v) owner[(size_t)(nblk + v)] = v % nq;      // virtual rows (inverse blocks): a few light tasks each
-    static const int MODE = [] { const char* e = getenv("STBA_MEGA_ROWMAP"); return e ? atoi(e) : 1; }();
-    if (MODE == 0) {
-        for (int row = 0; row < nblk; ++row) {
-            const int m = row % (2 * nq);
-            owner[(size_t)row] = m < nq ? m : 2 * nq - 1 - m;
-        }
-        return owner;
-    }
-    if (MODE == 2 || MODE == 3) {
-        for (int row = 0; row < nblk; ++row) owner[(size_t)row] = (MODE == 2 ? row : nblk - 1 - row) % nq;
-        return owner;
-    }
+    // (dealt boustrophedon or cyclically instead: measured 8 % worse)
     std::vector<double> load((size_t)nq, 0.0);
     for (int row = nblk - 1; row >= 0; --row) {
         int best = 0;
@@ -1803,12 +1405,23 @@ static std::vector<int> mega_row_owner(int nblk, int nq, int nvirt = 0) {
     }
     return owner;
 }
-// The ticket order is produced by LIST SCHEDULING a model of the machine on the host: `wg_per_q`
-// workers per XCD queue, measured task durations, and priorities that put the critical chain
-// D -> TU -> D first, then the panel (T, Uq), then the trailing updates column by column.  Sorting the
-// tasks by their simulated start time gives (i) one global topological order, which the deadlock
-// argument needs, and (ii) per-queue orders in which a workgroup rarely takes a ticket whose inputs
-// are far from ready (an in-order ticket queue has no other notion of priority).
+// Debug knobs (scheduling experiments) exist only in builds with -DSTBA_DEBUG_KNOBS; the product library
+// reads no environment variables here.
+#ifdef STBA_DEBUG_KNOBS
+static int knob_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+static double knob_double(const char* name, double dflt) { const char* e = getenv(name); return e ? atof(e) : dflt; }
+static const char* knob_str(const char* name) { return getenv(name); }
+#else
+static int knob_int(const char*, int dflt) { return dflt; }
+static double knob_double(const char*, double dflt) { return dflt; }
+static const char* knob_str(const char*) { return nullptr; }
+#endif
+
+// The ticket order is produced by LIST SCHEDULING a model of the machine on the host: `wg` workers per XCD queue, measured
+// task durations, and bottom-level priorities (longest path to the end of the graph, HLFET).  Sorting the tasks by the
+// time their model worker became free gives (i) one global topological order, which the deadlock argument needs, and
+// (ii) per-queue orders in which a workgroup rarely takes a ticket whose inputs are far from ready (an in-order ticket
+// list has no other notion of priority).
 struct MegaShardModel {          // what-if: the queues are spread over several GPUs (design study, DESIGN.md "sharded reduced solve")
     int n_gpus = 1;              // queue q belongs to GPU q / (nq / n_gpus)
     int rows_per_group = 0;      // tile rows are dealt to the GPUs in groups of this many consecutive rows (0: one XCD-round, nq / n_gpus)
@@ -1817,11 +1430,17 @@ struct MegaShardModel {          // what-if: the queues are spread over several 
     double cross_edges = 0.0;    // out: dependencies that crossed GPUs
     double tiles_in_max = 0.0;   // out: distinct remote tiles fetched by the busiest GPU
 };
-static void mega_build_tasks(int nblk, int nq, int wg_per_q, std::vector<int4>& out, int* qstart, int* hstart, std::vector<float>* sim_start = nullptr,
+struct MegaMachine {
+    int nq = 8;                  // XCD queues
+    int wg = 32;                 // model workers (= resident workgroups) per queue
+};
+static void mega_build_tasks(int nblk, const MegaMachine& mach, std::vector<int4>& out, int* lstart, std::vector<float>* sim_start = nullptr,
                              double* makespan_out = nullptr, int nwide = 0, MegaShardModel* shard = nullptr) {
-    struct Node { int4 tk; std::vector<int> succ; int indeg = 0; double dur = 0, prio = 0, start = 0, ready = 0, avail = 0; int q = 0; int last_pred = -1; bool noemit = false; };
+    struct Node { int4 tk; std::vector<int> succ; int indeg = 0; double dur = 0, prio = 0, start = 0, ready = 0, avail = 0; int q = 0; int last_pred = -1; };
     std::vector<Node> nodes;
     const int NBK = nblk;
+    const int nq = mach.nq;
+    const int nl = nq;                             // one ticket list per XCD queue
     std::vector<int> rowq = mega_row_owner(nblk, nq, 4 * nwide);
     const int n_gpus = shard ? shard->n_gpus : 1, q_per_gpu = nq / std::max(1, n_gpus);
     if (shard && n_gpus > 1) {
@@ -1832,32 +1451,30 @@ static void mega_build_tasks(int nblk, int nq, int wg_per_q, std::vector<int4>& 
             rowq[(size_t)row] = ((row / R) % n_gpus) * q_per_gpu + local % q_per_gpu;
         }
     }
-    auto gpu_of = [&](int q) { return n_gpus > 1 ? q / q_per_gpu : 0; };
-    static const int QROWS = [] { const char* e = getenv("STBA_MEGA_QROWS"); return e ? atoi(e) : 2; }();
+    auto gpu_of = [&](int l) { return n_gpus > 1 ? l / q_per_gpu : 0; };
+    static const int QROWS = knob_int("STBA_MEGA_QROWS", 2);
     // from panel QFROM on (the chain-bound part of the factorisation, where workgroups are idle) every row's tile in the next
     // panel column is updated by four quarter tasks: the row sweeps T -> U -> T get shorter
-    static const int QFROM = [] { const char* e = getenv("STBA_MEGA_QFROM"); return e ? atoi(e) : 1 << 30; }();
+    static const int QFROM = knob_int("STBA_MEGA_QFROM", 1 << 30);
     std::vector<int> idD((size_t)NBK, -1), idTI((size_t)NBK, -1), idTU((size_t)NBK * 4, -1), idT((size_t)NBK * NBK, -1),
         idUq((size_t)NBK * NBK * 4, -1), idU((size_t)NBK * NBK * NBK, -1);
     // measured on MI355X (tools/mega_trace.py), microseconds, plus ~2 us of flag latency per hop
-    // (STBA_MEGA_DUR=d,t,ti,u,uq,tu overrides them for experiments)
+    // (debug builds: STBA_MEGA_DUR=d,t,ti,u,uq,tu overrides them for experiments)
     double DUR[6] = {23.0, 23.0, 19.0, 25.0, 16.5, 20.0};      // (D: 21.3 us since round 2)
-    const double DUR_K = 18.0;     // one more panel (K += 128) inside a batched trailing update (measured: 24 us for one panel, 42 for two)
-    static const int BATCH = [] { const char* e = getenv("STBA_MEGA_BATCH"); return e ? std::max(1, std::min(16, atoi(e))) : 2; }();
-    // (STBA_MEGA_FUSET=1, an experiment, off: correct and deterministic, predicted -55 us by the model, measured 2.69-2.73 ms
-    // with and without -- the row sweeps are not what binds the machine)
-    static const int FUSET = [] { const char* e = getenv("STBA_MEGA_FUSET"); return e ? atoi(e) : 0; }();
-    static const int BLAG = [] { const char* e = getenv("STBA_MEGA_BLAG"); return e ? std::max(0, atoi(e)) : 3; }();
-    if (const char* e = getenv("STBA_MEGA_DUR")) sscanf(e, "%lf,%lf,%lf,%lf,%lf,%lf", &DUR[0], &DUR[1], &DUR[2], &DUR[3], &DUR[4], &DUR[5]);
+    double DUR_K = 18.0;           // one more panel (K += 128) inside a batched trailing update (measured: 24 us for one panel, 42 for two)
+    static const int BATCH = std::max(1, std::min(16, knob_int("STBA_MEGA_BATCH", 2)));
+    static const int BLAG = std::max(0, knob_int("STBA_MEGA_BLAG", 3));
+    if (const char* e = knob_str("STBA_MEGA_DUR")) sscanf(e, "%lf,%lf,%lf,%lf,%lf,%lf", &DUR[0], &DUR[1], &DUR[2], &DUR[3], &DUR[4], &DUR[5]);
     auto add = [&](int type, int b, int i, int j, double prio) {
-        Node nd; nd.tk = make_int4(type, b, i, j); nd.dur = DUR[type]; nd.prio = prio; nd.q = rowq[(size_t)mega_task_row(nd.tk)];
+        Node nd; nd.tk = make_int4(type, b, i, j); nd.dur = DUR[type]; nd.prio = prio;
+        nd.q = rowq[(size_t)mega_task_row(nd.tk)];
         nodes.push_back(nd);
         return (int)nodes.size() - 1;
     };
     // priorities: smaller = sooner.  The key is the block column a task works towards (10 per column)
     // plus a class offset, so that everything the NEXT panels need goes before trailing updates of far
     // columns, whatever step they belong to (an in-step order would bury the update of tile (b+1, b+1)
-    // by panel b-1 behind the whole backlog of panel b-2).
+    // by panel b-1 behind the whole backlog of panel b-2).  (Replaced by the bottom level below; kept as the tie-break.)
     for (int b = 0; b < NBK; ++b) {
         idD[(size_t)b] = add(TASK_D, b, 0, 0, 10.0 * b);
         idTI[(size_t)b] = add(TASK_TI, b, 0, 0, 10.0 * NBK + b);
@@ -1865,24 +1482,10 @@ static void mega_build_tasks(int nblk, int nq, int wg_per_q, std::vector<int4>& 
             for (int q = 0; q < 4; ++q) idTU[(size_t)b * 4 + q] = add(TASK_TU, b, q, 0, 10.0 * b + 5);
         for (int i = b + 2; i < NBK; ++i) {
             idT[(size_t)b * NBK + i] = add(TASK_T, b, i, 0, 10.0 * b + 6 + 1e-3 * i);
-            if (FUSET && b >= 1 && i >= b + 2) {        // second half of the fused task emitted with the previous panel
-                nodes[(size_t)idT[(size_t)b * NBK + i]].noemit = true;
-                nodes[(size_t)idT[(size_t)b * NBK + i]].dur = DUR[TASK_T] - 2.0;
-            }
             // the next panel's column: 32-row tasks (short latency) only for the rows the second critical chain
             // needs soon; a quarter task costs 14.5 us of a workgroup against 23.4 us for a whole tile, so the
             // rows further down take the whole-tile task (their panel solve comes a diagonal block later)
-            if (FUSET && i >= b + 3) {
-                // The last update of tile (i, b+1) -- by this panel -- belongs to the panel solve T(b+1; i) that consumes the
-                // tile: ONE task, emitted here (it can start as soon as this panel's tiles of the rows i and b+1 are there,
-                // i.e. while the diagonal block b+1 is still being factored), whose second half (the solve proper, the node
-                // T(b+1; i) created in the next round, not emitted) waits for that diagonal block inside.  Saves a tile round
-                // trip and a hand-over per tile row and panel: the row sweeps T -> U -> T were the longest chain.
-                const int ua = add(TASK_T, b + 1, i, 0, 10.0 * (b + 1) + 2 + 1e-3 * i);
-                nodes[(size_t)ua].tk.x |= 1 << 24;
-                nodes[(size_t)ua].dur = DUR_K;
-                idUq[((size_t)b * NBK + i) * 4] = ua;
-            } else if (i <= b + 1 + QROWS || b >= QFROM) {
+            if (i <= b + 1 + QROWS || b >= QFROM) {
                 for (int q = 0; q < 4; ++q)
                     idUq[((size_t)b * NBK + i) * 4 + q] = add(TASK_UQ, b, i * 4 + q, b + 1, 10.0 * (b + 1) + 2 + 1e-3 * i);
             } else {
@@ -1895,26 +1498,20 @@ static void mega_build_tasks(int nblk, int nq, int wg_per_q, std::vector<int4>& 
         // the task's fixed costs (waiting for the first operands and the tile, the stores, the hand-over: ~10 of 24 us) are
         // paid once per batch.  The task of a batch carries its LAST panel in .y and the panel count in bits 16..23 of .x;
         // the MFMAs run on the same accumulators in the same order as panel-by-panel, so the result is bit-identical.
-        if (BATCH <= 1) {
-            for (int j = b + 2; j < NBK; ++j)
-                for (int i = j; i < NBK; ++i)
-                    idU[((size_t)b * NBK + i) * NBK + j] = add(TASK_U, b, i, j, 10.0 * j + 3 + 1e-3 * i + 1e-6 * b);
-        } else {
-            for (int j = b + 2; j < NBK; ++j) {
-                // panels 0 .. j-2 of column j in batches [0, BATCH), [BATCH, 2 BATCH), ...: this panel closes a batch if it
-                // is the last of its group or the last one of the column
-                // (the last BLAG panels before the final one stay single tasks: a long batch there would sit on the path to
-                // the tile's panel solve)
-                const int lim = j - 2 - BLAG;
-                const int b0 = b > lim ? b : (b / BATCH) * BATCH, last = b > lim ? b : std::min(b0 + BATCH - 1, lim);
-                if (b != last) continue;
-                const int nb = b - b0 + 1;
-                for (int i = j; i < NBK; ++i) {
-                    const int id = add(TASK_U, b, i, j, 10.0 * j + 3 + 1e-3 * i + 1e-6 * b);
-                    nodes[(size_t)id].tk.x |= nb << 16;
-                    nodes[(size_t)id].dur = DUR[TASK_U] + (nb - 1) * DUR_K;
-                    for (int bb = b0; bb <= b; ++bb) idU[((size_t)bb * NBK + i) * NBK + j] = id;
-                }
+        for (int j = b + 2; j < NBK; ++j) {
+            // panels 0 .. j-2 of column j in batches [0, BATCH), [BATCH, 2 BATCH), ...: this panel closes a batch if it
+            // is the last of its group or the last one of the column
+            // (the last BLAG panels before the final one stay single tasks: a long batch there would sit on the path to
+            // the tile's panel solve)
+            const int lim = j - 2 - BLAG;
+            const int b0 = (BATCH <= 1 || b > lim) ? b : (b / BATCH) * BATCH, last = (BATCH <= 1 || b > lim) ? b : std::min(b0 + BATCH - 1, lim);
+            if (b != last) continue;
+            const int nb = b - b0 + 1;
+            for (int i = j; i < NBK; ++i) {
+                const int id = add(TASK_U, b, i, j, 10.0 * j + 3 + 1e-3 * i + 1e-6 * b);
+                nodes[(size_t)id].tk.x |= nb << 16;
+                nodes[(size_t)id].dur += (nb - 1) * DUR_K;
+                for (int bb = b0; bb <= b; ++bb) idU[((size_t)bb * NBK + i) * NBK + j] = id;
             }
         }
     }
@@ -1985,7 +1582,7 @@ static void mega_build_tasks(int nblk, int nq, int wg_per_q, std::vector<int4>& 
                 xdone[(size_t)j] = tv;
             }
         }
-    static const double BLW = [] { const char* e = getenv("STBA_MEGA_BLEVEL"); return e ? atof(e) : 1.0; }();
+    static const double BLW = knob_double("STBA_MEGA_BLEVEL", 1.0);
     if (BLW > 0.0) {
         // bottom level (longest path to the end of the graph) as the priority: HLFET list scheduling
         std::vector<int> indeg2(nodes.size()), topo;
@@ -2003,84 +1600,43 @@ static void mega_build_tasks(int nblk, int nq, int wg_per_q, std::vector<int4>& 
         }
         for (size_t k = 0; k < nodes.size(); ++k) nodes[k].prio = nodes[k].prio * (1.0 - BLW) * 5.0 - BLW * bl[k];
     }
-    // Event-driven list scheduling.  A ticket queue replays the model if the tickets are sorted by the time
+    // Event-driven list scheduling.  A ticket list replays the model if the tickets are sorted by the time
     // their worker became FREE (= the moment a workgroup picks its next ticket), not by the task's start:
     // a workgroup that picks a ticket early parks on it until its inputs arrive.
-    // Liveness: a ticket occupies its model worker from pick to end, so at most wg_per_q - 1 tickets that
-    // come later in the topological (start time) order can precede any ticket in its queue; with at least
-    // wg_per_q real workgroups per XCD one of them always reaches the earliest unfinished task.
-    // The model is faithful (C5: 2.55 ms predicted, 2.53-2.60 ms measured; tools/mega_trace.py prints the
-    // drift), which makes it the place to try policies -- tools/sim_sweep.py, no GPU.  Tried and rejected
-    // there AND on the machine: keeping RES[r] workers of the XCD that owns row b+1+r idle for the tasks of
-    // the critical chains (STBA_MEGA_RES=5,4,2: +2.4 % predicted, +2.3 % measured), boosting the priority
-    // of those rows, cyclic instead of LPT row ownership (+8 %).  What the model says: with 320 workers
-    // instead of 256 the makespan would be 2.36 ms, with unlimited workers 2.30 ms (the chain): the first
-    // 1.6 ms are bound by the rate of the trailing-update task (23.4 us per tile; DESIGN.md lists what was
-    // tried inside it), the rest by the chain D -> TU -> D.
+    // Liveness: a ticket occupies its model worker from pick to end, so at most W - 1 tickets that come later in the
+    // topological (start time) order can precede any ticket in its list, W = the list's model workers; with at least W
+    // real workgroups per list one of them always reaches the earliest unfinished task.
+    // The model is faithful (C5, one class: 2.55 ms predicted, 2.53-2.60 ms measured; tools/mega_trace.py prints the
+    // drift), which makes it the place to try policies -- tools/sim_sweep.py, no GPU.  Tried and rejected there AND on the
+    // machine in rounds 1-2 (and removed from the code since): workers reserved for the tasks of the critical chains,
+    // priority boosts for those rows, an urgent list per XCD claimed by whichever workgroup is free (a parked workgroup
+    // starts a critical task the moment its last flag flips; a claimed task pays 2-5 us per hand-over), the last update of
+    // a tile fused into the panel solve that consumes it.  DESIGN.md 4 has the numbers.
     typedef std::pair<double, int> PI;
     typedef std::priority_queue<PI, std::vector<PI>, std::greater<PI>> Heap;
-    int RES[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (const char* e = getenv("STBA_MEGA_RES")) {
-        for (int& r : RES) r = 0;
-        sscanf(e, "%d,%d,%d,%d,%d,%d,%d,%d", &RES[0], &RES[1], &RES[2], &RES[3], &RES[4], &RES[5], &RES[6], &RES[7]);
-    }
-    int urows = 0;
-    for (int r = 0; r < 8; ++r) if (RES[r] > 0) urows = r + 1;
-    // URGENT tasks (STBA_MEGA_HI=r, an EXPERIMENT, off by default): the diagonal blocks, the fused panel-solve + diagonal
-    // update of the next tile row, and every panel solve / trailing update that writes one of the next r tile rows get
-    // their own list per XCD, from which any free workgroup takes the first READY entry (see the kernel).  Measured on
-    // MI355X, 6000 unknowns, factorisation + substitution: in-order lists 2.74 ms; r = 1: 2.90, 2: 2.95, 3: 2.99,
-    // 4..6: 3.05, 8: 3.17, 12: 3.31.  A workgroup parked on the ticket of a critical task starts it the moment its last
-    // input flag flips and has its operands loaded by then; a dynamically claimed task pays 2-5 us per hand-over (flag
-    // round trips, the claim, the cold descriptor), four hand-overs per diagonal block.  Idle workgroups are plentiful
-    // (a third of the machine-time), so parking them costs nothing.
-    static const int HI_ROWS = [] { const char* e = getenv("STBA_MEGA_HI"); return e ? atoi(e) : 0; }();
-    auto is_urgent = [&](const int4& tk) {
-        if (HI_ROWS <= 0) return tk.x != TASK_TI && mega_task_row(tk) <= tk.y + urows;
-        if (tk.x == TASK_D || tk.x == TASK_TU) return true;
-        const int row = mega_task_row(tk);
-        return tk.x != TASK_TI && row < NBK && row <= tk.y + HI_ROWS;
-    };
-    std::vector<Heap> ready_u((size_t)nq), ready_b((size_t)nq);
-    Heap events;
-    std::vector<std::vector<double>> idle_since((size_t)nq, std::vector<double>((size_t)wg_per_q, 0.0));   // LIFO
-    std::vector<int> reserve((size_t)nq, 0);
-    int cur_b = -1;
-    auto set_step = [&](int b) {           // the chain has reached diagonal block b: move the reserve
-        cur_b = b;
-        for (int q = 0; q < nq; ++q) reserve[(size_t)q] = 0;
-        for (int r = 0; r < urows; ++r)
-            if (b + 1 + r < NBK) reserve[(size_t)rowq[(size_t)(b + 1 + r)]] += RES[r];
-    };
+    std::vector<Heap> ready_h((size_t)nl);
+    Heap events;                                // (time, node) a task ends | (time, -(node + 1)) the last remote input of a task arrives
+    std::vector<std::vector<double>> idle_since((size_t)nl, std::vector<double>((size_t)mach.wg, 0.0));   // LIFO
     double now = 0.0;
     struct Pick { double key, start; int node; };
-    std::vector<std::vector<Pick>> order((size_t)nq);
-    auto push_ready = [&](int k) {
-        Node& nd = nodes[(size_t)k];
-        (is_urgent(nd.tk) ? ready_u : ready_b)[(size_t)nd.q].push(PI(nd.prio, k));
-    };
+    std::vector<std::vector<Pick>> order((size_t)nl);
+    auto push_ready = [&](int k) { ready_h[(size_t)nodes[(size_t)k].q].push(PI(nodes[(size_t)k].prio, k)); };
     for (int k = 0; k < (int)nodes.size(); ++k)
         if (nodes[(size_t)k].indeg == 0) push_ready(k);
     double makespan = 0.0;
     std::vector<double> tiles_in((size_t)std::max(1, n_gpus), 0.0);
     for (;;) {
-        for (int q = 0; q < nq; ++q) {
-            std::vector<double>& idl = idle_since[(size_t)q];
-            for (;;) {
-                if (idl.empty()) break;
-                Heap& hu = ready_u[(size_t)q];
-                Heap& hb = ready_b[(size_t)q];
-                const bool bulk_ok = !hb.empty() && (int)idl.size() > reserve[(size_t)q];
-                int k = -1;
-                if (!hu.empty() && (HI_ROWS > 0 || !bulk_ok || hu.top().first <= hb.top().first)) { k = hu.top().second; hu.pop(); }
-                else if (bulk_ok) { k = hb.top().second; hb.pop(); }
-                else break;
+        for (int l = 0; l < nl; ++l) {
+            std::vector<double>& idl = idle_since[(size_t)l];
+            Heap& hb = ready_h[(size_t)l];
+            while (!idl.empty() && !hb.empty()) {
+                const int k = hb.top().second;
+                hb.pop();
                 Node& nd = nodes[(size_t)k];
-                order[(size_t)q].push_back({idl.back(), now, k});
+                order[(size_t)l].push_back({idl.back(), now, k});
                 idl.pop_back();
                 nd.start = now;
                 events.push(PI(now + nd.dur, k));
-                if (nd.tk.x == TASK_D && nd.tk.y > cur_b) set_step(nd.tk.y);
             }
         }
         if (events.empty()) break;
@@ -2116,7 +1672,7 @@ static void mega_build_tasks(int nblk, int nq, int wg_per_q, std::vector<int4>& 
     }
     if (makespan_out) *makespan_out = makespan;
     if (shard) shard->tiles_in_max = *std::max_element(tiles_in.begin(), tiles_in.end());
-    if (getenv("STBA_MEGA_SIMDBG")) {
+    if (knob_str("STBA_MEGA_SIMDBG")) {
         static const char* NM[6] = {"D", "T", "TI", "U", "Uq", "TU"};
         for (int b = 0; b + 1 < NBK; ++b) {
             const Node& d0 = nodes[(size_t)idD[(size_t)b]];
@@ -2135,42 +1691,27 @@ static void mega_build_tasks(int nblk, int nq, int wg_per_q, std::vector<int4>& 
         }
     }
     out.clear();
-    for (int q = 0; q < nq; ++q) {
-        std::stable_sort(order[(size_t)q].begin(), order[(size_t)q].end(), [](const Pick& x, const Pick& y) {
+    for (int l = 0; l < nl; ++l) {
+        std::stable_sort(order[(size_t)l].begin(), order[(size_t)l].end(), [](const Pick& x, const Pick& y) {
             return x.key != y.key ? x.key < y.key : x.start < y.start;
         });
-        qstart[q] = (int)out.size();
-        // bit 8 of the type word: the task's output can be an input of an urgent task (see the kernel's polling)
-        auto emit = [&](const Pick& pk) {
-            int4 tk = nodes[(size_t)pk.node].tk;
-            const int row = mega_task_row(tk);
-            if (HI_ROWS > 0 && (is_urgent(tk) || (tk.x != TASK_TI && row < NBK && row <= tk.y + HI_ROWS + 1))) tk.x |= 0x100;
-            out.push_back(tk);
+        lstart[l] = (int)out.size();
+        for (const Pick& pk : order[(size_t)l]) {
+            out.push_back(nodes[(size_t)pk.node].tk);
             if (sim_start) sim_start->push_back((float)pk.start);
-        };
-        for (const Pick& pk : order[(size_t)q]) {
-            if (nodes[(size_t)pk.node].noemit) continue;
-            if (HI_ROWS > 0 && is_urgent(nodes[(size_t)pk.node].tk)) continue;
-            emit(pk);
-        }
-        // the urgent list, by simulated start (a topological order: a task starts after its inputs have ended)
-        hstart[q] = (int)out.size();
-        if (HI_ROWS > 0) {
-            std::vector<Pick> hi;
-            for (const Pick& pk : order[(size_t)q]) if (!nodes[(size_t)pk.node].noemit && is_urgent(nodes[(size_t)pk.node].tk)) hi.push_back(pk);
-            std::stable_sort(hi.begin(), hi.end(), [](const Pick& x, const Pick& y) { return x.start < y.start; });
-            for (const Pick& pk : hi) emit(pk);
         }
     }
-    qstart[nq] = (int)out.size();
+    lstart[nl] = (int)out.size();
 }
 
 // diagnostics (tools/sim_sweep.py): the simulated makespan of the task graph, no GPU involved
 double chol_schedule_makespan(int nblk, int nq, int wg_per_q) {
     std::vector<int4> tasks;
-    int qstart[17], hstart[16];
+    std::vector<int> lstart((size_t)nq + 1);
     double ms = 0.0;
-    mega_build_tasks(nblk, nq, wg_per_q, tasks, qstart, hstart, nullptr, &ms);
+    MegaMachine m;
+    m.nq = nq; m.wg = wg_per_q;
+    mega_build_tasks(nblk, m, tasks, lstart.data(), nullptr, &ms);
     return ms;
 }
 
@@ -2179,11 +1720,13 @@ double chol_schedule_makespan(int nblk, int nq, int wg_per_q) {
 // busiest GPU}
 void chol_shard_model(int nblk, int n_gpus, int n_xcd, int wg_per_q, int rows_per_group, double hop_us, double tile_us, double* out3) {
     std::vector<int4> tasks;
-    std::vector<int> qstart((size_t)n_gpus * n_xcd + 1), hstart((size_t)n_gpus * n_xcd);
+    std::vector<int> lstart((size_t)n_gpus * n_xcd + 1);
     MegaShardModel sh;
     sh.n_gpus = n_gpus; sh.rows_per_group = rows_per_group; sh.hop_us = hop_us; sh.tile_us = tile_us;
     double ms = 0.0;
-    mega_build_tasks(nblk, n_gpus * n_xcd, wg_per_q, tasks, qstart.data(), hstart.data(), nullptr, &ms, 0, &sh);
+    MegaMachine m;
+    m.nq = n_gpus * n_xcd; m.wg = wg_per_q;
+    mega_build_tasks(nblk, m, tasks, lstart.data(), nullptr, &ms, 0, &sh);
     out3[0] = ms; out3[1] = sh.cross_edges; out3[2] = sh.tiles_in_max;
 }
 
@@ -2330,11 +1873,86 @@ __global__ __launch_bounds__(1024) void chol_bwd_wide_solve_kernel(const double*
 }
 
 // ------------------------------------------------------------------------------------------
+// Per-device state shared by every engine of the process.  Two persistent kernels must not share the device: each needs
+// its workgroups resident at the same time (four of one XCD for the TU quarters), and with the CUs split unevenly between
+// two of them each can starve the other on a different XCD.  Factorisations of one process are therefore chained on the
+// device, stream to stream, through an event; the host does not wait.  (Another PROCESS on the same device is what the
+// time-out and the stage-kernel fallback are for.)
+struct MegaDevice {
+    std::mutex m;
+    bool probed = false;
+    int ncu = 0, nq = 0;                // CUs of the device, XCDs seen by the probe
+    signed char xcc_queue[16];
+    hipEvent_t last = nullptr;
+    int cooldown = 0;                   // factorisations that take the stage kernels after a time-out of the persistent program
+};
+static MegaDevice& mega_device(int dev) {
+    static std::mutex mm;
+    static std::map<int, MegaDevice> devs;
+    std::lock_guard<std::mutex> g(mm);
+    return devs[dev];
+}
+
+// once per device: which XCDs do the workgroups of a ncu-wide launch land on?
+static int mega_device_init(MegaDevice& D, hipStream_t st) {
+    if (D.probed) return STBA_OK;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    STBA_HIP(hipGetDevice(&dev));
+    STBA_HIP(hipGetDeviceProperties(&prop, dev));
+    D.ncu = prop.multiProcessorCount;
+    int* probe = nullptr;
+    std::vector<int> h((size_t)D.ncu);
+    STBA_HIP(hipMalloc(reinterpret_cast<void**>(&probe), h.size() * sizeof(int)));
+    hipLaunchKernelGGL(xcc_probe_kernel, dim3(D.ncu), dim3(512), 0, st, probe);
+    hipError_t e = hipMemcpyAsync(h.data(), probe, h.size() * sizeof(int), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(probe);
+    STBA_HIP(e);
+    for (int i = 0; i < 16; ++i) D.xcc_queue[i] = -1;
+    int per_xcc[16] = {0};
+    D.nq = 0;
+    for (int x : h) {
+        if (D.xcc_queue[x & 15] < 0) D.xcc_queue[x & 15] = (signed char)D.nq++;
+        per_xcc[x & 15]++;
+    }
+    for (int i = 0; i < 16; ++i)
+        if (D.xcc_queue[i] >= 0 && per_xcc[i] < 4)
+            return fail(STBA_ERR_HIP, "chol: fewer than 4 workgroups per XCD (the TU tasks need 4)");
+    STBA_HIP(hipEventCreateWithFlags(&D.last, hipEventDisableTiming));
+    D.probed = true;
+    return STBA_OK;
+}
+
+static std::atomic<int> g_timeouts{0};
+static std::atomic<long long> g_spin_override{0};     // ticks of the 100 MHz clock; 0: automatic
+void chol_set_spin_limit_us(double us) { g_spin_override.store(us > 0.0 ? std::max(1LL, (long long)(us * 100.0)) : 0LL); }
+void chol_note_timeout() {
+    g_timeouts.fetch_add(1);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return;
+    MegaDevice& D = mega_device(dev);
+    std::lock_guard<std::mutex> g(D.m);
+    D.cooldown = 64;
+}
+int chol_timeout_count() { return g_timeouts.load(); }
+
+// which schedule a factorisation runs through
+enum { CHOL_PERSISTENT = 0, CHOL_STAGES = 1 };
+
 static int chol_run(double* A, int lda, int n, double* x_dev, int* flag_dev, hipStream_t st, CholProfile* prof,
-                    hipEvent_t mid_event = nullptr) {
-    static const bool MEGA_CHECK = [] { const char* e = getenv("STBA_MEGA_CHECK"); return e && atoi(e) != 0; }();
+                    hipEvent_t mid_event = nullptr, int schedule = CHOL_PERSISTENT) {
     if (lda % NB != 0 || lda < n + 1) return fail(STBA_ERR_INVALID_ARGUMENT, "chol: bad padded dimension");
     const int nblk = lda / NB;
+    int cur_dev = 0;
+    STBA_HIP(hipGetDevice(&cur_dev));
+    if (!prof && schedule == CHOL_PERSISTENT) {
+        // after a time-out (chol_note_timeout) the device is taken to be shared: the next factorisations do not try again
+        MegaDevice& D = mega_device(cur_dev);
+        std::lock_guard<std::mutex> g(D.m);
+        if (D.cooldown > 0) { --D.cooldown; schedule = CHOL_STAGES; }
+    }
+    const bool stages = prof != nullptr || schedule == CHOL_STAGES;
     // per diagonal block: its inverse transpose (written by the panel solve, read by the backward pass)
     // followed by the inverses of its eight 16x16 diagonal tiles (written by the diagonal kernel, read
     // by the panel solve)
@@ -2342,16 +1960,14 @@ static int chol_run(double* A, int lda, int n, double* x_dev, int* flag_dev, hip
     // workspace and task plan are per (host thread, device): a thread that switches devices, or a second GPU in
     // the same process, must not reuse another device's pointers or XCD probe
     struct MegaPlan {
-        int nblk = 0, nwide = -1, ntasks = 0, nq = 0, ncu = 0;
-        int qstart[17] = {0}, hstart[16] = {0};
-        signed char xcc_queue[16];
+        int nblk = 0, nwide = -1, ntasks = 0;
+        int lstart[MEGA_MAX_Q + 1] = {0};
         int4* tasks = nullptr; int* sync = nullptr; size_t sync_ints = 0;
+        double makespan_us = 0.0;
         std::vector<float> sim_start;     // simulated start time of every task (written to the trace file)
     };
     struct DevWs { double* linv = nullptr; int linv_blocks = 0; double* vbuf = nullptr; int vbuf_blocks = 0; MegaPlan plan; };
     static thread_local std::map<int, DevWs> ws_by_dev;
-    int cur_dev = 0;
-    STBA_HIP(hipGetDevice(&cur_dev));
     DevWs& ws = ws_by_dev[cur_dev];
     double*& linv = ws.linv;
     int& linv_blocks = ws.linv_blocks;
@@ -2363,8 +1979,7 @@ static int chol_run(double* A, int lda, int n, double* x_dev, int* flag_dev, hip
     }
     // wide (4-panel) inverse blocks for the backward substitution: every panel but the last 1..4 (the tail keeps
     // single-panel steps, so that no inverse-block task runs behind the last diagonal block)
-    static const bool WIDE = [] { const char* e = getenv("STBA_BWD_WIDE"); return !e || atoi(e) != 0; }();
-    const int nwide = (WIDE && !prof) ? (nblk - 1) / 4 : 0;
+    const int nwide = stages ? 0 : (nblk - 1) / 4;
     if (ws.vbuf_blocks < nwide) {
         if (ws.vbuf) (void)hipFree(ws.vbuf);
         ws.vbuf = nullptr; ws.vbuf_blocks = 0;
@@ -2372,9 +1987,14 @@ static int chol_run(double* A, int lda, int n, double* x_dev, int* flag_dev, hip
         ws.vbuf_blocks = nwide;
     }
     // panel of block b: diagonal kernel + panel solve of the (nblk - b - 1) * 8 row groups below it
+    static DeviceOnce diag_attr;
+    STBA_TRY(diag_attr.run([]() -> int {
+        STBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(chol_diag_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Diag2Smem)));
+        return STBA_OK;
+    }));
     auto launch_panel_diag = [&](int b, hipStream_t s_) {
         double* li = linv + (size_t)b * LINV_STRIDE;
-        hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(512), 0, s_, A, lda, b * NB, n, flag_dev, li + NB * NB);
+        hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(512), sizeof(Diag2Smem), s_, A, lda, b * NB, n, flag_dev, li + NB * NB);
     };
     auto launch_panel_trsm = [&](int b, hipStream_t s_) {
         double* li = linv + (size_t)b * LINV_STRIDE;
@@ -2389,8 +2009,10 @@ static int chol_run(double* A, int lda, int n, double* x_dev, int* flag_dev, hip
     }
     auto mark = [&](size_t k) -> int { if (prof) STBA_HIP(hipEventRecord(ev[k], st)); return STBA_OK; };
     STBA_HIP(hipMemsetAsync(flag_dev, 0, sizeof(int), st));
-    if (prof) {
-        // serial schedule: one kernel class at a time, so the per-class event times are clean
+    if (stages) {
+        // STAGE KERNELS: one kernel per stage and panel, in order on the caller's stream.  The diagnostic schedule of
+        // stba_cholesky_profile (per-class event times) and the FALLBACK of the persistent program: it needs nothing
+        // resident, so it always finishes, whoever else uses the device (see chol_factor_solve_robust).
         for (int b = 0; b < nblk; ++b) {
             const int k0 = b * NB;
             const int mt = nblk - b - 1;
@@ -2401,7 +2023,7 @@ static int chol_run(double* A, int lda, int n, double* x_dev, int* flag_dev, hip
             STBA_TRY(mark(4 * (size_t)b + 2));
             if (mt > 0) launch_syrk(A, lda, k0, 0, mt * (mt + 1) / 2, st);
             STBA_TRY(mark(4 * (size_t)b + 3));
-            if (mt > 0) {
+            if (mt > 0 && prof) {
                 const double m = std::max(0, n - (k0 + NB));
                 prof->syrk_flops += m * (m + 1.0) * NB;
                 prof->syrk_flops_padded += (double)(mt * (mt + 1) / 2) * 2.0 * NB * NB * NB;
@@ -2409,41 +2031,23 @@ static int chol_run(double* A, int lda, int n, double* x_dev, int* flag_dev, hip
             }
         }
     } else {
-        // production: one persistent kernel (see chol_mega_kernel)
+        // production: the persistent dataflow program (see chol_mega_kernel)
+        MegaDevice& D = mega_device(cur_dev);
+        std::lock_guard<std::mutex> dev_lock(D.m);
+        STBA_TRY(mega_device_init(D, st));
         MegaPlan& plan = ws.plan;
         if (plan.nblk != nblk || plan.nwide != nwide) {
             if (plan.tasks) (void)hipFree(plan.tasks);
             if (plan.sync) (void)hipFree(plan.sync);
             plan = MegaPlan();
-            int dev = 0;
-            hipDeviceProp_t prop;
-            STBA_HIP(hipGetDevice(&dev));
-            STBA_HIP(hipGetDeviceProperties(&prop, dev));
-            plan.ncu = prop.multiProcessorCount;
-            // which XCDs do the workgroups of a ncu-wide launch land on?
-            {
-                int* probe = nullptr;
-                std::vector<int> h((size_t)plan.ncu);
-                STBA_HIP(hipMalloc(reinterpret_cast<void**>(&probe), h.size() * sizeof(int)));
-                hipLaunchKernelGGL(xcc_probe_kernel, dim3(plan.ncu), dim3(512), 0, st, probe);
-                STBA_HIP(hipMemcpyAsync(h.data(), probe, h.size() * sizeof(int), hipMemcpyDeviceToHost, st));
-                STBA_HIP(hipStreamSynchronize(st));
-                (void)hipFree(probe);
-                for (int i = 0; i < 16; ++i) plan.xcc_queue[i] = -1;
-                int per_xcc[16] = {0};
-                for (int x : h) {
-                    if (plan.xcc_queue[x & 15] < 0) plan.xcc_queue[x & 15] = (signed char)plan.nq++;
-                    per_xcc[x & 15]++;
-                }
-                for (int i = 0; i < 16; ++i)
-                    if (plan.xcc_queue[i] >= 0 && per_xcc[i] < 4)
-                        return fail(STBA_ERR_HIP, "chol: fewer than 4 workgroups per XCD (the TU tasks need 4)");
-            }
+            MegaMachine mach;
+            mach.nq = D.nq;
+            mach.wg = std::max(4, D.ncu / D.nq);
             std::vector<int4> tasks;
-            mega_build_tasks(nblk, plan.nq, std::max(4, plan.ncu / plan.nq), tasks, plan.qstart, plan.hstart, &plan.sim_start, nullptr, nwide);
+            mega_build_tasks(nblk, mach, tasks, plan.lstart, &plan.sim_start, &plan.makespan_us, nwide);
             STBA_HIP(hipMalloc(reinterpret_cast<void**>(&plan.tasks), tasks.size() * sizeof(int4)));
             STBA_HIP(hipMemcpy(plan.tasks, tasks.data(), tasks.size() * sizeof(int4), hipMemcpyHostToDevice));
-            plan.sync_ints = MEGA_SYNC_HDR + 2 * (size_t)nblk + 2 * (size_t)nblk * (nblk + 4 * nwide) + tasks.size();
+            plan.sync_ints = MEGA_SYNC_HDR + 2 * (size_t)nblk + 2 * (size_t)nblk * (nblk + 4 * nwide);
             STBA_HIP(hipMalloc(reinterpret_cast<void**>(&plan.sync), plan.sync_ints * sizeof(int)));
             plan.ntasks = (int)tasks.size();
             plan.nblk = nblk; plan.nwide = nwide;
@@ -2451,15 +2055,17 @@ static int chol_run(double* A, int lda, int n, double* x_dev, int* flag_dev, hip
         STBA_HIP(hipMemsetAsync(plan.sync, 0, plan.sync_ints * sizeof(int), st));
         MegaArgs ma;
         ma.A = A; ma.lda = lda; ma.n = n; ma.nblk = nblk;
-        ma.tasks = plan.tasks; ma.nq = plan.nq; ma.sync = plan.sync;
-        memcpy(ma.qstart, plan.qstart, sizeof ma.qstart);
-        memcpy(ma.hstart, plan.hstart, sizeof ma.hstart);
-        memcpy(ma.xcc_queue, plan.xcc_queue, sizeof ma.xcc_queue);
+        ma.tasks = plan.tasks; ma.nq = D.nq; ma.sync = plan.sync;
+        memcpy(ma.lstart, plan.lstart, sizeof ma.lstart);
+        memcpy(ma.xcc_queue, D.xcc_queue, sizeof ma.xcc_queue);
         ma.linv = linv; ma.linv_stride = LINV_STRIDE; ma.flag = flag_dev;
         ma.vbuf = ws.vbuf; ma.nwide = nwide;
-        static const int PREDRAW = [] { const char* e = getenv("STBA_MEGA_PREDRAW"); return e ? atoi(e) : 2; }();
-        ma.predraw_nb = PREDRAW;
-        static const char* TRACE = getenv("STBA_MEGA_TRACE");
+        // a dependency that has not arrived after many times the predicted makespan never will: some workgroup of the
+        // program is not resident (another process holds the CUs).  The host then takes the stage kernels.
+        // (100 ms at least: 40 x the 2.4 ms of the C5 system; chol_set_spin_limit_us overrides it -- tests provoke the fallback)
+        ma.spin_limit = (long long)std::max(100e3, 40.0 * plan.makespan_us) * 100LL;
+        if (g_spin_override.load() > 0) ma.spin_limit = g_spin_override.load();
+        static const char* TRACE = knob_str("STBA_MEGA_TRACE");
         ma.trace = nullptr;
         if (TRACE) STBA_HIP(hipMalloc(reinterpret_cast<void**>(&ma.trace), (size_t)plan.ntasks * 8 * sizeof(long long)));
         struct TraceGuard { long long*& p; ~TraceGuard() { if (p) { (void)hipFree(p); p = nullptr; } } } trace_guard{ma.trace};
@@ -2469,22 +2075,9 @@ static int chol_run(double* A, int lda, int n, double* x_dev, int* flag_dev, hip
                                          hipFuncAttributeMaxDynamicSharedMemorySize, MEGA_SMEM_BYTES));
             return STBA_OK;
         }));
-        // Two persistent kernels must not share the device: each needs four workgroups of one XCD at the same time (the
-        // TU tasks), and with the CUs split unevenly between two of them each can starve the other on a different XCD
-        // (seen as a dependency time-out with two engines driven from two threads).  Factorisations of one process are
-        // therefore chained on the device, stream to stream, through an event; the host does not wait.
-        {
-            struct Chain { std::mutex m; hipEvent_t last = nullptr; };
-            static std::mutex chains_m;
-            static std::map<int, Chain> chains;
-            Chain* ch;
-            { std::lock_guard<std::mutex> g(chains_m); ch = &chains[cur_dev]; }
-            std::lock_guard<std::mutex> g(ch->m);
-            if (!ch->last) STBA_HIP(hipEventCreateWithFlags(&ch->last, hipEventDisableTiming));
-            else STBA_HIP(hipStreamWaitEvent(st, ch->last, 0));
-            hipLaunchKernelGGL(chol_mega_kernel, dim3(plan.ncu), dim3(512), MEGA_SMEM_BYTES, st, ma);
-            STBA_HIP(hipEventRecord(ch->last, st));
-        }
+        STBA_HIP(hipStreamWaitEvent(st, D.last, 0));
+        hipLaunchKernelGGL(chol_mega_kernel, dim3(D.ncu), dim3(512), MEGA_SMEM_BYTES, st, ma);
+        STBA_HIP(hipEventRecord(D.last, st));
         if (TRACE) {    // debugging aid: dump the task timeline of this factorisation (tools/mega_trace.py)
             std::vector<long long> h((size_t)plan.ntasks * 8);
             std::vector<int4> ht((size_t)plan.ntasks);
@@ -2498,12 +2091,6 @@ static int chol_run(double* A, int lda, int n, double* x_dev, int* flag_dev, hip
                 fwrite(plan.sim_start.data(), sizeof(float), plan.sim_start.size(), f);
                 fclose(f);
             }
-        }
-        if (MEGA_CHECK) {
-            int h = 0;
-            STBA_HIP(hipMemcpyAsync(&h, plan.sync + 16, sizeof h, hipMemcpyDeviceToHost, st));
-            STBA_HIP(hipStreamSynchronize(st));
-            if (h != 0) return fail(STBA_ERR_HIP, "chol: persistent kernel timed out waiting for a dependency");
         }
     }
     STBA_TRY(mark((size_t)nblk * 4));
@@ -2544,6 +2131,10 @@ int chol_factor_solve_dev(double* A, int lda, int n, double* x_dev, int* flag_de
     return chol_run(A, lda, n, x_dev, flag_dev, st, nullptr);
 }
 
+int chol_factor_solve_stages(double* A, int lda, int n, double* x_dev, int* flag_dev, hipStream_t st) {
+    return chol_run(A, lda, n, x_dev, flag_dev, st, nullptr, nullptr, CHOL_STAGES);
+}
+
 int chol_factor_solve_split(double* A, int lda, int n, double* x_dev, int* flag_dev, hipStream_t st, hipEvent_t mid_event) {
     return chol_run(A, lda, n, x_dev, flag_dev, st, nullptr, mid_event);
 }
@@ -2552,5 +2143,6 @@ int chol_factor_solve_profiled(double* A, int lda, int n, double* x_dev, int* fl
                                CholProfile* prof) {
     return chol_run(A, lda, n, x_dev, flag_dev, st, prof);
 }
+
 
 }  // namespace stba

@@ -472,7 +472,7 @@ static int ba_run_lm(stba_ba* b, const stba_lm_options* opt_in, int fixed_iterat
     bool pending = false, pending_accepted = false;
     int pending_iter = 0, pending_lin_ev = 8, spec_ev = 13;
 
-    int iter = 0;
+    int iter = 0, chol_timeouts = 0;
     s.termination_type = STBA_NO_CONVERGENCE;
     s.termination_reason = STBA_TERM_MAX_ITER;
     bool first = true;
@@ -553,7 +553,6 @@ static int ba_run_lm(stba_ba* b, const stba_lm_options* opt_in, int fixed_iterat
             STBA_TRY(download(&flag_h, b->flag, 1, b->st));
             STBA_HIP(hipStreamSynchronize(b->st));
         }
-        STBA_TRY(chol_flag_status(flag_h));          // (only valid after the synchronisation: the copy is asynchronous)
         if (pending) {
             double c2, g2;
             ba_finish_linear_scalars(b, &c2, &g2);
@@ -569,6 +568,22 @@ static int ba_run_lm(stba_ba* b, const stba_lm_options* opt_in, int fixed_iterat
                 s.termination_type = STBA_CONVERGENCE; s.termination_reason = STBA_TERM_GRADIENT;
                 break;
             }
+        }
+        if (flag_h == CHOL_FLAG_TIMEOUT) {
+            // The persistent factorisation gave up waiting for a dependency: some of its workgroups were not resident (the
+            // device is shared with another process).  S is half factored; it is rebuilt from the blocks -- the engine owns
+            // them -- and this iteration runs again, the factorisation through the stage kernels, which need nothing
+            // resident (chol_note_timeout: so do the next ones on this device).
+            chol_note_timeout();
+            if (++chol_timeouts > 3) return fail(STBA_ERR_HIP, "dense Cholesky: the persistent program timed out repeatedly");
+            if (speculated) {       // (the speculative linearisation overwrote the current point's residuals, Jacobians and blocks)
+                STBA_TRY(ba_linearize(b, b->cur, b->trial + TS_COST2));
+                STBA_TRY(ba_normal_blocks(b));
+                STBA_TRY(ba_fill_scalar_slots(b, b->trial + TS_COST2));
+            }
+            need_build = true;
+            --iter;
+            continue;
         }
         if (lin_timing_pending) { (void)hipEventElapsedTime(&ms, ev[0], ev[1]); s.ms_linearize += ms; lin_timing_pending = false; }
         (void)hipEventElapsedTime(&ms, ev[2], ev[3]); s.ms_schur += ms;
@@ -1255,6 +1270,23 @@ struct DenseWs {
         if (host_rhs) STBA_TRY(upload(rhs, host_rhs, (size_t)n, st));
         return chol_prepare_padding_dev(A, lda, n, rhs, st);
     }
+    // factor + solve of the system the host holds; synchronises the stream and hands back the pivot flag.  If the persistent
+    // program gives up (CHOL_FLAG_TIMEOUT: not all of its workgroups were resident, the device is shared with another
+    // process), the matrix is loaded again and the stage kernels -- which need nothing resident -- do the same job.
+    int load_factor_solve(const double* hostA, const double* host_rhs, int* flag_h) {
+        STBA_TRY(load(hostA, host_rhs));
+        STBA_TRY(chol_factor_solve_dev(A, lda, n, x, flag, st));
+        STBA_TRY(download(flag_h, flag, 1, st));
+        STBA_HIP(hipStreamSynchronize(st));
+        if (*flag_h == CHOL_FLAG_TIMEOUT) {
+            chol_note_timeout();
+            STBA_TRY(load(hostA, host_rhs));
+            STBA_TRY(chol_factor_solve_stages(A, lda, n, x, flag, st));
+            STBA_TRY(download(flag_h, flag, 1, st));
+            STBA_HIP(hipStreamSynchronize(st));
+        }
+        return STBA_OK;
+    }
 };
 
 int stba_cholesky_factor(double* A, int n, void* hip_stream) {
@@ -1262,10 +1294,8 @@ int stba_cholesky_factor(double* A, int n, void* hip_stream) {
     STBA_TRY(require_device());
     DenseWs w;
     STBA_TRY(w.init(n, hip_stream));
-    STBA_TRY(w.load(A, nullptr));
-    STBA_TRY(chol_factor_solve_dev(w.A, w.lda, n, w.x, w.flag, w.st));
     int flag_h = 0;
-    STBA_TRY(download(&flag_h, w.flag, 1, w.st));
+    STBA_TRY(w.load_factor_solve(A, nullptr, &flag_h));
     STBA_HIP(hipMemcpy2DAsync(A, (size_t)n * sizeof(double), w.A, (size_t)w.lda * sizeof(double),
                               (size_t)n * sizeof(double), (size_t)n, hipMemcpyDeviceToHost, w.st));
     STBA_HIP(hipStreamSynchronize(w.st));
@@ -1279,10 +1309,8 @@ int stba_cholesky_solve(const double* A, int n, double* bvec, void* hip_stream) 
     STBA_TRY(require_device());
     DenseWs w;
     STBA_TRY(w.init(n, hip_stream));
-    STBA_TRY(w.load(A, bvec));
-    STBA_TRY(chol_factor_solve_dev(w.A, w.lda, n, w.x, w.flag, w.st));
     int flag_h = 0;
-    STBA_TRY(download(&flag_h, w.flag, 1, w.st));
+    STBA_TRY(w.load_factor_solve(A, bvec, &flag_h));
     STBA_TRY(download(bvec, w.x, (size_t)n, w.st));
     STBA_HIP(hipStreamSynchronize(w.st));
     STBA_TRY(chol_flag_status(flag_h));
@@ -1334,6 +1362,13 @@ int stba_cholesky_schedule_model(int n, int n_xcd, int wg_per_xcd, double* makes
     if (n <= 0 || n_xcd <= 0 || n_xcd > 16 || wg_per_xcd < 4 || !makespan_us) return fail(STBA_ERR_INVALID_ARGUMENT, "bad argument");
     const int lda = ((n + 1 + 127) / 128) * 128;      // the padded system carries the right-hand side as one more row
     *makespan_us = chol_schedule_makespan(lda / 128, n_xcd, wg_per_xcd);
+    return STBA_OK;
+}
+
+int stba_cholesky_timeout_count(void) { return chol_timeout_count(); }
+int stba_cholesky_set_timeout_us(double us) {
+    if (!(us >= 0.0)) return fail(STBA_ERR_INVALID_ARGUMENT, "bad argument");
+    chol_set_spin_limit_us(us);
     return STBA_OK;
 }
 
@@ -1568,10 +1603,9 @@ int stba_dense_solve(stba_residual_fn fn, stba_plus_fn plus, void* user, int n_p
             Hd[(size_t)a * n + a] += dvec[a];
             dx[a] = -g[a];
         }
-        STBA_TRY(w.load(Hd.data(), dx.data()));
-        STBA_TRY(chol_factor_solve_dev(w.A, w.lda, n, w.x, w.flag, w.st));
         int flag_h = 0;
-        STBA_TRY(download(&flag_h, w.flag, 1, w.st)); STBA_TRY(download(dx.data(), w.x, (size_t)n, w.st));
+        STBA_TRY(w.load_factor_solve(Hd.data(), dx.data(), &flag_h));
+        STBA_TRY(download(dx.data(), w.x, (size_t)n, w.st));
         STBA_HIP(hipStreamSynchronize(w.st));
         STBA_TRY(chol_flag_status(flag_h));
         bool ok = (flag_h == 0);

@@ -174,7 +174,7 @@ def test_reference_triangulation_call_site_on_gpu(exe, tmp_path, scenes, O):
     not parameter blocks; AutoDiffCostFunction<Triangulation, 2, 3> per observation, sim_data.h:165-194, residual
     feature - proj).  The restated call site runs at the reference's size (29 cameras, 600 landmarks) through the
     generic callback path of the shim; the landmarks must equal the bulk kernel's (stba_ba_triangulate, one landmark
-    per lane) and the oracle's to 1e-6 (same minimiser, different stopping rules).  The wall time of the 600 tiny
+    per lane) and the oracle's up to the stopping rule, and the oracle's dense LM on the same 600 problems tightly.  The wall time of the 600 tiny
     solves is printed next to the bulk kernel's: INTEGRATION.md 2 quotes the ratio."""
     import time
     st = importlib.import_module("slam-tricks_amd")
@@ -195,12 +195,49 @@ def test_reference_triangulation_call_site_on_gpu(exe, tmp_path, scenes, O):
     e.triangulate()
     _, pts_bulk = e.get_params()
     t_bulk = time.perf_counter() - t0
+    seen = np.zeros(len(pts), bool); seen[s["obs_pt"]] = True
+    assert np.array_equal(pts[~seen], s["pts0"][~seen])
+    # (a) the same 600 problems through the oracle's dense LM with the same (default) options: the same iterates, tightly
+    cams = s["cams0"]
+
+    def rot(q):
+        x, y, z, w = q
+        return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                         [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                         [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+    Rs = np.stack([rot(c[:4]) for c in cams])
+    order = np.argsort(s["obs_pt"], kind="stable")
+    starts = np.searchsorted(s["obs_pt"][order], np.arange(len(pts) + 1))
+    worst, cost_shim, cost_bulk = 0.0, 0.0, 0.0
+
+    def make(j):
+        k = order[starts[j]:starts[j + 1]]
+        Rk, tk, fk = Rs[s["obs_cam"][k]], cams[s["obs_cam"][k], 4:], s["obs_feat"][k]
+
+        def res(p):
+            pc = np.einsum("kji,kj->ki", Rk, p[None, :] - tk)               # R^T (p - t)
+            iz = 1.0 / pc[:, 2]
+            r = (fk - pc[:, :2] * iz[:, None]).reshape(-1)                   # feature - proj (sim_data.h:191)
+            A = np.zeros((len(k), 2, 3))
+            A[:, 0, 0] = iz; A[:, 0, 2] = -pc[:, 0] * iz * iz; A[:, 1, 1] = iz; A[:, 1, 2] = -pc[:, 1] * iz * iz
+            J = -np.einsum("kab,kcb->kac", A, Rk).reshape(-1, 3)             # -A R^T
+            return r, J
+        return res, 2 * len(k)
+    for j in np.nonzero(seen)[0]:
+        res, nres = make(j)
+        po, so, _ = O.dense_lm(res, s["pts0"][j], nres)
+        worst = max(worst, float(np.abs(po - pts[j]).max()))
+        cost_shim += 0.5 * float(np.sum(res(pts[j])[0] ** 2))
+        cost_bulk += 0.5 * float(np.sum(res(pts_bulk[j])[0] ** 2))
+    assert worst < 1e-8, worst
+    # (b) against the bulk kernel and the oracle's triangulation, which iterate further than Ceres' default function
+    # tolerance 1e-6 lets the call site go: same minimiser (weakly observed depths move by ~1e-4 on a 10 m scene between the
+    # two stopping rules), the summed cost of the call site's landmarks within 1e-5 relative above the bulk result's
     o = O.BA(s["cams0"], s["pts0"], s["obs_cam"], s["obs_pt"], s["obs_feat"], s["cam_fixed"])
     o.triangulate()
-    seen = np.zeros(len(pts), bool); seen[s["obs_pt"]] = True
-    assert np.abs(pts[seen] - pts_bulk[seen]).max() < 1e-6
-    assert np.abs(pts[seen] - o.pts[seen]).max() < 1e-6
-    assert np.array_equal(pts[~seen], s["pts0"][~seen])
+    assert np.abs(pts_bulk[seen] - o.pts[seen]).max() < 1e-6
+    assert np.abs(pts[seen] - pts_bulk[seen]).max() < 2e-3
+    assert cost_bulk <= cost_shim * (1 + 1e-12) and cost_shim - cost_bulk <= 1e-5 * max(cost_bulk, 1e-30) + 1e-12, (cost_shim, cost_bulk)
     print(f"triangulation call site: {n_prob} per-landmark Solve() calls {secs * 1e3:.1f} ms "
           f"({secs / n_prob * 1e6:.0f} us each), bulk stba_ba_triangulate {t_bulk * 1e3:.2f} ms incl. read-back: ratio {secs / t_bulk:.0f}x")
 

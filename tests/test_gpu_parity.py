@@ -477,3 +477,66 @@ def test_edge_cases(st, O):
     e = st.BAEngine(cams, pts + 0.01, oc, op, feat, cam_fixed=np.ones((3, 6), np.uint8))
     summ, _ = e.solve()
     assert summ.num_iterations == so.num_iterations and abs(summ.final_cost - so.final_cost) < 1e-15
+
+
+# ------------------------------------------------------------------------------- persistent program: time-out and fallback
+def test_cholesky_falls_back_to_the_stage_kernels_on_a_timeout(st, O, scenes):
+    """The persistent factorisation needs its workgroups resident at the same time; on a device it does not own a
+    dependency may never arrive.  A workgroup then gives up after a bounded wait, the host REBUILDS the matrix and the
+    stage kernels (one launch per stage and panel, nothing resident) finish the job.  Provoked here with a wait bound of
+    10 ns: the result is the right one, the count goes up, and the LM loop survives it too."""
+    n = 1500
+    rng = np.random.default_rng(11)
+    A = rng.normal(size=(n, n)); A = A @ A.T + n * np.eye(n)
+    b = rng.normal(size=n)
+    before = st.cholesky_timeout_count()
+    st.cholesky_set_timeout_us(0.01)
+    try:
+        x = st.cholesky_solve(A, b)
+        L = st.cholesky_factor(A)
+        s = scenes.st20_scene(n_cams=40, n_pts=800, seed=9, pos_noise=0.1, ang_noise_deg=1.0, pix_noise=1e-3)
+        e, o = engine(st, s), oracle(O, s)
+        summ, tr = e.solve()
+    finally:
+        st.cholesky_set_timeout_us(0.0)
+    assert st.cholesky_timeout_count() > before
+    assert np.allclose(x, np.linalg.solve(A, b), rtol=1e-9, atol=1e-11)
+    assert np.allclose(L, np.linalg.cholesky(A), rtol=1e-10, atol=1e-10)
+    so, tro = o.solve()
+    assert summ.termination_type == 0 and summ.num_iterations == so.num_iterations
+    assert np.allclose(tr[: so.num_iterations + 1, 0], tro[: so.num_iterations + 1, 0], rtol=1e-9)
+    dq, dt = pose_err(e.get_params()[0], o.cams)
+    assert dq < 1e-8 and dt < 1e-8
+    # and afterwards the persistent program is used again (after the cool-down) and still right
+    for _ in range(70):
+        st.cholesky_solve(A[:300, :300], b[:300])
+    assert np.allclose(st.cholesky_factor(A), np.linalg.cholesky(A), rtol=1e-10, atol=1e-10)
+
+
+def test_two_processes_factor_on_one_gpu(st, tmp_path):
+    """two PROCESSES factoring n = 3000 systems concurrently on ONE GPU both finish with the right
+    factor -- whether the device time-slices their persistent kernels (no time-out) or lets them starve each other (the
+    stage kernels take over)."""
+    import os, subprocess, sys
+    from conftest import ROOT
+    code = f"""
+import importlib, sys, numpy as np
+sys.path.insert(0, {ROOT!r})
+st = importlib.import_module("slam-tricks_amd")
+n = 3000
+rng = np.random.default_rng(int(sys.argv[1]))
+B = rng.normal(size=(n, n)); A = B @ B.T + n * np.eye(n)
+ref = np.linalg.cholesky(A)
+worst = 0.0
+for k in range(12):
+    L = st.cholesky_factor(A)
+    worst = max(worst, float(np.abs(L - ref).max() / np.abs(ref).max()))
+print("RESULT", worst, st.cholesky_timeout_count())
+"""
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(k)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for k in (1, 2)]
+    outs = [p.communicate(timeout=900) for p in procs]
+    for p, (out, err) in zip(procs, outs):
+        assert p.returncode == 0, err[-2000:]
+        line = [l for l in out.splitlines() if l.startswith("RESULT")][0].split()
+        assert float(line[1]) < 1e-11, line
+        print("process: relative factor error", line[1], "time-outs (stage-kernel fallbacks)", line[2])

@@ -33,9 +33,20 @@ for ty, nph in ((0, 4), (1, 3), (2, 3), (4, 2), (5, 3)):
             out.append(((tr[m, 4 + k] - prev) / 100.0).mean()); prev = tr[m, 4 + k]
         out.append(((tr[m, 3] - prev) / 100.0).mean())
         print(f"{names[ty]:3s} phases (us):", np.round(out, 2))
-nwg = int(tr[:, 0].max()) + 1
-busy = (tr[:, 3] - tr[:, 2]).sum() / 100.0
-print("workgroups", nwg, "busy fraction", busy / (nwg * us(tr[:, 3].max())))
+bulk = tr[:, 0] >= 100000          # tasks run by the 256-thread bulk class (two workgroups per CU)
+for nm, m in (("chain / only class", ~bulk), ("bulk class", bulk)):
+    if not m.any(): continue
+    nwg = len(np.unique(tr[m, 0]))
+    busy = (tr[m, 3] - tr[m, 2]).sum() / 100.0
+    print(f"{nm}: workgroups {nwg} busy fraction {busy / (nwg * us(tr[:, 3].max())):.3f}")
+    mu = m & (tasks[:, 0] == 3)
+    if mu.any():
+        nbp = np.maximum(1, (np.frombuffer(raw[4:4 + 16 * nt], np.int32).reshape(nt, 4)[:, 0] >> 16) & 0xff)
+        for k in (1, 2):
+            mk = mu & (nbp == k)
+            if mk.any():
+                run = (tr[mk, 3] - tr[mk, 2]) / 100.0
+                print(f"   U tasks of {k} panel(s): n {mk.sum()} run mean {run.mean():.2f} med {np.median(run):.2f} p10 {np.percentile(run, 10):.2f} p90 {np.percentile(run, 90):.2f}")
 # critical chain: D(b) start/end
 dm = np.where(tasks[:, 0] == 0)[0]
 print("  b   D.ready   D.done   (ready - prev done)")
