@@ -205,56 +205,41 @@ int launch_absmax(const double* v, size_t n, const double* v2, size_t n2, double
     return STBA_OK;
 }
 
-// |gp|max of this rank and the cost into their slots of the scalar block behind S, the rest of the block zeroed: the second
-// stage of launch_absmax, the memset and the one-double copy of the separate path in one launch
-__global__ __launch_bounds__(256) void scalar_slots_final_kernel(const double* __restrict__ partial, int n, const double* __restrict__ cost2,
-                                                                 double* __restrict__ slots, int n_slots, int cost_slot, int max_slot) {
+// The whole trial block of one LM iteration in ONE launch behind the residual-only kernel: out[0] = sum of that kernel's
+// cost partials (summation order of sum_partials_kernel), out[1..3] / out[4..6] the three sums of the landmark / camera
+// update's partials (order of trial_sums_kernel), out[7] = 0; and, if host_out is given, the block plus the
+// factorisation's flag written straight into mapped host memory (export_trial_kernel): three launches less.
+__global__ __launch_bounds__(256) void trial_finish_kernel(const double* __restrict__ cost_partial, int n_cost,
+                                                           const double* __restrict__ part_p, int n_p, const double* __restrict__ part_c,
+                                                           int n_c, const int* __restrict__ flag, double* __restrict__ out,
+                                                           double* __restrict__ host_out) {
     __shared__ double s[256];
-    double m = 0.0;
-    for (int i = threadIdx.x; i < n; i += 256) m = fmax(m, partial[i]);
-    s[threadIdx.x] = m;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-        if (threadIdx.x < off) s[threadIdx.x] = fmax(s[threadIdx.x], s[threadIdx.x + off]);
-        __syncthreads();
-    }
-    for (int i = threadIdx.x; i < n_slots; i += 256) slots[i] = (i == cost_slot) ? cost2[0] : (i == max_slot) ? s[0] : 0.0;
-}
-
-int launch_scalar_slots(const double* v, size_t n, const double* cost2, double* slots, int n_slots, int cost_slot, int max_slot,
-                        double* partial, int n_partial, hipStream_t st) {
-    int grid = (int)std::min<size_t>((size_t)n_partial, std::max<size_t>(1, (n + 2047) / 2048));
-    hipLaunchKernelGGL(absmax_partial_kernel, dim3(grid), dim3(256), 0, st, v, n, (const double*)nullptr, (size_t)0, partial);
-    hipLaunchKernelGGL(scalar_slots_final_kernel, dim3(1), dim3(256), 0, st, partial, grid, cost2, slots, n_slots, cost_slot, max_slot);
-    STBA_HIP(hipGetLastError());
-    return STBA_OK;
-}
-
-// the trial block of one LM iteration: the three sums of the landmark update's partials into out[1..3], the three of the
-// camera update's into out[4..6] (same summation order as sum_partials_kernel), out[0] and out[7] zeroed -- the memset
-// and the two single-block sums of the separate path in one launch
-__global__ __launch_bounds__(256) void trial_sums_kernel(const double* __restrict__ part_p, int n_p, const double* __restrict__ part_c,
-                                                         int n_c, double* __restrict__ out) {
-    __shared__ double s[256];
-    for (int q = 0; q < 6; ++q) {
-        const double* partial = q < 3 ? part_p : part_c;
-        const int n = q < 3 ? n_p : n_c, k = q < 3 ? q : q - 3;
+    __shared__ double res[8];
+    for (int q = 0; q < 7; ++q) {
+        const double* partial = q == 0 ? cost_partial : (q < 4 ? part_p : part_c);
+        const int n = q == 0 ? n_cost : (q < 4 ? n_p : n_c);
+        const int stride = q == 0 ? 1 : 4, k = q == 0 ? 0 : (q < 4 ? q - 1 : q - 4);
         double v = 0.0;
-        for (int i = threadIdx.x; i < n; i += 256) v += partial[(size_t)i * 4 + k];
+        for (int i = threadIdx.x; i < n; i += 256) v += partial[(size_t)i * stride + k];
         s[threadIdx.x] = v;
         __syncthreads();
         for (int off = 128; off > 0; off >>= 1) {
             if (threadIdx.x < off) s[threadIdx.x] += s[threadIdx.x + off];
             __syncthreads();
         }
-        if (threadIdx.x == 0) out[1 + q] = s[0];
+        if (threadIdx.x == 0) res[q] = s[0];
         __syncthreads();
     }
-    if (threadIdx.x == 0) { out[0] = 0.0; out[7] = 0.0; }
+    if (threadIdx.x < 8) {
+        const double v = threadIdx.x < 7 ? res[threadIdx.x] : 0.0;
+        out[threadIdx.x] = v;
+        if (host_out) host_out[threadIdx.x] = v;
+    } else if (threadIdx.x == 8 && host_out) host_out[8] = (double)flag[0];
 }
 
-int launch_trial_sums(const double* part_p, int n_p, const double* part_c, int n_c, double* out, hipStream_t st) {
-    hipLaunchKernelGGL(trial_sums_kernel, dim3(1), dim3(256), 0, st, part_p, n_p, part_c, n_c, out);
+int launch_trial_finish(const double* cost_partial, int n_cost, const double* part_p, int n_p, const double* part_c, int n_c,
+                        const int* flag, double* out, double* host_out, hipStream_t st) {
+    hipLaunchKernelGGL(trial_finish_kernel, dim3(1), dim3(256), 0, st, cost_partial, n_cost, part_p, n_p, part_c, n_c, flag, out, host_out);
     STBA_HIP(hipGetLastError());
     return STBA_OK;
 }
@@ -309,12 +294,12 @@ __global__ __launch_bounds__(256) void ba_point_blocks_kernel(int n_pts, const i
                                                               const double* __restrict__ J8,
                                                               const unsigned char* __restrict__ omask,
                                                               const double2* __restrict__ r,
-                                                              double* __restrict__ Hpp6, double* __restrict__ gp) {
+                                                              double* __restrict__ Hpp6, double* __restrict__ gp,
+                                                              double* __restrict__ gpmax_partial) {
     const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= n_pts) return;
     double h0 = 0, h1 = 0, h2 = 0, h3 = 0, h4 = 0, h5 = 0, g0 = 0, g1 = 0, g2 = 0;
-    const int e = pt_start[j + 1];
-    for (int i = pt_start[j]; i < e; ++i) {
+    const int e = (j < n_pts) ? pt_start[j + 1] : 0;
+    for (int i = (j < n_pts) ? pt_start[j] : 0; i < e; ++i) {
         if (omask && (omask[i] & 64u)) continue;                   // constant landmark: zero block
         const double2* p = reinterpret_cast<const double2*>(J8 + (size_t)i * 8);
         const double2 a = p[1], b = p[2], c = p[3];   // a.x a.y b.x | b.y c.x c.y
@@ -324,16 +309,68 @@ __global__ __launch_bounds__(256) void ba_point_blocks_kernel(int n_pts, const i
         h3 += j01 * j01 + j11 * j11; h4 += j01 * j02 + j11 * j12; h5 += j02 * j02 + j12 * j12;
         g0 += j00 * ri.x + j10 * ri.y; g1 += j01 * ri.x + j11 * ri.y; g2 += j02 * ri.x + j12 * ri.y;
     }
-    double* H = Hpp6 + (size_t)j * 6;
-    H[0] = h0; H[1] = h1; H[2] = h2; H[3] = h3; H[4] = h4; H[5] = h5;
-    double* g = gp + (size_t)j * 3;
-    g[0] = g0; g[1] = g1; g[2] = g2;
+    if (j < n_pts) {
+        double* H = Hpp6 + (size_t)j * 6;
+        H[0] = h0; H[1] = h1; H[2] = h2; H[3] = h3; H[4] = h4; H[5] = h5;
+        double* g = gp + (size_t)j * 3;
+        g[0] = g0; g[1] = g1; g[2] = g2;
+    }
+    if (gpmax_partial) {
+        // max |gp| of this block's landmarks (the gradient max-norm of the LM loop: one partial per block, finished by
+        // linear_finish_kernel; a maximum does not depend on the order)
+        __shared__ double s[4];
+        double m = fmax(fabs(g0), fmax(fabs(g1), fabs(g2)));
+        for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_down(m, off, 64));
+        if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) gpmax_partial[blockIdx.x] = fmax(fmax(s[0], s[1]), fmax(s[2], s[3]));
+    }
 }
 
 int launch_point_blocks(int n_pts, const int* pt_start, const double* J8, const unsigned char* omask, const double2* r,
-                        double* Hpp6, double* gp, hipStream_t st) {
-    hipLaunchKernelGGL(ba_point_blocks_kernel, dim3((n_pts + 255) / 256), dim3(256), 0, st, n_pts, pt_start,
-                       J8, omask, r, Hpp6, gp);
+                        double* Hpp6, double* gp, double* gpmax_partial, hipStream_t st) {
+    if (n_pts > 0)
+        hipLaunchKernelGGL(ba_point_blocks_kernel, dim3((n_pts + 255) / 256), dim3(256), 0, st, n_pts, pt_start,
+                           J8, omask, r, Hpp6, gp, gpmax_partial);
+    STBA_HIP(hipGetLastError());
+    return STBA_OK;
+}
+
+// Behind a linearisation (residual + Jacobian kernel, landmark blocks): the cost partial sums of the linearise kernel's
+// workgroups -> cost2_out[0] (same summation order as sum_partials_kernel), the |gp| partial maxima -> this rank's slot,
+// and the scalar block behind S filled: slots[cost_slot] = cost2, slots[max_slot] = |gp|max, every other slot zero.
+// One launch instead of three (sum_partials, absmax_partial + scalar_slots_final).
+__global__ __launch_bounds__(256) void linear_finish_kernel(const double* __restrict__ cost_partial, int n_cost,
+                                                            const double* __restrict__ gpmax_partial, int n_gp,
+                                                            double* __restrict__ cost2_out, double* __restrict__ slots, int n_slots,
+                                                            int cost_slot, int max_slot) {
+    __shared__ double s[256];
+    double v = 0.0;
+    for (int i = threadIdx.x; i < n_cost; i += 256) v += cost_partial[i];
+    s[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) s[threadIdx.x] += s[threadIdx.x + off];
+        __syncthreads();
+    }
+    const double cost2 = s[0];
+    __syncthreads();
+    double m = 0.0;
+    for (int i = threadIdx.x; i < n_gp; i += 256) m = fmax(m, gpmax_partial[i]);
+    s[threadIdx.x] = m;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) s[threadIdx.x] = fmax(s[threadIdx.x], s[threadIdx.x + off]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) cost2_out[0] = cost2;
+    for (int i = threadIdx.x; i < n_slots; i += 256) slots[i] = (i == cost_slot) ? cost2 : (i == max_slot) ? s[0] : 0.0;
+}
+
+int launch_linear_finish(const double* cost_partial, int n_cost, const double* gpmax_partial, int n_gp, double* cost2_out,
+                         double* slots, int n_slots, int cost_slot, int max_slot, hipStream_t st) {
+    hipLaunchKernelGGL(linear_finish_kernel, dim3(1), dim3(256), 0, st, cost_partial, n_cost, gpmax_partial, n_gp, cost2_out, slots,
+                       n_slots, cost_slot, max_slot);
     STBA_HIP(hipGetLastError());
     return STBA_OK;
 }
@@ -480,8 +517,9 @@ __global__ __launch_bounds__(256) void ba_point_damp_invert_kernel(int n_pts, co
                                                                    const unsigned char* __restrict__ pt_fixed,
                                                                    double* __restrict__ scale, int init_scale, int use_scaling,
                                                                    double radius, double dmin, double dmax, double* __restrict__ dp,
-                                                                   double* __restrict__ Hinv6) {
+                                                                   double* __restrict__ Hinv6, double* __restrict__ zero_buf, int zero_n) {
     const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j < zero_n) zero_buf[j] = 0.0;          // (the three extras vectors behind S: one memset launch less per iteration)
     if (j >= n_pts) return;
     double H[6], Hi[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
@@ -512,9 +550,10 @@ __global__ __launch_bounds__(256) void ba_point_damp_invert_kernel(int n_pts, co
 }
 
 int launch_point_damp_invert(int n_pts, const double* Hpp6, const unsigned char* pt_fixed, double* scale, int init_scale,
-                             int use_scaling, double radius, double dmin, double dmax, double* dp, double* Hinv6, hipStream_t st) {
-    hipLaunchKernelGGL(ba_point_damp_invert_kernel, dim3((n_pts + 255) / 256), dim3(256), 0, st, n_pts, Hpp6, pt_fixed, scale,
-                       init_scale, use_scaling, radius, dmin, dmax, dp, Hinv6);
+                             int use_scaling, double radius, double dmin, double dmax, double* dp, double* Hinv6,
+                             double* zero_buf, int zero_n, hipStream_t st) {
+    hipLaunchKernelGGL(ba_point_damp_invert_kernel, dim3((std::max(n_pts, zero_n) + 255) / 256), dim3(256), 0, st, n_pts, Hpp6, pt_fixed, scale,
+                       init_scale, use_scaling, radius, dmin, dmax, dp, Hinv6, zero_buf, zero_n);
     STBA_HIP(hipGetLastError());
     return STBA_OK;
 }
@@ -528,183 +567,20 @@ int launch_point_invert(int n_pts, const double* Hpp6, const double* dp, const u
 }
 
 // ===========================================================================================
-// Schur complement of the landmark blocks, one observation per lane:
-//   E_i = W_i Hpp_j^-1 (6x3),  rhs[c_i] += E_i gp_j,
-//   S[c_i, c_l] -= E_i W_l^T  for every observation l of the same landmark with c_l <= c_i
-// (lower block triangle; within a diagonal block only a >= b).  FP64 hardware atomics
-// (global_atomic_add_f64) into the dense S.
+// Schur complement of the landmark blocks:  S[c_i, c_l] -= E_i W_l^T,  rhs[c_i] += E_i gp_j  for every pair of
+// observations (i, l) of one landmark j with c_l <= c_i,  W = Jc^T Jp (6x3),  E_i = W_i Hpp_j^-1.
+// One workgroup per TASK = (camera row c, a slice of that row's non-zero 6x6 blocks).  The blocks of the slice are
+// accumulated in LDS with ds_add_f64 and written to HBM once: no global atomics and no read-modify-write of the 288 MB
+// matrix (global FP64 atomics into S: 8.9 ms; a serial partner loop per observation: 0.52 ms; this form 0.27 ms in round
+// 2).  The pairs are enumerated ON THE HOST once (the structure is static), with the LDS slot of every pair's block
+// resolved; one lane handles one PAIR per trip: two independent 64 B gathers (J_i, J_l) plus the landmark's inverse
+// block, ~220 FMAs, 36 LDS atomics -- every iteration of every lane is independent.
+// The task zeroes its own stretch of its six rows of S (no 288 MB memset in front of the kernel), and the slice that
+// holds the diagonal block also makes the camera blocks Hcc = sum Jc^T Jc, gc = sum Jc^T r of its camera -- a wave
+// reduction over the camera's observations, whose records are in this CU's caches at that moment (as a kernel of its
+// own that gather cost 46 us per iteration).  Fixed summation order: Hcc and gc are bitwise reproducible.
 // ===========================================================================================
-__global__ __launch_bounds__(256) void ba_schur_kernel(int n_obs, const int* __restrict__ obs_cam,
-                                                       const int* __restrict__ obs_pt,
-                                                       const int* __restrict__ pt_start,
-                                                       const double* __restrict__ Jc, const unsigned char* __restrict__ Jp,
-                                                       const double* __restrict__ Hinv6, const double* __restrict__ gp,
-                                                       double* __restrict__ S, int lda, double* __restrict__ rhs) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n_obs) return;
-    const int c = obs_cam[i], j = obs_pt[i];
-    double Hi[6];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) Hi[k] = Hinv6[(size_t)j * 6 + k];
-    if (Hi[0] == 0.0 && Hi[3] == 0.0 && Hi[5] == 0.0) return;   // constant / degenerate landmark
-    double jc[12], jp[6];
-    load_jc_jp(Jc, Jp, i, jc, jp);
-    // W = Jc^T Jp (6x3), E = W Hinv (6x3)
-    double E[18];
-    double egp[6];
-    const double g0 = gp[(size_t)j * 3], g1 = gp[(size_t)j * 3 + 1], g2 = gp[(size_t)j * 3 + 2];
-    bool any = false;
-#pragma unroll
-    for (int a = 0; a < 6; ++a) {
-        const double w0 = jc[a] * jp[0] + jc[6 + a] * jp[3];
-        const double w1 = jc[a] * jp[1] + jc[6 + a] * jp[4];
-        const double w2 = jc[a] * jp[2] + jc[6 + a] * jp[5];
-        E[a * 3 + 0] = w0 * Hi[0] + w1 * Hi[1] + w2 * Hi[2];
-        E[a * 3 + 1] = w0 * Hi[1] + w1 * Hi[3] + w2 * Hi[4];
-        E[a * 3 + 2] = w0 * Hi[2] + w1 * Hi[4] + w2 * Hi[5];
-        egp[a] = E[a * 3] * g0 + E[a * 3 + 1] * g1 + E[a * 3 + 2] * g2;
-        any |= (w0 != 0.0) | (w1 != 0.0) | (w2 != 0.0);
-    }
-    if (!any) return;   // constant camera: zero Jacobian columns
-#pragma unroll
-    for (int a = 0; a < 6; ++a)
-        if (egp[a] != 0.0) unsafeAtomicAdd(&rhs[c * 6 + a], egp[a]);
-    const int e = pt_start[j + 1];
-    for (int l = pt_start[j]; l < e; ++l) {
-        const int c2 = obs_cam[l];
-        if (c2 > c) continue;
-        double jc2[12], jp2[6];
-        load_jc_jp(Jc, Jp, l, jc2, jp2);
-        double* Sblk = S + (size_t)(c * 6) * lda + c2 * 6;
-#pragma unroll
-        for (int b = 0; b < 6; ++b) {
-            const double w0 = jc2[b] * jp2[0] + jc2[6 + b] * jp2[3];
-            const double w1 = jc2[b] * jp2[1] + jc2[6 + b] * jp2[4];
-            const double w2 = jc2[b] * jp2[2] + jc2[6 + b] * jp2[5];
-            if (w0 == 0.0 && w1 == 0.0 && w2 == 0.0) continue;   // constant dof of camera c2
-#pragma unroll
-            for (int a = 0; a < 6; ++a) {
-                if (c2 == c && b > a) continue;
-                const double v = E[a * 3] * w0 + E[a * 3 + 1] * w1 + E[a * 3 + 2] * w2;
-                unsafeAtomicAdd(&Sblk[(size_t)a * lda + b], -v);
-            }
-        }
-    }
-}
-
-int launch_schur(int n_obs, const int* obs_cam, const int* obs_pt, const int* pt_start, const double* Jc,
-                 const unsigned char* Jp, const double* Hinv6, const double* gp, double* S, int lda, double* rhs,
-                 hipStream_t st) {
-    if (n_obs > 0)
-        hipLaunchKernelGGL(ba_schur_kernel, dim3((n_obs + 255) / 256), dim3(256), 0, st, n_obs, obs_cam, obs_pt,
-                           pt_start, Jc, Jp, Hinv6, gp, S, lda, rhs);
-    STBA_HIP(hipGetLastError());
-    return STBA_OK;
-}
-
-// -------------------------------------------------------------------------------------------
-// Row-wise Schur complement (the fast path).  One workgroup per task = (camera row c, a slice
-// of that camera's observation list).  The row's non-zero 6x6 blocks S[c, c2] (c2 <= c) are
-// accumulated in LDS with ds_add_f64 and written to HBM once, so the only global traffic is the
-// re-read of the landmark neighbours' Jacobian rows (L2-resident) and one store per non-zero
-// block: no global atomics and no read-modify-write of the 288 MB matrix.
-//   cols: sorted distinct c2 of the row (CSR row_col_ptr/row_cols), slot = binary search.
-// -------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(SCHUR_THREADS) void ba_schur_rows_kernel(SchurRowArgs a) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int task = blockIdx.x;
-    const int c = a.task_cam[task];
-    const int col0 = a.row_col_ptr[c], ncols = a.row_col_ptr[c + 1] - col0;
-    double* acc = smem;                          // [ncols][SCHUR_BLK_LD]
-    double* racc = smem + (size_t)a.max_cols * SCHUR_BLK_LD;   // [8]
-    int* cols = reinterpret_cast<int*>(racc + 8);    // [ncols]
-    const int tid = threadIdx.x;
-    for (int e = tid; e < ncols * SCHUR_BLK_LD; e += SCHUR_THREADS) acc[e] = 0.0;
-    if (tid < 8) racc[tid] = 0.0;
-    for (int e = tid; e < ncols; e += SCHUR_THREADS) cols[e] = a.row_cols[col0 + e];
-    __syncthreads();
-    const int pe = a.task_end[task];
-    for (int p = a.task_begin[task] + tid; p < pe; p += SCHUR_THREADS) {
-        const int i = a.cam_perm[p];
-        const int j = a.obs_pt[i];
-        double Hi[6];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) Hi[k] = a.Hinv6[(size_t)j * 6 + k];
-        if (Hi[0] == 0.0 && Hi[3] == 0.0 && Hi[5] == 0.0) continue;   // constant / degenerate landmark
-        double jc[12], jp[6];
-        load_jc_jp(a.Jc, a.Jp, i, jc, jp);
-        double E[18];
-        const double g0 = a.gp[(size_t)j * 3], g1 = a.gp[(size_t)j * 3 + 1], g2 = a.gp[(size_t)j * 3 + 2];
-        bool any = false;
-#pragma unroll
-        for (int q = 0; q < 6; ++q) {
-            const double w0 = jc[q] * jp[0] + jc[6 + q] * jp[3];
-            const double w1 = jc[q] * jp[1] + jc[6 + q] * jp[4];
-            const double w2 = jc[q] * jp[2] + jc[6 + q] * jp[5];
-            E[q * 3 + 0] = w0 * Hi[0] + w1 * Hi[1] + w2 * Hi[2];
-            E[q * 3 + 1] = w0 * Hi[1] + w1 * Hi[3] + w2 * Hi[4];
-            E[q * 3 + 2] = w0 * Hi[2] + w1 * Hi[4] + w2 * Hi[5];
-            any |= (w0 != 0.0) | (w1 != 0.0) | (w2 != 0.0);
-        }
-        if (!any) continue;   // constant camera
-#pragma unroll
-        for (int q = 0; q < 6; ++q) {
-            const double v = E[q * 3] * g0 + E[q * 3 + 1] * g1 + E[q * 3 + 2] * g2;
-            if (v != 0.0) unsafeAtomicAdd(&racc[q], v);
-        }
-        const int le = a.pt_start[j + 1];
-        for (int l = a.pt_start[j]; l < le; ++l) {
-            const int c2 = a.obs_cam[l];
-            if (c2 > c) continue;
-            int lo = 0, hi = ncols - 1;          // cols is sorted and contains c2
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                if (cols[mid] < c2) lo = mid + 1; else hi = mid;
-            }
-            double* blk = acc + (size_t)lo * SCHUR_BLK_LD;
-            double jc2[12], jp2[6];
-            load_jc_jp(a.Jc, a.Jp, l, jc2, jp2);
-#pragma unroll
-            for (int b = 0; b < 6; ++b) {
-                const double w0 = jc2[b] * jp2[0] + jc2[6 + b] * jp2[3];
-                const double w1 = jc2[b] * jp2[1] + jc2[6 + b] * jp2[4];
-                const double w2 = jc2[b] * jp2[2] + jc2[6 + b] * jp2[5];
-                if (w0 == 0.0 && w1 == 0.0 && w2 == 0.0) continue;   // constant dof of camera c2
-#pragma unroll
-                for (int q = 0; q < 6; ++q) {
-                    if (c2 == c && b > q) continue;
-                    const double v = E[q * 3] * w0 + E[q * 3 + 1] * w1 + E[q * 3 + 2] * w2;
-                    unsafeAtomicAdd(&blk[q * 6 + b], -v);
-                }
-            }
-        }
-    }
-    __syncthreads();
-    const bool single = a.task_single[task] != 0;
-    for (int e = tid; e < ncols * 36; e += SCHUR_THREADS) {
-        const int slot = e / 36, k = e - slot * 36, q = k / 6, b = k - q * 6;
-        const int c2 = cols[slot];
-        if (c2 == c && b > q) continue;
-        double* dst = a.S + (size_t)(c * 6 + q) * a.lda + c2 * 6 + b;
-        const double v = acc[slot * SCHUR_BLK_LD + k];
-        if (single) *dst = v;
-        else unsafeAtomicAdd(dst, v);
-    }
-    if (tid < 6) {
-        if (single) a.rhs[c * 6 + tid] = racc[tid];
-        else unsafeAtomicAdd(&a.rhs[c * 6 + tid], racc[tid]);
-    }
-}
-
-// -------------------------------------------------------------------------------------------
-// Pair-plan variant of the row-wise Schur kernel.  The row kernel above walks, per observation, the other
-// observations of its landmark in a serial loop of dependent loads (camera index -> binary search -> Jacobian
-// rows): latency-bound, 0.52 ms at C5.  Here the pairs of a camera row are enumerated ON THE HOST once
-// (the structure is static), with the LDS slot of every pair's block resolved; then one lane handles one
-// PAIR: two independent 144 B gathers (J_i, J_l) plus the landmark's inverse block, ~220 FMAs, 36 LDS
-// atomics -- every iteration of every lane is independent.
-// -------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(SCHUR_THREADS) void ba_schur_pairs_kernel(SchurRowArgs a) {
+__global__ __launch_bounds__(SCHUR_THREADS) void ba_schur_pairs_kernel(SchurArgs a) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int task = blockIdx.x;
     const int c = a.task_cam[task];
@@ -713,19 +589,19 @@ __global__ __launch_bounds__(SCHUR_THREADS) void ba_schur_pairs_kernel(SchurRowA
     const int col0 = a.row_col_ptr[c] + clo, ncols = chi - clo;
     double* acc = smem;                          // [ncols][SCHUR_BLK_LD]
     double* racc = smem + (size_t)a.max_cols * SCHUR_BLK_LD;   // [8]
-    int* cols = reinterpret_cast<int*>(racc + 8);    // [ncols]
+    double* cpart = racc + 8;                    // [8 waves][28]: the waves' partial camera blocks
+    int* cols = reinterpret_cast<int*>(cpart + 8 * 28);    // [ncols]
     const int tid = threadIdx.x;
+    const bool diag_piece = (chi == row_ncols);  // (the diagonal block is the last one of its row)
     for (int e = tid; e < ncols * SCHUR_BLK_LD; e += SCHUR_THREADS) acc[e] = 0.0;
     if (tid < 8) racc[tid] = 0.0;
     for (int e = tid; e < ncols; e += SCHUR_THREADS) cols[e] = a.row_cols[col0 + e];
-    if (a.zero_rows) {
-        // this row's six rows of S are zeroed HERE (up to the end of the diagonal 128-tile; nothing right of it
-        // is ever read) instead of by a 288 MB memset in front of the kernel: the stores drain under the
-        // LDS-atomic-bound pair loop.  (Only when every camera row is a single task.)
+    {
+        // this slice's stretch of the camera's six rows of S is zeroed HERE (the whole row up to the end of the diagonal
+        // 128-tile, shared out between the slices; nothing right of it is ever read): the stores drain under the pair loop
         const int cend = min(a.lda, ((c * 6 + 5) / 128 + 1) * 128);
-        // (a split row: every piece zeroes from its first block to the next piece's first block)
         const int z0 = (clo == 0) ? 0 : 6 * a.row_cols[col0];
-        const int z1 = (chi == row_ncols) ? cend : 6 * a.row_cols[col0 + ncols];
+        const int z1 = diag_piece ? cend : 6 * a.row_cols[col0 + ncols];
         for (int q = 0; q < 6; ++q) {
             double* row = a.S + (size_t)(c * 6 + q) * a.lda;
             for (int e = z0 + tid; e < z1; e += SCHUR_THREADS) row[e] = 0.0;
@@ -736,14 +612,13 @@ __global__ __launch_bounds__(SCHUR_THREADS) void ba_schur_pairs_kernel(SchurRowA
     // deep.  (Two pairs in flight per lane -- the second pair's gathers requested before the first is computed -- was
     // measured 7 % slower: the kernel is not bound by the gather latency.)
     const int ke = a.pair_end[task];
-    auto gather = [&](const int4& rc, double (&Hi)[6], double (&jc)[12], double (&jp)[6], double (&jc2)[12], double (&jp2)[6]) {
+    for (int k = a.pair_begin[task] + tid; k < ke; k += SCHUR_THREADS) {
+        const int4 rc = a.pair_rec[k];
+        double Hi[6], jc[12], jp[6], jc2[12], jp2[6];
 #pragma unroll
         for (int k2 = 0; k2 < 6; ++k2) Hi[k2] = a.Hinv6[(size_t)rc.z * 6 + k2];
-        load_jc_jp(a.Jc, a.Jp, rc.x, jc, jp);
-        load_jc_jp(a.Jc, a.Jp, rc.y, jc2, jp2);
-    };
-    auto accumulate = [&](const int4& rc, const double (&Hi)[6], const double (&jc)[12], const double (&jp)[6],
-                          const double (&jc2)[12], const double (&jp2)[6]) {
+        load_jc_jp(a.J8, a.omask, rc.x, jc, jp);
+        load_jc_jp(a.J8, a.omask, rc.y, jc2, jp2);
         const unsigned sl = (unsigned)rc.w;
         // E_i = (Jc_i^T Jp_i) Hinv_j recomputed per pair (cheaper than a pre-pass that stores it)
         double E[18];
@@ -775,52 +650,75 @@ __global__ __launch_bounds__(SCHUR_THREADS) void ba_schur_pairs_kernel(SchurRowA
                 else unsafeAtomicAdd(&blk[q * 6 + b], -(E[q * 3] * w0 + E[q * 3 + 1] * w1 + E[q * 3 + 2] * w2));
             }
         }
-    };
-    for (int k = a.pair_begin[task] + tid; k < ke; k += SCHUR_THREADS) {
-        const int4 r0 = a.pair_rec[k];
-        double Hi0[6], jc0[12], jp0[6], jcl0[12], jpl0[6];
-        gather(r0, Hi0, jc0, jp0, jcl0, jpl0);
-        accumulate(r0, Hi0, jc0, jp0, jcl0, jpl0);
+    }
+    if (diag_piece) {
+        // camera blocks of camera c: 21 unique entries of Jc^T Jc and 6 of Jc^T r summed over the camera's observations --
+        // a strided share per lane, a shuffle tree per wave, the eight waves' partial sums added in order below
+        double h[27];
+#pragma unroll
+        for (int k = 0; k < 27; ++k) h[k] = 0.0;
+        const int pe = a.cam_start[c + 1];
+        for (int p = a.cam_start[c] + tid; p < pe; p += SCHUR_THREADS) {
+            const int i = a.cam_perm[p];
+            double j[12], jpu[6];
+            load_jc_jp(a.J8, a.omask, i, j, jpu);
+            const double2 ri = a.r[i];
+            int idx = 0;
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+#pragma unroll
+                for (int b = 0; b <= q; ++b) h[idx++] += j[q] * j[b] + j[6 + q] * j[6 + b];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) h[21 + q] += j[q] * ri.x + j[6 + q] * ri.y;
+        }
+#pragma unroll
+        for (int k = 0; k < 27; ++k) {
+            double v = h[k];
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+            if ((tid & 63) == 0) cpart[(tid >> 6) * 28 + k] = v;
+        }
     }
     __syncthreads();
-    const bool single = a.task_single[task] != 0;
     for (int e = tid; e < ncols * 36; e += SCHUR_THREADS) {
         const int slot = e / 36, k = e - slot * 36, q = k / 6, b = k - q * 6;
         const int c2 = cols[slot];
         if (c2 == c && b > q) continue;
-        double* dst = a.S + (size_t)(c * 6 + q) * a.lda + c2 * 6 + b;
-        const double v = acc[slot * SCHUR_BLK_LD + k];
-        if (single) *dst = v;
-        else unsafeAtomicAdd(dst, v);
+        a.S[(size_t)(c * 6 + q) * a.lda + c2 * 6 + b] = acc[slot * SCHUR_BLK_LD + k];
     }
-    if (tid < 6 && chi == row_ncols) {           // (the piece with the diagonal block carries the right-hand side)
-        if (single) a.rhs[c * 6 + tid] = racc[tid];
-        else unsafeAtomicAdd(&a.rhs[c * 6 + tid], racc[tid]);
+    if (diag_piece) {                            // (the slice with the diagonal block carries the right-hand side and the camera blocks)
+        if (tid < 6) a.rhs[c * 6 + tid] = racc[tid];
+        if (tid >= 64 && tid < 64 + 27) {
+            const int k = tid - 64;
+            double s = 0.0;
+#pragma unroll
+            for (int w = 0; w < SCHUR_THREADS / 64; ++w) s += cpart[w * 28 + k];
+            if (k < 21) {
+                int q = 0, b = k;
+                while (b > q) { ++q; b -= q; }   // k = q(q+1)/2 + b
+                a.Hcc[(size_t)c * 36 + q * 6 + b] = s;
+                a.Hcc[(size_t)c * 36 + b * 6 + q] = s;
+            } else {
+                a.gc[(size_t)c * 6 + (k - 21)] = s;
+            }
+        }
     }
 }
 
 size_t schur_rows_lds_bytes(int max_cols) {
-    return ((size_t)max_cols * SCHUR_BLK_LD + 8) * sizeof(double) + (size_t)max_cols * sizeof(int) + 16;
+    return ((size_t)max_cols * SCHUR_BLK_LD + 8 + 8 * 28) * sizeof(double) + (size_t)max_cols * sizeof(int) + 16;
 }
 
-int launch_schur_rows(const SchurRowArgs& a, int n_tasks, hipStream_t st) {
+int launch_schur_rows(const SchurArgs& a, int n_tasks, hipStream_t st) {
     if (n_tasks <= 0) return STBA_OK;
     const size_t lds = schur_rows_lds_bytes(a.max_cols);
-    // the largest plan the engine ever builds (SCHUR_MAX_COLS columns) fixes the limit, once per device
+    // the largest slice the engine ever builds (SCHUR_SPLIT_COLS blocks) fixes the limit, once per device
     static DeviceOnce attr;
     STBA_TRY(attr.run([]() -> int {
-        const int lim = (int)schur_rows_lds_bytes(SCHUR_MAX_COLS);
-        STBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_schur_rows_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, lim));
         STBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_schur_pairs_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)schur_rows_lds_bytes(SCHUR_SPLIT_COLS)));
         return STBA_OK;
     }));
-    if (a.pair_rec) {
-        hipLaunchKernelGGL(ba_schur_pairs_kernel, dim3(n_tasks), dim3(SCHUR_THREADS), lds, st, a);
-    } else {
-        hipLaunchKernelGGL(ba_schur_rows_kernel, dim3(n_tasks), dim3(SCHUR_THREADS), lds, st, a);
-    }
+    hipLaunchKernelGGL(ba_schur_pairs_kernel, dim3(n_tasks), dim3(SCHUR_THREADS), lds, st, a);
     STBA_HIP(hipGetLastError());
     return STBA_OK;
 }
@@ -879,7 +777,11 @@ __global__ __launch_bounds__(256) void ba_reduced_finalize_kernel(int n_cams, in
                                                                   double* __restrict__ ex_diag, double* __restrict__ ex_gc,
                                                                   double* __restrict__ scale, int init_scale, int use_scaling,
                                                                   double radius, double dmin, double dmax, double* __restrict__ dc,
-                                                                  int blocks_cam) {
+                                                                  int blocks_cam, const double* __restrict__ scalars, int n_scalars,
+                                                                  double* __restrict__ host_out) {
+    // (host_out: the scalar slots and the gradient gc also go straight into mapped host memory -- [scalars | gc] -- where
+    // the LM loop reads them one synchronisation later: export_linear_kernel's launch saved)
+    if (host_out && blockIdx.x == 0 && (int)threadIdx.x < n_scalars) host_out[threadIdx.x] = scalars[threadIdx.x];
     if ((int)blockIdx.x >= blocks_cam) {
         // padding rows (chol_pad_kernel); the first n entries of the last row are written by the diagonal threads below
         const int r = n + ((int)blockIdx.x - blocks_cam);
@@ -906,6 +808,7 @@ __global__ __launch_bounds__(256) void ba_reduced_finalize_kernel(int n_cams, in
     ex_diag[i] = h;
     const double g = gc[i];
     ex_gc[i] = g;
+    if (host_out) host_out[n_scalars + i] = g;
     double rv = rhs[i] - g;
     // lm_diagonal_kernel, kind 2
     double sc = 1.0;
@@ -928,10 +831,11 @@ __global__ __launch_bounds__(256) void ba_reduced_finalize_kernel(int n_cams, in
 
 int launch_reduced_finalize(int n_cams, int n, const double* Hcc, const double* gc, const unsigned char* cam_fixed, double* S, int lda,
                             double* rhs, double* ex_diag, double* ex_gc, double* scale, int init_scale, int use_scaling,
-                            double radius, double dmin, double dmax, double* dc, hipStream_t st) {
+                            double radius, double dmin, double dmax, double* dc, const double* scalars, int n_scalars,
+                            double* host_out, hipStream_t st) {
     const int blocks_cam = (n_cams * 36 + 255) / 256;
     hipLaunchKernelGGL(ba_reduced_finalize_kernel, dim3(blocks_cam + (lda - n)), dim3(256), 0, st, n_cams, n, Hcc, gc, cam_fixed, S, lda,
-                       rhs, ex_diag, ex_gc, scale, init_scale, use_scaling, radius, dmin, dmax, dc, blocks_cam);
+                       rhs, ex_diag, ex_gc, scale, init_scale, use_scaling, radius, dmin, dmax, dc, blocks_cam, scalars, n_scalars, host_out);
     STBA_HIP(hipGetLastError());
     return STBA_OK;
 }
@@ -998,73 +902,70 @@ __device__ inline void block_sum4(double v[4], double* out) {
     if (threadIdx.x < 4) out[threadIdx.x] = s[0][threadIdx.x] + s[1][threadIdx.x] + s[2][threadIdx.x] + s[3][threadIdx.x];
 }
 
-__global__ __launch_bounds__(256) void ba_update_cams_kernel(int n_cams, const double* __restrict__ cams,
-                                                             const double* __restrict__ dxc,
-                                                             const unsigned char* __restrict__ cam_fixed,
-                                                             const double* __restrict__ gc, const double* __restrict__ dc,
-                                                             double* __restrict__ cams_new, double* __restrict__ partial) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
+// both manifold updates in one launch: workgroups [0, cb) the cameras, [cb, cb + pb) the landmarks
+__global__ __launch_bounds__(256) void ba_update_kernel(int n_cams, int n_pts, int cb, const double* __restrict__ cams, const double* __restrict__ pts,
+                                                        const double* __restrict__ dxc, const double* __restrict__ dxp,
+                                                        const unsigned char* __restrict__ cam_fixed, const unsigned char* __restrict__ pt_fixed,
+                                                        const double* __restrict__ gc, const double* __restrict__ dc,
+                                                        const double* __restrict__ gp, const double* __restrict__ dp,
+                                                        double* __restrict__ cams_new, double* __restrict__ pts_new,
+                                                        double* __restrict__ partial_c, double* __restrict__ partial_p) {
     double v[4] = {0, 0, 0, 0};
-    if (c < n_cams) {
-        const unsigned cm = cam_fixed ? cam_fixed[c] : 0u;
-        double d[6], q[4], qn[4];
+    if ((int)blockIdx.x < cb) {
+        const int c = blockIdx.x * 256 + threadIdx.x;
+        if (c < n_cams) {
+            const unsigned cm = cam_fixed ? cam_fixed[c] : 0u;
+            double d[6], q[4], qn[4];
 #pragma unroll
-        for (int a = 0; a < 6; ++a) d[a] = ((cm >> a) & 1u) ? 0.0 : dxc[c * 6 + a];
+            for (int a = 0; a < 6; ++a) d[a] = ((cm >> a) & 1u) ? 0.0 : dxc[c * 6 + a];
 #pragma unroll
-        for (int a = 0; a < 4; ++a) q[a] = cams[(size_t)c * 7 + a];
-        so3_plus(q, d, qn);
-        const bool rot_active = (cm & 7u) != 7u, pos_active = (cm & 56u) != 56u;
+            for (int a = 0; a < 4; ++a) q[a] = cams[(size_t)c * 7 + a];
+            so3_plus(q, d, qn);
+            const bool rot_active = (cm & 7u) != 7u, pos_active = (cm & 56u) != 56u;
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            const double out = rot_active ? qn[a] : q[a];
-            cams_new[(size_t)c * 7 + a] = out;
-            if (rot_active) { v[0] += (out - q[a]) * (out - q[a]); v[1] += q[a] * q[a]; }
+            for (int a = 0; a < 4; ++a) {
+                const double out = rot_active ? qn[a] : q[a];
+                cams_new[(size_t)c * 7 + a] = out;
+                if (rot_active) { v[0] += (out - q[a]) * (out - q[a]); v[1] += q[a] * q[a]; }
+            }
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const double t = cams[(size_t)c * 7 + 4 + a];
+                cams_new[(size_t)c * 7 + 4 + a] = t + d[3 + a];
+                if (pos_active) { v[0] += d[3 + a] * d[3 + a]; v[1] += t * t; }
+            }
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+                if (!((cm >> a) & 1u)) v[2] += -0.5 * gc[c * 6 + a] * d[a] + 0.5 * dc[c * 6 + a] * d[a] * d[a];
         }
+        block_sum4(v, partial_c + (size_t)blockIdx.x * 4);
+    } else {
+        const int blk = blockIdx.x - cb;
+        const int j = blk * 256 + threadIdx.x;
+        if (j < n_pts) {
+            const bool fx = pt_fixed ? (pt_fixed[j] != 0) : false;
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const double t = cams[(size_t)c * 7 + 4 + a];
-            cams_new[(size_t)c * 7 + 4 + a] = t + d[3 + a];
-            if (pos_active) { v[0] += d[3 + a] * d[3 + a]; v[1] += t * t; }
-        }
-#pragma unroll
-        for (int a = 0; a < 6; ++a)
-            if (!((cm >> a) & 1u)) v[2] += -0.5 * gc[c * 6 + a] * d[a] + 0.5 * dc[c * 6 + a] * d[a] * d[a];
-    }
-    block_sum4(v, partial + (size_t)blockIdx.x * 4);
-}
-
-__global__ __launch_bounds__(256) void ba_update_pts_kernel(int n_pts, const double* __restrict__ pts,
-                                                            const double* __restrict__ dxp,
-                                                            const unsigned char* __restrict__ pt_fixed,
-                                                            const double* __restrict__ gp, const double* __restrict__ dp,
-                                                            double* __restrict__ pts_new, double* __restrict__ partial) {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    double v[4] = {0, 0, 0, 0};
-    if (j < n_pts) {
-        const bool fx = pt_fixed ? (pt_fixed[j] != 0) : false;
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const double p = pts[(size_t)j * 3 + a];
-            const double d = fx ? 0.0 : dxp[(size_t)j * 3 + a];
-            pts_new[(size_t)j * 3 + a] = p + d;
-            if (!fx) {
-                v[0] += d * d; v[1] += p * p;
-                v[2] += -0.5 * gp[(size_t)j * 3 + a] * d + 0.5 * dp[(size_t)j * 3 + a] * d * d;
+            for (int a = 0; a < 3; ++a) {
+                const double p = pts[(size_t)j * 3 + a];
+                const double d = fx ? 0.0 : dxp[(size_t)j * 3 + a];
+                pts_new[(size_t)j * 3 + a] = p + d;
+                if (!fx) {
+                    v[0] += d * d; v[1] += p * p;
+                    v[2] += -0.5 * gp[(size_t)j * 3 + a] * d + 0.5 * dp[(size_t)j * 3 + a] * d * d;
+                }
             }
         }
+        block_sum4(v, partial_p + (size_t)blk * 4);
     }
-    block_sum4(v, partial + (size_t)blockIdx.x * 4);
 }
 
 int launch_update(int n_cams, int n_pts, const double* cams, const double* pts, const double* dxc,
                   const double* dxp, const unsigned char* cam_fixed, const unsigned char* pt_fixed,
                   const double* gc, const double* dc, const double* gp, const double* dp, double* cams_new,
                   double* pts_new, double* partial_c, double* partial_p, hipStream_t st) {
-    hipLaunchKernelGGL(ba_update_cams_kernel, dim3((n_cams + 255) / 256), dim3(256), 0, st, n_cams, cams, dxc,
-                       cam_fixed, gc, dc, cams_new, partial_c);
-    if (n_pts > 0)
-        hipLaunchKernelGGL(ba_update_pts_kernel, dim3((n_pts + 255) / 256), dim3(256), 0, st, n_pts, pts, dxp,
-                           pt_fixed, gp, dp, pts_new, partial_p);
+    const int cb = (n_cams + 255) / 256, pb = (n_pts + 255) / 256;
+    hipLaunchKernelGGL(ba_update_kernel, dim3(cb + pb), dim3(256), 0, st, n_cams, n_pts, cb, cams, pts, dxc, dxp, cam_fixed, pt_fixed,
+                       gc, dc, gp, dp, cams_new, pts_new, partial_c, partial_p);
     STBA_HIP(hipGetLastError());
     return STBA_OK;
 }

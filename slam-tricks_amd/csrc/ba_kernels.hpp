@@ -29,54 +29,56 @@ int launch_absmax(const double* v, size_t n, const double* v2, size_t n2, double
                   hipStream_t st);
 // (J8: compact Jacobian [n_obs][8]; omask: per-observation mask byte of constant dofs / landmarks, or null)
 int launch_expand_jacobian(int n_obs, const double* J8, const unsigned char* omask, double* Jc, double* Jp, hipStream_t st);
+// (gpmax_partial: optional, one max |gp| per workgroup of 256 landmarks, finished by launch_linear_finish)
 int launch_point_blocks(int n_pts, const int* pt_start, const double* J8, const unsigned char* omask, const double2* r,
-                        double* Hpp6, double* gp, hipStream_t st);
+                        double* Hpp6, double* gp, double* gpmax_partial, hipStream_t st);
+int launch_linear_finish(const double* cost_partial, int n_cost, const double* gpmax_partial, int n_gp, double* cost2_out,
+                         double* slots, int n_slots, int cost_slot, int max_slot, hipStream_t st);
+int launch_trial_finish(const double* cost_partial, int n_cost, const double* part_p, int n_p, const double* part_c, int n_c,
+                        const int* flag, double* out, double* host_out, hipStream_t st);
 int launch_camera_blocks(int n_cams, int n_chunks, const int* chunk_begin, const int* chunk_end,
                          const int* cam_chunk_start, const int* cam_perm, const double* J8, const unsigned char* omask,
                          const double2* r, double* partial, double* Hcc, double* gc, hipStream_t st);
 int launch_lm_diagonal(int n, int bs, int bstride, int kind, const double* H, double* scale, int init_scale,
                        int use_scaling, double radius, double dmin, double dmax, double* d, hipStream_t st);
 int launch_point_damp_invert(int n_pts, const double* Hpp6, const unsigned char* pt_fixed, double* scale, int init_scale,
-                             int use_scaling, double radius, double dmin, double dmax, double* dp, double* Hinv6, hipStream_t st);
-int launch_scalar_slots(const double* v, size_t n, const double* cost2, double* slots, int n_slots, int cost_slot, int max_slot,
-                        double* partial, int n_partial, hipStream_t st);
-int launch_trial_sums(const double* part_p, int n_p, const double* part_c, int n_c, double* out, hipStream_t st);
+                             int use_scaling, double radius, double dmin, double dmax, double* dp, double* Hinv6,
+                             double* zero_buf, int zero_n, hipStream_t st);
 int launch_point_invert(int n_pts, const double* Hpp6, const double* dp, const unsigned char* pt_fixed,
                         double* Hinv6, hipStream_t st);
-int launch_schur(int n_obs, const int* obs_cam, const int* obs_pt, const int* pt_start, const double* J8,
-                 const unsigned char* omask, const double* Hinv6, const double* gp, double* S, int lda, double* rhs,
-                 hipStream_t st);
-// row-wise Schur complement with LDS accumulation (plan built on the host at create time)
-constexpr int SCHUR_MAX_COLS = 480;    // non-zero blocks per camera row that fit the LDS accumulator
-constexpr int SCHUR_TASK_OBS = 4096;
-constexpr int SCHUR_SPLIT_COLS = 256;  // camera rows with more non-zero blocks are split by column range (two workgroups per CU)
+// Schur complement of the landmark blocks, row-wise with LDS accumulation (plan built on the host at create time:
+// stba_ba_create).  SCHUR_SPLIT_COLS: non-zero blocks one task accumulates in LDS (two workgroups per CU);
+// SCHUR_TASK_PAIRS: most (i, l) observation pairs per task (unlimited: smaller tasks measured slower).
+constexpr int SCHUR_SPLIT_COLS = 256;
+constexpr int SCHUR_TASK_PAIRS = 1 << 30;
 // LDS stride of one 6x6 accumulator block, in doubles: odd, so that the same entry of different blocks falls
 // into different bank pairs (36 = 72 dwords = 8 mod 64 gave 8-way conflicts on every ds_add_f64: measured,
 // the kernel was bound by them)
 constexpr int SCHUR_BLK_LD = 37;
-constexpr int SCHUR_THREADS = 512;    // one camera row per workgroup: 16 waves hide the L2 gathers   // observations of one camera handled by one workgroup
-struct SchurRowArgs {
-    const int* task_cam; const int* task_begin; const int* task_end; const unsigned char* task_single;
-    const int* task_col_lo; const int* task_col_hi;  // the task's slice of its row's column list (the whole row unless split)
+constexpr int SCHUR_THREADS = 512;    // 8 waves per task, two tasks per CU: 16 waves hide the L2 gathers
+struct SchurArgs {
+    const int* task_cam; const int* cam_start;       // camera row of the task; the camera's range of cam_perm
+    const int* task_col_lo; const int* task_col_hi;  // the task's slice of its row's column list
     const int* row_col_ptr; const int* row_cols; int max_cols;
-    const int* cam_perm; const int* obs_cam; const int* obs_pt; const int* pt_start;
-    const double* Jc; const unsigned char* Jp;       // compact Jacobian [n_obs][8] | per-observation mask byte (or null)
+    const int* cam_perm;
+    const double* J8; const unsigned char* omask;    // compact Jacobian [n_obs][8] | per-observation mask byte (or null)
+    const double2* r;
     const double* Hinv6; const double* gp;
     double* S; int lda; double* rhs;
-    // pair plan (optional, built at create time): every (observation i of the row's camera, observation l of
-    // the same landmark with camera(l) <= camera(i)) with the LDS slot of its 6x6 block resolved on the host
+    double* Hcc; double* gc;                         // camera blocks J_c^T J_c, J_c^T r: written by the slice that holds the diagonal block
+    // every (observation i of the row's camera, observation l of the same landmark with camera(l) <= camera(i)) of the
+    // slice, with the LDS slot of its 6x6 block resolved on the host
     const int* pair_begin; const int* pair_end;      // per task
     const int4* pair_rec;                            // (i, l, landmark, slot | 0x8000 if diagonal block | 0x4000 if l == i)
-    int n_obs;
-    int zero_rows;                                   // the pair kernel zeroes its rows of S itself (no memset of S)
 };
 size_t schur_rows_lds_bytes(int max_cols);
-int launch_schur_rows(const SchurRowArgs& a, int n_tasks, hipStream_t st);
+int launch_schur_rows(const SchurArgs& a, int n_tasks, hipStream_t st);
 int launch_reduced_add_camera(int n_cams, const double* Hcc, const double* gc, double* S, int lda, double* rhs,
                               double* ex_diag, double* ex_gc, hipStream_t st);
 int launch_reduced_finalize(int n_cams, int n, const double* Hcc, const double* gc, const unsigned char* cam_fixed, double* S, int lda,
                             double* rhs, double* ex_diag, double* ex_gc, double* scale, int init_scale, int use_scaling,
-                            double radius, double dmin, double dmax, double* dc, hipStream_t st);
+                            double radius, double dmin, double dmax, double* dc, const double* scalars, int n_scalars,
+                            double* host_out, hipStream_t st);
 int launch_reduced_damp(int n, const double* dc, const unsigned char* cam_fixed, double* S, int lda, double* rhs,
                         hipStream_t st);
 int launch_backsub(int n_pts, const int* pt_start, const int* obs_cam, const double* J8, const unsigned char* omask,

@@ -4,6 +4,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -34,6 +35,18 @@ inline int fail(int code, const std::string& msg) {
     } while (0)
 
 int require_device();   // STBA_OK or STBA_ERR_NO_DEVICE (there is no CPU fallback)
+
+// Experiment knobs (environment variables) exist only in builds with -DSTBA_DEBUG_KNOBS (STBA_DEBUG_KNOBS=1 in the
+// environment of slam-tricks_amd/build.py); the product library reads no environment variables for its schedules.
+#ifdef STBA_DEBUG_KNOBS
+inline int knob_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+inline double knob_double(const char* name, double dflt) { const char* e = getenv(name); return e ? atof(e) : dflt; }
+inline const char* knob_str(const char* name) { return getenv(name); }
+#else
+inline int knob_int(const char*, int dflt) { return dflt; }
+inline double knob_double(const char*, double dflt) { return dflt; }
+inline const char* knob_str(const char*) { return nullptr; }
+#endif
 
 // runs fn once per DEVICE (function attributes such as the dynamic-LDS limit are per-device state), thread-safe
 struct DeviceOnce {

@@ -1166,6 +1166,14 @@ __device__ __forceinline__ void syrk_q32(double* __restrict__ A, int lda, int k0
     PHASE_STAMP(1);
 }
 
+// tickets, flags and tile versions of a factorisation, and the pivot flag, back to zero (one launch in front of the
+// persistent kernel instead of two memsets)
+__global__ __launch_bounds__(256) void chol_reset_kernel(int* __restrict__ sync, int n, int* __restrict__ flag) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) sync[i] = 0;
+    if (i == 0) flag[0] = 0;
+}
+
 // ---- the flag arrays behind the header of MegaArgs::sync, and the readiness test of a task ----
 struct MegaView {
     int nblk, nrow;
@@ -1405,18 +1413,6 @@ static std::vector<int> mega_row_owner(int nblk, int nq, int nvirt = 0) {
     }
     return owner;
 }
-// Debug knobs (scheduling experiments) exist only in builds with -DSTBA_DEBUG_KNOBS; the product library
-// reads no environment variables here.
-#ifdef STBA_DEBUG_KNOBS
-static int knob_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
-static double knob_double(const char* name, double dflt) { const char* e = getenv(name); return e ? atof(e) : dflt; }
-static const char* knob_str(const char* name) { return getenv(name); }
-#else
-static int knob_int(const char*, int dflt) { return dflt; }
-static double knob_double(const char*, double dflt) { return dflt; }
-static const char* knob_str(const char*) { return nullptr; }
-#endif
-
 // The ticket order is produced by LIST SCHEDULING a model of the machine on the host: `wg` workers per XCD queue, measured
 // task durations, and bottom-level priorities (longest path to the end of the graph, HLFET).  Sorting the tasks by the
 // time their model worker became free gives (i) one global topological order, which the deadlock argument needs, and
@@ -2008,8 +2004,8 @@ static int chol_run(double* A, int lda, int n, double* x_dev, int* flag_dev, hip
         memset(prof, 0, sizeof *prof);
     }
     auto mark = [&](size_t k) -> int { if (prof) STBA_HIP(hipEventRecord(ev[k], st)); return STBA_OK; };
-    STBA_HIP(hipMemsetAsync(flag_dev, 0, sizeof(int), st));
     if (stages) {
+        STBA_HIP(hipMemsetAsync(flag_dev, 0, sizeof(int), st));
         // STAGE KERNELS: one kernel per stage and panel, in order on the caller's stream.  The diagnostic schedule of
         // stba_cholesky_profile (per-class event times) and the FALLBACK of the persistent program: it needs nothing
         // resident, so it always finishes, whoever else uses the device (see chol_factor_solve_robust).
@@ -2052,7 +2048,7 @@ static int chol_run(double* A, int lda, int n, double* x_dev, int* flag_dev, hip
             plan.ntasks = (int)tasks.size();
             plan.nblk = nblk; plan.nwide = nwide;
         }
-        STBA_HIP(hipMemsetAsync(plan.sync, 0, plan.sync_ints * sizeof(int), st));
+        hipLaunchKernelGGL(chol_reset_kernel, dim3((unsigned)((plan.sync_ints + 255) / 256)), dim3(256), 0, st, plan.sync, (int)plan.sync_ints, flag_dev);
         MegaArgs ma;
         ma.A = A; ma.lda = lda; ma.n = n; ma.nblk = nblk;
         ma.tasks = plan.tasks; ma.nq = D.nq; ma.sync = plan.sync;

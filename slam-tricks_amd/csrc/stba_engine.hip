@@ -85,15 +85,13 @@ struct stba_ba {
     int *obs_cam = nullptr, *obs_pt = nullptr, *pt_start = nullptr;
     int *cam_perm = nullptr, *chunk_begin = nullptr, *chunk_end = nullptr, *cam_chunk_start = nullptr;
     int n_chunks = 0;
-    // row-wise Schur plan (empty => global-atomic fallback kernel)
-    int *task_cam = nullptr, *task_begin = nullptr, *task_end = nullptr, *row_col_ptr = nullptr, *row_cols = nullptr;
-    int *task_col_lo = nullptr, *task_col_hi = nullptr;      // a task's slice [lo, hi) of its camera row's column list
-    unsigned char* task_single = nullptr;
+    // Schur plan: task = (camera row, slice [lo, hi) of the row's column list), see stba_ba_create
+    int *task_cam = nullptr, *cam_start = nullptr, *row_col_ptr = nullptr, *row_cols = nullptr;
+    int *task_col_lo = nullptr, *task_col_hi = nullptr;
     int n_tasks = 0, max_cols = 0;
     // pair plan of the Schur kernel (see ba_schur_pairs_kernel)
     int *pair_begin = nullptr, *pair_end = nullptr;
     int4* pair_rec = nullptr;           // (i, l, landmark, slot | flags)
-    bool all_single = false;            // every camera row is ONE Schur task and every camera has a task
     unsigned char *cam_fixed = nullptr, *pt_fixed = nullptr;
     double2* r = nullptr;
     double* J8 = nullptr;            // compact Jacobian [n_obs][8] (ba_kernels.hip)
@@ -119,6 +117,7 @@ struct stba_ba {
     hipEvent_t ev[15] = {};     // [12]: the trial block has reached the host; [13], [14]: second pair for the speculative linearisation
     double* lin_pin = nullptr;      // pinned host copy of [scalars (SC_GPMAX0 + world) | gc (n)], read one solve later
     double* lin_pin_dev = nullptr;  // (its device address)
+    bool lin_exported = false;      // the last reduced-system build wrote lin_pin itself
 
     double* S() const { return Sbuf; }
     double* ex_diag() const { return Sbuf + (size_t)lda * lda; }
@@ -148,7 +147,7 @@ static void ba_free(stba_ba* b) {
     F(b->pt_start); F(b->cam_perm); F(b->chunk_begin); F(b->chunk_end); F(b->cam_chunk_start); F(b->cam_fixed);
     F(b->pt_fixed); F(b->r); F(b->J8); F(b->omask); F(b->Hpp6); F(b->gp); F(b->Hinv6); F(b->dp); F(b->scale_p);
     F(b->Hcc); F(b->gc); F(b->cam_partial); F(b->dc); F(b->scale_c); F(b->Sbuf); F(b->Spack); F(b->pk_blocks); F(b->dxc); F(b->dxp);
-    F(b->task_cam); F(b->task_begin); F(b->task_end); F(b->task_col_lo); F(b->task_col_hi); F(b->row_col_ptr); F(b->row_cols); F(b->task_single);
+    F(b->task_cam); F(b->cam_start); F(b->task_col_lo); F(b->task_col_hi); F(b->row_col_ptr); F(b->row_cols);
     F(b->pair_begin); F(b->pair_end); F(b->pair_rec);
     F(b->cost_partial); F(b->upd_partial_c); F(b->upd_partial_p); F(b->trial); F(b->flag);
     for (auto& e : b->ev) if (e) (void)hipEventDestroy(e);
@@ -181,8 +180,18 @@ static int ba_cost_only(stba_ba* b, int which, double* cost2_dev) {
     return launch_sum_partials(b->cost_partial, b->lin_grid, 1, 1, cost2_dev, b->st);
 }
 
+// landmark blocks Hpp, gp.  The CAMERA blocks Hcc, gc are made by the Schur kernel on the way (ba_build_reduced: the
+// workgroup of a camera row has that camera's Jacobian records in its caches anyway); only the stage entry point
+// stba_ba_normal_blocks, which hands them out without building the reduced system, runs the camera-side kernel.
 static int ba_normal_blocks(stba_ba* b) {
-    STBA_TRY(launch_point_blocks(b->np, b->pt_start, b->J8, b->omask, b->r, b->Hpp6, b->gp, b->st));
+    return launch_point_blocks(b->np, b->pt_start, b->J8, b->omask, b->r, b->Hpp6, b->gp, b->upd_partial_p, b->st);
+}
+// residuals + Jacobians of the LM loop: the cost partial sums stay in cost_partial and are added up by
+// ba_fill_scalar_slots behind the landmark blocks (one launch less than ba_linearize)
+static int ba_linearize_lm(stba_ba* b, int which) {
+    return launch_linearize(lin_args(b, which, true), true, b->lin_grid, b->st);
+}
+static int ba_camera_blocks(stba_ba* b) {
     return launch_camera_blocks(b->nc, b->n_chunks, b->chunk_begin, b->chunk_end, b->cam_chunk_start, b->cam_perm,
                                 b->J8, b->omask, b->r, b->cam_partial, b->Hcc, b->gc, b->st);
 }
@@ -233,7 +242,7 @@ __global__ __launch_bounds__(256) void blk_pack_kernel(double* __restrict__ Sbuf
 // non-zero blocks (a 0/1 mask of the nc(nc+1)/2 lower blocks, summed with the same hook) if it is sparse
 static int ba_plan_pack(stba_ba* b) {
     const size_t nb = (size_t)b->nc * (b->nc + 1) / 2;
-    static const bool SPARSE = [] { const char* e = getenv("STBA_PACK_BLOCKS"); return !e || atoi(e) != 0; }();
+    static const bool SPARSE = knob_int("STBA_PACK_BLOCKS", 1) != 0;
     b->pk_state = 1;
     if (SPARSE && !b->h_row_col_ptr.empty()) {
         std::vector<double> mask(nb, 0.0);
@@ -267,6 +276,15 @@ static int ba_plan_pack(stba_ba* b) {
     return STBA_OK;
 }
 
+// pinned, mapped host copy of [scalars (SC_GPMAX0 + world) | gc (n)] of a linearisation, read one solve later
+static int ba_lin_pin(stba_ba* b) {
+    if (b->lin_pin) return STBA_OK;
+    const size_t nh = (size_t)SC_GPMAX0 + b->world;
+    STBA_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->lin_pin), (nh + (size_t)b->n) * sizeof(double), hipHostMallocMapped));
+    STBA_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&b->lin_pin_dev), b->lin_pin, 0));
+    return STBA_OK;
+}
+
 // device time of the last cross-rank sum of the reduced system: read once its events have completed (after a
 // synchronisation of the stream; a pair still in flight is waited for -- only on the multi-rank path)
 static void ba_collect_allreduce_time(stba_ba* b) {
@@ -276,37 +294,39 @@ static void ba_collect_allreduce_time(stba_ba* b) {
     b->ar_timing_pending = false;
 }
 
-static int ba_build_reduced(stba_ba* b, const Damping& dm) {
+static int ba_build_reduced(stba_ba* b, const Damping& dm, bool export_host = false) {
+    b->lin_exported = false;
     const int init_scale = b->scale_init ? 0 : 1;
+    // (the three extras vectors behind S -- diag, gc, rhs -- are zeroed on the way; the scalar slots are kept)
+    double* extras = b->Sbuf + (size_t)b->lda * b->lda;
     if (!dm.explicit_d)
         STBA_TRY(launch_point_damp_invert(b->np, b->Hpp6, b->pt_fixed, b->scale_p, init_scale, dm.use_scaling, dm.radius, dm.dmin,
-                                          dm.dmax, b->dp, b->Hinv6, b->st));
-    else
+                                          dm.dmax, b->dp, b->Hinv6, extras, 3 * b->lda, b->st));
+    else {
         STBA_TRY(launch_point_invert(b->np, b->Hpp6, b->dp, b->pt_fixed, b->Hinv6, b->st));
-    // S is zeroed by the pair-plan Schur kernel itself when every camera row is one task; the three extras
-    // vectors behind it (diag, gc, rhs) always here (the scalar slots are kept)
-    const bool self_zero = b->pair_rec != nullptr && b->all_single;
-    if (self_zero) STBA_HIP(hipMemsetAsync(b->Sbuf + (size_t)b->lda * b->lda, 0, 3 * (size_t)b->lda * sizeof(double), b->st));
-    else STBA_HIP(hipMemsetAsync(b->Sbuf, 0, ((size_t)b->lda * b->lda + 3 * (size_t)b->lda) * sizeof(double), b->st));
-    if (b->n_tasks > 0) {
-        SchurRowArgs sa;
-        sa.task_cam = b->task_cam; sa.task_begin = b->task_begin; sa.task_end = b->task_end;
-        sa.task_col_lo = b->task_col_lo; sa.task_col_hi = b->task_col_hi;
-        sa.task_single = b->task_single; sa.row_col_ptr = b->row_col_ptr; sa.row_cols = b->row_cols;
-        sa.max_cols = b->max_cols; sa.cam_perm = b->cam_perm; sa.obs_cam = b->obs_cam; sa.obs_pt = b->obs_pt;
-        sa.pt_start = b->pt_start; sa.Jc = b->J8; sa.Jp = b->omask; sa.Hinv6 = b->Hinv6; sa.gp = b->gp;
-        sa.S = b->S(); sa.lda = b->lda; sa.rhs = b->rhs();
+        STBA_HIP(hipMemsetAsync(extras, 0, 3 * (size_t)b->lda * sizeof(double), b->st));
+    }
+    // S is zeroed by the Schur kernel itself (every task its own stretch of its six rows)
+    {
+        SchurArgs sa;
+        sa.task_cam = b->task_cam; sa.cam_start = b->cam_start; sa.task_col_lo = b->task_col_lo; sa.task_col_hi = b->task_col_hi;
+        sa.row_col_ptr = b->row_col_ptr; sa.row_cols = b->row_cols; sa.max_cols = b->max_cols; sa.cam_perm = b->cam_perm;
+        sa.J8 = b->J8; sa.omask = b->omask; sa.r = b->r; sa.Hinv6 = b->Hinv6; sa.gp = b->gp;
+        sa.S = b->S(); sa.lda = b->lda; sa.rhs = b->rhs(); sa.Hcc = b->Hcc; sa.gc = b->gc;
         sa.pair_begin = b->pair_begin; sa.pair_end = b->pair_end; sa.pair_rec = b->pair_rec;
-        sa.n_obs = b->no; sa.zero_rows = self_zero ? 1 : 0;
         STBA_TRY(launch_schur_rows(sa, b->n_tasks, b->st));
-    } else {
-        STBA_TRY(launch_schur(b->no, b->obs_cam, b->obs_pt, b->pt_start, b->J8, b->omask, b->Hinv6, b->gp, b->S(),
-                              b->lda, b->rhs(), b->st));
     }
     if (!b->ar && !dm.explicit_d && b->n == 6 * b->nc) {
         // one rank: camera blocks, LM diagonal, damping and padding in one launch
+        double* host_out = nullptr;
+        if (export_host) {          // (cost, |g|max slots and the gradient go to mapped host memory in the same launch)
+            STBA_TRY(ba_lin_pin(b));
+            host_out = b->lin_pin_dev;
+            b->lin_exported = true;
+        }
         STBA_TRY(launch_reduced_finalize(b->nc, b->n, b->Hcc, b->gc, b->cam_fixed, b->S(), b->lda, b->rhs(), b->ex_diag(), b->ex_gc(),
-                                         b->scale_c, init_scale, dm.use_scaling, dm.radius, dm.dmin, dm.dmax, b->dc, b->st));
+                                         b->scale_c, init_scale, dm.use_scaling, dm.radius, dm.dmin, dm.dmax, b->dc, b->ex_scalar(),
+                                         SC_GPMAX0 + b->world, host_out, b->st));
         b->scale_init = true;
         return STBA_OK;
     }
@@ -341,32 +361,31 @@ static int ba_build_reduced(stba_ba* b, const Damping& dm) {
 }
 
 // cost slot + per-rank |gp|_inf slot, filled before the reduced system is built
-static int ba_fill_scalar_slots(stba_ba* b, const double* cost2_dev) {
-    return launch_scalar_slots(b->gp, (size_t)3 * b->np, cost2_dev, b->ex_scalar(), b->lda, SC_COST2, SC_GPMAX0 + b->rank,
-                               b->upd_partial_p, (b->np + 255) / 256 + 1, b->st);
+// (behind ba_linearize_lm + ba_normal_blocks: the cost of the linearisation point -> *cost2_dev and the cost slot, the
+// |gp| maxima of the landmark-block workgroups -> this rank's slot, the rest of the scalar block zeroed)
+static int ba_fill_scalar_slots(stba_ba* b, double* cost2_dev) {
+    return launch_linear_finish(b->cost_partial, b->lin_grid, b->upd_partial_p, (b->np + 255) / 256, cost2_dev, b->ex_scalar(), b->lda,
+                                SC_COST2, SC_GPMAX0 + b->rank, b->st);
 }
 
-static int ba_trial(stba_ba* b) {
+// trial point: both manifold updates (one launch), the residual-only kernel, and ONE launch that finishes every sum of
+// the trial block -- and, when host_out is given (one rank, nobody watching), writes the block and the factorisation's
+// flag straight into mapped host memory: the host waits for an event behind it instead of a device-to-host copy + stream
+// synchronisation, and the stream can go on
+static int ba_trial(stba_ba* b, double* host_out) {
     const int cur = b->cur, nxt = cur ^ 1;
     const int cb = (b->nc + 255) / 256, pb = (b->np + 255) / 256;
     STBA_TRY(launch_update(b->nc, b->np, b->cams[cur], b->pts[cur], b->dxc, b->dxp, b->cam_fixed, b->pt_fixed,
                            b->ex_gc(), b->dc, b->gp, b->dp, b->cams[nxt], b->pts[nxt], b->upd_partial_c,
                            b->upd_partial_p, b->st));
-    static_assert(TS_STEP2 == 1 && TS_X2 == 2 && TS_MODEL == 3 && TS_CAM == 4 && TS_COUNT == 8, "trial_sums_kernel writes this layout");
-    STBA_TRY(launch_trial_sums(b->upd_partial_p, b->np > 0 ? pb : 0, b->upd_partial_c, cb, b->trial, b->st));
-    STBA_TRY(ba_cost_only(b, nxt, b->trial + TS_COST2));
+    static_assert(TS_COST2 == 0 && TS_STEP2 == 1 && TS_X2 == 2 && TS_MODEL == 3 && TS_CAM == 4 && TS_COUNT == 8, "trial_finish_kernel writes this layout");
+    STBA_TRY(launch_linearize(lin_args(b, nxt, false), false, b->lin_grid, b->st));
+    STBA_TRY(launch_trial_finish(b->cost_partial, b->lin_grid, b->upd_partial_p, b->np > 0 ? pb : 0, b->upd_partial_c, cb, b->flag, b->trial,
+                                 b->ar ? nullptr : host_out, b->st));
     if (b->ar) {
         if (b->ar(b->ar_user, b->trial, 4, b->st) != 0) return fail(STBA_ERR_CALLBACK, "all-reduce hook failed");
     }
     return STBA_OK;
-}
-
-// the trial block and the factorisation's flag, written straight into mapped host memory: the host waits for an event
-// behind this kernel instead of a device-to-host copy + stream synchronisation, and the stream can go on
-__global__ void export_trial_kernel(const double* __restrict__ trial, const int* __restrict__ flag, double* __restrict__ out) {
-    const int k = threadIdx.x;
-    if (k < TS_COUNT) out[k] = trial[k];
-    else if (k == TS_COUNT) out[k] = (double)flag[0];
 }
 
 struct LMState {
@@ -417,11 +436,9 @@ __global__ __launch_bounds__(256) void export_linear_kernel(const double* __rest
 // (written by a kernel into mapped host memory: two device-to-host copies here cost ~30 us of idle GPU between the
 // compute queue and the copy engine, in front of every factorisation)
 static int ba_request_linear_scalars(stba_ba* b) {
+    if (b->lin_exported) return STBA_OK;         // (the reduced-system build wrote them on the way)
     const size_t nh = (size_t)SC_GPMAX0 + b->world;
-    if (!b->lin_pin) {
-        STBA_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->lin_pin), (nh + (size_t)b->n) * sizeof(double), hipHostMallocMapped));
-        STBA_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&b->lin_pin_dev), b->lin_pin, 0));
-    }
+    STBA_TRY(ba_lin_pin(b));
     const int total = (int)nh + b->n;
     hipLaunchKernelGGL(export_linear_kernel, dim3((total + 255) / 256), dim3(256), 0, b->st, b->ex_scalar(), (int)nh, b->ex_gc(), b->n,
                        b->lin_pin_dev);
@@ -459,14 +476,14 @@ static int ba_run_lm(stba_ba* b, const stba_lm_options* opt_in, int fixed_iterat
 
     // ---- iteration 0: linearise at the start point
     STBA_HIP(hipEventRecord(ev[0], b->st));
-    STBA_TRY(ba_linearize(b, b->cur, b->trial + TS_COST2));
+    STBA_TRY(ba_linearize_lm(b, b->cur));
     STBA_TRY(ba_normal_blocks(b));
     STBA_HIP(hipEventRecord(ev[1], b->st));
     STBA_TRY(ba_fill_scalar_slots(b, b->trial + TS_COST2));
     bool need_build = true;      // reduced system must be (re)built before the next solve
     bool lin_timing_pending = true;
 
-    static const bool SPECULATE = [] { const char* e = getenv("STBA_LM_SPECULATE"); return !e || atoi(e) != 0; }();
+    static const bool SPECULATE = knob_int("STBA_LM_SPECULATE", 1) != 0;
     // deferred read of (cost, |g|max) of a freshly linearised point: only when nobody watches the iterations
     const bool deferred_ok = (cb == nullptr) && !opt.minimizer_progress_to_stdout;
     bool pending = false, pending_accepted = false;
@@ -519,27 +536,26 @@ static int ba_run_lm(stba_ba* b, const stba_lm_options* opt_in, int fixed_iterat
         STBA_HIP(hipEventRecord(ev[4], b->st));
         STBA_TRY(launch_backsub(b->np, b->pt_start, b->obs_cam, b->J8, b->omask, b->Hinv6, b->gp, b->dxc, b->dxp, b->st));
         STBA_HIP(hipEventRecord(ev[5], b->st));
-        STBA_TRY(ba_trial(b));
-        STBA_HIP(hipEventRecord(ev[6], b->st));
-        double ts[TS_COUNT];
         // Nobody watches the iterations and there is one rank: the host learns the trial point's scalars through mapped
         // memory and an event, and meanwhile the stream already linearises AT THE TRIAL POINT -- a step is accepted far
         // more often than not, and the host's round trip (wake-up, decision, enqueue: ~35 us) would otherwise be a
         // bubble on the GPU in every iteration.  A rejected step costs one linearisation at the old point (below).
         const bool fast = deferred_ok && !b->ar && SPECULATE;
+        if (fast && !b->ts_host) {
+            STBA_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->ts_host), (TS_COUNT + 1) * sizeof(double), hipHostMallocMapped));
+            STBA_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&b->ts_host_dev), b->ts_host, 0));
+        }
+        STBA_TRY(ba_trial(b, fast ? b->ts_host_dev : nullptr));
+        STBA_HIP(hipEventRecord(ev[6], b->st));
+        double ts[TS_COUNT];
         bool speculated = false;
         if (fast) {
-            if (!b->ts_host) {
-                STBA_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->ts_host), (TS_COUNT + 1) * sizeof(double), hipHostMallocMapped));
-                STBA_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&b->ts_host_dev), b->ts_host, 0));
-            }
-            hipLaunchKernelGGL(export_trial_kernel, dim3(1), dim3(64), 0, b->st, b->trial, b->flag, b->ts_host_dev);
             STBA_HIP(hipEventRecord(ev[12], b->st));
             if (!(fixed && iter >= max_iter)) {
                 // (its own pair of events, alternating: the previous linearisation's pair is read behind the synchronisation below)
                 spec_ev = (spec_ev == 8) ? 13 : 8;
                 STBA_HIP(hipEventRecord(ev[spec_ev], b->st));
-                STBA_TRY(ba_linearize(b, b->cur ^ 1, b->trial + TS_SPEC_COST2));
+                STBA_TRY(ba_linearize_lm(b, b->cur ^ 1));
                 STBA_TRY(ba_normal_blocks(b));
                 STBA_HIP(hipEventRecord(ev[spec_ev + 1], b->st));
                 STBA_TRY(ba_fill_scalar_slots(b, b->trial + TS_SPEC_COST2));
@@ -577,7 +593,7 @@ static int ba_run_lm(stba_ba* b, const stba_lm_options* opt_in, int fixed_iterat
             chol_note_timeout();
             if (++chol_timeouts > 3) return fail(STBA_ERR_HIP, "dense Cholesky: the persistent program timed out repeatedly");
             if (speculated) {       // (the speculative linearisation overwrote the current point's residuals, Jacobians and blocks)
-                STBA_TRY(ba_linearize(b, b->cur, b->trial + TS_COST2));
+                STBA_TRY(ba_linearize_lm(b, b->cur));
                 STBA_TRY(ba_normal_blocks(b));
                 STBA_TRY(ba_fill_scalar_slots(b, b->trial + TS_COST2));
             }
@@ -647,7 +663,7 @@ static int ba_run_lm(stba_ba* b, const stba_lm_options* opt_in, int fixed_iterat
             const int e0 = deferred_ok ? spec_ev : 0, e2 = deferred_ok ? 10 : 2;
             if (!(speculated && accepted)) {
                 STBA_HIP(hipEventRecord(ev[e0], b->st));
-                STBA_TRY(ba_linearize(b, b->cur, b->trial + TS_COST2));
+                STBA_TRY(ba_linearize_lm(b, b->cur));
                 STBA_TRY(ba_normal_blocks(b));
                 STBA_HIP(hipEventRecord(ev[e0 + 1], b->st));
                 STBA_TRY(ba_fill_scalar_slots(b, b->trial + TS_COST2));
@@ -656,7 +672,7 @@ static int ba_run_lm(stba_ba* b, const stba_lm_options* opt_in, int fixed_iterat
             // next reduced-system build (one collective per iteration); build it now.
             dm.radius = L.radius;
             STBA_HIP(hipEventRecord(ev[e2], b->st));
-            STBA_TRY(ba_build_reduced(b, dm));
+            STBA_TRY(ba_build_reduced(b, dm, deferred_ok));
             STBA_HIP(hipEventRecord(ev[e2 + 1], b->st));
             need_build = false;
             lin_timing_pending = false;
@@ -677,7 +693,7 @@ static int ba_run_lm(stba_ba* b, const stba_lm_options* opt_in, int fixed_iterat
         }
         else if (speculated && !accepted) {
             // the speculative linearisation overwrote the residuals, Jacobians and blocks of the current point
-            STBA_TRY(ba_linearize(b, b->cur, b->trial + TS_COST2));
+            STBA_TRY(ba_linearize_lm(b, b->cur));
             STBA_TRY(ba_normal_blocks(b));
             STBA_TRY(ba_fill_scalar_slots(b, b->trial + TS_COST2));
         }
@@ -776,7 +792,7 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
     }
     int rc = STBA_OK;
     auto bail = [&](int code) { ba_free(b); return code; };
-    static const bool TIMING = [] { const char* e = getenv("STBA_CREATE_TIMING"); return e && atoi(e) != 0; }();
+    static const bool TIMING = knob_int("STBA_CREATE_TIMING", 0) != 0;
     auto tc0 = std::chrono::steady_clock::now();
     auto tmark = [&](const char* what) {
         if (!TIMING) return;
@@ -828,20 +844,23 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
     cam_chunk_start[n_cams] = (int)chunk_begin.size();
     b->n_chunks = (int)chunk_begin.size();
     tmark("regroup observations");
-    // ---- row-wise Schur plan: distinct partner cameras c2 <= c of every camera row + tasks
-    std::vector<int> row_col_ptr(n_cams + 1, 0), row_cols, task_cam, task_begin, task_end, task_col_lo, task_col_hi;
-    std::vector<unsigned char> task_single;
-    int max_cols = 0, task_max_cols = 0;
-    bool every_cam_exclusive = true;                  // every camera row is covered by tasks that own their blocks alone
-    // the pair plan (one (i, l) pair per lane, see ba_schur_pairs_kernel) is used unless it would be huge
-    static const bool PAIRS = [] { const char* v = getenv("STBA_SCHUR_PAIRS"); return !v || atoi(v) != 0; }();
+    // ---- Schur plan.  Camera row c of the reduced system has one non-zero 6x6 block per partner camera c2 <= c it shares a
+    // landmark with; every (observation i of c, observation l of the same landmark with camera(l) <= c) PAIR contributes to
+    // one of them.  A task = (camera row, a slice of the row's sorted column list): it owns its blocks alone (one writer per
+    // block of S, no atomics on S, and the task zeroes its own stretch of the six matrix rows).  A slice holds at most
+    // SCHUR_SPLIT_COLS blocks (the LDS accumulator: two workgroups per CU) and at most SCHUR_TASK_PAIRS pairs (no limit
+    // by default: see the task order below).  The pairs of every task are enumerated here once (the structure is static).
+    std::vector<int> row_col_ptr(n_cams + 1, 0), row_cols, task_cam, task_col_lo, task_col_hi;
+    std::vector<size_t> task_pairs;
+    int task_max_cols = 0;
     size_t total_pairs = 0;
     for (int j = 0; j < n_pts; ++j) { const size_t k = (size_t)(pt_start[j + 1] - pt_start[j]); total_pairs += k * (k + 1) / 2; }
-    bool pair_plan = PAIRS && total_pairs <= ((size_t)1 << 27);          // > 2 GB of plan: keep the row kernel
+    if (total_pairs > ((size_t)1 << 30)) { ba_free(b); return fail(STBA_ERR_INVALID_ARGUMENT, "stba_ba_create: more than 2^30 observation pairs (16 GB of Schur plan)"); }
+    static const int TASK_PAIRS = std::max(256, knob_int("STBA_SCHUR_TASK_PAIRS", SCHUR_TASK_PAIRS));
     {
-        std::vector<std::vector<int>> cols_of((size_t)n_cams);
+        std::vector<std::vector<int>> cols_of((size_t)n_cams), cnt_of((size_t)n_cams);
         host_parallel_for(n_cams, [&](int c_lo, int c_hi, int) {
-            std::vector<int> stamp(n_cams, -1);
+            std::vector<int> stamp(n_cams, -1), slot_of((size_t)n_cams, 0);
             for (int c = c_lo; c < c_hi; ++c) {
                 std::vector<int>& tmp = cols_of[(size_t)c];
                 for (int p = cam_start[c]; p < cam_start[c + 1]; ++p) {
@@ -852,102 +871,87 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
                     }
                 }
                 std::sort(tmp.begin(), tmp.end());
+                for (size_t q = 0; q < tmp.size(); ++q) slot_of[(size_t)tmp[q]] = (int)q;
+                std::vector<int>& cnt = cnt_of[(size_t)c];
+                cnt.assign(tmp.size(), 0);
+                for (int p = cam_start[c]; p < cam_start[c + 1]; ++p) {
+                    const int j = s_pt[cam_perm[p]];
+                    for (int l = pt_start[j]; l < pt_start[j + 1]; ++l)
+                        if (s_cam[l] <= c) ++cnt[(size_t)slot_of[(size_t)s_cam[l]]];
+                }
             }
         });
         for (int c = 0; c < n_cams; ++c) {
             const std::vector<int>& tmp = cols_of[(size_t)c];
+            const std::vector<int>& cnt = cnt_of[(size_t)c];
             row_cols.insert(row_cols.end(), tmp.begin(), tmp.end());
             row_col_ptr[c + 1] = (int)row_cols.size();
             const int ncols_c = (int)tmp.size();
-            max_cols = std::max(max_cols, ncols_c);
-            const int nobs_c = cam_start[c + 1] - cam_start[c];
-            const int nt = (nobs_c + SCHUR_TASK_OBS - 1) / SCHUR_TASK_OBS;
-            if (nt != 1) every_cam_exclusive = false;
-            // a wide row is split by COLUMN range (pair plan only): each piece owns its blocks alone, and its LDS
-            // accumulator is small enough for two workgroups per CU (the kernel is bound by LDS atomics and by the
-            // barrier behind them: one workgroup per CU leaves the CU idle a third of the time)
-            const int nsplit = (pair_plan && nt == 1 && ncols_c > SCHUR_SPLIT_COLS) ? (ncols_c + SCHUR_SPLIT_COLS - 1) / SCHUR_SPLIT_COLS : 1;
-            for (int k = 0; k < nt; ++k)
-                for (int sp = 0; sp < nsplit; ++sp) {
-                    task_cam.push_back(c);
-                    task_begin.push_back(cam_start[c] + k * SCHUR_TASK_OBS);
-                    task_end.push_back(std::min(cam_start[c] + (k + 1) * SCHUR_TASK_OBS, cam_start[c + 1]));
-                    task_single.push_back(nt == 1 ? 1 : 0);
-                    task_col_lo.push_back((int)((long)ncols_c * sp / nsplit));
-                    task_col_hi.push_back((int)((long)ncols_c * (sp + 1) / nsplit));
-                    task_max_cols = std::max(task_max_cols, task_col_hi.back() - task_col_lo.back());
+            int lo = 0;
+            size_t acc = 0;
+            for (int q = 0; q <= ncols_c; ++q) {
+                // close the slice in front of column q when it is full, and at the end of the row (a camera without
+                // observations still gets one empty task: it zeroes its rows and writes its zero camera block)
+                const bool end = q == ncols_c;
+                const bool full = !end && q > lo && (acc + (size_t)cnt[(size_t)q] > (size_t)TASK_PAIRS || q - lo >= SCHUR_SPLIT_COLS);
+                if (full || end) {
+                    task_cam.push_back(c); task_col_lo.push_back(lo); task_col_hi.push_back(q); task_pairs.push_back(acc);
+                    task_max_cols = std::max(task_max_cols, q - lo);
+                    lo = q; acc = 0;
                 }
+                if (!end) acc += (size_t)cnt[(size_t)q];
+            }
         }
-        // heaviest tasks first (more partners, more observations) for a better tail
+        // Task order: heaviest first (most pairs), for a short tail.  (Measured against it in round 3, C5, Schur kernel
+        // 0.324 ms: the cameras in trajectory order 0.39 ms; cut into eight contiguous ranges walked by one XCD each, so that
+        // the workgroups side by side on an XCD gather the same records, 0.39-0.40 ms -- the tail costs more than the L2
+        // hits bring.  Slices cut to 3072 / 4096 / 6144 / 8192 pairs: 0.49 / 0.37 / 0.34 / 0.34 ms: a task's fixed costs --
+        // zeroing its accumulator and its rows, the block stores -- outweigh the better balance.)
         std::vector<int> order(task_cam.size());
         for (size_t k = 0; k < order.size(); ++k) order[k] = (int)k;
-        std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
-            const long wx = (long)(task_end[x] - task_begin[x]) * (task_col_hi[x] - task_col_lo[x]);
-            const long wy = (long)(task_end[y] - task_begin[y]) * (task_col_hi[y] - task_col_lo[y]);
-            return wx > wy;
-        });
-        auto permute = [&](auto& v) { auto t = v; for (size_t k = 0; k < order.size(); ++k) v[k] = t[order[k]]; };
-        permute(task_cam); permute(task_begin); permute(task_end); permute(task_single); permute(task_col_lo); permute(task_col_hi);
+        std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return task_pairs[(size_t)x] > task_pairs[(size_t)y]; });
+        auto permute = [&](auto& v) { auto t = v; for (size_t k = 0; k < order.size(); ++k) v[k] = t[(size_t)order[k]]; };
+        permute(task_cam); permute(task_col_lo); permute(task_col_hi); permute(task_pairs);
     }
     tmark("row plan");
-    const bool row_plan = task_max_cols <= SCHUR_MAX_COLS;
-    b->n_tasks = row_plan ? (int)task_cam.size() : 0;
+    b->n_tasks = (int)task_cam.size();
     b->max_cols = task_max_cols;
-    b->all_single = row_plan && every_cam_exclusive;     // every block of S has exactly one writer: the Schur kernel can zero its rows itself
-    // pair plan: (i, l, landmark, slot) of every block contribution of every task, in task order
+    // pair records (i, l, landmark, slot | flags) of every task, in task order
     std::vector<int> pair_begin, pair_end;
     std::vector<int4> pair_rec;
-    pair_plan = pair_plan && row_plan && task_max_cols < 0x4000;
-    if (pair_plan) {
+    {
         const int ntask = (int)task_cam.size();
         pair_begin.resize((size_t)ntask); pair_end.resize((size_t)ntask);
-        // pass 1: pairs per task; pass 2: fill (both over independent tasks, on a few threads)
         std::vector<size_t> cnt((size_t)ntask + 1, 0);
+        for (int k = 0; k < ntask; ++k) cnt[(size_t)k + 1] = cnt[(size_t)k] + task_pairs[(size_t)k];
+        pair_rec.resize(cnt[(size_t)ntask]);
         host_parallel_for(ntask, [&](int k_lo, int k_hi, int) {
+            std::vector<int> slot_of((size_t)n_cams, 0);
             for (int k = k_lo; k < k_hi; ++k) {
                 const int c = task_cam[(size_t)k];
-                // the task's column slice is a range of partner cameras [c2_lo, c2_hi]
                 const int* cb = row_cols.data() + row_col_ptr[c];
-                const int c2_lo = cb[task_col_lo[(size_t)k]], c2_hi = cb[task_col_hi[(size_t)k] - 1];
-                size_t m = 0;
-                for (int p = task_begin[(size_t)k]; p < task_end[(size_t)k]; ++p) {
-                    const int j = s_pt[cam_perm[p]];
-                    for (int l = pt_start[j]; l < pt_start[j + 1]; ++l) m += (s_cam[l] >= c2_lo && s_cam[l] <= c2_hi) ? 1 : 0;
+                const int nco = row_col_ptr[c + 1] - row_col_ptr[c];
+                for (int q = 0; q < nco; ++q) slot_of[(size_t)cb[q]] = q;
+                const int slo = task_col_lo[(size_t)k], shi = task_col_hi[(size_t)k];
+                size_t w = cnt[(size_t)k];
+                pair_begin[(size_t)k] = (int)w;
+                for (int p = cam_start[c]; p < cam_start[c + 1]; ++p) {
+                    const int i = cam_perm[p];
+                    const int j = s_pt[i];
+                    for (int l = pt_start[j]; l < pt_start[j + 1]; ++l) {
+                        const int c2 = s_cam[l];
+                        if (c2 > c) continue;
+                        const int sl = slot_of[(size_t)c2];
+                        if (sl < slo || sl >= shi) continue;
+                        pair_rec[w] = make_int4(i, l, j, (sl - slo) | (c2 == c ? 0x8000 : 0) | (l == i ? 0x4000 : 0));
+                        ++w;
+                    }
                 }
-                cnt[(size_t)k + 1] = m;
+                pair_end[(size_t)k] = (int)w;
+                // (dealing the records out so that every 32 consecutive ones hit 32 different LDS bank pairs was measured:
+                // the bank conflicts it removes cost less than the locality of the landmark-major order it destroys)
             }
         });
-        for (int k = 0; k < ntask; ++k) cnt[(size_t)k + 1] += cnt[(size_t)k];
-        if (pair_plan) {
-            pair_rec.resize(cnt[(size_t)ntask]);
-            host_parallel_for(ntask, [&](int k_lo, int k_hi, int) {
-                std::vector<int> slot_of((size_t)n_cams, 0);
-                for (int k = k_lo; k < k_hi; ++k) {
-                    const int c = task_cam[(size_t)k];
-                    const int* cb = row_cols.data() + row_col_ptr[c];
-                    const int nco = row_col_ptr[c + 1] - row_col_ptr[c];
-                    for (int q = 0; q < nco; ++q) slot_of[(size_t)cb[q]] = q;
-                    const int slo = task_col_lo[(size_t)k], shi = task_col_hi[(size_t)k];
-                    size_t w = cnt[(size_t)k];
-                    pair_begin[(size_t)k] = (int)w;
-                    for (int p = task_begin[(size_t)k]; p < task_end[(size_t)k]; ++p) {
-                        const int i = cam_perm[p];
-                        const int j = s_pt[i];
-                        for (int l = pt_start[j]; l < pt_start[j + 1]; ++l) {
-                            const int c2 = s_cam[l];
-                            if (c2 > c) continue;
-                            const int sl = slot_of[(size_t)c2];
-                            if (sl < slo || sl >= shi) continue;
-                            pair_rec[w] = make_int4(i, l, j, (sl - slo) | (c2 == c ? 0x8000 : 0) | (l == i ? 0x4000 : 0));
-                            ++w;
-                        }
-                    }
-                    pair_end[(size_t)k] = (int)w;
-                    // (dealing the records out so that every 32 consecutive ones hit 32 different LDS bank pairs was measured:
-                    // the bank conflicts it removes cost less than the locality of the landmark-major order it destroys)
-                }
-            });
-        }
     }
     tmark("pair plan");
     std::vector<unsigned char> cmask;
@@ -972,16 +976,11 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
     A_(dev_alloc(&b->pt_start, np + 1)); A_(dev_alloc(&b->cam_perm, no));
     A_(dev_alloc(&b->chunk_begin, (size_t)b->n_chunks)); A_(dev_alloc(&b->chunk_end, (size_t)b->n_chunks));
     A_(dev_alloc(&b->cam_chunk_start, nc + 1));
-    if (b->n_tasks > 0) {
-        A_(dev_alloc(&b->task_cam, task_cam.size())); A_(dev_alloc(&b->task_begin, task_cam.size()));
-        A_(dev_alloc(&b->task_end, task_cam.size())); A_(dev_alloc(&b->task_single, task_cam.size()));
-        A_(dev_alloc(&b->task_col_lo, task_cam.size())); A_(dev_alloc(&b->task_col_hi, task_cam.size()));
-        A_(dev_alloc(&b->row_col_ptr, nc + 1)); A_(dev_alloc(&b->row_cols, row_cols.size()));
-        if (pair_plan && !pair_rec.empty()) {
-            A_(dev_alloc(&b->pair_begin, pair_begin.size())); A_(dev_alloc(&b->pair_end, pair_end.size()));
-            A_(dev_alloc(&b->pair_rec, pair_rec.size()));
-        }
-    }
+    A_(dev_alloc(&b->task_cam, task_cam.size())); A_(dev_alloc(&b->cam_start, nc + 1));
+    A_(dev_alloc(&b->task_col_lo, task_cam.size())); A_(dev_alloc(&b->task_col_hi, task_cam.size()));
+    A_(dev_alloc(&b->row_col_ptr, nc + 1)); A_(dev_alloc(&b->row_cols, std::max<size_t>(row_cols.size(), 1)));
+    A_(dev_alloc(&b->pair_begin, pair_begin.size())); A_(dev_alloc(&b->pair_end, pair_end.size()));
+    A_(dev_alloc(&b->pair_rec, std::max<size_t>(pair_rec.size(), 1)));
     if (cam_fixed) A_(dev_alloc(&b->cam_fixed, nc));
     if (pt_fixed) A_(dev_alloc(&b->pt_fixed, np));
     A_(dev_alloc(&b->r, no)); A_(dev_alloc(&b->J8, no * 8));
@@ -1005,21 +1004,15 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
     A_(upload(b->chunk_begin, chunk_begin.data(), (size_t)b->n_chunks, b->st));
     A_(upload(b->chunk_end, chunk_end.data(), (size_t)b->n_chunks, b->st));
     A_(upload(b->cam_chunk_start, cam_chunk_start.data(), nc + 1, b->st));
-    if (b->n_tasks > 0) {
-        A_(upload(b->task_cam, task_cam.data(), task_cam.size(), b->st));
-        A_(upload(b->task_begin, task_begin.data(), task_cam.size(), b->st));
-        A_(upload(b->task_end, task_end.data(), task_cam.size(), b->st));
-        A_(upload(b->task_single, task_single.data(), task_cam.size(), b->st));
-        A_(upload(b->task_col_lo, task_col_lo.data(), task_cam.size(), b->st));
-        A_(upload(b->task_col_hi, task_col_hi.data(), task_cam.size(), b->st));
-        b->h_row_col_ptr = row_col_ptr; b->h_row_cols = row_cols;
-        A_(upload(b->row_col_ptr, row_col_ptr.data(), nc + 1, b->st));
-        A_(upload(b->row_cols, row_cols.data(), row_cols.size(), b->st));
-        if (b->pair_rec) {
-            A_(upload(b->pair_begin, pair_begin.data(), pair_begin.size(), b->st)); A_(upload(b->pair_end, pair_end.data(), pair_end.size(), b->st));
-            A_(upload(b->pair_rec, pair_rec.data(), pair_rec.size(), b->st));
-        }
-    }
+    A_(upload(b->task_cam, task_cam.data(), task_cam.size(), b->st));
+    A_(upload(b->cam_start, cam_start.data(), nc + 1, b->st));
+    A_(upload(b->task_col_lo, task_col_lo.data(), task_cam.size(), b->st));
+    A_(upload(b->task_col_hi, task_col_hi.data(), task_cam.size(), b->st));
+    b->h_row_col_ptr = row_col_ptr; b->h_row_cols = row_cols;
+    A_(upload(b->row_col_ptr, row_col_ptr.data(), nc + 1, b->st));
+    if (!row_cols.empty()) A_(upload(b->row_cols, row_cols.data(), row_cols.size(), b->st));
+    A_(upload(b->pair_begin, pair_begin.data(), pair_begin.size(), b->st)); A_(upload(b->pair_end, pair_end.data(), pair_end.size(), b->st));
+    if (!pair_rec.empty()) A_(upload(b->pair_rec, pair_rec.data(), pair_rec.size(), b->st));
     if (cam_fixed) A_(upload(b->cam_fixed, cmask.data(), nc, b->st));
     std::vector<unsigned char> omask;
     if (b->omask) {
@@ -1127,6 +1120,7 @@ int stba_ba_normal_blocks(stba_ba* b, double* Hcc, double* gc, double* Hpp, doub
     if (!b) return fail(STBA_ERR_INVALID_ARGUMENT, "null engine");
     if (!b->have_lin) return fail(STBA_ERR_STATE, "stba_ba_normal_blocks needs stba_ba_evaluate first");
     STBA_TRY(ba_normal_blocks(b));
+    STBA_TRY(ba_camera_blocks(b));
     std::vector<double> h6;
     if (Hcc) STBA_TRY(download(Hcc, b->Hcc, (size_t)b->nc * 36, b->st));
     if (gc) STBA_TRY(download(gc, b->gc, (size_t)b->nc * 6, b->st));
@@ -1189,7 +1183,7 @@ int stba_ba_back_substitute(stba_ba* b, double* dxp) {
 int stba_ba_apply_step(stba_ba* b, int accept, double* new_cost) {
     if (!b) return fail(STBA_ERR_INVALID_ARGUMENT, "null engine");
     if (!b->have_dxp) return fail(STBA_ERR_STATE, "stba_ba_apply_step needs stba_ba_back_substitute first");
-    STBA_TRY(ba_trial(b));
+    STBA_TRY(ba_trial(b, nullptr));
     double ts[TS_COUNT];
     STBA_TRY(download(ts, b->trial, TS_COUNT, b->st));
     STBA_HIP(hipStreamSynchronize(b->st));
