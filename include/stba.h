@@ -311,6 +311,9 @@ int stba_pg_set_comm(stba_pg* pg, stba_comm* comm);
 int stba_pg_get_poses(stba_pg* pg, double* poses);
 /* r[n_edges*6], Ji / Jj [n_edges*36] (6x6 row-major, wrt delta_i / delta_j); any may be NULL */
 int stba_pg_evaluate(stba_pg* pg, double* cost, double* r, double* Ji, double* Jj);
+/* measurement: average device time (hipEvents on the engine's stream, `reps` launches each) of the residual + Jacobian
+ * kernel and of one matrix-free product q = (J^T J + D) p */
+int stba_pg_time_kernels(stba_pg* pg, int reps, double* ms_linearize, double* ms_matvec);
 int stba_pg_solve(stba_pg* pg, const stba_lm_options* opt, const stba_pcg_options* pcg, stba_lm_summary* summary,
                   double* trace, int* pcg_iterations_total);
 

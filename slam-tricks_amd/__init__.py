@@ -69,7 +69,7 @@ EXPORTS = ["stba_status_string", "stba_last_error", "stba_version", "stba_device
            "stba_ba_triangulate", "stba_ba_time_linearize", "stba_cholesky_factor", "stba_cholesky_solve",
            "stba_cholesky_time", "stba_cholesky_time_split", "stba_cholesky_schedule_model", "stba_cholesky_timeout_count", "stba_cholesky_set_timeout_us", "stba_cholesky_shard_model", "stba_cholesky_shard_owner", "stba_cholesky_profile", "stba_calib_evaluate", "stba_calib_gauss_newton",
            "stba_pcg_default_options", "stba_pg_create", "stba_pg_destroy", "stba_pg_set_allreduce", "stba_pg_get_poses", "stba_pg_evaluate",
-           "stba_pg_solve", "stba_dense_solve", "stba_corners_read", "stba_corners_write", "stba_zhang_init", "stba_two_view_init", "stba_odometry_read", "stba_odometry_write", "stba_trajectory_ate",
+           "stba_pg_solve", "stba_pg_time_kernels", "stba_dense_solve", "stba_corners_read", "stba_corners_write", "stba_zhang_init", "stba_two_view_init", "stba_odometry_read", "stba_odometry_write", "stba_trajectory_ate",
            "stba_comm_unique_id", "stba_comm_create", "stba_comm_destroy", "stba_comm_rank", "stba_comm_allreduce_sum",
            "stba_comm_allreduce_hook", "stba_ba_set_comm", "stba_pg_set_comm"]
 
@@ -325,6 +325,12 @@ class PGEngine:
         Jj = np.zeros((self.m, 6, 6)) if jac else None
         _chk(lib().stba_pg_evaluate(self._h, C.byref(cost), _p(r), _p(Ji), _p(Jj)), "stba_pg_evaluate")
         return cost.value, r, Ji, Jj
+
+    def time_kernels(self, reps=50):
+        """(ms per residual+Jacobian launch, ms per matrix-free product), hipEvent-timed on the device"""
+        a, b = C.c_double(), C.c_double()
+        _chk(lib().stba_pg_time_kernels(self._h, int(reps), C.byref(a), C.byref(b)), "stba_pg_time_kernels")
+        return a.value, b.value
 
     def solve(self, opt=None, pcg=None, **kw):
         opt = opt or default_options(**kw)

@@ -1879,7 +1879,9 @@ struct MegaDevice {
     bool probed = false;
     int ncu = 0, nq = 0;                // CUs of the device, XCDs seen by the probe
     signed char xcc_queue[16];
-    hipEvent_t last = nullptr;
+    hipEvent_t last = nullptr;          // behind the most recent persistent kernel of this device ...
+    hipStream_t last_stream = nullptr;  // ... which ran on this stream
+    bool last_recorded = false;
     int cooldown = 0;                   // factorisations that take the stage kernels after a time-out of the persistent program
 };
 static MegaDevice& mega_device(int dev) {
@@ -2071,9 +2073,12 @@ static int chol_run(double* A, int lda, int n, double* x_dev, int* flag_dev, hip
                                          hipFuncAttributeMaxDynamicSharedMemorySize, MEGA_SMEM_BYTES));
             return STBA_OK;
         }));
-        STBA_HIP(hipStreamWaitEvent(st, D.last, 0));
+        // (the previous factorisation of this device, if it went to ANOTHER stream, must have finished; on the same stream the
+        // order is there already -- and a wait on an event costs ~10 us of idle GPU even when the event has long fired)
+        if (D.last_stream != st && D.last_recorded) STBA_HIP(hipStreamWaitEvent(st, D.last, 0));
         hipLaunchKernelGGL(chol_mega_kernel, dim3(D.ncu), dim3(512), MEGA_SMEM_BYTES, st, ma);
         STBA_HIP(hipEventRecord(D.last, st));
+        D.last_stream = st; D.last_recorded = true;
         if (TRACE) {    // debugging aid: dump the task timeline of this factorisation (tools/mega_trace.py)
             std::vector<long long> h((size_t)plan.ntasks * 8);
             std::vector<int4> ht((size_t)plan.ntasks);

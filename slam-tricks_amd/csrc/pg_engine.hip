@@ -543,6 +543,32 @@ int stba_pg_evaluate(stba_pg* g, double* cost, double* r, double* Ji, double* Jj
     return STBA_OK;
 }
 
+// measurement (bench.py --config c4): hipEvent-timed averages of the two kernels a solve is made of -- the residual +
+// Jacobian kernel and one matrix-free product q = (J^T J + D) p (diagonal term + edge kernel) -- on the engine's stream
+int stba_pg_time_kernels(stba_pg* g, int reps, double* ms_linearize, double* ms_matvec) {
+    if (!g || reps <= 0 || !ms_linearize || !ms_matvec) return fail(STBA_ERR_INVALID_ARGUMENT, "bad argument");
+    hipEvent_t e0, e1, e2;
+    STBA_HIP(hipEventCreate(&e0)); STBA_HIP(hipEventCreate(&e1)); STBA_HIP(hipEventCreate(&e2));
+    STBA_TRY(pg_linearize(g, g->cur, true));            // warm-up; also makes the Jacobians the products use
+    STBA_HIP(hipMemsetAsync(g->p, 0, (size_t)6 * g->n * sizeof(double), g->st));
+    STBA_HIP(hipMemsetAsync(g->d, 0, (size_t)6 * g->n * sizeof(double), g->st));
+    stba_allreduce_fn ar = g->ar;
+    g->ar = nullptr;                                    // (kernel time only: no collective inside the timed region)
+    int rc = pg_apply(g, g->p, g->q, true);
+    if (rc == STBA_OK && hipEventRecord(e0, g->st) != hipSuccess) rc = fail(STBA_ERR_HIP, "hipEventRecord");
+    for (int k = 0; k < reps && rc == STBA_OK; ++k) rc = pg_linearize(g, g->cur, true);
+    if (rc == STBA_OK && hipEventRecord(e1, g->st) != hipSuccess) rc = fail(STBA_ERR_HIP, "hipEventRecord");
+    for (int k = 0; k < reps && rc == STBA_OK; ++k) rc = pg_apply(g, g->p, g->q, true);
+    if (rc == STBA_OK && hipEventRecord(e2, g->st) != hipSuccess) rc = fail(STBA_ERR_HIP, "hipEventRecord");
+    g->ar = ar;
+    if (rc == STBA_OK && hipStreamSynchronize(g->st) != hipSuccess) rc = fail(STBA_ERR_HIP, "hipStreamSynchronize");
+    float a = 0.f, b = 0.f;
+    if (rc == STBA_OK) { (void)hipEventElapsedTime(&a, e0, e1); (void)hipEventElapsedTime(&b, e1, e2); }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
+    *ms_linearize = a / reps; *ms_matvec = b / reps;
+    return rc;
+}
+
 int stba_pg_solve(stba_pg* g, const stba_lm_options* opt_in, const stba_pcg_options* pcg_in, stba_lm_summary* summary,
                   double* trace, int* pcg_iterations_total) {
     if (!g) return fail(STBA_ERR_INVALID_ARGUMENT, "null engine");
