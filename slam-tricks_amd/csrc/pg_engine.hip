@@ -269,10 +269,22 @@ __global__ __launch_bounds__(256) void pg_dot_kernel(int n, const double* __rest
     if (threadIdx.x == 0) { partial[blockIdx.x * 2] = out2[0]; partial[blockIdx.x * 2 + 1] = out2[1]; }
 }
 
+// sum of nb per-workgroup partials, by the WHOLE workgroup (256 threads): a strided share per thread, a shuffle tree per
+// wave, the four waves in order -- the same order in every workgroup and on every rank, so every one of them gets the same
+// bits.  (Every thread summing all partials serially -- 275 dependent loads -- made pg_pcg_update_kernel 27.5 us long, 40 %
+// of a PCG iteration: profiles/r3_a_c4_kernel_stats.csv.)
 __device__ inline double sum_partials_dev(const double* partial, int nb, int stride, int off) {
-    double s = 0.0;
-    for (int k = 0; k < nb; ++k) s += partial[k * stride + off];   // same order in every block: deterministic
-    return s;
+    __shared__ double s_w[4];
+    __shared__ double s_tot;
+    double v = 0.0;
+    for (int k = threadIdx.x; k < nb; k += 256) v += partial[k * stride + off];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    __syncthreads();                                     // (the shared slots may still be read from a previous call)
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) s_tot = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+    __syncthreads();
+    return s_tot;
 }
 
 // scal: [0] rz, [1] rr, [2] pq   (device-resident PCG scalars)
@@ -550,8 +562,12 @@ int stba_pg_time_kernels(stba_pg* g, int reps, double* ms_linearize, double* ms_
     hipEvent_t e0, e1, e2;
     STBA_HIP(hipEventCreate(&e0)); STBA_HIP(hipEventCreate(&e1)); STBA_HIP(hipEventCreate(&e2));
     STBA_TRY(pg_linearize(g, g->cur, true));            // warm-up; also makes the Jacobians the products use
-    STBA_HIP(hipMemsetAsync(g->p, 0, (size_t)6 * g->n * sizeof(double), g->st));
-    STBA_HIP(hipMemsetAsync(g->d, 0, (size_t)6 * g->n * sizeof(double), g->st));
+    // (a non-zero direction and damping -- the gradient of this linearisation, unit damping -- so that the product does the
+    // atomics a real one does)
+    STBA_HIP(hipMemsetAsync(g->g, 0, (size_t)g->n * 42 * sizeof(double), g->st));
+    hipLaunchKernelGGL(pg_accumulate_kernel, dim3((2 * g->m + 255) / 256), dim3(256), 0, g->st, g->m, g->ei, g->ej, g->r, g->Ji, g->Jj, g->g, g->Hd);
+    STBA_HIP(hipMemcpyAsync(g->p, g->g, (size_t)6 * g->n * sizeof(double), hipMemcpyDeviceToDevice, g->st));
+    STBA_HIP(hipMemcpyAsync(g->d, g->g, (size_t)6 * g->n * sizeof(double), hipMemcpyDeviceToDevice, g->st));
     stba_allreduce_fn ar = g->ar;
     g->ar = nullptr;                                    // (kernel time only: no collective inside the timed region)
     int rc = pg_apply(g, g->p, g->q, true);
