@@ -357,9 +357,17 @@ def main():
                    "collective": collective, "n_cams": n_cams, "n_pts": n_pts, "n_obs": n_obs},
         "final_cost": summ.final_cost,
     }
-    # device time per phase of the LAST repetition (hipEvents on the engine's stream), per step; with several ranks the
-    # MAXIMUM over ranks, plus what explains an N > 1 line: the cross-rank sum's device time and bytes per step and the
-    # observations each rank holds (the Cholesky of the reduced system is replicated on every rank: DESIGN.md 6)
+    # Device time per phase: ONE MORE run of K steps with stba_lm_options::phase_timing on (hipEvents between the phases; the
+    # timed repetitions above run without them: an event record costs ~5 us of idle GPU and an iteration would take eight),
+    # per step; with several ranks the MAXIMUM over ranks, plus what explains an N > 1 line: the cross-rank sum's device time
+    # and bytes per step and the observations each rank holds (the Cholesky of the reduced system is replicated on every
+    # rank: DESIGN.md 6)
+    eng.set_params(sh["cams0"], sh["pts0"])
+    sync()
+    t0 = time.perf_counter()
+    summ, _ = eng.lm_iterations(args.steps, phase_timing=1)
+    sync()
+    out["instrumented_ms_per_step"] = 1e3 * (time.perf_counter() - t0) / args.steps
     phase_keys = ("ms_linearize", "ms_schur", "ms_solve", "ms_backsub", "ms_cost", "ms_allreduce")
     phases = np.array([getattr(summ, k) / args.steps for k in phase_keys], dtype=np.float64)
     local_counts = np.zeros(world, dtype=np.float64)
@@ -373,7 +381,7 @@ def main():
         dist.all_reduce(tc)
         local_counts = tc.cpu().numpy()
     out["phase_ms_per_step"] = {k: float(v) for k, v in zip(phase_keys[:5], phases[:5])}
-    out["phase_ms_per_step"]["timing"] = "hipEvents on the engine stream, last repetition" + (", max over ranks" if world > 1 else "")
+    out["phase_ms_per_step"]["timing"] = "hipEvents on the engine stream, a separate instrumented run (instrumented_ms_per_step)" + (", max over ranks" if world > 1 else "")
     out["allreduce_ms"] = float(phases[5])                      # per step, inside ms_schur
     out["allreduce_bytes"] = float(summ.allreduce_bytes / max(1, summ.allreduce_calls))      # per call and rank
     out["allreduce_calls_per_step"] = float(summ.allreduce_calls / args.steps)
@@ -421,6 +429,19 @@ def main():
                      "algorithmic_flops_per_launch": chol_flops, "launches_per_lm_iteration": 1,
                      "microbench_ceiling": FP64_MFMA_MEASURED_CEILING_TFLOPS,
                      "frac_of_microbench_ceiling": chol_tflops / FP64_MFMA_MEASURED_CEILING_TFLOPS}
+        # the Schur-complement kernel: bound by LDS FP64 atomics (ds_add_f64 into the 6x6 accumulator blocks of a camera
+        # row).  Peak = what the microbenchmark retires with THIS address pattern (random block per lane, 36 consecutive
+        # doubles, 37-double block stride): profiles/lds_atomic_f64_microbench.txt, 2.38 lane-ops per cycle and CU
+        ms_schur, schur_atomics, schur_pairs = eng.time_schur(10)
+        LDS_ATOMIC_PEAK = 1459.2      # G lane-ops/s, all 256 CUs, Schur pattern (7.5 per cycle and CU without conflicts: 4617 G/s)
+        out["roofline_schur"] = {"kernel": "ba_schur_pairs_kernel (row-wise Schur complement, LDS accumulation; camera blocks on the way)",
+                                 "bound": "lds-atomic", "achieved": schur_atomics / (ms_schur * 1e-3) / 1e9, "peak": LDS_ATOMIC_PEAK,
+                                 "unit": "G ds_add_f64 lane-ops/s", "frac": schur_atomics / (ms_schur * 1e-3) / 1e9 / LDS_ATOMIC_PEAK,
+                                 "ms_per_launch": ms_schur, "lds_atomics_per_launch": schur_atomics, "pairs_per_launch": schur_pairs,
+                                 "floor_ms": schur_atomics / (LDS_ATOMIC_PEAK * 1e9) * 1e3,
+                                 "traffic": 923.1e6 if local_obs == 1000000 else None,
+                                 "traffic_source": "profiles/r2_a_pmc_assembly_kernels.json (FETCH_SIZE 738 MB + WRITE_SIZE 185 MB per launch, round-2 kernel; "
+                                                   "the second bound: the gathered Jacobian records are fetched ~9 times)"}
         # the dominant kernel by device time carries the headline roofline object
         out["roofline"] = roof_chol if ms_factor > ms_jac else roof_jac
         out["roofline_jacobian"] = roof_jac

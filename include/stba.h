@@ -79,6 +79,9 @@ typedef struct {
     int    num_threads;                   /* accepted and ignored (reference sets 1) */
     int    minimizer_progress_to_stdout;  /* solver.hpp:278 */
     int    update_state_every_iteration;  /* solver.hpp:277: copy parameters back before callbacks */
+    int    phase_timing;                  /* 0 (default): no per-phase device times.  1: hipEvents between the phases of every
+                                           * iteration fill stba_lm_summary::ms_* -- an event is a packet of its own on the queue
+                                           * and costs ~5 us of idle GPU, ~1.5 % of a C5 iteration for the eight it takes */
 } stba_lm_options;
 
 void stba_lm_default_options(stba_lm_options* opt);
@@ -99,7 +102,7 @@ typedef struct {
     double final_radius;
     double final_gradient_max_norm;
     double seconds_total;
-    /* device time per phase, milliseconds, summed over iterations (hipEvent) */
+    /* device time per phase, milliseconds, summed over iterations (hipEvent); zero unless stba_lm_options::phase_timing */
     double ms_linearize, ms_schur, ms_solve, ms_backsub, ms_cost;
     /* several ranks: the cross-rank sums of the reduced camera system of this run -- device time between
      * events around the collective (part of ms_schur), bytes handed to it per rank, number of calls; 0 on one rank */
@@ -192,6 +195,9 @@ int stba_ba_triangulate(stba_ba* ba, int max_iter);
 /* average device time (ms) of the residual+Jacobian kernel over `reps` back-to-back launches,
  * measured with hipEvents on the engine's stream (bench.py roofline leg). */
 int stba_ba_time_linearize(stba_ba* ba, int reps, double* ms_avg);
+/* the same for the Schur-complement kernel (linearises at the current point first); also hands back the number of LDS
+ * FP64 atomics and of observation pairs of one launch (either may be NULL) */
+int stba_ba_time_schur(stba_ba* ba, int reps, double* ms_avg, double* lds_atomics_per_launch, double* pairs_per_launch);
 
 /* ================================ dense SPD solver ======================================== */
 /* A: n*n row-major SPD (lower triangle read), overwritten by L (lower).  Runs the blocked MFMA

@@ -36,7 +36,8 @@ class LMOptions(C.Structure):
                 ("max_lm_diagonal", C.c_double), ("function_tolerance", C.c_double),
                 ("gradient_tolerance", C.c_double), ("parameter_tolerance", C.c_double),
                 ("jacobi_scaling", C.c_int), ("num_threads", C.c_int),
-                ("minimizer_progress_to_stdout", C.c_int), ("update_state_every_iteration", C.c_int)]
+                ("minimizer_progress_to_stdout", C.c_int), ("update_state_every_iteration", C.c_int),
+                ("phase_timing", C.c_int)]
 
 
 class LMSummary(C.Structure):
@@ -66,7 +67,7 @@ EXPORTS = ["stba_status_string", "stba_last_error", "stba_version", "stba_device
            "stba_ba_get_params", "stba_ba_set_allreduce", "stba_ba_reduced_dim", "stba_ba_evaluate",
            "stba_ba_cost", "stba_ba_normal_blocks", "stba_ba_reduced_system", "stba_ba_solve_reduced",
            "stba_ba_back_substitute", "stba_ba_apply_step", "stba_ba_solve", "stba_ba_lm_iterations",
-           "stba_ba_triangulate", "stba_ba_time_linearize", "stba_cholesky_factor", "stba_cholesky_solve",
+           "stba_ba_triangulate", "stba_ba_time_linearize", "stba_ba_time_schur", "stba_cholesky_factor", "stba_cholesky_solve",
            "stba_cholesky_time", "stba_cholesky_time_split", "stba_cholesky_schedule_model", "stba_cholesky_timeout_count", "stba_cholesky_set_timeout_us", "stba_cholesky_shard_model", "stba_cholesky_shard_owner", "stba_cholesky_profile", "stba_calib_evaluate", "stba_calib_gauss_newton",
            "stba_pcg_default_options", "stba_pg_create", "stba_pg_destroy", "stba_pg_set_allreduce", "stba_pg_get_poses", "stba_pg_evaluate",
            "stba_pg_solve", "stba_pg_time_kernels", "stba_dense_solve", "stba_corners_read", "stba_corners_write", "stba_zhang_init", "stba_two_view_init", "stba_odometry_read", "stba_odometry_write", "stba_trajectory_ate",
@@ -278,6 +279,12 @@ class BAEngine:
         ms = C.c_double()
         _chk(lib().stba_ba_time_linearize(self._h, int(reps), C.byref(ms)), "stba_ba_time_linearize")
         return ms.value
+
+    def time_schur(self, reps=10):
+        """(ms per launch of the Schur-complement kernel, LDS atomics per launch, observation pairs per launch)"""
+        ms, at, pr = C.c_double(), C.c_double(), C.c_double()
+        _chk(lib().stba_ba_time_schur(self._h, int(reps), C.byref(ms), C.byref(at), C.byref(pr)), "stba_ba_time_schur")
+        return ms.value, at.value, pr.value
 
 
 class PCGOptions(C.Structure):

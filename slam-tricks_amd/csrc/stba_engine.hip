@@ -92,6 +92,7 @@ struct stba_ba {
     // pair plan of the Schur kernel (see ba_schur_pairs_kernel)
     int *pair_begin = nullptr, *pair_end = nullptr;
     int4* pair_rec = nullptr;           // (i, l, landmark, slot | flags)
+    double schur_pairs = 0.0, schur_lds_atomics = 0.0;   // per launch of the Schur kernel (measurement)
     unsigned char *cam_fixed = nullptr, *pt_fixed = nullptr;
     double2* r = nullptr;
     double* J8 = nullptr;            // compact Jacobian [n_obs][8] (ba_kernels.hip)
@@ -112,7 +113,7 @@ struct stba_ba {
     bool have_lin = false, have_blocks = false, have_reduced = false, have_dxc = false, have_dxp = false;
     bool scale_init = false;
     hipEvent_t ev_ar[2] = {};   // around the cross-rank sum of the reduced system (several ranks only)
-    bool ar_timing_pending = false;
+    bool ar_timing_pending = false, ar_timing_on = false;
     double ar_ms = 0.0, ar_bytes = 0.0; int ar_calls = 0;   // accumulated over one LM run
     hipEvent_t ev[15] = {};     // [12]: the trial block has reached the host; [13], [14]: second pair for the speculative linearisation
     double* lin_pin = nullptr;      // pinned host copy of [scalars (SC_GPMAX0 + world) | gc (n)], read one solve later
@@ -154,6 +155,7 @@ static void ba_free(stba_ba* b) {
     for (auto& e : b->ev_ar) if (e) (void)hipEventDestroy(e);
     if (b->lin_pin) (void)hipHostFree(b->lin_pin);
     if (b->ts_host) (void)hipHostFree(b->ts_host);
+    if (b->st) { (void)hipStreamSynchronize(b->st); chol_forget_stream(b->st); }
     if (b->own_stream && b->st) (void)hipStreamDestroy(b->st);
     delete b;
 }
@@ -340,12 +342,13 @@ static int ba_build_reduced(stba_ba* b, const Damping& dm, bool export_host = fa
         if (b->pk_state == 2) hipLaunchKernelGGL(blk_pack_kernel, dim3(pgrid), dim3(256), 0, b->st, b->Sbuf, b->lda, b->pk_blocks, b->pk_nz, b->Spack, 1);
         else hipLaunchKernelGGL(tri_pack_kernel, dim3(b->n + 1), dim3(256), 0, b->st, b->Sbuf, b->lda, b->n, b->Spack, 1);
         ba_collect_allreduce_time(b);                     // (a previous build's pair, if nobody has read it yet)
-        if (!b->ev_ar[0]) { STBA_HIP(hipEventCreate(&b->ev_ar[0])); STBA_HIP(hipEventCreate(&b->ev_ar[1])); }
-        STBA_HIP(hipEventRecord(b->ev_ar[0], b->st));
+        if (b->ar_timing_on) {
+            if (!b->ev_ar[0]) { STBA_HIP(hipEventCreate(&b->ev_ar[0])); STBA_HIP(hipEventCreate(&b->ev_ar[1])); }
+            STBA_HIP(hipEventRecord(b->ev_ar[0], b->st));
+        }
         if (b->ar(b->ar_user, b->Spack, b->pack_count(), b->st) != 0)
             return fail(STBA_ERR_CALLBACK, "all-reduce hook failed");
-        STBA_HIP(hipEventRecord(b->ev_ar[1], b->st));
-        b->ar_timing_pending = true;
+        if (b->ar_timing_on) { STBA_HIP(hipEventRecord(b->ev_ar[1], b->st)); b->ar_timing_pending = true; }
         b->ar_bytes += (double)b->pack_count() * sizeof(double);
         b->ar_calls += 1;
         if (b->pk_state == 2) hipLaunchKernelGGL(blk_pack_kernel, dim3(pgrid), dim3(256), 0, b->st, b->Sbuf, b->lda, b->pk_blocks, b->pk_nz, b->Spack, 0);
@@ -407,6 +410,7 @@ static void default_options(stba_lm_options* o) {
     o->num_threads = 1;
     o->minimizer_progress_to_stdout = 0;
     o->update_state_every_iteration = 0;
+    o->phase_timing = 0;
 }
 
 // reads {cost2, gpmax slots, gc} after a reduced-system build and returns cost / gradient max norm
@@ -466,6 +470,8 @@ static int ba_run_lm(stba_ba* b, const stba_lm_options* opt_in, int fixed_iterat
     const int max_iter = fixed ? fixed_iterations : opt.max_num_iterations;
     float ms = 0.f;
     hipEvent_t* ev = b->ev;
+    const bool timing = opt.phase_timing != 0;       // (see stba_lm_options: every event costs ~5 us of idle GPU)
+    b->ar_timing_on = timing;
 
     b->scale_init = false;
     b->ar_ms = 0.0; b->ar_bytes = 0.0; b->ar_calls = 0; b->ar_timing_pending = false;
@@ -475,10 +481,10 @@ static int ba_run_lm(stba_ba* b, const stba_lm_options* opt_in, int fixed_iterat
     L.radius = opt.initial_trust_region_radius;
 
     // ---- iteration 0: linearise at the start point
-    STBA_HIP(hipEventRecord(ev[0], b->st));
+    if (timing) STBA_HIP(hipEventRecord(ev[0], b->st));
     STBA_TRY(ba_linearize_lm(b, b->cur));
     STBA_TRY(ba_normal_blocks(b));
-    STBA_HIP(hipEventRecord(ev[1], b->st));
+    if (timing) STBA_HIP(hipEventRecord(ev[1], b->st));
     STBA_TRY(ba_fill_scalar_slots(b, b->trial + TS_COST2));
     bool need_build = true;      // reduced system must be (re)built before the next solve
     bool lin_timing_pending = true;
@@ -489,7 +495,7 @@ static int ba_run_lm(stba_ba* b, const stba_lm_options* opt_in, int fixed_iterat
     bool pending = false, pending_accepted = false;
     int pending_iter = 0, pending_lin_ev = 8, spec_ev = 13;
 
-    int iter = 0, chol_timeouts = 0;
+    int iter = 0, chol_timeouts = 0, build_end_ev = 3;
     s.termination_type = STBA_NO_CONVERGENCE;
     s.termination_reason = STBA_TERM_MAX_ITER;
     bool first = true;
@@ -508,10 +514,18 @@ static int ba_run_lm(stba_ba* b, const stba_lm_options* opt_in, int fixed_iterat
             }
         }
         // ---- reduced system for the current radius
+        // (an event record is a packet of its own on the queue, ~5 us of idle GPU between two kernels: none is recorded that
+        // is not needed -- when the system was built behind the previous iteration, that build's end event is the start of
+        // this solve)
         dm.radius = L.radius;
-        STBA_HIP(hipEventRecord(ev[2], b->st));
-        if (need_build) STBA_TRY(ba_build_reduced(b, dm));
-        STBA_HIP(hipEventRecord(ev[3], b->st));
+        const bool built_here = need_build;
+        if (need_build) {
+            if (timing) STBA_HIP(hipEventRecord(ev[2], b->st));
+            STBA_TRY(ba_build_reduced(b, dm));
+            if (timing) STBA_HIP(hipEventRecord(ev[3], b->st));
+            build_end_ev = 3;
+        }
+        const int solve_start_ev = build_end_ev;
         if (first) {
             STBA_TRY(ba_read_linear_scalars(b, &L.cost, &L.gmax));
             s.initial_cost = L.cost;
@@ -533,9 +547,9 @@ static int ba_run_lm(stba_ba* b, const stba_lm_options* opt_in, int fixed_iterat
         // ---- factor + solve, back-substitute, trial point
         int flag_h = 0;
         STBA_TRY(chol_factor_solve_dev(b->S(), b->lda, b->n, b->dxc, b->flag, b->st));
-        STBA_HIP(hipEventRecord(ev[4], b->st));
+        if (timing) STBA_HIP(hipEventRecord(ev[4], b->st));
         STBA_TRY(launch_backsub(b->np, b->pt_start, b->obs_cam, b->J8, b->omask, b->Hinv6, b->gp, b->dxc, b->dxp, b->st));
-        STBA_HIP(hipEventRecord(ev[5], b->st));
+        if (timing) STBA_HIP(hipEventRecord(ev[5], b->st));
         // Nobody watches the iterations and there is one rank: the host learns the trial point's scalars through mapped
         // memory and an event, and meanwhile the stream already linearises AT THE TRIAL POINT -- a step is accepted far
         // more often than not, and the host's round trip (wake-up, decision, enqueue: ~35 us) would otherwise be a
@@ -546,7 +560,7 @@ static int ba_run_lm(stba_ba* b, const stba_lm_options* opt_in, int fixed_iterat
             STBA_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&b->ts_host_dev), b->ts_host, 0));
         }
         STBA_TRY(ba_trial(b, fast ? b->ts_host_dev : nullptr));
-        STBA_HIP(hipEventRecord(ev[6], b->st));
+        if (timing) STBA_HIP(hipEventRecord(ev[6], b->st));
         double ts[TS_COUNT];
         bool speculated = false;
         if (fast) {
@@ -554,10 +568,10 @@ static int ba_run_lm(stba_ba* b, const stba_lm_options* opt_in, int fixed_iterat
             if (!(fixed && iter >= max_iter)) {
                 // (its own pair of events, alternating: the previous linearisation's pair is read behind the synchronisation below)
                 spec_ev = (spec_ev == 8) ? 13 : 8;
-                STBA_HIP(hipEventRecord(ev[spec_ev], b->st));
+                if (timing) STBA_HIP(hipEventRecord(ev[spec_ev], b->st));
                 STBA_TRY(ba_linearize_lm(b, b->cur ^ 1));
                 STBA_TRY(ba_normal_blocks(b));
-                STBA_HIP(hipEventRecord(ev[spec_ev + 1], b->st));
+                if (timing) STBA_HIP(hipEventRecord(ev[spec_ev + 1], b->st));
                 STBA_TRY(ba_fill_scalar_slots(b, b->trial + TS_SPEC_COST2));
                 speculated = true;
             }
@@ -572,8 +586,8 @@ static int ba_run_lm(stba_ba* b, const stba_lm_options* opt_in, int fixed_iterat
         if (pending) {
             double c2, g2;
             ba_finish_linear_scalars(b, &c2, &g2);
-            if (hipEventElapsedTime(&ms, ev[pending_lin_ev], ev[pending_lin_ev + 1]) == hipSuccess) s.ms_linearize += ms;
-            if (hipEventElapsedTime(&ms, ev[10], ev[11]) == hipSuccess) s.ms_schur += ms;
+            if (timing && hipEventElapsedTime(&ms, ev[pending_lin_ev], ev[pending_lin_ev + 1]) == hipSuccess) s.ms_linearize += ms;
+            if (timing && hipEventElapsedTime(&ms, ev[10], ev[11]) == hipSuccess) s.ms_schur += ms;
             L.gmax = g2;
             if (pending_accepted) L.cost = c2;
             if (trace) trace[(size_t)pending_iter * STBA_TRACE_COLS + 2] = g2;
@@ -601,11 +615,14 @@ static int ba_run_lm(stba_ba* b, const stba_lm_options* opt_in, int fixed_iterat
             --iter;
             continue;
         }
-        if (lin_timing_pending) { (void)hipEventElapsedTime(&ms, ev[0], ev[1]); s.ms_linearize += ms; lin_timing_pending = false; }
-        (void)hipEventElapsedTime(&ms, ev[2], ev[3]); s.ms_schur += ms;
-        (void)hipEventElapsedTime(&ms, ev[3], ev[4]); s.ms_solve += ms;
-        (void)hipEventElapsedTime(&ms, ev[4], ev[5]); s.ms_backsub += ms;
-        (void)hipEventElapsedTime(&ms, ev[5], ev[6]); s.ms_cost += ms;
+        if (timing) {
+            if (lin_timing_pending) { (void)hipEventElapsedTime(&ms, ev[0], ev[1]); s.ms_linearize += ms; }
+            if (built_here) { (void)hipEventElapsedTime(&ms, ev[2], ev[3]); s.ms_schur += ms; }
+            (void)hipEventElapsedTime(&ms, ev[solve_start_ev], ev[4]); s.ms_solve += ms;
+            (void)hipEventElapsedTime(&ms, ev[4], ev[5]); s.ms_backsub += ms;
+            (void)hipEventElapsedTime(&ms, ev[5], ev[6]); s.ms_cost += ms;
+        }
+        lin_timing_pending = false;
 
         bool step_ok = (flag_h == 0);
         const double new_cost = 0.5 * ts[TS_COST2];
@@ -662,18 +679,19 @@ static int ba_run_lm(stba_ba* b, const stba_lm_options* opt_in, int fixed_iterat
             // speculation records into the other one, so the pair is still intact when the host reads it one solve later)
             const int e0 = deferred_ok ? spec_ev : 0, e2 = deferred_ok ? 10 : 2;
             if (!(speculated && accepted)) {
-                STBA_HIP(hipEventRecord(ev[e0], b->st));
+                if (timing) STBA_HIP(hipEventRecord(ev[e0], b->st));
                 STBA_TRY(ba_linearize_lm(b, b->cur));
                 STBA_TRY(ba_normal_blocks(b));
-                STBA_HIP(hipEventRecord(ev[e0 + 1], b->st));
+                if (timing) STBA_HIP(hipEventRecord(ev[e0 + 1], b->st));
                 STBA_TRY(ba_fill_scalar_slots(b, b->trial + TS_COST2));
             }
             // gradient of the new point is needed for the convergence test: it arrives with the
             // next reduced-system build (one collective per iteration); build it now.
             dm.radius = L.radius;
-            STBA_HIP(hipEventRecord(ev[e2], b->st));
+            if (timing) STBA_HIP(hipEventRecord(ev[e2], b->st));
             STBA_TRY(ba_build_reduced(b, dm, deferred_ok));
-            STBA_HIP(hipEventRecord(ev[e2 + 1], b->st));
+            if (timing) STBA_HIP(hipEventRecord(ev[e2 + 1], b->st));
+            build_end_ev = e2 + 1;
             need_build = false;
             lin_timing_pending = false;
             if (deferred_ok) {
@@ -685,8 +703,10 @@ static int ba_run_lm(stba_ba* b, const stba_lm_options* opt_in, int fixed_iterat
             } else {
                 double c2, g2;
                 STBA_TRY(ba_read_linear_scalars(b, &c2, &g2));
-                (void)hipEventElapsedTime(&ms, ev[0], ev[1]); s.ms_linearize += ms;
-                (void)hipEventElapsedTime(&ms, ev[2], ev[3]); s.ms_schur += ms;
+                if (timing) {
+                    (void)hipEventElapsedTime(&ms, ev[0], ev[1]); s.ms_linearize += ms;
+                    (void)hipEventElapsedTime(&ms, ev[2], ev[3]); s.ms_schur += ms;
+                }
                 L.gmax = g2;
                 if (accepted) L.cost = c2;   // same value as new_cost up to summation order
             }
@@ -952,6 +972,11 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
                 // the bank conflicts it removes cost less than the locality of the landmark-major order it destroys)
             }
         });
+    }
+    {   // LDS atomics of one launch: 36 per pair (21 in a diagonal block) + 6 for a pair's share of the right-hand side
+        double at = 0.0;
+        for (const int4& pr : pair_rec) at += ((pr.w & 0x8000) ? 21.0 : 36.0) + ((pr.w & 0x4000) ? 6.0 : 0.0);
+        b->schur_pairs = (double)pair_rec.size(); b->schur_lds_atomics = at;
     }
     tmark("pair plan");
     std::vector<unsigned char> cmask;
@@ -1231,6 +1256,36 @@ int stba_ba_time_linearize(stba_ba* b, int reps, double* ms_avg) {
     return STBA_OK;
 }
 
+// measurement (bench.py roofline_schur): average device time of the Schur-complement kernel at the current point -- a fresh
+// linearisation and landmark blocks first, then `reps` reduced-system builds timed around the kernel alone
+int stba_ba_time_schur(stba_ba* b, int reps, double* ms_avg, double* lds_atomics_per_launch, double* pairs_per_launch) {
+    if (!b || reps <= 0 || !ms_avg) return fail(STBA_ERR_INVALID_ARGUMENT, "bad argument");
+    STBA_TRY(ba_linearize_lm(b, b->cur));
+    STBA_TRY(ba_normal_blocks(b));
+    STBA_TRY(ba_fill_scalar_slots(b, b->trial + TS_COST2));
+    Damping dm;
+    STBA_TRY(launch_point_damp_invert(b->np, b->Hpp6, b->pt_fixed, b->scale_p, b->scale_init ? 0 : 1, dm.use_scaling, dm.radius, dm.dmin,
+                                      dm.dmax, b->dp, b->Hinv6, b->Sbuf + (size_t)b->lda * b->lda, 3 * b->lda, b->st));
+    SchurArgs sa;
+    sa.task_cam = b->task_cam; sa.cam_start = b->cam_start; sa.task_col_lo = b->task_col_lo; sa.task_col_hi = b->task_col_hi;
+    sa.row_col_ptr = b->row_col_ptr; sa.row_cols = b->row_cols; sa.max_cols = b->max_cols; sa.cam_perm = b->cam_perm;
+    sa.J8 = b->J8; sa.omask = b->omask; sa.r = b->r; sa.Hinv6 = b->Hinv6; sa.gp = b->gp;
+    sa.S = b->S(); sa.lda = b->lda; sa.rhs = b->rhs(); sa.Hcc = b->Hcc; sa.gc = b->gc;
+    sa.pair_begin = b->pair_begin; sa.pair_end = b->pair_end; sa.pair_rec = b->pair_rec;
+    STBA_TRY(launch_schur_rows(sa, b->n_tasks, b->st));      // warm
+    STBA_HIP(hipEventRecord(b->ev[0], b->st));
+    for (int k = 0; k < reps; ++k) STBA_TRY(launch_schur_rows(sa, b->n_tasks, b->st));
+    STBA_HIP(hipEventRecord(b->ev[1], b->st));
+    STBA_HIP(hipStreamSynchronize(b->st));
+    float ms = 0.f;
+    STBA_HIP(hipEventElapsedTime(&ms, b->ev[0], b->ev[1]));
+    *ms_avg = (double)ms / reps;
+    if (lds_atomics_per_launch) *lds_atomics_per_launch = b->schur_lds_atomics;
+    if (pairs_per_launch) *pairs_per_launch = b->schur_pairs;
+    b->have_lin = b->have_blocks = b->have_reduced = b->have_dxc = b->have_dxp = false;
+    return STBA_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // dense SPD solver entry points
 // ---------------------------------------------------------------------------------------------
@@ -1245,6 +1300,7 @@ struct DenseWs {
         if (x) (void)hipFree(x);
         if (rhs) (void)hipFree(rhs);
         if (flag) (void)hipFree(flag);
+        if (st) { (void)hipStreamSynchronize(st); chol_forget_stream(st); }
         if (own && st) (void)hipStreamDestroy(st);
     }
     int init(int n_, void* stream) {

@@ -12,5 +12,5 @@ else:
     s = scenes.st20_scene(n_cams=1000, n_pts=100000, max_obs_per_pt=10, seed=20, pix_noise=1e-3)
     np.savez(cache, **s)
 e = st.BAEngine(s["cams0"], s["pts0"], s["obs_cam"], s["obs_pt"], s["obs_feat"], s["cam_fixed"])
-summ, tr = e.lm_iterations(int(sys.argv[1]) if len(sys.argv) > 1 else 3)
+summ, tr = e.lm_iterations(int(sys.argv[1]) if len(sys.argv) > 1 else 3, phase_timing=1)
 print("ms", {k: getattr(summ, k) for k in ("ms_linearize", "ms_schur", "ms_solve", "ms_backsub", "ms_cost")})

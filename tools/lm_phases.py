@@ -16,6 +16,8 @@ for rep in range(3):
     t0 = time.perf_counter()
     summ, tr = eng.lm_iterations(steps)
     dt = (time.perf_counter() - t0) / steps * 1e3
+    eng.set_params(s["cams0"], s["pts0"])
+    summ, tr = eng.lm_iterations(steps, phase_timing=1)
     ph = {k: getattr(summ, k) / steps for k in ("ms_linearize", "ms_schur", "ms_solve", "ms_backsub", "ms_cost")}
     if best is None or dt < best[0]: best = (dt, ph, summ.final_cost)
 dt, ph, fc = best
