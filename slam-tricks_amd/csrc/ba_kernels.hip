@@ -778,7 +778,9 @@ __global__ __launch_bounds__(256) void ba_reduced_finalize_kernel(int n_cams, in
                                                                   double* __restrict__ scale, int init_scale, int use_scaling,
                                                                   double radius, double dmin, double dmax, double* __restrict__ dc,
                                                                   int blocks_cam, const double* __restrict__ scalars, int n_scalars,
-                                                                  double* __restrict__ host_out) {
+                                                                  double* __restrict__ host_out, int reduced) {
+    // (reduced != 0 -- several ranks, behind the cross-rank sum: the camera blocks are in S already and diag(Hcc), gc come
+    // summed over the ranks from ex_diag / ex_gc; what is left is the LM diagonal, the damping and the padding)
     // (host_out: the scalar slots and the gradient gc also go straight into mapped host memory -- [scalars | gc] -- where
     // the LM loop reads them one synchronisation later: export_linear_kernel's launch saved)
     if (host_out && blockIdx.x == 0 && (int)threadIdx.x < n_scalars) host_out[threadIdx.x] = scalars[threadIdx.x];
@@ -798,18 +800,18 @@ __global__ __launch_bounds__(256) void ba_reduced_finalize_kernel(int n_cams, in
     const int c = gid / 36, k = gid - c * 36;
     if (c >= n_cams) return;
     const int a = k / 6, b = k - a * 6;
-    const double h = Hcc[(size_t)c * 36 + k];
+    const int i = c * 6 + a;
+    if (reduced && a != b) return;
+    const double h = reduced ? ex_diag[i] : Hcc[(size_t)c * 36 + k];
     if (a != b) {
         if (b < a) S[(size_t)(c * 6 + a) * lda + c * 6 + b] += h;
         return;
     }
-    const int i = c * 6 + a;
-    double sd = S[(size_t)i * lda + i] + h;
-    ex_diag[i] = h;
-    const double g = gc[i];
-    ex_gc[i] = g;
+    double sd = S[(size_t)i * lda + i] + (reduced ? 0.0 : h);
+    const double g = reduced ? ex_gc[i] : gc[i];
+    if (!reduced) { ex_diag[i] = h; ex_gc[i] = g; }
     if (host_out) host_out[n_scalars + i] = g;
-    double rv = rhs[i] - g;
+    double rv = rhs[i] - (reduced ? 0.0 : g);
     // lm_diagonal_kernel, kind 2
     double sc = 1.0;
     if (use_scaling) {
@@ -832,10 +834,11 @@ __global__ __launch_bounds__(256) void ba_reduced_finalize_kernel(int n_cams, in
 int launch_reduced_finalize(int n_cams, int n, const double* Hcc, const double* gc, const unsigned char* cam_fixed, double* S, int lda,
                             double* rhs, double* ex_diag, double* ex_gc, double* scale, int init_scale, int use_scaling,
                             double radius, double dmin, double dmax, double* dc, const double* scalars, int n_scalars,
-                            double* host_out, hipStream_t st) {
+                            double* host_out, int reduced, hipStream_t st) {
     const int blocks_cam = (n_cams * 36 + 255) / 256;
     hipLaunchKernelGGL(ba_reduced_finalize_kernel, dim3(blocks_cam + (lda - n)), dim3(256), 0, st, n_cams, n, Hcc, gc, cam_fixed, S, lda,
-                       rhs, ex_diag, ex_gc, scale, init_scale, use_scaling, radius, dmin, dmax, dc, blocks_cam, scalars, n_scalars, host_out);
+                       rhs, ex_diag, ex_gc, scale, init_scale, use_scaling, radius, dmin, dmax, dc, blocks_cam, scalars, n_scalars, host_out,
+                       reduced);
     STBA_HIP(hipGetLastError());
     return STBA_OK;
 }

@@ -78,7 +78,7 @@ int launch_reduced_add_camera(int n_cams, const double* Hcc, const double* gc, d
 int launch_reduced_finalize(int n_cams, int n, const double* Hcc, const double* gc, const unsigned char* cam_fixed, double* S, int lda,
                             double* rhs, double* ex_diag, double* ex_gc, double* scale, int init_scale, int use_scaling,
                             double radius, double dmin, double dmax, double* dc, const double* scalars, int n_scalars,
-                            double* host_out, hipStream_t st);
+                            double* host_out, int reduced, hipStream_t st);
 int launch_reduced_damp(int n, const double* dc, const unsigned char* cam_fixed, double* S, int lda, double* rhs,
                         hipStream_t st);
 int launch_backsub(int n_pts, const int* pt_start, const int* obs_cam, const double* J8, const unsigned char* omask,

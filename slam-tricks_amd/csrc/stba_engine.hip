@@ -328,7 +328,7 @@ static int ba_build_reduced(stba_ba* b, const Damping& dm, bool export_host = fa
         }
         STBA_TRY(launch_reduced_finalize(b->nc, b->n, b->Hcc, b->gc, b->cam_fixed, b->S(), b->lda, b->rhs(), b->ex_diag(), b->ex_gc(),
                                          b->scale_c, init_scale, dm.use_scaling, dm.radius, dm.dmin, dm.dmax, b->dc, b->ex_scalar(),
-                                         SC_GPMAX0 + b->world, host_out, b->st));
+                                         SC_GPMAX0 + b->world, host_out, 0, b->st));
         b->scale_init = true;
         return STBA_OK;
     }
@@ -355,6 +355,17 @@ static int ba_build_reduced(stba_ba* b, const Damping& dm, bool export_host = fa
         else hipLaunchKernelGGL(tri_pack_kernel, dim3(b->n + 1), dim3(256), 0, b->st, b->Sbuf, b->lda, b->n, b->Spack, 0);
         STBA_HIP(hipGetLastError());
     }
+    if (!dm.explicit_d && b->n == 6 * b->nc) {
+        // behind the cross-rank sum: LM diagonal of the summed diag(Hcc), damping, padding (and the export of the scalars
+        // and the gradient to the host) in ONE launch, as on one rank
+        double* host_out = nullptr;
+        if (export_host) { STBA_TRY(ba_lin_pin(b)); host_out = b->lin_pin_dev; b->lin_exported = true; }
+        STBA_TRY(launch_reduced_finalize(b->nc, b->n, b->Hcc, b->gc, b->cam_fixed, b->S(), b->lda, b->rhs(), b->ex_diag(), b->ex_gc(),
+                                         b->scale_c, init_scale, dm.use_scaling, dm.radius, dm.dmin, dm.dmax, b->dc, b->ex_scalar(),
+                                         SC_GPMAX0 + b->world, host_out, 1, b->st));
+        b->scale_init = true;
+        return STBA_OK;
+    }
     if (!dm.explicit_d)
         STBA_TRY(launch_lm_diagonal(b->n, 1, 1, 2, b->ex_diag(), b->scale_c, init_scale, dm.use_scaling, dm.radius,
                                     dm.dmin, dm.dmax, b->dc, b->st));
@@ -369,6 +380,13 @@ static int ba_build_reduced(stba_ba* b, const Damping& dm, bool export_host = fa
 static int ba_fill_scalar_slots(stba_ba* b, double* cost2_dev) {
     return launch_linear_finish(b->cost_partial, b->lin_grid, b->upd_partial_p, (b->np + 255) / 256, cost2_dev, b->ex_scalar(), b->lda,
                                 SC_COST2, SC_GPMAX0 + b->rank, b->st);
+}
+
+// the trial block and the factorisation's flag into mapped host memory (several ranks; one rank: trial_finish_kernel does it)
+__global__ void export_trial_kernel(const double* __restrict__ trial, const int* __restrict__ flag, double* __restrict__ out) {
+    const int k = threadIdx.x;
+    if (k < TS_COUNT) out[k] = trial[k];
+    else if (k == TS_COUNT) out[k] = (double)flag[0];
 }
 
 // trial point: both manifold updates (one launch), the residual-only kernel, and ONE launch that finishes every sum of
@@ -387,6 +405,9 @@ static int ba_trial(stba_ba* b, double* host_out) {
                                  b->ar ? nullptr : host_out, b->st));
     if (b->ar) {
         if (b->ar(b->ar_user, b->trial, 4, b->st) != 0) return fail(STBA_ERR_CALLBACK, "all-reduce hook failed");
+        // (several ranks: the block goes to the host behind the cross-rank sum of its first four entries)
+        if (host_out) hipLaunchKernelGGL(export_trial_kernel, dim3(1), dim3(64), 0, b->st, b->trial, b->flag, host_out);
+        STBA_HIP(hipGetLastError());
     }
     return STBA_OK;
 }
@@ -554,7 +575,9 @@ static int ba_run_lm(stba_ba* b, const stba_lm_options* opt_in, int fixed_iterat
         // memory and an event, and meanwhile the stream already linearises AT THE TRIAL POINT -- a step is accepted far
         // more often than not, and the host's round trip (wake-up, decision, enqueue: ~35 us) would otherwise be a
         // bubble on the GPU in every iteration.  A rejected step costs one linearisation at the old point (below).
-        const bool fast = deferred_ok && !b->ar && SPECULATE;
+        // (With several ranks too: every rank takes the same decision from the same all-reduced block, and the collectives of
+        // the speculative build are enqueued on the stream like everything else.)
+        const bool fast = deferred_ok && SPECULATE;
         if (fast && !b->ts_host) {
             STBA_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->ts_host), (TS_COUNT + 1) * sizeof(double), hipHostMallocMapped));
             STBA_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&b->ts_host_dev), b->ts_host, 0));
