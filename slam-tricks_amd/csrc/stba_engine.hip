@@ -947,8 +947,8 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
         }
         // Task order: heaviest first (most pairs), for a short tail.  (Measured against it in round 3, C5, Schur kernel
         // 0.324 ms: the cameras in trajectory order 0.39 ms; cut into eight contiguous ranges walked by one XCD each, so that
-        // the workgroups side by side on an XCD gather the same records, 0.39-0.40 ms -- the tail costs more than the L2
-        // hits bring.  Slices cut to 3072 / 4096 / 6144 / 8192 pairs: 0.49 / 0.37 / 0.34 / 0.34 ms: a task's fixed costs --
+        // the workgroups side by side on an XCD gather the same records, 0.39-0.40 ms in camera order and 0.323 ms heaviest
+        // first inside every range: the L2 hits bring nothing.  Slices cut to 3072 / 4096 / 6144 / 8192 pairs: 0.49 / 0.37 / 0.34 / 0.34 ms: a task's fixed costs --
         // zeroing its accumulator and its rows, the block stores -- outweigh the better balance.)
         std::vector<int> order(task_cam.size());
         for (size_t k = 0; k < order.size(); ++k) order[k] = (int)k;
