@@ -122,11 +122,12 @@ def ceres_row(scene_file, n_iter):
 # algorithmic HBM bytes per edge of the two pose-graph kernels (FP64):
 #   residual + Jacobian: read 8 B (two indices) + 56 B (measurement) + 2 x 56 B poses / (edge ends per node = 2 m / n = 8);
 #                        write 48 B (r) + 2 x 288 B (Ji, Jj)
-#   matrix-free product: read 8 B + 2 x 288 B (Ji, Jj) + 2 x 48 B of p / 8; read-modify-write 2 x 48 B of q / 8 (twice)
+#   matrix-free product, edge kernel: read 8 B + 2 x 288 B (Ji, Jj) + 2 x 48 B of p / 8; write 96 B (u = Ji^T t | Jj^T t, which the
+#                        node kernel gathers: no atomics)
 def pg_bytes_per_edge(n_nodes, n_edges):
     ends = 2.0 * n_edges / max(n_nodes, 1)
     lin = 8 + 56 + 2 * 56 / ends + 48 + 2 * 288
-    mv = 8 + 2 * 288 + 2 * 48 / ends + 2 * 2 * 48 / ends
+    mv = 8 + 2 * 288 + 2 * 48 / ends + 96
     return lin, mv
 
 
@@ -172,14 +173,15 @@ def bench_c4(args):
                    "n_nodes": n, "n_edges": m, "parallelism": "single GPU"},
         "solve_seconds": dt, "lm_iterations": int(iters), "pcg_iterations": int(pcg_total), "pcg_iterations_per_sec": pcg_total / dt,
         "edge_visits_per_sec": m * (products + 2.0 * iters) / dt,       # every product and every (trial / accepted) linearisation visits every edge
+        "us_per_pcg_iteration": 1e6 * dt / max(pcg_total, 1),
         "initial_cost": icost, "final_cost": fcost, "converged": bool(term == 0),
         "reps_solve_seconds": [r[0] for r in reps], "timing": "median of reps",
-        "roofline": {"kernel": "pg_matvec_kernel (q += J^T J p, one edge per lane, FP64 atomics into the 6 n vector) + pg_diag_mul_kernel",
+        "roofline": {"kernel": "pg_edge_product_kernel (t = J [p_i; p_j], u = J^T t per edge, component-major Jacobians; the node kernel gathers u)",
                      "bound": "hbm", "achieved": b_mv * m / (ms_mv * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": b_mv * m / (ms_mv * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "ms_per_launch": ms_mv,
                      "algorithmic_bytes_per_edge": b_mv, "algorithmic_bytes_per_launch": b_mv * m,
-                     "note": f"{b_mv * m / 1e6:.1f} MB per product: 3 us at 8 TB/s -- at this size the product is bound by launch and "
-                             "atomic latency, not by bandwidth; the 40k-edge graph fills 157 of 256 CUs once"},
+                     "note": f"{b_mv * m / 1e6:.1f} MB per product: 3.5 us at 8 TB/s -- at this size a launch is latency, not bandwidth: "
+                             "the 40k-edge graph fills 157 of 256 CUs once, and a PCG iteration is three dependent launches"},
         "roofline_linearize": {"kernel": "pg_linearize_kernel (residual + both 6x6 Jacobians per edge)", "bound": "hbm",
                                "achieved": b_lin * m / (ms_lin * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": b_lin * m / (ms_lin * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "ms_per_launch": ms_lin,

@@ -11,7 +11,9 @@
 //              (6 n_nodes unknowns, block-sparse) are solved matrix-free by block-Jacobi
 //              preconditioned conjugate gradients: every kernel is HBM/latency bound, no MFMA.
 //
-// Data in HBM: poses [n][7] (two copies), edges (i, j) int32, meas [m][7], r [m][6], Ji/Jj [m][36],
+// Data in HBM: poses [n][7] (two copies), edges (i, j) int32, meas [m][7], r [m][6], Ji/Jj [36][m] (COMPONENT-major: entry k
+// of edge e at k m + e, so that the lanes of a wave -- consecutive edges -- read and write consecutive addresses; edge-major
+// [m][36] made every load instruction touch 64 cache lines: the matrix-free product took 24 us for 25 MB),
 // g [6n], Hd [n][36] (diagonal blocks), Minv [n][36], PCG vectors x r z p q [6n].
 #include <algorithm>
 #include <chrono>
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(256) void pg_linearize_kernel(int n_edges, const do
         if (r) for (int k = 0; k < 6; ++k) r[(size_t)e * 6 + k] = re[k];
         if (with_jac) {
             const bool fi = fixed && fixed[i], fj = fixed && fixed[j];
-            for (int k = 0; k < 36; ++k) { Ji[(size_t)e * 36 + k] = fi ? 0.0 : ji[k]; Jj[(size_t)e * 36 + k] = fj ? 0.0 : jj[k]; }
+            for (int k = 0; k < 36; ++k) { Ji[(size_t)k * n_edges + e] = fi ? 0.0 : ji[k]; Jj[(size_t)k * n_edges + e] = fj ? 0.0 : jj[k]; }
         }
     }
     double out2[2];
@@ -174,11 +176,11 @@ __global__ __launch_bounds__(256) void pg_accumulate_kernel(int n_edges, const i
     const int e = gid >> 1, side = gid & 1;
     if (e >= n_edges) return;
     const int node = side ? ej[e] : ei[e];
-    const double* J = (side ? Jj : Ji) + (size_t)e * 36;
+    const double* J = (side ? Jj : Ji) + e;
     const double* re = r + (size_t)e * 6;
     double Jl[36], rl[6];
     bool any = false;
-    for (int k = 0; k < 36; ++k) { Jl[k] = J[k]; any |= (Jl[k] != 0.0); }
+    for (int k = 0; k < 36; ++k) { Jl[k] = J[(size_t)k * n_edges]; any |= (Jl[k] != 0.0); }
     if (!any) return;   // constant node
     for (int k = 0; k < 6; ++k) rl[k] = re[k];
     for (int a = 0; a < 6; ++a) {
@@ -241,8 +243,8 @@ __global__ __launch_bounds__(256) void pg_matvec_kernel(int n_edges, const int* 
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= n_edges) return;
     const int i = ei[e], j = ej[e];
-    const double* A = Ji + (size_t)e * 36;
-    const double* B = Jj + (size_t)e * 36;
+    double A[36], B[36];
+    for (int k = 0; k < 36; ++k) { A[k] = Ji[(size_t)k * n_edges + e]; B[k] = Jj[(size_t)k * n_edges + e]; }
     double pi[6], pj[6], t[6];
     for (int k = 0; k < 6; ++k) { pi[k] = p[(size_t)i * 6 + k]; pj[k] = p[(size_t)j * 6 + k]; }
     for (int a = 0; a < 6; ++a) {
@@ -351,6 +353,113 @@ __global__ __launch_bounds__(256) void pg_pcg_dir_kernel(int n, int nb, const do
     if (i < n) p[i] = z[i] + beta * p[i];
 }
 
+// ---------------------------------------------------------------- one rank: a PCG iteration in THREE launches, no atomics
+// (1) p^T q = p^T D p + |J p|^2 = sum_i d_i p_i^2 + sum_e |t_e|^2 with t_e = J_e [p_i; p_j]: the dot product needs no pass over
+//     the finished q -- the edge kernel adds up |t_e|^2, the kernel that makes the direction p adds up d p^2.
+// (2) q is never scattered: the edge kernel stores u_e = (Ji^T t_e | Jj^T t_e), 12 doubles per edge, component-major, and the
+//     node kernel GATHERS q_i = d_i p_i + sum over the node's edge ends of u (a CSR of the ends built at create time) while it
+//     updates x, r, z.  The scatter with FP64 atomics was the bound of the product: 480 k device-scope atomics per product
+//     retire at ~20 G/s whatever the access pattern -- the product scaled linearly with the edge count at 1.65 G edges/s
+//     (24.7 us at 40 k edges, 95 us at 160 k, 387 us at 640 k).  Measured on the way: one lane per edge END with a segmented
+//     scan over a node's lanes and 6 atomics per node instead of 12 per edge (21.1 against 23.8 us: fewer atomics, but every
+//     edge read twice and no coalescing); the whole loop as ONE persistent kernel with four grid barriers per iteration
+//     (correct, 59 us per iteration against 40 us for the launches: a barrier across eight XCDs costs more than a kernel
+//     boundary).
+//     (Also measured: the direction p = z + beta p_old formed on the fly by the edge kernel and again by the node kernel, the
+//     node term of the dot product added up by the edge ends -- TWO launches per iteration: 32 us against 30 us for three.
+//     Every kernel that needs a scalar of the loop adds up its partial sums first, ~2 us each; two kernels that need three
+//     each lose more than the launch they save.)
+__global__ __launch_bounds__(256) void pg_edge_product_kernel(int n_edges, const int* __restrict__ ei, const int* __restrict__ ej,
+                                                              const double* __restrict__ Ji, const double* __restrict__ Jj,
+                                                              const double* __restrict__ p, double* __restrict__ u,
+                                                              double* __restrict__ part_tt) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    double tt2 = 0.0;
+    if (e < n_edges) {
+        const int i = ei[e], j = ej[e];
+        double A[36], B[36];
+        for (int k = 0; k < 36; ++k) { A[k] = Ji[(size_t)k * n_edges + e]; B[k] = Jj[(size_t)k * n_edges + e]; }
+        double pi[6], pj[6], t[6];
+        for (int k = 0; k < 6; ++k) { pi[k] = p[(size_t)i * 6 + k]; pj[k] = p[(size_t)j * 6 + k]; }
+        for (int a = 0; a < 6; ++a) {
+            double s = 0.0;
+            for (int k = 0; k < 6; ++k) s += A[a * 6 + k] * pi[k] + B[a * 6 + k] * pj[k];
+            t[a] = s;
+            tt2 += s * s;
+        }
+        for (int k = 0; k < 6; ++k) {
+            double si = 0.0, sj = 0.0;
+            for (int a = 0; a < 6; ++a) { si += A[a * 6 + k] * t[a]; sj += B[a * 6 + k] * t[a]; }
+            u[(size_t)k * n_edges + e] = si;
+            u[(size_t)(6 + k) * n_edges + e] = sj;
+        }
+    }
+    double out2[2];
+    block_sum2(tt2, 0.0, out2);
+    if (threadIdx.x == 0) { part_tt[blockIdx.x * 2] = out2[0]; part_tt[blockIdx.x * 2 + 1] = 0.0; }
+}
+
+// q_i = d_i p_i + sum_ends u;  alpha = rz / (sum |t|^2 + sum d p^2);  x += alpha p;  r -= alpha q;  z = M r;  partial -> rz_new, rr
+__global__ __launch_bounds__(256) void pg_pcg_update3_kernel(int n_nodes, int n_edges, int nb_rz, const double* __restrict__ part_rz,
+                                                             int nb_tt, const double* __restrict__ part_tt, int nb_dp,
+                                                             const double* __restrict__ part_dp, const double* __restrict__ Minv,
+                                                             const double* __restrict__ d, const int* __restrict__ node_start,
+                                                             const int* __restrict__ end_code, const double* __restrict__ u,
+                                                             const double* __restrict__ p, double* __restrict__ x, double* __restrict__ r,
+                                                             double* __restrict__ z, double* __restrict__ part_out) {
+    const double rz = sum_partials_dev(part_rz, nb_rz, 2, 0);
+    const double pq = sum_partials_dev(part_tt, nb_tt, 2, 0) + sum_partials_dev(part_dp, nb_dp, 2, 0);
+    const double alpha = (pq > 0.0) ? rz / pq : 0.0;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    double a = 0.0, b = 0.0;
+    if (i < n_nodes) {
+        double ql[6], pl[6], rl[6];
+        for (int k = 0; k < 6; ++k) { pl[k] = p[(size_t)i * 6 + k]; ql[k] = d[(size_t)i * 6 + k] * pl[k]; }
+        const int e1 = node_start[i + 1];
+        for (int c = node_start[i]; c < e1; ++c) {
+            const int code = end_code[c], e = code >> 1, side = code & 1;
+            const double* ue = u + (size_t)(6 * side) * n_edges + e;
+            for (int k = 0; k < 6; ++k) ql[k] += ue[(size_t)k * n_edges];
+        }
+        for (int k = 0; k < 6; ++k) {
+            const size_t o = (size_t)i * 6 + k;
+            x[o] += alpha * pl[k];
+            rl[k] = r[o] - alpha * ql[k];
+            r[o] = rl[k];
+        }
+        for (int k = 0; k < 6; ++k) {
+            double s = 0.0;
+            for (int m = 0; m < 6; ++m) s += Minv[(size_t)i * 36 + k * 6 + m] * rl[m];
+            z[(size_t)i * 6 + k] = s;
+            a += rl[k] * s; b += rl[k] * rl[k];
+        }
+    }
+    double out2[2];
+    block_sum2(a, b, out2);
+    if (threadIdx.x == 0) { part_out[blockIdx.x * 2] = out2[0]; part_out[blockIdx.x * 2 + 1] = out2[1]; }
+}
+
+// beta = rz_new / rz_old (first: p = z); p = z + beta p; partial -> sum d p^2
+__global__ __launch_bounds__(256) void pg_pcg_dir3_kernel(int n, int nb, const double* __restrict__ part_new,
+                                                          const double* __restrict__ part_old, int first, const double* __restrict__ z,
+                                                          const double* __restrict__ d, double* __restrict__ p, double* __restrict__ part_dp) {
+    double beta = 0.0;
+    if (!first) {
+        const double rzn = sum_partials_dev(part_new, nb, 2, 0), rzo = sum_partials_dev(part_old, nb, 2, 0);
+        beta = (rzo > 0.0) ? rzn / rzo : 0.0;
+    }
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    double dp2 = 0.0;
+    if (i < n) {
+        const double pv = first ? z[i] : z[i] + beta * p[i];
+        p[i] = pv;
+        dp2 = d[i] * pv * pv;
+    }
+    double out2[2];
+    block_sum2(dp2, 0.0, out2);
+    if (threadIdx.x == 0) { part_dp[blockIdx.x * 2] = out2[0]; part_dp[blockIdx.x * 2 + 1] = 0.0; }
+}
+
 // trial poses + statistics: partial[b] = {|x_new - x|^2, |x|^2}
 __global__ __launch_bounds__(256) void pg_update_kernel(int n_nodes, const double* __restrict__ poses, const double* __restrict__ dx,
                                                         const unsigned char* __restrict__ fixed, double* __restrict__ poses_new,
@@ -408,9 +517,12 @@ struct stba_pg {
     int *ei = nullptr, *ej = nullptr;
     double *meas = nullptr, *r = nullptr, *Ji = nullptr, *Jj = nullptr, *g = nullptr, *Hd = nullptr, *Minv = nullptr,
            *d = nullptr, *scale = nullptr, *x = nullptr, *rr = nullptr, *z = nullptr, *p = nullptr, *q = nullptr,
-           *part_e = nullptr, *part_a = nullptr, *part_b = nullptr, *part_c = nullptr;
+           *part_e = nullptr, *part_a = nullptr, *part_b = nullptr, *part_c = nullptr, *part_d = nullptr;
     unsigned char* fixed = nullptr;
     int nb_nodes = 1, nb_vec = 1, nb_edges = 1;
+    // one rank: the edge ends (edge * 2 + side) of every node as a CSR, and the per-edge products u = (Ji^T t | Jj^T t) [12][m]
+    int *node_start = nullptr, *end_code = nullptr;
+    double* u = nullptr;
     // multi-GPU: this engine holds one shard of the EDGES, all nodes are replicated; the hook sums the
     // gradient | diagonal blocks, every matrix-vector product and the cost across ranks
     stba_allreduce_fn ar = nullptr;
@@ -425,7 +537,7 @@ void pg_free(stba_pg* g) {
     auto F = [](void* p) { if (p) (void)hipFree(p); };
     F(g->poses[0]); F(g->poses[1]); F(g->ei); F(g->ej); F(g->meas); F(g->r); F(g->Ji); F(g->Jj); F(g->g);
     F(g->Minv); F(g->d); F(g->scale); F(g->x); F(g->rr); F(g->z); F(g->p); F(g->q); F(g->part_e); F(g->part_a);
-    F(g->part_b); F(g->part_c); F(g->fixed); F(g->scalar);
+    F(g->part_b); F(g->part_c); F(g->part_d); F(g->fixed); F(g->scalar); F(g->node_start); F(g->end_code); F(g->u);
     if (g->own && g->st) (void)hipStreamDestroy(g->st);
     delete g;
 }
@@ -506,8 +618,24 @@ int stba_pg_create(stba_pg** out, int n_nodes, int n_edges, const double* poses,
     A_(dalloc(&g->p, n * 6)); A_(dalloc(&g->q, n * 6));
     const size_t np_ = (size_t)std::max(g->nb_vec, std::max(g->nb_nodes, g->nb_edges)) * 2 + 2;
     A_(dalloc(&g->part_e, np_)); A_(dalloc(&g->part_a, np_)); A_(dalloc(&g->part_b, np_)); A_(dalloc(&g->part_c, np_));
+    A_(dalloc(&g->part_d, np_));
     if (node_fixed) A_(dalloc(&g->fixed, n));
+    A_(dalloc(&g->node_start, n + 1)); A_(dalloc(&g->end_code, 2 * m)); A_(dalloc(&g->u, 12 * m));
 #undef A_
+    {   // edge ends sorted by node (counting sort; stable: a node's ends in edge order)
+        std::vector<int> start((size_t)n_nodes + 1, 0), code(2 * m);
+        for (int e = 0; e < n_edges; ++e) { ++start[(size_t)edge_i[e] + 1]; ++start[(size_t)edge_j[e] + 1]; }
+        for (int i = 0; i < n_nodes; ++i) start[(size_t)i + 1] += start[(size_t)i];
+        std::vector<int> fill(start.begin(), start.end() - 1);
+        for (int e = 0; e < n_edges; ++e) {
+            code[(size_t)fill[(size_t)edge_i[e]]++] = 2 * e;
+            code[(size_t)fill[(size_t)edge_j[e]]++] = 2 * e + 1;
+        }
+        if (hipMemcpyAsync(g->node_start, start.data(), (n + 1) * sizeof(int), hipMemcpyHostToDevice, g->st) != hipSuccess ||
+            hipMemcpyAsync(g->end_code, code.data(), 2 * m * sizeof(int), hipMemcpyHostToDevice, g->st) != hipSuccess ||
+            hipStreamSynchronize(g->st) != hipSuccess)
+            return bail(fail(STBA_ERR_HIP, "stba_pg_create: upload failed"));
+    }
     if (hipMemcpyAsync(g->poses[0], poses, n * 7 * sizeof(double), hipMemcpyHostToDevice, g->st) != hipSuccess ||
         hipMemcpyAsync(g->ei, edge_i, m * sizeof(int), hipMemcpyHostToDevice, g->st) != hipSuccess ||
         hipMemcpyAsync(g->ej, edge_j, m * sizeof(int), hipMemcpyHostToDevice, g->st) != hipSuccess ||
@@ -549,9 +677,16 @@ int stba_pg_evaluate(stba_pg* g, double* cost, double* r, double* Ji, double* Jj
     STBA_TRY(pg_sum_ranks(g, &c2));
     if (cost) *cost = 0.5 * c2;
     if (r) STBA_HIP(hipMemcpyAsync(r, g->r, (size_t)g->m * 6 * sizeof(double), hipMemcpyDeviceToHost, g->st));
-    if (Ji) STBA_HIP(hipMemcpyAsync(Ji, g->Ji, (size_t)g->m * 36 * sizeof(double), hipMemcpyDeviceToHost, g->st));
-    if (Jj) STBA_HIP(hipMemcpyAsync(Jj, g->Jj, (size_t)g->m * 36 * sizeof(double), hipMemcpyDeviceToHost, g->st));
+    // (the device keeps the Jacobians component-major, [36][m]; the caller gets them edge-major, [m][6][6])
+    std::vector<double> ti, tj;
+    if (Ji) { ti.resize((size_t)g->m * 36); STBA_HIP(hipMemcpyAsync(ti.data(), g->Ji, ti.size() * sizeof(double), hipMemcpyDeviceToHost, g->st)); }
+    if (Jj) { tj.resize((size_t)g->m * 36); STBA_HIP(hipMemcpyAsync(tj.data(), g->Jj, tj.size() * sizeof(double), hipMemcpyDeviceToHost, g->st)); }
     STBA_HIP(hipStreamSynchronize(g->st));
+    for (int k = 0; k < 36; ++k)
+        for (int e = 0; e < g->m; ++e) {
+            if (Ji) Ji[(size_t)e * 36 + k] = ti[(size_t)k * g->m + e];
+            if (Jj) Jj[(size_t)e * 36 + k] = tj[(size_t)k * g->m + e];
+        }
     return STBA_OK;
 }
 
@@ -568,15 +703,16 @@ int stba_pg_time_kernels(stba_pg* g, int reps, double* ms_linearize, double* ms_
     hipLaunchKernelGGL(pg_accumulate_kernel, dim3((2 * g->m + 255) / 256), dim3(256), 0, g->st, g->m, g->ei, g->ej, g->r, g->Ji, g->Jj, g->g, g->Hd);
     STBA_HIP(hipMemcpyAsync(g->p, g->g, (size_t)6 * g->n * sizeof(double), hipMemcpyDeviceToDevice, g->st));
     STBA_HIP(hipMemcpyAsync(g->d, g->g, (size_t)6 * g->n * sizeof(double), hipMemcpyDeviceToDevice, g->st));
-    stba_allreduce_fn ar = g->ar;
-    g->ar = nullptr;                                    // (kernel time only: no collective inside the timed region)
-    int rc = pg_apply(g, g->p, g->q, true);
-    if (rc == STBA_OK && hipEventRecord(e0, g->st) != hipSuccess) rc = fail(STBA_ERR_HIP, "hipEventRecord");
+    // the product as the one-rank solve runs it: the edge kernel (t_e, u_e = J_e^T t_e, |t_e|^2) -- the node kernel gathers u
+    // while it updates x, r, z and is not a product kernel of its own
+    int rc = STBA_OK;
+    hipLaunchKernelGGL(pg_edge_product_kernel, dim3(g->nb_edges), dim3(256), 0, g->st, g->m, g->ei, g->ej, g->Ji, g->Jj, g->p, g->u, g->part_c);
+    if (hipEventRecord(e0, g->st) != hipSuccess) rc = fail(STBA_ERR_HIP, "hipEventRecord");
     for (int k = 0; k < reps && rc == STBA_OK; ++k) rc = pg_linearize(g, g->cur, true);
     if (rc == STBA_OK && hipEventRecord(e1, g->st) != hipSuccess) rc = fail(STBA_ERR_HIP, "hipEventRecord");
-    for (int k = 0; k < reps && rc == STBA_OK; ++k) rc = pg_apply(g, g->p, g->q, true);
+    for (int k = 0; k < reps && rc == STBA_OK; ++k)
+        hipLaunchKernelGGL(pg_edge_product_kernel, dim3(g->nb_edges), dim3(256), 0, g->st, g->m, g->ei, g->ej, g->Ji, g->Jj, g->p, g->u, g->part_c);
     if (rc == STBA_OK && hipEventRecord(e2, g->st) != hipSuccess) rc = fail(STBA_ERR_HIP, "hipEventRecord");
-    g->ar = ar;
     if (rc == STBA_OK && hipStreamSynchronize(g->st) != hipSuccess) rc = fail(STBA_ERR_HIP, "hipStreamSynchronize");
     float a = 0.f, b = 0.f;
     if (rc == STBA_OK) { (void)hipEventElapsedTime(&a, e0, e1); (void)hipEventElapsedTime(&b, e1, e2); }
@@ -642,12 +778,28 @@ int stba_pg_solve(stba_pg* g, const stba_lm_options* opt_in, const stba_pcg_opti
         const double tol2 = pcg.relative_tolerance * pcg.relative_tolerance * rr0;
         int k = 0;
         bool ok = std::isfinite(rr0);
+        // (one rank: three launches per iteration, the dot product p.q gathered on the way -- see pg_matvec_dot_kernel; with
+        // several ranks the product needs a cross-rank sum between the edge kernel and the dot product: five launches)
+        const bool fused3 = (g->ar == nullptr);
+        if (fused3 && ok && rr0 > 0.0)
+            hipLaunchKernelGGL(pg_pcg_dir3_kernel, dim3(g->nb_vec), dim3(256), 0, g->st, N, g->nb_nodes, part_rz, part_rz, 1, g->z, g->d, g->p,
+                               g->part_d);
         while (ok && rr0 > 0.0 && k < pcg.max_iterations) {
-            STBA_TRY(pg_apply(g, g->p, g->q, true));
-            hipLaunchKernelGGL(pg_dot_kernel, dim3(g->nb_vec), dim3(256), 0, g->st, N, g->p, g->q, g->part_c);
-            hipLaunchKernelGGL(pg_pcg_update_kernel, dim3(g->nb_nodes), dim3(256), 0, g->st, g->n, g->nb_nodes, part_rz, g->nb_vec,
-                               g->part_c, g->Minv, g->p, g->q, g->x, g->rr, g->z, part_new);
-            hipLaunchKernelGGL(pg_pcg_dir_kernel, dim3(g->nb_vec), dim3(256), 0, g->st, N, g->nb_nodes, part_new, part_rz, g->z, g->p);
+            if (fused3) {
+                hipLaunchKernelGGL(pg_edge_product_kernel, dim3(g->nb_edges), dim3(256), 0, g->st, g->m, g->ei, g->ej, g->Ji, g->Jj, g->p, g->u,
+                                   g->part_c);
+                hipLaunchKernelGGL(pg_pcg_update3_kernel, dim3(g->nb_nodes), dim3(256), 0, g->st, g->n, g->m, g->nb_nodes, part_rz, g->nb_edges,
+                                   g->part_c, g->nb_vec, g->part_d, g->Minv, g->d, g->node_start, g->end_code, g->u, g->p, g->x, g->rr, g->z,
+                                   part_new);
+                hipLaunchKernelGGL(pg_pcg_dir3_kernel, dim3(g->nb_vec), dim3(256), 0, g->st, N, g->nb_nodes, part_new, part_rz, 0, g->z, g->d,
+                                   g->p, g->part_d);
+            } else {
+                STBA_TRY(pg_apply(g, g->p, g->q, true));
+                hipLaunchKernelGGL(pg_dot_kernel, dim3(g->nb_vec), dim3(256), 0, g->st, N, g->p, g->q, g->part_c);
+                hipLaunchKernelGGL(pg_pcg_update_kernel, dim3(g->nb_nodes), dim3(256), 0, g->st, g->n, g->nb_nodes, part_rz, g->nb_vec,
+                                   g->part_c, g->Minv, g->p, g->q, g->x, g->rr, g->z, part_new);
+                hipLaunchKernelGGL(pg_pcg_dir_kernel, dim3(g->nb_vec), dim3(256), 0, g->st, N, g->nb_nodes, part_new, part_rz, g->z, g->p);
+            }
             std::swap(part_rz, part_new);
             ++k;
             if (k % std::max(1, pcg.check_every) == 0) {
