@@ -213,21 +213,32 @@ __global__ __launch_bounds__(256) void trial_finish_kernel(const double* __restr
                                                            const double* __restrict__ part_p, int n_p, const double* __restrict__ part_c,
                                                            int n_c, const int* __restrict__ flag, double* __restrict__ out,
                                                            double* __restrict__ host_out) {
-    __shared__ double s[256];
+    // the seven sums side by side: per thread a strided share of each, then ONE tree for all of them (every sum in the order it
+    // always had: strided shares, then halving)
+    __shared__ double s[7][256];
     __shared__ double res[8];
-    for (int q = 0; q < 7; ++q) {
-        const double* partial = q == 0 ? cost_partial : (q < 4 ? part_p : part_c);
-        const int n = q == 0 ? n_cost : (q < 4 ? n_p : n_c);
-        const int stride = q == 0 ? 1 : 4, k = q == 0 ? 0 : (q < 4 ? q - 1 : q - 4);
-        double v = 0.0;
-        for (int i = threadIdx.x; i < n; i += 256) v += partial[(size_t)i * stride + k];
-        s[threadIdx.x] = v;
+    {
+        double v[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        for (int i = threadIdx.x; i < n_cost; i += 256) v[0] += cost_partial[i];
+        for (int i = threadIdx.x; i < n_p; i += 256) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) v[1 + k] += part_p[(size_t)i * 4 + k];
+        }
+        for (int i = threadIdx.x; i < n_c; i += 256) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) v[4 + k] += part_c[(size_t)i * 4 + k];
+        }
+#pragma unroll
+        for (int q = 0; q < 7; ++q) s[q][threadIdx.x] = v[q];
         __syncthreads();
         for (int off = 128; off > 0; off >>= 1) {
-            if (threadIdx.x < off) s[threadIdx.x] += s[threadIdx.x + off];
+            if (threadIdx.x < off) {
+#pragma unroll
+                for (int q = 0; q < 7; ++q) s[q][threadIdx.x] += s[q][threadIdx.x + off];
+            }
             __syncthreads();
         }
-        if (threadIdx.x == 0) res[q] = s[0];
+        if (threadIdx.x < 7) res[threadIdx.x] = s[threadIdx.x][0];
         __syncthreads();
     }
     if (threadIdx.x < 8) {
@@ -290,47 +301,84 @@ int launch_expand_jacobian(int n_obs, const double* J8, const unsigned char* oma
 // ===========================================================================================
 // point blocks: Hpp_j = sum Jp^T Jp, gp_j = sum Jp^T r over the landmark's observation segment
 // ===========================================================================================
-__global__ __launch_bounds__(256) void ba_point_blocks_kernel(int n_pts, const int* __restrict__ pt_start,
-                                                              const double* __restrict__ J8,
-                                                              const unsigned char* __restrict__ omask,
-                                                              const double2* __restrict__ r,
-                                                              double* __restrict__ Hpp6, double* __restrict__ gp,
-                                                              double* __restrict__ gpmax_partial) {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    double h0 = 0, h1 = 0, h2 = 0, h3 = 0, h4 = 0, h5 = 0, g0 = 0, g1 = 0, g2 = 0;
-    const int e = (j < n_pts) ? pt_start[j + 1] : 0;
-    for (int i = (j < n_pts) ? pt_start[j] : 0; i < e; ++i) {
-        if (omask && (omask[i] & 64u)) continue;                   // constant landmark: zero block
-        const double2* p = reinterpret_cast<const double2*>(J8 + (size_t)i * 8);
-        const double2 a = p[1], b = p[2], c = p[3];   // a.x a.y b.x | b.y c.x c.y
-        const double2 ri = r[i];
-        const double j00 = a.x, j01 = a.y, j02 = b.x, j10 = b.y, j11 = c.x, j12 = c.y;
-        h0 += j00 * j00 + j10 * j10; h1 += j00 * j01 + j10 * j11; h2 += j00 * j02 + j10 * j12;
-        h3 += j01 * j01 + j11 * j11; h4 += j01 * j02 + j11 * j12; h5 += j02 * j02 + j12 * j12;
-        g0 += j00 * ri.x + j10 * ri.y; g1 += j01 * ri.x + j11 * ri.y; g2 += j02 * ri.x + j12 * ri.y;
-    }
-    if (j < n_pts) {
-        double* H = Hpp6 + (size_t)j * 6;
-        H[0] = h0; H[1] = h1; H[2] = h2; H[3] = h3; H[4] = h4; H[5] = h5;
-        double* g = gp + (size_t)j * 3;
-        g[0] = g0; g[1] = g1; g[2] = g2;
-    }
-    if (gpmax_partial) {
-        // max |gp| of this block's landmarks (the gradient max-norm of the LM loop: one partial per block, finished by
-        // linear_finish_kernel; a maximum does not depend on the order)
-        __shared__ double s[4];
-        double m = fmax(fabs(g0), fmax(fabs(g1), fabs(g2)));
-        for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_down(m, off, 64));
-        if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = m;
+// A workgroup owns PB_LM consecutive landmarks, i.e. ONE contiguous stretch of observation records (the observations
+// are sorted by landmark).  Pass 1, one record per lane and trip: full-line loads of the records, the nine products
+// of a record into LDS (component-major).  Pass 2, one OUTPUT entry per lane: the entry's landmark's records are summed
+// in observation order (bitwise independent of the launch geometry) and stored -- consecutive lanes, consecutive
+// addresses.  (Before: one landmark per lane walking its ~10 records, every lane of a wave in a different line: 25 us
+// for 80 MB.)
+constexpr int PB_LM = 32, PB_THREADS = 128, PB_CHUNK = 3 * PB_THREADS, PB_LD = PB_CHUNK + 1;
+__global__ __launch_bounds__(PB_THREADS) void ba_point_blocks_kernel(int n_pts, const int* __restrict__ pt_start,
+                                                                     const double* __restrict__ J8,
+                                                                     const unsigned char* __restrict__ omask,
+                                                                     const double2* __restrict__ r,
+                                                                     double* __restrict__ Hpp6, double* __restrict__ gp,
+                                                                     double* __restrict__ gpmax_partial) {
+    __shared__ double u[9 * PB_LD];
+    __shared__ int seg[PB_LM + 1];
+    __shared__ double smax[PB_THREADS / 64];
+    const int t = threadIdx.x;
+    const int j0 = blockIdx.x * PB_LM, nl = min(PB_LM, n_pts - j0);
+    if (t <= nl) seg[t] = pt_start[j0 + t];
+    __syncthreads();
+    const int rb = seg[0], re = seg[nl];
+    // this lane's output entries: o = t and t + 128 of the 6 nl entries of Hpp6, o = t of the 3 nl entries of gp
+    double acc[3] = {0.0, 0.0, 0.0};
+    int lj[3], lk[3];
+    lj[0] = t / 6; lk[0] = t % 6;
+    lj[1] = (t + PB_THREADS) / 6; lk[1] = (t + PB_THREADS) % 6;
+    lj[2] = t / 3; lk[2] = 6 + t % 3;
+    if (t >= 3 * PB_LM) lj[2] = nl;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) if (lj[q] > nl) lj[q] = nl;        // (seg[nl] .. seg[nl]: nothing to sum)
+    for (int cb = rb; cb < re; cb += PB_CHUNK) {
+        const int ce = min(cb + PB_CHUNK, re);
+#pragma unroll
+        for (int s2 = 0; s2 < 3; ++s2) {
+            const int x = t + PB_THREADS * s2, i = cb + x;
+            if (i < ce) {
+                const double2* p = reinterpret_cast<const double2*>(J8 + (size_t)i * 8);
+                const double2 a = p[1], b = p[2], c = p[3];   // a.x a.y b.x | b.y c.x c.y
+                const double2 ri = r[i];
+                const bool off = omask && (omask[i] & 64u);          // constant landmark: zero block
+                const double j00 = off ? 0.0 : a.x, j01 = off ? 0.0 : a.y, j02 = off ? 0.0 : b.x;
+                const double j10 = off ? 0.0 : b.y, j11 = off ? 0.0 : c.x, j12 = off ? 0.0 : c.y;
+                u[0 * PB_LD + x] = j00 * j00 + j10 * j10; u[1 * PB_LD + x] = j00 * j01 + j10 * j11; u[2 * PB_LD + x] = j00 * j02 + j10 * j12;
+                u[3 * PB_LD + x] = j01 * j01 + j11 * j11; u[4 * PB_LD + x] = j01 * j02 + j11 * j12; u[5 * PB_LD + x] = j02 * j02 + j12 * j12;
+                u[6 * PB_LD + x] = j00 * ri.x + j10 * ri.y; u[7 * PB_LD + x] = j01 * ri.x + j11 * ri.y; u[8 * PB_LD + x] = j02 * ri.x + j12 * ri.y;
+            }
+        }
         __syncthreads();
-        if (threadIdx.x == 0) gpmax_partial[blockIdx.x] = fmax(fmax(s[0], s[1]), fmax(s[2], s[3]));
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            if (lj[q] < nl) {
+                const int b0 = max(seg[lj[q]], cb), e0 = min(seg[lj[q] + 1], ce);
+                const double* uk = u + lk[q] * PB_LD - cb;
+                for (int i = b0; i < e0; ++i) acc[q] += uk[i];
+            }
+        }
+        __syncthreads();
+    }
+    if (lj[0] < nl) Hpp6[(size_t)j0 * 6 + t] = acc[0];
+    if (lj[1] < nl) Hpp6[(size_t)j0 * 6 + t + PB_THREADS] = acc[1];
+    if (lj[2] < nl) gp[(size_t)j0 * 3 + t] = acc[2];
+    if (gpmax_partial) {
+        // max |gp| of this workgroup's landmarks (the gradient max-norm of the LM loop: one partial per workgroup, finished
+        // by linear_finish_kernel; a maximum does not depend on the order)
+        double m = (lj[2] < nl) ? fabs(acc[2]) : 0.0;
+        for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_down(m, off, 64));
+        if ((t & 63) == 0) smax[t >> 6] = m;
+        __syncthreads();
+        if (t == 0) gpmax_partial[blockIdx.x] = fmax(smax[0], smax[1]);
     }
 }
+
+int point_blocks_grid(int n_pts) { return (n_pts + PB_LM - 1) / PB_LM; }
 
 int launch_point_blocks(int n_pts, const int* pt_start, const double* J8, const unsigned char* omask, const double2* r,
                         double* Hpp6, double* gp, double* gpmax_partial, hipStream_t st) {
     if (n_pts > 0)
-        hipLaunchKernelGGL(ba_point_blocks_kernel, dim3((n_pts + 255) / 256), dim3(256), 0, st, n_pts, pt_start,
+        hipLaunchKernelGGL(ba_point_blocks_kernel, dim3(point_blocks_grid(n_pts)), dim3(PB_THREADS), 0, st, n_pts, pt_start,
                            J8, omask, r, Hpp6, gp, gpmax_partial);
     STBA_HIP(hipGetLastError());
     return STBA_OK;
@@ -344,27 +392,23 @@ __global__ __launch_bounds__(256) void linear_finish_kernel(const double* __rest
                                                             const double* __restrict__ gpmax_partial, int n_gp,
                                                             double* __restrict__ cost2_out, double* __restrict__ slots, int n_slots,
                                                             int cost_slot, int max_slot) {
-    __shared__ double s[256];
-    double v = 0.0;
+    __shared__ double s[256], smx[256];
+    double v = 0.0, m = 0.0;
     for (int i = threadIdx.x; i < n_cost; i += 256) v += cost_partial[i];
+    for (int i = threadIdx.x; i < n_gp; i += 256) m = fmax(m, gpmax_partial[i]);
     s[threadIdx.x] = v;
+    smx[threadIdx.x] = m;
     __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-        if (threadIdx.x < off) s[threadIdx.x] += s[threadIdx.x + off];
+    for (int off = 128; off > 0; off >>= 1) {          // sum and maximum in one tree
+        if (threadIdx.x < off) {
+            s[threadIdx.x] += s[threadIdx.x + off];
+            smx[threadIdx.x] = fmax(smx[threadIdx.x], smx[threadIdx.x + off]);
+        }
         __syncthreads();
     }
     const double cost2 = s[0];
-    __syncthreads();
-    double m = 0.0;
-    for (int i = threadIdx.x; i < n_gp; i += 256) m = fmax(m, gpmax_partial[i]);
-    s[threadIdx.x] = m;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-        if (threadIdx.x < off) s[threadIdx.x] = fmax(s[threadIdx.x], s[threadIdx.x + off]);
-        __syncthreads();
-    }
     if (threadIdx.x == 0) cost2_out[0] = cost2;
-    for (int i = threadIdx.x; i < n_slots; i += 256) slots[i] = (i == cost_slot) ? cost2 : (i == max_slot) ? s[0] : 0.0;
+    for (int i = threadIdx.x; i < n_slots; i += 256) slots[i] = (i == cost_slot) ? cost2 : (i == max_slot) ? smx[0] : 0.0;
 }
 
 int launch_linear_finish(const double* cost_partial, int n_cost, const double* gpmax_partial, int n_gp, double* cost2_out,
@@ -851,39 +895,144 @@ int launch_reduced_damp(int n, const double* dc, const unsigned char* cam_fixed,
     return STBA_OK;
 }
 
+// one camera of the manifold update: cams_new[c] = cams[c] (+) dxc[c] (constant dofs stay), v += {|step|^2, |x|^2, model term}
+__device__ __forceinline__ void camera_update_lane(int c, const double* __restrict__ cams, const double* __restrict__ dxc,
+                                                   const unsigned char* __restrict__ cam_fixed, const double* __restrict__ gc,
+                                                   const double* __restrict__ dc, double* __restrict__ cams_new, double v[4]) {
+    const unsigned cm = cam_fixed ? cam_fixed[c] : 0u;
+    double d[6], q[4], qn[4];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) d[a] = ((cm >> a) & 1u) ? 0.0 : dxc[c * 6 + a];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) q[a] = cams[(size_t)c * 7 + a];
+    so3_plus(q, d, qn);
+    const bool rot_active = (cm & 7u) != 7u, pos_active = (cm & 56u) != 56u;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const double out = rot_active ? qn[a] : q[a];
+        cams_new[(size_t)c * 7 + a] = out;
+        if (rot_active) { v[0] += (out - q[a]) * (out - q[a]); v[1] += q[a] * q[a]; }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const double t = cams[(size_t)c * 7 + 4 + a];
+        cams_new[(size_t)c * 7 + 4 + a] = t + d[3 + a];
+        if (pos_active) { v[0] += d[3 + a] * d[3 + a]; v[1] += t * t; }
+    }
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+        if (!((cm >> a) & 1u)) v[2] += -0.5 * gc[c * 6 + a] * d[a] + 0.5 * dc[c * 6 + a] * d[a] * d[a];
+}
+
 // ===========================================================================================
 // back-substitution: dxp_j = Hinv_j ( -gp_j - sum_l Jp_l^T (Jc_l dxc[c_l]) )
 // ===========================================================================================
-__global__ __launch_bounds__(256) void ba_backsub_kernel(int n_pts, const int* __restrict__ pt_start,
-                                                         const int* __restrict__ obs_cam,
-                                                         const double* __restrict__ Jc, const unsigned char* __restrict__ Jp,
-                                                         const double* __restrict__ Hinv6, const double* __restrict__ gp,
-                                                         const double* __restrict__ dxc, double* __restrict__ dxp) {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= n_pts) return;
-    double v0 = -gp[(size_t)j * 3], v1 = -gp[(size_t)j * 3 + 1], v2 = -gp[(size_t)j * 3 + 2];
-    const int e = pt_start[j + 1];
-    for (int l = pt_start[j]; l < e; ++l) {
-        const int c = obs_cam[l];
-        double jc[12], jp[6];
-        load_jc_jp(Jc, Jp, l, jc, jp);
-        double m0 = 0.0, m1 = 0.0;
+// Same shape as ba_point_blocks_kernel: a workgroup owns PB_LM consecutive landmarks = one contiguous stretch of records.
+// Pass 1 (a record per lane and trip, full-line loads): Jp^T (Jc dxc[cam]) of the record into LDS; pass 2 (an entry of dxp
+// per lane): the landmark's records summed in observation order, then dxp = Hinv v through LDS.  With `up.pts_new` the
+// landmark half of the manifold update and of the step statistics (ba_update_kernel) rides along: the trial point's
+// landmarks and one partial[4] per workgroup, no second pass over dxp.
+__global__ __launch_bounds__(PB_THREADS) void ba_backsub_kernel(int n_pts, const int* __restrict__ pt_start,
+                                                                const int* __restrict__ obs_cam,
+                                                                const double* __restrict__ Jc, const unsigned char* __restrict__ Jp,
+                                                                const double* __restrict__ Hinv6, const double* __restrict__ gp,
+                                                                const double* __restrict__ dxc, double* __restrict__ dxp,
+                                                                BacksubUpdate up) {
+    __shared__ double u[3 * PB_LD];
+    __shared__ int seg[PB_LM + 1];
+    __shared__ double vv[3 * PB_LM];
+    __shared__ double ssum[PB_THREADS / 64][3];
+    const int t = threadIdx.x;
+    const int gp_blocks = (n_pts + PB_LM - 1) / PB_LM;
+    if ((int)blockIdx.x >= gp_blocks) {
+        // the camera half of the update, PB_THREADS cameras per workgroup (only launched with up.cams_new)
+        const int cblk = blockIdx.x - gp_blocks, c = cblk * PB_THREADS + t;
+        double v[4] = {0.0, 0.0, 0.0, 0.0};
+        if (c < up.n_cams) camera_update_lane(c, up.cams, dxc, up.cam_fixed, up.gc, up.dc, up.cams_new, v);
 #pragma unroll
-        for (int a = 0; a < 6; ++a) { const double d = dxc[c * 6 + a]; m0 += jc[a] * d; m1 += jc[6 + a] * d; }
-        v0 -= jp[0] * m0 + jp[3] * m1;
-        v1 -= jp[1] * m0 + jp[4] * m1;
-        v2 -= jp[2] * m0 + jp[5] * m1;
+        for (int k = 0; k < 3; ++k) {
+            double x = v[k];
+            for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+            if ((t & 63) == 0) ssum[t >> 6][k] = x;
+        }
+        __syncthreads();
+        if (t < 4) up.partial_c[(size_t)cblk * 4 + t] = (t < 3) ? ssum[0][t] + ssum[1][t] : 0.0;
+        return;
     }
-    const double* Hi = Hinv6 + (size_t)j * 6;
-    dxp[(size_t)j * 3 + 0] = Hi[0] * v0 + Hi[1] * v1 + Hi[2] * v2;
-    dxp[(size_t)j * 3 + 1] = Hi[1] * v0 + Hi[3] * v1 + Hi[4] * v2;
-    dxp[(size_t)j * 3 + 2] = Hi[2] * v0 + Hi[4] * v1 + Hi[5] * v2;
+    const int j0 = blockIdx.x * PB_LM, nl = min(PB_LM, n_pts - j0);
+    if (t <= nl) seg[t] = pt_start[j0 + t];
+    __syncthreads();
+    const int rb = seg[0], re = seg[nl];
+    const int lj = t / 3, lk = t % 3;
+    const bool mine = (t < 3 * PB_LM) && (lj < nl);
+    double acc = mine ? -gp[(size_t)j0 * 3 + t] : 0.0;
+    for (int cb = rb; cb < re; cb += PB_CHUNK) {
+        const int ce = min(cb + PB_CHUNK, re);
+#pragma unroll
+        for (int s2 = 0; s2 < 3; ++s2) {
+            const int x = t + PB_THREADS * s2, l = cb + x;
+            if (l < ce) {
+                const int c = obs_cam[l];
+                double jc[12], jp[6];
+                load_jc_jp(Jc, Jp, l, jc, jp);
+                double m0 = 0.0, m1 = 0.0;
+#pragma unroll
+                for (int a = 0; a < 6; ++a) { const double d = dxc[c * 6 + a]; m0 += jc[a] * d; m1 += jc[6 + a] * d; }
+                u[0 * PB_LD + x] = jp[0] * m0 + jp[3] * m1;
+                u[1 * PB_LD + x] = jp[1] * m0 + jp[4] * m1;
+                u[2 * PB_LD + x] = jp[2] * m0 + jp[5] * m1;
+            }
+        }
+        __syncthreads();
+        if (mine) {
+            const int b0 = max(seg[lj], cb), e0 = min(seg[lj + 1], ce);
+            const double* uk = u + lk * PB_LD - cb;
+            for (int i = b0; i < e0; ++i) acc -= uk[i];
+        }
+        __syncthreads();
+    }
+    if (t < 3 * PB_LM) vv[t] = acc;
+    __syncthreads();
+    double st[3] = {0.0, 0.0, 0.0};
+    if (mine) {
+        const double* Hi = Hinv6 + (size_t)(j0 + lj) * 6;
+        const double h0 = Hi[lk == 0 ? 0 : lk], h1 = Hi[lk == 0 ? 1 : (lk == 1 ? 3 : 4)], h2 = Hi[lk == 0 ? 2 : (lk == 1 ? 4 : 5)];
+        const double d = h0 * vv[3 * lj] + h1 * vv[3 * lj + 1] + h2 * vv[3 * lj + 2];
+        dxp[(size_t)j0 * 3 + t] = d;
+        if (up.pts_new) {
+            const bool fx = up.pt_fixed ? (up.pt_fixed[j0 + lj] != 0) : false;
+            const double p = up.pts[(size_t)j0 * 3 + t];
+            const double dd = fx ? 0.0 : d;
+            up.pts_new[(size_t)j0 * 3 + t] = p + dd;
+            if (!fx) {
+                st[0] = dd * dd; st[1] = p * p;
+                st[2] = -0.5 * gp[(size_t)j0 * 3 + t] * dd + 0.5 * up.dp[(size_t)j0 * 3 + t] * dd * dd;
+            }
+        }
+    }
+    if (up.pts_new) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            double x = st[k];
+            for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+            if ((t & 63) == 0) ssum[t >> 6][k] = x;
+        }
+        __syncthreads();
+        if (t < 4) up.partial_p[(size_t)blockIdx.x * 4 + t] = (t < 3) ? ssum[0][t] + ssum[1][t] : 0.0;
+    }
 }
 
+int backsub_grid(int n_pts) { return (n_pts + PB_LM - 1) / PB_LM; }
+int backsub_cam_grid(int n_cams) { return (n_cams + PB_THREADS - 1) / PB_THREADS; }
+
 int launch_backsub(int n_pts, const int* pt_start, const int* obs_cam, const double* Jc, const unsigned char* Jp,
-                   const double* Hinv6, const double* gp, const double* dxc, double* dxp, hipStream_t st) {
-    hipLaunchKernelGGL(ba_backsub_kernel, dim3((n_pts + 255) / 256), dim3(256), 0, st, n_pts, pt_start, obs_cam, Jc,
-                       Jp, Hinv6, gp, dxc, dxp);
+                   const double* Hinv6, const double* gp, const double* dxc, double* dxp, hipStream_t st, const BacksubUpdate* up) {
+    BacksubUpdate u0{};
+    if (up) u0 = *up;
+    const int grid = backsub_grid(n_pts) + (u0.cams_new ? backsub_cam_grid(u0.n_cams) : 0);
+    if (grid > 0)
+        hipLaunchKernelGGL(ba_backsub_kernel, dim3(grid), dim3(PB_THREADS), 0, st, n_pts, pt_start, obs_cam, Jc,
+                           Jp, Hinv6, gp, dxc, dxp, u0);
     STBA_HIP(hipGetLastError());
     return STBA_OK;
 }
@@ -916,31 +1065,7 @@ __global__ __launch_bounds__(256) void ba_update_kernel(int n_cams, int n_pts, i
     double v[4] = {0, 0, 0, 0};
     if ((int)blockIdx.x < cb) {
         const int c = blockIdx.x * 256 + threadIdx.x;
-        if (c < n_cams) {
-            const unsigned cm = cam_fixed ? cam_fixed[c] : 0u;
-            double d[6], q[4], qn[4];
-#pragma unroll
-            for (int a = 0; a < 6; ++a) d[a] = ((cm >> a) & 1u) ? 0.0 : dxc[c * 6 + a];
-#pragma unroll
-            for (int a = 0; a < 4; ++a) q[a] = cams[(size_t)c * 7 + a];
-            so3_plus(q, d, qn);
-            const bool rot_active = (cm & 7u) != 7u, pos_active = (cm & 56u) != 56u;
-#pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                const double out = rot_active ? qn[a] : q[a];
-                cams_new[(size_t)c * 7 + a] = out;
-                if (rot_active) { v[0] += (out - q[a]) * (out - q[a]); v[1] += q[a] * q[a]; }
-            }
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                const double t = cams[(size_t)c * 7 + 4 + a];
-                cams_new[(size_t)c * 7 + 4 + a] = t + d[3 + a];
-                if (pos_active) { v[0] += d[3 + a] * d[3 + a]; v[1] += t * t; }
-            }
-#pragma unroll
-            for (int a = 0; a < 6; ++a)
-                if (!((cm >> a) & 1u)) v[2] += -0.5 * gc[c * 6 + a] * d[a] + 0.5 * dc[c * 6 + a] * d[a] * d[a];
-        }
+        if (c < n_cams) camera_update_lane(c, cams, dxc, cam_fixed, gc, dc, cams_new, v);
         block_sum4(v, partial_c + (size_t)blockIdx.x * 4);
     } else {
         const int blk = blockIdx.x - cb;

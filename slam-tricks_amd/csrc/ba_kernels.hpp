@@ -30,6 +30,7 @@ int launch_absmax(const double* v, size_t n, const double* v2, size_t n2, double
 // (J8: compact Jacobian [n_obs][8]; omask: per-observation mask byte of constant dofs / landmarks, or null)
 int launch_expand_jacobian(int n_obs, const double* J8, const unsigned char* omask, double* Jc, double* Jp, hipStream_t st);
 // (gpmax_partial: optional, one max |gp| per workgroup of 256 landmarks, finished by launch_linear_finish)
+int point_blocks_grid(int n_pts);      // workgroups of the landmark-block kernel = entries of its gpmax partial array
 int launch_point_blocks(int n_pts, const int* pt_start, const double* J8, const unsigned char* omask, const double2* r,
                         double* Hpp6, double* gp, double* gpmax_partial, hipStream_t st);
 int launch_linear_finish(const double* cost_partial, int n_cost, const double* gpmax_partial, int n_gp, double* cost2_out,
@@ -81,8 +82,19 @@ int launch_reduced_finalize(int n_cams, int n, const double* Hcc, const double* 
                             double* host_out, int reduced, hipStream_t st);
 int launch_reduced_damp(int n, const double* dc, const unsigned char* cam_fixed, double* S, int lda, double* rhs,
                         hipStream_t st);
+// the landmark half of the trial point made by the back-substitution kernel itself (LM loop): pts_new = pts (+) dxp and one
+// partial[4] = {|step|^2, |x|^2, model term, 0} per landmark workgroup of the launch (backsub_grid of them); all null: plain back-substitution
+// (and the camera half, in extra workgroups behind the landmark ones, when cams_new is given: backsub_cam_grid partials)
+struct BacksubUpdate {
+    const double* pts; const unsigned char* pt_fixed; const double* dp;
+    double* pts_new; double* partial_p;
+    int n_cams; const double* cams; const unsigned char* cam_fixed; const double* gc; const double* dc;
+    double* cams_new; double* partial_c;
+};
+int backsub_grid(int n_pts);
+int backsub_cam_grid(int n_cams);
 int launch_backsub(int n_pts, const int* pt_start, const int* obs_cam, const double* J8, const unsigned char* omask,
-                   const double* Hinv6, const double* gp, const double* dxc, double* dxp, hipStream_t st);
+                   const double* Hinv6, const double* gp, const double* dxc, double* dxp, hipStream_t st, const BacksubUpdate* up = nullptr);
 int launch_update(int n_cams, int n_pts, const double* cams, const double* pts, const double* dxc,
                   const double* dxp, const unsigned char* cam_fixed, const unsigned char* pt_fixed,
                   const double* gc, const double* dc, const double* gp, const double* dp, double* cams_new,

@@ -378,7 +378,7 @@ static int ba_build_reduced(stba_ba* b, const Damping& dm, bool export_host = fa
 // (behind ba_linearize_lm + ba_normal_blocks: the cost of the linearisation point -> *cost2_dev and the cost slot, the
 // |gp| maxima of the landmark-block workgroups -> this rank's slot, the rest of the scalar block zeroed)
 static int ba_fill_scalar_slots(stba_ba* b, double* cost2_dev) {
-    return launch_linear_finish(b->cost_partial, b->lin_grid, b->upd_partial_p, (b->np + 255) / 256, cost2_dev, b->ex_scalar(), b->lda,
+    return launch_linear_finish(b->cost_partial, b->lin_grid, b->upd_partial_p, point_blocks_grid(b->np), cost2_dev, b->ex_scalar(), b->lda,
                                 SC_COST2, SC_GPMAX0 + b->rank, b->st);
 }
 
@@ -389,16 +389,25 @@ __global__ void export_trial_kernel(const double* __restrict__ trial, const int*
     else if (k == TS_COUNT) out[k] = (double)flag[0];
 }
 
+// back-substitution of the LM loop: dxp, and on the way the trial point (landmarks and cameras) + its step statistics
+static int ba_backsub_trial(stba_ba* b) {
+    BacksubUpdate up{b->pts[b->cur], b->pt_fixed, b->dp, b->pts[b->cur ^ 1], b->upd_partial_p,
+                     b->nc, b->cams[b->cur], b->cam_fixed, b->ex_gc(), b->dc, b->cams[b->cur ^ 1], b->upd_partial_c};
+    return launch_backsub(b->np, b->pt_start, b->obs_cam, b->J8, b->omask, b->Hinv6, b->gp, b->dxc, b->dxp, b->st, &up);
+}
+
 // trial point: both manifold updates (one launch), the residual-only kernel, and ONE launch that finishes every sum of
 // the trial block -- and, when host_out is given (one rank, nobody watching), writes the block and the factorisation's
 // flag straight into mapped host memory: the host waits for an event behind it instead of a device-to-host copy + stream
 // synchronisation, and the stream can go on
-static int ba_trial(stba_ba* b, double* host_out) {
+// (updated: the back-substitution kernel has made the trial point and the partial sums of its step already, see ba_backsub_trial)
+static int ba_trial(stba_ba* b, double* host_out, bool updated = false) {
     const int cur = b->cur, nxt = cur ^ 1;
-    const int cb = (b->nc + 255) / 256, pb = (b->np + 255) / 256;
-    STBA_TRY(launch_update(b->nc, b->np, b->cams[cur], b->pts[cur], b->dxc, b->dxp, b->cam_fixed, b->pt_fixed,
-                           b->ex_gc(), b->dc, b->gp, b->dp, b->cams[nxt], b->pts[nxt], b->upd_partial_c,
-                           b->upd_partial_p, b->st));
+    const int cb = updated ? backsub_cam_grid(b->nc) : (b->nc + 255) / 256, pb = updated ? backsub_grid(b->np) : (b->np + 255) / 256;
+    if (!updated)
+        STBA_TRY(launch_update(b->nc, b->np, b->cams[cur], b->pts[cur], b->dxc, b->dxp, b->cam_fixed, b->pt_fixed,
+                               b->ex_gc(), b->dc, b->gp, b->dp, b->cams[nxt], b->pts[nxt], b->upd_partial_c,
+                               b->upd_partial_p, b->st));
     static_assert(TS_COST2 == 0 && TS_STEP2 == 1 && TS_X2 == 2 && TS_MODEL == 3 && TS_CAM == 4 && TS_COUNT == 8, "trial_finish_kernel writes this layout");
     STBA_TRY(launch_linearize(lin_args(b, nxt, false), false, b->lin_grid, b->st));
     STBA_TRY(launch_trial_finish(b->cost_partial, b->lin_grid, b->upd_partial_p, b->np > 0 ? pb : 0, b->upd_partial_c, cb, b->flag, b->trial,
@@ -569,7 +578,7 @@ static int ba_run_lm(stba_ba* b, const stba_lm_options* opt_in, int fixed_iterat
         int flag_h = 0;
         STBA_TRY(chol_factor_solve_dev(b->S(), b->lda, b->n, b->dxc, b->flag, b->st));
         if (timing) STBA_HIP(hipEventRecord(ev[4], b->st));
-        STBA_TRY(launch_backsub(b->np, b->pt_start, b->obs_cam, b->J8, b->omask, b->Hinv6, b->gp, b->dxc, b->dxp, b->st));
+        STBA_TRY(ba_backsub_trial(b));
         if (timing) STBA_HIP(hipEventRecord(ev[5], b->st));
         // Nobody watches the iterations and there is one rank: the host learns the trial point's scalars through mapped
         // memory and an event, and meanwhile the stream already linearises AT THE TRIAL POINT -- a step is accepted far
@@ -582,7 +591,7 @@ static int ba_run_lm(stba_ba* b, const stba_lm_options* opt_in, int fixed_iterat
             STBA_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->ts_host), (TS_COUNT + 1) * sizeof(double), hipHostMallocMapped));
             STBA_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&b->ts_host_dev), b->ts_host, 0));
         }
-        STBA_TRY(ba_trial(b, fast ? b->ts_host_dev : nullptr));
+        STBA_TRY(ba_trial(b, fast ? b->ts_host_dev : nullptr, true));
         if (timing) STBA_HIP(hipEventRecord(ev[6], b->st));
         double ts[TS_COUNT];
         bool speculated = false;
@@ -1040,8 +1049,8 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
     A_(dev_alloc(&b->Sbuf, b->sbuf_count()));
     A_(dev_alloc(&b->dxc, (size_t)b->lda)); A_(dev_alloc(&b->dxp, np * 3));
     A_(dev_alloc(&b->cost_partial, (size_t)b->lin_grid));
-    A_(dev_alloc(&b->upd_partial_c, (size_t)((n_cams + 255) / 256) * 4));
-    A_(dev_alloc(&b->upd_partial_p, (size_t)((n_pts + 255) / 256 + 1) * 4));
+    A_(dev_alloc(&b->upd_partial_c, (size_t)backsub_cam_grid(n_cams) * 4));    // (>= (n_cams + 255) / 256 blocks of 4)
+    A_(dev_alloc(&b->upd_partial_p, (size_t)(point_blocks_grid(n_pts) + 1) * 4));    // (>= (n_pts + 255) / 256 + 1 blocks of 4)
     A_(dev_alloc(&b->trial, (size_t)TS_COUNT + 1)); A_(dev_alloc(&b->flag, 1));
 
     tmark("device allocations");
