@@ -401,7 +401,10 @@ static int ba_backsub_trial(stba_ba* b) {
 // flag straight into mapped host memory: the host waits for an event behind it instead of a device-to-host copy + stream
 // synchronisation, and the stream can go on
 // (updated: the back-substitution kernel has made the trial point and the partial sums of its step already, see ba_backsub_trial)
-static int ba_trial(stba_ba* b, double* host_out, bool updated = false) {
+// (with_jac: the stream is going to linearise at the trial point anyway (speculation, see ba_run_lm) -- then THAT kernel
+// evaluates the trial point: residuals, Jacobian records and the cost partials in one pass instead of a residual-only pass
+// followed by the full one)
+static int ba_trial(stba_ba* b, double* host_out, bool updated = false, bool with_jac = false) {
     const int cur = b->cur, nxt = cur ^ 1;
     const int cb = updated ? backsub_cam_grid(b->nc) : (b->nc + 255) / 256, pb = updated ? backsub_grid(b->np) : (b->np + 255) / 256;
     if (!updated)
@@ -409,7 +412,8 @@ static int ba_trial(stba_ba* b, double* host_out, bool updated = false) {
                                b->ex_gc(), b->dc, b->gp, b->dp, b->cams[nxt], b->pts[nxt], b->upd_partial_c,
                                b->upd_partial_p, b->st));
     static_assert(TS_COST2 == 0 && TS_STEP2 == 1 && TS_X2 == 2 && TS_MODEL == 3 && TS_CAM == 4 && TS_COUNT == 8, "trial_finish_kernel writes this layout");
-    STBA_TRY(launch_linearize(lin_args(b, nxt, false), false, b->lin_grid, b->st));
+    if (with_jac) STBA_TRY(ba_linearize_lm(b, nxt));
+    else STBA_TRY(launch_linearize(lin_args(b, nxt, false), false, b->lin_grid, b->st));
     STBA_TRY(launch_trial_finish(b->cost_partial, b->lin_grid, b->upd_partial_p, b->np > 0 ? pb : 0, b->upd_partial_c, cb, b->flag, b->trial,
                                  b->ar ? nullptr : host_out, b->st));
     if (b->ar) {
@@ -591,17 +595,18 @@ static int ba_run_lm(stba_ba* b, const stba_lm_options* opt_in, int fixed_iterat
             STBA_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->ts_host), (TS_COUNT + 1) * sizeof(double), hipHostMallocMapped));
             STBA_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&b->ts_host_dev), b->ts_host, 0));
         }
-        STBA_TRY(ba_trial(b, fast ? b->ts_host_dev : nullptr, true));
+        // (the speculative linearisation IS the evaluation of the trial point: one pass over the observations, not two)
+        const bool speculate = fast && !(fixed && iter >= max_iter);
+        STBA_TRY(ba_trial(b, fast ? b->ts_host_dev : nullptr, true, speculate));
         if (timing) STBA_HIP(hipEventRecord(ev[6], b->st));
         double ts[TS_COUNT];
         bool speculated = false;
         if (fast) {
             STBA_HIP(hipEventRecord(ev[12], b->st));
-            if (!(fixed && iter >= max_iter)) {
+            if (speculate) {
                 // (its own pair of events, alternating: the previous linearisation's pair is read behind the synchronisation below)
                 spec_ev = (spec_ev == 8) ? 13 : 8;
                 if (timing) STBA_HIP(hipEventRecord(ev[spec_ev], b->st));
-                STBA_TRY(ba_linearize_lm(b, b->cur ^ 1));
                 STBA_TRY(ba_normal_blocks(b));
                 if (timing) STBA_HIP(hipEventRecord(ev[spec_ev + 1], b->st));
                 STBA_TRY(ba_fill_scalar_slots(b, b->trial + TS_SPEC_COST2));
