@@ -479,6 +479,45 @@ def test_edge_cases(st, O):
     assert summ.num_iterations == so.num_iterations and abs(summ.final_cost - so.final_cost) < 1e-15
 
 
+def test_landmarks_with_many_observations(st, O, scenes):
+    """The landmark kernels (blocks, back-substitution) take a workgroup's 32 landmarks' records through LDS 384 at a time:
+    with ~25 observations per landmark a workgroup makes several passes, and 300 landmarks leave a ragged last workgroup."""
+    s = scenes.st20_scene(n_cams=120, n_pts=300, seed=5)
+    per_pt = np.bincount(s["obs_pt"], minlength=300)
+    assert per_pt.max() > 24 and per_pt[:288].reshape(9, 32).sum(1).max() > 2 * 384      # (three passes)
+    e, o = engine(st, s), oracle(O, s)
+    e.evaluate()
+    Hcc, gc, Hpp, gp = e.normal_blocks()
+    _, ro, Jco, Jpo = o.evaluate()
+    Hcco, gco, Hppo, gpo = o.normal_blocks(ro, Jco, Jpo)
+    for a, b in ((Hcc, Hcco), (gc, gco), (Hpp, Hppo), (gp, gpo)):
+        assert np.abs(a - b).max() <= 1e-12 * max(1.0, np.abs(b).max())
+    rng = np.random.default_rng(1)
+    dc = rng.uniform(0.01, 0.1, (e.nc, 6)); dp = rng.uniform(0.01, 0.1, (e.np_, 3))
+    e.reduced_system(dc, dp)
+    So, rhso = o.reduced_system(ro, Jco, Jpo, dc, dp)
+    dxc = e.solve_reduced()
+    dxp = e.back_substitute()
+    v = -gpo.copy()
+    for i in range(o.no):
+        c, j = o.obs_cam[i], o.obs_pt[i]
+        v[j] -= Jpo[i].T @ (Jco[i] @ dxc[6 * c:6 * c + 6])
+    ref_p = np.linalg.solve(Hppo + np.einsum("ij,jk->ijk", dp, np.eye(3)), v[..., None])[..., 0]
+    assert np.abs(dxp - ref_p).max() < 1e-10 * max(1.0, np.abs(ref_p).max())
+    # and the LM loop (its back-substitution makes the trial point on the way) follows the oracle
+    e, o = engine(st, s), oracle(O, s)
+    summ, tr = e.solve()
+    so, tro = o.solve()
+    assert summ.num_iterations == so.num_iterations and summ.termination_reason == so.termination_reason
+    n = min(len(tr), len(tro))
+    big = tro[:n, 0] > 1e-9
+    assert np.allclose(tr[:n, 0][big], tro[:n, 0][big], rtol=1e-6) and np.all(tr[:n, 6] == tro[:n, 6])
+    assert np.allclose(tr[:n, 3], tro[:n, 3], rtol=1e-6, atol=1e-12)        # step norms (the fused update's statistics)
+    cams, pts = e.get_params()
+    dq, dt = pose_err(cams, o.cams)
+    assert dq < 1e-8 and dt < 1e-8 and np.abs(pts - o.pts).max() < 1e-7
+
+
 # ------------------------------------------------------------------------------- persistent program: time-out and fallback
 def test_cholesky_falls_back_to_the_stage_kernels_on_a_timeout(st, O, scenes):
     """The persistent factorisation needs its workgroups resident at the same time; on a device it does not own a
