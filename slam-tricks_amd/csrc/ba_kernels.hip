@@ -212,7 +212,7 @@ int launch_absmax(const double* v, size_t n, const double* v2, size_t n2, double
 __global__ __launch_bounds__(256) void trial_finish_kernel(const double* __restrict__ cost_partial, int n_cost,
                                                            const double* __restrict__ part_p, int n_p, const double* __restrict__ part_c,
                                                            int n_c, const int* __restrict__ flag, double* __restrict__ out,
-                                                           double* __restrict__ host_out) {
+                                                           double* __restrict__ host_out, double host_seq) {
     // the seven sums side by side: per thread a strided share of each, then ONE tree for all of them (every sum in the order it
     // always had: strided shares, then halving)
     __shared__ double s[7][256];
@@ -246,11 +246,19 @@ __global__ __launch_bounds__(256) void trial_finish_kernel(const double* __restr
         out[threadIdx.x] = v;
         if (host_out) host_out[threadIdx.x] = v;
     } else if (threadIdx.x == 8 && host_out) host_out[8] = (double)flag[0];
+    if (host_out) {
+        // the host polls host_out[9] (no event on the stream: an event record is ~5 us of idle GPU): the block first,
+        // system-wide, then the sequence number
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) { host_out[9] = host_seq; __threadfence_system(); }
+    }
 }
 
 int launch_trial_finish(const double* cost_partial, int n_cost, const double* part_p, int n_p, const double* part_c, int n_c,
-                        const int* flag, double* out, double* host_out, hipStream_t st) {
-    hipLaunchKernelGGL(trial_finish_kernel, dim3(1), dim3(256), 0, st, cost_partial, n_cost, part_p, n_p, part_c, n_c, flag, out, host_out);
+                        const int* flag, double* out, double* host_out, double host_seq, hipStream_t st) {
+    hipLaunchKernelGGL(trial_finish_kernel, dim3(1), dim3(256), 0, st, cost_partial, n_cost, part_p, n_p, part_c, n_c, flag, out, host_out,
+                       host_seq);
     STBA_HIP(hipGetLastError());
     return STBA_OK;
 }

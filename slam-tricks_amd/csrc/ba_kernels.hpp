@@ -36,7 +36,7 @@ int launch_point_blocks(int n_pts, const int* pt_start, const double* J8, const 
 int launch_linear_finish(const double* cost_partial, int n_cost, const double* gpmax_partial, int n_gp, double* cost2_out,
                          double* slots, int n_slots, int cost_slot, int max_slot, hipStream_t st);
 int launch_trial_finish(const double* cost_partial, int n_cost, const double* part_p, int n_p, const double* part_c, int n_c,
-                        const int* flag, double* out, double* host_out, hipStream_t st);
+                        const int* flag, double* out, double* host_out, double host_seq, hipStream_t st);
 int launch_camera_blocks(int n_cams, int n_chunks, const int* chunk_begin, const int* chunk_end,
                          const int* cam_chunk_start, const int* cam_perm, const double* J8, const unsigned char* omask,
                          const double2* r, double* partial, double* Hcc, double* gc, hipStream_t st);

@@ -5,6 +5,7 @@
 // defaults listed in SURVEY.md 8c; all arithmetic on problem-sized data runs in HIP kernels.
 // There is no CPU fallback: without a HIP device every compute entry point fails.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <thread>
 #include <vector>
@@ -105,6 +106,7 @@ struct stba_ba {
     double* trial = nullptr;   // TS_COUNT + 1 doubles
     double* ts_host = nullptr;   // mapped pinned host memory: the trial block + the factorisation flag, written by a kernel
     double* ts_host_dev = nullptr;
+    double ts_seq = 0.0;         // sequence number of the last trial block asked for (entry TS_COUNT + 1 of ts_host)
     int* flag = nullptr;
     int lin_grid = 1;
     stba_allreduce_fn ar = nullptr;
@@ -383,10 +385,13 @@ static int ba_fill_scalar_slots(stba_ba* b, double* cost2_dev) {
 }
 
 // the trial block and the factorisation's flag into mapped host memory (several ranks; one rank: trial_finish_kernel does it)
-__global__ void export_trial_kernel(const double* __restrict__ trial, const int* __restrict__ flag, double* __restrict__ out) {
+__global__ void export_trial_kernel(const double* __restrict__ trial, const int* __restrict__ flag, double* __restrict__ out, double seq) {
     const int k = threadIdx.x;
     if (k < TS_COUNT) out[k] = trial[k];
     else if (k == TS_COUNT) out[k] = (double)flag[0];
+    __threadfence_system();
+    __syncthreads();
+    if (k == 0) { out[TS_COUNT + 1] = seq; __threadfence_system(); }      // (the host polls this entry, see ba_wait_trial)
 }
 
 // back-substitution of the LM loop: dxp, and on the way the trial point (landmarks and cameras) + its step statistics
@@ -404,7 +409,7 @@ static int ba_backsub_trial(stba_ba* b) {
 // (with_jac: the stream is going to linearise at the trial point anyway (speculation, see ba_run_lm) -- then THAT kernel
 // evaluates the trial point: residuals, Jacobian records and the cost partials in one pass instead of a residual-only pass
 // followed by the full one)
-static int ba_trial(stba_ba* b, double* host_out, bool updated = false, bool with_jac = false) {
+static int ba_trial(stba_ba* b, double* host_out, bool updated = false, bool with_jac = false, double host_seq = 0.0) {
     const int cur = b->cur, nxt = cur ^ 1;
     const int cb = updated ? backsub_cam_grid(b->nc) : (b->nc + 255) / 256, pb = updated ? backsub_grid(b->np) : (b->np + 255) / 256;
     if (!updated)
@@ -415,13 +420,32 @@ static int ba_trial(stba_ba* b, double* host_out, bool updated = false, bool wit
     if (with_jac) STBA_TRY(ba_linearize_lm(b, nxt));
     else STBA_TRY(launch_linearize(lin_args(b, nxt, false), false, b->lin_grid, b->st));
     STBA_TRY(launch_trial_finish(b->cost_partial, b->lin_grid, b->upd_partial_p, b->np > 0 ? pb : 0, b->upd_partial_c, cb, b->flag, b->trial,
-                                 b->ar ? nullptr : host_out, b->st));
+                                 b->ar ? nullptr : host_out, host_seq, b->st));
     if (b->ar) {
         if (b->ar(b->ar_user, b->trial, 4, b->st) != 0) return fail(STBA_ERR_CALLBACK, "all-reduce hook failed");
         // (several ranks: the block goes to the host behind the cross-rank sum of its first four entries)
-        if (host_out) hipLaunchKernelGGL(export_trial_kernel, dim3(1), dim3(64), 0, b->st, b->trial, b->flag, host_out);
+        if (host_out) hipLaunchKernelGGL(export_trial_kernel, dim3(1), dim3(64), 0, b->st, b->trial, b->flag, host_out, host_seq);
         STBA_HIP(hipGetLastError());
     }
+    return STBA_OK;
+}
+
+// The host's side of the mapped-memory hand-off: the trial block is complete once the sequence number behind it is the
+// one this iteration's kernel was given.  (No event: a record between two kernels costs the GPU ~5 us, and the stream goes
+// straight on with the speculative work.)  The stream is queried now and then so that a device fault ends the wait.
+static int ba_wait_trial(stba_ba* b, double seq) {
+    volatile double* h = b->ts_host;
+    const double t0 = wall_s();
+    for (unsigned long n = 1; h[TS_COUNT + 1] != seq; ++n) {
+        if ((n & 0x3fff) == 0) {
+            const hipError_t q = hipStreamQuery(b->st);
+            if (q != hipSuccess && q != hipErrorNotReady) return fail(STBA_ERR_HIP, std::string("stream failed while waiting for the trial point: ") + hipGetErrorString(q));
+            if (q == hipSuccess && h[TS_COUNT + 1] != seq) return fail(STBA_ERR_HIP, "the trial block never arrived in mapped host memory");
+            if (wall_s() - t0 > 120.0) return fail(STBA_ERR_HIP, "timed out waiting for the trial point");
+        }
+        __builtin_ia32_pause();
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
     return STBA_OK;
 }
 
@@ -592,17 +616,18 @@ static int ba_run_lm(stba_ba* b, const stba_lm_options* opt_in, int fixed_iterat
         // the speculative build are enqueued on the stream like everything else.)
         const bool fast = deferred_ok && SPECULATE;
         if (fast && !b->ts_host) {
-            STBA_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->ts_host), (TS_COUNT + 1) * sizeof(double), hipHostMallocMapped));
+            STBA_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->ts_host), (TS_COUNT + 2) * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
             STBA_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&b->ts_host_dev), b->ts_host, 0));
+            b->ts_host[TS_COUNT + 1] = 0.0;
         }
         // (the speculative linearisation IS the evaluation of the trial point: one pass over the observations, not two)
         const bool speculate = fast && !(fixed && iter >= max_iter);
-        STBA_TRY(ba_trial(b, fast ? b->ts_host_dev : nullptr, true, speculate));
+        const double seq = fast ? (b->ts_seq += 1.0) : 0.0;
+        STBA_TRY(ba_trial(b, fast ? b->ts_host_dev : nullptr, true, speculate, seq));
         if (timing) STBA_HIP(hipEventRecord(ev[6], b->st));
         double ts[TS_COUNT];
         bool speculated = false;
         if (fast) {
-            STBA_HIP(hipEventRecord(ev[12], b->st));
             if (speculate) {
                 // (its own pair of events, alternating: the previous linearisation's pair is read behind the synchronisation below)
                 spec_ev = (spec_ev == 8) ? 13 : 8;
@@ -612,7 +637,7 @@ static int ba_run_lm(stba_ba* b, const stba_lm_options* opt_in, int fixed_iterat
                 STBA_TRY(ba_fill_scalar_slots(b, b->trial + TS_SPEC_COST2));
                 speculated = true;
             }
-            STBA_HIP(hipEventSynchronize(ev[12]));
+            STBA_TRY(ba_wait_trial(b, seq));
             for (int k = 0; k < TS_COUNT; ++k) ts[k] = b->ts_host[k];
             flag_h = (int)b->ts_host[TS_COUNT];
         } else {
