@@ -102,7 +102,10 @@ typedef struct {
     double final_radius;
     double final_gradient_max_norm;
     double seconds_total;
-    /* device time per phase, milliseconds, summed over iterations (hipEvent); zero unless stba_lm_options::phase_timing */
+    /* device time per phase, milliseconds, summed over iterations (hipEvent); zero unless stba_lm_options::phase_timing.
+     * ms_backsub: back-substitution + the manifold update to the trial point (one kernel); ms_cost: evaluation of the trial
+     * point -- when the loop speculates (no callback, no progress output) that is the FULL linearisation at the trial point,
+     * and ms_linearize then holds only the landmark blocks behind it */
     double ms_linearize, ms_schur, ms_solve, ms_backsub, ms_cost;
     /* several ranks: the cross-rank sums of the reduced camera system of this run -- device time between
      * events around the collective (part of ms_schur), bytes handed to it per rank, number of calls; 0 on one rank */
