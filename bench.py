@@ -442,7 +442,7 @@ def main():
                                  "ms_per_launch": ms_schur, "lds_atomics_per_launch": schur_atomics, "pairs_per_launch": schur_pairs,
                                  "floor_ms": schur_atomics / (LDS_ATOMIC_PEAK * 1e9) * 1e3,
                                  "traffic": 681.3e6 if local_obs == 1000000 else None,
-                                 "traffic_source": "profiles/r3_pmc_assembly_kernels.json (rocprofv3 --pmc, separate passes: FETCH_SIZE 495.9 MB + WRITE_SIZE "
+                                 "traffic_source": "profiles/r3_e_pmc_assembly_kernels.json (rocprofv3 --pmc, separate passes: FETCH_SIZE 495.9 MB + WRITE_SIZE "
                                                    "185.4 MB per launch at C5; a recorded figure, not measured in this run).  The second bound of the "
                                                    "kernel: 65 MB of Jacobian records are fetched ~6 times over, 144 MB of S zeroed + 40 MB of blocks written"}
         # the dominant kernel by device time carries the headline roofline object
