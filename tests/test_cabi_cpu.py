@@ -30,6 +30,16 @@ def test_header_symbols_are_exported(st):
     assert L.stba_version() == 2
 
 
+def test_shipped_library_reads_no_experiment_knobs(st):
+    """the in-tree library is the PRODUCT build: the scheduling-experiment environment variables exist only in
+    STBA_DEBUG_KNOBS builds (csrc/common.hpp knob_int), which must not be what travels to the GPU box"""
+    if os.environ.get("STBA_DEBUG_KNOBS", "0") not in ("", "0"):
+        pytest.skip("debug-knob build requested by the environment")
+    blob = open(st.LIB_PATH, "rb").read()
+    for name in (b"STBA_MEGA_QROWS", b"STBA_MEGA_DUR", b"STBA_LM_SPECULATE", b"STBA_MEGA_TRACE"):
+        assert name not in blob, name
+
+
 def test_default_options_are_ceres_defaults(st):
     o = st.default_options()
     assert o.max_num_iterations == 50 and o.initial_trust_region_radius == 1e4
