@@ -632,7 +632,7 @@ int launch_point_invert(int n_pts, const double* Hpp6, const double* dp, const u
 // reduction over the camera's observations, whose records are in this CU's caches at that moment (as a kernel of its
 // own that gather cost 46 us per iteration).  Fixed summation order: Hcc and gc are bitwise reproducible.
 // ===========================================================================================
-__global__ __launch_bounds__(SCHUR_THREADS) void ba_schur_pairs_kernel(SchurArgs a) {
+__global__ __launch_bounds__(SCHUR_THREADS, 4) void ba_schur_pairs_kernel(SchurArgs a) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int task = blockIdx.x;
     const int c = a.task_cam[task];
@@ -641,8 +641,8 @@ __global__ __launch_bounds__(SCHUR_THREADS) void ba_schur_pairs_kernel(SchurArgs
     const int col0 = a.row_col_ptr[c] + clo, ncols = chi - clo;
     double* acc = smem;                          // [ncols][SCHUR_BLK_LD]
     double* racc = smem + (size_t)a.max_cols * SCHUR_BLK_LD;   // [8]
-    double* cpart = racc + 8;                    // [8 waves][28]: the waves' partial camera blocks
-    int* cols = reinterpret_cast<int*>(cpart + 8 * 28);    // [ncols]
+    double* cpart = racc + 8;                    // [8 waves][SCHUR_CAM_LD]: the waves' partial camera blocks and (i, i) terms
+    int* cols = reinterpret_cast<int*>(cpart + 8 * SCHUR_CAM_LD);    // [ncols]
     const int tid = threadIdx.x;
     const bool diag_piece = (chi == row_ncols);  // (the diagonal block is the last one of its row)
     for (int e = tid; e < ncols * SCHUR_BLK_LD; e += SCHUR_THREADS) acc[e] = 0.0;
@@ -683,11 +683,6 @@ __global__ __launch_bounds__(SCHUR_THREADS) void ba_schur_pairs_kernel(SchurArgs
             E[q * 3 + 1] = w0 * Hi[1] + w1 * Hi[3] + w2 * Hi[4];
             E[q * 3 + 2] = w0 * Hi[2] + w1 * Hi[4] + w2 * Hi[5];
         }
-        if (sl & 0x4000u) {                  // l == i: this observation's share of the right-hand side
-            const double g0 = a.gp[(size_t)rc.z * 3], g1 = a.gp[(size_t)rc.z * 3 + 1], g2 = a.gp[(size_t)rc.z * 3 + 2];
-#pragma unroll
-            for (int q = 0; q < 6; ++q) unsafeAtomicAdd(&racc[q], E[q * 3] * g0 + E[q * 3 + 1] * g1 + E[q * 3 + 2] * g2);
-        }
         const bool diag = (sl & 0x8000u) != 0;
         double* blk = acc + (size_t)(sl & 0x3fffu) * SCHUR_BLK_LD;
 #pragma unroll
@@ -706,28 +701,88 @@ __global__ __launch_bounds__(SCHUR_THREADS) void ba_schur_pairs_kernel(SchurArgs
     if (diag_piece) {
         // camera blocks of camera c: 21 unique entries of Jc^T Jc and 6 of Jc^T r summed over the camera's observations --
         // a strided share per lane, a shuffle tree per wave, the eight waves' partial sums added in order below
-        double h[27];
-#pragma unroll
-        for (int k = 0; k < 27; ++k) h[k] = 0.0;
+        // The same pass makes the pairs (i, i): every observation's own term E_i W_i^T of the DIAGONAL block and its share
+        // E_i gp of the right-hand side.  As LDS atomics they were the worst ones of the kernel -- a thousand pairs per row
+        // adding to the same 21 + 6 addresses, a dozen of them in every wave (27 of the 198 M atomics of a C5 launch);
+        // here they are register sums like the camera block.
+        // (two passes over the camera's records, 27 running sums each: all 54 in one loop need 238 registers and halve
+        // the occupancy of the whole kernel; the second pass finds the records in the L1 / L2)
         const int pe = a.cam_start[c + 1];
-        for (int p = a.cam_start[c] + tid; p < pe; p += SCHUR_THREADS) {
-            const int i = a.cam_perm[p];
-            double j[12], jpu[6];
-            load_jc_jp(a.J8, a.omask, i, j, jpu);
-            const double2 ri = a.r[i];
-            int idx = 0;
+        {
+            double h[27];
 #pragma unroll
-            for (int q = 0; q < 6; ++q)
+            for (int k = 0; k < 27; ++k) h[k] = 0.0;
+            for (int p = a.cam_start[c] + tid; p < pe; p += SCHUR_THREADS) {
+                const int i = a.cam_perm[p];
+                double j[12], jpu[6];
+                load_jc_jp(a.J8, a.omask, i, j, jpu);
+                const double2 ri = a.r[i];
+                int idx = 0;
 #pragma unroll
-                for (int b = 0; b <= q; ++b) h[idx++] += j[q] * j[b] + j[6 + q] * j[6 + b];
+                for (int q = 0; q < 6; ++q)
 #pragma unroll
-            for (int q = 0; q < 6; ++q) h[21 + q] += j[q] * ri.x + j[6 + q] * ri.y;
+                    for (int b = 0; b <= q; ++b) h[idx++] += j[q] * j[b] + j[6 + q] * j[6 + b];
+#pragma unroll
+                for (int q = 0; q < 6; ++q) h[21 + q] += j[q] * ri.x + j[6 + q] * ri.y;
+            }
+#pragma unroll
+            for (int k = 0; k < 27; ++k) {
+                double v = h[k];
+                for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+                if ((tid & 63) == 0) cpart[(tid >> 6) * SCHUR_CAM_LD + k] = v;
+            }
         }
+        {
+            double h[27];       // [0 .. 20] = -sum E W^T (lower triangle, row-wise), [21 .. 26] = sum E gp
 #pragma unroll
-        for (int k = 0; k < 27; ++k) {
-            double v = h[k];
-            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-            if ((tid & 63) == 0) cpart[(tid >> 6) * 28 + k] = v;
+            for (int k = 0; k < 27; ++k) h[k] = 0.0;
+            for (int p = a.cam_start[c] + tid; p < pe; p += SCHUR_THREADS) {
+                const int i = a.cam_perm[p];
+                double j[12], jpu[6];
+                load_jc_jp(a.J8, a.omask, i, j, jpu);
+                const int lm = a.obs_pt[i];
+                double Hi[6];
+#pragma unroll
+                for (int k2 = 0; k2 < 6; ++k2) Hi[k2] = a.Hinv6[(size_t)lm * 6 + k2];
+                const double g0 = a.gp[(size_t)lm * 3], g1 = a.gp[(size_t)lm * 3 + 1], g2 = a.gp[(size_t)lm * 3 + 2];
+                double W[18];
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
+                    W[q * 3 + 0] = j[q] * jpu[0] + j[6 + q] * jpu[3];
+                    W[q * 3 + 1] = j[q] * jpu[1] + j[6 + q] * jpu[4];
+                    W[q * 3 + 2] = j[q] * jpu[2] + j[6 + q] * jpu[5];
+                }
+                int idx = 0;
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
+                    const double e0 = W[q * 3] * Hi[0] + W[q * 3 + 1] * Hi[1] + W[q * 3 + 2] * Hi[2];
+                    const double e1 = W[q * 3] * Hi[1] + W[q * 3 + 1] * Hi[3] + W[q * 3 + 2] * Hi[4];
+                    const double e2 = W[q * 3] * Hi[2] + W[q * 3 + 1] * Hi[4] + W[q * 3 + 2] * Hi[5];
+#pragma unroll
+                    for (int b = 0; b <= q; ++b) h[idx++] -= e0 * W[b * 3] + e1 * W[b * 3 + 1] + e2 * W[b * 3 + 2];
+                    h[21 + q] += e0 * g0 + e1 * g1 + e2 * g2;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 27; ++k) {
+                double v = h[k];
+                for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+                if ((tid & 63) == 0) cpart[(tid >> 6) * SCHUR_CAM_LD + 27 + k] = v;
+            }
+        }
+        __syncthreads();
+        // the eight waves' sums of the diagonal block and of the right-hand side join the LDS accumulators (in wave order)
+        if (tid < 27 && ncols > 0) {
+            double s2 = 0.0;
+#pragma unroll
+            for (int w = 0; w < SCHUR_THREADS / 64; ++w) s2 += cpart[w * SCHUR_CAM_LD + 27 + tid];
+            if (tid < 21) {
+                int q = 0, b = tid;
+                while (b > q) { ++q; b -= q; }   // tid = q(q+1)/2 + b
+                acc[(size_t)(ncols - 1) * SCHUR_BLK_LD + q * 6 + b] += s2;      // (the diagonal block is the slice's last one)
+            } else {
+                racc[tid - 21] += s2;
+            }
         }
     }
     __syncthreads();
@@ -743,7 +798,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void ba_schur_pairs_kernel(SchurArgs
             const int k = tid - 64;
             double s = 0.0;
 #pragma unroll
-            for (int w = 0; w < SCHUR_THREADS / 64; ++w) s += cpart[w * 28 + k];
+            for (int w = 0; w < SCHUR_THREADS / 64; ++w) s += cpart[w * SCHUR_CAM_LD + k];
             if (k < 21) {
                 int q = 0, b = k;
                 while (b > q) { ++q; b -= q; }   // k = q(q+1)/2 + b
@@ -757,7 +812,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void ba_schur_pairs_kernel(SchurArgs
 }
 
 size_t schur_rows_lds_bytes(int max_cols) {
-    return ((size_t)max_cols * SCHUR_BLK_LD + 8 + 8 * 28) * sizeof(double) + (size_t)max_cols * sizeof(int) + 16;
+    return ((size_t)max_cols * SCHUR_BLK_LD + 8 + 8 * SCHUR_CAM_LD) * sizeof(double) + (size_t)max_cols * sizeof(int) + 16;
 }
 
 int launch_schur_rows(const SchurArgs& a, int n_tasks, hipStream_t st) {

@@ -56,6 +56,8 @@ constexpr int SCHUR_TASK_PAIRS = 1 << 30;
 // into different bank pairs (36 = 72 dwords = 8 mod 64 gave 8-way conflicts on every ds_add_f64: measured,
 // the kernel was bound by them)
 constexpr int SCHUR_BLK_LD = 37;
+constexpr int SCHUR_CAM_SUMS = 54;   // per camera: 21 + 6 of the camera block, 21 + 6 of the pairs (i, i) (see the Schur kernel)
+constexpr int SCHUR_CAM_LD = 56;
 constexpr int SCHUR_THREADS = 512;    // 8 waves per task, two tasks per CU: 16 waves hide the L2 gathers
 struct SchurArgs {
     const int* task_cam; const int* cam_start;       // camera row of the task; the camera's range of cam_perm
@@ -70,7 +72,8 @@ struct SchurArgs {
     // every (observation i of the row's camera, observation l of the same landmark with camera(l) <= camera(i)) of the
     // slice, with the LDS slot of its 6x6 block resolved on the host
     const int* pair_begin; const int* pair_end;      // per task
-    const int4* pair_rec;                            // (i, l, landmark, slot | 0x8000 if diagonal block | 0x4000 if l == i)
+    const int* obs_pt;                               // landmark of every observation
+    const int4* pair_rec;                            // (i, l, landmark, slot | 0x8000 if diagonal block), l != i
 };
 size_t schur_rows_lds_bytes(int max_cols);
 int launch_schur_rows(const SchurArgs& a, int n_tasks, hipStream_t st);

@@ -317,7 +317,7 @@ static int ba_build_reduced(stba_ba* b, const Damping& dm, bool export_host = fa
         sa.row_col_ptr = b->row_col_ptr; sa.row_cols = b->row_cols; sa.max_cols = b->max_cols; sa.cam_perm = b->cam_perm;
         sa.J8 = b->J8; sa.omask = b->omask; sa.r = b->r; sa.Hinv6 = b->Hinv6; sa.gp = b->gp;
         sa.S = b->S(); sa.lda = b->lda; sa.rhs = b->rhs(); sa.Hcc = b->Hcc; sa.gc = b->gc;
-        sa.pair_begin = b->pair_begin; sa.pair_end = b->pair_end; sa.pair_rec = b->pair_rec;
+        sa.obs_pt = b->obs_pt; sa.pair_begin = b->pair_begin; sa.pair_end = b->pair_end; sa.pair_rec = b->pair_rec;
         STBA_TRY(launch_schur_rows(sa, b->n_tasks, b->st));
     }
     if (!b->ar && !dm.explicit_d && b->n == 6 * b->nc) {
@@ -959,7 +959,7 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
                 for (int p = cam_start[c]; p < cam_start[c + 1]; ++p) {
                     const int j = s_pt[cam_perm[p]];
                     for (int l = pt_start[j]; l < pt_start[j + 1]; ++l)
-                        if (s_cam[l] <= c) ++cnt[(size_t)slot_of[(size_t)s_cam[l]]];
+                        if (s_cam[l] <= c && l != cam_perm[p]) ++cnt[(size_t)slot_of[(size_t)s_cam[l]]];     // (not the pair (i, i): below)
                 }
             }
         });
@@ -1022,10 +1022,12 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
                     const int j = s_pt[i];
                     for (int l = pt_start[j]; l < pt_start[j + 1]; ++l) {
                         const int c2 = s_cam[l];
-                        if (c2 > c) continue;
+                        // (the pairs (i, i) -- an observation's own term of the diagonal block and of the right-hand side -- are
+                        // made by the camera-block pass of the Schur kernel in registers, not here)
+                        if (c2 > c || l == i) continue;
                         const int sl = slot_of[(size_t)c2];
                         if (sl < slo || sl >= shi) continue;
-                        pair_rec[w] = make_int4(i, l, j, (sl - slo) | (c2 == c ? 0x8000 : 0) | (l == i ? 0x4000 : 0));
+                        pair_rec[w] = make_int4(i, l, j, (sl - slo) | (c2 == c ? 0x8000 : 0));
                         ++w;
                     }
                 }
@@ -1035,9 +1037,9 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
             }
         });
     }
-    {   // LDS atomics of one launch: 36 per pair (21 in a diagonal block) + 6 for a pair's share of the right-hand side
+    {   // LDS atomics of one launch: 36 per pair (21 in a diagonal block)
         double at = 0.0;
-        for (const int4& pr : pair_rec) at += ((pr.w & 0x8000) ? 21.0 : 36.0) + ((pr.w & 0x4000) ? 6.0 : 0.0);
+        for (const int4& pr : pair_rec) at += (pr.w & 0x8000) ? 21.0 : 36.0;
         b->schur_pairs = (double)pair_rec.size(); b->schur_lds_atomics = at;
     }
     tmark("pair plan");
@@ -1333,7 +1335,7 @@ int stba_ba_time_schur(stba_ba* b, int reps, double* ms_avg, double* lds_atomics
     sa.row_col_ptr = b->row_col_ptr; sa.row_cols = b->row_cols; sa.max_cols = b->max_cols; sa.cam_perm = b->cam_perm;
     sa.J8 = b->J8; sa.omask = b->omask; sa.r = b->r; sa.Hinv6 = b->Hinv6; sa.gp = b->gp;
     sa.S = b->S(); sa.lda = b->lda; sa.rhs = b->rhs(); sa.Hcc = b->Hcc; sa.gc = b->gc;
-    sa.pair_begin = b->pair_begin; sa.pair_end = b->pair_end; sa.pair_rec = b->pair_rec;
+    sa.obs_pt = b->obs_pt; sa.pair_begin = b->pair_begin; sa.pair_end = b->pair_end; sa.pair_rec = b->pair_rec;
     STBA_TRY(launch_schur_rows(sa, b->n_tasks, b->st));      // warm
     STBA_HIP(hipEventRecord(b->ev[0], b->st));
     for (int k = 0; k < reps; ++k) STBA_TRY(launch_schur_rows(sa, b->n_tasks, b->st));
