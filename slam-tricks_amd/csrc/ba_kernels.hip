@@ -632,6 +632,7 @@ int launch_point_invert(int n_pts, const double* Hpp6, const double* dp, const u
 // reduction over the camera's observations, whose records are in this CU's caches at that moment (as a kernel of its
 // own that gather cost 46 us per iteration).  Fixed summation order: Hcc and gc are bitwise reproducible.
 // ===========================================================================================
+template <int ROTS>
 __global__ __launch_bounds__(SCHUR_THREADS, 4) void ba_schur_pairs_kernel(SchurArgs a) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int task = blockIdx.x;
@@ -664,6 +665,7 @@ __global__ __launch_bounds__(SCHUR_THREADS, 4) void ba_schur_pairs_kernel(SchurA
     // deep.  (Two pairs in flight per lane -- the second pair's gathers requested before the first is computed -- was
     // measured 7 % slower: the kernel is not bound by the gather latency.)
     const int ke = a.pair_end[task];
+    const int rot = tid % ROTS;
     for (int k = a.pair_begin[task] + tid; k < ke; k += SCHUR_THREADS) {
         const int4 rc = a.pair_rec[k];
         double Hi[6], jc[12], jp[6], jc2[12], jp2[6];
@@ -685,16 +687,31 @@ __global__ __launch_bounds__(SCHUR_THREADS, 4) void ba_schur_pairs_kernel(SchurA
         }
         const bool diag = (sl & 0x8000u) != 0;
         double* blk = acc + (size_t)(sl & 0x3fffu) * SCHUR_BLK_LD;
+        // The lanes of a wave walk the six columns of their blocks in ROTS different rotations (lane mod ROTS): the pairs of
+        // one wave hit the same block again and again -- the cameras next to c share most of its landmarks: 25 of 64 lanes
+        // share their block with an earlier lane, the busiest block of a wave has 7 -- and lanes that add to the SAME
+        // address in the same instruction are served one after the other.  With the rotation they meet in different columns.
 #pragma unroll
-        for (int b = 0; b < 6; ++b) {
-            const double w0 = jc2[b] * jp2[0] + jc2[6 + b] * jp2[3];
-            const double w1 = jc2[b] * jp2[1] + jc2[6 + b] * jp2[4];
-            const double w2 = jc2[b] * jp2[2] + jc2[6 + b] * jp2[5];
+        for (int s2 = 0; s2 < 6; ++s2) {
+            double ja = jc2[s2], jb = jc2[6 + s2];
+            int b = s2;
+#pragma unroll
+            for (int r = 1; r < ROTS; ++r) {
+                const int bb = (s2 + r * (6 / ROTS)) % 6;
+                if (rot == r) { ja = jc2[bb]; jb = jc2[6 + bb]; b = bb; }
+            }
+            const double w0 = ja * jp2[0] + jb * jp2[3];
+            const double w1 = ja * jp2[1] + jb * jp2[4];
+            const double w2 = ja * jp2[2] + jb * jp2[5];
+            double* col = blk + b;
             // (no tests for zero contributions of constant dofs: adding a zero is harmless)
 #pragma unroll
             for (int q = 0; q < 6; ++q) {
-                if (b > q) { if (!diag) unsafeAtomicAdd(&blk[q * 6 + b], -(E[q * 3] * w0 + E[q * 3 + 1] * w1 + E[q * 3 + 2] * w2)); }
-                else unsafeAtomicAdd(&blk[q * 6 + b], -(E[q * 3] * w0 + E[q * 3 + 1] * w1 + E[q * 3 + 2] * w2));
+                const double v = -(E[q * 3] * w0 + E[q * 3 + 1] * w1 + E[q * 3 + 2] * w2);
+                if (ROTS == 1) {
+                    if (b > q) { if (!diag) unsafeAtomicAdd(&col[q * 6], v); }
+                    else unsafeAtomicAdd(&col[q * 6], v);
+                } else if (!(diag && b > q)) unsafeAtomicAdd(&col[q * 6], v);
             }
         }
     }
@@ -821,11 +838,12 @@ int launch_schur_rows(const SchurArgs& a, int n_tasks, hipStream_t st) {
     // the largest slice the engine ever builds (SCHUR_SPLIT_COLS blocks) fixes the limit, once per device
     static DeviceOnce attr;
     STBA_TRY(attr.run([]() -> int {
-        STBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_schur_pairs_kernel),
+        STBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_schur_pairs_kernel<SCHUR_ROTS>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)schur_rows_lds_bytes(SCHUR_SPLIT_COLS)));
         return STBA_OK;
     }));
-    hipLaunchKernelGGL(ba_schur_pairs_kernel, dim3(n_tasks), dim3(SCHUR_THREADS), lds, st, a);
+    // (column rotations measured at C5: 1 / 2 / 3 / 6 -> 0.283 / 0.268 / 0.264 / 0.266 ms)
+    hipLaunchKernelGGL(ba_schur_pairs_kernel<SCHUR_ROTS>, dim3(n_tasks), dim3(SCHUR_THREADS), lds, st, a);
     STBA_HIP(hipGetLastError());
     return STBA_OK;
 }

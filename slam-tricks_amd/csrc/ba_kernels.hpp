@@ -58,6 +58,7 @@ constexpr int SCHUR_TASK_PAIRS = 1 << 30;
 constexpr int SCHUR_BLK_LD = 37;
 constexpr int SCHUR_CAM_SUMS = 54;   // per camera: 21 + 6 of the camera block, 21 + 6 of the pairs (i, i) (see the Schur kernel)
 constexpr int SCHUR_CAM_LD = 56;
+constexpr int SCHUR_ROTS = 3;        // column rotations of the Schur kernel's lanes (lane mod SCHUR_ROTS), see its pair loop
 constexpr int SCHUR_THREADS = 512;    // 8 waves per task, two tasks per CU: 16 waves hide the L2 gathers
 struct SchurArgs {
     const int* task_cam; const int* cam_start;       // camera row of the task; the camera's range of cam_perm
