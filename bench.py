@@ -441,10 +441,11 @@ def main():
                                  "unit": "G ds_add_f64 lane-ops/s", "frac": schur_atomics / (ms_schur * 1e-3) / 1e9 / LDS_ATOMIC_PEAK,
                                  "ms_per_launch": ms_schur, "lds_atomics_per_launch": schur_atomics, "pairs_per_launch": schur_pairs,
                                  "floor_ms": schur_atomics / (LDS_ATOMIC_PEAK * 1e9) * 1e3,
-                                 "traffic": 681.3e6 if local_obs == 1000000 else None,
-                                 "traffic_source": "profiles/r3_e_pmc_assembly_kernels.json (rocprofv3 --pmc, separate passes: FETCH_SIZE 495.9 MB + WRITE_SIZE "
-                                                   "185.4 MB per launch at C5; a recorded figure, not measured in this run).  The second bound of the "
-                                                   "kernel: 65 MB of Jacobian records are fetched ~6 times over, 144 MB of S zeroed + 40 MB of blocks written"}
+                                 "traffic": 897.2e6 if local_obs == 1000000 else None,
+                                 "traffic_source": "profiles/r3_f_pmc_assembly_kernels.json (rocprofv3 --pmc, separate passes: FETCH_SIZE 699.7 MB + WRITE_SIZE "
+                                                   "197.5 MB per launch at C5; a recorded figure, not measured in this run).  The second bound of the "
+                                                   "kernel: 65 MB of Jacobian records are fetched ~6 times over by the pair loop (496 MB), the diagonal slices' "
+                                                   "two register passes over their camera's records add ~200 MB; 144 MB of S zeroed + 40 MB of blocks written"}
         # the dominant kernel by device time carries the headline roofline object
         out["roofline"] = roof_chol if ms_factor > ms_jac else roof_jac
         out["roofline_jacobian"] = roof_jac
