@@ -20,6 +20,11 @@ __global__ __launch_bounds__(512) void k(const int* __restrict__ slots, double* 
         if (MODE == 0) {
 #pragma unroll
             for (int k2 = 0; k2 < 36; ++k2) unsafeAtomicAdd(&acc[((t + 64 * k2) % (NSLOT * LD))], v);     // distinct addresses, consecutive lanes
+        } else if (MODE == 4 || MODE == 5) {
+            unsigned long long* ua = reinterpret_cast<unsigned long long*>(MODE == 4 ? blk : acc);
+            const unsigned long long uv = (unsigned long long)(long long)(v * 1048576.0);
+#pragma unroll
+            for (int k2 = 0; k2 < 36; ++k2) atomicAdd(MODE == 4 ? &ua[k2] : &ua[(t + 64 * k2) % (NSLOT * LD)], uv);   // ds_add_u64
         } else if (MODE == 3) {
 #pragma unroll
             for (int k2 = 0; k2 < 36; ++k2) blk[k2] = v + k2;                                             // plain stores, Schur addresses
@@ -54,6 +59,8 @@ int main() {
         run<1>("ds_add_f64, Schur pattern (random 6x6 block/lane)", d_slots, d_out, 400);
         run<2>("ds_add_f64, one block per wave (all lanes collide)", d_slots, d_out, 100);
         run<3>("ds_write_b64, Schur addresses (reference)", d_slots, d_out, 400);
+        run<4>("ds_add_u64, Schur pattern", d_slots, d_out, 400);
+        run<5>("ds_add_u64, distinct addresses, lane-consecutive", d_slots, d_out, 400);
     }
     return 0;
 }
