@@ -666,8 +666,12 @@ __global__ __launch_bounds__(SCHUR_THREADS, 4) void ba_schur_pairs_kernel(SchurA
     // measured 7 % slower: the kernel is not bound by the gather latency.)
     const int ke = a.pair_end[task];
     const int rot = tid % ROTS;
-    for (int k = a.pair_begin[task] + tid; k < ke; k += SCHUR_THREADS) {
-        const int4 rc = a.pair_rec[k];
+    // (the pair record runs one trip ahead: one dependent memory round trip less per trip)
+    int k = a.pair_begin[task] + tid;
+    int4 rn = (k < ke) ? a.pair_rec[k] : make_int4(0, 0, 0, 0);
+    for (; k < ke; k += SCHUR_THREADS) {
+        const int4 rc = rn;
+        if (k + SCHUR_THREADS < ke) rn = a.pair_rec[k + SCHUR_THREADS];
         double Hi[6], jc[12], jp[6], jc2[12], jp2[6];
 #pragma unroll
         for (int k2 = 0; k2 < 6; ++k2) Hi[k2] = a.Hinv6[(size_t)rc.z * 6 + k2];
