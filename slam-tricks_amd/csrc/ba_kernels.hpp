@@ -56,8 +56,7 @@ constexpr int SCHUR_TASK_PAIRS = 1 << 30;
 // into different bank pairs (36 = 72 dwords = 8 mod 64 gave 8-way conflicts on every ds_add_f64: measured,
 // the kernel was bound by them)
 constexpr int SCHUR_BLK_LD = 37;
-constexpr int SCHUR_CAM_SUMS = 54;   // per camera: 21 + 6 of the camera block, 21 + 6 of the pairs (i, i) (see the Schur kernel)
-constexpr int SCHUR_CAM_LD = 56;
+constexpr int SCHUR_CAM_LD = 56;      // per wave of a diagonal slice: 21 + 6 sums of the camera block, 21 + 6 of the pairs (i, i), padded
 constexpr int SCHUR_ROTS = 3;        // column rotations of the Schur kernel's lanes (lane mod SCHUR_ROTS), see its pair loop
 constexpr int SCHUR_THREADS = 512;    // 8 waves per task, two tasks per CU: 16 waves hide the L2 gathers
 struct SchurArgs {
