@@ -689,7 +689,6 @@ __global__ __launch_bounds__(SCHUR_THREADS, 4) void ba_schur_pairs_kernel(SchurA
             E[q * 3 + 1] = w0 * Hi[1] + w1 * Hi[3] + w2 * Hi[4];
             E[q * 3 + 2] = w0 * Hi[2] + w1 * Hi[4] + w2 * Hi[5];
         }
-        const bool diag = (sl & 0x8000u) != 0;
         double* blk = acc + (size_t)(sl & 0x3fffu) * SCHUR_BLK_LD;
         // The lanes of a wave walk the six columns of their blocks in ROTS different rotations (lane mod ROTS): the pairs of
         // one wave hit the same block again and again -- the cameras next to c share most of its landmarks: 25 of 64 lanes
@@ -709,14 +708,11 @@ __global__ __launch_bounds__(SCHUR_THREADS, 4) void ba_schur_pairs_kernel(SchurA
             const double w2 = ja * jp2[2] + jb * jp2[5];
             double* col = blk + b;
             // (no tests for zero contributions of constant dofs: adding a zero is harmless)
+            // (every entry, also the upper triangle of a diagonal block, which the write-out never reads -- pairs in the
+            // diagonal block are the rare (i, l != i) of one camera, and a test per atomic costs an exec-mask branch each)
 #pragma unroll
-            for (int q = 0; q < 6; ++q) {
-                const double v = -(E[q * 3] * w0 + E[q * 3 + 1] * w1 + E[q * 3 + 2] * w2);
-                if (ROTS == 1) {
-                    if (b > q) { if (!diag) unsafeAtomicAdd(&col[q * 6], v); }
-                    else unsafeAtomicAdd(&col[q * 6], v);
-                } else if (!(diag && b > q)) unsafeAtomicAdd(&col[q * 6], v);
-            }
+            for (int q = 0; q < 6; ++q)
+                unsafeAtomicAdd(&col[q * 6], -(E[q * 3] * w0 + E[q * 3 + 1] * w1 + E[q * 3 + 2] * w2));
         }
     }
     if (diag_piece) {
