@@ -377,7 +377,11 @@ __global__ __launch_bounds__(PB_THREADS) void ba_point_blocks_kernel(int n_pts, 
         for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_down(m, off, 64));
         if ((t & 63) == 0) smax[t >> 6] = m;
         __syncthreads();
-        if (t == 0) gpmax_partial[blockIdx.x] = fmax(smax[0], smax[1]);
+        if (t == 0) {
+            double mm = 0.0;
+            for (int w = 0; w < PB_THREADS / 64; ++w) mm = fmax(mm, smax[w]);
+            gpmax_partial[blockIdx.x] = mm;
+        }
     }
 }
 
@@ -1037,7 +1041,11 @@ __global__ __launch_bounds__(PB_THREADS) void ba_backsub_kernel(int n_pts, const
             if ((t & 63) == 0) ssum[t >> 6][k] = x;
         }
         __syncthreads();
-        if (t < 4) up.partial_c[(size_t)cblk * 4 + t] = (t < 3) ? ssum[0][t] + ssum[1][t] : 0.0;
+        if (t < 4) {
+            double sv = 0.0;
+            if (t < 3) for (int w = 0; w < PB_THREADS / 64; ++w) sv += ssum[w][t];
+            up.partial_c[(size_t)cblk * 4 + t] = sv;
+        }
         return;
     }
     const int j0 = blockIdx.x * PB_LM, nl = min(PB_LM, n_pts - j0);
@@ -1099,7 +1107,11 @@ __global__ __launch_bounds__(PB_THREADS) void ba_backsub_kernel(int n_pts, const
             if ((t & 63) == 0) ssum[t >> 6][k] = x;
         }
         __syncthreads();
-        if (t < 4) up.partial_p[(size_t)blockIdx.x * 4 + t] = (t < 3) ? ssum[0][t] + ssum[1][t] : 0.0;
+        if (t < 4) {
+            double sv = 0.0;
+            if (t < 3) for (int w = 0; w < PB_THREADS / 64; ++w) sv += ssum[w][t];
+            up.partial_p[(size_t)blockIdx.x * 4 + t] = sv;
+        }
     }
 }
 
