@@ -4,7 +4,7 @@
 
 namespace stba {
 
-constexpr int LIN_THREADS = 512;               // observations per workgroup tile
+constexpr int LIN_THREADS = 1024;              // observations per workgroup tile
 constexpr int LIN_MAX_LDS = 160 * 1024 - 512;  // dynamic LDS budget of the linearize kernel
 constexpr int CAM_CHUNK = 256;                 // observations per camera-side reduction chunk
 
