@@ -480,11 +480,11 @@ def test_edge_cases(st, O):
 
 
 def test_landmarks_with_many_observations(st, O, scenes):
-    """The landmark kernels (blocks, back-substitution) take a workgroup's 32 landmarks' records through LDS 384 at a time:
+    """The landmark kernels (blocks, back-substitution) take a workgroup's 32 landmarks' records through LDS 256 at a time:
     with ~25 observations per landmark a workgroup makes several passes, and 300 landmarks leave a ragged last workgroup."""
     s = scenes.st20_scene(n_cams=120, n_pts=300, seed=5)
     per_pt = np.bincount(s["obs_pt"], minlength=300)
-    assert per_pt.max() > 24 and per_pt[:288].reshape(9, 32).sum(1).max() > 2 * 384      # (three passes)
+    assert per_pt.max() > 24 and per_pt[:288].reshape(9, 32).sum(1).max() > 3 * 256      # (four passes)
     e, o = engine(st, s), oracle(O, s)
     e.evaluate()
     Hcc, gc, Hpp, gp = e.normal_blocks()
