@@ -219,7 +219,10 @@ __global__ __launch_bounds__(256) void trial_finish_kernel(const double* __restr
     __shared__ double res[8];
     {
         double v[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        // (unrolled: the loads of several trips are in flight together, the additions keep their order)
+#pragma unroll 4
         for (int i = threadIdx.x; i < n_cost; i += 256) v[0] += cost_partial[i];
+#pragma unroll 4
         for (int i = threadIdx.x; i < n_p; i += 256) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) v[1 + k] += part_p[(size_t)i * 4 + k];
@@ -408,7 +411,9 @@ __global__ __launch_bounds__(256) void linear_finish_kernel(const double* __rest
                                                             int cost_slot, int max_slot) {
     __shared__ double s[256], smx[256];
     double v = 0.0, m = 0.0;
+#pragma unroll 4
     for (int i = threadIdx.x; i < n_cost; i += 256) v += cost_partial[i];
+#pragma unroll 4
     for (int i = threadIdx.x; i < n_gp; i += 256) m = fmax(m, gpmax_partial[i]);
     s[threadIdx.x] = v;
     smx[threadIdx.x] = m;
