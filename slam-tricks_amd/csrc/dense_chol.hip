@@ -1841,11 +1841,15 @@ __global__ __launch_bounds__(1024) void chol_bwd_apply_kernel(double* __restrict
         A[(size_t)(lda - 1) * lda + c0 + t] = yv - acc;
     }
 }
-// solve: workgroup g owns rows 32 g .. 32 g + 31 of the block; thread (r, cc) = (t >> 5, t & 31) takes 16 columns
-__global__ __launch_bounds__(1024) void chol_bwd_wide_solve_kernel(const double* __restrict__ A, int lda, const double* __restrict__ V, int row0,
-                                                                   double* __restrict__ x) {
+// solve: workgroup g owns rows BWD_SOLVE_ROWS g .. of the block; thread (r, cc) = (t >> 5, t & 31) takes 16 columns.
+// (A GEMV of this size is paced by what ONE workgroup can pull from memory, ~60 GB/s: 64 workgroups of 8 rows instead
+// of 16 of 32 took the substitution from 0.139 to 0.106 ms.  The apply kernel with 16 columns per workgroup instead of
+// 32: no change -- it is bound by the panel rows' total, not per workgroup.)
+constexpr int BWD_SOLVE_ROWS = 8;
+__global__ __launch_bounds__(32 * BWD_SOLVE_ROWS) void chol_bwd_wide_solve_kernel(const double* __restrict__ A, int lda, const double* __restrict__ V, int row0,
+                                                                                  double* __restrict__ x) {
     __shared__ double ys[4 * NB];
-    const int t = threadIdx.x, r = blockIdx.x * 32 + (t >> 5), cc = t & 31;
+    const int t = threadIdx.x, r = blockIdx.x * BWD_SOLVE_ROWS + (t >> 5), cc = t & 31;
     const bool live = (cc >> 3) >= (r >> 7);            // tiles left of the block diagonal are zero (and never written)
     double v[16];
     if (live) {
@@ -1853,7 +1857,7 @@ __global__ __launch_bounds__(1024) void chol_bwd_wide_solve_kernel(const double*
 #pragma unroll
         for (int j = 0; j < 16; ++j) v[j] = vr[j];
     }
-    if (t < 4 * NB) ys[t] = A[(size_t)(lda - 1) * lda + row0 + t];
+    for (int e = t; e < 4 * NB; e += 32 * BWD_SOLVE_ROWS) ys[e] = A[(size_t)(lda - 1) * lda + row0 + e];
     __syncthreads();
     double s = 0.0;
     if (live) {
@@ -2124,7 +2128,7 @@ static int chol_run(double* A, int lda, int n, double* x_dev, int* flag_dev, hip
         const int row0 = qw * 4 * NB;
         if (qw == nwide - 1) hipLaunchKernelGGL(chol_bwd_apply_kernel<4>, dim3((row0 + 4 * NB) / 32), dim3(1024), 0, st, A, lda, row0 + 4 * NB, x_dev);
         else hipLaunchKernelGGL(chol_bwd_apply_kernel<16>, dim3((row0 + 4 * NB) / 32), dim3(1024), 0, st, A, lda, row0 + 4 * NB, x_dev);
-        hipLaunchKernelGGL(chol_bwd_wide_solve_kernel, dim3(16), dim3(1024), 0, st, A, lda, ws.vbuf + (size_t)qw * 16 * NB * NB, row0, x_dev);
+        hipLaunchKernelGGL(chol_bwd_wide_solve_kernel, dim3(4 * NB / BWD_SOLVE_ROWS), dim3(32 * BWD_SOLVE_ROWS), 0, st, A, lda, ws.vbuf + (size_t)qw * 16 * NB * NB, row0, x_dev);
     }
     STBA_TRY(mark((size_t)nblk * 4 + 1));
     STBA_HIP(hipGetLastError());
