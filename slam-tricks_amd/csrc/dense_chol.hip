@@ -720,6 +720,7 @@ static void launch_syrk(double* A, int lda, int k0, int tile_mode, int tiles128,
 //                 diagonal tile, fused (the critical hand-off D(b) -> D(b+1), see tu_task512)
 //                                                         needs D(b), ver[b+1][b] == ver[b+1][b+1] == 4b
 //   T(b, i)       panel solve of the 128 rows of tile row i > b+1     needs D(b), ver[i][b] == 4b
+//                 (from panel 3 nblk / 8 on as two half tasks of 64 rows: see mega_build_tasks)
 //   TI(b)         inverse transpose of block b (for the backward substitution)   needs D(b)
 //   U(b; i, j)    tile (i, j) -= L_ib L_jb^T       needs T(b,i), T(b,j), ver[i][j] == 4b;  ver += 4
 //   Uq(b; i,q,j)  the same for 32 rows of a tile of the NEXT panel's column (j = b+1)       ver += 1
@@ -976,13 +977,19 @@ __device__ __forceinline__ bool mega_wait(const int* p, int target, int* abortf,
 __device__ __forceinline__ bool trsm_compute512(double4v (&W)[8], const double* __restrict__ rowp, bool ident,
                                                 int ident_row0, int nv, const double* __restrict__ Lb, int lda,
                                                 const double* __restrict__ dinv, double* smem, int t, long long* ph,
-                                                const int* dflag, int* abortf, int* s_ok, long long spin_limit, bool flag_known = false) {
+                                                const int* dflag, int* abortf, int* s_ok, long long spin_limit, bool flag_known = false,
+                                                bool active = true) {
     const int lane = t & 63;
     const int n = lane & 15, g = lane >> 4;
-    // this wave's rows (issued first: they are not needed before the staging is done)
+    // this wave's rows (issued first: they are not needed before the staging is done).  (active == false: a wave of a
+    // HALF panel-solve task that has no rows -- it helps to stage the factor and sits the arithmetic out, so that the four
+    // waves with rows have a SIMD each)
 #pragma unroll
     for (int J = 0; J < 8; ++J) {
-        if (ident) {
+        if (!active) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) W[J][r] = 0.0;
+        } else if (ident) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) W[J][r] = (16 * J + 4 * g + r == ident_row0 + n) ? 1.0 : 0.0;
         } else {
@@ -1030,6 +1037,7 @@ __device__ __forceinline__ bool trsm_compute512(double4v (&W)[8], const double* 
     }
     __syncthreads();
     PHASE_STAMP(0);
+    if (active) {
 #pragma unroll
     for (int I = 0; I < 8; ++I) {
         const double4v iv = *reinterpret_cast<const double4v*>(smem + (28 + I) * 256 + lane * 4);
@@ -1045,6 +1053,7 @@ __device__ __forceinline__ bool trsm_compute512(double4v (&W)[8], const double* 
             for (int q = 0; q < 4; ++q) W[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(l[q], y[q], W[J], 0, 0, 0);
         }
     }
+    }
     PHASE_STAMP(1);
     return true;
 }
@@ -1053,12 +1062,15 @@ __device__ __forceinline__ bool trsm_compute512(double4v (&W)[8], const double* 
 __device__ __forceinline__ bool trsm_task512(double* __restrict__ rowp, bool ident, int ident_row0, int nv,
                                              const double* __restrict__ Lb, int lda,
                                              const double* __restrict__ dinv, double* smem, int t, long long* ph,
-                                             const int* dflag, int* abortf, int* s_ok, long long spin_limit, bool flag_known = false) {
+                                             const int* dflag, int* abortf, int* s_ok, long long spin_limit, bool flag_known = false,
+                                             bool active = true) {
     double4v W[8];
-    if (!trsm_compute512(W, rowp, ident, ident_row0, nv, Lb, lda, dinv, smem, t, ph, dflag, abortf, s_ok, spin_limit, flag_known)) return false;
+    if (!trsm_compute512(W, rowp, ident, ident_row0, nv, Lb, lda, dinv, smem, t, ph, dflag, abortf, s_ok, spin_limit, flag_known, active)) return false;
     const int g = (t & 63) >> 4;
+    if (active) {
 #pragma unroll
-    for (int J = 0; J < 8; ++J) gst4<true>(rowp + 16 * J + 4 * g, W[J]);
+        for (int J = 0; J < 8; ++J) gst4<true>(rowp + 16 * J + 4 * g, W[J]);
+    }
     PHASE_STAMP(2);
     return true;
 }
@@ -1328,10 +1340,14 @@ __global__ __launch_bounds__(512) void chol_mega_kernel(MegaArgs a) {
         } else if (type == TASK_T) {
             const int lane = tt & 63, w = tt >> 6;
             int ldr;
-            double* rowp = tile_ptr(ti, b, ldr) + (size_t)(16 * w + (lane & 15)) * ldr;
+            // tj = 0: the whole tile row (eight waves, 16 rows each); tj = 1 / 2: its upper / lower 64 rows on waves 0..3 -- half
+            // the bytes to wait for and a SIMD per wave: the panel solve of a row is one link of the row sweeps T -> U -> T
+            const bool active = (tj == 0) || (w < 4);
+            const int row_in_tile = (tj == 0 ? 16 * w : 64 * (tj - 1) + 16 * (w & 3)) + (lane & 15);
+            double* rowp = tile_ptr(ti, b, ldr) + (size_t)row_in_tile * ldr;
             // (a panel solve is only started once its diagonal block is there: see mega_ready)
             if (!trsm_task512(rowp, false, 0, NB, a.A + (size_t)k0 * a.lda + k0, a.lda, li + NB * NB, smem, tt, ph, &dflag[b], abortf, &s_ok,
-                              a.spin_limit, true)) {
+                              a.spin_limit, true, active)) {
                 if (t == 0) atomicExch(a.flag, CHOL_FLAG_TIMEOUT);
                 break;
             }
@@ -1374,7 +1390,7 @@ __global__ __launch_bounds__(512) void chol_mega_kernel(MegaArgs a) {
         __syncthreads();
         if (t == 0) {
             if (type == TASK_D) __hip_atomic_fetch_add(&dflag[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else if (type == TASK_T) __hip_atomic_fetch_add(&tflag[b * nrow + ti], 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else if (type == TASK_T) __hip_atomic_fetch_add(&tflag[b * nrow + ti], tj == 0 ? 4 : 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             else if (type == TASK_TI) { if (b < 4 * a.nwide) __hip_atomic_fetch_add(&tflag[b * nrow + nblk + b], 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
             else if (type == TASK_TU) __hip_atomic_fetch_add(&tflag[b * nrow + b + 1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (ver: inside the task)
             else if (type == TASK_U) __hip_atomic_fetch_add(&ver[ti * nblk + tj], 4 * max(1, (d.x >> 16) & 0xff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1449,10 +1465,12 @@ static void mega_build_tasks(int nblk, const MegaMachine& mach, std::vector<int4
     }
     auto gpu_of = [&](int l) { return n_gpus > 1 ? l / q_per_gpu : 0; };
     static const int QROWS = knob_int("STBA_MEGA_QROWS", 2);
+    const int THALF_FROM = knob_int("STBA_MEGA_THALF_FROM", (3 * nblk) / 8);      // (panel 17 of 47: where the trailing updates stop pacing the factorisation)
+    static const double THALF_DUR = knob_double("STBA_MEGA_THALF_DUR", 0.6);
     // from panel QFROM on (the chain-bound part of the factorisation, where workgroups are idle) every row's tile in the next
     // panel column is updated by four quarter tasks: the row sweeps T -> U -> T get shorter
     static const int QFROM = knob_int("STBA_MEGA_QFROM", 1 << 30);
-    std::vector<int> idD((size_t)NBK, -1), idTI((size_t)NBK, -1), idTU((size_t)NBK * 4, -1), idT((size_t)NBK * NBK, -1),
+    std::vector<int> idD((size_t)NBK, -1), idTI((size_t)NBK, -1), idTU((size_t)NBK * 4, -1), idT((size_t)NBK * NBK, -1), idT2((size_t)NBK * NBK, -1),
         idUq((size_t)NBK * NBK * 4, -1), idU((size_t)NBK * NBK * NBK, -1);
     // measured on MI355X (tools/mega_trace.py), microseconds, plus ~2 us of flag latency per hop
     // (debug builds: STBA_MEGA_DUR=d,t,ti,u,uq,tu overrides them for experiments)
@@ -1477,7 +1495,16 @@ static void mega_build_tasks(int nblk, const MegaMachine& mach, std::vector<int4
         if (b + 1 < NBK)
             for (int q = 0; q < 4; ++q) idTU[(size_t)b * 4 + q] = add(TASK_TU, b, q, 0, 10.0 * b + 5);
         for (int i = b + 2; i < NBK; ++i) {
-            idT[(size_t)b * NBK + i] = add(TASK_T, b, i, 0, 10.0 * b + 6 + 1e-3 * i);
+            if (b >= THALF_FROM) {
+                // two HALF tasks (64 rows each on four waves, see the kernel's TASK_T) once the chains pace the factorisation:
+                // a panel solve is one of the two links of every row sweep T -> U -> T, and as a half it waits for 136 KB
+                // instead of 200 and has a SIMD per wave -- 11 us instead of 18.4.  (Measured at n = 6000, same box: whole
+                // tasks 2.509 ms; halves from panel 0 / 10 / 14 / 17 / 20 / 24: 2.493 / 2.445 / 2.425 / 2.425 / 2.431 / 2.427;
+                // QUARTER tasks from 17 / 24: 2.517 / 2.472 -- the 72 KB of the diagonal factor every part stages do not shrink.)
+                idT[(size_t)b * NBK + i] = add(TASK_T, b, i, 1, 10.0 * b + 6 + 1e-3 * i);
+                idT2[(size_t)b * NBK + i] = add(TASK_T, b, i, 2, 10.0 * b + 6 + 1e-3 * i + 5e-4);
+                nodes[(size_t)idT[(size_t)b * NBK + i]].dur = nodes[(size_t)idT2[(size_t)b * NBK + i]].dur = THALF_DUR * DUR[TASK_T];
+            } else idT[(size_t)b * NBK + i] = add(TASK_T, b, i, 0, 10.0 * b + 6 + 1e-3 * i);
             // the next panel's column: 32-row tasks (short latency) only for the rows the second critical chain
             // needs soon; a quarter task costs 14.5 us of a workgroup against 23.4 us for a whole tile, so the
             // rows further down take the whole-tile task (their panel solve comes a diagonal block later)
@@ -1531,14 +1558,14 @@ static void mega_build_tasks(int nblk, const MegaMachine& mach, std::vector<int4
                 }
             }
         for (int i = b + 2; i < NBK; ++i) {
-            const int t = idT[(size_t)b * NBK + i];
-            dep(d, t);
+            const int t = idT[(size_t)b * NBK + i], t2 = idT2[(size_t)b * NBK + i];
+            dep(d, t); dep(d, t2);
             if (b > 0)
-                for (int q2 = 0; q2 < 4; ++q2) dep(idUq[((size_t)(b - 1) * NBK + i) * 4 + q2], t);
+                for (int q2 = 0; q2 < 4; ++q2) { const int uu = idUq[((size_t)(b - 1) * NBK + i) * 4 + q2]; dep(uu, t); dep(uu, t2); }
             for (int q = 0; q < 4; ++q) {
                 const int uq = idUq[((size_t)b * NBK + i) * 4 + q];
                 if (uq < 0) continue;            // (rows with ONE whole-tile task use slot 0 only)
-                dep(t, uq);
+                dep(t, uq); dep(t2, uq);
                 for (int q2 = 0; q2 < 4; ++q2) dep(idTU[(size_t)b * 4 + q2], uq);
                 if (b > 0) dep(idU[((size_t)(b - 1) * NBK + i) * NBK + (b + 1)], uq);
             }
@@ -1547,8 +1574,7 @@ static void mega_build_tasks(int nblk, const MegaMachine& mach, std::vector<int4
             for (int i = j; i < NBK; ++i) {
                 const int u = idU[((size_t)b * NBK + i) * NBK + j];
                 if (nodes[(size_t)u].tk.y != b) continue;          // (a batch: its dependencies hang on its last panel)
-                dep(idT[(size_t)b * NBK + i], u);
-                if (j != i) dep(idT[(size_t)b * NBK + j], u);
+                for (auto* v : {&idT, &idT2}) { dep((*v)[(size_t)b * NBK + i], u); if (j != i) dep((*v)[(size_t)b * NBK + j], u); }
                 const int nbp = std::max(1, (nodes[(size_t)u].tk.x >> 16) & 0xff);
                 if (b - nbp >= 0) dep(idU[((size_t)(b - nbp) * NBK + i) * NBK + j], u);
             }
@@ -1568,7 +1594,7 @@ static void mega_build_tasks(int nblk, const MegaMachine& mach, std::vector<int4
                     const int u = add(TASK_U, k, iv, bj, 10.0 * NBK + bj);
                     dep(xdone[(size_t)(k - 4 * qw)], u);
                     if (bj == k + 1) { for (int q2 = 0; q2 < 4; ++q2) dep(idTU[(size_t)k * 4 + q2], u); }
-                    else dep(idT[(size_t)k * NBK + bj], u);
+                    else for (auto* v : {&idT, &idT2}) dep((*v)[(size_t)k * NBK + bj], u);
                     dep(prev, u);
                     prev = u;
                 }
