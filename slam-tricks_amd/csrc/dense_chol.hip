@@ -714,9 +714,9 @@ static void launch_syrk(double* A, int lda, int k0, int tile_mode, int tiles128,
 // outputs (release fence + flag) and goes on.  Tickets are handed out in an order that is a topological order of the task
 // graph, and a workgroup only ever waits for tasks that come earlier in that order -- which are finished, held by a
 // resident workgroup, or the next ticket of some list -- so the program cannot deadlock as long as every list has a
-// resident workgroup (4 for the lists that carry the TU tasks).
+// resident workgroup (MEGA_NTU = 10 for the lists that carry the TU tasks).
 //   D(b)          diagonal block b                        needs ver[b][b] == 4b
-//   TU(b, q)      q = 0..3: block row b+1 of the panel solve AND rows 32q.. of the update of the next
+//   TU(b, q)      q = 0..9: rows of block row b+1 of the panel solve AND a 2 x 2-tile block of the update of the next
 //                 diagonal tile, fused (the critical hand-off D(b) -> D(b+1), see tu_task512)
 //                                                         needs D(b), ver[b+1][b] == ver[b+1][b+1] == 4b
 //   T(b, i)       panel solve of the 128 rows of tile row i > b+1     needs D(b), ver[i][b] == 4b
@@ -748,7 +748,7 @@ struct MegaArgs {
     int nq;                 // number of XCD queues (= XCDs seen by the probe)
     int lstart[MEGA_MAX_Q + 1];   // list q (one per XCD) holds tasks [lstart[q], lstart[q+1]), taken in order
     signed char xcc_queue[16];   // HW_REG_XCC_ID -> queue
-    int* sync;              // [0..16) tickets of the lists, [16] abort, then dflag[nblk], tuflag[nblk],
+    int* sync;              // [0..16) tickets of the lists, [16] abort, then dflag[nblk], tuflag[nblk], tudone[nblk],
                             // tflag[nblk*nrow], ver[nrow*nblk] (nrow = nblk + 4 nwide)
     double* linv; size_t linv_stride;
     double* vbuf; int nwide;   // inverse transposes of the 512 x 512 diagonal blocks 0 .. nwide-1 (row-major, ld 512): see below
@@ -1075,12 +1075,13 @@ __device__ __forceinline__ bool trsm_task512(double* __restrict__ rowp, bool ide
     return true;
 }
 
-// TU task (b, q): the critical hand-off D(b) -> D(b+1) in ONE task instead of a panel solve, a flag, and
+// TU task, FOUR-workgroup form (the panels in front of MEGA's TU10_FROM, where workgroups are scarce and ten siblings
+// would wait for each other): the critical hand-off D(b) -> D(b+1) in ONE task instead of a panel solve, a flag, and
 // a trailing update.  Each of the four workgroups q = 0..3 solves the WHOLE block row b+1 of the panel
 // (X = A[b+1, b] L_bb^-T, 128 x 128, redundantly), exchanges X between its waves through LDS (a wave's
 // accumulators are already MFMA operand fragments: 128 KB), and applies rows 32q..32q+31 of the update
 // A[b+1, b+1] -= X X^T (lower-triangle tiles only).  Workgroup q also writes rows 32q..32q+31 of X.
-__device__ __forceinline__ bool tu_task512(double* __restrict__ A, int lda, int k0, int rb, int q,
+__device__ __forceinline__ bool tu4_task512(double* __restrict__ A, int lda, int k0, int rb, int q,
                                            const double* __restrict__ dinv, double* smem, int t, long long* ph,
                                            int* loaded, int* ver_diag, const int* dflag, int* abortf, int* s_ok, long long spin_limit,
                                            bool flag_known = false) {
@@ -1147,6 +1148,86 @@ __device__ __forceinline__ bool tu_task512(double* __restrict__ A, int lda, int 
     return true;
 }
 
+// TU task (b, q): the critical hand-off D(b) -> D(b+1) in ONE kind of task instead of a panel solve, a flag, and a
+// trailing update: block row b+1 of the panel solve AND the update of the next diagonal tile A[b+1, b+1] -= X X^T, fused.
+// The 8 x 8 grid of 16 x 16 tiles of the diagonal tile is cut into 2 x 2-tile blocks (I, J), I >= J, q = I (I + 1) / 2 + J:
+// MEGA_NTU = 10 workgroups.  Block (I, J) needs the tile rows {2I, 2I+1} and {2J, 2J+1} of X only, so it solves 64 rows
+// (32 on the diagonal) of X = A[b+1, b] L_bb^-T -- one wave per tile row, a SIMD each --, exchanges them between its waves
+// through LDS (a wave's accumulators are already MFMA operand fragments) and updates its four (three) tiles.  The diagonal
+// blocks (I, I) also write their 32 rows of X.  (Until round 3 FOUR workgroups each solved the WHOLE block row redundantly
+// -- 200 KB to wait for instead of 136 / 104, two waves per SIMD -- and updated 32 rows of the tile: 17 us from the
+// diagonal block's flag to the next one's, now ~12.)
+constexpr int MEGA_NTU = 10;
+__device__ __forceinline__ bool tu_task512(double* __restrict__ A, int lda, int k0, int rb, int q,
+                                           const double* __restrict__ dinv, double* smem, int t, long long* ph,
+                                           int* loaded, int* done_cnt, int* ver_diag, const int* dflag, int* abortf, int* s_ok, long long spin_limit,
+                                           bool flag_known = false) {
+    const int lane = t & 63, w = t >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    int I = 0;
+    while ((I + 1) * (I + 2) / 2 <= q) ++I;
+    const int J = q - I * (I + 1) / 2;
+    const bool diag = (I == J);
+    const int nrow = diag ? 2 : 4;                 // tile rows of X this block solves: local 0, 1 = 2I, 2I+1; local 2, 3 = 2J, 2J+1
+    const bool active = w < nrow;
+    const int trow = (w < 2) ? 2 * I + (w & 1) : 2 * J + (w & 1);
+    double* rowp = A + (size_t)(rb * NB + 16 * trow + n) * lda + k0;
+    // output tiles, one per wave e = w: diagonal block (2I,2I) (2I+1,2I) (2I+1,2I+1); off-diagonal (2I,2J) (2I,2J+1) (2I+1,2J) (2I+1,2J+1).
+    // lm / ln: the LOCAL tile rows of X the tile multiplies.  Their current values are requested first: they do not depend on D(b).
+    const int ntile = diag ? 3 : 4;
+    const int lm = diag ? (w >= 1 ? 1 : 0) : (w >> 1), ln = diag ? (w == 2 ? 1 : 0) : 2 + (w & 1);
+    const int tm = 2 * I + lm, tn = diag ? 2 * I + ln : 2 * J + (w & 1);
+    double* Cb = A + (size_t)(rb * NB) * lda + rb * NB;
+    double4v acc = {0.0, 0.0, 0.0, 0.0};
+    if (w < ntile) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = Cb[(size_t)(16 * tm + g + 4 * r) * lda + 16 * tn + n];
+    }
+    double4v W[8];
+    if (!trsm_compute512(W, rowp, false, 0, NB, A + (size_t)k0 * lda + k0, lda, dinv, smem, t, ph, dflag, abortf, s_ok, spin_limit, flag_known, active)) return false;
+    __syncthreads();                          // every wave is done with the L11 tiles in smem and has consumed its rows
+    // the workgroups of this step all READ rows of the block row and the diagonal blocks WRITE 32 rows of it each in
+    // place: count the readers, and store only once all of them have their copy (see below)
+    if (t == 0) __hip_atomic_fetch_add(loaded, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (active) {
+#pragma unroll
+        for (int J2 = 0; J2 < 8; ++J2) *reinterpret_cast<double4v*>(smem + (w * 8 + J2) * 256 + lane * 4) = W[J2];
+    }
+    __syncthreads();
+    if (w < ntile) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const double4v fa = *reinterpret_cast<const double4v*>(smem + (lm * 8 + c) * 256 + lane * 4);
+            const double4v fb = *reinterpret_cast<const double4v*>(smem + (ln * 8 + c) * 256 + lane * 4);
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-fa[qq], fb[qq], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gst<false>(&Cb[(size_t)(16 * tm + g + 4 * r) * lda + 16 * tn + n], acc[r]);
+    }
+    // D(b+1) needs nothing but this tile (it runs on this XCD and finds it in the L2): the LAST block to get here signals
+    // it now, the panel rows below are off the critical chain
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t == 0) {
+        if (__hip_atomic_fetch_add(done_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == MEGA_NTU - 1)
+            __hip_atomic_fetch_add(ver_diag, 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // Only the diagonal blocks write (their 32 rows of X, over rows the others read): they alone wait for every
+        // sibling to have its copy -- the siblings hold tickets of the same queue, the off-diagonal ones EARLIER ones (see
+        // mega_build_tasks), and are taken as soon as any workgroup of this XCD is free (needs >= MEGA_NTU resident
+        // workgroups per XCD, checked on the host).
+        *s_ok = (!diag || mega_wait(loaded, MEGA_NTU, abortf, spin_limit)) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!*s_ok) return false;
+    if (diag && active) {
+#pragma unroll
+        for (int J2 = 0; J2 < 8; ++J2) gst4<true>(rowp + 16 * J2 + 4 * g, W[J2]);
+    }
+    PHASE_STAMP(2);
+    return true;
+}
+
 // C(32 x 128) -= P_i P_j^T for the next panel's tile column: operands straight from global memory
 // into MFMA operand registers (every load of the task is in flight at once: one memory latency
 // instead of eight), wave w -> output columns 16w..16w+15, two 16x16 tiles.
@@ -1189,7 +1270,7 @@ __global__ __launch_bounds__(256) void chol_reset_kernel(int* __restrict__ sync,
 // ---- the flag arrays behind the header of MegaArgs::sync, and the readiness test of a task ----
 struct MegaView {
     int nblk, nrow;
-    int* abortf; int* dflag; int* tuflag; int* tflag; int* ver;
+    int* abortf; int* dflag; int* tuflag; int* tudone; int* tflag; int* ver;
 };
 __device__ __forceinline__ MegaView mega_view(const MegaArgs& a) {
     MegaView v;
@@ -1202,7 +1283,8 @@ __device__ __forceinline__ MegaView mega_view(const MegaArgs& a) {
     v.abortf = a.sync + MEGA_ABORT;
     v.dflag = a.sync + MEGA_SYNC_HDR;
     v.tuflag = v.dflag + a.nblk;
-    v.tflag = v.tuflag + a.nblk;                // [panel b][row i], i < nrow
+    v.tudone = v.tuflag + a.nblk;
+    v.tflag = v.tudone + a.nblk;                // [panel b][row i], i < nrow
     v.ver = v.tflag + a.nblk * v.nrow;          // [row i][panel j]
     return v;
 }
@@ -1376,8 +1458,12 @@ __global__ __launch_bounds__(512) void chol_mega_kernel(MegaArgs a) {
                 syrk_tile512_gen<128>(Cb, ldc, Pi, ldi, Pj, ldj, b == first_panel(ti), smem, tt);
             }
         } else if (type == TASK_TU) {
-            if (!tu_task512(a.A, a.lda, k0, b + 1, ti, li + NB * NB, smem, tt, ph, &tuflag[b], &ver[(b + 1) * nblk + b + 1], &dflag[b], abortf, &s_ok,
-                            a.spin_limit, s_dset != 0)) {
+            const bool tu_ok = (tj == 2)
+                ? tu4_task512(a.A, a.lda, k0, b + 1, ti, li + NB * NB, smem, tt, ph, &tuflag[b], &ver[(b + 1) * nblk + b + 1], &dflag[b], abortf, &s_ok,
+                              a.spin_limit, s_dset != 0)
+                : tu_task512(a.A, a.lda, k0, b + 1, ti, li + NB * NB, smem, tt, ph, &tuflag[b], &v.tudone[b], &ver[(b + 1) * nblk + b + 1], &dflag[b], abortf, &s_ok,
+                             a.spin_limit, s_dset != 0);
+            if (!tu_ok) {
                 if (t == 0) atomicExch(a.flag, CHOL_FLAG_TIMEOUT);
                 break;
             }
@@ -1392,7 +1478,7 @@ __global__ __launch_bounds__(512) void chol_mega_kernel(MegaArgs a) {
             if (type == TASK_D) __hip_atomic_fetch_add(&dflag[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             else if (type == TASK_T) __hip_atomic_fetch_add(&tflag[b * nrow + ti], tj == 0 ? 4 : 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             else if (type == TASK_TI) { if (b < 4 * a.nwide) __hip_atomic_fetch_add(&tflag[b * nrow + nblk + b], 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-            else if (type == TASK_TU) __hip_atomic_fetch_add(&tflag[b * nrow + b + 1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (ver: inside the task)
+            else if (type == TASK_TU) { if (tj != 0) __hip_atomic_fetch_add(&tflag[b * nrow + b + 1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }   // (the four diagonal blocks: they wrote X; ver: inside the task)
             else if (type == TASK_U) __hip_atomic_fetch_add(&ver[ti * nblk + tj], 4 * max(1, (d.x >> 16) & 0xff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             else if (type == TASK_UQ) __hip_atomic_fetch_add(&ver[(ti >> 2) * nblk + tj], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (a.trace) a.trace[8 * (size_t)task + 3] = wall_clock64();
@@ -1467,10 +1553,17 @@ static void mega_build_tasks(int nblk, const MegaMachine& mach, std::vector<int4
     static const int QROWS = knob_int("STBA_MEGA_QROWS", 2);
     const int THALF_FROM = knob_int("STBA_MEGA_THALF_FROM", (3 * nblk) / 8);      // (panel 17 of 47: where the trailing updates stop pacing the factorisation)
     static const double THALF_DUR = knob_double("STBA_MEGA_THALF_DUR", 0.6);
+    // the fused panel-solve + diagonal-tile update of a step: ten 2 x 2-tile block tasks from panel TU10_FROM on, four
+    // quarter tasks (each solving the whole block row) before
+    // (n = 6000, medians of interleaved runs on one box, tools/chol_ab.py: never 2.388 ms; from panel 18 / 26 / 28 / 32 / 36 / 40:
+    // 2.373 / 2.357 / 2.364 / 2.351 / 2.365 / 2.382 -- while workgroups are scarce ten siblings wait for each other)
+    const int TU10_FROM = knob_int("STBA_MEGA_TU10_FROM", (11 * nblk) / 16);
+    static const double TU10_DUR = knob_double("STBA_MEGA_TU10_DUR", 0.65);
+    auto ntu = [&](int b) { return b >= TU10_FROM ? MEGA_NTU : 4; };
     // from panel QFROM on (the chain-bound part of the factorisation, where workgroups are idle) every row's tile in the next
     // panel column is updated by four quarter tasks: the row sweeps T -> U -> T get shorter
-    static const int QFROM = knob_int("STBA_MEGA_QFROM", 1 << 30);
-    std::vector<int> idD((size_t)NBK, -1), idTI((size_t)NBK, -1), idTU((size_t)NBK * 4, -1), idT((size_t)NBK * NBK, -1), idT2((size_t)NBK * NBK, -1),
+    const int QFROM = knob_int("STBA_MEGA_QFROM", (21 * nblk) / 32);      // (panel 30 of 47; with the short TU tasks behind it: 2.351 -> 2.343 ms)
+    std::vector<int> idD((size_t)NBK, -1), idTI((size_t)NBK, -1), idTU((size_t)NBK * MEGA_NTU, -1), idT((size_t)NBK * NBK, -1), idT2((size_t)NBK * NBK, -1),
         idUq((size_t)NBK * NBK * 4, -1), idU((size_t)NBK * NBK * NBK, -1);
     // measured on MI355X (tools/mega_trace.py), microseconds, plus ~2 us of flag latency per hop
     // (debug builds: STBA_MEGA_DUR=d,t,ti,u,uq,tu overrides them for experiments)
@@ -1493,7 +1586,13 @@ static void mega_build_tasks(int nblk, const MegaMachine& mach, std::vector<int4
         idD[(size_t)b] = add(TASK_D, b, 0, 0, 10.0 * b);
         idTI[(size_t)b] = add(TASK_TI, b, 0, 0, 10.0 * NBK + b);
         if (b + 1 < NBK)
-            for (int q = 0; q < 4; ++q) idTU[(size_t)b * 4 + q] = add(TASK_TU, b, q, 0, 10.0 * b + 5);
+            for (int q = 0; q < ntu(b); ++q) {        // (tk.w = 1: a diagonal block (I, I), which writes 32 rows of X; 2: the four-workgroup form)
+                int I = 0;
+                while ((I + 1) * (I + 2) / 2 <= q) ++I;
+                const bool dg = (q == I * (I + 1) / 2 + I);
+                idTU[(size_t)b * MEGA_NTU + q] = add(TASK_TU, b, q, ntu(b) == 4 ? 2 : dg ? 1 : 0, 10.0 * b + 5 + (ntu(b) != 4 && dg ? 1e-4 : 0.0));
+                if (ntu(b) != 4) nodes[(size_t)idTU[(size_t)b * MEGA_NTU + q]].dur = TU10_DUR * DUR[TASK_TU];
+            }
         for (int i = b + 2; i < NBK; ++i) {
             if (b >= THALF_FROM) {
                 // two HALF tasks (64 rows each on four waves, see the kernel's TASK_T) once the chains pace the factorisation:
@@ -1546,11 +1645,11 @@ static void mega_build_tasks(int nblk, const MegaMachine& mach, std::vector<int4
     for (int b = 0; b < NBK; ++b) {
         const int d = idD[(size_t)b];
         if (b > 0)
-            for (int q = 0; q < 4; ++q) dep(idTU[(size_t)(b - 1) * 4 + q], d);
+            for (int q = 0; q < ntu(b - 1); ++q) dep(idTU[(size_t)(b - 1) * MEGA_NTU + q], d);
         dep(d, idTI[(size_t)b]);
         if (b + 1 < NBK)
-            for (int q = 0; q < 4; ++q) {
-                const int tu = idTU[(size_t)b * 4 + q];
+            for (int q = 0; q < ntu(b); ++q) {
+                const int tu = idTU[(size_t)b * MEGA_NTU + q];
                 dep(d, tu);
                 if (b > 0) {
                     for (int q2 = 0; q2 < 4; ++q2) dep(idUq[((size_t)(b - 1) * NBK + (b + 1)) * 4 + q2], tu);
@@ -1566,7 +1665,7 @@ static void mega_build_tasks(int nblk, const MegaMachine& mach, std::vector<int4
                 const int uq = idUq[((size_t)b * NBK + i) * 4 + q];
                 if (uq < 0) continue;            // (rows with ONE whole-tile task use slot 0 only)
                 dep(t, uq); dep(t2, uq);
-                for (int q2 = 0; q2 < 4; ++q2) dep(idTU[(size_t)b * 4 + q2], uq);
+                for (int q2 = 0; q2 < ntu(b); ++q2) dep(idTU[(size_t)b * MEGA_NTU + q2], uq);
                 if (b > 0) dep(idU[((size_t)(b - 1) * NBK + i) * NBK + (b + 1)], uq);
             }
         }
@@ -1593,7 +1692,7 @@ static void mega_build_tasks(int nblk, const MegaMachine& mach, std::vector<int4
                 for (int k = pnl; k < bj; ++k) {
                     const int u = add(TASK_U, k, iv, bj, 10.0 * NBK + bj);
                     dep(xdone[(size_t)(k - 4 * qw)], u);
-                    if (bj == k + 1) { for (int q2 = 0; q2 < 4; ++q2) dep(idTU[(size_t)k * 4 + q2], u); }
+                    if (bj == k + 1) { for (int q2 = 0; q2 < ntu(k); ++q2) dep(idTU[(size_t)k * MEGA_NTU + q2], u); }
                     else for (auto* v : {&idT, &idT2}) dep((*v)[(size_t)k * NBK + bj], u);
                     dep(prev, u);
                     prev = u;
@@ -1699,11 +1798,11 @@ static void mega_build_tasks(int nblk, const MegaMachine& mach, std::vector<int4
         for (int b = 0; b + 1 < NBK; ++b) {
             const Node& d0 = nodes[(size_t)idD[(size_t)b]];
             const Node& d1 = nodes[(size_t)idD[(size_t)b + 1]];
-            const Node& tu = nodes[(size_t)idTU[(size_t)b * 4 + 3]];
+            const Node& tu = nodes[(size_t)idTU[(size_t)b * MEGA_NTU + ntu(b) - 1]];
             const double e0 = d0.start + d0.dur;
             fprintf(stderr, "b=%2d step %6.1f | TU ready %+6.1f start %+6.1f | D+1 ready %+6.1f start %+6.1f", b, d1.start - d0.start,
                     tu.ready - e0, tu.start - e0, d1.ready - e0, d1.start - e0);
-            int k = idTU[(size_t)b * 4 + 3];
+            int k = idTU[(size_t)b * MEGA_NTU + ntu(b) - 1];
             for (int hop = 0; hop < 4 && k >= 0; ++hop) {       // walk back along the last-arriving inputs
                 const Node& nd = nodes[(size_t)k];
                 fprintf(stderr, " <- %s(%d;%d,%d) rdy %+.1f st %+.1f", NM[nd.tk.x & 0xff], nd.tk.y, nd.tk.z, nd.tk.w, nd.ready - e0, nd.start - e0);
@@ -1944,8 +2043,8 @@ static int mega_device_init(MegaDevice& D, hipStream_t st) {
         per_xcc[x & 15]++;
     }
     for (int i = 0; i < 16; ++i)
-        if (D.xcc_queue[i] >= 0 && per_xcc[i] < 4)
-            return fail(STBA_ERR_HIP, "chol: fewer than 4 workgroups per XCD (the TU tasks need 4)");
+        if (D.xcc_queue[i] >= 0 && per_xcc[i] < MEGA_NTU)
+            return fail(STBA_ERR_HIP, "chol: fewer than 10 workgroups per XCD (the TU tasks of a step need one each)");
     STBA_HIP(hipEventCreateWithFlags(&D.last, hipEventDisableTiming));
     D.probed = true;
     return STBA_OK;
@@ -2079,12 +2178,12 @@ static int chol_run(double* A, int lda, int n, double* x_dev, int* flag_dev, hip
             plan = MegaPlan();
             MegaMachine mach;
             mach.nq = D.nq;
-            mach.wg = std::max(4, D.ncu / D.nq);
+            mach.wg = std::max(MEGA_NTU, D.ncu / D.nq);
             std::vector<int4> tasks;
             mega_build_tasks(nblk, mach, tasks, plan.lstart, &plan.sim_start, &plan.makespan_us, nwide);
             STBA_HIP(hipMalloc(reinterpret_cast<void**>(&plan.tasks), tasks.size() * sizeof(int4)));
             STBA_HIP(hipMemcpy(plan.tasks, tasks.data(), tasks.size() * sizeof(int4), hipMemcpyHostToDevice));
-            plan.sync_ints = MEGA_SYNC_HDR + 2 * (size_t)nblk + 2 * (size_t)nblk * (nblk + 4 * nwide);
+            plan.sync_ints = MEGA_SYNC_HDR + 3 * (size_t)nblk + 2 * (size_t)nblk * (nblk + 4 * nwide);
             STBA_HIP(hipMalloc(reinterpret_cast<void**>(&plan.sync), plan.sync_ints * sizeof(int)));
             plan.ntasks = (int)tasks.size();
             plan.nblk = nblk; plan.nwide = nwide;
