@@ -1570,7 +1570,7 @@ static void mega_build_tasks(int nblk, const MegaMachine& mach, std::vector<int4
     double DUR[6] = {23.0, 23.0, 19.0, 25.0, 16.5, 20.0};      // (D: 21.3 us since round 2)
     double DUR_K = 18.0;           // one more panel (K += 128) inside a batched trailing update (measured: 24 us for one panel, 42 for two)
     static const int BATCH = std::max(1, std::min(16, knob_int("STBA_MEGA_BATCH", 2)));
-    static const int BLAG = std::max(0, knob_int("STBA_MEGA_BLAG", 3));
+    static const int BLAG = std::max(0, knob_int("STBA_MEGA_BLAG", 2));      // (round 3, with the shorter chain tasks: 3 -> 2: -0.02 ms; 1: the same; 0: +0.25 ms)
     if (const char* e = knob_str("STBA_MEGA_DUR")) sscanf(e, "%lf,%lf,%lf,%lf,%lf,%lf", &DUR[0], &DUR[1], &DUR[2], &DUR[3], &DUR[4], &DUR[5]);
     auto add = [&](int type, int b, int i, int j, double prio) {
         Node nd; nd.tk = make_int4(type, b, i, j); nd.dur = DUR[type]; nd.prio = prio;
