@@ -720,7 +720,7 @@ static void launch_syrk(double* A, int lda, int k0, int tile_mode, int tiles128,
 //                 diagonal tile, fused (the critical hand-off D(b) -> D(b+1), see tu_task512)
 //                                                         needs D(b), ver[b+1][b] == ver[b+1][b+1] == 4b
 //   T(b, i)       panel solve of the 128 rows of tile row i > b+1     needs D(b), ver[i][b] == 4b
-//                 (from panel 3 nblk / 8 on as two half tasks of 64 rows: see mega_build_tasks)
+//                 (in the last 30 panels as two half tasks of 64 rows: see mega_build_tasks)
 //   TI(b)         inverse transpose of block b (for the backward substitution)   needs D(b)
 //   U(b; i, j)    tile (i, j) -= L_ib L_jb^T       needs T(b,i), T(b,j), ver[i][j] == 4b;  ver += 4
 //   Uq(b; i,q,j)  the same for 32 rows of a tile of the NEXT panel's column (j = b+1)       ver += 1
@@ -1551,18 +1551,21 @@ static void mega_build_tasks(int nblk, const MegaMachine& mach, std::vector<int4
     }
     auto gpu_of = [&](int l) { return n_gpus > 1 ? l / q_per_gpu : 0; };
     static const int QROWS = knob_int("STBA_MEGA_QROWS", 2);
-    const int THALF_FROM = knob_int("STBA_MEGA_THALF_FROM", (3 * nblk) / 8);      // (panel 17 of 47: where the trailing updates stop pacing the factorisation)
+    // (The chains pace the last ~30 panels whatever the size: the trailing updates of panel nblk - r are r^2 / 2 tiles of ~24 us
+    // on 256 workgroups, < 45 us for r < 31.  The three thresholds below count from the END: measured at n = 6000 -- nblk = 47,
+    // panels 17 / 32 / 30 -- and at n = 12 000, where fractions of nblk cost 2-3 %.)
+    const int THALF_FROM = knob_int("STBA_MEGA_THALF_FROM", std::max(0, nblk - 30));
     static const double THALF_DUR = knob_double("STBA_MEGA_THALF_DUR", 0.6);
     // the fused panel-solve + diagonal-tile update of a step: ten 2 x 2-tile block tasks from panel TU10_FROM on, four
     // quarter tasks (each solving the whole block row) before
     // (n = 6000, medians of interleaved runs on one box, tools/chol_ab.py: never 2.388 ms; from panel 18 / 26 / 28 / 32 / 36 / 40:
     // 2.373 / 2.357 / 2.364 / 2.351 / 2.365 / 2.382 -- while workgroups are scarce ten siblings wait for each other)
-    const int TU10_FROM = knob_int("STBA_MEGA_TU10_FROM", (11 * nblk) / 16);
+    const int TU10_FROM = knob_int("STBA_MEGA_TU10_FROM", std::max(0, nblk - 15));
     static const double TU10_DUR = knob_double("STBA_MEGA_TU10_DUR", 0.65);
     auto ntu = [&](int b) { return b >= TU10_FROM ? MEGA_NTU : 4; };
     // from panel QFROM on (the chain-bound part of the factorisation, where workgroups are idle) every row's tile in the next
     // panel column is updated by four quarter tasks: the row sweeps T -> U -> T get shorter
-    const int QFROM = knob_int("STBA_MEGA_QFROM", (21 * nblk) / 32);      // (panel 30 of 47; with the short TU tasks behind it: 2.351 -> 2.343 ms)
+    const int QFROM = knob_int("STBA_MEGA_QFROM", std::max(0, nblk - 17));      // (panel 30 of 47; with the short TU tasks behind it: 2.351 -> 2.343 ms)
     std::vector<int> idD((size_t)NBK, -1), idTI((size_t)NBK, -1), idTU((size_t)NBK * MEGA_NTU, -1), idT((size_t)NBK * NBK, -1), idT2((size_t)NBK * NBK, -1),
         idUq((size_t)NBK * NBK * 4, -1), idU((size_t)NBK * NBK * NBK, -1);
     // measured on MI355X (tools/mega_trace.py), microseconds, plus ~2 us of flag latency per hop

@@ -100,7 +100,7 @@ def test_schedule_model_runs_on_the_host():
     divided by the workers, grows with n, and shrinks when the model gets more workers."""
     st = importlib.import_module("slam-tricks_amd")
     m6 = st.cholesky_schedule_model(6000)
-    # the model's durations of the diagonal block and the TU hand-over (ten short block tasks from panel 11 * 47 / 16 = 32 on)
+    # the model's durations of the diagonal block and the TU hand-over (ten short block tasks in the last 15 panels: from panel 32 on)
     chain = 32 * (23.0 + 20.0) + 15 * (23.0 + 0.65 * 20.0)
     unlimited = st.cholesky_schedule_model(6000, 1, 4096)
     assert chain - 1 <= unlimited <= st.cholesky_schedule_model(6000, 1, 320) <= m6 <= 1.3 * chain
