@@ -350,9 +350,11 @@ def test_calibration_pipeline_from_corner_files(st, known):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n", [1000, 1500, 3000])
+@pytest.mark.parametrize("n", [1000, 1500, 2000, 3000, 4100, 6000])
 def test_cholesky_persistent_kernel_is_deterministic(st, n):
-    """The persistent (dataflow) factorisation fixes the order of every floating-point operation, so
+    """(sizes: 8 .. 47 block columns -- every mix of the program's task forms: half panel solves in the last 30 panels, the TU
+    hand-off as ten block tasks in the last 15 and as four quarter tasks before, quarter updates in the last 17)
+    The persistent (dataflow) factorisation fixes the order of every floating-point operation, so
     repeated factorisations must agree bit for bit; a difference is a synchronisation or cache-coherence
     race between workgroups (this test found three).  The matrix is a low-rank product plus a small
     ridge: every trailing update matters, a stale tile gives a negative pivot."""
