@@ -1565,9 +1565,10 @@ static void mega_build_tasks(int nblk, const MegaMachine& mach, std::vector<int4
     auto ntu = [&](int b) { return b >= TU10_FROM ? MEGA_NTU : 4; };
     // from panel QFROM on (the chain-bound part of the factorisation, where workgroups are idle) every row's tile in the next
     // panel column is updated by four quarter tasks: the row sweeps T -> U -> T get shorter
+    const int DQ_FROM = knob_int("STBA_MEGA_DQ_FROM", std::max(0, nblk - 17));      // quarter updates of the diagonal tile after next, see below
     const int QFROM = knob_int("STBA_MEGA_QFROM", std::max(0, nblk - 17));      // (panel 30 of 47; with the short TU tasks behind it: 2.351 -> 2.343 ms)
     std::vector<int> idD((size_t)NBK, -1), idTI((size_t)NBK, -1), idTU((size_t)NBK * MEGA_NTU, -1), idT((size_t)NBK * NBK, -1), idT2((size_t)NBK * NBK, -1),
-        idUq((size_t)NBK * NBK * 4, -1), idU((size_t)NBK * NBK * NBK, -1);
+        idUq((size_t)NBK * NBK * 4, -1), idU((size_t)NBK * NBK * NBK, -1), idUd((size_t)NBK * 4, -1);
     // measured on MI355X (tools/mega_trace.py), microseconds, plus ~2 us of flag latency per hop
     // (debug builds: STBA_MEGA_DUR=d,t,ti,u,uq,tu overrides them for experiments)
     double DUR[6] = {23.0, 23.0, 19.0, 25.0, 16.5, 20.0};      // (D: 21.3 us since round 2)
@@ -1633,6 +1634,18 @@ static void mega_build_tasks(int nblk, const MegaMachine& mach, std::vector<int4
             if (b != last) continue;
             const int nb = b - b0 + 1;
             for (int i = j; i < NBK; ++i) {
+                if (i == j && j == b + 2 && b >= DQ_FROM) {
+                    // The diagonal tile (b+2, b+2): its update by panel b is the last input of TU(b+1) to arrive in the
+                    // chain-bound part -- D(b) -> half panel solve of row b+2 (12 us) -> this update (24 us as a whole-tile
+                    // task) = 38 us against a step of 36 (trace: the last TU(b) block became ready 6 us AFTER D(b) every
+                    // other panel).  Four quarter tasks (32 rows each, operands straight from memory: 14.6 us) instead.
+                    for (int q = 0; q < 4; ++q) {
+                        const int id = add(TASK_UQ, b, i * 4 + q, j, 10.0 * j + 1 + 1e-3 * q);
+                        idUd[(size_t)b * 4 + q] = id;
+                        if (q == 0) idU[((size_t)b * NBK + i) * NBK + j] = id;
+                    }
+                    continue;
+                }
                 const int id = add(TASK_U, b, i, j, 10.0 * j + 3 + 1e-3 * i + 1e-6 * b);
                 nodes[(size_t)id].tk.x |= nb << 16;
                 nodes[(size_t)id].dur += (nb - 1) * DUR_K;
@@ -1657,6 +1670,7 @@ static void mega_build_tasks(int nblk, const MegaMachine& mach, std::vector<int4
                 if (b > 0) {
                     for (int q2 = 0; q2 < 4; ++q2) dep(idUq[((size_t)(b - 1) * NBK + (b + 1)) * 4 + q2], tu);
                     dep(idU[((size_t)(b - 1) * NBK + (b + 1)) * NBK + (b + 1)], tu);
+                    for (int q2 = 1; q2 < 4; ++q2) dep(idUd[(size_t)(b - 1) * 4 + q2], tu);     // (its quarters, if it was split)
                 }
             }
         for (int i = b + 2; i < NBK; ++i) {
@@ -1674,11 +1688,15 @@ static void mega_build_tasks(int nblk, const MegaMachine& mach, std::vector<int4
         }
         for (int j = b + 2; j < NBK; ++j)
             for (int i = j; i < NBK; ++i) {
-                const int u = idU[((size_t)b * NBK + i) * NBK + j];
-                if (nodes[(size_t)u].tk.y != b) continue;          // (a batch: its dependencies hang on its last panel)
-                for (auto* v : {&idT, &idT2}) { dep((*v)[(size_t)b * NBK + i], u); if (j != i) dep((*v)[(size_t)b * NBK + j], u); }
-                const int nbp = std::max(1, (nodes[(size_t)u].tk.x >> 16) & 0xff);
-                if (b - nbp >= 0) dep(idU[((size_t)(b - nbp) * NBK + i) * NBK + j], u);
+                const int u0 = idU[((size_t)b * NBK + i) * NBK + j];
+                if (nodes[(size_t)u0].tk.y != b) continue;          // (a batch: its dependencies hang on its last panel)
+                const bool split = (nodes[(size_t)u0].tk.x & 0xff) == TASK_UQ;       // (the diagonal tile after next, in quarters)
+                for (int q2 = 0; q2 < (split ? 4 : 1); ++q2) {
+                    const int u = split ? idUd[(size_t)b * 4 + q2] : u0;
+                    for (auto* v : {&idT, &idT2}) { dep((*v)[(size_t)b * NBK + i], u); if (j != i) dep((*v)[(size_t)b * NBK + j], u); }
+                    const int nbp = split ? 1 : std::max(1, (nodes[(size_t)u].tk.x >> 16) & 0xff);
+                    if (b - nbp >= 0) dep(idU[((size_t)(b - nbp) * NBK + i) * NBK + j], u);
+                }
             }
     }
     // wide inverse blocks: the identity block under panel p = 4q + v of wide block q (virtual row nblk + p) is carried
