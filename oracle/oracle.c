@@ -1498,3 +1498,346 @@ int orc_pg_solve(orc_pg_problem* p, const orc_lm_options* opt, orc_lm_summary* s
     return orc_dense_lm(pg_residual_cb, pg_plus_cb, &c, 7 * p->n_nodes, 6 * p->n_nodes, 6 * p->n_edges, p->poses,
                         NULL, NULL, opt, sum, trace);
 }
+
+/* --------------------------------------------------------------------------------------
+ * C4-SIZE pose graph (10 000 nodes): the same Levenberg-Marquardt control flow as orc_dense_lm above (cost, Jacobi scaling
+ * fixed at the first linearisation, clamped LM diagonal / radius, rho test, radius update, the three stopping rules, trace
+ * columns), with the damped normal equations (J^T J + D) x = -g solved WITHOUT forming them: conjugate gradients on the
+ * matrix-free product, run to 1e-13 of |g| and then CERTIFIED -- the explicit residual |(J^T J + D) x + g| <= 1e-10 |g| is
+ * recomputed from scratch and the solve fails loudly if it does not hold.  So the step is the exact LM step to that accuracy
+ * however the iteration got there; the preconditioner (6x6 block Jacobi + a coarse space of six rigid-body modes per group of
+ * consecutive nodes, delta_k = Ad(T_k^-1 T_ref) xi, Galerkin coarse matrix factored densely) only decides how long it takes.
+ * Build-defined like everything about C4 (the reference has no pose graph): conventions st23-lie-group-v2/doc.tex:862-996.
+ * Checked against orc_pg_solve (dense normal equations) trace for trace on small graphs and against a sparse direct solve
+ * (scipy splu) of one C4-size system: tests/test_oracle_pg.py, tests/golden/make_oracle_traces.py. */
+typedef struct {
+    int n, m;
+    const int *ei, *ej;
+    const double *Ji, *Jj, *D;
+    int *nstart, *ncode;
+    double* t;
+} pgs_op;
+
+static void pgs_apply(const pgs_op* A, const double* v, double* q) {
+    const int n = A->n, m = A->m;
+#pragma omp parallel for schedule(static)
+    for (int e = 0; e < m; ++e) {
+        const double *ji = &A->Ji[(size_t)e * 36], *jj = &A->Jj[(size_t)e * 36];
+        const double *vi = &v[(size_t)A->ei[e] * 6], *vj = &v[(size_t)A->ej[e] * 6];
+        for (int a = 0; a < 6; ++a) {
+            double s = 0;
+            for (int k = 0; k < 6; ++k) s += ji[a * 6 + k] * vi[k] + jj[a * 6 + k] * vj[k];
+            A->t[(size_t)e * 6 + a] = s;
+        }
+    }
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; ++i) {
+        double acc[6];
+        for (int k = 0; k < 6; ++k) acc[k] = A->D ? A->D[(size_t)i * 6 + k] * v[(size_t)i * 6 + k] : 0.0;
+        for (int c = A->nstart[i]; c < A->nstart[i + 1]; ++c) {
+            const int e = A->ncode[c] >> 1, side = A->ncode[c] & 1;
+            const double* J = side ? &A->Jj[(size_t)e * 36] : &A->Ji[(size_t)e * 36];
+            const double* te = &A->t[(size_t)e * 6];
+            for (int k = 0; k < 6; ++k) {
+                double s = 0;
+                for (int a = 0; a < 6; ++a) s += J[a * 6 + k] * te[a];
+                acc[k] += s;
+            }
+        }
+        for (int k = 0; k < 6; ++k) q[(size_t)i * 6 + k] = acc[k];
+    }
+}
+
+static double vdot(const double* a, const double* b, int n) {
+    double s = 0;
+#pragma omp parallel for reduction(+ : s) schedule(static)
+    for (int i = 0; i < n; ++i) s += a[i] * b[i];
+    return s;
+}
+
+/* 6x6 SPD inverse by Gauss-Jordan (no pivoting); returns 0 on success */
+static int inv6_spd(const double* A, double* B) {
+    double M[36];
+    memcpy(M, A, sizeof M);
+    memset(B, 0, sizeof(double) * 36);
+    for (int k = 0; k < 6; ++k) B[k * 7] = 1.0;
+    for (int c = 0; c < 6; ++c) {
+        if (!(M[c * 7] > 0.0)) return 1;
+        const double inv = 1.0 / M[c * 7];
+        for (int k = 0; k < 6; ++k) { M[c * 6 + k] *= inv; B[c * 6 + k] *= inv; }
+        for (int r = 0; r < 6; ++r) {
+            if (r == c) continue;
+            const double f = M[r * 6 + c];
+            for (int k = 0; k < 6; ++k) { M[r * 6 + k] -= f * M[c * 6 + k]; B[r * 6 + k] -= f * B[c * 6 + k]; }
+        }
+    }
+    return 0;
+}
+
+int orc_pg_solve_sparse(orc_pg_problem* p, const orc_lm_options* opt, orc_lm_summary* sum, double* trace,
+                        int* cg_iterations_total, double* worst_linear_residual) {
+    const int n = p->n_nodes, m = p->n_edges, N = 6 * n;
+    const int agg = n >= 4000 ? 64 : n >= 1000 ? 32 : n >= 200 ? 16 : 8;
+    const int na = (n + agg - 1) / agg, nc = 6 * na;
+    double* r = malloc(sizeof(double) * 6 * (size_t)m);
+    double* rn = malloc(sizeof(double) * 6 * (size_t)m);
+    double* Ji = malloc(sizeof(double) * 36 * (size_t)m);
+    double* Jj = malloc(sizeof(double) * 36 * (size_t)m);
+    double* g = calloc((size_t)N, sizeof(double));
+    double* Hd = calloc((size_t)n * 36, sizeof(double));
+    double* Minv = calloc((size_t)n * 36, sizeof(double));
+    double* Pm = calloc((size_t)n * 36, sizeof(double));
+    double* D = calloc((size_t)N, sizeof(double));
+    double* scale = calloc((size_t)N, sizeof(double));
+    double* dx = calloc((size_t)N, sizeof(double));
+    double* cr = calloc((size_t)N, sizeof(double));
+    double* cz = calloc((size_t)N, sizeof(double));
+    double* cp = calloc((size_t)N, sizeof(double));
+    double* cq = calloc((size_t)N, sizeof(double));
+    double* xn = malloc(sizeof(double) * 7 * (size_t)n);
+    double* Ac = malloc(sizeof(double) * (size_t)nc * nc);
+    double* Lt = malloc(sizeof(double) * (size_t)nc * nc);
+    double* Gi = malloc(sizeof(double) * 36 * (size_t)m);
+    double* Gj = malloc(sizeof(double) * 36 * (size_t)m);
+    double* rc_ = calloc((size_t)nc, sizeof(double));
+    int* nstart = calloc((size_t)n + 1, sizeof(int));
+    int* ncode = malloc(sizeof(int) * 2 * (size_t)m);
+    double* tbuf = malloc(sizeof(double) * 6 * (size_t)m);
+    memset(sum, 0, sizeof *sum);
+    const double t_start = now_s();
+    int rc = ORC_NO_CONVERGENCE, cg_total = 0;
+    double worst = 0.0;
+    sum->termination_reason = ORC_TERM_MAX_ITER;
+    {   /* edge ends by node */
+        for (int e = 0; e < m; ++e) { ++nstart[p->edge_i[e] + 1]; ++nstart[p->edge_j[e] + 1]; }
+        for (int i = 0; i < n; ++i) nstart[i + 1] += nstart[i];
+        int* fill = malloc(sizeof(int) * (size_t)n);
+        memcpy(fill, nstart, sizeof(int) * (size_t)n);
+        for (int e = 0; e < m; ++e) { ncode[fill[p->edge_i[e]]++] = 2 * e; ncode[fill[p->edge_j[e]]++] = 2 * e + 1; }
+        free(fill);
+    }
+    pgs_op A = {n, m, p->edge_i, p->edge_j, Ji, Jj, D, nstart, ncode, tbuf};
+    pgs_op A0 = A;
+    A0.D = NULL;
+
+#define PGS_LINEARIZE(costvar)                                                                      \
+    do {                                                                                            \
+        costvar = orc_pg_evaluate(p, r, Ji, Jj);                                                     \
+        _Pragma("omp parallel for schedule(static)")                                                \
+        for (int i = 0; i < n; ++i) {                                                               \
+            double* gi = &g[(size_t)i * 6];                                                         \
+            double* hi = &Hd[(size_t)i * 36];                                                       \
+            memset(gi, 0, sizeof(double) * 6); memset(hi, 0, sizeof(double) * 36);                  \
+            for (int c = nstart[i]; c < nstart[i + 1]; ++c) {                                       \
+                const int e = ncode[c] >> 1, side = ncode[c] & 1;                                   \
+                const double* J = side ? &Jj[(size_t)e * 36] : &Ji[(size_t)e * 36];                 \
+                for (int a = 0; a < 6; ++a)                                                         \
+                    for (int k = 0; k < 6; ++k) {                                                   \
+                        gi[k] += J[a * 6 + k] * r[(size_t)e * 6 + a];                               \
+                        for (int l = 0; l < 6; ++l) hi[k * 6 + l] += J[a * 6 + k] * J[a * 6 + l];   \
+                    }                                                                               \
+            }                                                                                       \
+        }                                                                                           \
+        gmax = 0;                                                                                   \
+        for (int a = 0; a < N; ++a) if (fabs(g[a]) > gmax) gmax = fabs(g[a]);                       \
+        /* coarse space: P_k = Ad(T_k^-1 T_ref(group)), zero rows for constant nodes; G = J P */    \
+        for (int k = 0; k < n; ++k) {                                                               \
+            const int ref = (k / agg) * agg + agg / 2 < n ? (k / agg) * agg + agg / 2 : n - 1;      \
+            double Tki[7], rel[7];                                                                  \
+            orc_se3_inverse(&p->poses[(size_t)k * 7], Tki);                                         \
+            orc_se3_compose(Tki, &p->poses[(size_t)ref * 7], rel);                                  \
+            se3_Ad(rel, &Pm[(size_t)k * 36]);                                                       \
+            if (p->node_fixed && p->node_fixed[k]) memset(&Pm[(size_t)k * 36], 0, sizeof(double) * 36); \
+        }                                                                                           \
+        _Pragma("omp parallel for schedule(static)")                                                \
+        for (int e = 0; e < m; ++e) {                                                               \
+            mat6_mul(&Ji[(size_t)e * 36], &Pm[(size_t)p->edge_i[e] * 36], &Gi[(size_t)e * 36]);     \
+            mat6_mul(&Jj[(size_t)e * 36], &Pm[(size_t)p->edge_j[e] * 36], &Gj[(size_t)e * 36]);     \
+        }                                                                                           \
+    } while (0)
+
+    double cost, gmax;
+    PGS_LINEARIZE(cost);
+    sum->initial_cost = cost;
+    for (int a = 0; a < N; ++a) scale[a] = opt->jacobi_scaling ? 1.0 / (1.0 + sqrt(Hd[(size_t)(a / 6) * 36 + (a % 6) * 7])) : 1.0;
+    double radius = opt->initial_trust_region_radius, decrease_factor = 2.0;
+    double x_norm = 0;
+    for (int a = 0; a < 7 * n; ++a) x_norm += p->poses[a] * p->poses[a];
+    x_norm = sqrt(x_norm);
+    int iter = 0;
+    if (trace) { memset(trace, 0, sizeof(double) * ORC_TRACE_COLS); trace[0] = cost; trace[2] = gmax; trace[5] = radius; trace[6] = 1; }
+    if (gmax <= opt->gradient_tolerance) { rc = ORC_CONVERGENCE; sum->termination_reason = ORC_TERM_GRADIENT; goto fin; }
+
+    while (1) {
+        if (iter >= opt->max_num_iterations) { rc = ORC_NO_CONVERGENCE; sum->termination_reason = ORC_TERM_MAX_ITER; break; }
+        if (radius < opt->min_trust_region_radius) { rc = ORC_CONVERGENCE; sum->termination_reason = ORC_TERM_MIN_RADIUS; break; }
+        ++iter;
+        int ok = 1;
+        for (int a = 0; a < N; ++a) {
+            const double s2 = scale[a] * scale[a];
+            const double h = Hd[(size_t)(a / 6) * 36 + (a % 6) * 7];
+            D[a] = fmin(fmax(h * s2, opt->min_lm_diagonal), opt->max_lm_diagonal) / radius / s2;
+        }
+        /* preconditioner: block Jacobi */
+        for (int i = 0; i < n && ok; ++i) {
+            double B[36];
+            memcpy(B, &Hd[(size_t)i * 36], sizeof B);
+            for (int k = 0; k < 6; ++k) B[k * 7] += D[(size_t)i * 6 + k];
+            if (p->node_fixed && p->node_fixed[i]) { memset(&Minv[(size_t)i * 36], 0, sizeof(double) * 36); continue; }
+            if (inv6_spd(B, &Minv[(size_t)i * 36])) ok = 0;
+        }
+        /* ... + Galerkin coarse matrix Ac = P^T (J^T J + D) P, dense, Cholesky */
+        if (ok) {
+            memset(Ac, 0, sizeof(double) * (size_t)nc * nc);
+            for (int e = 0; e < m; ++e) {
+                const int ai = p->edge_i[e] / agg, aj = p->edge_j[e] / agg;
+                const double *gi = &Gi[(size_t)e * 36], *gj = &Gj[(size_t)e * 36];
+                for (int a = 0; a < 6; ++a)
+                    for (int k = 0; k < 6; ++k)
+                        for (int l = 0; l < 6; ++l) {
+                            Ac[(size_t)(6 * ai + k) * nc + 6 * ai + l] += gi[a * 6 + k] * gi[a * 6 + l];
+                            Ac[(size_t)(6 * aj + k) * nc + 6 * aj + l] += gj[a * 6 + k] * gj[a * 6 + l];
+                            Ac[(size_t)(6 * ai + k) * nc + 6 * aj + l] += gi[a * 6 + k] * gj[a * 6 + l];
+                            Ac[(size_t)(6 * aj + k) * nc + 6 * ai + l] += gj[a * 6 + k] * gi[a * 6 + l];
+                        }
+            }
+            for (int k = 0; k < n; ++k) {
+                const int a0 = 6 * (k / agg);
+                const double* P = &Pm[(size_t)k * 36];
+                for (int c = 0; c < 6; ++c)
+                    for (int u = 0; u < 6; ++u)
+                        for (int v = 0; v < 6; ++v) Ac[(size_t)(a0 + u) * nc + a0 + v] += P[c * 6 + u] * D[(size_t)k * 6 + c] * P[c * 6 + v];
+            }
+            for (int a = 0; a < nc; ++a) if (!(Ac[(size_t)a * nc + a] > 0.0)) Ac[(size_t)a * nc + a] = 1.0;   /* a group of constant nodes */
+            if (orc_cholesky_lower(Ac, nc, 8) != 0) ok = 0;
+            if (ok)
+                for (int a = 0; a < nc; ++a)
+                    for (int b = 0; b <= a; ++b) Lt[(size_t)b * nc + a] = Ac[(size_t)a * nc + b];
+        }
+#define PGS_PRECOND(rv, zv)                                                                         \
+        do {                                                                                        \
+            memset(rc_, 0, sizeof(double) * (size_t)nc);                                            \
+            for (int k = 0; k < n; ++k) {                                                           \
+                const double* P = &Pm[(size_t)k * 36];                                              \
+                for (int u = 0; u < 6; ++u) {                                                       \
+                    double s = 0, z0 = 0;                                                           \
+                    for (int c = 0; c < 6; ++c) { s += P[c * 6 + u] * rv[(size_t)k * 6 + c]; z0 += Minv[(size_t)k * 36 + u * 6 + c] * rv[(size_t)k * 6 + c]; } \
+                    rc_[6 * (k / agg) + u] += s;                                                    \
+                    zv[(size_t)k * 6 + u] = z0;                                                     \
+                }                                                                                   \
+            }                                                                                       \
+            for (int a = 0; a < nc; ++a) rc_[a] = (rc_[a] - dotk(&Ac[(size_t)a * nc], rc_, a)) / Ac[(size_t)a * nc + a];          \
+            for (int a = nc - 1; a >= 0; --a) rc_[a] = (rc_[a] - dotk(&Lt[(size_t)a * nc + a + 1], &rc_[a + 1], nc - 1 - a)) / Ac[(size_t)a * nc + a]; \
+            for (int k = 0; k < n; ++k) {                                                           \
+                const double* P = &Pm[(size_t)k * 36];                                              \
+                for (int c = 0; c < 6; ++c) {                                                       \
+                    double s = 0;                                                                   \
+                    for (int u = 0; u < 6; ++u) s += P[c * 6 + u] * rc_[6 * (k / agg) + u];         \
+                    zv[(size_t)k * 6 + c] += s;                                                     \
+                }                                                                                   \
+            }                                                                                       \
+        } while (0)
+        double model_change = 0, new_cost = 0, step_norm = 0, rho = 0;
+        if (ok) {
+            /* PCG on (J^T J + D) x = -g */
+            double bb = 0;
+            for (int a = 0; a < N; ++a) { dx[a] = 0; cr[a] = -g[a]; bb += g[a] * g[a]; }
+            PGS_PRECOND(cr, cz);
+            memcpy(cp, cz, sizeof(double) * (size_t)N);
+            double rz = vdot(cr, cz, N), rr = bb;
+            int k = 0;
+            while (rr > 1e-26 * bb && k < 20000) {
+                pgs_apply(&A, cp, cq);
+                const double pq = vdot(cp, cq, N);
+                if (!(pq > 0.0)) { ok = 0; break; }
+                const double alpha = rz / pq;
+                for (int a = 0; a < N; ++a) { dx[a] += alpha * cp[a]; cr[a] -= alpha * cq[a]; }
+                PGS_PRECOND(cr, cz);
+                const double rzn = vdot(cr, cz, N);
+                rr = vdot(cr, cr, N);
+                const double beta = rzn / rz;
+                rz = rzn;
+                for (int a = 0; a < N; ++a) cp[a] = cz[a] + beta * cp[a];
+                ++k;
+            }
+            cg_total += k;
+            /* certificate: the residual recomputed from scratch */
+            pgs_apply(&A, dx, cq);
+            double res = 0;
+            for (int a = 0; a < N; ++a) res += (cq[a] + g[a]) * (cq[a] + g[a]);
+            res = sqrt(res / (bb > 0 ? bb : 1.0));
+            if (res > worst) worst = res;
+            if (!(res <= 1e-10)) ok = 0;
+        }
+        if (ok) {
+            pgs_apply(&A0, dx, cq);                         /* J^T J dx */
+            model_change = -vdot(g, dx, N) - 0.5 * vdot(dx, cq, N);
+            if (!(model_change > 0) || !isfinite(model_change)) ok = 0;
+        }
+        int accepted = 0;
+        if (ok) {
+            for (int i = 0; i < n; ++i) {
+                if (p->node_fixed && p->node_fixed[i]) memcpy(&xn[(size_t)i * 7], &p->poses[(size_t)i * 7], sizeof(double) * 7);
+                else orc_se3_retract(&p->poses[(size_t)i * 7], &dx[(size_t)i * 6], &xn[(size_t)i * 7]);
+            }
+            orc_pg_problem q = *p;
+            q.poses = xn;
+            new_cost = orc_pg_evaluate(&q, rn, NULL, NULL);
+            for (int a = 0; a < 7 * n; ++a) step_norm += (xn[a] - p->poses[a]) * (xn[a] - p->poses[a]);
+            step_norm = sqrt(step_norm);
+            const double cost_change = cost - new_cost;
+            rho = cost_change / model_change;
+            if (trace) { double* tr = &trace[iter * ORC_TRACE_COLS]; tr[0] = new_cost; tr[1] = cost_change; tr[3] = step_norm; tr[4] = rho; }
+            if (step_norm <= opt->parameter_tolerance * (x_norm + opt->parameter_tolerance)) {
+                rc = ORC_CONVERGENCE; sum->termination_reason = ORC_TERM_PARAMETER;
+                if (trace) { trace[iter * ORC_TRACE_COLS + 5] = radius; trace[iter * ORC_TRACE_COLS + 2] = gmax; }
+                break;
+            }
+            if (fabs(cost_change) <= opt->function_tolerance * cost) {
+                if (rho > opt->min_relative_decrease) {
+                    memcpy(p->poses, xn, sizeof(double) * 7 * (size_t)n); cost = new_cost; ++sum->num_successful_steps;
+                    if (trace) trace[iter * ORC_TRACE_COLS + 6] = 1;
+                }
+                rc = ORC_CONVERGENCE; sum->termination_reason = ORC_TERM_FUNCTION;
+                if (trace) { trace[iter * ORC_TRACE_COLS + 5] = radius; trace[iter * ORC_TRACE_COLS + 2] = gmax; }
+                break;
+            }
+            accepted = rho > opt->min_relative_decrease;
+        }
+        if (accepted) {
+            memcpy(p->poses, xn, sizeof(double) * 7 * (size_t)n);
+            x_norm = 0;
+            for (int a = 0; a < 7 * n; ++a) x_norm += p->poses[a] * p->poses[a];
+            x_norm = sqrt(x_norm);
+            ++sum->num_successful_steps;
+            PGS_LINEARIZE(cost);
+            const double t = 2.0 * rho - 1.0;
+            radius = fmin(opt->max_trust_region_radius, radius / fmax(1.0 / 3.0, 1.0 - t * t * t));
+            decrease_factor = 2.0;
+        } else {
+            ++sum->num_unsuccessful_steps;
+            radius /= decrease_factor;
+            decrease_factor *= 2.0;
+        }
+        if (trace) {
+            double* tr = &trace[iter * ORC_TRACE_COLS];
+            if (!ok) { tr[0] = cost; tr[1] = 0; tr[3] = 0; tr[4] = 0; }
+            tr[2] = gmax; tr[5] = radius; tr[6] = accepted;
+        }
+        if (accepted && gmax <= opt->gradient_tolerance) { rc = ORC_CONVERGENCE; sum->termination_reason = ORC_TERM_GRADIENT; break; }
+    }
+fin:
+    sum->num_iterations = iter;
+    sum->final_cost = cost;
+    sum->final_radius = radius;
+    sum->final_gradient_max_norm = gmax;
+    sum->termination_type = rc;
+    sum->seconds_total = now_s() - t_start;
+    if (cg_iterations_total) *cg_iterations_total = cg_total;
+    if (worst_linear_residual) *worst_linear_residual = worst;
+    free(r); free(rn); free(Ji); free(Jj); free(g); free(Hd); free(Minv); free(Pm); free(D); free(scale); free(dx); free(cr); free(cz);
+    free(cp); free(cq); free(xn); free(Ac); free(Lt); free(Gi); free(Gj); free(rc_); free(nstart); free(ncode); free(tbuf);
+    return rc;
+}
+#undef PGS_LINEARIZE
+#undef PGS_PRECOND

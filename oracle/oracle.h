@@ -219,6 +219,11 @@ void orc_se3_retract(const double* T, const double* delta, double* out);  /* T e
 double orc_pg_evaluate(const orc_pg_problem* p, double* r, double* Ji, double* Jj);
 /* LM with the dense (6 n_nodes)^2 normal equations + Cholesky: small graphs only */
 int orc_pg_solve(orc_pg_problem* p, const orc_lm_options* opt, orc_lm_summary* sum, double* trace);
+/* the same LM with the normal equations solved matrix-free (certified conjugate gradients, see oracle.c): any graph size,
+ * 10 000 nodes in seconds.  cg_iterations_total / worst_linear_residual (max over the iterations of |(J^T J + D) x + g| / |g|,
+ * recomputed from scratch) may be NULL */
+int orc_pg_solve_sparse(orc_pg_problem* p, const orc_lm_options* opt, orc_lm_summary* sum, double* trace,
+                        int* cg_iterations_total, double* worst_linear_residual);
 /* st4 absTrajectoryError (pose_simulation.cpp:198-209): sqrt(mean |log(truth^-1 est)|^2) */
 double orc_pg_ate(int n, const double* truth, const double* est);
 #ifdef __cplusplus

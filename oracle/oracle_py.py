@@ -409,6 +409,17 @@ class PG:
         lib().orc_pg_solve(C.byref(s), C.byref(opt), C.byref(summ), _p(trace))
         return summ, trace[: summ.num_iterations + 1]
 
+    def solve_sparse(self, opt=None, **kw):
+        """the same LM with the normal equations solved matrix-free (certified CG): any size; returns
+        (summary, trace, cg_iterations_total, worst_linear_residual)"""
+        opt = opt or default_options(**kw)
+        trace = np.zeros((opt.max_num_iterations + 1, TRACE_COLS))
+        summ = LMSummary()
+        s = self._struct()
+        cg = C.c_int(); worst = C.c_double()
+        lib().orc_pg_solve_sparse(C.byref(s), C.byref(opt), C.byref(summ), _p(trace), C.byref(cg), C.byref(worst))
+        return summ, trace[: summ.num_iterations + 1], cg.value, worst.value
+
 
 def se3_compose(a, b):
     o = np.zeros(7); lib().orc_se3_compose(_p(f64(a)), _p(f64(b)), _p(o)); return o

@@ -30,7 +30,32 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+HEAD_FILE = os.path.join(HERE, "BUILD_HEAD")
+
+
+def stamp_head():
+    """git head of the tree the library was built from -> slam-tricks_amd/BUILD_HEAD (git-ignored; it travels to the GPU box,
+    where there is no .git: bench.py and the tools/pmc_*.sh scripts put it into what they write, so that a counter file
+    can be held against the bench line it belongs to)."""
+    try:
+        root = os.path.dirname(HERE)
+        head = subprocess.check_output(["git", "-C", root, "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL, text=True).strip()
+        dirty = subprocess.call(["git", "-C", root, "diff", "--quiet", "HEAD", "--", "slam-tricks_amd/csrc", "include"]) != 0
+        with open(HEAD_FILE, "w") as f:
+            f.write(head + ("+dirty" if dirty else "") + "\n")
+    except Exception:
+        pass                      # no git here (the GPU box): keep the file that came with the snapshot
+
+
+def build_head():
+    try:
+        return open(HEAD_FILE).read().strip()
+    except OSError:
+        return "unknown"
+
+
 def build(force=False, verbose=False):
+    stamp_head()
     if not force and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -1528,6 +1528,20 @@ struct MegaShardModel {          // what-if: the queues are spread over several 
     double cross_edges = 0.0;    // out: dependencies that crossed GPUs
     double tiles_in_max = 0.0;   // out: distinct remote tiles fetched by the busiest GPU
 };
+// Far trailing updates are applied `batch` panels per pass over a tile (see mega_build_tasks).  The batch trades traffic for
+// task length: a tile is read and written once per batch (round 4, PMC passes at n = 24 000 with two-panel batches: 383 GB per
+// factorisation = 4 TB/s averaged over the kernel -- HBM-bound, 256 KB of operands + 128 KB of tile per panel and tile, no
+// reuse of the operand panels in the L2s), but a batch of B panels is a task of ~6 + 18 B us that nothing can pre-empt.  Small
+// systems are chain-bound and want short tasks (n = 6000: 2.294 / 2.295 / 2.344 ms with B = 2 / 3 / 4); large ones are
+// throughput-bound (n = 12 000: 13.09 / 12.01 / 11.55 ms with B = 2 / 4 / 8; n = 24 000: 96.9 / 88.6 / 84.7 / 82.6 ms with
+// B = 2 / 4 / 8 / 16, 0.61 -> 0.71 of the FP64 matrix-core peak).  Rule: double the batch while a batch round still
+// leaves every workgroup a few tasks (nblk^2 / 2 tiles on 256 workgroups).
+static int mega_default_batch(int nblk) {
+    const double tiles_per_wg = 0.5 * nblk * nblk / 256.0;
+    int b = 2;
+    while (b < 16 && tiles_per_wg / b >= 2.2) b *= 2;
+    return b;
+}
 struct MegaMachine {
     int nq = 8;                  // XCD queues
     int wg = 32;                 // model workers (= resident workgroups) per queue
@@ -1573,7 +1587,8 @@ static void mega_build_tasks(int nblk, const MegaMachine& mach, std::vector<int4
     // (debug builds: STBA_MEGA_DUR=d,t,ti,u,uq,tu overrides them for experiments)
     double DUR[6] = {23.0, 23.0, 19.0, 25.0, 16.5, 20.0};      // (D: 21.3 us since round 2)
     double DUR_K = 18.0;           // one more panel (K += 128) inside a batched trailing update (measured: 24 us for one panel, 42 for two)
-    static const int BATCH = std::max(1, std::min(16, knob_int("STBA_MEGA_BATCH", 2)));
+    static const int BATCH_KNOB = knob_int("STBA_MEGA_BATCH", 0);
+    const int BATCH = BATCH_KNOB > 0 ? std::min(64, BATCH_KNOB) : mega_default_batch(nblk);
     static const int BLAG = std::max(0, knob_int("STBA_MEGA_BLAG", 2));      // (round 3, with the shorter chain tasks: 3 -> 2: -0.02 ms; 1: the same; 0: +0.25 ms)
     if (const char* e = knob_str("STBA_MEGA_DUR")) sscanf(e, "%lf,%lf,%lf,%lf,%lf,%lf", &DUR[0], &DUR[1], &DUR[2], &DUR[3], &DUR[4], &DUR[5]);
     auto add = [&](int type, int b, int i, int j, double prio) {

@@ -46,3 +46,52 @@ def test_pg_solve_reduces_ate(O, scenes):
     assert summ.termination_type == 0 and summ.final_cost < summ.initial_cost * 0.2
     assert ate1 < 0.5 * ate0
     assert np.all(pg.poses[0] == s["poses0"][0])        # node 0 fixed
+
+
+def test_pg_matrix_free_lm_reproduces_the_dense_lm_trace(O, scenes):
+    """orc_pg_solve_sparse (certified conjugate gradients on the matrix-free normal equations) against orc_pg_solve (dense
+    normal equations + Cholesky): the same LM, iteration for iteration."""
+    s = scenes.pose_graph_scene(n_nodes=150, loops_per_node=3, seed=4, sigma_t=0.02, sigma_r=0.004, turns=6)
+    a = O.PG(s["poses0"], s["edge_i"], s["edge_j"], s["meas"], s["node_fixed"])
+    b = O.PG(s["poses0"], s["edge_i"], s["edge_j"], s["meas"], s["node_fixed"])
+    sa, tra = a.solve()
+    sb, trb, cg, worst = b.solve_sparse()
+    assert sa.termination_type == 0 and sb.termination_type == 0
+    assert sa.num_iterations == sb.num_iterations and sa.termination_reason == sb.termination_reason
+    assert np.allclose(tra[:, 0], trb[:, 0], rtol=1e-11) and np.all(tra[:, 6] == trb[:, 6])
+    assert np.allclose(tra[:, 5], trb[:, 5], rtol=1e-9)            # radius
+    assert np.abs(a.poses - b.poses).max() < 1e-11
+    assert cg > 0 and worst <= 1e-10
+
+
+def test_pg_matrix_free_first_step_against_a_sparse_direct_solve(O, scenes):
+    """one LM step of a 1 500-node graph: the oracle's certified CG step against scipy's sparse LU of the same damped
+    normal equations (an independent solver: the new cost must agree)"""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spl
+    s = scenes.pose_graph_scene(n_nodes=1500, loops_per_node=3, seed=9, sigma_t=0.02, sigma_r=0.004, turns=6)
+    ei, ej = s["edge_i"], s["edge_j"]
+    n, m = 1500, len(ei)
+    pg = O.PG(s["poses0"], ei, ej, s["meas"], s["node_fixed"])
+    cost, r, Ji, Jj = pg.evaluate()
+    rows = np.repeat(np.arange(6 * m).reshape(m, 6, 1), 6, 2)
+    ci = 6 * ei[:, None, None] + np.arange(6)[None, None, :] + np.zeros((m, 6, 1), int)
+    cj = 6 * ej[:, None, None] + np.arange(6)[None, None, :] + np.zeros((m, 6, 1), int)
+    J = sp.csr_matrix((np.concatenate([Ji.ravel(), Jj.ravel()]), (np.concatenate([rows.ravel()] * 2), np.concatenate([ci.ravel(), cj.ravel()]))),
+                      shape=(6 * m, 6 * n))
+    H = (J.T @ J).tocsc()
+    g = J.T @ r.ravel()
+    diag = H.diagonal()
+    scale = 1.0 / (1.0 + np.sqrt(diag))
+    D = np.clip(diag * scale ** 2, 1e-6, 1e32) / 1e4 / scale ** 2
+    dx = spl.splu((H + sp.diags(D)).tocsc()).solve(-g)
+    newp = pg.poses.copy()
+    for k in range(n):
+        if not s["node_fixed"][k]:
+            newp[k] = O.se3_retract(pg.poses[k], dx[6 * k:6 * k + 6])
+    c_direct = O.PG(newp, ei, ej, s["meas"], s["node_fixed"]).evaluate(jac=False)[0]
+    opt = O.default_options(max_num_iterations=1)
+    summ, tr, cg, worst = pg.solve_sparse(opt)
+    assert worst <= 1e-10
+    assert abs(tr[1, 0] - c_direct) <= 1e-9 * c_direct
+    assert np.abs(pg.poses - newp).max() < 1e-9
