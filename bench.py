@@ -131,11 +131,20 @@ def pg_bytes_per_edge(n_nodes, n_edges):
     return lin, mv
 
 
+def build_head():
+    """git head the library was built from (slam-tricks_amd/BUILD_HEAD, written by build.py where .git exists)"""
+    try:
+        return importlib.import_module("slam-tricks_amd.build").build_head()
+    except Exception:
+        return "unknown"
+
+
 def bench_c4(args):
     """BASELINE config C4 (build-defined: the reference has no pose-graph code): 10 000 SE3 nodes, ~40 000 relative-pose
-    edges, LM with a matrix-free block-Jacobi PCG (pg_engine.hip).  A "step" is one LM iteration (linearisation, PCG solve,
-    trial point); `value` = LM iterations / s over whole solves to convergence from the same start, median of the
-    repetitions.  N = 1 only (the sharded variant is covered by tests/test_sharding.py)."""
+    edges, LM with inexact Newton steps: matrix-free PCG, two-level preconditioner (block Jacobi + rigid-body coarse space),
+    forcing sequence (pg_engine.hip).  A "step" is one LM iteration (linearisation, coarse operator, PCG solve, trial point);
+    `value` = LM iterations / s over whole solves to convergence from the same start, median of the repetitions.  N = 1 only
+    (the sharded variant is covered by tests/test_sharding.py)."""
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: libstba has no CPU fallback")
@@ -157,9 +166,17 @@ def bench_c4(args):
         summ, tr, pcg_total = e.solve(max_num_iterations=args.steps)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        reps.append((dt, summ.num_iterations, pcg_total, summ.final_cost, summ.initial_cost, summ.termination_type))
-    reps.sort()
-    dt, iters, pcg_total, fcost, icost, term = reps[len(reps) // 2]
+        reps.append((dt, summ.num_iterations, pcg_total, summ.final_cost, summ.initial_cost, summ.termination_type, e.pcg_summary().as_dict(),
+                     e.get_poses(), [int(x) for x in tr[:, 6]]))
+    reps.sort(key=lambda r: r[0])
+    dt, iters, pcg_total, fcost, icost, term, pcg_sum, gpu_poses, gpu_acc = reps[len(reps) // 2]
+    # the same solve with EXACT steps (PCG to 1e-12): what the forcing sequence saves, and the run the oracle's trace is held against
+    e = fresh()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    summ_x, tr_x, pcg_x = e.solve(max_num_iterations=args.steps, pcg=e.pcg_options(forcing_eta0=0.0, relative_tolerance=1e-12, max_iterations=2000))
+    torch.cuda.synchronize()
+    dt_x = time.perf_counter() - t0
     e = fresh()
     ms_lin, ms_mv = e.time_kernels(reps=200)
     b_lin, b_mv = pg_bytes_per_edge(n, m)
@@ -169,41 +186,57 @@ def bench_c4(args):
         "n_gpus": 1, "steps": int(iters), "warmup": int(args.warmup > 0), "ms_per_step": 1e3 * dt / max(iters, 1), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"C4 pose graph (build-defined): {n} SE3 nodes on the st4 sphere spiral, {m} relative-pose edges "
-                               f"({n - 1} odometry + loop closures one revolution apart), LM to convergence + matrix-free block-Jacobi PCG",
+                               f"({n - 1} odometry + loop closures one revolution apart), LM to convergence, inexact steps: matrix-free PCG, "
+                               "block Jacobi + rigid-body coarse space, Eisenstat-Walker forcing sequence",
                    "n_nodes": n, "n_edges": m, "parallelism": "single GPU"},
-        "solve_seconds": dt, "lm_iterations": int(iters), "pcg_iterations": int(pcg_total), "pcg_iterations_per_sec": pcg_total / dt,
+        "solve_seconds": dt, "lm_iterations": int(iters), "pcg_iterations": int(pcg_total), "pcg_iterations_per_lm_iteration": pcg_total / max(iters, 1),
+        "pcg_hit_cap": int(pcg_sum["hit_cap"]), "pcg_summary": pcg_sum, "pcg_iterations_per_sec": pcg_total / dt,
         "edge_visits_per_sec": m * (products + 2.0 * iters) / dt,       # every product and every (trial / accepted) linearisation visits every edge
-        "us_per_pcg_iteration": 1e6 * dt / max(pcg_total, 1),
         "initial_cost": icost, "final_cost": fcost, "converged": bool(term == 0),
+        "exact_steps": {"lm_iterations": int(summ_x.num_iterations), "pcg_iterations": int(pcg_x), "solve_seconds": dt_x,
+                        "lm_iterations_per_sec": summ_x.num_iterations / dt_x, "final_cost": summ_x.final_cost,
+                        "note": "the same solve with the PCG run to 1e-12 (forcing_eta0 = 0): the LM trace the oracle's is compared with"},
         "reps_solve_seconds": [r[0] for r in reps], "timing": "median of reps",
         "roofline": {"kernel": "pg_edge_product_kernel (t = J [p_i; p_j], u = J^T t per edge, component-major Jacobians; the node kernel gathers u)",
                      "bound": "hbm", "achieved": b_mv * m / (ms_mv * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": b_mv * m / (ms_mv * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "ms_per_launch": ms_mv,
                      "algorithmic_bytes_per_edge": b_mv, "algorithmic_bytes_per_launch": b_mv * m,
                      "note": f"{b_mv * m / 1e6:.1f} MB per product: 3.5 us at 8 TB/s -- at this size a launch is latency, not bandwidth: "
-                             "the 40k-edge graph fills 157 of 256 CUs once, and a PCG iteration is three dependent launches"},
+                             "the 40k-edge graph fills 157 of 256 CUs once, and a PCG iteration is four dependent launches"},
         "roofline_linearize": {"kernel": "pg_linearize_kernel (residual + both 6x6 Jacobians per edge)", "bound": "hbm",
                                "achieved": b_lin * m / (ms_lin * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": b_lin * m / (ms_lin * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "ms_per_launch": ms_lin,
                                "algorithmic_bytes_per_edge": b_lin, "algorithmic_bytes_per_launch": b_lin * m},
         "edges_per_sec_linearize": m / (ms_lin * 1e-3), "edges_per_sec_matvec": m / (ms_mv * 1e-3),
+        "build_head": build_head(),
     }
     if not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
-        import oracle_py as O       # cpu_baseline leg only
+        import oracle_py as O       # cpu_baseline leg + matched-result gate only
         o = O.PG(s["poses0"], s["edge_i"], s["edge_j"], s["meas"], s["node_fixed"])
-        o.evaluate()
         t0 = time.perf_counter()
-        k = 0
-        while time.perf_counter() - t0 < 5.0:
-            o.evaluate(); k += 1
-        tcpu = (time.perf_counter() - t0) / k
-        out["cpu_baseline"] = {"value": m / tcpu, "unit": "edges/s (residual + Jacobians)", "cores": 1, "kind": "port", "cpu_model": cpu_model(),
-                               "sample": f"{k} evaluations of all {m} edges by oracle/liboracle.so (orc_pg_evaluate, one thread), {k * tcpu:.1f} s wall; "
-                                         "the oracle's LM solves DENSE normal equations and is limited to ~1000 nodes (35 s at 300 nodes), so the "
-                                         "kernel-level rate is what can be put beside the GPU's edges_per_sec_linearize",
-                               "seconds": k * tcpu}
-        out["speedup_linearize_vs_cpu_port"] = out["edges_per_sec_linearize"] / out["cpu_baseline"]["value"]
+        so, tro, cg, worst = o.solve_sparse(O.default_options(max_num_iterations=args.steps))
+        tcpu = time.perf_counter() - t0
+        dq = np.minimum(np.abs(gpu_poses[:, :4] - o.poses[:, :4]).max(1), np.abs(gpu_poses[:, :4] + o.poses[:, :4]).max(1)).max()
+        dpose = float(max(dq, np.abs(gpu_poses[:, 4:] - o.poses[:, 4:]).max()))
+        nx = min(len(tr_x), len(tro))
+        gate = {"passed": bool(abs(fcost - so.final_cost) <= 1e-6 * so.final_cost and dpose <= 1e-5 and iters == so.num_iterations
+                               and summ_x.num_iterations == so.num_iterations and np.allclose(tr_x[:nx, 0], tro[:nx, 0], rtol=1e-7)
+                               and np.all(tr_x[:nx, 6] == tro[:nx, 6])),
+                "final_cost_rel_diff": abs(fcost - so.final_cost) / so.final_cost, "pose_max_abs_diff": dpose,
+                "lm_iterations_gpu": int(iters), "lm_iterations_gpu_exact_steps": int(summ_x.num_iterations), "lm_iterations_cpu": int(so.num_iterations),
+                "exact_step_cost_trace_max_rel_diff": float(np.max(np.abs(tr_x[:nx, 0] - tro[:nx, 0]) / tro[:nx, 0])),
+                "ate_gpu": float(O.pg_ate(s["poses_true"], gpu_poses)), "ate_cpu": float(O.pg_ate(s["poses_true"], o.poses)),
+                "ate_initial": float(O.pg_ate(s["poses_true"], s["poses0"])),
+                "tolerances": {"cost_rel": 1e-6, "pose": 1e-5, "exact_step_trace_rel": 1e-7}}
+        out["matched_result_gate"] = gate
+        out["cpu_baseline"] = {"value": so.num_iterations / tcpu, "unit": "LM iterations/s", "cores": 16, "kind": "port", "cpu_model": cpu_model(),
+                               "sample": f"one whole solve of the same C4 problem to convergence ({so.num_iterations} LM iterations, {cg} CG iterations) by "
+                                         "oracle/liboracle.so: orc_pg_solve_sparse -- the same LM with EXACT steps, the normal equations solved matrix-free by "
+                                         f"conjugate gradients to 1e-13 and certified (worst explicit residual {worst:.1e}), OpenMP teams of at most 16 threads, "
+                                         f"{tcpu:.1f} s wall", "seconds": tcpu, "cg_iterations": int(cg)}
+        if gate["passed"]:
+            out["speedup_vs_cpu_port"] = out["value"] / out["cpu_baseline"]["value"]
     print(json.dumps(out), flush=True)
 
 

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define STBA_VERSION 2
+#define STBA_VERSION 3
 
 /* status codes */
 enum {
@@ -301,14 +301,31 @@ int stba_calib_gauss_newton(int n_views, int n_corners, double* params, const do
 /* BUILD-DEFINED: the reference has no pose-graph code (SURVEY.md header fact 3).  Conventions from the
  * reference's Lie-group notes (st23-lie-group-v2/doc.tex:862-996): node pose T = (qx qy qz qw tx ty tz),
  * right-multiplicative update T <- T exp(delta), tangent [rho, theta]; edge measurement Z_ij ~ T_i^-1 T_j;
- * residual r_ij = log(Z_ij^-1 T_i^-1 T_j).  Levenberg-Marquardt with block-Jacobi preconditioned CG. */
+ * residual r_ij = log(Z_ij^-1 T_i^-1 T_j).  Levenberg-Marquardt; the damped normal equations are solved matrix-free by
+ * conjugate gradients with a two-level preconditioner (6x6 block Jacobi + a coarse space of six rigid-body modes per group
+ * of consecutive nodes, inverted densely) as an INEXACT Newton step: the PCG stops at |r| <= eta_k |g|, decided on the
+ * device; eta_k follows Eisenstat & Walker's forcing sequence (eta_0 = forcing_eta0, tightening as the gradient falls). */
 typedef struct stba_pg stba_pg;
 typedef struct {
-    int    max_iterations;       /* 1000 */
-    double relative_tolerance;   /* 1e-12 on |residual| / |rhs| */
-    int    check_every;          /* 20: iterations between host-side convergence checks */
+    int    max_iterations;       /* 1000: cap on the PCG iterations of one linear solve (stba_pcg_summary::hit_cap counts the solves that reach it) */
+    double relative_tolerance;   /* 1e-12 on |residual| / |rhs|: used when forcing_eta0 <= 0 (a fixed tolerance, i.e. exact steps) */
+    int    check_every;          /* 4: PCG iterations enqueued between the host's looks at the device-side convergence flag */
+    double forcing_eta0;         /* 0.1: first and largest forcing term; <= 0: fixed relative_tolerance */
+    double forcing_eta_min;      /* 1e-10 */
+    int    coarse_group;         /* nodes per group of the coarse space, a power of two; 0: automatic (<= 200 groups, >= 8 nodes);
+                                  * -1: no coarse space (block Jacobi only, the round-3 preconditioner) */
+    int    coarse_refresh_every; /* 1: LM iterations between re-inversions of the coarse operator while only the damping changes */
 } stba_pcg_options;
 void stba_pcg_default_options(stba_pcg_options* o);
+typedef struct {
+    int    iterations_total;            /* PCG iterations of the whole solve */
+    int    solves;                      /* linear solves (one per LM iteration) */
+    int    hit_cap;                     /* solves that ran into max_iterations before reaching their tolerance */
+    int    max_iterations_in_a_solve;
+    int    coarse_dim;                  /* unknowns of the coarse space (0: none) */
+    int    coarse_refreshes;            /* coarse operators inverted */
+    double last_eta;                    /* forcing term of the last solve */
+} stba_pcg_summary;
 int stba_pg_create(stba_pg** out, int n_nodes, int n_edges, const double* poses, const int* edge_i, const int* edge_j,
                    const double* meas, const unsigned char* node_fixed, void* hip_stream);
 int stba_pg_destroy(stba_pg* pg);
@@ -325,6 +342,8 @@ int stba_pg_evaluate(stba_pg* pg, double* cost, double* r, double* Ji, double* J
 int stba_pg_time_kernels(stba_pg* pg, int reps, double* ms_linearize, double* ms_matvec);
 int stba_pg_solve(stba_pg* pg, const stba_lm_options* opt, const stba_pcg_options* pcg, stba_lm_summary* summary,
                   double* trace, int* pcg_iterations_total);
+/* the linear-solver side of the last stba_pg_solve of this engine */
+int stba_pg_last_pcg_summary(stba_pg* pg, stba_pcg_summary* out);
 
 /* ================================ small dense LM problems ================================ */
 /* Residual blocks evaluated by a HOST callback (user CostFunction::Evaluate, solver.hpp:168-212;

@@ -1510,6 +1510,14 @@ int orc_pg_solve(orc_pg_problem* p, const orc_lm_options* opt, orc_lm_summary* s
  * Build-defined like everything about C4 (the reference has no pose graph): conventions st23-lie-group-v2/doc.tex:862-996.
  * Checked against orc_pg_solve (dense normal equations) trace for trace on small graphs and against a sparse direct solve
  * (scipy splu) of one C4-size system: tests/test_oracle_pg.py, tests/golden/make_oracle_traces.py. */
+/* OpenMP team size for a loop of `work` items: the GPU box has 256 logical cores, and a parallel region over a few hundred
+ * items with 256 threads costs more than the loop (a 150-node solve took minutes there); at most 16 threads, 512 items each */
+static int pgs_threads(int work) {
+    int t = work / 512;
+    if (t < 1) t = 1;
+    if (t > 16) t = 16;
+    return t;
+}
 typedef struct {
     int n, m;
     const int *ei, *ej;
@@ -1520,7 +1528,7 @@ typedef struct {
 
 static void pgs_apply(const pgs_op* A, const double* v, double* q) {
     const int n = A->n, m = A->m;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(pgs_threads(m))
     for (int e = 0; e < m; ++e) {
         const double *ji = &A->Ji[(size_t)e * 36], *jj = &A->Jj[(size_t)e * 36];
         const double *vi = &v[(size_t)A->ei[e] * 6], *vj = &v[(size_t)A->ej[e] * 6];
@@ -1530,7 +1538,7 @@ static void pgs_apply(const pgs_op* A, const double* v, double* q) {
             A->t[(size_t)e * 6 + a] = s;
         }
     }
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(pgs_threads(n))
     for (int i = 0; i < n; ++i) {
         double acc[6];
         for (int k = 0; k < 6; ++k) acc[k] = A->D ? A->D[(size_t)i * 6 + k] * v[(size_t)i * 6 + k] : 0.0;
@@ -1550,7 +1558,7 @@ static void pgs_apply(const pgs_op* A, const double* v, double* q) {
 
 static double vdot(const double* a, const double* b, int n) {
     double s = 0;
-#pragma omp parallel for reduction(+ : s) schedule(static)
+#pragma omp parallel for reduction(+ : s) schedule(static) num_threads(pgs_threads(n / 8))
     for (int i = 0; i < n; ++i) s += a[i] * b[i];
     return s;
 }
@@ -1623,7 +1631,7 @@ int orc_pg_solve_sparse(orc_pg_problem* p, const orc_lm_options* opt, orc_lm_sum
 #define PGS_LINEARIZE(costvar)                                                                      \
     do {                                                                                            \
         costvar = orc_pg_evaluate(p, r, Ji, Jj);                                                     \
-        _Pragma("omp parallel for schedule(static)")                                                \
+        _Pragma("omp parallel for schedule(static) num_threads(pgs_threads(n))")                    \
         for (int i = 0; i < n; ++i) {                                                               \
             double* gi = &g[(size_t)i * 6];                                                         \
             double* hi = &Hd[(size_t)i * 36];                                                       \
@@ -1649,7 +1657,7 @@ int orc_pg_solve_sparse(orc_pg_problem* p, const orc_lm_options* opt, orc_lm_sum
             se3_Ad(rel, &Pm[(size_t)k * 36]);                                                       \
             if (p->node_fixed && p->node_fixed[k]) memset(&Pm[(size_t)k * 36], 0, sizeof(double) * 36); \
         }                                                                                           \
-        _Pragma("omp parallel for schedule(static)")                                                \
+        _Pragma("omp parallel for schedule(static) num_threads(pgs_threads(m))")                    \
         for (int e = 0; e < m; ++e) {                                                               \
             mat6_mul(&Ji[(size_t)e * 36], &Pm[(size_t)p->edge_i[e] * 36], &Gi[(size_t)e * 36]);     \
             mat6_mul(&Jj[(size_t)e * 36], &Pm[(size_t)p->edge_j[e] * 36], &Gj[(size_t)e * 36]);     \
@@ -1709,7 +1717,7 @@ int orc_pg_solve_sparse(orc_pg_problem* p, const orc_lm_options* opt, orc_lm_sum
                         for (int v = 0; v < 6; ++v) Ac[(size_t)(a0 + u) * nc + a0 + v] += P[c * 6 + u] * D[(size_t)k * 6 + c] * P[c * 6 + v];
             }
             for (int a = 0; a < nc; ++a) if (!(Ac[(size_t)a * nc + a] > 0.0)) Ac[(size_t)a * nc + a] = 1.0;   /* a group of constant nodes */
-            if (orc_cholesky_lower(Ac, nc, 8) != 0) ok = 0;
+            if (orc_cholesky_lower(Ac, nc, pgs_threads(nc * 4)) != 0) ok = 0;
             if (ok)
                 for (int a = 0; a < nc; ++a)
                     for (int b = 0; b <= a; ++b) Lt[(size_t)b * nc + a] = Ac[(size_t)a * nc + b];

@@ -70,7 +70,7 @@ EXPORTS = ["stba_status_string", "stba_last_error", "stba_version", "stba_device
            "stba_ba_triangulate", "stba_ba_time_linearize", "stba_ba_time_schur", "stba_cholesky_factor", "stba_cholesky_solve",
            "stba_cholesky_time", "stba_cholesky_time_split", "stba_cholesky_schedule_model", "stba_cholesky_timeout_count", "stba_cholesky_set_timeout_us", "stba_cholesky_shard_model", "stba_cholesky_shard_owner", "stba_cholesky_profile", "stba_calib_evaluate", "stba_calib_gauss_newton",
            "stba_pcg_default_options", "stba_pg_create", "stba_pg_destroy", "stba_pg_set_allreduce", "stba_pg_get_poses", "stba_pg_evaluate",
-           "stba_pg_solve", "stba_pg_time_kernels", "stba_dense_solve", "stba_corners_read", "stba_corners_write", "stba_zhang_init", "stba_two_view_init", "stba_odometry_read", "stba_odometry_write", "stba_trajectory_ate",
+           "stba_pg_solve", "stba_pg_last_pcg_summary", "stba_pg_time_kernels", "stba_dense_solve", "stba_corners_read", "stba_corners_write", "stba_zhang_init", "stba_two_view_init", "stba_odometry_read", "stba_odometry_write", "stba_trajectory_ate",
            "stba_comm_unique_id", "stba_comm_create", "stba_comm_destroy", "stba_comm_rank", "stba_comm_allreduce_sum",
            "stba_comm_allreduce_hook", "stba_ba_set_comm", "stba_pg_set_comm"]
 
@@ -288,7 +288,17 @@ class BAEngine:
 
 
 class PCGOptions(C.Structure):
-    _fields_ = [("max_iterations", C.c_int), ("relative_tolerance", C.c_double), ("check_every", C.c_int)]
+    _fields_ = [("max_iterations", C.c_int), ("relative_tolerance", C.c_double), ("check_every", C.c_int),
+                ("forcing_eta0", C.c_double), ("forcing_eta_min", C.c_double), ("coarse_group", C.c_int),
+                ("coarse_refresh_every", C.c_int)]
+
+
+class PCGSummary(C.Structure):
+    _fields_ = [("iterations_total", C.c_int), ("solves", C.c_int), ("hit_cap", C.c_int), ("max_iterations_in_a_solve", C.c_int),
+                ("coarse_dim", C.c_int), ("coarse_refreshes", C.c_int), ("last_eta", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
 
 
 class PGEngine:
@@ -339,11 +349,23 @@ class PGEngine:
         _chk(lib().stba_pg_time_kernels(self._h, int(reps), C.byref(a), C.byref(b)), "stba_pg_time_kernels")
         return a.value, b.value
 
+    def pcg_options(self, **kw):
+        pcg = PCGOptions()
+        lib().stba_pcg_default_options(C.byref(pcg))
+        for k, v in kw.items():
+            setattr(pcg, k, v)
+        return pcg
+
+    def pcg_summary(self):
+        """linear-solver side of the last solve(): PCG iterations, solves that hit the cap, coarse dimension, ..."""
+        out = PCGSummary()
+        _chk(lib().stba_pg_last_pcg_summary(self._h, C.byref(out)), "stba_pg_last_pcg_summary")
+        return out
+
     def solve(self, opt=None, pcg=None, **kw):
         opt = opt or default_options(**kw)
         if pcg is None:
-            pcg = PCGOptions()
-            lib().stba_pcg_default_options(C.byref(pcg))
+            pcg = self.pcg_options()
         trace = np.zeros((opt.max_num_iterations + 1, TRACE_COLS))
         summ = LMSummary()
         total = C.c_int()

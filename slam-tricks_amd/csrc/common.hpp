@@ -104,6 +104,10 @@ void chol_shard_model(int nblk, int n_gpus, int n_xcd, int wg_per_q, int rows_pe
 int chol_shard_row_owner(int row, int n_gpus, int rows_per_group);
 // fills the padding (identity) and the rhs row of a padded system
 int chol_prepare_padding_dev(double* A_dev, int lda, int n, const double* rhs_dev, hipStream_t st);
+// explicit inverse of a small SPD matrix (pose graph coarse operator): W = [A . ; I 0] (2 np x 2 np, np a multiple of 128)
+// -> lower right block = -A^-1 (lower triangle); dense_chol.hip
+size_t chol_spd_inverse_workspace_doubles(int np);
+int chol_spd_inverse_dev(double* W, int ldw, int np, int n_real, int* flag_dev, double* work, hipStream_t st);
 
 // ---- small device math ----------------------------------------------------------------------
 __host__ __device__ inline void quat_to_rot(const double q[4], double R[9]) {

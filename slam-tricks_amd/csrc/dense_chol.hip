@@ -2307,6 +2307,37 @@ static int chol_run(double* A, int lda, int n, double* x_dev, int* flag_dev, hip
     return STBA_OK;
 }
 
+// Explicit inverse of a small SPD matrix through a PARTIAL factorisation with the stage kernels (the pose graph's coarse
+// operator, pg_engine.hip: 6 unknowns per group of nodes, a few hundred to ~1500 in all; applied once per PCG iteration as
+// a dense product, so it is wanted explicitly).  W is ldw x ldw, ldw = 2 np, np a multiple of 128:
+//        [ A   . ]     panels 0 .. np/128 - 1 of the blocked right-looking      [ L       .     ]
+//        [ I   0 ]     factorisation, applied to ALL 2 np rows            ->    [ L^-T   -A^-1  ]
+// the panel solves turn the identity rows into X = I L^-T, and the trailing updates subtract X X^T = A^-1 from the lower
+// right block (lower triangle).  No factorisation of the lower right block follows, so it survives.
+// workspace: (NB NB + 8 256) doubles per panel (the diagonal tiles' inverses the panel solve multiplies by).
+size_t chol_spd_inverse_workspace_doubles(int np) { return (size_t)(np / NB) * ((size_t)NB * NB + 8 * 256); }
+int chol_spd_inverse_dev(double* W, int ldw, int np, int n_real, int* flag_dev, double* work, hipStream_t st) {
+    if (np % NB != 0 || ldw != 2 * np || np <= 0) return fail(STBA_ERR_INVALID_ARGUMENT, "chol_spd_inverse_dev: bad dimensions");
+    constexpr size_t LINV_STRIDE = (size_t)NB * NB + 8 * 256;
+    static DeviceOnce diag_attr;
+    STBA_TRY(diag_attr.run([]() -> int {
+        STBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(chol_diag_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Diag2Smem)));
+        return STBA_OK;
+    }));
+    STBA_HIP(hipMemsetAsync(flag_dev, 0, sizeof(int), st));
+    const int nblk = ldw / NB;
+    for (int b = 0; b < np / NB; ++b) {
+        double* li = work + (size_t)b * LINV_STRIDE;
+        const int mt = nblk - b - 1;
+        hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(512), sizeof(Diag2Smem), st, W, ldw, b * NB, n_real, flag_dev, li + NB * NB);
+        const int groups = mt * (NB / 16);
+        hipLaunchKernelGGL(chol_trsm_kernel, dim3(groups + NB / 16), dim3(64), 0, st, W, ldw, b * NB, groups, li, li + NB * NB);
+        launch_syrk(W, ldw, b * NB, 0, mt * (mt + 1) / 2, st);
+    }
+    STBA_HIP(hipGetLastError());
+    return STBA_OK;
+}
+
 int chol_factor_solve_dev(double* A, int lda, int n, double* x_dev, int* flag_dev, hipStream_t st) {
     return chol_run(A, lda, n, x_dev, flag_dev, st, nullptr);
 }

@@ -8,14 +8,28 @@
 //   Jacobians  d r/d delta_j = Jr^-1(r),  d r/d delta_i = -Jr^-1(r) Ad(T_j^-1 T_i),
 //              Jr^-1(r) = I + ad(r)/2 + ad(r)^2/12
 //   solver     Levenberg-Marquardt (same control flow as the BA engine); the damped normal equations
-//              (6 n_nodes unknowns, block-sparse) are solved matrix-free by block-Jacobi
-//              preconditioned conjugate gradients: every kernel is HBM/latency bound, no MFMA.
+//              (6 n_nodes unknowns, block-sparse) are solved matrix-free by preconditioned conjugate
+//              gradients as an INEXACT Newton step: the PCG stops at |r| <= eta |g| with a forcing
+//              sequence eta_k (Eisenstat-Walker), decided on the device.
+//   preconditioner (round 4)  M^-1 = blockdiag(H_ii + D_i)^-1 + P (P^T (J^T J + D) P)^-1 P^T: two levels, additive.
+//              The coarse space holds six rigid-body modes per GROUP of consecutive nodes (a stretch of
+//              the trajectory moved as one body): delta_k = Ad(T_k^-1 T_ref(group)) xi.  Block Jacobi alone
+//              leaves the long, smooth error modes of the chain (drift) to the Krylov iteration -- 939
+//              iterations to 1e-12 at C4, the cap of 1000 on every LM iteration in round 3; a block
+//              TRIDIAGONAL preconditioner (the odometry chain factored exactly) was measured first and
+//              hardly helps (812: its diagonal carries the loop closures' stiffness, which the smooth
+//              modes do not feel); the rigid-body coarse space cuts it to 67-109 (groups of 16-64
+//              nodes), and with the forcing sequence a C4 LM iteration takes ~24 PCG iterations.
+//              The coarse matrix (942 unknowns at C4) is inverted explicitly once per LM iteration
+//              (dense_chol.hip, chol_spd_inverse_dev: the only MFMA work of this engine) and applied
+//              as a dense product.
 //
 // Data in HBM: poses [n][7] (two copies), edges (i, j) int32, meas [m][7], r [m][6], Ji/Jj [36][m] (COMPONENT-major: entry k
 // of edge e at k m + e, so that the lanes of a wave -- consecutive edges -- read and write consecutive addresses; edge-major
 // [m][36] made every load instruction touch 64 cache lines: the matrix-free product took 24 us for 25 MB),
 // g [6n], Hd [n][36] (diagonal blocks), Minv [n][36], PCG vectors x r z p q [6n].
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <vector>
 
@@ -141,13 +155,26 @@ __device__ inline void block_sum2(double a, double b, double* out2) {
     if (threadIdx.x == 0) { out2[0] = s[0][0] + s[0][1] + s[0][2] + s[0][3]; out2[1] = s[1][0] + s[1][1] + s[1][2] + s[1][3]; }
 }
 
+// device-resident scalars of one PCG solve; every kernel of iteration k reads rz[k & 1], the direction kernel writes rz[(k + 1) & 1]
+struct PcgState {
+    double rz[2];
+    double rr0, rr, tol2;
+    int iters, done, hit_cap, ticks;
+};
+// what the host polls (mapped, coherent host memory; written by workgroup 0 of the direction kernel, ticks last)
+struct PcgExport {
+    double rr0, rr;
+    int iters, done, hit_cap, ticks;
+};
+
 // ---------------------------------------------------------------- kernels
 __global__ __launch_bounds__(256) void pg_linearize_kernel(int n_edges, const double* __restrict__ poses,
                                                            const int* __restrict__ ei, const int* __restrict__ ej,
                                                            const double* __restrict__ meas,
                                                            const unsigned char* __restrict__ fixed, int with_jac,
                                                            double* __restrict__ r, double* __restrict__ Ji,
-                                                           double* __restrict__ Jj, double* __restrict__ partial) {
+                                                           double* __restrict__ Jj, double* __restrict__ partial,
+                                                           double* __restrict__ contrib) {
     const int e = blockIdx.x * 256 + threadIdx.x;
     double c = 0.0;
     if (e < n_edges) {
@@ -159,7 +186,29 @@ __global__ __launch_bounds__(256) void pg_linearize_kernel(int n_edges, const do
         if (r) for (int k = 0; k < 6; ++k) r[(size_t)e * 6 + k] = re[k];
         if (with_jac) {
             const bool fi = fixed && fixed[i], fj = fixed && fixed[j];
-            for (int k = 0; k < 36; ++k) { Ji[(size_t)k * n_edges + e] = fi ? 0.0 : ji[k]; Jj[(size_t)k * n_edges + e] = fj ? 0.0 : jj[k]; }
+            for (int k = 0; k < 36; ++k) { ji[k] = fi ? 0.0 : ji[k]; jj[k] = fj ? 0.0 : jj[k]; Ji[(size_t)k * n_edges + e] = ji[k]; Jj[(size_t)k * n_edges + e] = jj[k]; }
+            // what this edge adds to its two nodes' gradient and diagonal block, 27 doubles per end {J^T r (6), upper triangle of J^T J (21)}:
+            // pg_gather_blocks_kernel sums a node's ends in a fixed order -- no atomics (the scatter with 42 FP64 atomics per edge
+            // end took 156 us per linearisation at C4, 9 % of an LM iteration; rocprofv3, profiles/r4_b_c4_kernel_stats.csv)
+            if (contrib) {
+                for (int side = 0; side < 2; ++side) {
+                    const double* J = side ? jj : ji;
+                    double* out = contrib + ((size_t)e * 2 + side) * 28;
+                    int w = 0;
+                    for (int a = 0; a < 6; ++a) {
+                        double sg = 0.0;
+                        for (int k = 0; k < 6; ++k) sg += J[k * 6 + a] * re[k];
+                        out[w++] = sg;
+                    }
+                    for (int a = 0; a < 6; ++a)
+                        for (int b = a; b < 6; ++b) {
+                            double h = 0.0;
+                            for (int k = 0; k < 6; ++k) h += J[k * 6 + a] * J[k * 6 + b];
+                            out[w++] = h;
+                        }
+                    out[27] = 0.0;
+                }
+            }
         }
     }
     double out2[2];
@@ -289,70 +338,6 @@ __device__ inline double sum_partials_dev(const double* partial, int nb, int str
     return s_tot;
 }
 
-// scal: [0] rz, [1] rr, [2] pq   (device-resident PCG scalars)
-// init: r = b (b = -g), x = 0, z = M r, p = z; partial -> rz, rr
-__global__ __launch_bounds__(256) void pg_pcg_init_kernel(int n_nodes, const double* __restrict__ g, const double* __restrict__ Minv,
-                                                          double* __restrict__ x, double* __restrict__ r, double* __restrict__ z,
-                                                          double* __restrict__ p, double* __restrict__ partial) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    double a = 0.0, b = 0.0;
-    if (i < n_nodes) {
-        double rl[6];
-        for (int k = 0; k < 6; ++k) { rl[k] = -g[(size_t)i * 6 + k]; r[(size_t)i * 6 + k] = rl[k]; x[(size_t)i * 6 + k] = 0.0; }
-        for (int k = 0; k < 6; ++k) {
-            double s = 0.0;
-            for (int m = 0; m < 6; ++m) s += Minv[(size_t)i * 36 + k * 6 + m] * rl[m];
-            z[(size_t)i * 6 + k] = s; p[(size_t)i * 6 + k] = s;
-            a += rl[k] * s; b += rl[k] * rl[k];
-        }
-    }
-    double out2[2];
-    block_sum2(a, b, out2);
-    if (threadIdx.x == 0) { partial[blockIdx.x * 2] = out2[0]; partial[blockIdx.x * 2 + 1] = out2[1]; }
-}
-
-// alpha = rz / pq; x += alpha p; r -= alpha q; z = M r; partial -> rz_new, rr
-__global__ __launch_bounds__(256) void pg_pcg_update_kernel(int n_nodes, int nb_rz, const double* __restrict__ part_rz,
-                                                            int nb_pq, const double* __restrict__ part_pq,
-                                                            const double* __restrict__ Minv,
-                                                            const double* __restrict__ p, const double* __restrict__ q,
-                                                            double* __restrict__ x, double* __restrict__ r, double* __restrict__ z,
-                                                            double* __restrict__ part_out) {
-    const double rz = sum_partials_dev(part_rz, nb_rz, 2, 0);
-    const double pq = sum_partials_dev(part_pq, nb_pq, 2, 0);
-    const double alpha = (pq > 0.0) ? rz / pq : 0.0;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    double a = 0.0, b = 0.0;
-    if (i < n_nodes) {
-        double rl[6];
-        for (int k = 0; k < 6; ++k) {
-            const size_t o = (size_t)i * 6 + k;
-            x[o] += alpha * p[o];
-            rl[k] = r[o] - alpha * q[o];
-            r[o] = rl[k];
-        }
-        for (int k = 0; k < 6; ++k) {
-            double s = 0.0;
-            for (int m = 0; m < 6; ++m) s += Minv[(size_t)i * 36 + k * 6 + m] * rl[m];
-            z[(size_t)i * 6 + k] = s;
-            a += rl[k] * s; b += rl[k] * rl[k];
-        }
-    }
-    double out2[2];
-    block_sum2(a, b, out2);
-    if (threadIdx.x == 0) { part_out[blockIdx.x * 2] = out2[0]; part_out[blockIdx.x * 2 + 1] = out2[1]; }
-}
-
-// beta = rz_new / rz_old; p = z + beta p
-__global__ __launch_bounds__(256) void pg_pcg_dir_kernel(int n, int nb, const double* __restrict__ part_new,
-                                                         const double* __restrict__ part_old, const double* __restrict__ z,
-                                                         double* __restrict__ p) {
-    const double rzn = sum_partials_dev(part_new, nb, 2, 0), rzo = sum_partials_dev(part_old, nb, 2, 0);
-    const double beta = (rzo > 0.0) ? rzn / rzo : 0.0;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) p[i] = z[i] + beta * p[i];
-}
-
 // ---------------------------------------------------------------- one rank: a PCG iteration in THREE launches, no atomics
 // (1) p^T q = p^T D p + |J p|^2 = sum_i d_i p_i^2 + sum_e |t_e|^2 with t_e = J_e [p_i; p_j]: the dot product needs no pass over
 //     the finished q -- the edge kernel adds up |t_e|^2, the kernel that makes the direction p adds up d p^2.
@@ -372,7 +357,8 @@ __global__ __launch_bounds__(256) void pg_pcg_dir_kernel(int n, int nb, const do
 __global__ __launch_bounds__(256) void pg_edge_product_kernel(int n_edges, const int* __restrict__ ei, const int* __restrict__ ej,
                                                               const double* __restrict__ Ji, const double* __restrict__ Jj,
                                                               const double* __restrict__ p, double* __restrict__ u,
-                                                              double* __restrict__ part_tt) {
+                                                              double* __restrict__ part_tt, const PcgState* __restrict__ state) {
+    if (state && state->done) return;          // (the solve has converged: see pg_pcg_dir4_kernel)
     const int e = blockIdx.x * 256 + threadIdx.x;
     double tt2 = 0.0;
     if (e < n_edges) {
@@ -387,90 +373,547 @@ __global__ __launch_bounds__(256) void pg_edge_product_kernel(int n_edges, const
             t[a] = s;
             tt2 += s * s;
         }
+        // u edge-major, 12 doubles per edge (i-side | j-side): the node kernel's gather then reads 48 contiguous bytes per edge end
+        // (component-major u -- better for these stores -- made it six scattered 8-byte loads per end: 14 us for the node kernel)
+        double ue[12];
         for (int k = 0; k < 6; ++k) {
             double si = 0.0, sj = 0.0;
             for (int a = 0; a < 6; ++a) { si += A[a * 6 + k] * t[a]; sj += B[a * 6 + k] * t[a]; }
-            u[(size_t)k * n_edges + e] = si;
-            u[(size_t)(6 + k) * n_edges + e] = sj;
+            ue[k] = si; ue[6 + k] = sj;
         }
+        double2* dst = reinterpret_cast<double2*>(u + (size_t)e * 12);
+        for (int k = 0; k < 6; ++k) dst[k] = make_double2(ue[2 * k], ue[2 * k + 1]);
     }
     double out2[2];
     block_sum2(tt2, 0.0, out2);
     if (threadIdx.x == 0) { part_tt[blockIdx.x * 2] = out2[0]; part_tt[blockIdx.x * 2 + 1] = 0.0; }
 }
 
-// q_i = d_i p_i + sum_ends u;  alpha = rz / (sum |t|^2 + sum d p^2);  x += alpha p;  r -= alpha q;  z = M r;  partial -> rz_new, rr
-__global__ __launch_bounds__(256) void pg_pcg_update3_kernel(int n_nodes, int n_edges, int nb_rz, const double* __restrict__ part_rz,
-                                                             int nb_tt, const double* __restrict__ part_tt, int nb_dp,
-                                                             const double* __restrict__ part_dp, const double* __restrict__ Minv,
-                                                             const double* __restrict__ d, const int* __restrict__ node_start,
-                                                             const int* __restrict__ end_code, const double* __restrict__ u,
-                                                             const double* __restrict__ p, double* __restrict__ x, double* __restrict__ r,
-                                                             double* __restrict__ z, double* __restrict__ part_out) {
-    const double rz = sum_partials_dev(part_rz, nb_rz, 2, 0);
-    const double pq = sum_partials_dev(part_tt, nb_tt, 2, 0) + sum_partials_dev(part_dp, nb_dp, 2, 0);
+// ================================================================= round 4: two-level preconditioner, device-side PCG control
+constexpr int PG_NT = 1024;             // node kernels of the PCG: 1024 threads = 128 nodes x 8 lanes
+constexpr int PG_NPW = PG_NT / 8;       // nodes per workgroup
+
+// sum of nb per-workgroup partials by a workgroup of NT threads, fixed order (same bits in every workgroup and on every rank)
+template <int NT>
+__device__ inline double sum_partials_n(const double* partial, int nb, int stride, int off) {
+    __shared__ double s_w[NT / 64];
+    __shared__ double s_tot;
+    double v = 0.0;
+    for (int k = threadIdx.x; k < nb; k += NT) v += partial[k * stride + off];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) { double t = 0.0; for (int w = 0; w < NT / 64; ++w) t += s_w[w]; s_tot = t; }
+    __syncthreads();
+    return s_tot;
+}
+template <int NT>
+__device__ inline void block_sum2_n(double a, double b, double* out2) {
+    __shared__ double s[2][NT / 64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off, 64); b += __shfl_down(b, off, 64); }
+    __syncthreads();
+    if (lane == 0) { s[0][w] = a; s[1][w] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double x = 0.0, y = 0.0;
+        for (int k = 0; k < NT / 64; ++k) { x += s[0][k]; y += s[1][k]; }
+        out2[0] = x; out2[1] = y;
+    }
+}
+
+// gradient and diagonal blocks of a node = sum over its edge ends of the 27 doubles the linearise kernel left per end (fixed order: no
+// atomics, same bits every run).  Eight lanes per node, one end each per trip, a butterfly over the eight lanes.
+__global__ __launch_bounds__(PG_NT) void pg_gather_blocks_kernel(int n, const int* __restrict__ node_start, const int* __restrict__ end_code,
+                                                                const double* __restrict__ contrib, double* __restrict__ g, double* __restrict__ Hd) {
+    const int t = threadIdx.x, nl = t >> 3, k = t & 7;
+    const int node = blockIdx.x * PG_NPW + nl;
+    double acc[27];
+    for (int q = 0; q < 27; ++q) acc[q] = 0.0;
+    if (node < n) {
+        const int e1 = node_start[node + 1];
+        for (int c = node_start[node] + k; c < e1; c += 8) {
+            const double2* src = reinterpret_cast<const double2*>(contrib + (size_t)end_code[c] * 28);
+            for (int q = 0; q < 13; ++q) { const double2 v = src[q]; acc[2 * q] += v.x; acc[2 * q + 1] += v.y; }
+            acc[26] += src[13].x;
+        }
+    }
+    for (int q = 0; q < 27; ++q) {
+        acc[q] += __shfl_xor(acc[q], 1, 8);
+        acc[q] += __shfl_xor(acc[q], 2, 8);
+        acc[q] += __shfl_xor(acc[q], 4, 8);
+    }
+    if (node < n && k < 6) {
+        // row k of the symmetric block from the packed upper triangle: entry (a, b), a <= b, at 6 + a (13 - a) / 2 + (b - a)
+        double gk = 0.0, row[6];
+        for (int a = 0; a < 6; ++a) if (a == k) gk = acc[a];
+        for (int b = 0; b < 6; ++b) {
+            double v = 0.0;
+            for (int a = 0; a < 6; ++a) {
+                const int lo = a < b ? a : b, hi = a < b ? b : a;
+                if (a == k) v = acc[6 + lo * (13 - lo) / 2 + (hi - lo)];
+            }
+            row[b] = v;
+        }
+        g[(size_t)node * 6 + k] = gk;
+        for (int b = 0; b < 6; ++b) Hd[(size_t)node * 36 + k * 6 + b] = row[b];
+    }
+}
+
+// |g|^2 and |g|_inf as per-workgroup partials {sum, max} (behind the cross-rank sum of g when there are several ranks)
+__global__ __launch_bounds__(256) void pg_gnorm_kernel(int N, const double* __restrict__ g, double* __restrict__ part) {
+    __shared__ double sm[4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const double v = i < N ? g[i] : 0.0;
+    double s = v * v, mx = fabs(v);
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_down(s, o, 64); mx = fmax(mx, __shfl_down(mx, o, 64)); }
+    __shared__ double ss[4];
+    if ((threadIdx.x & 63) == 0) { ss[threadIdx.x >> 6] = s; sm[threadIdx.x >> 6] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) { part[blockIdx.x * 2] = (ss[0] + ss[1]) + (ss[2] + ss[3]); part[blockIdx.x * 2 + 1] = fmax(fmax(sm[0], sm[1]), fmax(sm[2], sm[3])); }
+}
+
+// damping term of the coarse matrix: Dc[group] = sum over the group's nodes of P_k^T diag(d_k) P_k (6 x 6), one workgroup per group
+__global__ __launch_bounds__(256) void pg_coarse_dc_kernel(int n, int agg, const double* __restrict__ AdP, const double* __restrict__ d,
+                                                           double* __restrict__ Dc) {
+    __shared__ double sw[4][36];
+    const int a = blockIdx.x, t = threadIdx.x;
+    const int k0 = a * agg, k1 = min(n, k0 + agg);
+    double acc[36];
+    for (int q = 0; q < 36; ++q) acc[q] = 0.0;
+    for (int item = t; item < (k1 - k0) * 6; item += 256) {          // (node, tangent component)
+        const int k = k0 + item / 6, c = item % 6;
+        const double dv = d[(size_t)k * 6 + c];
+        double row[6];
+        for (int u = 0; u < 6; ++u) row[u] = AdP[(size_t)k * 36 + c * 6 + u];
+        for (int u = 0; u < 6; ++u)
+            for (int w = 0; w < 6; ++w) acc[u * 6 + w] += row[u] * dv * row[w];
+    }
+    for (int q = 0; q < 36; ++q) {
+        double v = acc[q];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+        if ((t & 63) == 0) sw[t >> 6][q] = v;
+    }
+    __syncthreads();
+    if (t < 36) Dc[(size_t)a * 36 + t] = (sw[0][t] + sw[1][t]) + (sw[2][t] + sw[3][t]);
+}
+
+// coarse basis: P_k = Ad(T_k^-1 T_ref), T_ref = the pose in the middle of the node's group; zero for constant nodes.
+// Ad(R, t) = [[R, hat(t) R], [0, R]] for the tangent order [rho, theta] (st23-lie-group-v2/doc.tex:945-963)
+__global__ __launch_bounds__(256) void pg_coarse_basis_kernel(int n, int agg, const double* __restrict__ poses,
+                                                              const unsigned char* __restrict__ fixed, double* __restrict__ AdP) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    double M[36];
+    for (int q = 0; q < 36; ++q) M[q] = 0.0;
+    if (!(fixed && fixed[k])) {
+        const int ref = min((k / agg) * agg + agg / 2, n - 1);
+        double Tk[7], Tr[7], Tki[7], rel[7], R[9], Hh[9];
+        for (int q = 0; q < 7; ++q) { Tk[q] = poses[(size_t)k * 7 + q]; Tr[q] = poses[(size_t)ref * 7 + q]; }
+        se3_inverse(Tk, Tki);
+        se3_compose(Tki, Tr, rel);
+        quat_to_rot(rel, R);
+        hat3d(rel + 4, Hh);
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                double s = 0.0;
+                for (int q = 0; q < 3; ++q) s += Hh[i * 3 + q] * R[q * 3 + j];
+                M[i * 6 + j] = R[i * 3 + j]; M[i * 6 + 3 + j] = s; M[(3 + i) * 6 + 3 + j] = R[i * 3 + j];
+            }
+    }
+    for (int q = 0; q < 36; ++q) AdP[(size_t)k * 36 + q] = M[q];
+}
+
+// Galerkin coarse matrix without the damping term, Ac0 = P^T J^T J P (nc x nc, dense): one workgroup per group of nodes
+// = six rows of Ac0.  Every edge END of the group's nodes is one work item: with G_s = J_self P_self, G_o = J_other P_other
+// it adds G_s^T G_s to the diagonal block and G_s^T G_o to block (group, group of the other node) -- the other end does the
+// same from its side, so the four blocks of an edge are all made and no workgroup writes another one's rows.  The row panel
+// is accumulated in LDS (ds_add_f64; the diagonal block, which every item adds to, as register sums + a shuffle tree first)
+// and written once, zeros included: no global atomics, no memset.
+__global__ __launch_bounds__(256) void pg_coarse_build_kernel(int n, int m, int agg, int nc, const int* __restrict__ node_start,
+                                                              const int* __restrict__ end_code, const int* __restrict__ end_node,
+                                                              const int* __restrict__ ei, const int* __restrict__ ej,
+                                                              const double* __restrict__ Ji, const double* __restrict__ Jj,
+                                                              const double* __restrict__ AdP, double* __restrict__ Ac0) {
+    extern __shared__ double rowp[];            // [6][nc]
+    const int a = blockIdx.x, t = threadIdx.x;
+    for (int q = t; q < 6 * nc; q += 256) rowp[q] = 0.0;
+    __syncthreads();
+    const int k0 = a * agg, k1 = min(n, k0 + agg);
+    const int c0 = node_start[k0], c1 = node_start[k1];
+    double dg[36];
+    for (int q = 0; q < 36; ++q) dg[q] = 0.0;
+    for (int c = c0 + t; c < c1; c += 256) {
+        const int self = end_node[c], code = end_code[c], e = code >> 1, side = code & 1;
+        const int other = side ? ei[e] : ej[e];
+        const double* Js = (side ? Jj : Ji) + e;
+        const double* Jo = (side ? Ji : Jj) + e;
+        double Gs[36], Go[36];
+        {
+            double J[36], P[36];
+            for (int q = 0; q < 36; ++q) { J[q] = Js[(size_t)q * m]; P[q] = AdP[(size_t)self * 36 + q]; }
+            for (int i = 0; i < 6; ++i)
+                for (int j = 0; j < 6; ++j) {
+                    double s = 0.0;
+                    for (int q = 0; q < 6; ++q) s += J[i * 6 + q] * P[q * 6 + j];
+                    Gs[i * 6 + j] = s;
+                }
+            for (int q = 0; q < 36; ++q) { J[q] = Jo[(size_t)q * m]; P[q] = AdP[(size_t)other * 36 + q]; }
+            for (int i = 0; i < 6; ++i)
+                for (int j = 0; j < 6; ++j) {
+                    double s = 0.0;
+                    for (int q = 0; q < 6; ++q) s += J[i * 6 + q] * P[q * 6 + j];
+                    Go[i * 6 + j] = s;
+                }
+        }
+        const int ao = other / agg;
+        for (int u = 0; u < 6; ++u)
+            for (int v = 0; v < 6; ++v) {
+                double ss = 0.0, so = 0.0;
+                for (int q = 0; q < 6; ++q) { ss += Gs[q * 6 + u] * Gs[q * 6 + v]; so += Gs[q * 6 + u] * Go[q * 6 + v]; }
+                dg[u * 6 + v] += ss;
+                if (ao == a) dg[u * 6 + v] += so;
+                else unsafeAtomicAdd(&rowp[u * nc + 6 * ao + v], so);
+            }
+    }
+    for (int q = 0; q < 36; ++q) {
+        double v = dg[q];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+        if ((t & 63) == 0) unsafeAtomicAdd(&rowp[(q / 6) * nc + 6 * a + (q % 6)], v);
+    }
+    __syncthreads();
+    for (int q = t; q < 6 * nc; q += 256) Ac0[(size_t)(6 * a + q / nc) * nc + (q % nc)] = rowp[q];
+}
+
+// the inversion workspace of an LM iteration: W = [Ac0 + P^T D P (identity-padded to np) | . ; I | 0], see chol_spd_inverse_dev
+__global__ __launch_bounds__(256) void pg_coarse_assemble_kernel(int nc, int np, const double* __restrict__ Ac0,
+                                                                 const double* __restrict__ Dc, double* __restrict__ W) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t per = (size_t)np * np;
+    if (idx >= 3 * per) return;
+    const int quad = (int)(idx / per);
+    const int r = (int)((idx % per) / np), c = (int)(idx % np);
+    const size_t ldw = 2 * (size_t)np;
+    if (quad == 1) { W[(np + r) * ldw + c] = (r == c) ? 1.0 : 0.0; return; }
+    if (quad == 2) { W[(np + r) * ldw + np + c] = 0.0; return; }
+    double v = (r == c) ? 1.0 : 0.0;
+    if (r < nc && c < nc) {
+        v = Ac0[(size_t)r * nc + c];
+        if (r / 6 == c / 6) {
+            v += Dc[(size_t)(r / 6) * 36 + (r % 6) * 6 + (c % 6)];
+            if (r == c && !(v > 0.0)) v = 1.0;          // a group of constant nodes
+        }
+    }
+    W[r * ldw + c] = v;
+}
+
+// Ainv = -(lower right block of W), symmetric, full
+__global__ __launch_bounds__(256) void pg_coarse_finish_kernel(int nc, int np, const double* __restrict__ W, double* __restrict__ Ainv) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)nc * nc) return;
+    const int r = (int)(idx / nc), c = (int)(idx % nc);
+    const int hi = max(r, c), lo = min(r, c);
+    Ainv[idx] = -W[((size_t)np + hi) * (2 * (size_t)np) + np + lo];
+}
+
+// restriction of a workgroup's 128 nodes: w[node][u] = (P_node^T r_node)[u] sits in LDS; the groups that END in this
+// workgroup's range are summed serially in node order (fixed order: same bits everywhere).  Groups of up to 128 nodes lie
+// inside one workgroup (128 % agg == 0); larger ones (agg = 256, 512, ...) span agg / 128 workgroups, each of which writes
+// its own partial row of rc_part -- the coarse kernel adds the parts in order.
+__device__ inline void pg_restrict_store(const double (*wsm)[6], int n, int agg, int node0, double* __restrict__ rc_part) {
+    const int t = threadIdx.x;
+    if (agg <= PG_NPW) {
+        const int ng = PG_NPW / agg;
+        if (t < 6 * ng) {
+            const int gl = t / 6, u = t % 6;
+            const int kb = gl * agg;
+            if (node0 + kb < n) {
+                double s = 0.0;
+                for (int k = 0; k < agg && node0 + kb + k < n; ++k) s += wsm[kb + k][u];
+                rc_part[(size_t)((node0 + kb) / agg) * 6 + u] = s;
+            }
+        }
+    } else if (t < 6) {
+        double s = 0.0;
+        for (int k = 0; k < PG_NPW && node0 + k < n; ++k) s += wsm[k][t];
+        rc_part[(size_t)(node0 / PG_NPW) * 6 + t] = s;
+    }
+}
+
+// PCG start: r = -g, x = 0, z0 = Minv r (into z), restriction of r; partial -> {r.z0, r.r}
+__global__ __launch_bounds__(PG_NT) void pg_pcg_init4_kernel(int n, int agg, const double* __restrict__ g, const double* __restrict__ Minv,
+                                                            const double* __restrict__ AdP, double* __restrict__ x, double* __restrict__ r,
+                                                            double* __restrict__ z, double* __restrict__ rc_part, double* __restrict__ part) {
+    __shared__ double wsm[PG_NPW][6];
+    const int t = threadIdx.x, nl = t >> 3, k = t & 7;
+    const int node0 = blockIdx.x * PG_NPW, node = node0 + nl;
+    double a = 0.0, b = 0.0;
+    if (node < n && k < 6) {
+        double rl[6];
+        for (int q = 0; q < 6; ++q) rl[q] = -g[(size_t)node * 6 + q];
+        double z0 = 0.0, w = 0.0;
+        for (int q = 0; q < 6; ++q) { z0 += Minv[(size_t)node * 36 + k * 6 + q] * rl[q]; if (AdP) w += AdP[(size_t)node * 36 + q * 6 + k] * rl[q]; }
+        r[(size_t)node * 6 + k] = rl[k]; x[(size_t)node * 6 + k] = 0.0; z[(size_t)node * 6 + k] = z0;
+        wsm[nl][k] = w;
+        a = rl[k] * z0; b = rl[k] * rl[k];
+    }
+    __syncthreads();
+    if (AdP) pg_restrict_store(wsm, n, agg, node0, rc_part);
+    double out2[2];
+    block_sum2_n<PG_NT>(a, b, out2);
+    if (t == 0) { part[blockIdx.x * 2] = out2[0]; part[blockIdx.x * 2 + 1] = out2[1]; }
+}
+
+// one PCG step on the nodes: q (GATHERED from the edge kernel's u on one rank, read from the all-reduced product with several),
+// alpha = rz / p.q, x += alpha p, r -= alpha q, z0 = Minv r, restriction; partial -> {r.z0, r.r}.  Eight lanes per node: lane j takes
+// the node's edge ends j, j + 8, ... (all loads of the gather in flight at once -- one lane per node walking its ends was a
+// chain of dependent round trips, 19 us for 10 000 nodes in round 3), the six components are summed over the lanes with a
+// butterfly, lanes 0..5 then own one component each.
+template <bool GATHER>
+__global__ __launch_bounds__(PG_NT) void pg_pcg_update4_kernel(int n, int m, int agg, int slot, const PcgState* __restrict__ state,
+                                                              int nb_a, const double* __restrict__ part_a, int nb_b,
+                                                              const double* __restrict__ part_b, const double* __restrict__ Minv,
+                                                              const double* __restrict__ AdP, const double* __restrict__ d,
+                                                              const int* __restrict__ node_start, const int* __restrict__ end_code,
+                                                              const double* __restrict__ u, const double* __restrict__ qin,
+                                                              const double* __restrict__ p, double* __restrict__ x, double* __restrict__ r,
+                                                              double* __restrict__ z, double* __restrict__ rc_part, double* __restrict__ part_out) {
+    __shared__ double wsm[PG_NPW][6];
+    __shared__ double s_red[2][PG_NT / 64];
+    const int t = threadIdx.x, nl = t >> 3, k = t & 7;
+    const int node0 = blockIdx.x * PG_NPW, node = node0 + nl;
+    // Everything that does not depend on alpha is REQUESTED first, in one go: the kernel is a chain of memory round trips
+    // (~1 us each on a machine this empty), and in program order -- state, partial sums, CSR, edge products, vectors, blocks --
+    // it took 14 us for 10 000 nodes.  The `done` flag is looked at only after the requests are out.
+    const int done = state->done;
+    const double rz = state->rz[slot];
+    double pa = 0.0, pb = 0.0;
+    for (int q = t; q < nb_a; q += PG_NT) pa += part_a[q * 2];
+    if (part_b) for (int q = t; q < nb_b; q += PG_NT) pb += part_b[q * 2];
+    double ql[6] = {0, 0, 0, 0, 0, 0};
+    double pk = 0.0, rk = 0.0, dk = 0.0, xk = 0.0, mrow[6] = {0, 0, 0, 0, 0, 0}, pcol[6] = {0, 0, 0, 0, 0, 0};
+    const bool act = node < n && k < 6;
+    const size_t o = (size_t)node * 6 + k;
+    if (act) {
+        pk = p[o]; rk = r[o]; xk = x[o];
+        if (GATHER) dk = d[o]; else dk = qin[o];
+        for (int q = 0; q < 6; ++q) mrow[q] = Minv[(size_t)node * 36 + k * 6 + q];
+        if (AdP) for (int q = 0; q < 6; ++q) pcol[q] = AdP[(size_t)node * 36 + q * 6 + k];
+    }
+    if (GATHER && node < n) {
+        const int e1 = node_start[node + 1];
+        for (int c = node_start[node] + k; c < e1; c += 8) {
+            const int code = end_code[c];                              // = 2 e + side: the end's six doubles start at u + 6 code
+            const double2* ue = reinterpret_cast<const double2*>(u + (size_t)code * 6);
+            const double2 a0 = ue[0], a1 = ue[1], a2 = ue[2];
+            ql[0] += a0.x; ql[1] += a0.y; ql[2] += a1.x; ql[3] += a1.y; ql[4] += a2.x; ql[5] += a2.y;
+        }
+    }
+    if (done) return;
+    // p.q: one rank: sum |t_e|^2 (edge kernel) + sum d p^2 (direction kernel); several: the dot-product kernel's partials.
+    // Fixed order: every workgroup (and every rank) gets the same bits.
+    for (int off = 32; off > 0; off >>= 1) { pa += __shfl_down(pa, off, 64); pb += __shfl_down(pb, off, 64); }
+    if ((t & 63) == 0) { s_red[0][t >> 6] = pa; s_red[1][t >> 6] = pb; }
+    __syncthreads();
+    double pq = 0.0, pq2 = 0.0;
+    for (int w = 0; w < PG_NT / 64; ++w) { pq += s_red[0][w]; pq2 += s_red[1][w]; }
+    pq += pq2;
     const double alpha = (pq > 0.0) ? rz / pq : 0.0;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    double a = 0.0, b = 0.0;
-    if (i < n_nodes) {
-        double ql[6], pl[6], rl[6];
-        for (int k = 0; k < 6; ++k) { pl[k] = p[(size_t)i * 6 + k]; ql[k] = d[(size_t)i * 6 + k] * pl[k]; }
-        const int e1 = node_start[i + 1];
-        for (int c = node_start[i]; c < e1; ++c) {
-            const int code = end_code[c], e = code >> 1, side = code & 1;
-            const double* ue = u + (size_t)(6 * side) * n_edges + e;
-            for (int k = 0; k < 6; ++k) ql[k] += ue[(size_t)k * n_edges];
-        }
-        for (int k = 0; k < 6; ++k) {
-            const size_t o = (size_t)i * 6 + k;
-            x[o] += alpha * pl[k];
-            rl[k] = r[o] - alpha * ql[k];
-            r[o] = rl[k];
-        }
-        for (int k = 0; k < 6; ++k) {
-            double s = 0.0;
-            for (int m = 0; m < 6; ++m) s += Minv[(size_t)i * 36 + k * 6 + m] * rl[m];
-            z[(size_t)i * 6 + k] = s;
-            a += rl[k] * s; b += rl[k] * rl[k];
+    if (GATHER) {
+        for (int q = 0; q < 6; ++q) {
+            ql[q] += __shfl_xor(ql[q], 1, 8);
+            ql[q] += __shfl_xor(ql[q], 2, 8);
+            ql[q] += __shfl_xor(ql[q], 4, 8);
         }
     }
+    if (act) {
+        double qk;
+        if (GATHER) {
+            qk = ql[0];
+            if (k == 1) qk = ql[1]; else if (k == 2) qk = ql[2]; else if (k == 3) qk = ql[3]; else if (k == 4) qk = ql[4]; else if (k == 5) qk = ql[5];
+            qk += dk * pk;
+        } else qk = dk;
+        x[o] = xk + alpha * pk;
+        rk = rk - alpha * qk;
+        r[o] = rk;
+    } else rk = 0.0;
+    double rl[6];
+    for (int q = 0; q < 6; ++q) rl[q] = __shfl(rk, q, 8);
+    double a = 0.0, b = 0.0;
+    if (act) {
+        double z0 = 0.0, w = 0.0;
+        for (int q = 0; q < 6; ++q) { z0 += mrow[q] * rl[q]; w += pcol[q] * rl[q]; }
+        z[o] = z0;
+        wsm[nl][k] = w;
+        a = rk * z0; b = rk * rk;
+    }
+    __syncthreads();
+    if (AdP) pg_restrict_store(wsm, n, agg, node0, rc_part);
     double out2[2];
-    block_sum2(a, b, out2);
-    if (threadIdx.x == 0) { part_out[blockIdx.x * 2] = out2[0]; part_out[blockIdx.x * 2 + 1] = out2[1]; }
+    block_sum2_n<PG_NT>(a, b, out2);
+    if (t == 0) { part_out[blockIdx.x * 2] = out2[0]; part_out[blockIdx.x * 2 + 1] = out2[1]; }
 }
 
-// beta = rz_new / rz_old (first: p = z); p = z + beta p; partial -> sum d p^2
-__global__ __launch_bounds__(256) void pg_pcg_dir3_kernel(int n, int nb, const double* __restrict__ part_new,
-                                                          const double* __restrict__ part_old, int first, const double* __restrict__ z,
-                                                          const double* __restrict__ d, double* __restrict__ p, double* __restrict__ part_dp) {
-    double beta = 0.0;
-    if (!first) {
-        const double rzn = sum_partials_dev(part_new, nb, 2, 0), rzo = sum_partials_dev(part_old, nb, 2, 0);
-        beta = (rzo > 0.0) ? rzn / rzo : 0.0;
+// coarse correction: zc = Ainv rc (one wave per row; rc = the parts of its group added in order); partial -> rc.zc
+__global__ __launch_bounds__(256) void pg_coarse_solve_kernel(int nc, int parts, const PcgState* __restrict__ state, const double* __restrict__ Ainv,
+                                                              const double* __restrict__ rc_part, double* __restrict__ zc,
+                                                              double* __restrict__ part_cz) {
+    __shared__ double sw[4];
+    const int done = state ? state->done : 0;           // (looked at below, behind the row's first loads)
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + w;
+    auto rc = [&](int c) {
+        const int a = c / 6, u = c % 6;
+        double s = 0.0;
+        for (int j = 0; j < parts; ++j) s += rc_part[(size_t)(a * parts + j) * 6 + u];
+        return s;
+    };
+    double acc = 0.0;
+    if (row < nc)
+        for (int c = lane; c < nc; c += 64) acc += Ainv[(size_t)row * nc + c] * rc(c);
+    if (done) return;
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if (lane == 0) {
+        double prod = 0.0;
+        if (row < nc) { zc[row] = acc; prod = rc(row) * acc; }
+        sw[w] = prod;
     }
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    __syncthreads();
+    if (threadIdx.x == 0) { part_cz[blockIdx.x * 2] = (sw[0] + sw[1]) + (sw[2] + sw[3]); part_cz[blockIdx.x * 2 + 1] = 0.0; }
+}
+
+// z = z0 + P zc; rz_new = sum r.z0 + rc.zc; beta = rz_new / rz_old (first: p = z); p = z + beta p; partial -> sum d p^2.
+// Workgroup 0 also keeps the books of the solve: rz for the next iteration, the iteration count, and the STOPPING TEST
+// |r|^2 <= eta^2 |b|^2 (or the iteration cap) -- once `done` is set every later kernel of the solve returns at once, so the
+// host can enqueue iterations ahead of what it knows (it polls the exported block in mapped memory).
+__global__ __launch_bounds__(PG_NT) void pg_pcg_dir4_kernel(int n, int agg, int slot, int first, double eta, int max_iters, PcgState* __restrict__ state,
+                                                           PcgExport* __restrict__ exp_, int nb_rz, const double* __restrict__ part_rz, int nb_cz,
+                                                           const double* __restrict__ part_cz, const double* __restrict__ AdP,
+                                                           const double* __restrict__ zc, const double* __restrict__ z, const double* __restrict__ d,
+                                                           double* __restrict__ p, double* __restrict__ part_dp) {
+    __shared__ double s_red[3][PG_NT / 64];
+    const int t = threadIdx.x;
+    // (as in the update kernel: every load that does not depend on beta is requested before anything is waited for)
+    const int was_done = first ? 0 : state->done;
+    const double rzo = first ? 1.0 : state->rz[slot];
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    for (int q = t; q < nb_rz; q += PG_NT) { s0 += part_rz[q * 2]; s2 += part_rz[q * 2 + 1]; }
+    if (part_cz) for (int q = t; q < nb_cz; q += PG_NT) s1 += part_cz[q * 2];
+    const int nl = t >> 3, k = t & 7;
+    const int node = blockIdx.x * PG_NPW + nl;
+    const bool act = node < n && k < 6;
+    const size_t o = (size_t)node * 6 + k;
+    double zk = 0.0, pold = 0.0, dk = 0.0;
+    if (act) {
+        zk = z[o]; dk = d[o];
+        if (!first) pold = p[o];
+        if (AdP) {
+            const int a = node / agg;
+            for (int q = 0; q < 6; ++q) zk += AdP[(size_t)node * 36 + k * 6 + q] * zc[(size_t)a * 6 + q];
+        }
+    }
+    if (was_done) {
+        if (blockIdx.x == 0 && t == 0) {
+            const int tk = state->ticks + 1;
+            state->ticks = tk;
+            if (exp_) { __threadfence_system(); exp_->ticks = tk; __threadfence_system(); }
+        }
+        return;
+    }
+    for (int off = 32; off > 0; off >>= 1) { s0 += __shfl_down(s0, off, 64); s1 += __shfl_down(s1, off, 64); s2 += __shfl_down(s2, off, 64); }
+    if ((t & 63) == 0) { s_red[0][t >> 6] = s0; s_red[1][t >> 6] = s1; s_red[2][t >> 6] = s2; }
+    __syncthreads();
+    double rzn = 0.0, rcz = 0.0, rr = 0.0;
+    for (int w = 0; w < PG_NT / 64; ++w) { rzn += s_red[0][w]; rcz += s_red[1][w]; rr += s_red[2][w]; }
+    rzn += rcz;
+    const double beta = first ? 0.0 : ((rzo > 0.0) ? rzn / rzo : 0.0);
     double dp2 = 0.0;
-    if (i < n) {
-        const double pv = first ? z[i] : z[i] + beta * p[i];
-        p[i] = pv;
-        dp2 = d[i] * pv * pv;
+    if (act) {
+        const double pv = first ? zk : zk + beta * pold;
+        p[o] = pv;
+        dp2 = dk * pv * pv;
     }
     double out2[2];
-    block_sum2(dp2, 0.0, out2);
-    if (threadIdx.x == 0) { part_dp[blockIdx.x * 2] = out2[0]; part_dp[blockIdx.x * 2 + 1] = 0.0; }
+    block_sum2_n<PG_NT>(dp2, 0.0, out2);
+    if (t == 0) { part_dp[blockIdx.x * 2] = out2[0]; part_dp[blockIdx.x * 2 + 1] = 0.0; }
+    if (blockIdx.x == 0 && t == 0) {
+        int iters, done, cap = 0, tk;
+        double rr0, tol2;
+        if (first) {
+            rr0 = rr; tol2 = eta * eta * rr0; iters = 0; tk = 1;
+            done = !(rr0 > 0.0) || !isfinite(rr0) || !isfinite(rzn);
+        } else {
+            rr0 = state->rr0; tol2 = state->tol2; iters = state->iters + 1; tk = state->ticks + 1;
+            done = !(rr > tol2);                              // (also ends the solve on a NaN)
+            if (!done && iters >= max_iters) { done = 1; cap = 1; }
+        }
+        state->rz[slot ^ 1] = rzn;
+        state->rr0 = rr0; state->tol2 = tol2; state->rr = rr; state->iters = iters; state->done = done; state->hit_cap = cap; state->ticks = tk;
+        if (exp_) {
+            exp_->rr0 = rr0; exp_->rr = rr; exp_->iters = iters; exp_->done = done; exp_->hit_cap = cap;
+            __threadfence_system();
+            exp_->ticks = tk;
+            __threadfence_system();
+        }
+    }
 }
 
-// trial poses + statistics: partial[b] = {|x_new - x|^2, |x|^2}
-__global__ __launch_bounds__(256) void pg_update_kernel(int n_nodes, const double* __restrict__ poses, const double* __restrict__ dx,
-                                                        const unsigned char* __restrict__ fixed, double* __restrict__ poses_new,
-                                                        double* __restrict__ partial) {
+// trial point of an LM iteration: the scalars the host decides on, summed on the device and written to mapped host memory
+// (one rank) or to a device block the cross-rank sum goes over first.  out: {cost2_new, |J x|^2, g.x, |dx|^2, |x|^2, seq}
+__global__ __launch_bounds__(256) void pg_trial_finish_kernel(int nb_e, const double* __restrict__ part_e, int nb_tt,
+                                                              const double* __restrict__ part_tt, int nb_u, const double* __restrict__ part_u,
+                                                              const PcgState* __restrict__ state, double* __restrict__ out, double seq) {
+    const double c2 = sum_partials_dev(part_e, nb_e, 1, 0);
+    const double tt = sum_partials_dev(part_tt, nb_tt, 2, 0);
+    const double gx = sum_partials_dev(part_u, nb_u, 4, 0);
+    const double s2 = sum_partials_dev(part_u, nb_u, 4, 1);
+    const double x2 = sum_partials_dev(part_u, nb_u, 4, 2);
+    if (threadIdx.x == 0) {
+        out[0] = c2; out[1] = tt; out[2] = gx; out[3] = s2; out[4] = x2;
+        out[5] = state ? (double)state->iters : 0.0; out[6] = state ? (double)state->hit_cap : 0.0; out[7] = state ? state->rr0 : 0.0;
+        __threadfence_system();
+        out[8] = seq;
+        __threadfence_system();
+    }
+}
+// linearisation: {cost2, |g|_inf, seq}
+__global__ __launch_bounds__(256) void pg_linear_finish_kernel(int nb_e, const double* __restrict__ part_e, int nb_g, const double* __restrict__ part_g,
+                                                               double* __restrict__ out, double seq) {
+    const double c2 = sum_partials_dev(part_e, nb_e, 1, 0);
+    const double g2 = sum_partials_dev(part_g, nb_g, 2, 0);
+    __shared__ double sq[256];
+    double mx = 0.0;
+    for (int k = threadIdx.x; k < nb_g; k += 256) mx = fmax(mx, part_g[2 * k + 1]);
+    sq[threadIdx.x] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 256; ++k) mx = fmax(mx, sq[k]);
+        out[0] = c2; out[1] = mx; out[2] = g2;
+        __threadfence_system();
+        out[3] = seq;
+        __threadfence_system();
+    }
+}
+__global__ void pg_export_kernel(int cnt, const double* __restrict__ src, double* __restrict__ out, double seq) {
+    const int k = threadIdx.x;
+    if (k < cnt) out[k] = src[k];
+    __threadfence_system();
+    __syncthreads();
+    if (k == 0) { out[cnt] = seq; __threadfence_system(); }
+}
+
+// trial poses + statistics of the step: partial[b] = {g.x, |x_new - x|^2, |x|^2, 0}
+__global__ __launch_bounds__(256) void pg_update4_kernel(int n_nodes, const double* __restrict__ poses, const double* __restrict__ dx,
+                                                         const double* __restrict__ g, const unsigned char* __restrict__ fixed,
+                                                         double* __restrict__ poses_new, double* __restrict__ partial) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    double a = 0.0, b = 0.0;
+    double a = 0.0, b = 0.0, c = 0.0;
     if (i < n_nodes) {
         double T[7], d[6], Tn[7];
         for (int k = 0; k < 7; ++k) T[k] = poses[(size_t)i * 7 + k];
         const bool fx = fixed && fixed[i];
-        for (int k = 0; k < 6; ++k) d[k] = fx ? 0.0 : dx[(size_t)i * 6 + k];
+        for (int k = 0; k < 6; ++k) { d[k] = fx ? 0.0 : dx[(size_t)i * 6 + k]; c += g[(size_t)i * 6 + k] * d[k]; }
         if (fx) for (int k = 0; k < 7; ++k) Tn[k] = T[k];
         else se3_retract(T, d, Tn);
         for (int k = 0; k < 7; ++k) {
@@ -478,20 +921,11 @@ __global__ __launch_bounds__(256) void pg_update_kernel(int n_nodes, const doubl
             if (!fx) { a += (Tn[k] - T[k]) * (Tn[k] - T[k]); b += T[k] * T[k]; }
         }
     }
-    double out2[2];
+    double out2[2], out3[2];
     block_sum2(a, b, out2);
-    if (threadIdx.x == 0) { partial[blockIdx.x * 2] = out2[0]; partial[blockIdx.x * 2 + 1] = out2[1]; }
-}
-
-// model change terms: partial = {sum g x, sum x (Hx)}
-__global__ __launch_bounds__(256) void pg_model_kernel(int n, const double* __restrict__ g, const double* __restrict__ x,
-                                                       const double* __restrict__ hx, double* __restrict__ partial) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    double a = 0.0, b = 0.0;
-    if (i < n) { a = g[i] * x[i]; b = x[i] * hx[i]; }
-    double out2[2];
-    block_sum2(a, b, out2);
-    if (threadIdx.x == 0) { partial[blockIdx.x * 2] = out2[0]; partial[blockIdx.x * 2 + 1] = out2[1]; }
+    __syncthreads();
+    block_sum2(c, 0.0, out3);
+    if (threadIdx.x == 0) { partial[blockIdx.x * 4] = out3[0]; partial[blockIdx.x * 4 + 1] = out2[0]; partial[blockIdx.x * 4 + 2] = out2[1]; partial[blockIdx.x * 4 + 3] = 0.0; }
 }
 
 template <class T>
@@ -529,6 +963,20 @@ struct stba_pg {
     void* ar_user = nullptr;
     int rank = 0, world = 1;
     double* scalar = nullptr;           // one device double for the cost sums
+    // ---- round 4: coarse space of the two-level preconditioner (see the header) and the device-side PCG control
+    int agg = 0, na = 0, nc = 0, np = 0, parts = 1;      // nodes per group, groups, coarse unknowns, padded, workgroups per group
+    int* end_node = nullptr;                             // owner node of every edge end of the CSR
+    double *AdP = nullptr, *Ac0 = nullptr, *W = nullptr, *Ainv = nullptr, *inv_work = nullptr, *rc_part = nullptr, *zc = nullptr,
+           *part_cz = nullptr, *part_u = nullptr, *scal_dev = nullptr, *contrib = nullptr, *Dc = nullptr;
+    int* cflag = nullptr;
+    PcgState* state = nullptr;
+    PcgExport *exp_host = nullptr, *exp_dev = nullptr;   // mapped
+    double *fin_host = nullptr, *fin_dev = nullptr;      // mapped: trial / linearisation scalars + sequence number
+    double seq = 0.0;
+    int nb_nodes4 = 1;
+    bool coarse_valid = false;
+    double coarse_radius = 0.0;
+    stba_pcg_summary last_pcg;
 };
 
 namespace stba {
@@ -538,6 +986,10 @@ void pg_free(stba_pg* g) {
     F(g->poses[0]); F(g->poses[1]); F(g->ei); F(g->ej); F(g->meas); F(g->r); F(g->Ji); F(g->Jj); F(g->g);
     F(g->Minv); F(g->d); F(g->scale); F(g->x); F(g->rr); F(g->z); F(g->p); F(g->q); F(g->part_e); F(g->part_a);
     F(g->part_b); F(g->part_c); F(g->part_d); F(g->fixed); F(g->scalar); F(g->node_start); F(g->end_code); F(g->u);
+    F(g->end_node); F(g->AdP); F(g->Ac0); F(g->W); F(g->Ainv); F(g->inv_work); F(g->rc_part); F(g->zc); F(g->part_cz); F(g->part_u);
+    F(g->scal_dev); F(g->cflag); F(g->state); F(g->contrib); F(g->Dc);
+    if (g->exp_host) (void)hipHostFree(g->exp_host);
+    if (g->fin_host) (void)hipHostFree(g->fin_host);
     if (g->own && g->st) (void)hipStreamDestroy(g->st);
     delete g;
 }
@@ -553,7 +1005,7 @@ double host_sum(hipStream_t st, const double* dev, int n, int stride, int off, s
 
 int pg_linearize(stba_pg* g, int which, bool jac) {
     hipLaunchKernelGGL(pg_linearize_kernel, dim3(g->nb_edges), dim3(256), 0, g->st, g->m, g->poses[which], g->ei, g->ej,
-                       g->meas, g->fixed, jac ? 1 : 0, jac ? g->r : nullptr, g->Ji, g->Jj, g->part_e);
+                       g->meas, g->fixed, jac ? 1 : 0, jac ? g->r : nullptr, g->Ji, g->Jj, g->part_e, jac ? g->contrib : nullptr);
     STBA_HIP(hipGetLastError());
     return STBA_OK;
 }
@@ -582,13 +1034,69 @@ int pg_sum_ranks(stba_pg* g, double* v) {
 }  // namespace
 }  // namespace stba
 
+// ---- coarse space: sizes and buffers for a group size (lazily: the group size is an option of the solve)
+static int pg_setup_coarse(stba_pg* g, int group_opt) {
+    int agg = group_opt;
+    if (agg == 0) {            // auto: about 160 groups (C4: 64 nodes per group, 942 coarse unknowns), at least 8 nodes per group
+        agg = 8;
+        while ((g->n + agg - 1) / agg > 200) agg *= 2;
+    }
+    if (agg < 0) { g->agg = -1; g->coarse_valid = false; return STBA_OK; }
+    if (agg < 2 || (agg & (agg - 1)) != 0) return fail(STBA_ERR_INVALID_ARGUMENT, "stba_pg_solve: coarse_group must be a power of two >= 2 (0: automatic, -1: off)");
+    if (agg == g->agg) return STBA_OK;
+    const int na = (g->n + agg - 1) / agg, nc = 6 * na, np = ((nc + 127) / 128) * 128, parts = std::max(1, agg / PG_NPW);
+    if ((size_t)6 * nc * sizeof(double) > 150 * 1024) return fail(STBA_ERR_INVALID_ARGUMENT, "stba_pg_solve: coarse space too large for this group size");
+    auto F = [](void* p) { if (p) (void)hipFree(p); };
+    F(g->AdP); F(g->Ac0); F(g->W); F(g->Ainv); F(g->inv_work); F(g->rc_part); F(g->zc); F(g->part_cz); F(g->Dc);
+    g->AdP = g->Ac0 = g->W = g->Ainv = g->inv_work = g->rc_part = g->zc = g->part_cz = g->Dc = nullptr;
+    g->agg = 0;
+    STBA_TRY(dalloc(&g->AdP, (size_t)g->n * 36)); STBA_TRY(dalloc(&g->Ac0, (size_t)nc * nc)); STBA_TRY(dalloc(&g->W, (size_t)4 * np * np));
+    STBA_TRY(dalloc(&g->Ainv, (size_t)nc * nc)); STBA_TRY(dalloc(&g->Dc, (size_t)na * 36)); STBA_TRY(dalloc(&g->inv_work, chol_spd_inverse_workspace_doubles(np)));
+    STBA_TRY(dalloc(&g->rc_part, (size_t)na * parts * 6)); STBA_TRY(dalloc(&g->zc, (size_t)nc)); STBA_TRY(dalloc(&g->part_cz, (size_t)((nc + 3) / 4) * 2 + 2));
+    STBA_HIP(hipMemsetAsync(g->rc_part, 0, (size_t)na * parts * 6 * sizeof(double), g->st));
+    static DeviceOnce attr;
+    STBA_TRY(attr.run([]() -> int {
+        STBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pg_coarse_build_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        return STBA_OK;
+    }));
+    g->agg = agg; g->na = na; g->nc = nc; g->np = np; g->parts = parts;
+    g->coarse_valid = false;
+    return STBA_OK;
+}
+
+// waits until the sequence number behind a block in mapped host memory is `seq` (the stream is queried now and then so
+// that a device fault ends the wait)
+template <class T>
+static int pg_wait_mapped(stba_pg* g, const volatile T* slot, T want, bool at_least) {
+    const double t0 = wall();
+    for (unsigned long k = 1;; ++k) {
+        const T v = *slot;
+        if (at_least ? (v >= want) : (v == want)) break;
+        if ((k & 0x3fff) == 0) {
+            const hipError_t q = hipStreamQuery(g->st);
+            if (q != hipSuccess && q != hipErrorNotReady) return fail(STBA_ERR_HIP, std::string("pose graph: stream failed: ") + hipGetErrorString(q));
+            if (q == hipSuccess) { const T v2 = *slot; if (!(at_least ? (v2 >= want) : (v2 == want))) return fail(STBA_ERR_HIP, "pose graph: the device never wrote the block the host waits for"); break; }
+            if (wall() - t0 > 120.0) return fail(STBA_ERR_HIP, "pose graph: timed out waiting for the device");
+        }
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    return STBA_OK;
+}
+
 extern "C" {
 
 void stba_pcg_default_options(stba_pcg_options* o) {
     if (!o) return;
     o->max_iterations = 1000;
     o->relative_tolerance = 1e-12;
-    o->check_every = 20;
+    o->check_every = 4;
+    o->forcing_eta0 = 0.1;
+    o->forcing_eta_min = 1e-10;
+    o->coarse_group = 0;
+    o->coarse_refresh_every = 1;
 }
 
 int stba_pg_create(stba_pg** out, int n_nodes, int n_edges, const double* poses, const int* edge_i, const int* edge_j,
@@ -621,18 +1129,31 @@ int stba_pg_create(stba_pg** out, int n_nodes, int n_edges, const double* poses,
     A_(dalloc(&g->part_d, np_));
     if (node_fixed) A_(dalloc(&g->fixed, n));
     A_(dalloc(&g->node_start, n + 1)); A_(dalloc(&g->end_code, 2 * m)); A_(dalloc(&g->u, 12 * m));
+    A_(dalloc(&g->end_node, 2 * m)); A_(dalloc(&g->contrib, 2 * m * 28));
+    g->nb_nodes4 = (n_nodes + PG_NPW - 1) / PG_NPW;
+    A_(dalloc(&g->part_u, (size_t)g->nb_nodes * 4 + 4)); A_(dalloc(&g->scal_dev, 16)); A_(dalloc(&g->state, 1)); A_(dalloc(&g->cflag, 1));
+    if (hipHostMalloc(reinterpret_cast<void**>(&g->exp_host), sizeof(PcgExport), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+        hipHostGetDevicePointer(reinterpret_cast<void**>(&g->exp_dev), g->exp_host, 0) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void**>(&g->fin_host), 16 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+        hipHostGetDevicePointer(reinterpret_cast<void**>(&g->fin_dev), g->fin_host, 0) != hipSuccess)
+        return bail(fail(STBA_ERR_ALLOC, "stba_pg_create: mapped host memory"));
+    memset(g->exp_host, 0, sizeof(PcgExport)); memset(g->fin_host, 0, 16 * sizeof(double));
+    memset(&g->last_pcg, 0, sizeof g->last_pcg);
 #undef A_
     {   // edge ends sorted by node (counting sort; stable: a node's ends in edge order)
         std::vector<int> start((size_t)n_nodes + 1, 0), code(2 * m);
         for (int e = 0; e < n_edges; ++e) { ++start[(size_t)edge_i[e] + 1]; ++start[(size_t)edge_j[e] + 1]; }
         for (int i = 0; i < n_nodes; ++i) start[(size_t)i + 1] += start[(size_t)i];
-        std::vector<int> fill(start.begin(), start.end() - 1);
+        std::vector<int> fill(start.begin(), start.end() - 1), owner(2 * m);
         for (int e = 0; e < n_edges; ++e) {
+            owner[(size_t)fill[(size_t)edge_i[e]]] = edge_i[e];
             code[(size_t)fill[(size_t)edge_i[e]]++] = 2 * e;
+            owner[(size_t)fill[(size_t)edge_j[e]]] = edge_j[e];
             code[(size_t)fill[(size_t)edge_j[e]]++] = 2 * e + 1;
         }
         if (hipMemcpyAsync(g->node_start, start.data(), (n + 1) * sizeof(int), hipMemcpyHostToDevice, g->st) != hipSuccess ||
             hipMemcpyAsync(g->end_code, code.data(), 2 * m * sizeof(int), hipMemcpyHostToDevice, g->st) != hipSuccess ||
+            hipMemcpyAsync(g->end_node, owner.data(), 2 * m * sizeof(int), hipMemcpyHostToDevice, g->st) != hipSuccess ||
             hipStreamSynchronize(g->st) != hipSuccess)
             return bail(fail(STBA_ERR_HIP, "stba_pg_create: upload failed"));
     }
@@ -706,12 +1227,12 @@ int stba_pg_time_kernels(stba_pg* g, int reps, double* ms_linearize, double* ms_
     // the product as the one-rank solve runs it: the edge kernel (t_e, u_e = J_e^T t_e, |t_e|^2) -- the node kernel gathers u
     // while it updates x, r, z and is not a product kernel of its own
     int rc = STBA_OK;
-    hipLaunchKernelGGL(pg_edge_product_kernel, dim3(g->nb_edges), dim3(256), 0, g->st, g->m, g->ei, g->ej, g->Ji, g->Jj, g->p, g->u, g->part_c);
+    hipLaunchKernelGGL(pg_edge_product_kernel, dim3(g->nb_edges), dim3(256), 0, g->st, g->m, g->ei, g->ej, g->Ji, g->Jj, g->p, g->u, g->part_c, (const PcgState*)nullptr);
     if (hipEventRecord(e0, g->st) != hipSuccess) rc = fail(STBA_ERR_HIP, "hipEventRecord");
     for (int k = 0; k < reps && rc == STBA_OK; ++k) rc = pg_linearize(g, g->cur, true);
     if (rc == STBA_OK && hipEventRecord(e1, g->st) != hipSuccess) rc = fail(STBA_ERR_HIP, "hipEventRecord");
     for (int k = 0; k < reps && rc == STBA_OK; ++k)
-        hipLaunchKernelGGL(pg_edge_product_kernel, dim3(g->nb_edges), dim3(256), 0, g->st, g->m, g->ei, g->ej, g->Ji, g->Jj, g->p, g->u, g->part_c);
+        hipLaunchKernelGGL(pg_edge_product_kernel, dim3(g->nb_edges), dim3(256), 0, g->st, g->m, g->ei, g->ej, g->Ji, g->Jj, g->p, g->u, g->part_c, (const PcgState*)nullptr);
     if (rc == STBA_OK && hipEventRecord(e2, g->st) != hipSuccess) rc = fail(STBA_ERR_HIP, "hipEventRecord");
     if (rc == STBA_OK && hipStreamSynchronize(g->st) != hipSuccess) rc = fail(STBA_ERR_HIP, "hipStreamSynchronize");
     float a = 0.f, b = 0.f;
@@ -731,37 +1252,62 @@ int stba_pg_solve(stba_pg* g, const stba_lm_options* opt_in, const stba_pcg_opti
     stba_lm_summary s;
     memset(&s, 0, sizeof s);
     const double t0 = wall();
-    std::vector<double> buf;
     const int N = 6 * g->n;
-    int pcg_total = 0;
+    STBA_TRY(pg_setup_coarse(g, pcg.coarse_group));
+    const bool coarse = g->agg > 0;
+    const bool multi = (g->ar != nullptr);
+    const int chunk = std::max(1, pcg.check_every);
+    const bool forcing = pcg.forcing_eta0 > 0.0;
+    stba_pcg_summary ps;
+    memset(&ps, 0, sizeof ps);
+    ps.coarse_dim = coarse ? g->nc : 0;
+    double* fin = g->fin_host;
 
-    auto linearize_full = [&](double* cost, double* gmax) -> int {
+    // ---- linearisation at the current point: residuals, Jacobians, gradient | diagonal blocks, the coarse basis and matrix
+    auto linearize_enqueue = [&]() -> int {
         STBA_TRY(pg_linearize(g, g->cur, true));
-        double c2 = host_sum(g->st, g->part_e, g->nb_edges, 1, 0, buf);
-        STBA_TRY(pg_sum_ranks(g, &c2));
-        *cost = 0.5 * c2;
-        STBA_HIP(hipMemsetAsync(g->g, 0, (size_t)g->n * 42 * sizeof(double), g->st));
-        hipLaunchKernelGGL(pg_accumulate_kernel, dim3((2 * g->m + 255) / 256), dim3(256), 0, g->st, g->m, g->ei, g->ej, g->r,
-                           g->Ji, g->Jj, g->g, g->Hd);
+        hipLaunchKernelGGL(pg_gather_blocks_kernel, dim3(g->nb_nodes4), dim3(PG_NT), 0, g->st, g->n, g->node_start, g->end_code, g->contrib, g->g, g->Hd);
         if (g->ar && g->ar(g->ar_user, g->g, (size_t)g->n * 42, g->st) != 0) return fail(STBA_ERR_CALLBACK, "all-reduce hook failed");
-        STBA_TRY(launch_absmax(g->g, (size_t)N, nullptr, 0, g->part_c, g->part_a, g->nb_vec, g->st));
-        double gm = 0.0;
-        STBA_HIP(hipMemcpyAsync(&gm, g->part_c, sizeof(double), hipMemcpyDeviceToHost, g->st));
-        STBA_HIP(hipStreamSynchronize(g->st));
-        *gmax = gm;
+        hipLaunchKernelGGL(pg_gnorm_kernel, dim3(g->nb_vec), dim3(256), 0, g->st, N, g->g, g->part_c);
+        if (coarse) {
+            hipLaunchKernelGGL(pg_coarse_basis_kernel, dim3(g->nb_nodes), dim3(256), 0, g->st, g->n, g->agg, g->poses[g->cur], g->fixed, g->AdP);
+            hipLaunchKernelGGL(pg_coarse_build_kernel, dim3(g->na), dim3(256), (size_t)6 * g->nc * sizeof(double), g->st, g->n, g->m, g->agg, g->nc,
+                               g->node_start, g->end_code, g->end_node, g->ei, g->ej, g->Ji, g->Jj, g->AdP, g->Ac0);
+            if (g->ar && g->ar(g->ar_user, g->Ac0, (size_t)g->nc * g->nc, g->st) != 0) return fail(STBA_ERR_CALLBACK, "all-reduce hook failed");
+            g->coarse_valid = false;
+        }
+        STBA_HIP(hipGetLastError());
+        return STBA_OK;
+    };
+    // cost and |g|_inf of that linearisation: one kernel sums, the host reads mapped memory (several ranks: the cost goes over the hook)
+    auto linearize_finish = [&](double* cost, double* gmax, double* g2) -> int {
+        g->seq += 1.0;
+        if (!multi) {
+            hipLaunchKernelGGL(pg_linear_finish_kernel, dim3(1), dim3(256), 0, g->st, g->nb_edges, g->part_e, g->nb_vec, g->part_c, g->fin_dev, g->seq);
+        } else {
+            hipLaunchKernelGGL(pg_linear_finish_kernel, dim3(1), dim3(256), 0, g->st, g->nb_edges, g->part_e, g->nb_vec, g->part_c, g->scal_dev, g->seq);
+            if (g->ar(g->ar_user, g->scal_dev, 1, g->st) != 0) return fail(STBA_ERR_CALLBACK, "all-reduce hook failed");
+            hipLaunchKernelGGL(pg_export_kernel, dim3(1), dim3(64), 0, g->st, 3, g->scal_dev, g->fin_dev, g->seq);
+        }
+        STBA_HIP(hipGetLastError());
+        STBA_TRY(pg_wait_mapped<double>(g, &fin[3], g->seq, false));
+        *cost = 0.5 * fin[0]; *gmax = fin[1]; *g2 = fin[2];
         return STBA_OK;
     };
 
-    double cost = 0.0, gmax = 0.0;
-    STBA_TRY(linearize_full(&cost, &gmax));
+    double cost = 0.0, gmax = 0.0, g2 = 0.0;
+    STBA_TRY(linearize_enqueue());
+    STBA_TRY(linearize_finish(&cost, &gmax, &g2));
     s.initial_cost = cost;
     double radius = opt.initial_trust_region_radius, decrease = 2.0;
     bool scale_init = false;
     int iter = 0;
+    double eta = pcg.forcing_eta0;
     if (trace) { memset(trace, 0, sizeof(double) * STBA_TRACE_COLS); trace[0] = cost; trace[2] = gmax; trace[5] = radius; trace[6] = 1; }
     s.termination_type = STBA_NO_CONVERGENCE; s.termination_reason = STBA_TERM_MAX_ITER;
     bool done = gmax <= opt.gradient_tolerance;
     if (done) { s.termination_type = STBA_CONVERGENCE; s.termination_reason = STBA_TERM_GRADIENT; }
+    int since_refresh = 0;
     while (!done) {
         if (iter >= opt.max_num_iterations) break;
         if (radius < opt.min_trust_region_radius) { s.termination_type = STBA_CONVERGENCE; s.termination_reason = STBA_TERM_MIN_RADIUS; break; }
@@ -769,64 +1315,95 @@ int stba_pg_solve(stba_pg* g, const stba_lm_options* opt_in, const stba_pcg_opti
         hipLaunchKernelGGL(pg_precond_kernel, dim3(g->nb_nodes), dim3(256), 0, g->st, g->n, g->Hd, g->scale, scale_init ? 0 : 1,
                            opt.jacobi_scaling, radius, opt.min_lm_diagonal, opt.max_lm_diagonal, g->fixed, g->d, g->Minv);
         scale_init = true;
-        // ---- PCG on (J^T J + D) x = -g
-        hipLaunchKernelGGL(pg_pcg_init_kernel, dim3(g->nb_nodes), dim3(256), 0, g->st, g->n, g->g, g->Minv, g->x, g->rr, g->z, g->p,
-                           g->part_a);
-        double* part_rz = g->part_a;
-        double* part_new = g->part_b;
-        const double rr0 = host_sum(g->st, part_rz, g->nb_nodes, 2, 1, buf);
-        const double tol2 = pcg.relative_tolerance * pcg.relative_tolerance * rr0;
-        int k = 0;
-        bool ok = std::isfinite(rr0);
-        // (one rank: three launches per iteration, the dot product p.q gathered on the way -- see pg_matvec_dot_kernel; with
-        // several ranks the product needs a cross-rank sum between the edge kernel and the dot product: five launches)
-        const bool fused3 = (g->ar == nullptr);
-        if (fused3 && ok && rr0 > 0.0)
-            hipLaunchKernelGGL(pg_pcg_dir3_kernel, dim3(g->nb_vec), dim3(256), 0, g->st, N, g->nb_nodes, part_rz, part_rz, 1, g->z, g->d, g->p,
-                               g->part_d);
-        while (ok && rr0 > 0.0 && k < pcg.max_iterations) {
-            if (fused3) {
-                hipLaunchKernelGGL(pg_edge_product_kernel, dim3(g->nb_edges), dim3(256), 0, g->st, g->m, g->ei, g->ej, g->Ji, g->Jj, g->p, g->u,
-                                   g->part_c);
-                hipLaunchKernelGGL(pg_pcg_update3_kernel, dim3(g->nb_nodes), dim3(256), 0, g->st, g->n, g->m, g->nb_nodes, part_rz, g->nb_edges,
-                                   g->part_c, g->nb_vec, g->part_d, g->Minv, g->d, g->node_start, g->end_code, g->u, g->p, g->x, g->rr, g->z,
-                                   part_new);
-                hipLaunchKernelGGL(pg_pcg_dir3_kernel, dim3(g->nb_vec), dim3(256), 0, g->st, N, g->nb_nodes, part_new, part_rz, 0, g->z, g->d,
-                                   g->p, g->part_d);
-            } else {
-                STBA_TRY(pg_apply(g, g->p, g->q, true));
-                hipLaunchKernelGGL(pg_dot_kernel, dim3(g->nb_vec), dim3(256), 0, g->st, N, g->p, g->q, g->part_c);
-                hipLaunchKernelGGL(pg_pcg_update_kernel, dim3(g->nb_nodes), dim3(256), 0, g->st, g->n, g->nb_nodes, part_rz, g->nb_vec,
-                                   g->part_c, g->Minv, g->p, g->q, g->x, g->rr, g->z, part_new);
-                hipLaunchKernelGGL(pg_pcg_dir_kernel, dim3(g->nb_vec), dim3(256), 0, g->st, N, g->nb_nodes, part_new, part_rz, g->z, g->p);
-            }
-            std::swap(part_rz, part_new);
-            ++k;
-            if (k % std::max(1, pcg.check_every) == 0) {
-                const double rrk = host_sum(g->st, part_rz, g->nb_nodes, 2, 1, buf);
-                if (!(rrk > tol2)) break;
-                if (!std::isfinite(rrk)) { ok = false; break; }
-            }
+        // ---- coarse operator (P^T (J^T J + D) P)^-1: rebuilt when the linearisation or (every coarse_refresh_every-th time) the damping changed
+        // (the inverse is a preconditioner: one made at an earlier linearisation / damping still is one, only weaker -- with
+        // coarse_refresh_every = k it is re-made every k-th LM iteration; the first two iterations always make theirs)
+        if (coarse && (ps.coarse_refreshes < 2 || since_refresh >= std::max(1, pcg.coarse_refresh_every))) {
+            const size_t cnt = (size_t)3 * g->np * g->np;
+            hipLaunchKernelGGL(pg_coarse_dc_kernel, dim3(g->na), dim3(256), 0, g->st, g->n, g->agg, g->AdP, g->d, g->Dc);
+            hipLaunchKernelGGL(pg_coarse_assemble_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, g->st, g->nc, g->np, g->Ac0, g->Dc, g->W);
+            STBA_TRY(chol_spd_inverse_dev(g->W, 2 * g->np, g->np, g->nc, g->cflag, g->inv_work, g->st));
+            hipLaunchKernelGGL(pg_coarse_finish_kernel, dim3((unsigned)(((size_t)g->nc * g->nc + 255) / 256)), dim3(256), 0, g->st, g->nc, g->np, g->W, g->Ainv);
+            g->coarse_valid = true;
+            since_refresh = 0;
+            ++ps.coarse_refreshes;
         }
-        pcg_total += k;
+        ++since_refresh;
+        // ---- PCG on (J^T J + D) x = -g, stopped on the device at |r| <= eta |g|
+        const double eta_k = forcing ? eta : pcg.relative_tolerance;
+        const double* AdP = coarse ? g->AdP : nullptr;
+        // (every kernel of the previous solve has finished -- the host has read the trial block behind them -- so the exported
+        // block can be taken back: the wait below must not see the previous solve's tick count and `done`)
+        g->exp_host->ticks = 0; g->exp_host->done = 0;
+        std::atomic_thread_fence(std::memory_order_seq_cst);
+        hipLaunchKernelGGL(pg_pcg_init4_kernel, dim3(g->nb_nodes4), dim3(PG_NT), 0, g->st, g->n, g->agg, g->g, g->Minv, AdP, g->x, g->rr, g->z,
+                           g->rc_part, g->part_a);
+        if (coarse)
+            hipLaunchKernelGGL(pg_coarse_solve_kernel, dim3((g->nc + 3) / 4), dim3(256), 0, g->st, g->nc, g->parts, (const PcgState*)nullptr, g->Ainv, g->rc_part,
+                               g->zc, g->part_cz);
+        hipLaunchKernelGGL(pg_pcg_dir4_kernel, dim3(g->nb_nodes4), dim3(PG_NT), 0, g->st, g->n, g->agg, 1, 1, eta_k, pcg.max_iterations, g->state, g->exp_dev,
+                           g->nb_nodes4, g->part_a, (g->nc + 3) / 4, coarse ? g->part_cz : nullptr, AdP, g->zc, g->z, g->d, g->p, g->part_d);
         STBA_HIP(hipGetLastError());
-        // ---- model change, trial point
-        STBA_TRY(pg_apply(g, g->x, g->q, false));
-        hipLaunchKernelGGL(pg_model_kernel, dim3(g->nb_vec), dim3(256), 0, g->st, N, g->g, g->x, g->q, g->part_c);
+        int enq = 0;
+        bool pcg_done = false;
+        STBA_TRY(pg_wait_mapped<int>(g, &g->exp_host->ticks, 1, true));          // (also: the previous solve's ticks are gone)
+        if (g->exp_host->done) pcg_done = true;
+        while (!pcg_done && enq < pcg.max_iterations) {
+            const int todo = std::min(chunk, pcg.max_iterations - enq);
+            for (int c = 0; c < todo; ++c, ++enq) {
+                const int slot = enq & 1;
+                if (!multi) {
+                    hipLaunchKernelGGL(pg_edge_product_kernel, dim3(g->nb_edges), dim3(256), 0, g->st, g->m, g->ei, g->ej, g->Ji, g->Jj, g->p, g->u,
+                                       g->part_c, g->state);
+                    hipLaunchKernelGGL(pg_pcg_update4_kernel<true>, dim3(g->nb_nodes4), dim3(PG_NT), 0, g->st, g->n, g->m, g->agg, slot, g->state, g->nb_edges,
+                                       g->part_c, g->nb_nodes4, g->part_d, g->Minv, AdP, g->d, g->node_start, g->end_code, g->u, (const double*)nullptr,
+                                       g->p, g->x, g->rr, g->z, g->rc_part, g->part_a);
+                } else {
+                    STBA_TRY(pg_apply(g, g->p, g->q, true));
+                    hipLaunchKernelGGL(pg_dot_kernel, dim3(g->nb_vec), dim3(256), 0, g->st, N, g->p, g->q, g->part_c);
+                    hipLaunchKernelGGL(pg_pcg_update4_kernel<false>, dim3(g->nb_nodes4), dim3(PG_NT), 0, g->st, g->n, g->m, g->agg, slot, g->state, g->nb_vec,
+                                       g->part_c, 0, (const double*)nullptr, g->Minv, AdP, g->d, g->node_start, g->end_code, g->u, g->q,
+                                       g->p, g->x, g->rr, g->z, g->rc_part, g->part_a);
+                }
+                if (coarse)
+                    hipLaunchKernelGGL(pg_coarse_solve_kernel, dim3((g->nc + 3) / 4), dim3(256), 0, g->st, g->nc, g->parts, g->state, g->Ainv, g->rc_part, g->zc,
+                                       g->part_cz);
+                hipLaunchKernelGGL(pg_pcg_dir4_kernel, dim3(g->nb_nodes4), dim3(PG_NT), 0, g->st, g->n, g->agg, slot, 0, eta_k, pcg.max_iterations, g->state,
+                                   g->exp_dev, g->nb_nodes4, g->part_a, (g->nc + 3) / 4, coarse ? g->part_cz : nullptr, AdP, g->zc, g->z, g->d, g->p, g->part_d);
+            }
+            STBA_HIP(hipGetLastError());
+            // one rank: the host looks at the chunk BEFORE the one it has just enqueued (the stream never runs dry; the kernels of a
+            // chunk enqueued past convergence return at once).  Several ranks: every rank must enqueue the same collectives, so the
+            // decision waits for the chunk itself -- the solve state is replicated and every rank sees the same `done`.
+            const int want = 1 + (multi ? enq : enq - todo);
+            STBA_TRY(pg_wait_mapped<int>(g, &g->exp_host->ticks, want, true));
+            if (g->exp_host->done) pcg_done = true;
+        }
+        // ---- model change, trial point: |J x|^2 from the edge kernel (its |t_e|^2 sums), g.x and the step norms from the update kernel
+        hipLaunchKernelGGL(pg_edge_product_kernel, dim3(g->nb_edges), dim3(256), 0, g->st, g->m, g->ei, g->ej, g->Ji, g->Jj, g->x, g->u, g->part_b,
+                           (const PcgState*)nullptr);
         const int nxt = g->cur ^ 1;
-        double* part_upd = g->part_a;     // the PCG scalars are no longer needed
-        hipLaunchKernelGGL(pg_update_kernel, dim3(g->nb_nodes), dim3(256), 0, g->st, g->n, g->poses[g->cur], g->x, g->fixed,
-                           g->poses[nxt], part_upd);
+        hipLaunchKernelGGL(pg_update4_kernel, dim3(g->nb_nodes), dim3(256), 0, g->st, g->n, g->poses[g->cur], g->x, g->g, g->fixed, g->poses[nxt], g->part_u);
         STBA_TRY(pg_linearize(g, nxt, false));
-        const double gx = host_sum(g->st, g->part_c, g->nb_vec, 2, 0, buf);
-        double xhx = 0.0;
-        for (int b = 0; b < g->nb_vec; ++b) xhx += buf[(size_t)b * 2 + 1];
-        const double step2 = host_sum(g->st, part_upd, g->nb_nodes, 2, 0, buf);
-        double x2 = 0.0;
-        for (int b = 0; b < g->nb_nodes; ++b) x2 += buf[(size_t)b * 2 + 1];
-        double nc2 = host_sum(g->st, g->part_e, g->nb_edges, 1, 0, buf);
-        STBA_TRY(pg_sum_ranks(g, &nc2));
-        const double new_cost = 0.5 * nc2;
+        g->seq += 1.0;
+        if (!multi) {
+            hipLaunchKernelGGL(pg_trial_finish_kernel, dim3(1), dim3(256), 0, g->st, g->nb_edges, g->part_e, g->nb_edges, g->part_b, g->nb_nodes, g->part_u,
+                               g->state, g->fin_dev, g->seq);
+        } else {
+            hipLaunchKernelGGL(pg_trial_finish_kernel, dim3(1), dim3(256), 0, g->st, g->nb_edges, g->part_e, g->nb_edges, g->part_b, g->nb_nodes, g->part_u,
+                               g->state, g->scal_dev, g->seq);
+            if (g->ar(g->ar_user, g->scal_dev, 2, g->st) != 0) return fail(STBA_ERR_CALLBACK, "all-reduce hook failed");      // cost and |J x|^2 over the edge shards
+            hipLaunchKernelGGL(pg_export_kernel, dim3(1), dim3(64), 0, g->st, 8, g->scal_dev, g->fin_dev, g->seq);
+        }
+        STBA_HIP(hipGetLastError());
+        STBA_TRY(pg_wait_mapped<double>(g, &fin[8], g->seq, false));
+        const double new_cost = 0.5 * fin[0], xhx = fin[1], gx = fin[2], step2 = fin[3], x2 = fin[4];
+        const int k = (int)fin[5];
+        const bool capped = fin[6] != 0.0;
+        const double rr0 = fin[7];
+        ps.iterations_total += k; ++ps.solves; ps.hit_cap += capped ? 1 : 0; ps.max_iterations_in_a_solve = std::max(ps.max_iterations_in_a_solve, k);
+        ps.last_eta = eta_k;
+        bool ok = std::isfinite(rr0);
         const double model_change = -gx - 0.5 * xhx;
         const double step_norm = std::sqrt(step2), x_norm = std::sqrt(x2);
         ok = ok && model_change > 0.0 && std::isfinite(model_change) && std::isfinite(new_cost);
@@ -838,7 +1415,7 @@ int stba_pg_solve(stba_pg* g, const stba_lm_options* opt_in, const stba_pcg_opti
             if (step_norm <= opt.parameter_tolerance * (x_norm + opt.parameter_tolerance)) {
                 s.termination_type = STBA_CONVERGENCE; s.termination_reason = STBA_TERM_PARAMETER; stop = true;
             } else if (std::fabs(cost_change) <= opt.function_tolerance * cost) {
-                if (rho > opt.min_relative_decrease) { g->cur = nxt; cost = new_cost; ++s.num_successful_steps; accepted = true; }
+                if (rho > opt.min_relative_decrease) { g->cur = nxt; cost = new_cost; ++s.num_successful_steps; accepted = true; g->coarse_valid = false; }
                 s.termination_type = STBA_CONVERGENCE; s.termination_reason = STBA_TERM_FUNCTION; stop = true;
             }
             if (!stop) accepted = rho > opt.min_relative_decrease;
@@ -855,9 +1432,18 @@ int stba_pg_solve(stba_pg* g, const stba_lm_options* opt_in, const stba_pcg_opti
             const double t = 2.0 * rho - 1.0;
             radius = std::min(opt.max_trust_region_radius, radius / std::max(1.0 / 3.0, 1.0 - t * t * t));
             decrease = 2.0;
-            double c2;
-            STBA_TRY(linearize_full(&c2, &gmax));
+            double c2, g2_new = 0.0;
+            STBA_TRY(linearize_enqueue());
+            STBA_TRY(linearize_finish(&c2, &gmax, &g2_new));
             cost = c2;
+            // forcing sequence (Eisenstat & Walker, choice 2): eta_{k+1} = 0.9 (|g_{k+1}| / |g_k|)^2 with their safeguard, kept in
+            // [eta_min, eta0]; after a rejected step the gradient has not moved and eta stays
+            if (forcing && g2 > 0.0 && std::isfinite(g2_new)) {
+                double e2 = 0.9 * g2_new / g2;
+                if (0.9 * eta * eta > 0.1) e2 = std::max(e2, 0.9 * eta * eta);
+                eta = std::min(pcg.forcing_eta0, std::max(pcg.forcing_eta_min, e2));
+            }
+            g2 = g2_new;
             if (trace) { trace[(size_t)iter * STBA_TRACE_COLS + 2] = gmax; trace[(size_t)iter * STBA_TRACE_COLS + 5] = radius; }
             if (gmax <= opt.gradient_tolerance) { s.termination_type = STBA_CONVERGENCE; s.termination_reason = STBA_TERM_GRADIENT; break; }
         } else {
@@ -866,12 +1452,20 @@ int stba_pg_solve(stba_pg* g, const stba_lm_options* opt_in, const stba_pcg_opti
             if (trace) trace[(size_t)iter * STBA_TRACE_COLS + 5] = radius;
         }
         if (opt.minimizer_progress_to_stdout)
-            printf("%4d  %.6e   % .2e    %.2e   %.2e  % .2e  %.2e  pcg %d\n", iter, cost, cost_change, gmax, step_norm, rho, radius, k);
+            printf("%4d  %.6e   % .2e    %.2e   %.2e  % .2e  %.2e  pcg %d eta %.1e%s\n", iter, cost, cost_change, gmax, step_norm, rho, radius, k, eta_k,
+                   capped ? " CAP" : "");
     }
     s.num_iterations = iter; s.final_cost = cost; s.final_radius = radius; s.final_gradient_max_norm = gmax;
     s.seconds_total = wall() - t0;
     if (summary) *summary = s;
-    if (pcg_iterations_total) *pcg_iterations_total = pcg_total;
+    if (pcg_iterations_total) *pcg_iterations_total = ps.iterations_total;
+    g->last_pcg = ps;
+    return STBA_OK;
+}
+
+int stba_pg_last_pcg_summary(stba_pg* g, stba_pcg_summary* out) {
+    if (!g || !out) return fail(STBA_ERR_INVALID_ARGUMENT, "null argument");
+    *out = g->last_pcg;
     return STBA_OK;
 }
 

@@ -3,7 +3,13 @@ the oracle -- the checker every GPU parity test trusts -- cannot drift unnoticed
   st20  the reference's own bundle-adjustment size (29 cameras x 600 landmarks, scenes.st20_scene())
   c2    BASELINE config C2 (2 cameras, 5 000 landmarks, scenes.two_view_scene())
 for each: the LM cost trace, the accept/reject sequence, the iteration count and the final parameters (all cameras,
-the first 20 landmarks).  Run from the repository root:  python tests/golden/make_oracle_traces.py
+the first 20 landmarks); and (round 4)
+  c4    BASELINE config C4 (10 000 SE3 nodes, 39 999 edges, scenes.pose_graph_scene()) solved by the oracle's matrix-free LM
+        (orc_pg_solve_sparse: certified conjugate gradients): trace, final cost, ATE, every 50th final pose.  The generator
+        also solves the FIRST damped system of that problem with a sparse direct solver (scipy splu) and refuses to write
+        the file unless the oracle's first trial cost agrees to 1e-9 -- the linear algebra of the C4-size oracle is checked
+        against an independent solver at full size once, here (minutes), not in the test suite.
+Run from the repository root:  python tests/golden/make_oracle_traces.py
 
 This does NOT pin the oracle against the reference: the reference cannot be built here (Ceres, Sophus, Eigen are
 absent) and holds no vectors for this leg -- "parity unpinned"  stands.  It pins the oracle
@@ -33,13 +39,58 @@ def run(name, s, O):
             "final_cams": o.cams.reshape(-1).tolist(), "final_pts_head": o.pts[:20].reshape(-1).tolist()}
 
 
+def first_step_direct(s, O):
+    """cost after ONE exact LM step from the initial point, the damped normal equations solved by scipy's sparse LU"""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spl
+    ei, ej = s["edge_i"], s["edge_j"]
+    n, m = len(s["poses0"]), len(ei)
+    pg = O.PG(s["poses0"], ei, ej, s["meas"], s["node_fixed"])
+    cost, r, Ji, Jj = pg.evaluate()
+    rows = np.repeat(np.arange(6 * m).reshape(m, 6, 1), 6, 2)
+    ci = 6 * ei[:, None, None] + np.arange(6)[None, None, :] + np.zeros((m, 6, 1), int)
+    cj = 6 * ej[:, None, None] + np.arange(6)[None, None, :] + np.zeros((m, 6, 1), int)
+    J = sp.csr_matrix((np.concatenate([Ji.ravel(), Jj.ravel()]), (np.concatenate([rows.ravel()] * 2), np.concatenate([ci.ravel(), cj.ravel()]))),
+                      shape=(6 * m, 6 * n))
+    H = (J.T @ J).tocsc()
+    g = J.T @ r.ravel()
+    diag = H.diagonal()
+    scale = 1.0 / (1.0 + np.sqrt(diag))
+    D = np.clip(diag * scale ** 2, 1e-6, 1e32) / 1e4 / scale ** 2
+    dx = spl.splu((H + sp.diags(D)).tocsc()).solve(-g)
+    newp = pg.poses.copy()
+    for k in range(n):
+        if not s["node_fixed"][k]:
+            newp[k] = O.se3_retract(pg.poses[k], dx[6 * k:6 * k + 6])
+    return O.PG(newp, ei, ej, s["meas"], s["node_fixed"]).evaluate(jac=False)[0]
+
+
+def run_c4(O, scenes):
+    s = scenes.pose_graph_scene(n_nodes=10000, loops_per_node=3, seed=4)
+    o = O.PG(s["poses0"], s["edge_i"], s["edge_j"], s["meas"], s["node_fixed"])
+    summ, tr, cg, worst = o.solve_sparse()
+    c_direct = first_step_direct(s, O)
+    assert abs(tr[1, 0] - c_direct) <= 1e-9 * c_direct, (tr[1, 0], c_direct)
+    return {"scene": "pose_graph_scene(n_nodes=10000, loops_per_node=3, seed=4)", "n_nodes": int(o.n), "n_edges": int(o.ne),
+            "num_iterations": int(summ.num_iterations), "termination_type": int(summ.termination_type),
+            "termination_reason": int(summ.termination_reason),
+            "initial_cost": float(summ.initial_cost), "final_cost": float(summ.final_cost),
+            "cost_trace": [float(x) for x in tr[:, 0]], "accepted": [int(x) for x in tr[:, 6]],
+            "radius_trace": [float(x) for x in tr[:, 5]], "cg_iterations_total": int(cg), "worst_linear_residual": float(worst),
+            "first_trial_cost_sparse_direct": float(c_direct),
+            "ate_initial": float(O.pg_ate(s["poses_true"], s["poses0"])), "ate_final": float(O.pg_ate(s["poses_true"], o.poses)),
+            "final_poses_every_50th": o.poses[::50].reshape(-1).tolist()}
+
+
 if __name__ == "__main__":
     import oracle_py as O
     O.build()
     scenes = importlib.import_module("slam-tricks_amd.scenes")
     out = {"generator": "tests/golden/make_oracle_traces.py", "oracle": "oracle/oracle.c (self-regression, not a reference pin)",
            "st20": run("st20_scene()", scenes.st20_scene(), O),
-           "c2": run("two_view_scene(n_pts=5000)", scenes.two_view_scene(n_pts=5000), O)}
+           "c2": run("two_view_scene(n_pts=5000)", scenes.two_view_scene(n_pts=5000), O),
+           "c4": run_c4(O, scenes)}
     with open(os.path.join(HERE, "oracle_traces.json"), "w") as f:
         json.dump(out, f, indent=0)
     print({k: (v["num_iterations"], v["final_cost"]) for k, v in out.items() if isinstance(v, dict)})
+    print("c4: first trial cost", out["c4"]["cost_trace"][1], "sparse direct", out["c4"]["first_trial_cost_sparse_direct"])

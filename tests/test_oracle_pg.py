@@ -95,3 +95,24 @@ def test_pg_matrix_free_first_step_against_a_sparse_direct_solve(O, scenes):
     assert worst <= 1e-10
     assert abs(tr[1, 0] - c_direct) <= 1e-9 * c_direct
     assert np.abs(pg.poses - newp).max() < 1e-9
+
+
+def test_c4_oracle_has_not_drifted_from_its_frozen_trace(O, scenes):
+    """tests/golden/oracle_traces.json["c4"]: the C4-size oracle (10 000 nodes, matrix-free LM) against what it produced when
+    the fixture was made -- and the fixture's generator held its first step against a sparse direct solve of the same system"""
+    import json
+    import os
+    from conftest import GOLDEN
+    with open(os.path.join(GOLDEN, "oracle_traces.json")) as f:
+        g = json.load(f)["c4"]
+    s = scenes.pose_graph_scene(n_nodes=10000, loops_per_node=3, seed=4)
+    o = O.PG(s["poses0"], s["edge_i"], s["edge_j"], s["meas"], s["node_fixed"])
+    assert (o.n, o.ne) == (g["n_nodes"], g["n_edges"])
+    summ, tr, cg, worst = o.solve_sparse()
+    assert summ.num_iterations == g["num_iterations"] and summ.termination_reason == g["termination_reason"]
+    assert [int(x) for x in tr[:, 6]] == g["accepted"]
+    assert np.allclose(tr[:, 0], g["cost_trace"], rtol=1e-9)
+    assert worst <= 1e-10
+    assert abs(g["cost_trace"][1] - g["first_trial_cost_sparse_direct"]) <= 1e-9 * g["cost_trace"][1]
+    assert np.abs(o.poses[::50].reshape(-1) - np.array(g["final_poses_every_50th"])).max() < 1e-7
+    assert abs(O.pg_ate(s["poses_true"], o.poses) - g["ate_final"]) < 1e-9

@@ -209,7 +209,9 @@ def test_pose_graph_two_edge_shards_on_one_gpu(scenes):
         sh = sharding.make_pg_shard(s, rank, world)
         e = st.PGEngine(sh["poses0"], sh["edge_i"], sh["edge_j"], sh["meas"], sh["node_fixed"])
         e.set_allreduce(make_hook(rank), rank, world)
-        summ, tr, npcg = e.solve(max_num_iterations=6)
+        # (exact LM steps, so that the traces can be compared digit for digit: with the production forcing sequence the
+        # one-rank and the sharded PCG stop on different sides of the threshold now and then)
+        summ, tr, npcg = e.solve(max_num_iterations=6, pcg=e.pcg_options(forcing_eta0=0.0))
         out[rank] = (summ, tr, npcg, e.get_poses())
 
     th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
@@ -219,7 +221,7 @@ def test_pose_graph_two_edge_shards_on_one_gpu(scenes):
         t.join(timeout=300)
     assert all(o is not None for o in out)
     e1 = st.PGEngine(s["poses0"], s["edge_i"], s["edge_j"], s["meas"], s["node_fixed"])
-    s1, tr1, n1 = e1.solve(max_num_iterations=6)
+    s1, tr1, n1 = e1.solve(max_num_iterations=6, pcg=e1.pcg_options(forcing_eta0=0.0))
     p1 = e1.get_poses()
     for rank in range(world):
         summ, tr, npcg, poses = out[rank]

@@ -38,8 +38,14 @@ for N in "$SIZES".split():
     d["ms_per_factorisation_under_the_profiler"] = ms
     n = int(N); nblk = (n + 1 + 127) // 128
     # one v_mfma_f64_16x16x4_f64 = 2048 flop = 64 cycles of one SIMD's FP64 matrix pipe (profiles/mfma_f64_microbench.txt)
+    # SQ_VALU_MFMA_BUSY_CYCLES: busy cycles of the matrix pipes summed over the 1024 SIMDs (measured: exactly 64 per
+    # SQ_INSTS_MFMA).  GRBM_GUI_ACTIVE comes back summed over the 8 XCDs (43.7 M for a 2.34 ms kernel = 8 x 5.46 M cycles at
+    # 2.33 GHz), so the kernel's shader cycles are GRBM_GUI_ACTIVE / 8 and
+    #   MFMA utilisation = busy cycles / (1024 SIMDs x kernel cycles)
     if "SQ_VALU_MFMA_BUSY_CYCLES" in d and "GRBM_GUI_ACTIVE" in d and d["GRBM_GUI_ACTIVE"] > 0:
-        d["mfma_busy_frac_of_gui_active_per_simd"] = d["SQ_VALU_MFMA_BUSY_CYCLES"] / (d["GRBM_GUI_ACTIVE"] * 256 * 4)
+        d["kernel_shader_cycles"] = d["GRBM_GUI_ACTIVE"] / 8.0
+        d["mfma_utilisation"] = d["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * d["kernel_shader_cycles"])
+        if d.get("SQ_INSTS_MFMA"): d["mfma_busy_cycles_per_instruction"] = d["SQ_VALU_MFMA_BUSY_CYCLES"] / d["SQ_INSTS_MFMA"]
     if "SQ_VALU_MFMA_BUSY_CYCLES" in d and d.get("SQ_BUSY_CU_CYCLES"):
         d["mfma_busy_over_busy_cu_cycles"] = d["SQ_VALU_MFMA_BUSY_CYCLES"] / d["SQ_BUSY_CU_CYCLES"]
     if d.get("TCC_HIT_sum") is not None and d.get("TCC_MISS_sum") is not None and d["TCC_HIT_sum"] + d["TCC_MISS_sum"] > 0:
