@@ -131,6 +131,33 @@ def pg_bytes_per_edge(n_nodes, n_edges):
     return lin, mv
 
 
+def pmc_file(kind):
+    """newest profiles/r<N>_pmc_<kind>.json (tools/pmc_round.sh) -> (relative path, dict) or (None, None)"""
+    import glob
+    import re
+    best = None
+    for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_" + kind + ".json")):
+        m = re.match(r"r(\d+)", os.path.basename(f))
+        if m and (best is None or int(m.group(1)) >= best[0]):
+            best = (int(m.group(1)), f)
+    if best is None:
+        return None, None
+    try:
+        with open(best[1]) as fh:
+            return os.path.relpath(best[1], ROOT), json.load(fh)
+    except Exception:
+        return None, None
+
+
+def traffic_source(path, d, what):
+    """says which file a `traffic` figure comes from, the build it was measured on and whether that is THIS build (same source hash)"""
+    head = (d or {}).get("head", "unknown")
+    mine = build_head()
+    same = ("src:" in head and "src:" in mine and head.split("src:")[1] == mine.split("src:")[1])
+    return {"file": path, "what": what, "measured_on_build": head, "this_build": mine, "same_sources_as_this_build": bool(same),
+            "note": "rocprofv3 PMC passes are separate runs (tools/pmc_round.sh); the figure is recorded there, not measured inside bench.py"}
+
+
 def build_head():
     """git head the library was built from (slam-tricks_amd/BUILD_HEAD, written by build.py where .git exists)"""
     try:
@@ -250,6 +277,7 @@ def main():
     ap.add_argument("--pts", type=int, default=100000)
     ap.add_argument("--obs-per-pt", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-library-baseline", action="store_true", help="skip the rocSOLVER potrf cross-check")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: CPU rendezvous test of the launch path")
     ap.add_argument("--hook", default="native", choices=["native", "torch"], help="cross-rank sum: native RCCL communicator | torch.distributed hook")
     ap.add_argument("--config", default="c5", choices=["c5", "c4"], help="c5: the headline BA workload (default); c4: the 10k-node pose graph")
@@ -434,32 +462,34 @@ def main():
         chol_tflops = chol_flops / (ms_factor * 1e-3) / 1e12
         prof = st.cholesky_profile(nred)                          # stage-per-kernel schedule (diagnostic)
         syrk_tflops = prof["syrk_flops"] / (prof["ms_syrk"] * 1e-3) / 1e12 if prof["ms_syrk"] > 0 else 0.0
-        # HBM bytes per launch from the PMC passes (tools/pmc_jacobian.sh -> profiles/pmc_jacobian.json);
-        # only valid for the C5 shape it was collected on
-        traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "pmc_jacobian.json")) as f:
-                pj = json.load(f)
-            if local_obs == 1000000:
-                traffic = pj["hbm_bytes_per_launch"]
-        except Exception:
-            pass
-        roof_jac = {"kernel": "ba_linearize_kernel<cams-in-LDS, with-Jacobian> (residual + compact 64 B Jacobian per observation)", "bound": "hbm", "achieved": jac_gbs,
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": jac_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                    "traffic_source": "profiles/pmc_jacobian.json (PMC passes of tools/pmc_jacobian.sh on the C5 shape; a recorded figure, not measured in this run)",
-                    "ms_per_launch": ms_jac, "algorithmic_bytes_per_launch": jac_bytes, "algorithmic_bytes_per_observation": BYTES_PER_OBS_JAC}
-        chol_traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "pmc_chol.json")) as f:
-                pc = json.load(f)
-            if nred == 6000:
-                chol_traffic = pc["hbm_bytes_per_launch"]      # PMC passes of tools/pmc_chol.sh, C5 shape only
-        except Exception:
-            pass
+        # HBM bytes per launch from the PMC passes of the round (tools/pmc_round.sh -> profiles/r<N>_pmc_*.json, stamped with the
+        # build they were taken on); only valid for the C5 shape they were collected on
+        pj_path, pj = pmc_file("jacobian")
+        traffic = pj["hbm_bytes_per_launch"] if (pj and local_obs == 1000000) else None
+        # IN the LM iteration the kernel runs behind the back-substitution with cold caches: its time there is the 'cost' phase of the
+        # instrumented run (the speculative linearisation at the trial point IS that kernel; it includes the event packets around it);
+        # the back-to-back figure (the kernel alone, 20 launches) is kept beside it
+        ms_jac_iter = float(phases[4]) if (world == 1 and phases[4] > 0) else None
+        ms_for_roof = ms_jac_iter if ms_jac_iter else ms_jac
+        roof_jac = {"kernel": "ba_linearize_kernel<cams-in-LDS, with-Jacobian> (residual + compact 64 B Jacobian per observation)", "bound": "hbm",
+                    "achieved": jac_bytes / (ms_for_roof * 1e-3) / 1e9,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": jac_bytes / (ms_for_roof * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+                    "traffic_source": traffic_source(pj_path, pj, "FETCH_SIZE (doubled, gfx950) + WRITE_SIZE per launch, C5 shape"),
+                    "ms_per_launch": ms_for_roof,
+                    "timing": "in the LM iteration: phase 'ms_cost' of the instrumented run (hipEvents around the kernel on the engine stream)" if ms_jac_iter
+                              else "back-to-back launches of the kernel alone",
+                    "solo": {"ms_per_launch": ms_jac, "achieved": jac_gbs, "frac": jac_gbs / HBM_PEAK_GBS,
+                             "timing": "the kernel alone, 20 back-to-back launches (stba_ba_time_linearize)"},
+                    "algorithmic_bytes_per_launch": jac_bytes, "algorithmic_bytes_per_observation": BYTES_PER_OBS_JAC}
+        pc_path, pc = pmc_file("chol_mfma")
+        pc6 = (pc or {}).get("sizes", {}).get("6000") if nred == 6000 else None
+        chol_traffic = pc6.get("hbm_bytes_per_launch") if pc6 else None
         roof_chol = {"kernel": "chol_mega_kernel (persistent dataflow Cholesky, v_mfma_f64_16x16x4_f64)",
                      "bound": "mfma", "achieved": chol_tflops, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": chol_tflops / FP64_MFMA_PEAK_TFLOPS, "traffic": chol_traffic,
-                     "traffic_source": "profiles/pmc_chol.json (PMC passes of tools/pmc_chol.sh at n = 6000; a recorded figure, not measured in this run)",
+                     "traffic_source": traffic_source(pc_path, pc, "FETCH_SIZE (doubled, gfx950) + WRITE_SIZE per factorisation at n = 6000"),
+                     "mfma_utilisation_pmc": pc6.get("mfma_utilisation") if pc6 else None,
+                     "l2_hit_rate_pmc": pc6.get("l2_hit_rate") if pc6 else None,
                      "ms_per_launch": ms_factor,
                      "algorithmic_flops_per_launch": chol_flops, "launches_per_lm_iteration": 1,
                      "microbench_ceiling": FP64_MFMA_MEASURED_CEILING_TFLOPS,
@@ -468,17 +498,22 @@ def main():
         # row).  Peak = what the microbenchmark retires with THIS address pattern (random block per lane, 36 consecutive
         # doubles, 37-double block stride): profiles/lds_atomic_f64_microbench.txt, 2.38 lane-ops per cycle and CU
         ms_schur, schur_atomics, schur_pairs = eng.time_schur(10)
+        pk_path, pk = pmc_file("assembly_kernels")
+        schur_traffic = None
+        if pk and local_obs == 1000000:
+            for kname, kd in pk.get("kernels", {}).items():
+                if "schur_pairs" in kname and "hbm_bytes_per_launch_raw" in kd:
+                    schur_traffic = kd["hbm_bytes_per_launch_raw"]
         LDS_ATOMIC_PEAK = 1459.2      # G lane-ops/s, all 256 CUs, Schur pattern (7.5 per cycle and CU without conflicts: 4617 G/s)
         out["roofline_schur"] = {"kernel": "ba_schur_pairs_kernel (row-wise Schur complement, LDS accumulation; camera blocks on the way)",
                                  "bound": "lds-atomic", "achieved": schur_atomics / (ms_schur * 1e-3) / 1e9, "peak": LDS_ATOMIC_PEAK,
                                  "unit": "G ds_add_f64 lane-ops/s", "frac": schur_atomics / (ms_schur * 1e-3) / 1e9 / LDS_ATOMIC_PEAK,
                                  "ms_per_launch": ms_schur, "lds_atomics_per_launch": schur_atomics, "pairs_per_launch": schur_pairs,
                                  "floor_ms": schur_atomics / (LDS_ATOMIC_PEAK * 1e9) * 1e3,
-                                 "traffic": 897.2e6 if local_obs == 1000000 else None,
-                                 "traffic_source": "profiles/r3_f_pmc_assembly_kernels.json (rocprofv3 --pmc, separate passes: FETCH_SIZE 699.7 MB + WRITE_SIZE "
-                                                   "197.5 MB per launch at C5; a recorded figure, not measured in this run).  The second bound of the "
-                                                   "kernel: 65 MB of Jacobian records are fetched ~6 times over by the pair loop (496 MB), the diagonal slices' "
-                                                   "two register passes over their camera's records add ~200 MB; 144 MB of S zeroed + 40 MB of blocks written"}
+                                 "traffic": schur_traffic,
+                                 "traffic_source": traffic_source(pk_path, pk, "FETCH_SIZE + WRITE_SIZE per launch at C5, RAW (the pair loop gathers 64-B records: "
+                                                                  "narrow requests, not the wide coalesced reads the gfx950 doubling is for); the second bound of the "
+                                                                  "kernel: 65 MB of Jacobian records are fetched several times over by the pair loop")}
         # the dominant kernel by device time carries the headline roofline object
         out["roofline"] = roof_chol if ms_factor > ms_jac else roof_jac
         out["roofline_jacobian"] = roof_jac
@@ -594,6 +629,50 @@ def main():
             except Exception:
                 scene_file = None
             out["ceres_baseline"] = ceres_row(scene_file, n_gate) if scene_file else ceres_row("", n_gate)
+        out["build_head"] = build_head()
+        # ---- what landmark sharding can and cannot buy on this problem, from THIS run's phase times (a model, printed so that a
+        # measured N-GPU point can be held against it): the factorisation + backward substitution are replicated on every rank,
+        # the Jacobian / Schur / back-substitution / trial-cost work divides by N, and one packed all-reduce of the reduced system
+        # per build is added (bounds: a ring over one xGMI link, 48 GB/s each way; reduce-scatter + all-gather over all N - 1 links)
+        if local_counts.sum() > 0:
+            ph = out["phase_ms_per_step"]
+            t_repl = ph["ms_solve"]
+            t_shard = max(0.0, ph["ms_linearize"] + ph["ms_schur"] - out["allreduce_ms"] + ph["ms_backsub"] + ph["ms_cost"]) * world
+            t_other = max(0.0, ms_step - (ph["ms_linearize"] + ph["ms_schur"] + ph["ms_solve"] + ph["ms_backsub"] + ph["ms_cost"]))
+            ar_bytes = out["allreduce_bytes"] if world > 1 else 40.7e6 * (n_cams / 1000.0) ** 2
+            pred = {}
+            for N in (1, 2, 4, 8):
+                ring = 0.0 if N == 1 else 2.0 * (N - 1) / N * ar_bytes / 48e9 * 1e3
+                direct = 0.0 if N == 1 else 2.0 * ar_bytes / N / 48e9 * 1e3
+                lo, hi = t_repl + t_other + t_shard / N + direct, t_repl + t_other + t_shard / N + ring
+                pred[str(N)] = {"ms_per_step_best": lo, "ms_per_step_ring": hi, "it_per_s_best": 1e3 / lo, "it_per_s_ring": 1e3 / hi}
+            base = pred["1"]["ms_per_step_best"]
+            out["predicted_scaling"] = {"model": "T(N) = replicated (factorisation + backward substitution) + other + sharded / N + all-reduce(N); terms from this run's "
+                                                 "phase_ms_per_step; all-reduce of the packed reduced system: ring over one 48 GB/s xGMI link | direct over N - 1 links",
+                                        "replicated_ms": t_repl, "sharded_ms_total": t_shard, "other_ms": t_other, "allreduce_bytes": ar_bytes,
+                                        "per_gpus": pred, "speedup_at_8_best": base / pred["8"]["ms_per_step_best"],
+                                        "speedup_at_8_ring": base / pred["8"]["ms_per_step_ring"],
+                                        "note": "strong scaling of C5 is bounded by the replicated factorisation (DESIGN.md 6); a problem with few cameras and many "
+                                                "landmarks (python bench.py --gpus N --cams 100 --pts 1000000) is where landmark sharding scales"}
+        # ---- library cross-check: rocSOLVER's potrf + potrs of the same size on the same box, a stated baseline
+        # like the CPU leg.  librocsolver is dlopen'ed by the TOOL, never by libstba.
+        if world == 1 and not args.no_library_baseline:
+            try:
+                import importlib.util
+                spec = importlib.util.spec_from_file_location("rocsolver_potrf", os.path.join(ROOT, "tools", "rocsolver_potrf.py"))
+                mod = importlib.util.module_from_spec(spec)
+                spec.loader.exec_module(mod)
+                lb = mod.time_potrf(nred, reps=3)
+                if lb.get("found"):
+                    out["library_baseline"] = {"library": "rocSOLVER (rocsolver_dpotrf + rocsolver_dpotrs, one right-hand side), dlopen'ed by tools/rocsolver_potrf.py",
+                                               "n": nred, "potrf_ms": lb["potrf_ms_median"], "potrs_ms": lb["potrs_ms_median"], "potrf_tflops": lb["potrf_tflops"],
+                                               "stba_factor_ms": ms_factor, "stba_backward_ms": ms_bwd,
+                                               "rocsolver_over_stba": (lb["potrf_ms_median"] + lb["potrs_ms_median"]) / (ms_factor + ms_bwd),
+                                               "kind": "baseline only: never linked into or called by libstba.so"}
+                else:
+                    out["library_baseline"] = {"found": False}
+            except Exception as e:      # noqa: BLE001
+                out["library_baseline"] = {"found": False, "error": repr(e)}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

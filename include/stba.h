@@ -151,13 +151,29 @@ typedef struct stba_ba stba_ba;
  * order (the engine regroups them landmark-major); obs_feat: n_obs*2 normalised image coords.
  * cam_fixed: n_cams*6 bytes (1 = dof constant; NULL = all free; order [rot(3), pos(3)]);
  * pt_fixed: n_pts bytes (1 = landmark constant; NULL = all free).
- * hip_stream: hipStream_t to enqueue on (NULL = the engine creates its own). */
+ * hip_stream: hipStream_t to enqueue on (NULL = the engine creates its own).
+ * Limit: the Schur complement kernel works from a plan with one 16-byte record per PAIR of observations of the same
+ * landmark (sum over landmarks of k (k + 1) / 2, k = cameras seeing it; 5.5 M at 1000 cameras x 100 000 landmarks x 10
+ * observations each), built once here, on the host and on the device.  More than 2^30 pairs, or a plan larger than half of
+ * the free device memory, is refused with STBA_ERR_INVALID_ARGUMENT (very dense visibility: every camera sees everything). */
 int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double* cams,
                    const double* pts, const int* obs_cam, const int* obs_pt, const double* obs_feat,
                    const unsigned char* cam_fixed, const unsigned char* pt_fixed, void* hip_stream);
 int stba_ba_destroy(stba_ba* ba);
 int stba_ba_set_params(stba_ba* ba, const double* cams, const double* pts);
 int stba_ba_get_params(stba_ba* ba, double* cams, double* pts);
+/* BA-SHAPED problems whose factor is NOT the built-in reprojection (the reference's BA cost is a generic
+ * DynamicAutoDiffCostFunction, test_ceres.h:56,109-121: a robustified, scaled or otherwise different 4+3+3 -> 2 factor must not
+ * fall back to dense normal equations).  With a host lineariser the residuals and Jacobians of every observation come from the
+ * caller -- the C++ shim evaluates the user's cost functions in bulk -- and everything behind them runs on the device
+ * unchanged: landmark blocks, Schur complement, dense factorisation, back-substitution, manifold update, LM control.
+ *   fn(user, cams[n_cams*7], pts[n_pts*3], r[n_obs*2], Jc, Jp) -> 0 on success
+ * in the CALLER's observation order (the order given to stba_ba_create; obs_feat is not used in this mode);
+ * Jc[n_obs*12]: 2x6 row-major w.r.t. the camera's LOCAL coordinates [dtheta(3) of q <- q (x) exp(dtheta), dt(3)];
+ * Jp[n_obs*6]: 2x3 w.r.t. the landmark; Jc = Jp = NULL when only the cost of a trial point is wanted.
+ * The callback runs on the calling thread, between kernels: the LM loop does not overlap host and device work in this mode. */
+typedef int (*stba_ba_linearize_fn)(void* user, const double* cams, const double* pts, double* r, double* Jc, double* Jp);
+int stba_ba_set_host_linearizer(stba_ba* ba, stba_ba_linearize_fn fn, void* user);
 /* multi-GPU: this engine holds one landmark shard; all cameras are replicated.  The hook sums
  * the packed reduced system / scalars across ranks.  rank 0 owns the once-only diagonal terms. */
 int stba_ba_set_allreduce(stba_ba* ba, stba_allreduce_fn fn, void* user, int rank, int world_size);

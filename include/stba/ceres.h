@@ -31,6 +31,8 @@
 //     proj(R^T (L - t)) - feature at generic points, its Jet Jacobian equals the closed form)
 //     -> fully device-resident BA engine (stba_ba_*): residuals and Jacobians are computed by the
 //     HIP kernel too, the user functor is never called during the solve;
+//   * a BA-SHAPED problem (every block {4, 3, 3} -> 2, quaternion chart) with any OTHER factor -> the device engine with the
+//     user's cost functions evaluated on the host in bulk ("gpu-ba-hostjac", stba_ba_set_host_linearizer);
 //   * any other problem -> the callback path of stba_dense_solve (<= 4096 local parameters).
 // There is no CPU solver behind this header: without a HIP device Solve() reports FAILURE.
 #ifndef STBA_CERES_H
@@ -434,7 +436,7 @@ public:
         double initial_cost = 0, final_cost = 0, total_time_in_seconds = 0;
         int num_successful_steps = 0, num_unsuccessful_steps = 0;
         std::vector<IterationSummary> iterations;
-        std::string execution_path;   // "gpu-ba" | "gpu-dense-callback"
+        std::string execution_path;   // "gpu-ba" | "gpu-ba-hostjac" | "gpu-dense-callback"
         std::string BriefReport() const {
             char buf[512];
             const char* t = termination_type == CONVERGENCE ? "CONVERGENCE" : termination_type == NO_CONVERGENCE ? "NO_CONVERGENCE"
@@ -595,7 +597,9 @@ struct BaLayout {
     std::vector<double> feat;
 };
 
-inline bool DetectBa(Problem& p, BaLayout* L) {
+// probe = false: only the SHAPE is required (blocks 4 / 3 / 3 -> 2 residuals, quaternion chart on the first block, no bounds);
+// the factor itself stays the user's (host-linearised path, see Solve) and L->feat is left at zero.
+inline bool DetectBa(Problem& p, BaLayout* L, bool probe = true) {
     if (p.residuals().empty()) return false;
     std::map<std::pair<int, int>, int> cam_of;   // (rot block, pos block) -> camera index
     std::map<int, int> pt_of;
@@ -603,7 +607,11 @@ inline bool DetectBa(Problem& p, BaLayout* L) {
     for (auto& r : p.residuals()) {
         auto* f = dynamic_cast<ReprojectionFactor*>(r.cost);
         double feature[2];
-        if (f) { feature[0] = f->fx(); feature[1] = f->fy(); }
+        if (!probe) {
+            const auto& sz = r.cost->parameter_block_sizes();
+            if (r.cost->num_residuals() != 2 || sz.size() != 3 || sz[0] != 4 || sz[1] != 3 || sz[2] != 3 || r.blocks.size() != 3) return false;
+            feature[0] = feature[1] = 0.0;
+        } else if (f) { feature[0] = f->fx(); feature[1] = f->fy(); }
         else {
             // the user's own cost function (test_ceres.h:111-121): accepted iff it IS the reprojection factor
             if (!ProbeReprojectionValue(r.cost, feature)) return false;
@@ -663,7 +671,43 @@ inline void BaCopyOut(void* user) {
         std::memcpy(s->p->blocks()[s->L->pt_block[j]].ptr, &s->pts[j * 3], 3 * sizeof(double));
 }
 
-inline bool SolveBa(const Solver::Options& o, Problem* p, const BaLayout& L, Solver::Summary* sum) {
+// host lineariser of the "gpu-ba-hostjac" path (stba_ba_set_host_linearizer): the user's cost functions, evaluated in bulk at
+// the engine's current parameters, in residual-block order; the camera Jacobian is composed with the rotation block's chart
+// (2x4 . 4x3) next to the 2x3 position block.  options.num_threads > 1 (and an OpenMP build) evaluates blocks in parallel,
+// as Ceres does -- the reference pins num_threads = 1 (test_ceres.h:143).
+struct BaHostCtx { Problem* p; const BaLayout* L; int threads; };
+inline int BaHostLinearize(void* user, const double* cams, const double* pts, double* r, double* Jc, double* Jp) {
+    auto* c = static_cast<BaHostCtx*>(user);
+    auto& res = c->p->residuals();
+    const int no = (int)res.size();
+    int bad = 0;
+#if defined(_OPENMP)
+#pragma omp parallel for schedule(static) num_threads(c->threads > 1 ? c->threads : 1) reduction(+ : bad)
+#endif
+    for (int i = 0; i < no; ++i) {
+        const double* q = cams + (size_t)c->L->obs_cam[i] * 7;
+        const double* prm[3] = {q, q + 4, pts + (size_t)c->L->obs_pt[i] * 3};
+        double Jq[8], Jt[6], JL[6];
+        double* J[3] = {Jq, Jt, JL};
+        if (!res[i].cost->Evaluate(prm, r + (size_t)i * 2, Jc ? J : nullptr)) { ++bad; continue; }
+        if (!Jc) continue;
+        double plus[12];
+        const LocalParameterization* lp = c->p->blocks()[res[i].blocks[0]].local;
+        if (!lp->ComputeJacobian(q, plus)) { ++bad; continue; }
+        for (int row = 0; row < 2; ++row) {
+            for (int l = 0; l < 3; ++l) {
+                double sacc = 0.0;
+                for (int g = 0; g < 4; ++g) sacc += Jq[row * 4 + g] * plus[g * 3 + l];
+                Jc[(size_t)i * 12 + row * 6 + l] = sacc;
+                Jc[(size_t)i * 12 + row * 6 + 3 + l] = Jt[row * 3 + l];
+                Jp[(size_t)i * 6 + row * 3 + l] = JL[row * 3 + l];
+            }
+        }
+    }
+    return bad ? 1 : 0;
+}
+
+inline bool SolveBa(const Solver::Options& o, Problem* p, const BaLayout& L, Solver::Summary* sum, bool host_jacobians = false) {
     const int nc = (int)L.rot_block.size(), np = (int)L.pt_block.size(), no = (int)L.obs_cam.size();
     BaSync sync{nullptr, p, &L, std::vector<double>((size_t)nc * 7), std::vector<double>((size_t)np * 3)};
     std::vector<unsigned char> cam_fixed((size_t)nc * 6, 0), pt_fixed((size_t)np, 0);
@@ -681,6 +725,12 @@ inline bool SolveBa(const Solver::Options& o, Problem* p, const BaLayout& L, Sol
     int rc = stba_ba_create(&sync.ba, nc, np, no, sync.cams.data(), sync.pts.data(), L.obs_cam.data(), L.obs_pt.data(),
                             L.feat.data(), cam_fixed.data(), pt_fixed.data(), nullptr);
     if (rc != STBA_OK) { sum->termination_type = FAILURE; sum->message = std::string("stba_ba_create: ") + stba_last_error(); return false; }
+    BaHostCtx hctx{p, &L, o.num_threads};
+    if (host_jacobians && (rc = stba_ba_set_host_linearizer(sync.ba, &BaHostLinearize, &hctx)) != STBA_OK) {
+        sum->termination_type = FAILURE; sum->message = std::string("stba_ba_set_host_linearizer: ") + stba_last_error();
+        stba_ba_destroy(sync.ba);
+        return false;
+    }
     stba_lm_options co = ToC(o);
     stba_lm_summary cs;
     std::vector<double> trace((size_t)(o.max_num_iterations + 1) * STBA_TRACE_COLS, 0.0);
@@ -835,7 +885,17 @@ inline void Solve(const Solver::Options& options, Problem* problem, Solver::Summ
     bool ba = !force_cb && internal::DetectBa(*problem, &L);
     if (ba)
         for (int rb : L.rot_block) ba = ba && internal::UsesQuaternionRightPlus(problem->blocks()[rb].local);
-    if (ba) { summary->execution_path = "gpu-ba"; internal::SolveBa(options, problem, L, summary); }
+    if (ba) { summary->execution_path = "gpu-ba"; internal::SolveBa(options, problem, L, summary); return; }
+    // BA-SHAPED, but not (or not to be taken for) the built-in factor: every residual block is {quaternion 4, position 3,
+    // landmark 3} -> 2 with the quaternion right-plus chart.  The user's cost functions are evaluated on the host, in bulk, into
+    // the device engine's residual / Jacobian buffers, and the Schur complement, the factorisation, the back-substitution and the
+    // LM loop run on the device as for the built-in factor ("gpu-ba-hostjac"): any size the engine takes, where the dense
+    // callback path below stops at 4096 local parameters.  (The reference's BA cost IS a generic functor: test_ceres.h:56.)
+    internal::BaLayout L2;
+    bool shape = internal::DetectBa(*problem, &L2, false);
+    if (shape)
+        for (int rb : L2.rot_block) shape = shape && internal::UsesQuaternionRightPlus(problem->blocks()[rb].local);
+    if (shape) { summary->execution_path = "gpu-ba-hostjac"; internal::SolveBa(options, problem, L2, summary, true); }
     else { summary->execution_path = "gpu-dense-callback"; internal::SolveDense(options, problem, summary); }
 }
 

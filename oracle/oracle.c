@@ -1170,7 +1170,7 @@ static void se2_exp_f(const float d[3], float T[4]) {
     const float th = d[2];
     const float c = cosf(th), s = sinf(th);
     float sbt, omcbt;                                  /* sin(theta)/theta, (1 - cos(theta))/theta */
-    if (fabsf(th) < 1e-10f) {                          /* Sophus: Constants<float>::epsilon() */
+    if (fabsf(th) < 1e-5f) {                           /* Sophus: Constants<float>::epsilon() = 1e-5f */
         const float th2 = th * th;
         sbt = 1.0f - (1.0f / 6.0f) * th2;
         omcbt = 0.5f * th - (1.0f / 24.0f) * th * th2;
@@ -1205,8 +1205,10 @@ int orc_icp_se2_gauss_newton(int n, const float* pc1, const float* pc2, int iter
         /* T <- exp(delta) * T  (:46) */
         const float c = E[0] * T[0] - E[1] * T[1], s = E[1] * T[0] + E[0] * T[1];
         const float tx = E[0] * T[2] - E[1] * T[3] + E[2], ty = E[1] * T[2] + E[0] * T[3] + E[3];
-        const float nrm = sqrtf(c * c + s * s);                                               /* SO2 stays normalised */
-        T[0] = c / nrm; T[1] = s / nrm; T[2] = tx; T[3] = ty;
+        /* Sophus SO2 product: no square root -- the first-order factor 2 / (1 + |z|^2), applied only when |z|^2 != 1 */
+        const float n2 = c * c + s * s;
+        const float sc = (n2 != 1.0f) ? 2.0f / (1.0f + n2) : 1.0f;
+        T[0] = c * sc; T[1] = s * sc; T[2] = tx; T[3] = ty;
     }
     return it;
 }

@@ -64,7 +64,7 @@ PLUS_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_dou
 # every symbol include/stba.h declares (tests check the library exports all of them)
 EXPORTS = ["stba_status_string", "stba_last_error", "stba_version", "stba_device_count",
            "stba_lm_default_options", "stba_ba_create", "stba_ba_destroy", "stba_ba_set_params",
-           "stba_ba_get_params", "stba_ba_set_allreduce", "stba_ba_reduced_dim", "stba_ba_evaluate",
+           "stba_ba_get_params", "stba_ba_set_host_linearizer", "stba_ba_set_allreduce", "stba_ba_reduced_dim", "stba_ba_evaluate",
            "stba_ba_cost", "stba_ba_normal_blocks", "stba_ba_reduced_system", "stba_ba_solve_reduced",
            "stba_ba_back_substitute", "stba_ba_apply_step", "stba_ba_solve", "stba_ba_lm_iterations",
            "stba_ba_triangulate", "stba_ba_time_linearize", "stba_ba_time_schur", "stba_cholesky_factor", "stba_cholesky_solve",
@@ -329,6 +329,11 @@ class PGEngine:
         cb = ALLREDUCE_FN(fn)
         self._keep = getattr(self, "_keep", []) + [cb]
         _chk(lib().stba_pg_set_allreduce(self._h, cb, None, rank, world), "stba_pg_set_allreduce")
+
+    def set_comm(self, comm):
+        """edge shard of a multi-GPU solve: cross-rank sums through a native RCCL communicator"""
+        self._keep = getattr(self, "_keep", []) + [comm]
+        _chk(lib().stba_pg_set_comm(self._h, comm._h if comm is not None else None), "stba_pg_set_comm")
 
     def get_poses(self):
         out = np.zeros((self.n, 7))

@@ -33,6 +33,19 @@ def _stale():
 HEAD_FILE = os.path.join(HERE, "BUILD_HEAD")
 
 
+def source_hash():
+    """content hash of everything the library is compiled from (csrc + include/stba.h): identifies a BUILD independently of
+    commits that only touch documents or profiles"""
+    import hashlib
+    h = hashlib.sha1()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp", ".cpp")))
+    files.append(os.path.join(HERE, "..", "include", "stba.h"))
+    for f in files:
+        with open(f, "rb") as fh:
+            h.update(os.path.basename(f).encode() + b"\0" + fh.read())
+    return h.hexdigest()[:12]
+
+
 def stamp_head():
     """git head of the tree the library was built from -> slam-tricks_amd/BUILD_HEAD (git-ignored; it travels to the GPU box,
     where there is no .git: bench.py and the tools/pmc_*.sh scripts put it into what they write, so that a counter file
@@ -42,16 +55,19 @@ def stamp_head():
         head = subprocess.check_output(["git", "-C", root, "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL, text=True).strip()
         dirty = subprocess.call(["git", "-C", root, "diff", "--quiet", "HEAD", "--", "slam-tricks_amd/csrc", "include"]) != 0
         with open(HEAD_FILE, "w") as f:
-            f.write(head + ("+dirty" if dirty else "") + "\n")
+            f.write(head + ("+dirty" if dirty else "") + " src:" + source_hash() + "\n")
     except Exception:
         pass                      # no git here (the GPU box): keep the file that came with the snapshot
 
 
 def build_head():
+    """'<git head>[+dirty] src:<hash>' of the tree the library was built from; the src: part is recomputed from the files at hand
+    (it must describe what is loaded, and a commit of documents moves the git head but not the library)"""
     try:
-        return open(HEAD_FILE).read().strip()
+        head = open(HEAD_FILE).read().strip().split(" src:")[0]
     except OSError:
-        return "unknown"
+        head = "unknown"
+    return head + " src:" + source_hash()
 
 
 def build(force=False, verbose=False):

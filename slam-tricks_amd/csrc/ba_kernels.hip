@@ -206,8 +206,8 @@ int launch_absmax(const double* v, size_t n, const double* v2, size_t n2, double
 }
 
 // The whole trial block of one LM iteration in ONE launch behind the residual-only kernel: out[0] = sum of that kernel's
-// cost partials (summation order of sum_partials_kernel), out[1..3] / out[4..6] the three sums of the landmark / camera
-// update's partials (order of trial_sums_kernel), out[7] = 0; and, if host_out is given, the block plus the
+// cost partials (summation order of sum_partials_kernel), out[1..3] / out[5..7] the three sums of the landmark / camera
+// update's partials (order of trial_sums_kernel), out[4] = 1 if the factorisation timed out on this rank; and, if host_out is given, the block plus the
 // factorisation's flag written straight into mapped host memory (export_trial_kernel): three launches less.
 __global__ __launch_bounds__(256) void trial_finish_kernel(const double* __restrict__ cost_partial, int n_cost,
                                                            const double* __restrict__ part_p, int n_p, const double* __restrict__ part_c,
@@ -245,9 +245,12 @@ __global__ __launch_bounds__(256) void trial_finish_kernel(const double* __restr
         __syncthreads();
     }
     if (threadIdx.x < 8) {
-        const double v = threadIdx.x < 7 ? res[threadIdx.x] : 0.0;
-        out[threadIdx.x] = v;
-        if (host_out) host_out[threadIdx.x] = v;
+        // block layout (stba_engine.hip, TS_*): [cost2, step2, x2, model | timed out | the three camera sums]; entry 4 = 1.0 if the
+        // factorisation of this iteration timed out on this rank (CHOL_FLAG_TIMEOUT): it lies inside the prefix the ranks sum
+        const int k = threadIdx.x;
+        const double v = k < 4 ? res[k] : k == 4 ? ((flag[0] == CHOL_FLAG_TIMEOUT) ? 1.0 : 0.0) : res[k - 1];
+        out[k] = v;
+        if (host_out) host_out[k] = v;
     } else if (threadIdx.x == 8 && host_out) host_out[8] = (double)flag[0];
     if (host_out) {
         // the host polls host_out[9] (no event on the stream: an event record is ~5 us of idle GPU): the block first,
@@ -268,11 +271,27 @@ int launch_trial_finish(const double* cost_partial, int n_cost, const double* pa
 
 // compact Jacobian of observation i -> the 2x6 camera block (d/dtheta | d/dt) and the 2x3 landmark block; columns of
 // constant dofs (mask bits 0..5) and of constant landmarks (bit 6) are zero, as the stored form used to have them
+// GEN (host-linearised factors, stba_ba_set_host_linearizer): the landmark block is still the record's P (so the landmark kernels
+// need no second form), the camera block is NOT a function of it and comes from its own array Jc12 [n_obs][12] (2 x 6 row-major).
+template <bool GEN = false>
 __device__ inline void load_jc_jp(const double* __restrict__ J8, const unsigned char* __restrict__ omask, int i,
-                                  double jc[12], double jp[6]) {
+                                  double jc[12], double jp[6], const double* __restrict__ Jc12 = nullptr) {
     const double2* pj = reinterpret_cast<const double2*>(J8 + (size_t)i * 8);
     const double2 v0 = pj[0], v1 = pj[1], v2 = pj[2], v3 = pj[3];
     const unsigned m = omask ? omask[i] : 0u;
+    if constexpr (GEN) {
+        const double2* pc = reinterpret_cast<const double2*>(Jc12 + (size_t)i * 12);
+        const double P[6] = {v1.x, v1.y, v2.x, v2.y, v3.x, v3.y};
+        const bool pf = (m & 64u) != 0u;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const double2 v = pc[k];
+            jc[2 * k] = ((m >> ((2 * k) % 6)) & 1u) ? 0.0 : v.x;
+            jc[2 * k + 1] = ((m >> ((2 * k + 1) % 6)) & 1u) ? 0.0 : v.y;
+            jp[k] = pf ? 0.0 : P[k];
+        }
+        return;
+    }
     const double xn = v0.x, yn = v0.y;
     const double P[6] = {v1.x, v1.y, v2.x, v2.y, v3.x, v3.y};
     jc[0] = (m & 1u) ? 0.0 : xn * yn;
@@ -643,8 +662,8 @@ int launch_point_invert(int n_pts, const double* Hpp6, const double* dp, const u
 // reduction over the camera's observations, whose records are in this CU's caches at that moment (as a kernel of its
 // own that gather cost 46 us per iteration).  Fixed summation order: Hcc and gc are bitwise reproducible.
 // ===========================================================================================
-template <int ROTS>
-__global__ __launch_bounds__(SCHUR_THREADS, 4) void ba_schur_pairs_kernel(SchurArgs a) {
+template <int ROTS, bool GEN = false>
+__global__ __launch_bounds__(SCHUR_THREADS, GEN ? 2 : 4) void ba_schur_pairs_kernel(SchurArgs a) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int task = blockIdx.x;
     const int c = a.task_cam[task];
@@ -686,8 +705,8 @@ __global__ __launch_bounds__(SCHUR_THREADS, 4) void ba_schur_pairs_kernel(SchurA
         double Hi[6], jc[12], jp[6], jc2[12], jp2[6];
 #pragma unroll
         for (int k2 = 0; k2 < 6; ++k2) Hi[k2] = a.Hinv6[(size_t)rc.z * 6 + k2];
-        load_jc_jp(a.J8, a.omask, rc.x, jc, jp);
-        load_jc_jp(a.J8, a.omask, rc.y, jc2, jp2);
+        load_jc_jp<GEN>(a.J8, a.omask, rc.x, jc, jp, a.Jc12);
+        load_jc_jp<GEN>(a.J8, a.omask, rc.y, jc2, jp2, a.Jc12);
         const unsigned sl = (unsigned)rc.w;
         // E_i = (Jc_i^T Jp_i) Hinv_j recomputed per pair (cheaper than a pre-pass that stores it)
         double E[18];
@@ -743,7 +762,7 @@ __global__ __launch_bounds__(SCHUR_THREADS, 4) void ba_schur_pairs_kernel(SchurA
             for (int p = a.cam_start[c] + tid; p < pe; p += SCHUR_THREADS) {
                 const int i = a.cam_perm[p];
                 double j[12], jpu[6];
-                load_jc_jp(a.J8, a.omask, i, j, jpu);
+                load_jc_jp<GEN>(a.J8, a.omask, i, j, jpu, a.Jc12);
                 const double2 ri = a.r[i];
                 int idx = 0;
 #pragma unroll
@@ -767,7 +786,7 @@ __global__ __launch_bounds__(SCHUR_THREADS, 4) void ba_schur_pairs_kernel(SchurA
             for (int p = a.cam_start[c] + tid; p < pe; p += SCHUR_THREADS) {
                 const int i = a.cam_perm[p];
                 double j[12], jpu[6];
-                load_jc_jp(a.J8, a.omask, i, j, jpu);
+                load_jc_jp<GEN>(a.J8, a.omask, i, j, jpu, a.Jc12);
                 const int lm = a.obs_pt[i];
                 double Hi[6];
 #pragma unroll
@@ -854,6 +873,15 @@ int launch_schur_rows(const SchurArgs& a, int n_tasks, hipStream_t st) {
         return STBA_OK;
     }));
     // (column rotations measured at C5: 1 / 2 / 3 / 6 -> 0.283 / 0.268 / 0.264 / 0.266 ms)
+    if (a.Jc12) {       // host-linearised factors: the same kernel with the camera block read from its own array
+        static DeviceOnce attr_gen;
+        STBA_TRY(attr_gen.run([]() -> int {
+            STBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_schur_pairs_kernel<SCHUR_ROTS, true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)schur_rows_lds_bytes(SCHUR_SPLIT_COLS)));
+            return STBA_OK;
+        }));
+        hipLaunchKernelGGL((ba_schur_pairs_kernel<SCHUR_ROTS, true>), dim3(n_tasks), dim3(SCHUR_THREADS), lds, st, a);
+    } else
     hipLaunchKernelGGL(ba_schur_pairs_kernel<SCHUR_ROTS>, dim3(n_tasks), dim3(SCHUR_THREADS), lds, st, a);
     STBA_HIP(hipGetLastError());
     return STBA_OK;
@@ -1024,12 +1052,13 @@ __device__ __forceinline__ void camera_update_lane(int c, const double* __restri
 // per lane): the landmark's records summed in observation order, then dxp = Hinv v through LDS.  With `up.pts_new` the
 // landmark half of the manifold update and of the step statistics (ba_update_kernel) rides along: the trial point's
 // landmarks and one partial[4] per workgroup, no second pass over dxp.
+template <bool GEN>
 __global__ __launch_bounds__(PB_THREADS) void ba_backsub_kernel(int n_pts, const int* __restrict__ pt_start,
                                                                 const int* __restrict__ obs_cam,
                                                                 const double* __restrict__ Jc, const unsigned char* __restrict__ Jp,
                                                                 const double* __restrict__ Hinv6, const double* __restrict__ gp,
                                                                 const double* __restrict__ dxc, double* __restrict__ dxp,
-                                                                BacksubUpdate up) {
+                                                                BacksubUpdate up, const double* __restrict__ Jc12) {
     __shared__ double u[3 * PB_LD];
     __shared__ int seg[PB_LM + 1];
     __shared__ double vv[3 * PB_LM];
@@ -1070,7 +1099,7 @@ __global__ __launch_bounds__(PB_THREADS) void ba_backsub_kernel(int n_pts, const
             if (l < ce) {
                 const int c = obs_cam[l];
                 double jc[12], jp[6];
-                load_jc_jp(Jc, Jp, l, jc, jp);
+                load_jc_jp<GEN>(Jc, Jp, l, jc, jp, Jc12);
                 double m0 = 0.0, m1 = 0.0;
 #pragma unroll
                 for (int a = 0; a < 6; ++a) { const double d = dxc[c * 6 + a]; m0 += jc[a] * d; m1 += jc[6 + a] * d; }
@@ -1126,13 +1155,17 @@ int backsub_grid(int n_pts) { return (n_pts + PB_LM - 1) / PB_LM; }
 int backsub_cam_grid(int n_cams) { return (n_cams + PB_THREADS - 1) / PB_THREADS; }
 
 int launch_backsub(int n_pts, const int* pt_start, const int* obs_cam, const double* Jc, const unsigned char* Jp,
-                   const double* Hinv6, const double* gp, const double* dxc, double* dxp, hipStream_t st, const BacksubUpdate* up) {
+                   const double* Hinv6, const double* gp, const double* dxc, double* dxp, hipStream_t st, const BacksubUpdate* up,
+                   const double* Jc12) {
     BacksubUpdate u0{};
     if (up) u0 = *up;
     const int grid = backsub_grid(n_pts) + (u0.cams_new ? backsub_cam_grid(u0.n_cams) : 0);
-    if (grid > 0)
-        hipLaunchKernelGGL(ba_backsub_kernel, dim3(grid), dim3(PB_THREADS), 0, st, n_pts, pt_start, obs_cam, Jc,
-                           Jp, Hinv6, gp, dxc, dxp, u0);
+    if (grid > 0 && Jc12)
+        hipLaunchKernelGGL(ba_backsub_kernel<true>, dim3(grid), dim3(PB_THREADS), 0, st, n_pts, pt_start, obs_cam, Jc,
+                           Jp, Hinv6, gp, dxc, dxp, u0, Jc12);
+    else if (grid > 0)
+        hipLaunchKernelGGL(ba_backsub_kernel<false>, dim3(grid), dim3(PB_THREADS), 0, st, n_pts, pt_start, obs_cam, Jc,
+                           Jp, Hinv6, gp, dxc, dxp, u0, (const double*)nullptr);
     STBA_HIP(hipGetLastError());
     return STBA_OK;
 }

@@ -65,6 +65,7 @@ struct SchurArgs {
     const int* row_col_ptr; const int* row_cols; int max_cols;
     const int* cam_perm;
     const double* J8; const unsigned char* omask;    // compact Jacobian [n_obs][8] | per-observation mask byte (or null)
+    const double* Jc12 = nullptr;                    // host-linearised factors only: the camera blocks [n_obs][12] (then J8 holds {0, 0, Jp})
     const double2* r;
     const double* Hinv6; const double* gp;
     double* S; int lda; double* rhs;
@@ -97,7 +98,8 @@ struct BacksubUpdate {
 int backsub_grid(int n_pts);
 int backsub_cam_grid(int n_cams);
 int launch_backsub(int n_pts, const int* pt_start, const int* obs_cam, const double* J8, const unsigned char* omask,
-                   const double* Hinv6, const double* gp, const double* dxc, double* dxp, hipStream_t st, const BacksubUpdate* up = nullptr);
+                   const double* Hinv6, const double* gp, const double* dxc, double* dxp, hipStream_t st, const BacksubUpdate* up = nullptr,
+                   const double* Jc12 = nullptr);
 int launch_update(int n_cams, int n_pts, const double* cams, const double* pts, const double* dxc,
                   const double* dxp, const unsigned char* cam_fixed, const unsigned char* pt_fixed,
                   const double* gc, const double* dc, const double* gp, const double* dp, double* cams_new,

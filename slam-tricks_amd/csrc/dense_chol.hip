@@ -2081,7 +2081,7 @@ static int mega_device_init(MegaDevice& D, hipStream_t st) {
     for (int i = 0; i < 16; ++i)
         if (D.xcc_queue[i] >= 0 && per_xcc[i] < MEGA_NTU)
             return fail(STBA_ERR_HIP, "chol: fewer than 10 workgroups per XCD (the TU tasks of a step need one each)");
-    STBA_HIP(hipEventCreateWithFlags(&D.last, hipEventDisableTiming));
+    if (!D.last) STBA_HIP(hipEventCreateWithFlags(&D.last, hipEventDisableTiming));
     D.probed = true;
     return STBA_OK;
 }
@@ -2181,6 +2181,17 @@ static int chol_run(double* A, int lda, int n, double* x_dev, int* flag_dev, hip
     }
     auto mark = [&](size_t k) -> int { if (prof) STBA_HIP(hipEventRecord(ev[k], st)); return STBA_OK; };
     if (stages) {
+        {   // the per-thread workspace (linv) is shared by every stream this host thread factors on: order this factorisation
+            // behind the previous one's backward substitution if that ran on another stream (as the persistent branch does)
+            MegaDevice& D = mega_device(cur_dev);
+            std::lock_guard<std::mutex> dev_lock(D.m);
+            if (!D.last) STBA_HIP(hipEventCreateWithFlags(&D.last, hipEventDisableTiming));
+            if (D.last_stream != nullptr && D.last_stream != st) {
+                STBA_HIP(hipEventRecord(D.last, D.last_stream));
+                STBA_HIP(hipStreamWaitEvent(st, D.last, 0));
+            }
+            D.last_stream = st;
+        }
         STBA_HIP(hipMemsetAsync(flag_dev, 0, sizeof(int), st));
         // STAGE KERNELS: one kernel per stage and panel, in order on the caller's stream.  The diagnostic schedule of
         // stba_cholesky_profile (per-class event times) and the FALLBACK of the persistent program: it needs nothing

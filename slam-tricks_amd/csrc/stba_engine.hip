@@ -56,7 +56,9 @@ static int download(T* dst, const T* src, size_t count, hipStream_t st) {
 // scalar slots in the extras region behind S (summed across ranks together with S)
 enum { SC_COST2 = 0, SC_GPMAX0 = 8, SC_MAX_WORLD = 64 };
 // trial-point scalars: [0..3] summed across ranks (landmark shards), [4..6] camera terms
-enum { TS_COST2 = 0, TS_STEP2 = 1, TS_X2 = 2, TS_MODEL = 3, TS_CAM = 4, TS_COUNT = 8,
+// (TS_TIMEOUT: 1.0 if this rank's persistent factorisation gave up -- it sits inside the all-reduced prefix of the block, so with
+// several ranks every rank sees the NUMBER of ranks that timed out and they all take the recovery path together)
+enum { TS_COST2 = 0, TS_STEP2 = 1, TS_X2 = 2, TS_MODEL = 3, TS_TIMEOUT = 4, TS_CAM = 5, TS_COUNT = 8,
        TS_SPEC_COST2 = 8 };      // (behind the trial block: cost of the speculative linearisation at the trial point)
 
 }  // namespace stba
@@ -97,6 +99,12 @@ struct stba_ba {
     unsigned char *cam_fixed = nullptr, *pt_fixed = nullptr;
     double2* r = nullptr;
     double* J8 = nullptr;            // compact Jacobian [n_obs][8] (ba_kernels.hip)
+    // host-linearised factors (stba_ba_set_host_linearizer): the user's cost functions make r and the 2x6 | 2x3 Jacobians on the
+    // host; J8 then holds {0, 0, Jp} per observation and Jc12 the camera blocks -- everything behind the linearisation is unchanged
+    stba_ba_linearize_fn hl_fn = nullptr;
+    void* hl_user = nullptr;
+    double* Jc12 = nullptr;          // [n_obs][12]
+    std::vector<double> hl_cams, hl_pts, hl_r, hl_jc, hl_jp, hl_stage;   // host staging (caller order | engine order)
     unsigned char* omask = nullptr;  // per observation: constant dofs of its camera (bits 0..5) | constant landmark (bit 6); null if none
     double *Hpp6 = nullptr, *gp = nullptr, *Hinv6 = nullptr, *dp = nullptr, *scale_p = nullptr;
     double *Hcc = nullptr, *gc = nullptr, *cam_partial = nullptr, *dc = nullptr, *scale_c = nullptr;
@@ -148,7 +156,7 @@ static void ba_free(stba_ba* b) {
     auto F = [](void* p) { if (p) (void)hipFree(p); };
     F(b->cams[0]); F(b->cams[1]); F(b->pts[0]); F(b->pts[1]); F(b->feat); F(b->obs_cam); F(b->obs_pt);
     F(b->pt_start); F(b->cam_perm); F(b->chunk_begin); F(b->chunk_end); F(b->cam_chunk_start); F(b->cam_fixed);
-    F(b->pt_fixed); F(b->r); F(b->J8); F(b->omask); F(b->Hpp6); F(b->gp); F(b->Hinv6); F(b->dp); F(b->scale_p);
+    F(b->pt_fixed); F(b->r); F(b->J8); F(b->Jc12); F(b->omask); F(b->Hpp6); F(b->gp); F(b->Hinv6); F(b->dp); F(b->scale_p);
     F(b->Hcc); F(b->gc); F(b->cam_partial); F(b->dc); F(b->scale_c); F(b->Sbuf); F(b->Spack); F(b->pk_blocks); F(b->dxc); F(b->dxp);
     F(b->task_cam); F(b->cam_start); F(b->task_col_lo); F(b->task_col_hi); F(b->row_col_ptr); F(b->row_cols);
     F(b->pair_begin); F(b->pair_end); F(b->pair_rec);
@@ -172,15 +180,57 @@ static LinArgs lin_args(stba_ba* b, int which, bool store_r) {
     return a;
 }
 
+// Host-linearised factors: parameters of buffer `which` -> host, the caller's callback makes r (and, with_jac, the 2x6 | 2x3
+// Jacobians in LOCAL camera coordinates [dtheta, dt]) in ITS observation order, the engine regroups them landmark-major and
+// uploads them where the device kernel would have put them: r, J8 = {0, 0, Jp}, Jc12, and sum r^2 as the first cost partial.
+// Synchronous by nature (the callback is host code); the LM loop does not speculate in this mode.
+static int ba_host_linearize(stba_ba* b, int which, bool with_jac) {
+    const size_t no = (size_t)b->no;
+    b->hl_cams.resize((size_t)b->nc * 7); b->hl_pts.resize((size_t)b->np * 3); b->hl_r.resize(no * 2);
+    if (with_jac) { b->hl_jc.resize(no * 12); b->hl_jp.resize(no * 6); }
+    STBA_TRY(download(b->hl_cams.data(), b->cams[which], b->hl_cams.size(), b->st));
+    STBA_TRY(download(b->hl_pts.data(), b->pts[which], b->hl_pts.size(), b->st));
+    STBA_HIP(hipStreamSynchronize(b->st));
+    if (b->hl_fn(b->hl_user, b->hl_cams.data(), b->hl_pts.data(), b->hl_r.data(), with_jac ? b->hl_jc.data() : nullptr,
+                 with_jac ? b->hl_jp.data() : nullptr) != 0)
+        return fail(STBA_ERR_CALLBACK, "host lineariser failed (a cost function returned false)");
+    double c2 = 0.0;
+    for (size_t k = 0; k < no * 2; ++k) c2 += b->hl_r[k] * b->hl_r[k];
+    if (!std::isfinite(c2)) return fail(STBA_ERR_CALLBACK, "host lineariser: non-finite residual");
+    std::vector<double>& st = b->hl_stage;
+    st.assign((size_t)b->lin_grid, 0.0);
+    st[0] = c2;
+    STBA_TRY(upload(b->cost_partial, st.data(), st.size(), b->st));
+    if (with_jac) {
+        st.resize(no * 12);
+        for (size_t p = 0; p < no; ++p) { const size_t i = (size_t)b->perm[p]; memcpy(&st[p * 2], &b->hl_r[i * 2], 2 * sizeof(double)); }
+        STBA_TRY(upload(reinterpret_cast<double*>(b->r), st.data(), no * 2, b->st));
+        STBA_HIP(hipStreamSynchronize(b->st));              // (the staging buffer is reused)
+        for (size_t p = 0; p < no; ++p) {
+            const size_t i = (size_t)b->perm[p];
+            st[p * 8] = 0.0; st[p * 8 + 1] = 0.0;
+            memcpy(&st[p * 8 + 2], &b->hl_jp[i * 6], 6 * sizeof(double));
+        }
+        STBA_TRY(upload(b->J8, st.data(), no * 8, b->st));
+        STBA_HIP(hipStreamSynchronize(b->st));
+        for (size_t p = 0; p < no; ++p) memcpy(&st[p * 12], &b->hl_jc[(size_t)b->perm[p] * 12], 12 * sizeof(double));
+        STBA_TRY(upload(b->Jc12, st.data(), no * 12, b->st));
+        STBA_HIP(hipStreamSynchronize(b->st));
+    }
+    return STBA_OK;
+}
+
 // residuals + Jacobians at parameter buffer `which`; sum r^2 -> *cost2_dev
 static int ba_linearize(stba_ba* b, int which, double* cost2_dev) {
-    STBA_TRY(launch_linearize(lin_args(b, which, true), true, b->lin_grid, b->st));
+    if (b->hl_fn) STBA_TRY(ba_host_linearize(b, which, true));
+    else STBA_TRY(launch_linearize(lin_args(b, which, true), true, b->lin_grid, b->st));
     return launch_sum_partials(b->cost_partial, b->lin_grid, 1, 1, cost2_dev, b->st);
 }
 
 // residual-only kernel (nothing stored): sum r^2 -> *cost2_dev
 static int ba_cost_only(stba_ba* b, int which, double* cost2_dev) {
-    STBA_TRY(launch_linearize(lin_args(b, which, false), false, b->lin_grid, b->st));
+    if (b->hl_fn) STBA_TRY(ba_host_linearize(b, which, false));
+    else STBA_TRY(launch_linearize(lin_args(b, which, false), false, b->lin_grid, b->st));
     return launch_sum_partials(b->cost_partial, b->lin_grid, 1, 1, cost2_dev, b->st);
 }
 
@@ -193,6 +243,7 @@ static int ba_normal_blocks(stba_ba* b) {
 // residuals + Jacobians of the LM loop: the cost partial sums stay in cost_partial and are added up by
 // ba_fill_scalar_slots behind the landmark blocks (one launch less than ba_linearize)
 static int ba_linearize_lm(stba_ba* b, int which) {
+    if (b->hl_fn) return ba_host_linearize(b, which, true);
     return launch_linearize(lin_args(b, which, true), true, b->lin_grid, b->st);
 }
 static int ba_camera_blocks(stba_ba* b) {
@@ -315,7 +366,7 @@ static int ba_build_reduced(stba_ba* b, const Damping& dm, bool export_host = fa
         SchurArgs sa;
         sa.task_cam = b->task_cam; sa.cam_start = b->cam_start; sa.task_col_lo = b->task_col_lo; sa.task_col_hi = b->task_col_hi;
         sa.row_col_ptr = b->row_col_ptr; sa.row_cols = b->row_cols; sa.max_cols = b->max_cols; sa.cam_perm = b->cam_perm;
-        sa.J8 = b->J8; sa.omask = b->omask; sa.r = b->r; sa.Hinv6 = b->Hinv6; sa.gp = b->gp;
+        sa.J8 = b->J8; sa.omask = b->omask; sa.Jc12 = b->hl_fn ? b->Jc12 : nullptr; sa.r = b->r; sa.Hinv6 = b->Hinv6; sa.gp = b->gp;
         sa.S = b->S(); sa.lda = b->lda; sa.rhs = b->rhs(); sa.Hcc = b->Hcc; sa.gc = b->gc;
         sa.obs_pt = b->obs_pt; sa.pair_begin = b->pair_begin; sa.pair_end = b->pair_end; sa.pair_rec = b->pair_rec;
         STBA_TRY(launch_schur_rows(sa, b->n_tasks, b->st));
@@ -398,7 +449,7 @@ __global__ void export_trial_kernel(const double* __restrict__ trial, const int*
 static int ba_backsub_trial(stba_ba* b) {
     BacksubUpdate up{b->pts[b->cur], b->pt_fixed, b->dp, b->pts[b->cur ^ 1], b->upd_partial_p,
                      b->nc, b->cams[b->cur], b->cam_fixed, b->ex_gc(), b->dc, b->cams[b->cur ^ 1], b->upd_partial_c};
-    return launch_backsub(b->np, b->pt_start, b->obs_cam, b->J8, b->omask, b->Hinv6, b->gp, b->dxc, b->dxp, b->st, &up);
+    return launch_backsub(b->np, b->pt_start, b->obs_cam, b->J8, b->omask, b->Hinv6, b->gp, b->dxc, b->dxp, b->st, &up, b->hl_fn ? b->Jc12 : nullptr);
 }
 
 // trial point: both manifold updates (one launch), the residual-only kernel, and ONE launch that finishes every sum of
@@ -416,14 +467,15 @@ static int ba_trial(stba_ba* b, double* host_out, bool updated = false, bool wit
         STBA_TRY(launch_update(b->nc, b->np, b->cams[cur], b->pts[cur], b->dxc, b->dxp, b->cam_fixed, b->pt_fixed,
                                b->ex_gc(), b->dc, b->gp, b->dp, b->cams[nxt], b->pts[nxt], b->upd_partial_c,
                                b->upd_partial_p, b->st));
-    static_assert(TS_COST2 == 0 && TS_STEP2 == 1 && TS_X2 == 2 && TS_MODEL == 3 && TS_CAM == 4 && TS_COUNT == 8, "trial_finish_kernel writes this layout");
+    static_assert(TS_COST2 == 0 && TS_STEP2 == 1 && TS_X2 == 2 && TS_MODEL == 3 && TS_TIMEOUT == 4 && TS_CAM == 5 && TS_COUNT == 8, "trial_finish_kernel writes this layout");
     if (with_jac) STBA_TRY(ba_linearize_lm(b, nxt));
+    else if (b->hl_fn) STBA_TRY(ba_host_linearize(b, nxt, false));
     else STBA_TRY(launch_linearize(lin_args(b, nxt, false), false, b->lin_grid, b->st));
     STBA_TRY(launch_trial_finish(b->cost_partial, b->lin_grid, b->upd_partial_p, b->np > 0 ? pb : 0, b->upd_partial_c, cb, b->flag, b->trial,
                                  b->ar ? nullptr : host_out, host_seq, b->st));
     if (b->ar) {
-        if (b->ar(b->ar_user, b->trial, 4, b->st) != 0) return fail(STBA_ERR_CALLBACK, "all-reduce hook failed");
-        // (several ranks: the block goes to the host behind the cross-rank sum of its first four entries)
+        if (b->ar(b->ar_user, b->trial, TS_TIMEOUT + 1, b->st) != 0) return fail(STBA_ERR_CALLBACK, "all-reduce hook failed");
+        // (several ranks: the block goes to the host behind the cross-rank sum of its first five entries)
         if (host_out) hipLaunchKernelGGL(export_trial_kernel, dim3(1), dim3(64), 0, b->st, b->trial, b->flag, host_out, host_seq);
         STBA_HIP(hipGetLastError());
     }
@@ -443,7 +495,9 @@ static int ba_wait_trial(stba_ba* b, double seq) {
             if (q == hipSuccess && h[TS_COUNT + 1] != seq) return fail(STBA_ERR_HIP, "the trial block never arrived in mapped host memory");
             if (wall_s() - t0 > 120.0) return fail(STBA_ERR_HIP, "timed out waiting for the trial point");
         }
+#if defined(__x86_64__)
         __builtin_ia32_pause();
+#endif
     }
     std::atomic_thread_fence(std::memory_order_acquire);
     return STBA_OK;
@@ -614,7 +668,7 @@ static int ba_run_lm(stba_ba* b, const stba_lm_options* opt_in, int fixed_iterat
         // bubble on the GPU in every iteration.  A rejected step costs one linearisation at the old point (below).
         // (With several ranks too: every rank takes the same decision from the same all-reduced block, and the collectives of
         // the speculative build are enqueued on the stream like everything else.)
-        const bool fast = deferred_ok && SPECULATE;
+        const bool fast = deferred_ok && SPECULATE && !b->hl_fn;      // (host-linearised factors: the callback is synchronous host work)
         if (fast && !b->ts_host) {
             STBA_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->ts_host), (TS_COUNT + 2) * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
             STBA_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&b->ts_host_dev), b->ts_host, 0));
@@ -661,13 +715,19 @@ static int ba_run_lm(stba_ba* b, const stba_lm_options* opt_in, int fixed_iterat
                 break;
             }
         }
-        if (flag_h == CHOL_FLAG_TIMEOUT) {
+        // (several ranks: the decision is COLLECTIVE -- ts[TS_TIMEOUT] is the all-reduced count of ranks whose factorisation timed
+        // out, the same number on every rank.  A rank-local decision would leave one rank re-running the iteration, with its
+        // all-reduces of a system linearised at the old point, while the others move on: mismatched collectives.)
+        if (flag_h == CHOL_FLAG_TIMEOUT || ts[TS_TIMEOUT] > 0.0) {
             // The persistent factorisation gave up waiting for a dependency: some of its workgroups were not resident (the
             // device is shared with another process).  S is half factored; it is rebuilt from the blocks -- the engine owns
             // them -- and this iteration runs again, the factorisation through the stage kernels, which need nothing
             // resident (chol_note_timeout: so do the next ones on this device).
-            chol_note_timeout();
-            if (++chol_timeouts > 3) return fail(STBA_ERR_HIP, "dense Cholesky: the persistent program timed out repeatedly");
+            if (flag_h == CHOL_FLAG_TIMEOUT) chol_note_timeout();
+            // (a device that keeps timing out is shared for good: the cool-down is renewed every time, so a long run goes on through
+            // the stage kernels instead of failing; only time-outs that come back-to-back without a good iteration in between --
+            // the stage kernels cannot time out -- end the solve)
+            if (++chol_timeouts > 8) return fail(STBA_ERR_HIP, "dense Cholesky: the persistent program timed out repeatedly");
             if (speculated) {       // (the speculative linearisation overwrote the current point's residuals, Jacobians and blocks)
                 STBA_TRY(ba_linearize_lm(b, b->cur));
                 STBA_TRY(ba_normal_blocks(b));
@@ -685,6 +745,7 @@ static int ba_run_lm(stba_ba* b, const stba_lm_options* opt_in, int fixed_iterat
             (void)hipEventElapsedTime(&ms, ev[5], ev[6]); s.ms_cost += ms;
         }
         lin_timing_pending = false;
+        chol_timeouts = 0;
 
         bool step_ok = (flag_h == 0);
         const double new_cost = 0.5 * ts[TS_COST2];
@@ -937,7 +998,18 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
     int task_max_cols = 0;
     size_t total_pairs = 0;
     for (int j = 0; j < n_pts; ++j) { const size_t k = (size_t)(pt_start[j + 1] - pt_start[j]); total_pairs += k * (k + 1) / 2; }
-    if (total_pairs > ((size_t)1 << 30)) { ba_free(b); return fail(STBA_ERR_INVALID_ARGUMENT, "stba_ba_create: more than 2^30 observation pairs (16 GB of Schur plan)"); }
+    {   // the plan costs 16 bytes per pair on the host and on the device: refuse what cannot be held instead of running out of memory
+        // half-way (a landmark seen by k cameras makes k (k + 1) / 2 pairs: 1000 cameras that ALL see 100 000 landmarks are 5e10)
+        size_t free_b = 0, total_b = 0;
+        const bool have_info = hipMemGetInfo(&free_b, &total_b) == hipSuccess;
+        const size_t cap = std::min<size_t>((size_t)1 << 30, have_info ? free_b / 2 / 16 : ((size_t)1 << 30));
+        if (total_pairs > cap) {
+            ba_free(b);
+            return fail(STBA_ERR_INVALID_ARGUMENT, "stba_ba_create: " + std::to_string(total_pairs) + " observation pairs (sum over landmarks of k (k + 1) / 2, "
+                        "k = cameras that see the landmark) need a Schur plan of " + std::to_string(total_pairs * 16 / (1 << 20)) + " MiB; the limit here is " +
+                        std::to_string(cap) + " pairs (2^30, or half of the free device memory)");
+        }
+    }
     static const int TASK_PAIRS = std::max(256, knob_int("STBA_SCHUR_TASK_PAIRS", SCHUR_TASK_PAIRS));
     {
         std::vector<std::vector<int>> cols_of((size_t)n_cams), cnt_of((size_t)n_cams);
@@ -1145,6 +1217,14 @@ int stba_ba_get_params(stba_ba* b, double* cams, double* pts) {
     return STBA_OK;
 }
 
+int stba_ba_set_host_linearizer(stba_ba* b, stba_ba_linearize_fn fn, void* user) {
+    if (!b) return fail(STBA_ERR_INVALID_ARGUMENT, "null engine");
+    if (fn && !b->Jc12) STBA_TRY(dev_alloc(&b->Jc12, (size_t)b->no * 12));
+    b->hl_fn = fn; b->hl_user = user;
+    b->have_lin = b->have_blocks = b->have_reduced = b->have_dxc = b->have_dxp = false;
+    return STBA_OK;
+}
+
 int stba_ba_set_allreduce(stba_ba* b, stba_allreduce_fn fn, void* user, int rank, int world_size) {
     if (!b || world_size < 1 || rank < 0 || rank >= world_size || world_size > SC_MAX_WORLD)
         return fail(STBA_ERR_INVALID_ARGUMENT, "stba_ba_set_allreduce: bad rank/world");
@@ -1175,6 +1255,7 @@ int stba_ba_evaluate(stba_ba* b, double* cost, double* r, double* Jc, double* Jp
     if (r) { tr.resize(no * 2); STBA_TRY(download(tr.data(), reinterpret_cast<double*>(b->r), no * 2, b->st)); }
     double *djc = nullptr, *djp = nullptr;     // the device holds the compact Jacobian; the 2x6 | 2x3 form is expanded for the caller
     struct TmpGuard { double*& a; double*& c; ~TmpGuard() { if (a) (void)hipFree(a); if (c) (void)hipFree(c); } } tmp_guard{djc, djp};
+    if ((Jc || Jp) && b->hl_fn) return fail(STBA_ERR_STATE, "stba_ba_evaluate: with a host lineariser the Jacobians are the caller's own");
     if (Jc || Jp) {
         if (Jc) STBA_TRY(dev_alloc(&djc, no * 12));
         if (Jp) STBA_TRY(dev_alloc(&djp, no * 6));
@@ -1253,6 +1334,20 @@ int stba_ba_solve_reduced(stba_ba* b, double* dxc) {
     if (dxc) STBA_TRY(download(dxc, b->dxc, (size_t)b->n, b->st));
     STBA_HIP(hipStreamSynchronize(b->st));
     b->have_reduced = false;   // S now holds the factor
+    if (flag_h == CHOL_FLAG_TIMEOUT && !b->ar && b->have_blocks) {
+        // the persistent factorisation gave up (shared device): start the cool-down, rebuild S from the blocks with the damping
+        // the caller gave (it is still on the device) and factor through the stage kernels, as the LM loop does.  (Several ranks:
+        // the rebuild is a collective and this is a rank-local decision -- the error below stands.)
+        chol_note_timeout();
+        Damping dm;
+        dm.explicit_d = true;
+        STBA_HIP(hipMemsetAsync(b->ex_scalar(), 0, (size_t)b->lda * sizeof(double), b->st));
+        STBA_TRY(ba_build_reduced(b, dm));
+        STBA_TRY(chol_factor_solve_stages(b->S(), b->lda, b->n, b->dxc, b->flag, b->st));
+        STBA_TRY(download(&flag_h, b->flag, 1, b->st));
+        if (dxc) STBA_TRY(download(dxc, b->dxc, (size_t)b->n, b->st));
+        STBA_HIP(hipStreamSynchronize(b->st));
+    }
     STBA_TRY(chol_flag_status(flag_h));
     if (flag_h != 0) return fail(STBA_ERR_NOT_POSITIVE_DEFINITE, "reduced camera system: pivot " + std::to_string(flag_h));
     b->have_dxc = true;
@@ -1262,7 +1357,7 @@ int stba_ba_solve_reduced(stba_ba* b, double* dxc) {
 int stba_ba_back_substitute(stba_ba* b, double* dxp) {
     if (!b) return fail(STBA_ERR_INVALID_ARGUMENT, "null engine");
     if (!b->have_dxc) return fail(STBA_ERR_STATE, "stba_ba_back_substitute needs stba_ba_solve_reduced first");
-    STBA_TRY(launch_backsub(b->np, b->pt_start, b->obs_cam, b->J8, b->omask, b->Hinv6, b->gp, b->dxc, b->dxp, b->st));
+    STBA_TRY(launch_backsub(b->np, b->pt_start, b->obs_cam, b->J8, b->omask, b->Hinv6, b->gp, b->dxc, b->dxp, b->st, nullptr, b->hl_fn ? b->Jc12 : nullptr));
     if (dxp) STBA_TRY(download(dxp, b->dxp, (size_t)b->np * 3, b->st));
     STBA_HIP(hipStreamSynchronize(b->st));
     b->have_dxp = true;

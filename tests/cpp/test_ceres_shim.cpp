@@ -170,7 +170,7 @@ struct ProjectFactor {
 };
 
 // NOT the reprojection factor (residual scaled by 2: same minimiser, different function): must be rejected
-// by the probe and run through the host-callback path.
+// by the probe; BA-shaped, so the device engine runs it with this functor evaluated on the host ("gpu-ba-hostjac").
 struct ScaledProjectFactor {
     double feature[2];
     explicit ScaledProjectFactor(const double* f) { feature[0] = f[0]; feature[1] = f[1]; }
@@ -346,6 +346,12 @@ int main(int argc, char** argv) {
         Scene s;
         if (!s.load(argv[2])) { std::printf("scene_load_failed\n"); return 2; }
         SolveBA(s, 1, "ba_user", std::atoi(argv[3]), 1000000);
+        return 0;
+    }
+    if (argc >= 4 && std::strcmp(argv[1], "generic_big") == 0) {      // a BA-shaped problem with a factor the probe rejects, any size
+        Scene s;
+        if (!s.load(argv[2])) { std::printf("scene_load_failed\n"); return 2; }
+        SolveBA(s, 2, "ba_generic", std::atoi(argv[3]), 1000000);
         return 0;
     }
     // ---- ceres_bound.cpp:25-68

@@ -95,7 +95,7 @@ def test_reference_call_sites_on_gpu(exe, tmp_path, scenes, O, known):
     small = scenes.st20_scene(n_cams=10, n_pts=120, seed=3, pos_noise=0.1, ang_noise_deg=1.0)
     f_pnp, f_sc, f_small = (str(tmp_path / n) for n in ("pnp.bin", "scene.bin", "small.bin"))
     write_pnp(f_pnp, pnp); write_scene(f_sc, sc); write_scene(f_small, small)
-    out = run(exe, f_pnp, f_sc, f_small)
+    out = run(exe, f_pnp, f_sc, f_sc)
     # ceres_bound.cpp
     assert abs(float(out["bound_0"].split()[1]) - known["st17_ceres_bound"]["x_free"]) < 1e-8
     assert abs(float(out["bound_1"].split()[1]) - known["st17_ceres_bound"]["x_bounded"]) < 1e-12
@@ -138,13 +138,38 @@ def test_reference_call_sites_on_gpu(exe, tmp_path, scenes, O, known):
     cu = vec(out, "ba_user_cams").reshape(-1, 7)
     dq = np.minimum(np.abs(cu[:, :4] - o.cams[:, :4]).max(1), np.abs(cu[:, :4] + o.cams[:, :4]).max(1)).max()
     assert dq < 1e-8 and np.abs(cu[:, 4:] - o.cams[:, 4:]).max() < 1e-8
-    # BA with a user functor that is NOT the reprojection factor: callback path, same minimiser
-    assert out["ba_generic_path"] == "gpu-dense-callback"
-    o2 = O.BA(small["cams0"], small["pts0"], small["obs_cam"], small["obs_pt"], small["obs_feat"], small["cam_fixed"])
-    o2.solve()
+    # BA with a user functor that is NOT the reprojection factor (residual scaled by 2: rejected by the probe): BA-shaped, so it
+    # runs on the device engine with the user's cost functions evaluated on the host in bulk -- "gpu-ba-hostjac" -- at the
+    # reference's own size, and follows the oracle's trace (costs x 4: a scaled residual with Jacobi scaling is the same LM)
+    assert out["ba_generic_path"] == "gpu-ba-hostjac"
+    tg = out["ba_generic_term"].split()
+    assert int(tg[0]) == 0 and int(tg[2]) == so.num_iterations
+    _, tro = O.BA(sc["cams0"], sc["pts0"], sc["obs_cam"], sc["obs_pt"], sc["obs_feat"], sc["cam_fixed"]).solve()
+    costs = vec(out, "ba_generic_costs")
+    assert len(costs) == len(tro) and np.allclose(costs, 4.0 * tro[:, 0], rtol=1e-6, atol=1e-12)
     cams2 = vec(out, "ba_generic_cams").reshape(-1, 7)
-    dq = np.minimum(np.abs(cams2[:, :4] - o2.cams[:, :4]).max(1), np.abs(cams2[:, :4] + o2.cams[:, :4]).max(1)).max()
-    assert dq < 1e-6 and np.abs(cams2[:, 4:] - o2.cams[:, 4:]).max() < 1e-5
+    dq = np.minimum(np.abs(cams2[:, :4] - o.cams[:, :4]).max(1), np.abs(cams2[:, :4] + o.cams[:, :4]).max(1)).max()
+    assert dq < 1e-8 and np.abs(cams2[:, 4:] - o.cams[:, 4:]).max() < 1e-8
+    assert small is not None
+
+
+@pytest.mark.gpu
+def test_generic_ba_factor_beyond_the_dense_limit(exe, tmp_path, scenes, O):
+    """100 cameras x 10 000 landmarks with a user factor the probe rejects: 600 + 30 000 local parameters, far beyond the
+    4096 of the dense callback path (which used to refuse it).  Host-linearised device engine, the oracle's trace (x 4)."""
+    s = scenes.st20_scene(n_cams=100, n_pts=10000, max_obs_per_pt=8, seed=31, pix_noise=1e-3)
+    f = str(tmp_path / "g.bin")
+    write_scene(f, s)
+    out = run(exe, "generic_big", f, "4")
+    assert out["ba_generic_path"] == "gpu-ba-hostjac", out["ba_generic_report"]
+    o = O.BA(s["cams0"], s["pts0"], s["obs_cam"], s["obs_pt"], s["obs_feat"], s["cam_fixed"])
+    so, tro = o.solve(max_num_iterations=4, num_threads=8)
+    costs = vec(out, "ba_generic_costs")
+    assert len(costs) == so.num_iterations + 1
+    assert np.allclose(costs, 4.0 * tro[: len(costs), 0], rtol=1e-6)
+    cams = vec(out, "ba_generic_cams").reshape(-1, 7)
+    dq = np.minimum(np.abs(cams[:, :4] - o.cams[:, :4]).max(1), np.abs(cams[:, :4] + o.cams[:, :4]).max(1)).max()
+    assert dq < 1e-6 and np.abs(cams[:, 4:] - o.cams[:, 4:]).max() < 1e-6
 
 
 @pytest.mark.gpu

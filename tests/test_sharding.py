@@ -172,7 +172,7 @@ def test_two_shards_on_one_gpu(scenes, O, n_cams, n_pts, max_obs, sparse):
     n = 6 * n_cams
     lda = ((n + 1 + 127) // 128) * 128
     tri = n * (n + 1) // 2 + 4 * lda
-    big = [c for c in counts[0] if c > 4]
+    big = [c for c in counts[0] if c > 5]            # (5: the trial block's summed prefix -- four sums + the time-out indicator)
     assert counts[0] == counts[1] and big[0] == n_cams * (n_cams + 1) // 2
     assert all((c < tri // 2) == sparse and (c - 4 * lda) % 36 == 0 or (not sparse and c == tri) for c in big[1:])
 
@@ -356,3 +356,83 @@ def test_two_processes_two_shards_product_engine(scenes):
         assert np.abs(cams - cams1).max() < 1e-9
         assert np.abs(pts - pts1[lo:hi]).max() < 1e-6
     assert np.array_equal(res[0][4], res[1][4])             # both processes hold bit-identical cameras
+
+
+def _rccl_worker(rank, world, idfile, q):
+    """one process per GPU: the product engine with the NATIVE communicator (stba_comm: ncclAllReduce on the engine's stream)"""
+    import time
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    torch.cuda.set_device(rank)
+    st = importlib.import_module("slam-tricks_amd")
+    scenes = importlib.import_module("slam-tricks_amd.scenes")
+    sharding = importlib.import_module("slam-tricks_amd.sharding")
+    if rank == 0:
+        uid = st.comm_unique_id()
+        with open(idfile + ".tmp", "wb") as f:
+            f.write(bytes(uid))
+        os.replace(idfile + ".tmp", idfile)
+    else:
+        t0 = time.time()
+        while not os.path.exists(idfile):
+            if time.time() - t0 > 120:
+                q.put((rank, "no unique id"))
+                return
+            time.sleep(0.05)
+        with open(idfile, "rb") as f:
+            uid = f.read()
+    try:
+        comm = st.Comm(uid, rank, world, device=rank)
+        s = scenes.st20_scene(n_cams=24, n_pts=1500, max_obs_per_pt=8, seed=6, pix_noise=1e-3)
+        sh = sharding.make_shard(s, rank, world)
+        e = st.BAEngine(sh["cams0"], sh["pts0"], sh["obs_cam"], sh["obs_pt"], sh["obs_feat"], sh["cam_fixed"])
+        e.set_comm(comm)
+        summ, tr = e.solve()
+        cams, pts = e.get_params()
+        # pose graph over the same communicator: edge shards
+        g = scenes.pose_graph_scene(n_nodes=400, loops_per_node=3, seed=4)
+        gs = sharding.make_pg_shard(g, rank, world)
+        pg = st.PGEngine(gs["poses0"], gs["edge_i"], gs["edge_j"], gs["meas"], gs["node_fixed"])
+        pg.set_comm(comm)
+        ps, ptr, _ = pg.solve(max_num_iterations=6, pcg=pg.pcg_options(forcing_eta0=0.0))
+        q.put((rank, summ.num_iterations, summ.termination_type, tr[:, 0].copy(), cams, pts, sh["lo"], sh["hi"], ptr[:, 0].copy(), pg.get_poses()))
+        pg.close(); e.close(); comm.close()
+    except Exception as ex:      # noqa: BLE001
+        q.put((rank, repr(ex)))
+
+
+@pytest.mark.gpu
+def test_native_rccl_two_ranks_two_gpus(scenes, tmp_path):
+    """TWO ranks of the native RCCL communicator, one GPU each (until now RCCL had only ever reduced
+    across one rank of this engine).  Needs two devices: skipped on the one-GPU test box, run wherever there are two.
+    Both engines (landmark-sharded BA, edge-sharded pose graph) must follow the single-GPU solve."""
+    import torch
+    import torch.multiprocessing as mp
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (the native communicator refuses two ranks on one device)")
+    st = importlib.import_module("slam-tricks_amd")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    idfile = str(tmp_path / "nccl_id.bin")
+    procs = [ctx.Process(target=_rccl_worker, args=(r, 2, idfile, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in range(2)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+    assert all(len(r) > 2 for r in res), res
+    s = scenes.st20_scene(n_cams=24, n_pts=1500, max_obs_per_pt=8, seed=6, pix_noise=1e-3)
+    e1 = st.BAEngine(s["cams0"], s["pts0"], s["obs_cam"], s["obs_pt"], s["obs_feat"], s["cam_fixed"])
+    s1, tr1 = e1.solve()
+    cams1, pts1 = e1.get_params()
+    g = scenes.pose_graph_scene(n_nodes=400, loops_per_node=3, seed=4)
+    pg1 = st.PGEngine(g["poses0"], g["edge_i"], g["edge_j"], g["meas"], g["node_fixed"])
+    _, ptr1, _ = pg1.solve(max_num_iterations=6, pcg=pg1.pcg_options(forcing_eta0=0.0))
+    for rank, iters, term, costs, cams, pts, lo, hi, pcosts, poses in res:
+        assert iters == s1.num_iterations and term == 0
+        assert np.allclose(costs, tr1[:, 0], rtol=1e-9)
+        assert np.abs(cams - cams1).max() < 1e-9 and np.abs(pts - pts1[lo:hi]).max() < 1e-6
+        assert np.allclose(pcosts, ptr1[:, 0], rtol=1e-8) and np.abs(poses - pg1.get_poses()).max() < 1e-7
+    assert np.array_equal(res[0][4], res[1][4]) and np.array_equal(res[0][9], res[1][9])      # replicated state bit-identical on both GPUs

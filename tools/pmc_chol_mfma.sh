@@ -8,7 +8,7 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/pmc_chol_mfma_$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp
-HEAD=$(cat $R/slam-tricks_amd/BUILD_HEAD 2>/dev/null || echo unknown)
+HEAD=$(python -c "import importlib,sys; sys.path.insert(0,'$R'); print(importlib.import_module('slam-tricks_amd.build').build_head())")
 for N in $SIZES; do
   i=0
   for SET in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
