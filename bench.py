@@ -138,8 +138,9 @@ def pmc_file(kind):
     best = None
     for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_" + kind + ".json")):
         m = re.match(r"r(\d+)", os.path.basename(f))
-        if m and (best is None or int(m.group(1)) >= best[0]):
-            best = (int(m.group(1)), f)
+        key = (int(m.group(1)), os.path.basename(f)) if m else None          # round number, then the tag's letter (r4_a < r4_e)
+        if key and (best is None or key > best[0]):
+            best = (key, f)
     if best is None:
         return None, None
     try:
@@ -658,9 +659,9 @@ def main():
         # like the CPU leg.  librocsolver is dlopen'ed by the TOOL, never by libstba.
         if world == 1 and not args.no_library_baseline:
             try:
-                import importlib.util
-                spec = importlib.util.spec_from_file_location("rocsolver_potrf", os.path.join(ROOT, "tools", "rocsolver_potrf.py"))
-                mod = importlib.util.module_from_spec(spec)
+                import importlib.util as ilu
+                spec = ilu.spec_from_file_location("rocsolver_potrf", os.path.join(ROOT, "tools", "rocsolver_potrf.py"))
+                mod = ilu.module_from_spec(spec)
                 spec.loader.exec_module(mod)
                 lb = mod.time_potrf(nred, reps=3)
                 if lb.get("found"):
