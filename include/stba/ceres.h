@@ -528,10 +528,14 @@ struct ProbePoint { double q[4], t[3], L[3]; };
 inline const ProbePoint* ProbePoints() {
     // (the third point has a different geometry: a rotation of more than 90 degrees and a landmark that projects far off
     // the optical axis, |x/z| ~ 1.9: a cost that clamps or guards large image coordinates differs here)
-    static const ProbePoint pts[3] = {
+    // (the fourth point lies BEHIND the camera, z = -1.6 in the camera frame: the built-in factor divides by z whatever its sign,
+    // as the reference's functor does (test_ceres.h:72-78); a cost with a cheirality guard differs here and keeps its own code --
+    // on the host-linearised device path if the problem is BA-shaped)
+    static const ProbePoint pts[4] = {
         {{0.18257418583505536, 0.3651483716701107, 0.5477225575051661, 0.7302967433402214}, {0.3, -0.2, 0.1}, {1.1, 0.7, 2.9}},
         {{-0.2721655269759087, 0.1360827634879543, 0.4082482904638630, 0.8606629658238704}, {-0.4, 0.25, -0.6}, {0.2, -0.9, 3.3}},
-        {{0.0, 0.8, 0.0, 0.6}, {0.5, 0.1, -0.2}, {1.035, -0.775, -2.83}}};
+        {{0.0, 0.8, 0.0, 0.6}, {0.5, 0.1, -0.2}, {1.035, -0.775, -2.83}},
+        {{0.0, 0.0, 0.0, 1.0}, {0.2, -0.1, 0.4}, {0.9, 0.3, -1.2}}};
     return pts;
 }
 
@@ -548,7 +552,7 @@ inline bool ProbeReprojectionValue(const CostFunction* cost, double* feature) {
     if (!cost->Evaluate(p0, r, nullptr) || !std::isfinite(r[0]) || !std::isfinite(r[1])) return false;
     feature[0] = -r[0]; feature[1] = -r[1];
     const ProbePoint* pp = ProbePoints();
-    for (int k = 0; k < 3; ++k) {
+    for (int k = 0; k < 4; ++k) {
         const double* p[3] = {pp[k].q, pp[k].t, pp[k].L};
         double proj[2];
         ReprojectionAt(pp[k].q, pp[k].t, pp[k].L, proj);
@@ -876,8 +880,8 @@ inline void Solve(const Solver::Options& options, Problem* problem, Solver::Summ
     *summary = Solver::Summary();
     internal::BaLayout L;
     // CONTRACT of the recognition (DetectBa): a user cost function is replaced by the built-in device factor if it equals
-    // proj(conj(q)(L - t)) - feature at three probe points (1e-12) and, once per C++ type, its Jacobian equals the closed form
-    // at one of them (1e-9).  A cost that agrees there and differs elsewhere (a guard that only fires behind the camera, say)
+    // proj(conj(q)(L - t)) - feature at four probe points, one of them behind the camera (1e-12) and, once per C++ type, its Jacobian equals the closed form
+    // at one of them (1e-9).  A cost that agrees there and differs elsewhere (a clamp that only fires far off the image, say)
     // would be replaced silently: Solver::Options::force_callback_path = true (or STBA_CERES_FORCE_CALLBACK=1 in the
     // environment) keeps every block on the generic path, where the user's Evaluate is what runs.
     const char* fe = std::getenv("STBA_CERES_FORCE_CALLBACK");

@@ -2245,8 +2245,9 @@ static int chol_run(double* A, int lda, int n, double* x_dev, int* flag_dev, hip
         ma.vbuf = ws.vbuf; ma.nwide = nwide;
         // a dependency that has not arrived after many times the predicted makespan never will: some workgroup of the
         // program is not resident (another process holds the CUs).  The host then takes the stage kernels.
-        // (100 ms at least: 40 x the 2.4 ms of the C5 system; chol_set_spin_limit_us overrides it -- tests provoke the fallback)
-        ma.spin_limit = (long long)std::max(100e3, 40.0 * plan.makespan_us) * 100LL;
+        // (25 ms at least -- a starved factorisation used to cost 100 ms before the 3.7 ms fallback ran; 40 x the makespan covers a
+        // profiler's PMC passes, which slow the kernel 2-2.5x; chol_set_spin_limit_us overrides it -- tests provoke the fallback)
+        ma.spin_limit = (long long)std::max(25e3, 40.0 * plan.makespan_us) * 100LL;
         if (g_spin_override.load() > 0) ma.spin_limit = g_spin_override.load();
         static const char* TRACE = knob_str("STBA_MEGA_TRACE");
         ma.trace = nullptr;
