@@ -146,3 +146,49 @@ def test_calibration_jacobian_numeric(O, scenes):
             return O.calib_evaluate(pp, s["obj"], s["img"], jac=False)[1]
         num = (shifted(+1) - shifted(-1)) / (2 * eps)
         assert np.allclose(num[v], Jx[v, ..., k], rtol=1e-5, atol=1e-3)
+
+
+def test_published_iteration_counts_against_the_oracles_distribution(O, scenes):
+    """The only iteration counts the reference publishes: st17-ceres/img/release.png (20 valid features, initial cost 2.232755:
+    `Iterations: 6` for both autodiff solvers, `iter num: 7` for SelfGaussNewton) and img/debug.png (21 features, initial cost
+    2.958739: `Iterations: 7`, `iter num: 7`).  The scenes behind the screenshots are clock-seeded and cannot be reproduced, but
+    scenes LIKE them can be drawn from the same generator (main.cpp:37-87 restated in scenes.pnp_scene): same feature count,
+    initial cost within 25 % of the published one.  Over those scenes:
+      * SelfGaussNewton with the reference's rotation Jacobian (solver.hpp:387-462, :425) takes 7 iterations most often -- the
+        published count in both screenshots;
+      * the oracle's Ceres-style LM takes 5 or 6 steps (release-like) and 6 steps (debug-like, 9 of 10 scenes).  Ceres'
+        BriefReport counts the initial evaluation as an iteration (Ceres >= 2.0: "Iterations" = successful + unsuccessful steps with
+        iteration 0 among them), so the published 6 / 7 are 5 / 6 LM steps: both inside what the oracle does, the second one its
+        mode.  Read as plain step counts, the debug screenshot's 7 would be a count the oracle NEVER takes on such scenes -- the
+        two screenshots together decide the reading.
+    A statistical pin of the oracle's iteration behaviour against the reference's published runs (a single scene could agree
+    by luck).  It is not a per-iteration diff against Ceres, which stays unpinned."""
+    import collections
+    dist = {}
+    for tag, n_feat, c0 in (("release", 20, 2.232755), ("debug", 21, 2.958739)):
+        lm, gn = collections.Counter(), collections.Counter()
+        for seed in range(900):
+            s = scenes.pnp_scene(seed=seed)
+            n = len(s["pts"])
+            if n != n_feat:
+                continue
+            ba = O.BA(s["pose_init"][None], s["pts"], np.zeros(n, np.int32), np.arange(n, dtype=np.int32), s["feats"],
+                      pt_fixed=np.ones(n, np.uint8))
+            summ, _ = ba.solve()
+            if abs(summ.initial_cost - c0) > 0.25 * c0:
+                continue
+            assert summ.termination_type == 0 and summ.final_cost < 1e-15
+            lm[summ.num_iterations] += 1
+            _, _, it_ref, _ = O.pnp_gauss_newton(s["pts"], s["feats"], s["pose_init"][:4], s["pose_init"][4:], 1, max_iter=40)
+            gn[it_ref] += 1
+        dist[tag] = (lm, gn, sum(lm.values()))
+        assert dist[tag][2] >= 25, dist
+    lm_r, gn_r, tot_r = dist["release"]
+    lm_d, gn_d, tot_d = dist["debug"]
+    # SelfGaussNewton, published 7 and 7
+    assert gn_r.most_common(1)[0][0] == 7 and gn_r[7] >= 0.6 * tot_r, gn_r
+    assert gn_d[7] >= 0.4 * tot_d and set(gn_d) <= {6, 7, 8, 9}, gn_d
+    # LM: published "Iterations" 6 and 7 = 5 and 6 steps
+    assert set(lm_r) <= {5, 6, 7} and lm_r[5] >= 0.2 * tot_r, lm_r
+    assert lm_d.most_common(1)[0][0] == 6 and lm_d[6] >= 0.7 * tot_d, lm_d
+    assert lm_d[7] == 0          # (the plain-step reading of the debug screenshot is outside the oracle's behaviour)
