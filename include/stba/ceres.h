@@ -325,6 +325,152 @@ private:
 };
 
 // ------------------------------------------------------------------------------------------
+// Pose graph through the same operator API (BASELINE config C4; build-defined: the reference has no pose-graph code, the
+// conventions are its Lie-group notes', st23-lie-group-v2/doc.tex:862-996).  A pose is ONE parameter block of 7 doubles
+// (qx qy qz qw tx ty tz); SE3RightPlus is its chart T <- T exp(delta), delta = [rho, theta] (Sophus' SE3 tangent order);
+// RelativePoseFactor is the edge r = log(Z^-1 T_i^-1 T_j) in R^6.  A Problem made only of these runs on the device pose-graph
+// engine (stba_pg_*: "gpu-pg"); Evaluate / Plus / ComputeJacobian below are what the generic host path uses.
+// ------------------------------------------------------------------------------------------
+namespace se3 {
+template <typename T> inline void QuatMul(const T* a, const T* b, T* o) {
+    o[0] = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+    o[1] = a[3] * b[1] - a[0] * b[2] + a[1] * b[3] + a[2] * b[0];
+    o[2] = a[3] * b[2] + a[0] * b[1] - a[1] * b[0] + a[2] * b[3];
+    o[3] = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+}
+template <typename T> inline void QuatRotate(const T* q, const T* v, T* o) {     // R(q) v = v + 2w (u x v) + 2 u x (u x v)
+    const T u0 = q[0], u1 = q[1], u2 = q[2], w = q[3];
+    const T a0 = T(2.0) * (u1 * v[2] - u2 * v[1]), a1 = T(2.0) * (u2 * v[0] - u0 * v[2]), a2 = T(2.0) * (u0 * v[1] - u1 * v[0]);
+    o[0] = v[0] + w * a0 + (u1 * a2 - u2 * a1);
+    o[1] = v[1] + w * a1 + (u2 * a0 - u0 * a2);
+    o[2] = v[2] + w * a2 + (u0 * a1 - u1 * a0);
+}
+template <typename T> inline void Inverse(const T* a, T* o) {
+    const T qc[4] = {-a[0], -a[1], -a[2], a[3]};
+    T t[3];
+    QuatRotate(qc, a + 4, t);
+    for (int i = 0; i < 4; ++i) o[i] = qc[i];
+    for (int i = 0; i < 3; ++i) o[4 + i] = -t[i];
+}
+template <typename T> inline void Compose(const T* a, const T* b, T* o) {
+    T q[4], t[3];
+    QuatMul(a, b, q);
+    QuatRotate(a, b + 4, t);
+    for (int i = 0; i < 4; ++i) o[i] = q[i];
+    for (int i = 0; i < 3; ++i) o[4 + i] = t[i] + a[4 + i];
+}
+// Sophus SE3::log of (q, t) -> [rho, theta]
+template <typename T> inline void Log(const T* P, T* xi) {
+    const T n2 = P[0] * P[0] + P[1] * P[1] + P[2] * P[2], qw = P[3];
+    T k;
+    if (n2 < T(1e-20)) k = T(2.0) / qw - T(2.0 / 3.0) * n2 / (qw * qw * qw);
+    else { const T n = sqrt(n2); k = T(2.0) * ((qw < T(0.0)) ? atan2(-n, -qw) : atan2(n, qw)) / n; }
+    const T w[3] = {k * P[0], k * P[1], k * P[2]};
+    const T th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+    T a, b;
+    if (th2 < T(1e-20)) { a = T(0.5) - th2 / T(24.0); b = T(1.0 / 6.0) - th2 / T(120.0); }
+    else { const T th = sqrt(th2); a = (T(1.0) - cos(th)) / th2; b = (th - sin(th)) / (th2 * th); }
+    const T K[9] = {T(0.0), -w[2], w[1], w[2], T(0.0), -w[0], -w[1], w[0], T(0.0)};
+    T V[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            const T k2 = K[i * 3] * K[j] + K[i * 3 + 1] * K[3 + j] + K[i * 3 + 2] * K[6 + j];
+            V[i * 3 + j] = (i == j ? T(1.0) : T(0.0)) + a * K[i * 3 + j] + b * k2;
+        }
+    const T aa = V[0], bb = V[1], cc = V[2], dd = V[3], ee = V[4], ff = V[5], gg = V[6], hh = V[7], ii = V[8];
+    const T C0 = ee * ii - ff * hh, C1 = ff * gg - dd * ii, C2 = dd * hh - ee * gg;
+    const T inv = T(1.0) / (aa * C0 + bb * C1 + cc * C2);
+    const T* t = P + 4;
+    xi[0] = inv * (C0 * t[0] + (cc * hh - bb * ii) * t[1] + (bb * ff - cc * ee) * t[2]);
+    xi[1] = inv * (C1 * t[0] + (aa * ii - cc * gg) * t[1] + (cc * dd - aa * ff) * t[2]);
+    xi[2] = inv * (C2 * t[0] + (bb * gg - aa * hh) * t[1] + (aa * ee - bb * dd) * t[2]);
+    xi[3] = w[0]; xi[4] = w[1]; xi[5] = w[2];
+}
+// Sophus SE3::exp of [rho, theta] -> (q, t)
+inline void Exp(const double* d, double* P) {
+    const double* th = d + 3;
+    const double th2 = th[0] * th[0] + th[1] * th[1] + th[2] * th[2];
+    double im, re, a, b;
+    if (th2 < 1e-20) { im = 0.5 - th2 / 48.0; re = 1.0 - th2 / 8.0; a = 0.5 - th2 / 24.0; b = 1.0 / 6.0 - th2 / 120.0; }
+    else { const double t = std::sqrt(th2); im = std::sin(0.5 * t) / t; re = std::cos(0.5 * t); a = (1.0 - std::cos(t)) / th2; b = (t - std::sin(t)) / (th2 * t); }
+    P[0] = im * th[0]; P[1] = im * th[1]; P[2] = im * th[2]; P[3] = re;
+    const double K[9] = {0, -th[2], th[1], th[2], 0, -th[0], -th[1], th[0], 0};
+    for (int i = 0; i < 3; ++i) {
+        double s = 0.0;
+        for (int j = 0; j < 3; ++j) {
+            const double k2 = K[i * 3] * K[j] + K[i * 3 + 1] * K[3 + j] + K[i * 3 + 2] * K[6 + j];
+            s += ((i == j ? 1.0 : 0.0) + a * K[i * 3 + j] + b * k2) * d[j];
+        }
+        P[4 + i] = s;
+    }
+}
+}  // namespace se3
+
+class SE3RightPlus : public LocalParameterization {
+public:
+    bool Plus(const double* x, const double* d, double* out) const override {
+        double e[7], o[7];
+        se3::Exp(d, e);
+        se3::Compose(x, e, o);
+        const double n = std::sqrt(o[0] * o[0] + o[1] * o[1] + o[2] * o[2] + o[3] * o[3]);
+        for (int i = 0; i < 4; ++i) out[i] = o[i] / n;
+        for (int i = 0; i < 3; ++i) out[4 + i] = o[4 + i];
+        return true;
+    }
+    // d (x (+) delta) / d delta at 0, 7 x 6 row-major: the quaternion moves with theta only (the 4 x 3 block of
+    // QuaternionRightPlus), the translation with rho only (R(q))
+    bool ComputeJacobian(const double* x, double* J) const override {
+        std::fill(J, J + 42, 0.0);
+        const double qx = 0.5 * x[0], qy = 0.5 * x[1], qz = 0.5 * x[2], qw = 0.5 * x[3];
+        const double M[12] = {qw, -qz, qy, qz, qw, -qx, -qy, qx, qw, -qx, -qy, -qz};
+        for (int r = 0; r < 4; ++r) for (int c = 0; c < 3; ++c) J[r * 6 + 3 + c] = M[r * 3 + c];
+        for (int c = 0; c < 3; ++c) {
+            double e[3] = {0, 0, 0}, col[3];
+            e[c] = 1.0;
+            se3::QuatRotate(x, e, col);
+            for (int r = 0; r < 3; ++r) J[(4 + r) * 6 + c] = col[r];
+        }
+        return true;
+    }
+    int GlobalSize() const override { return 7; }
+    int LocalSize() const override { return 6; }
+};
+
+class RelativePoseFactor : public SizedCostFunction<6, 7, 7> {
+public:
+    explicit RelativePoseFactor(const double* measurement) { std::memcpy(z_, measurement, sizeof z_); }
+    static RelativePoseFactor* Create(const double* measurement) { return new RelativePoseFactor(measurement); }
+    const double* measurement() const { return z_; }
+    template <typename T>
+    bool operator()(const T* Ti, const T* Tj, T* r) const {
+        T Z[7], Zi[7], Tii[7], A[7], E[7];
+        for (int k = 0; k < 7; ++k) Z[k] = T(z_[k]);
+        se3::Inverse(Z, Zi);
+        se3::Inverse(Ti, Tii);
+        se3::Compose(Tii, Tj, A);
+        se3::Compose(Zi, A, E);
+        if (E[3] < T(0.0)) for (int k = 0; k < 4; ++k) E[k] = -E[k];       // shortest rotation
+        se3::Log(E, r);
+        return true;
+    }
+    bool Evaluate(double const* const* p, double* residuals, double** jacobians) const override {
+        if (!jacobians) return (*this)(p[0], p[1], residuals);
+        using J14 = Jet<double, 14>;
+        J14 x[14], out[6];
+        for (int k = 0; k < 7; ++k) { x[k] = J14(p[0][k], k); x[7 + k] = J14(p[1][k], 7 + k); }
+        (*this)(x, x + 7, out);
+        for (int r = 0; r < 6; ++r) {
+            residuals[r] = out[r].a;
+            if (jacobians[0]) for (int k = 0; k < 7; ++k) jacobians[0][r * 7 + k] = out[r].v[k];
+            if (jacobians[1]) for (int k = 0; k < 7; ++k) jacobians[1][r * 7 + k] = out[r].v[7 + k];
+        }
+        return true;
+    }
+private:
+    double z_[7];
+};
+
+// ------------------------------------------------------------------------------------------
 // Problem
 // ------------------------------------------------------------------------------------------
 class Problem {
@@ -436,7 +582,7 @@ public:
         double initial_cost = 0, final_cost = 0, total_time_in_seconds = 0;
         int num_successful_steps = 0, num_unsuccessful_steps = 0;
         std::vector<IterationSummary> iterations;
-        std::string execution_path;   // "gpu-ba" | "gpu-ba-hostjac" | "gpu-dense-callback"
+        std::string execution_path;   // "gpu-ba" | "gpu-ba-hostjac" | "gpu-pg" | "gpu-dense-callback"
         std::string BriefReport() const {
             char buf[512];
             const char* t = termination_type == CONVERGENCE ? "CONVERGENCE" : termination_type == NO_CONVERGENCE ? "NO_CONVERGENCE"
@@ -874,6 +1020,55 @@ inline bool SolveDense(const Solver::Options& o, Problem* p, Solver::Summary* su
     return true;
 }
 
+// ---- path 3: pose graph on the device engine (stba_pg_*) -------------------------------------
+// returns false WITHOUT touching the summary if the problem is not a pose graph of built-in factors
+inline bool SolvePoseGraph(const Solver::Options& o, Problem* p, Solver::Summary* sum) {
+    if (p->residuals().empty()) return false;
+    std::map<int, int> node_of;
+    std::vector<int> node_block, ei, ej;
+    std::vector<double> meas;
+    for (auto& r : p->residuals()) {
+        auto* f = dynamic_cast<RelativePoseFactor*>(r.cost);
+        if (!f || r.blocks.size() != 2 || r.blocks[0] == r.blocks[1]) return false;
+        int ends[2];
+        for (int k = 0; k < 2; ++k) {
+            const auto& b = p->blocks()[r.blocks[k]];
+            if (b.size != 7 || !b.local || !dynamic_cast<SE3RightPlus*>(b.local) || !b.lower.empty()) return false;
+            auto it = node_of.find(r.blocks[k]);
+            if (it == node_of.end()) { ends[k] = (int)node_block.size(); node_of[r.blocks[k]] = ends[k]; node_block.push_back(r.blocks[k]); }
+            else ends[k] = it->second;
+        }
+        ei.push_back(ends[0]); ej.push_back(ends[1]);
+        meas.insert(meas.end(), f->measurement(), f->measurement() + 7);
+    }
+    const int n = (int)node_block.size(), m = (int)ei.size();
+    std::vector<double> poses((size_t)n * 7);
+    std::vector<unsigned char> fixed((size_t)n, 0);
+    for (int k = 0; k < n; ++k) {
+        std::memcpy(&poses[(size_t)k * 7], p->blocks()[node_block[k]].ptr, 7 * sizeof(double));
+        fixed[k] = p->blocks()[node_block[k]].constant ? 1 : 0;
+    }
+    sum->execution_path = "gpu-pg";
+    stba_pg* pg = nullptr;
+    int rc = stba_pg_create(&pg, n, m, poses.data(), ei.data(), ej.data(), meas.data(), fixed.data(), nullptr);
+    if (rc != STBA_OK) { sum->termination_type = FAILURE; sum->message = std::string("stba_pg_create: ") + stba_last_error(); return true; }
+    stba_lm_options co = ToC(o);
+    stba_lm_summary cs;
+    std::vector<double> trace((size_t)(o.max_num_iterations + 1) * STBA_TRACE_COLS, 0.0);
+    int pcg_total = 0;
+    rc = stba_pg_solve(pg, &co, nullptr, &cs, trace.data(), &pcg_total);
+    if (rc == STBA_OK) rc = stba_pg_get_poses(pg, poses.data());
+    if (rc == STBA_OK) {
+        for (int k = 0; k < n; ++k) std::memcpy(p->blocks()[node_block[k]].ptr, &poses[(size_t)k * 7], 7 * sizeof(double));
+        FillSummary(cs, trace, sum);
+    } else {
+        sum->termination_type = FAILURE;
+        sum->message = std::string("stba_pg_solve: ") + stba_last_error();
+    }
+    stba_pg_destroy(pg);
+    return true;
+}
+
 }  // namespace internal
 
 inline void Solve(const Solver::Options& options, Problem* problem, Solver::Summary* summary) {
@@ -895,6 +1090,8 @@ inline void Solve(const Solver::Options& options, Problem* problem, Solver::Summ
     // the device engine's residual / Jacobian buffers, and the Schur complement, the factorisation, the back-substitution and the
     // LM loop run on the device as for the built-in factor ("gpu-ba-hostjac"): any size the engine takes, where the dense
     // callback path below stops at 4096 local parameters.  (The reference's BA cost IS a generic functor: test_ceres.h:56.)
+    // a pose graph: every residual block a RelativePoseFactor between two 7-double pose blocks with the SE3 right-plus chart
+    if (!force_cb && options.callbacks.empty() && internal::SolvePoseGraph(options, problem, summary)) return;
     internal::BaLayout L2;
     bool shape = internal::DetectBa(*problem, &L2, false);
     if (shape)

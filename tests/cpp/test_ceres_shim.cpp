@@ -348,6 +348,40 @@ int main(int argc, char** argv) {
         SolveBA(s, 1, "ba_user", std::atoi(argv[3]), 1000000);
         return 0;
     }
+    if (argc >= 3 && std::strcmp(argv[1], "pg") == 0) {
+        // a pose graph through the operator API: one 7-double block per pose with the SE3 right-plus chart, one RelativePoseFactor
+        // per edge (build-defined, BASELINE config C4).  argv[3] = "dense": force the generic host path (checks Evaluate / the chart)
+        std::ifstream f(argv[2], std::ios::binary);
+        int n = 0, m = 0;
+        f.read((char*)&n, 4); f.read((char*)&m, 4);
+        std::vector<double> poses((size_t)n * 7), meas((size_t)m * 7);
+        std::vector<int> ei(m), ej(m);
+        std::vector<unsigned char> fixed(n);
+        f.read((char*)poses.data(), poses.size() * 8); f.read((char*)ei.data(), m * 4); f.read((char*)ej.data(), m * 4);
+        f.read((char*)meas.data(), meas.size() * 8); f.read((char*)fixed.data(), n);
+        if (!f) { std::printf("pg_load_failed\n"); return 2; }
+        ceres::LocalParameterization* chart = new ceres::SE3RightPlus();
+        ceres::Problem problem;
+        for (int e = 0; e < m; ++e)
+            problem.AddResidualBlock(ceres::RelativePoseFactor::Create(&meas[(size_t)e * 7]), nullptr, {&poses[(size_t)ei[e] * 7], &poses[(size_t)ej[e] * 7]});
+        for (int k = 0; k < n; ++k) {
+            problem.AddParameterBlock(&poses[(size_t)k * 7], 7, chart);
+            if (fixed[k]) problem.SetParameterBlockConstant(&poses[(size_t)k * 7]);
+        }
+        ceres::Solver::Options options;
+        options.num_threads = 1;
+        options.force_callback_path = (argc > 3 && std::strcmp(argv[3], "dense") == 0);
+        ceres::Solver::Summary summary;
+        ceres::Solve(options, &problem, &summary);
+        std::printf("pg_path %s\npg_msg %s\n", summary.execution_path.c_str(), summary.message.c_str());
+        std::printf("pg_term %d iters %d initial %.17g final %.17g\n", (int)summary.termination_type, (int)summary.iterations.size() - 1,
+                    summary.initial_cost, summary.final_cost);
+        std::vector<double> costs;
+        for (auto& it : summary.iterations) costs.push_back(it.cost);
+        print_vec("pg_costs", costs.data(), (int)costs.size());
+        print_vec("pg_poses", poses.data(), n * 7);
+        return 0;
+    }
     if (argc >= 4 && std::strcmp(argv[1], "generic_big") == 0) {      // a BA-shaped problem with a factor the probe rejects, any size
         Scene s;
         if (!s.load(argv[2])) { std::printf("scene_load_failed\n"); return 2; }
