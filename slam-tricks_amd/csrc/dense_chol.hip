@@ -775,15 +775,16 @@ __global__ void xcc_probe_kernel(int* out) {
 // C(TM x 128) -= P_i P_j^T, K = 128 panel columns, 512 threads; smem: 2*(TM+128)*16 doubles
 // C(TM x 128) -= P_i P_j^T, K = 128 panel columns, 512 threads; smem: 2*(TM+128)*16 doubles
 // (kchunks 16-column chunks of K: 8 for one panel; a batched trailing update runs several panels in one pass)
-template <int TM>
+template <int TM, int KCH = 16>
 __device__ __forceinline__ void syrk_tile512(double* __restrict__ A, int lda, int k0, int row_i, int row_j,
                                              double* smem, int t, int kchunks = NB / 16) {
     constexpr int WR = (TM == 128) ? 2 : 1, WC = 8 / WR;      // wave grid
     constexpr int MB = TM / (16 * WR);                        // MFMA row blocks per wave: 4 | 2
     constexpr int NBK = 8 / WC;                               // MFMA col blocks per wave: 2 | 1
     constexpr int RBA = TM / 16;                              // 16-row blocks of the A tile
-    double* sA = smem;                   // [2][TM * 16]
-    double* sB = smem + 2 * TM * 16;     // [2][2048]
+    constexpr int SA = TM * KCH, SB = 128 * KCH, NH = KCH / 8;
+    double* sA = smem;                   // [2][TM * KCH]
+    double* sB = smem + 2 * SA;          // [2][128 * KCH]
     const int lane = t & 63, w = t >> 6;
     const int wr = w / WC, wc = w % WC;
     double4v acc[MB][NBK];
@@ -798,46 +799,50 @@ __device__ __forceinline__ void syrk_tile512(double* __restrict__ A, int lda, in
                 acc[m][n][r] = A[(size_t)row * lda + col];
             }
     // staging map: wave w, half h -> row = (lane&15) + 16*w, k = 2*((lane>>4) + 4h)
-    double2 ga[2], gb[2];
+    double2 ga[NH], gb[NH];
     const int lrow = lane & 15, lkp = lane >> 4;
-    const bool stage_a = (w < RBA);
+    // (TM = 128: all eight waves stage rows of the A tile.  Said at compile time: with the run-time test `w < RBA` the compiler put
+    // an exec-mask branch around every A load and store of the K loop -- three s_cbranch per chunk between the MFMAs; without them
+    // the factorisation is 1.4 % faster at n = 6000, round 4)
+    const bool stage_a = (RBA == 8) ? true : (w < RBA);
     auto gload = [&](int kc) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < NH; ++h) {
             const int row = lrow + 16 * w;
             const int k = 2 * (lkp + 4 * h);
-            if (stage_a) ga[h] = *reinterpret_cast<const double2*>(&A[(size_t)(row_i + row) * lda + k0 + kc * 16 + k]);
-            gb[h] = *reinterpret_cast<const double2*>(&A[(size_t)(row_j + row) * lda + k0 + kc * 16 + k]);
+            if (stage_a) ga[h] = *reinterpret_cast<const double2*>(&A[(size_t)(row_i + row) * lda + k0 + kc * KCH + k]);
+            gb[h] = *reinterpret_cast<const double2*>(&A[(size_t)(row_j + row) * lda + k0 + kc * KCH + k]);
         }
     };
     auto lstore = [&](int buf) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < NH; ++h) {
             const int k = 2 * (lkp + 4 * h);
             if (stage_a) {
                 const int posa = (((k >> 2) * RBA + w) << 6) + ((k & 3) << 4) + lrow;
-                sA[buf * TM * 16 + posa] = ga[h].x;
-                sA[buf * TM * 16 + posa + 16] = ga[h].y;      // k+1: (k&3) is even so +1 -> +16
+                // (the A operand is negated HERE, once per element, not at every fragment read: four v_xor per k-step less between
+                // the MFMAs -- alone it measured +0.7 %, together with the branch-free staging -2.2 % at n = 6000, -3.8 % at 24 000)
+                sA[buf * SA + posa] = -ga[h].x;
+                sA[buf * SA + posa + 16] = -ga[h].y;     // k+1: (k&3) is even so +1 -> +16
             }
             const int posb = (((k >> 2) * 8 + w) << 6) + ((k & 3) << 4) + lrow;
-            sB[buf * 2048 + posb] = gb[h].x;
-            sB[buf * 2048 + posb + 16] = gb[h].y;
+            sB[buf * SB + posb] = gb[h].x;
+            sB[buf * SB + posb + 16] = gb[h].y;
         }
     };
     gload(0);
     lstore(0);
     __syncthreads();
-    const int KC = kchunks;
-    for (int kc = 0; kc < KC; ++kc) {
-        const int buf = kc & 1;
+    const int KC = kchunks * 16 / KCH;
+    auto chunk = [&](int kc, int buf) {
         if (kc + 1 < KC) gload(kc + 1);
 #pragma unroll
-        for (int kq = 0; kq < 4; ++kq) {
+        for (int kq = 0; kq < KCH / 4; ++kq) {
             double a[MB], b[NBK];
 #pragma unroll
-            for (int m = 0; m < MB; ++m) a[m] = -sA[buf * TM * 16 + (((kq * RBA + wr * MB + m) << 6) + lane)];
+            for (int m = 0; m < MB; ++m) a[m] = sA[buf * SA + (((kq * RBA + wr * MB + m) << 6) + lane)];
 #pragma unroll
-            for (int n = 0; n < NBK; ++n) b[n] = sB[buf * 2048 + (((kq * 8 + wc * NBK + n) << 6) + lane)];
+            for (int n = 0; n < NBK; ++n) b[n] = sB[buf * SB + (((kq * 8 + wc * NBK + n) << 6) + lane)];
 #pragma unroll
             for (int m = 0; m < MB; ++m)
 #pragma unroll
@@ -846,7 +851,11 @@ __device__ __forceinline__ void syrk_tile512(double* __restrict__ A, int lda, in
         }
         if (kc + 1 < KC) lstore(buf ^ 1);
         __syncthreads();
-    }
+    };
+    // (measured and not kept, round 4: the loop unrolled by two so that the LDS offsets become immediates: +4 % at n = 6000, +8 % at
+    // 24 000 -- the compiler then hoists the operand reads of both chunks and the staging stores drift; KCH = 32, half the barriers
+    // at 128 KB of LDS: +1.5 % / +1.2 %; s_setprio around the MFMAs: +1.8 %)
+    for (int kc = 0; kc < KC; ++kc) chunk(kc, kc & 1);
 #pragma unroll
     for (int m = 0; m < MB; ++m)
 #pragma unroll
@@ -888,7 +897,7 @@ __device__ __forceinline__ void syrk_tile512_gen(double* __restrict__ Cb, int ld
     // staging map: wave w, half h -> row = (lane&15) + 16*w, k = 2*((lane>>4) + 4h)
     double2 ga[2], gb[2];
     const int lrow = lane & 15, lkp = lane >> 4;
-    const bool stage_a = (w < RBA);
+    const bool stage_a = (RBA == 8) ? true : (w < RBA);   // see syrk_tile512
     auto gload = [&](int kc) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -904,8 +913,8 @@ __device__ __forceinline__ void syrk_tile512_gen(double* __restrict__ Cb, int ld
             const int k = 2 * (lkp + 4 * h);
             if (stage_a) {
                 const int posa = (((k >> 2) * RBA + w) << 6) + ((k & 3) << 4) + lrow;
-                sA[buf * TM * 16 + posa] = ga[h].x;
-                sA[buf * TM * 16 + posa + 16] = ga[h].y;      // k+1: (k&3) is even so +1 -> +16
+                sA[buf * TM * 16 + posa] = -ga[h].x;     // negated at staging, see syrk_tile512
+                sA[buf * TM * 16 + posa + 16] = -ga[h].y;     // k+1: (k&3) is even so +1 -> +16
             }
             const int posb = (((k >> 2) * 8 + w) << 6) + ((k & 3) << 4) + lrow;
             sB[buf * 2048 + posb] = gb[h].x;
@@ -923,7 +932,7 @@ __device__ __forceinline__ void syrk_tile512_gen(double* __restrict__ Cb, int ld
         for (int kq = 0; kq < 4; ++kq) {
             double a[MB], b[NBK];
 #pragma unroll
-            for (int m = 0; m < MB; ++m) a[m] = -sA[buf * TM * 16 + (((kq * RBA + wr * MB + m) << 6) + lane)];
+            for (int m = 0; m < MB; ++m) a[m] = sA[buf * TM * 16 + (((kq * RBA + wr * MB + m) << 6) + lane)];
 #pragma unroll
             for (int n = 0; n < NBK; ++n) b[n] = sB[buf * 2048 + (((kq * 8 + wc * NBK + n) << 6) + lane)];
 #pragma unroll
