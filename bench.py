@@ -458,7 +458,7 @@ def main():
         jac_bytes = BYTES_PER_OBS_JAC * local_obs
         jac_gbs = jac_bytes / (ms_jac * 1e-3) / 1e9
         nred = 6 * n_cams
-        ms_factor, ms_bwd = st.cholesky_time_split(nred, reps=5)
+        ms_factor, ms_bwd = st.cholesky_time_split(nred, reps=15)   # medians; ms_factor = the persistent kernel alone (events right around it)
         chol_flops = nred ** 3 / 3.0 + nred ** 2 / 2.0            # algorithmic flops of one n x n Cholesky
         chol_tflops = chol_flops / (ms_factor * 1e-3) / 1e12
         prof = st.cholesky_profile(nred)                          # stage-per-kernel schedule (diagnostic)
@@ -492,6 +492,8 @@ def main():
                      "mfma_utilisation_pmc": pc6.get("mfma_utilisation") if pc6 else None,
                      "l2_hit_rate_pmc": pc6.get("l2_hit_rate") if pc6 else None,
                      "ms_per_launch": ms_factor,
+                     "timing": "median of 15 factorisations of a synthetic SPD matrix of the C5 size, hipEvents on the engine's stream right "
+                               "in front of and behind chol_mega_kernel (the quantity rocprofv3 --kernel-trace reports for it)",
                      "algorithmic_flops_per_launch": chol_flops, "launches_per_lm_iteration": 1,
                      "microbench_ceiling": FP64_MFMA_MEASURED_CEILING_TFLOPS,
                      "frac_of_microbench_ceiling": chol_tflops / FP64_MFMA_MEASURED_CEILING_TFLOPS}

@@ -89,7 +89,8 @@ void chol_set_spin_limit_us(double us);    // how long a workgroup waits for a d
 int chol_timeout_count();
 
 // the production schedule with an event recorded between the factorisation and the backward substitution
-int chol_factor_solve_split(double* A_dev, int lda, int n, double* x_dev, int* flag_dev, hipStream_t st, hipEvent_t mid_event);
+int chol_factor_solve_split(double* A_dev, int lda, int n, double* x_dev, int* flag_dev, hipStream_t st, hipEvent_t mid_event,
+                            hipEvent_t pre_event = nullptr);   // pre_event: recorded right in front of the persistent kernel (stage schedule: never)
 struct CholProfile {
     double ms_diag, ms_trsm, ms_syrk, ms_bwd;
     double syrk_flops;          // algorithmic: sum over steps of m(m+1)*128, m = remaining real rows

@@ -2122,7 +2122,7 @@ int chol_timeout_count() { return g_timeouts.load(); }
 enum { CHOL_PERSISTENT = 0, CHOL_STAGES = 1 };
 
 static int chol_run(double* A, int lda, int n, double* x_dev, int* flag_dev, hipStream_t st, CholProfile* prof,
-                    hipEvent_t mid_event = nullptr, int schedule = CHOL_PERSISTENT) {
+                    hipEvent_t mid_event = nullptr, int schedule = CHOL_PERSISTENT, hipEvent_t pre_event = nullptr) {
     if (lda % NB != 0 || lda < n + 1) return fail(STBA_ERR_INVALID_ARGUMENT, "chol: bad padded dimension");
     const int nblk = lda / NB;
     int cur_dev = 0;
@@ -2277,6 +2277,7 @@ static int chol_run(double* A, int lda, int n, double* x_dev, int* flag_dev, hip
             STBA_HIP(hipEventRecord(D.last, D.last_stream));
             STBA_HIP(hipStreamWaitEvent(st, D.last, 0));
         }
+        if (pre_event) STBA_HIP(hipEventRecord(pre_event, st));    // (timing only: the persistent kernel alone, without the flag reset in front)
         hipLaunchKernelGGL(chol_mega_kernel, dim3(D.ncu), dim3(512), MEGA_SMEM_BYTES, st, ma);
         D.last_stream = st;
         if (TRACE) {    // debugging aid: dump the task timeline of this factorisation (tools/mega_trace.py)
@@ -2367,8 +2368,8 @@ int chol_factor_solve_stages(double* A, int lda, int n, double* x_dev, int* flag
     return chol_run(A, lda, n, x_dev, flag_dev, st, nullptr, nullptr, CHOL_STAGES);
 }
 
-int chol_factor_solve_split(double* A, int lda, int n, double* x_dev, int* flag_dev, hipStream_t st, hipEvent_t mid_event) {
-    return chol_run(A, lda, n, x_dev, flag_dev, st, nullptr, mid_event);
+int chol_factor_solve_split(double* A, int lda, int n, double* x_dev, int* flag_dev, hipStream_t st, hipEvent_t mid_event, hipEvent_t pre_event) {
+    return chol_run(A, lda, n, x_dev, flag_dev, st, nullptr, mid_event, CHOL_PERSISTENT, pre_event);
 }
 
 int chol_factor_solve_profiled(double* A, int lda, int n, double* x_dev, int* flag_dev, hipStream_t st,
