@@ -30,7 +30,7 @@ def run(code, lib):
     e = dict(os.environ); e["STBA_LIB"] = os.path.join(ROOT, "tmp_libs", lib + ".so")
     return subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=900)
 for l in libs:
-    p = run(CHECK % (ROOT, min(n, 6000)), l)
+    p = run(CHECK % (ROOT, min(n, int(os.environ.get('CHECK_N', '6000')))), l)   # CHECK_N: check at a larger size (numpy factors it on the host)
     print(l, (p.stdout.strip().splitlines() or [p.stderr[-300:]])[-1], flush=True)
 res = {l: [] for l in libs}
 for r in range(rounds):
