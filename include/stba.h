@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define STBA_VERSION 3
+#define STBA_VERSION 4
 
 /* status codes */
 enum {
@@ -152,14 +152,23 @@ typedef struct stba_ba stba_ba;
  * cam_fixed: n_cams*6 bytes (1 = dof constant; NULL = all free; order [rot(3), pos(3)]);
  * pt_fixed: n_pts bytes (1 = landmark constant; NULL = all free).
  * hip_stream: hipStream_t to enqueue on (NULL = the engine creates its own).
- * Limit: the Schur complement kernel works from a plan with one 16-byte record per PAIR of observations of the same
- * landmark (sum over landmarks of k (k + 1) / 2, k = cameras seeing it; 5.5 M at 1000 cameras x 100 000 landmarks x 10
- * observations each), built once here, on the host and on the device.  More than 2^30 pairs, or a plan larger than half of
- * the free device memory, is refused with STBA_ERR_INVALID_ARGUMENT (very dense visibility: every camera sees everything). */
+ * The Schur complement has two forms (stba_ba_set_schur_mode).  PAIRS: a plan with one 16-byte record per PAIR of observations
+ * of the same landmark (sum over landmarks of k (k + 1) / 2, k = cameras seeing it; 5.5 M at 1000 cameras x 100 000 landmarks x
+ * 10 observations each), built once here, on the host and on the device; one 6 x 6 block accumulated in LDS per pair.  DENSE: the
+ * scaled camera-landmark blocks in a dense [6 n_cams] x [3 n_pts] matrix Y and S = -(Y Y^T) as ONE symmetric rank-k product on the
+ * matrix cores -- no plan, 8 x 18 n_cams n_pts bytes of device memory, the right form when most cameras see most landmarks.
+ * The engine picks DENSE by itself when the plan would have more than 2^30 pairs (or would not fit half of the free device
+ * memory), or more than 2^20 pairs at a visibility of 30 % and more; a problem that fits neither form is refused with
+ * STBA_ERR_INVALID_ARGUMENT. */
 int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double* cams,
                    const double* pts, const int* obs_cam, const int* obs_pt, const double* obs_feat,
                    const unsigned char* cam_fixed, const unsigned char* pt_fixed, void* hip_stream);
 int stba_ba_destroy(stba_ba* ba);
+/* form of the Schur complement (above): STBA_SCHUR_AUTO = what stba_ba_create chose.  STBA_SCHUR_PAIRS fails if the engine was
+ * created without a pair plan (too many pairs), STBA_SCHUR_DENSE if Y does not fit the device. */
+enum { STBA_SCHUR_AUTO = 0, STBA_SCHUR_PAIRS = 1, STBA_SCHUR_DENSE = 2 };
+int stba_ba_set_schur_mode(stba_ba* ba, int mode);
+int stba_ba_schur_mode(const stba_ba* ba, int* mode);
 int stba_ba_set_params(stba_ba* ba, const double* cams, const double* pts);
 int stba_ba_get_params(stba_ba* ba, double* cams, double* pts);
 /* BA-SHAPED problems whose factor is NOT the built-in reprojection (the reference's BA cost is a generic

@@ -64,7 +64,7 @@ PLUS_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_dou
 # every symbol include/stba.h declares (tests check the library exports all of them)
 EXPORTS = ["stba_status_string", "stba_last_error", "stba_version", "stba_device_count",
            "stba_lm_default_options", "stba_ba_create", "stba_ba_destroy", "stba_ba_set_params",
-           "stba_ba_get_params", "stba_ba_set_host_linearizer", "stba_ba_set_allreduce", "stba_ba_reduced_dim", "stba_ba_evaluate",
+           "stba_ba_get_params", "stba_ba_set_schur_mode", "stba_ba_schur_mode", "stba_ba_set_host_linearizer", "stba_ba_set_allreduce", "stba_ba_reduced_dim", "stba_ba_evaluate",
            "stba_ba_cost", "stba_ba_normal_blocks", "stba_ba_reduced_system", "stba_ba_solve_reduced",
            "stba_ba_back_substitute", "stba_ba_apply_step", "stba_ba_solve", "stba_ba_lm_iterations",
            "stba_ba_triangulate", "stba_ba_time_linearize", "stba_ba_time_schur", "stba_cholesky_factor", "stba_cholesky_solve",
@@ -279,6 +279,18 @@ class BAEngine:
         ms = C.c_double()
         _chk(lib().stba_ba_time_linearize(self._h, int(reps), C.byref(ms)), "stba_ba_time_linearize")
         return ms.value
+
+    SCHUR_AUTO, SCHUR_PAIRS, SCHUR_DENSE = 0, 1, 2
+
+    def set_schur_mode(self, mode):
+        """form of the Schur complement: SCHUR_PAIRS (pair plan, LDS accumulation) | SCHUR_DENSE (S = -(Y Y^T) on the matrix cores,
+        for dense visibility) | SCHUR_AUTO (what the engine chose at creation)"""
+        _chk(lib().stba_ba_set_schur_mode(self._h, int(mode)), "stba_ba_set_schur_mode")
+
+    def schur_mode(self):
+        m = C.c_int()
+        _chk(lib().stba_ba_schur_mode(self._h, C.byref(m)), "stba_ba_schur_mode")
+        return m.value
 
     def time_schur(self, reps=10):
         """(ms per launch of the Schur-complement kernel, LDS atomics per launch, observation pairs per launch)"""

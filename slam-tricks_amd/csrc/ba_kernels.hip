@@ -858,6 +858,140 @@ __global__ __launch_bounds__(SCHUR_THREADS, GEN ? 2 : 4) void ba_schur_pairs_ker
     }
 }
 
+// ===========================================================================================
+// The same Schur complement for DENSE visibility (most cameras see most landmarks): per observation i of landmark j the 6 x 3 block
+// Y_i = (Jc_i^T Jp_i) R_j with R_j R_j^T = Hpp_j^-1 (Cholesky of the inverse landmark block), written into a dense matrix
+// Y [6 n_cams padded] x [3 n_pts padded]; then S = -(Y Y^T) (lower triangle) is ONE symmetric rank-k product on the matrix cores
+// (chol_yyt_lower_dev) and rhs = Y v, v_j = R_j^T gp_j.  No pair plan: the pair formulation costs 16 B of plan and 36 LDS atomics
+// per pair of observations of a landmark -- k (k + 1) / 2 pairs for a landmark seen by k cameras; the product costs 6 C x 6 C x 3
+// multiply-adds per landmark whatever k is, and wins from k / C ~ 0.3 on.  The zero blocks of Y (camera does not see landmark)
+// are zeroed once, at the first launch: the visibility pattern is static.
+// ===========================================================================================
+__device__ inline void chol3_of_sym6(const double h[6], double R[6]) {
+    // h = (00, 01, 02, 11, 12, 22) of an SPD (or zero) 3 x 3 block; R = (r00, r10, r20, r11, r21, r22) lower triangular, R R^T = h
+    const double r00 = h[0] > 0.0 ? sqrt(h[0]) : 0.0;
+    const double i0 = r00 > 0.0 ? 1.0 / r00 : 0.0;
+    const double r10 = h[1] * i0, r20 = h[2] * i0;
+    const double d1 = h[3] - r10 * r10;
+    const double r11 = d1 > 0.0 ? sqrt(d1) : 0.0;
+    const double i1 = r11 > 0.0 ? 1.0 / r11 : 0.0;
+    const double r21 = (h[4] - r20 * r10) * i1;
+    const double d2 = h[5] - r20 * r20 - r21 * r21;
+    const double r22 = d2 > 0.0 ? sqrt(d2) : 0.0;
+    R[0] = r00; R[1] = r10; R[2] = r20; R[3] = r11; R[4] = r21; R[5] = r22;
+}
+template <bool GEN>
+__global__ __launch_bounds__(256) void ba_schur_yfill_kernel(int n_obs, const int* __restrict__ obs_cam, const int* __restrict__ obs_pt,
+                                                             const double* __restrict__ J8, const unsigned char* __restrict__ omask,
+                                                             const double* __restrict__ Jc12, const double* __restrict__ Hinv6,
+                                                             double* __restrict__ Y, size_t ldy) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_obs) return;
+    const int c = obs_cam[i], j = obs_pt[i];
+    double jc[12], jp[6], h[6], R[6];
+    load_jc_jp<GEN>(J8, omask, i, jc, jp, Jc12);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) h[k] = Hinv6[(size_t)j * 6 + k];
+    chol3_of_sym6(h, R);
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        const double w0 = jc[q] * jp[0] + jc[6 + q] * jp[3];
+        const double w1 = jc[q] * jp[1] + jc[6 + q] * jp[4];
+        const double w2 = jc[q] * jp[2] + jc[6 + q] * jp[5];
+        double* y = Y + (size_t)(c * 6 + q) * ldy + (size_t)j * 3;
+        y[0] = w0 * R[0] + w1 * R[1] + w2 * R[2];
+        y[1] = w1 * R[3] + w2 * R[4];
+        y[2] = w2 * R[5];
+    }
+}
+// v_j = R_j^T gp_j
+__global__ __launch_bounds__(256) void ba_schur_yvec_kernel(int n_pts, const double* __restrict__ Hinv6, const double* __restrict__ gp,
+                                                            double* __restrict__ v) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n_pts) return;
+    double h[6], R[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) h[k] = Hinv6[(size_t)j * 6 + k];
+    chol3_of_sym6(h, R);
+    const double g0 = gp[(size_t)j * 3], g1 = gp[(size_t)j * 3 + 1], g2 = gp[(size_t)j * 3 + 2];
+    v[(size_t)j * 3] = R[0] * g0 + R[1] * g1 + R[2] * g2;
+    v[(size_t)j * 3 + 1] = R[3] * g1 + R[4] * g2;
+    v[(size_t)j * 3 + 2] = R[5] * g2;
+}
+// rhs[row] = sum_k Y[row, k] v[k]: one workgroup per row, a strided share per lane, fixed-order sums (bitwise reproducible)
+__global__ __launch_bounds__(256) void ba_schur_yrhs_kernel(const double* __restrict__ Y, size_t ldy, size_t kcols, const double* __restrict__ v,
+                                                            double* __restrict__ rhs) {
+    __shared__ double part[4];
+    const double* y = Y + (size_t)blockIdx.x * ldy;
+    double s = 0.0;
+    for (size_t k = threadIdx.x; k < kcols; k += 256) s += y[k] * v[k];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) rhs[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+// camera blocks Hcc = sum Jc^T Jc, gc = sum Jc^T r of camera c over its observations (the pair kernel makes them on its way)
+template <bool GEN>
+__global__ __launch_bounds__(256) void ba_camera_blocks_kernel(const int* __restrict__ cam_start, const int* __restrict__ cam_perm,
+                                                               const double* __restrict__ J8, const unsigned char* __restrict__ omask,
+                                                               const double* __restrict__ Jc12, const double2* __restrict__ r,
+                                                               double* __restrict__ Hcc, double* __restrict__ gc) {
+    __shared__ double cpart[4][28];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    double h[27];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) h[k] = 0.0;
+    for (int p = cam_start[c] + tid; p < cam_start[c + 1]; p += 256) {
+        const int i = cam_perm[p];
+        double j[12], jpu[6];
+        load_jc_jp<GEN>(J8, omask, i, j, jpu, Jc12);
+        const double2 ri = r[i];
+        int idx = 0;
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+#pragma unroll
+            for (int b = 0; b <= q; ++b) h[idx++] += j[q] * j[b] + j[6 + q] * j[6 + b];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) h[21 + q] += j[q] * ri.x + j[6 + q] * ri.y;
+    }
+#pragma unroll
+    for (int k = 0; k < 27; ++k) {
+        double v = h[k];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if ((tid & 63) == 0) cpart[tid >> 6][k] = v;
+    }
+    __syncthreads();
+    if (tid < 27) {
+        const double s = (cpart[0][tid] + cpart[1][tid]) + (cpart[2][tid] + cpart[3][tid]);
+        if (tid < 21) {
+            int q = 0, b = tid;
+            while (b > q) { ++q; b -= q; }   // tid = q(q+1)/2 + b
+            Hcc[(size_t)c * 36 + q * 6 + b] = s;
+            Hcc[(size_t)c * 36 + b * 6 + q] = s;
+        } else gc[(size_t)c * 6 + (tid - 21)] = s;
+    }
+}
+
+int launch_schur_dense(const SchurDenseArgs& a, hipStream_t st) {
+    if (a.n_obs > 0) {
+        if (a.Jc12) hipLaunchKernelGGL(ba_schur_yfill_kernel<true>, dim3((a.n_obs + 255) / 256), dim3(256), 0, st, a.n_obs, a.obs_cam, a.obs_pt, a.J8,
+                                       a.omask, a.Jc12, a.Hinv6, a.Y, a.ldy);
+        else hipLaunchKernelGGL(ba_schur_yfill_kernel<false>, dim3((a.n_obs + 255) / 256), dim3(256), 0, st, a.n_obs, a.obs_cam, a.obs_pt, a.J8,
+                                a.omask, a.Jc12, a.Hinv6, a.Y, a.ldy);
+    }
+    if (a.n_pts > 0) hipLaunchKernelGGL(ba_schur_yvec_kernel, dim3((a.n_pts + 255) / 256), dim3(256), 0, st, a.n_pts, a.Hinv6, a.gp, a.v);
+    STBA_TRY(chol_yyt_lower_dev(a.Y, a.ldy, a.kcols, a.S, a.lda, a.ws, st));
+    if (a.n_cams > 0) {
+        hipLaunchKernelGGL(ba_schur_yrhs_kernel, dim3(6 * a.n_cams), dim3(256), 0, st, a.Y, a.ldy, (size_t)3 * a.n_pts, a.v, a.rhs);
+        if (a.Jc12) hipLaunchKernelGGL(ba_camera_blocks_kernel<true>, dim3(a.n_cams), dim3(256), 0, st, a.cam_start, a.cam_perm, a.J8, a.omask, a.Jc12,
+                                       a.r, a.Hcc, a.gc);
+        else hipLaunchKernelGGL(ba_camera_blocks_kernel<false>, dim3(a.n_cams), dim3(256), 0, st, a.cam_start, a.cam_perm, a.J8, a.omask, a.Jc12,
+                                a.r, a.Hcc, a.gc);
+    }
+    STBA_HIP(hipGetLastError());
+    return STBA_OK;
+}
+
 size_t schur_rows_lds_bytes(int max_cols) {
     return ((size_t)max_cols * SCHUR_BLK_LD + 8 + 8 * SCHUR_CAM_LD) * sizeof(double) + (size_t)max_cols * sizeof(int) + 16;
 }

@@ -76,6 +76,18 @@ struct SchurArgs {
     const int* obs_pt;                               // landmark of every observation
     const int4* pair_rec;                            // (i, l, landmark, slot | 0x8000 if diagonal block), l != i
 };
+// the Schur complement for dense visibility as a symmetric rank-k product (ba_kernels.hip, "DENSE visibility")
+struct SchurDenseArgs {
+    int n_cams, n_pts, n_obs;
+    const int* obs_cam; const int* obs_pt; const int* cam_start; const int* cam_perm;
+    const double* J8; const unsigned char* omask; const double* Jc12; const double2* r;
+    const double* Hinv6; const double* gp;
+    double* Y; size_t ldy; size_t kcols;         // [lda][ldy], kcols = 3 n_pts rounded up to 16 (<= ldy); zero where nothing is observed
+    double* v;                                    // [kcols]
+    double* ws;                                   // workspace of chol_yyt_workspace_doubles(lda, kcols) doubles (or null)
+    double* S; int lda; double* rhs; double* Hcc; double* gc;
+};
+int launch_schur_dense(const SchurDenseArgs& a, hipStream_t st);
 size_t schur_rows_lds_bytes(int max_cols);
 int launch_schur_rows(const SchurArgs& a, int n_tasks, hipStream_t st);
 int launch_reduced_add_camera(int n_cams, const double* Hcc, const double* gc, double* S, int lda, double* rhs,

@@ -107,6 +107,11 @@ int chol_shard_row_owner(int row, int n_gpus, int rows_per_group);
 int chol_prepare_padding_dev(double* A_dev, int lda, int n, const double* rhs_dev, hipStream_t st);
 // explicit inverse of a small SPD matrix (pose graph coarse operator): W = [A . ; I 0] (2 np x 2 np, np a multiple of 128)
 // -> lower right block = -A^-1 (lower triangle); dense_chol.hip
+// lower triangle of S = -(Y Y^T) on the matrix cores (the Schur complement of a bundle adjustment with dense visibility):
+// Y is lda x kcols (kcols a multiple of 16, leading dimension ldy), S lda x lda (lda a multiple of 128); ws: workspace of
+// chol_yyt_workspace_doubles doubles (0: none needed)
+size_t chol_yyt_workspace_doubles(int lda, size_t kcols);
+int chol_yyt_lower_dev(const double* Y, size_t ldy, size_t kcols, double* S, int lda, double* ws, hipStream_t st);
 size_t chol_spd_inverse_workspace_doubles(int np);
 int chol_spd_inverse_dev(double* W, int ldw, int np, int n_real, int* flag_dev, double* work, hipStream_t st);
 

@@ -873,8 +873,8 @@ __device__ __forceinline__ void syrk_tile512(double* __restrict__ A, int lda, in
 // C (TM x 128) -= Pi Pj^T with K = 128: C at Cb (leading dimension ldc), Pi rows at Pi (ldi), Pj rows at Pj (ldj).
 // c_zero: C counts as zero on entry (the first update of a tile of an inverse block, see the wide inverse blocks).
 template <int TM>
-__device__ __forceinline__ void syrk_tile512_gen(double* __restrict__ Cb, int ldc, const double* __restrict__ Pi, int ldi,
-                                             const double* __restrict__ Pj, int ldj, bool c_zero, double* smem, int t) {
+__device__ __forceinline__ void syrk_tile512_gen(double* __restrict__ Cb, int ldc, const double* __restrict__ Pi, size_t ldi,
+                                             const double* __restrict__ Pj, size_t ldj, bool c_zero, double* smem, int t, int kchunks = NB / 16) {
     constexpr int WR = (TM == 128) ? 2 : 1, WC = 8 / WR;      // wave grid
     constexpr int MB = TM / (16 * WR);                        // MFMA row blocks per wave: 4 | 2
     constexpr int NBK = 8 / WC;                               // MFMA col blocks per wave: 2 | 1
@@ -903,8 +903,8 @@ __device__ __forceinline__ void syrk_tile512_gen(double* __restrict__ Cb, int ld
         for (int h = 0; h < 2; ++h) {
             const int row = lrow + 16 * w;
             const int k = 2 * (lkp + 4 * h);
-            if (stage_a) ga[h] = *reinterpret_cast<const double2*>(&Pi[(size_t)row * ldi + kc * 16 + k]);
-            gb[h] = *reinterpret_cast<const double2*>(&Pj[(size_t)row * ldj + kc * 16 + k]);
+            if (stage_a) ga[h] = *reinterpret_cast<const double2*>(&Pi[(size_t)row * ldi + (size_t)kc * 16 + k]);
+            gb[h] = *reinterpret_cast<const double2*>(&Pj[(size_t)row * ldj + (size_t)kc * 16 + k]);
         }
     };
     auto lstore = [&](int buf) {
@@ -924,7 +924,7 @@ __device__ __forceinline__ void syrk_tile512_gen(double* __restrict__ Cb, int ld
     gload(0);
     lstore(0);
     __syncthreads();
-    constexpr int KC = NB / 16;
+    const int KC = kchunks;
     for (int kc = 0; kc < KC; ++kc) {
         const int buf = kc & 1;
         if (kc + 1 < KC) gload(kc + 1);
@@ -2356,6 +2356,79 @@ int chol_spd_inverse_dev(double* W, int ldw, int np, int n_real, int* flag_dev, 
         hipLaunchKernelGGL(chol_trsm_kernel, dim3(groups + NB / 16), dim3(64), 0, st, W, ldw, b * NB, groups, li, li + NB * NB);
         launch_syrk(W, ldw, b * NB, 0, mt * (mt + 1) / 2, st);
     }
+    STBA_HIP(hipGetLastError());
+    return STBA_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Lower triangle of S = -(Y Y^T), Y (lda x kcols, leading dimension ldy) the scaled camera-landmark blocks of a bundle adjustment
+// with DENSE visibility (ba_kernels.hip: Y_i = J_c^T J_p chol(Hpp^-1) per observation, zero where a camera does not see a
+// landmark): the Schur complement as a symmetric rank-k product on the matrix cores instead of one LDS-atomic 6 x 6 block per pair
+// of observations (whose plan costs 16 B per pair -- 1000 cameras that all see 100 000 landmarks are 5e10 pairs).  One 512-thread
+// workgroup per (tile, K slice): the update task's loop (syrk_tile512_gen) over the slice's K range on a zero accumulator; with
+// more than one slice the partial tiles go to a workspace and are added in slice order (no atomics: bitwise reproducible).
+__global__ __launch_bounds__(512) void yyt_tile_kernel(const double* __restrict__ Y, size_t ldy, double* __restrict__ S, int lda, int ntiles, int nsplit,
+                                                       int chunks_per_split, int chunks_total, double* __restrict__ ws) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    // slices of one tile side by side (they share nothing), tiles of one tile row in consecutive blocks
+    const int tile = blockIdx.x % ntiles, split = blockIdx.x / ntiles;
+    int I = (int)((sqrt(8.0 * tile + 1.0) - 1.0) * 0.5);
+    while ((I + 1) * (I + 2) / 2 <= tile) ++I;
+    while (I * (I + 1) / 2 > tile) --I;
+    const int J = tile - I * (I + 1) / 2;
+    const int c0 = split * chunks_per_split, c1 = min(chunks_total, c0 + chunks_per_split);
+    double* Cb = (nsplit == 1) ? S + (size_t)I * NB * lda + (size_t)J * NB : ws + ((size_t)split * ntiles + tile) * NB * NB;
+    const int ldc = (nsplit == 1) ? lda : NB;
+    if (c1 <= c0) {         // (an empty slice still defines its partial tile)
+        for (int e = threadIdx.x; e < NB * NB; e += 512) Cb[(size_t)(e / NB) * ldc + e % NB] = 0.0;
+        return;
+    }
+    syrk_tile512_gen<128>(Cb, ldc, Y + (size_t)I * NB * ldy + (size_t)c0 * 16, ldy, Y + (size_t)J * NB * ldy + (size_t)c0 * 16, ldy, true, smem,
+                          threadIdx.x, c1 - c0);
+}
+// S tile = sum of the slices' partial tiles, in slice order; diagonal tiles keep their lower triangle only (the strictly upper part
+// of the matrix is never read, but the diagonal 6 x 6 blocks are completed by later kernels that expect zeros there)
+__global__ __launch_bounds__(256) void yyt_reduce_kernel(const double* __restrict__ ws, int ntiles, int nsplit, double* __restrict__ S, int lda) {
+    const int tile = blockIdx.x / (NB * NB / 256);
+    const int e = (blockIdx.x % (NB * NB / 256)) * 256 + threadIdx.x;
+    int I = (int)((sqrt(8.0 * tile + 1.0) - 1.0) * 0.5);
+    while ((I + 1) * (I + 2) / 2 <= tile) ++I;
+    while (I * (I + 1) / 2 > tile) --I;
+    const int J = tile - I * (I + 1) / 2;
+    const int r = e / NB, c = e % NB;
+    double s = 0.0;
+    if (nsplit == 1) s = S[((size_t)I * NB + r) * lda + (size_t)J * NB + c];
+    else for (int k = 0; k < nsplit; ++k) s += ws[((size_t)k * ntiles + tile) * NB * NB + e];
+    if (I == J && c > r) s = 0.0;
+    S[((size_t)I * NB + r) * lda + (size_t)J * NB + c] = s;
+}
+// K slices: enough workgroups to fill the part several times over when the matrix has few tiles
+static int yyt_splits(int ntiles, int chunks_total) {
+    int ns = (ntiles >= 1024) ? 1 : (1024 + ntiles - 1) / ntiles;
+    ns = std::min(ns, 64);
+    ns = std::min(ns, std::max(1, chunks_total / 8));     // at least 128 columns per slice
+    return std::max(1, ns);
+}
+size_t chol_yyt_workspace_doubles(int lda, size_t kcols) {
+    const int nb = lda / NB, ntiles = nb * (nb + 1) / 2;
+    const int ns = yyt_splits(ntiles, (int)(kcols / 16));
+    return ns == 1 ? 0 : (size_t)ns * ntiles * NB * NB;
+}
+int chol_yyt_lower_dev(const double* Y, size_t ldy, size_t kcols, double* S, int lda, double* ws, hipStream_t st) {
+    if (lda % NB != 0 || kcols % 16 != 0 || ldy < kcols) return fail(STBA_ERR_INVALID_ARGUMENT, "chol_yyt_lower_dev: bad dimensions");
+    const int nb = lda / NB, ntiles = nb * (nb + 1) / 2;
+    const int chunks_total = (int)(kcols / 16);
+    const int ns = yyt_splits(ntiles, chunks_total);
+    if (ns > 1 && !ws) return fail(STBA_ERR_INVALID_ARGUMENT, "chol_yyt_lower_dev: workspace missing");
+    const int cps = (chunks_total + ns - 1) / ns;
+    constexpr int LDS = 2 * (128 + 128) * 16 * (int)sizeof(double);
+    static DeviceOnce attr;
+    STBA_TRY(attr.run([]() -> int {
+        STBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(yyt_tile_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        return STBA_OK;
+    }));
+    hipLaunchKernelGGL(yyt_tile_kernel, dim3((unsigned)(ntiles * ns)), dim3(512), LDS, st, Y, ldy, S, lda, ntiles, ns, cps, chunks_total, ws);
+    hipLaunchKernelGGL(yyt_reduce_kernel, dim3((unsigned)(ntiles * (NB * NB / 256))), dim3(256), 0, st, ws, ntiles, ns, S, lda);
     STBA_HIP(hipGetLastError());
     return STBA_OK;
 }

@@ -96,6 +96,11 @@ struct stba_ba {
     int *pair_begin = nullptr, *pair_end = nullptr;
     int4* pair_rec = nullptr;           // (i, l, landmark, slot | flags)
     double schur_pairs = 0.0, schur_lds_atomics = 0.0;   // per launch of the Schur kernel (measurement)
+    // the Schur complement as a dense symmetric product (dense visibility; ba_kernels.hip "DENSE visibility", stba_ba_set_schur_mode)
+    int schur_mode = STBA_SCHUR_PAIRS, schur_mode_auto = STBA_SCHUR_PAIRS;
+    bool have_pair_plan = false;
+    double* Y = nullptr; size_t ldy = 0, ykcols = 0;     // [lda][ldy]
+    double *yv = nullptr, *yws = nullptr;
     unsigned char *cam_fixed = nullptr, *pt_fixed = nullptr;
     double2* r = nullptr;
     double* J8 = nullptr;            // compact Jacobian [n_obs][8] (ba_kernels.hip)
@@ -159,7 +164,7 @@ static void ba_free(stba_ba* b) {
     F(b->pt_fixed); F(b->r); F(b->J8); F(b->Jc12); F(b->omask); F(b->Hpp6); F(b->gp); F(b->Hinv6); F(b->dp); F(b->scale_p);
     F(b->Hcc); F(b->gc); F(b->cam_partial); F(b->dc); F(b->scale_c); F(b->Sbuf); F(b->Spack); F(b->pk_blocks); F(b->dxc); F(b->dxp);
     F(b->task_cam); F(b->cam_start); F(b->task_col_lo); F(b->task_col_hi); F(b->row_col_ptr); F(b->row_cols);
-    F(b->pair_begin); F(b->pair_end); F(b->pair_rec);
+    F(b->pair_begin); F(b->pair_end); F(b->pair_rec); F(b->Y); F(b->yv); F(b->yws);
     F(b->cost_partial); F(b->upd_partial_c); F(b->upd_partial_p); F(b->trial); F(b->flag);
     for (auto& e : b->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : b->ev_ar) if (e) (void)hipEventDestroy(e);
@@ -349,6 +354,47 @@ static void ba_collect_allreduce_time(stba_ba* b) {
     b->ar_timing_pending = false;
 }
 
+// Y for the dense form of the Schur complement: [lda][ldy] doubles, zeroed once (the visibility pattern is static)
+static int ba_dense_alloc(stba_ba* b) {
+    if (b->Y) return STBA_OK;
+    const size_t kcols = ((size_t)3 * b->np + 15) / 16 * 16;
+    const size_t ldy = kcols + ((kcols % 512 == 0) ? 16 : 0);          // (not a multiple of 4 KB: rows would alias in the memory channels)
+    const size_t ycount = (size_t)b->lda * ldy;
+    const size_t wcount = chol_yyt_workspace_doubles(b->lda, kcols);
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (ycount + wcount + kcols) * sizeof(double) > free_b / 10 * 9)
+        return fail(STBA_ERR_INVALID_ARGUMENT, "the dense form of the Schur complement needs " + std::to_string((ycount + wcount) * 8 / (1 << 20)) +
+                    " MiB (6 cameras x 3 landmarks doubles, padded), more than the device has free");
+    STBA_TRY(dev_alloc(&b->Y, ycount));
+    STBA_TRY(dev_alloc(&b->yv, kcols));
+    if (wcount) STBA_TRY(dev_alloc(&b->yws, wcount));
+    STBA_HIP(hipMemsetAsync(b->Y, 0, ycount * sizeof(double), b->st));
+    STBA_HIP(hipMemsetAsync(b->yv, 0, kcols * sizeof(double), b->st));
+    b->ldy = ldy; b->ykcols = kcols;
+    return STBA_OK;
+}
+
+// S (lower triangle), rhs, Hcc, gc from the linearisation and the inverse landmark blocks: the pair plan or the dense product
+static int ba_schur_step(stba_ba* b) {
+    if (b->schur_mode == STBA_SCHUR_DENSE) {
+        STBA_TRY(ba_dense_alloc(b));
+        SchurDenseArgs da;
+        da.n_cams = b->nc; da.n_pts = b->np; da.n_obs = b->no;
+        da.obs_cam = b->obs_cam; da.obs_pt = b->obs_pt; da.cam_start = b->cam_start; da.cam_perm = b->cam_perm;
+        da.J8 = b->J8; da.omask = b->omask; da.Jc12 = b->hl_fn ? b->Jc12 : nullptr; da.r = b->r; da.Hinv6 = b->Hinv6; da.gp = b->gp;
+        da.Y = b->Y; da.ldy = b->ldy; da.kcols = b->ykcols; da.v = b->yv; da.ws = b->yws;
+        da.S = b->S(); da.lda = b->lda; da.rhs = b->rhs(); da.Hcc = b->Hcc; da.gc = b->gc;
+        return launch_schur_dense(da, b->st);
+    }
+    SchurArgs sa;
+    sa.task_cam = b->task_cam; sa.cam_start = b->cam_start; sa.task_col_lo = b->task_col_lo; sa.task_col_hi = b->task_col_hi;
+    sa.row_col_ptr = b->row_col_ptr; sa.row_cols = b->row_cols; sa.max_cols = b->max_cols; sa.cam_perm = b->cam_perm;
+    sa.J8 = b->J8; sa.omask = b->omask; sa.Jc12 = b->hl_fn ? b->Jc12 : nullptr; sa.r = b->r; sa.Hinv6 = b->Hinv6; sa.gp = b->gp;
+    sa.S = b->S(); sa.lda = b->lda; sa.rhs = b->rhs(); sa.Hcc = b->Hcc; sa.gc = b->gc;
+    sa.obs_pt = b->obs_pt; sa.pair_begin = b->pair_begin; sa.pair_end = b->pair_end; sa.pair_rec = b->pair_rec;
+    return launch_schur_rows(sa, b->n_tasks, b->st);
+}
+
 static int ba_build_reduced(stba_ba* b, const Damping& dm, bool export_host = false) {
     b->lin_exported = false;
     const int init_scale = b->scale_init ? 0 : 1;
@@ -361,16 +407,8 @@ static int ba_build_reduced(stba_ba* b, const Damping& dm, bool export_host = fa
         STBA_TRY(launch_point_invert(b->np, b->Hpp6, b->dp, b->pt_fixed, b->Hinv6, b->st));
         STBA_HIP(hipMemsetAsync(extras, 0, 3 * (size_t)b->lda * sizeof(double), b->st));
     }
-    // S is zeroed by the Schur kernel itself (every task its own stretch of its six rows)
-    {
-        SchurArgs sa;
-        sa.task_cam = b->task_cam; sa.cam_start = b->cam_start; sa.task_col_lo = b->task_col_lo; sa.task_col_hi = b->task_col_hi;
-        sa.row_col_ptr = b->row_col_ptr; sa.row_cols = b->row_cols; sa.max_cols = b->max_cols; sa.cam_perm = b->cam_perm;
-        sa.J8 = b->J8; sa.omask = b->omask; sa.Jc12 = b->hl_fn ? b->Jc12 : nullptr; sa.r = b->r; sa.Hinv6 = b->Hinv6; sa.gp = b->gp;
-        sa.S = b->S(); sa.lda = b->lda; sa.rhs = b->rhs(); sa.Hcc = b->Hcc; sa.gc = b->gc;
-        sa.obs_pt = b->obs_pt; sa.pair_begin = b->pair_begin; sa.pair_end = b->pair_end; sa.pair_rec = b->pair_rec;
-        STBA_TRY(launch_schur_rows(sa, b->n_tasks, b->st));
-    }
+    // S is zeroed (pair plan) or overwritten (dense product) by the Schur step itself
+    STBA_TRY(ba_schur_step(b));
     if (!b->ar && !dm.explicit_d && b->n == 6 * b->nc) {
         // one rank: camera blocks, LM diagonal, damping and padding in one launch
         double* host_out = nullptr;
@@ -1003,15 +1041,31 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
         size_t free_b = 0, total_b = 0;
         const bool have_info = hipMemGetInfo(&free_b, &total_b) == hipSuccess;
         const size_t cap = std::min<size_t>((size_t)1 << 30, have_info ? free_b / 2 / 16 : ((size_t)1 << 30));
-        if (total_pairs > cap) {
+        // dense visibility: the Schur complement as one symmetric product on the matrix cores instead (ba_kernels.hip): no plan
+        const double visibility = (n_pts > 0 && n_cams > 0) ? (double)n_obs / ((double)n_pts * n_cams) : 0.0;
+        const size_t y_bytes = (size_t)b->lda * (((size_t)3 * n_pts + 31) / 16 * 16) * sizeof(double);
+        const bool y_fits = !have_info || y_bytes < free_b / 2;
+        if (total_pairs > cap && !y_fits) {
             ba_free(b);
             return fail(STBA_ERR_INVALID_ARGUMENT, "stba_ba_create: " + std::to_string(total_pairs) + " observation pairs (sum over landmarks of k (k + 1) / 2, "
                         "k = cameras that see the landmark) need a Schur plan of " + std::to_string(total_pairs * 16 / (1 << 20)) + " MiB; the limit here is " +
-                        std::to_string(cap) + " pairs (2^30, or half of the free device memory)");
+                        std::to_string(cap) + " pairs (2^30, or half of the free device memory) -- and the dense form needs " +
+                        std::to_string(y_bytes / (1 << 20)) + " MiB, which the device does not have free either");
         }
+        // (measured, tools/dense_schur_time.py, 59 % visibility: 29 x 600 -- 94 k pairs -- 0.053 ms either way; 60 x 12 000 -- 7.8 M pairs --
+        // 1.30 ms by the plan, 0.30 ms as a product; 100 x 8000 -- 14 M -- 1.53 against 0.37 ms)
+        if (total_pairs > cap || (total_pairs > ((size_t)1 << 20) && visibility >= 0.3 && y_fits)) b->schur_mode = b->schur_mode_auto = STBA_SCHUR_DENSE;
     }
+    const bool build_pair_plan = b->schur_mode != STBA_SCHUR_DENSE;
+    b->have_pair_plan = build_pair_plan;
     static const int TASK_PAIRS = std::max(256, knob_int("STBA_SCHUR_TASK_PAIRS", SCHUR_TASK_PAIRS));
-    {
+    if (!build_pair_plan) {
+        // no plan: the block pattern (only the cross-rank packing reads it) is taken as full -- enumerating it costs as much as the pairs
+        for (int c = 0; c < n_cams; ++c) {
+            for (int c2 = 0; c2 <= c; ++c2) row_cols.push_back(c2);
+            row_col_ptr[c + 1] = (int)row_cols.size();
+        }
+    } else {
         std::vector<std::vector<int>> cols_of((size_t)n_cams), cnt_of((size_t)n_cams);
         host_parallel_for(n_cams, [&](int c_lo, int c_hi, int) {
             std::vector<int> stamp(n_cams, -1), slot_of((size_t)n_cams, 0);
@@ -1073,7 +1127,7 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
     // pair records (i, l, landmark, slot | flags) of every task, in task order
     std::vector<int> pair_begin, pair_end;
     std::vector<int4> pair_rec;
-    {
+    if (build_pair_plan) {
         const int ntask = (int)task_cam.size();
         pair_begin.resize((size_t)ntask); pair_end.resize((size_t)ntask);
         std::vector<size_t> cnt((size_t)ntask + 1, 0);
@@ -1137,10 +1191,10 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
     A_(dev_alloc(&b->pt_start, np + 1)); A_(dev_alloc(&b->cam_perm, no));
     A_(dev_alloc(&b->chunk_begin, (size_t)b->n_chunks)); A_(dev_alloc(&b->chunk_end, (size_t)b->n_chunks));
     A_(dev_alloc(&b->cam_chunk_start, nc + 1));
-    A_(dev_alloc(&b->task_cam, task_cam.size())); A_(dev_alloc(&b->cam_start, nc + 1));
-    A_(dev_alloc(&b->task_col_lo, task_cam.size())); A_(dev_alloc(&b->task_col_hi, task_cam.size()));
+    A_(dev_alloc(&b->task_cam, std::max<size_t>(task_cam.size(), 1))); A_(dev_alloc(&b->cam_start, nc + 1));
+    A_(dev_alloc(&b->task_col_lo, std::max<size_t>(task_cam.size(), 1))); A_(dev_alloc(&b->task_col_hi, std::max<size_t>(task_cam.size(), 1)));
     A_(dev_alloc(&b->row_col_ptr, nc + 1)); A_(dev_alloc(&b->row_cols, std::max<size_t>(row_cols.size(), 1)));
-    A_(dev_alloc(&b->pair_begin, pair_begin.size())); A_(dev_alloc(&b->pair_end, pair_end.size()));
+    A_(dev_alloc(&b->pair_begin, std::max<size_t>(pair_begin.size(), 1))); A_(dev_alloc(&b->pair_end, std::max<size_t>(pair_end.size(), 1)));
     A_(dev_alloc(&b->pair_rec, std::max<size_t>(pair_rec.size(), 1)));
     if (cam_fixed) A_(dev_alloc(&b->cam_fixed, nc));
     if (pt_fixed) A_(dev_alloc(&b->pt_fixed, np));
@@ -1190,6 +1244,22 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
 #undef A_
     tmark("uploads + sync");
     *out = b;
+    return STBA_OK;
+}
+
+int stba_ba_set_schur_mode(stba_ba* ba, int mode) {
+    if (!ba || mode < STBA_SCHUR_AUTO || mode > STBA_SCHUR_DENSE) return fail(STBA_ERR_INVALID_ARGUMENT, "stba_ba_set_schur_mode: bad argument");
+    if (mode == STBA_SCHUR_AUTO) mode = ba->schur_mode_auto;
+    if (mode == STBA_SCHUR_PAIRS && !ba->have_pair_plan)
+        return fail(STBA_ERR_INVALID_ARGUMENT, "stba_ba_set_schur_mode: this engine was created without a pair plan (too many observation pairs)");
+    if (mode == STBA_SCHUR_DENSE) STBA_TRY(ba_dense_alloc(ba));
+    ba->schur_mode = mode;
+    ba->have_reduced = ba->have_dxc = ba->have_dxp = false;
+    return STBA_OK;
+}
+int stba_ba_schur_mode(const stba_ba* ba, int* mode) {
+    if (!ba || !mode) return fail(STBA_ERR_INVALID_ARGUMENT, "stba_ba_schur_mode: bad argument");
+    *mode = ba->schur_mode;
     return STBA_OK;
 }
 
@@ -1425,15 +1495,9 @@ int stba_ba_time_schur(stba_ba* b, int reps, double* ms_avg, double* lds_atomics
     Damping dm;
     STBA_TRY(launch_point_damp_invert(b->np, b->Hpp6, b->pt_fixed, b->scale_p, b->scale_init ? 0 : 1, dm.use_scaling, dm.radius, dm.dmin,
                                       dm.dmax, b->dp, b->Hinv6, b->Sbuf + (size_t)b->lda * b->lda, 3 * b->lda, b->st));
-    SchurArgs sa;
-    sa.task_cam = b->task_cam; sa.cam_start = b->cam_start; sa.task_col_lo = b->task_col_lo; sa.task_col_hi = b->task_col_hi;
-    sa.row_col_ptr = b->row_col_ptr; sa.row_cols = b->row_cols; sa.max_cols = b->max_cols; sa.cam_perm = b->cam_perm;
-    sa.J8 = b->J8; sa.omask = b->omask; sa.r = b->r; sa.Hinv6 = b->Hinv6; sa.gp = b->gp;
-    sa.S = b->S(); sa.lda = b->lda; sa.rhs = b->rhs(); sa.Hcc = b->Hcc; sa.gc = b->gc;
-    sa.obs_pt = b->obs_pt; sa.pair_begin = b->pair_begin; sa.pair_end = b->pair_end; sa.pair_rec = b->pair_rec;
-    STBA_TRY(launch_schur_rows(sa, b->n_tasks, b->st));      // warm
+    STBA_TRY(ba_schur_step(b));      // warm
     STBA_HIP(hipEventRecord(b->ev[0], b->st));
-    for (int k = 0; k < reps; ++k) STBA_TRY(launch_schur_rows(sa, b->n_tasks, b->st));
+    for (int k = 0; k < reps; ++k) STBA_TRY(ba_schur_step(b));
     STBA_HIP(hipEventRecord(b->ev[1], b->st));
     STBA_HIP(hipStreamSynchronize(b->st));
     float ms = 0.f;

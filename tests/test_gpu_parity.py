@@ -581,3 +581,71 @@ print("RESULT", worst, st.cholesky_timeout_count())
         line = [l for l in out.splitlines() if l.startswith("RESULT")][0].split()
         assert float(line[1]) < 1e-11, line
         print("process: relative factor error", line[1], "time-outs (stage-kernel fallbacks)", line[2])
+
+
+# ------------------------------------------------------------------------------- the dense form of the Schur complement
+def _dense_visibility_scene(scenes, n_cams, n_pts, seed):
+    """a 143-degree field of view: every camera sees 59 % of the cube's landmarks"""
+    return scenes.st20_scene(n_cams=n_cams, n_pts=n_pts, seed=seed, pos_noise=0.1, ang_noise_deg=1.5, pix_noise=1e-3, half_w=3.0, half_h=3.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_cams,n_pts", [(12, 300), (30, 2000), (50, 777)])
+def test_dense_schur_form_builds_the_same_reduced_system(st, O, scenes, n_cams, n_pts):
+    """S = -(Y Y^T) on the matrix cores (STBA_SCHUR_DENSE) against the pair plan and against the oracle: same S, same rhs
+    (one tile, several tiles, split K; 50 cameras = 300 rows: three tile rows with a ragged last one)"""
+    s = _dense_visibility_scene(scenes, n_cams, n_pts, seed=7)
+    s["cam_fixed"] = s["cam_fixed"].copy(); s["cam_fixed"][3, 4] = 1           # a constant dof in the middle as well
+    e, o = engine(st, s), oracle(O, s)
+    assert e.schur_mode() == e.SCHUR_PAIRS                                     # (small: the engine keeps the pair plan by itself)
+    e.evaluate(); e.normal_blocks()
+    _, ro, Jco, Jpo = o.evaluate()
+    rng = np.random.default_rng(2)
+    dc = rng.uniform(0.01, 0.1, (e.nc, 6)); dp = rng.uniform(0.01, 0.1, (e.np_, 3))
+    S1, rhs1 = e.reduced_system(dc, dp)
+    e.set_schur_mode(e.SCHUR_DENSE)
+    assert e.schur_mode() == e.SCHUR_DENSE
+    e.evaluate(); e.normal_blocks()
+    S2, rhs2 = e.reduced_system(dc, dp)
+    So, rhso = o.reduced_system(ro, Jco, Jpo, dc, dp)
+    # (the two forms round differently -- W Hinv W^T against (W R)(W R)^T -- and the diagonal blocks are differences of large
+    # sums: 1e-10 of the largest entry, where the pair plan and the oracle, which share their formula, agree to 1e-11)
+    scale = np.abs(So).max()
+    assert np.abs(np.tril(S2) - np.tril(So)).max() < 1e-10 * scale
+    assert np.abs(np.tril(S2) - np.tril(S1)).max() < 1e-10 * scale
+    assert np.abs(rhs2 - rhso).max() < 1e-10 * max(1.0, np.abs(rhso).max())
+    assert np.abs(rhs2 - rhs1).max() < 1e-10 * max(1.0, np.abs(rhso).max())
+    S3, _ = e.reduced_system(dc, dp)                                           # no atomics anywhere in this form: bit for bit
+    assert np.array_equal(np.tril(S3), np.tril(S2))
+    dxc = e.solve_reduced()
+    ref = np.linalg.solve(np.tril(So) + np.tril(So, -1).T, rhso)
+    assert np.abs(dxc - ref).max() < 1e-9 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.gpu
+def test_dense_schur_form_solves_like_the_pair_plan_and_the_oracle(st, O, scenes):
+    s = _dense_visibility_scene(scenes, 29, 600, seed=20)
+    e1, e2, o = engine(st, s), engine(st, s), oracle(O, s)
+    e2.set_schur_mode(e2.SCHUR_DENSE)
+    s1, t1 = e1.solve(); s2, t2 = e2.solve(); so, to = o.solve()
+    assert s2.termination_type == 0 and s2.num_iterations == s1.num_iterations == so.num_iterations
+    assert np.allclose(t2[:, 0], to[:, 0], rtol=1e-8, atol=1e-12)
+    c1, p1 = e1.get_params(); c2, p2 = e2.get_params()
+    assert max(pose_err(c2, c1)) < 1e-9 and max(pose_err(c2, o.cams)) < 1e-8 and np.abs(p2 - p1).max() < 1e-8
+
+
+@pytest.mark.gpu
+def test_dense_visibility_picks_the_dense_form_by_itself(st, scenes):
+    """120 cameras of which 71 see any one of 8000 landmarks: 20.6 M observation pairs at 59 % visibility -- the engine takes the
+    matrix-core form without being told (and the pair plan is not even built)"""
+    s = _dense_visibility_scene(scenes, 120, 8000, seed=3)
+    assert len(s["obs_cam"]) > 0.55 * 120 * len(s["pts0"])
+    e = engine(st, s)
+    assert e.schur_mode() == e.SCHUR_DENSE
+    with pytest.raises(st.StbaError):
+        e.set_schur_mode(e.SCHUR_PAIRS)
+    c0 = e.cost()
+    summ, tr = e.solve()
+    assert summ.termination_type == 0 and summ.final_cost < 1e-3 * c0
+    dq, dt = pose_err(e.get_params()[0], s["cams_true"])
+    assert dq < 1e-3 and dt < 1e-2                                             # (1e-3 pixel noise: the truth up to the noise)
