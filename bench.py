@@ -47,7 +47,8 @@ BYTES_PER_OBS_JAC = 106.5    # residual + COMPACT Jacobian kernel at 10 obs/land
 
 def load_scene(args, rank):
     scenes = importlib.import_module("slam-tricks_amd.scenes")
-    tag = f"c{args.cams}_p{args.pts}_m{args.obs_per_pt}_s20"
+    dense = bool(getattr(args, "dense_visibility", False))
+    tag = f"c{args.cams}_p{args.pts}_m{'all' if dense else args.obs_per_pt}_s20"
     cache = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"stba_scene_{tag}.npz")
     if os.path.exists(cache):
         try:
@@ -55,8 +56,12 @@ def load_scene(args, rank):
             return {k: z[k] for k in z.files}
         except Exception:
             pass
-    s = scenes.st20_scene(n_cams=args.cams, n_pts=args.pts, max_obs_per_pt=args.obs_per_pt, seed=20,
-                          pix_noise=1e-3)
+    if dense:
+        s = scenes.st20_scene(n_cams=args.cams, n_pts=args.pts, max_obs_per_pt=None, seed=20, pix_noise=1e-3, half_w=3.0, half_h=3.0,
+                              retriangulate=False)
+    else:
+        s = scenes.st20_scene(n_cams=args.cams, n_pts=args.pts, max_obs_per_pt=args.obs_per_pt, seed=20,
+                              pix_noise=1e-3)
     if rank == 0:
         try:
             np.savez(cache + f".tmp{os.getpid()}.npz", **s)
@@ -277,6 +282,10 @@ def main():
     ap.add_argument("--cams", type=int, default=1000)
     ap.add_argument("--pts", type=int, default=100000)
     ap.add_argument("--obs-per-pt", type=int, default=10)
+    ap.add_argument("--dense-visibility", action="store_true",
+                    help="a scene where every camera sees every landmark in front of it (143 degree field of view, no observation cap): the Schur "
+                         "complement then runs as one symmetric product on the matrix cores (DESIGN.md 4); with few cameras and many landmarks "
+                         "(--cams 100 --pts 200000) this is the workload landmark sharding scales on")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-library-baseline", action="store_true", help="skip the rocSOLVER potrf cross-check")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: CPU rendezvous test of the launch path")
@@ -414,7 +423,8 @@ def main():
         "n_gpus": world, "ranks": world if dist is None else dist.get_world_size(), "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_step, "reps": len(rep_ms), "reps_ms_per_step": rep_ms, "timing": "median of reps, max over ranks",
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"C5 large synthetic BA: {n_cams} cams, {n_pts} pts, {n_obs} obs "
+        "config": {"workload": ("dense-visibility synthetic BA (not a BASELINE config; the matrix-core form of the Schur complement): "
+                                if args.dense_visibility else "C5 large synthetic BA: ") + f"{n_cams} cams, {n_pts} pts, {n_obs} obs "
                                f"({2 * n_obs} residuals), Schur + dense {6 * n_cams}x{6 * n_cams} Cholesky, "
                                "st20 spiral/cube scene seed 20, pixel noise 1e-3",
                    "parallelism": f"landmark-shard x{world}" if world > 1 else "single GPU",
@@ -517,8 +527,18 @@ def main():
                                  "traffic_source": traffic_source(pk_path, pk, "FETCH_SIZE + WRITE_SIZE per launch at C5, RAW (the pair loop gathers 64-B records: "
                                                                   "narrow requests, not the wide coalesced reads the gfx950 doubling is for); the second bound of the "
                                                                   "kernel: 65 MB of Jacobian records are fetched several times over by the pair loop")}
+        if eng.schur_mode() == eng.SCHUR_DENSE:
+            # dense visibility: S = -(Y Y^T) on the matrix cores; algorithmic flops of the lower triangle: n^2 / 2 entries x K x 2
+            n_local_pts = len(sh["pts0"])
+            yyt_flops = float(nred) * nred * 3.0 * n_local_pts
+            out["roofline_schur"] = {"kernel": "ba_schur_yfill_kernel + yyt_tile_kernel (dense visibility: S = -(Y Y^T), v_mfma_f64_16x16x4_f64; timing: the whole "
+                                               "Schur step, Y fill, product, right-hand side and camera blocks)",
+                                     "bound": "mfma", "achieved": yyt_flops / (ms_schur * 1e-3) / 1e12, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                     "frac": yyt_flops / (ms_schur * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, "ms_per_launch": ms_schur,
+                                     "algorithmic_flops_per_launch": yyt_flops, "traffic": None}
         # the dominant kernel by device time carries the headline roofline object
         out["roofline"] = roof_chol if ms_factor > ms_jac else roof_jac
+        if eng.schur_mode() == eng.SCHUR_DENSE and ms_schur > max(ms_factor, ms_jac): out["roofline"] = out["roofline_schur"]
         out["roofline_jacobian"] = roof_jac
         out["roofline_mfma"] = roof_chol
         out["cholesky_ms"] = {"factor_persistent_kernel": ms_factor, "backward": ms_bwd,
@@ -642,7 +662,7 @@ def main():
             t_repl = ph["ms_solve"]
             t_shard = max(0.0, ph["ms_linearize"] + ph["ms_schur"] - out["allreduce_ms"] + ph["ms_backsub"] + ph["ms_cost"]) * world
             t_other = max(0.0, ms_step - (ph["ms_linearize"] + ph["ms_schur"] + ph["ms_solve"] + ph["ms_backsub"] + ph["ms_cost"]))
-            ar_bytes = out["allreduce_bytes"] if world > 1 else 40.7e6 * (n_cams / 1000.0) ** 2
+            ar_bytes = out["allreduce_bytes"] if world > 1 else (4.0 * nred * (nred + 1) if args.dense_visibility else 40.7e6 * (n_cams / 1000.0) ** 2)
             pred = {}
             for N in (1, 2, 4, 8):
                 ring = 0.0 if N == 1 else 2.0 * (N - 1) / N * ar_bytes / 48e9 * 1e3

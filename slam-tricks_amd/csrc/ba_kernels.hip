@@ -880,114 +880,94 @@ __device__ inline void chol3_of_sym6(const double h[6], double R[6]) {
     const double r22 = d2 > 0.0 ? sqrt(d2) : 0.0;
     R[0] = r00; R[1] = r10; R[2] = r20; R[3] = r11; R[4] = r21; R[5] = r22;
 }
+// One WAVE per chunk of <= CAM_CHUNK observations of ONE camera (the camera-sorted permutation, landmarks ascending inside a camera:
+// the lanes of a wave write neighbouring 24-byte pieces of the camera's six rows of Y).  On the way the wave sums what else the
+// Schur step owes for its camera: the camera block Jc^T Jc (21), Jc^T r (6) and the right-hand side sum_i W_i Hpp^-1 gp (6); a
+// second kernel adds a camera's chunks in order (no atomics: bitwise reproducible).
+constexpr int YCAM_LD = 36;      // doubles per chunk partial: 21 + 6 + 6, padded
 template <bool GEN>
-__global__ __launch_bounds__(256) void ba_schur_yfill_kernel(int n_obs, const int* __restrict__ obs_cam, const int* __restrict__ obs_pt,
-                                                             const double* __restrict__ J8, const unsigned char* __restrict__ omask,
-                                                             const double* __restrict__ Jc12, const double* __restrict__ Hinv6,
-                                                             double* __restrict__ Y, size_t ldy) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n_obs) return;
-    const int c = obs_cam[i], j = obs_pt[i];
-    double jc[12], jp[6], h[6], R[6];
-    load_jc_jp<GEN>(J8, omask, i, jc, jp, Jc12);
+__global__ __launch_bounds__(256) void ba_schur_dense_chunk_kernel(int n_chunks, const int* __restrict__ chunk_begin, const int* __restrict__ chunk_end,
+                                                                   const int* __restrict__ cam_perm, const int* __restrict__ obs_cam,
+                                                                   const int* __restrict__ obs_pt, const double* __restrict__ J8,
+                                                                   const unsigned char* __restrict__ omask, const double* __restrict__ Jc12,
+                                                                   const double2* __restrict__ r, const double* __restrict__ Hinv6,
+                                                                   const double* __restrict__ gp, double* __restrict__ Y, size_t ldy,
+                                                                   double* __restrict__ partial) {
+    const int lane = threadIdx.x & 63;
+    const int ch = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ch >= n_chunks) return;
+    double acc[33];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) h[k] = Hinv6[(size_t)j * 6 + k];
-    chol3_of_sym6(h, R);
-#pragma unroll
-    for (int q = 0; q < 6; ++q) {
-        const double w0 = jc[q] * jp[0] + jc[6 + q] * jp[3];
-        const double w1 = jc[q] * jp[1] + jc[6 + q] * jp[4];
-        const double w2 = jc[q] * jp[2] + jc[6 + q] * jp[5];
-        double* y = Y + (size_t)(c * 6 + q) * ldy + (size_t)j * 3;
-        y[0] = w0 * R[0] + w1 * R[1] + w2 * R[2];
-        y[1] = w1 * R[3] + w2 * R[4];
-        y[2] = w2 * R[5];
-    }
-}
-// v_j = R_j^T gp_j
-__global__ __launch_bounds__(256) void ba_schur_yvec_kernel(int n_pts, const double* __restrict__ Hinv6, const double* __restrict__ gp,
-                                                            double* __restrict__ v) {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= n_pts) return;
-    double h[6], R[6];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) h[k] = Hinv6[(size_t)j * 6 + k];
-    chol3_of_sym6(h, R);
-    const double g0 = gp[(size_t)j * 3], g1 = gp[(size_t)j * 3 + 1], g2 = gp[(size_t)j * 3 + 2];
-    v[(size_t)j * 3] = R[0] * g0 + R[1] * g1 + R[2] * g2;
-    v[(size_t)j * 3 + 1] = R[3] * g1 + R[4] * g2;
-    v[(size_t)j * 3 + 2] = R[5] * g2;
-}
-// rhs[row] = sum_k Y[row, k] v[k]: one workgroup per row, a strided share per lane, fixed-order sums (bitwise reproducible)
-__global__ __launch_bounds__(256) void ba_schur_yrhs_kernel(const double* __restrict__ Y, size_t ldy, size_t kcols, const double* __restrict__ v,
-                                                            double* __restrict__ rhs) {
-    __shared__ double part[4];
-    const double* y = Y + (size_t)blockIdx.x * ldy;
-    double s = 0.0;
-    for (size_t k = threadIdx.x; k < kcols; k += 256) s += y[k] * v[k];
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) rhs[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
-}
-// camera blocks Hcc = sum Jc^T Jc, gc = sum Jc^T r of camera c over its observations (the pair kernel makes them on its way)
-template <bool GEN>
-__global__ __launch_bounds__(256) void ba_camera_blocks_kernel(const int* __restrict__ cam_start, const int* __restrict__ cam_perm,
-                                                               const double* __restrict__ J8, const unsigned char* __restrict__ omask,
-                                                               const double* __restrict__ Jc12, const double2* __restrict__ r,
-                                                               double* __restrict__ Hcc, double* __restrict__ gc) {
-    __shared__ double cpart[4][28];
-    const int c = blockIdx.x, tid = threadIdx.x;
-    double h[27];
-#pragma unroll
-    for (int k = 0; k < 27; ++k) h[k] = 0.0;
-    for (int p = cam_start[c] + tid; p < cam_start[c + 1]; p += 256) {
+    for (int k = 0; k < 33; ++k) acc[k] = 0.0;
+    const int e = chunk_end[ch];
+    for (int p = chunk_begin[ch] + lane; p < e; p += 64) {
         const int i = cam_perm[p];
-        double j[12], jpu[6];
-        load_jc_jp<GEN>(J8, omask, i, j, jpu, Jc12);
+        const int c = obs_cam[i], j = obs_pt[i];
+        double jc[12], jp[6], h[6], R[6];
+        load_jc_jp<GEN>(J8, omask, i, jc, jp, Jc12);
         const double2 ri = r[i];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) h[k] = Hinv6[(size_t)j * 6 + k];
+        const double g0 = gp[(size_t)j * 3], g1 = gp[(size_t)j * 3 + 1], g2 = gp[(size_t)j * 3 + 2];
+        chol3_of_sym6(h, R);
+        const double t0 = h[0] * g0 + h[1] * g1 + h[2] * g2, t1 = h[1] * g0 + h[3] * g1 + h[4] * g2, t2 = h[2] * g0 + h[4] * g1 + h[5] * g2;
         int idx = 0;
 #pragma unroll
-        for (int q = 0; q < 6; ++q)
+        for (int q = 0; q < 6; ++q) {
+            const double w0 = jc[q] * jp[0] + jc[6 + q] * jp[3];
+            const double w1 = jc[q] * jp[1] + jc[6 + q] * jp[4];
+            const double w2 = jc[q] * jp[2] + jc[6 + q] * jp[5];
+            double* y = Y + (size_t)(c * 6 + q) * ldy + (size_t)j * 3;
+            y[0] = w0 * R[0] + w1 * R[1] + w2 * R[2];
+            y[1] = w1 * R[3] + w2 * R[4];
+            y[2] = w2 * R[5];
 #pragma unroll
-            for (int b = 0; b <= q; ++b) h[idx++] += j[q] * j[b] + j[6 + q] * j[6 + b];
-#pragma unroll
-        for (int q = 0; q < 6; ++q) h[21 + q] += j[q] * ri.x + j[6 + q] * ri.y;
+            for (int b = 0; b <= q; ++b) acc[idx++] += jc[q] * jc[b] + jc[6 + q] * jc[6 + b];
+            acc[21 + q] += jc[q] * ri.x + jc[6 + q] * ri.y;
+            acc[27 + q] += w0 * t0 + w1 * t1 + w2 * t2;
+        }
     }
 #pragma unroll
-    for (int k = 0; k < 27; ++k) {
-        double v = h[k];
+    for (int k = 0; k < 33; ++k) {
+        double v = acc[k];
         for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-        if ((tid & 63) == 0) cpart[tid >> 6][k] = v;
+        acc[k] = v;
     }
-    __syncthreads();
-    if (tid < 27) {
-        const double s = (cpart[0][tid] + cpart[1][tid]) + (cpart[2][tid] + cpart[3][tid]);
-        if (tid < 21) {
-            int q = 0, b = tid;
-            while (b > q) { ++q; b -= q; }   // tid = q(q+1)/2 + b
-            Hcc[(size_t)c * 36 + q * 6 + b] = s;
-            Hcc[(size_t)c * 36 + b * 6 + q] = s;
-        } else gc[(size_t)c * 6 + (tid - 21)] = s;
+    if (lane == 0) {
+        double* o = partial + (size_t)ch * YCAM_LD;
+#pragma unroll
+        for (int k = 0; k < 33; ++k) o[k] = acc[k];
     }
 }
+__global__ __launch_bounds__(256) void ba_schur_dense_final_kernel(int n_cams, const int* __restrict__ cam_chunk_start, const double* __restrict__ partial,
+                                                                   double* __restrict__ Hcc, double* __restrict__ gc, double* __restrict__ rhs) {
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    const int c = gid / 33, k = gid - c * 33;
+    if (c >= n_cams) return;
+    double s = 0.0;
+    const int e = cam_chunk_start[c + 1];
+    for (int ch = cam_chunk_start[c]; ch < e; ++ch) s += partial[(size_t)ch * YCAM_LD + k];
+    if (k < 21) {
+        int a = 0, b = k;
+        while (b > a) { ++a; b -= a; }   // k = a(a+1)/2 + b
+        Hcc[(size_t)c * 36 + a * 6 + b] = s;
+        Hcc[(size_t)c * 36 + b * 6 + a] = s;
+    } else if (k < 27) gc[(size_t)c * 6 + (k - 21)] = s;
+    else rhs[(size_t)c * 6 + (k - 27)] = s;
+}
+size_t schur_dense_partial_doubles(int n_chunks) { return (size_t)std::max(1, n_chunks) * YCAM_LD; }
 
 int launch_schur_dense(const SchurDenseArgs& a, hipStream_t st) {
-    if (a.n_obs > 0) {
-        if (a.Jc12) hipLaunchKernelGGL(ba_schur_yfill_kernel<true>, dim3((a.n_obs + 255) / 256), dim3(256), 0, st, a.n_obs, a.obs_cam, a.obs_pt, a.J8,
-                                       a.omask, a.Jc12, a.Hinv6, a.Y, a.ldy);
-        else hipLaunchKernelGGL(ba_schur_yfill_kernel<false>, dim3((a.n_obs + 255) / 256), dim3(256), 0, st, a.n_obs, a.obs_cam, a.obs_pt, a.J8,
-                                a.omask, a.Jc12, a.Hinv6, a.Y, a.ldy);
+    if (a.n_chunks > 0) {
+        if (a.Jc12) hipLaunchKernelGGL(ba_schur_dense_chunk_kernel<true>, dim3((a.n_chunks + 3) / 4), dim3(256), 0, st, a.n_chunks, a.chunk_begin, a.chunk_end,
+                                       a.cam_perm, a.obs_cam, a.obs_pt, a.J8, a.omask, a.Jc12, a.r, a.Hinv6, a.gp, a.Y, a.ldy, a.partial);
+        else hipLaunchKernelGGL(ba_schur_dense_chunk_kernel<false>, dim3((a.n_chunks + 3) / 4), dim3(256), 0, st, a.n_chunks, a.chunk_begin, a.chunk_end,
+                                a.cam_perm, a.obs_cam, a.obs_pt, a.J8, a.omask, a.Jc12, a.r, a.Hinv6, a.gp, a.Y, a.ldy, a.partial);
     }
-    if (a.n_pts > 0) hipLaunchKernelGGL(ba_schur_yvec_kernel, dim3((a.n_pts + 255) / 256), dim3(256), 0, st, a.n_pts, a.Hinv6, a.gp, a.v);
     STBA_TRY(chol_yyt_lower_dev(a.Y, a.ldy, a.kcols, a.S, a.lda, a.ws, st));
-    if (a.n_cams > 0) {
-        hipLaunchKernelGGL(ba_schur_yrhs_kernel, dim3(6 * a.n_cams), dim3(256), 0, st, a.Y, a.ldy, (size_t)3 * a.n_pts, a.v, a.rhs);
-        if (a.Jc12) hipLaunchKernelGGL(ba_camera_blocks_kernel<true>, dim3(a.n_cams), dim3(256), 0, st, a.cam_start, a.cam_perm, a.J8, a.omask, a.Jc12,
-                                       a.r, a.Hcc, a.gc);
-        else hipLaunchKernelGGL(ba_camera_blocks_kernel<false>, dim3(a.n_cams), dim3(256), 0, st, a.cam_start, a.cam_perm, a.J8, a.omask, a.Jc12,
-                                a.r, a.Hcc, a.gc);
-    }
+    if (a.n_cams > 0)
+        hipLaunchKernelGGL(ba_schur_dense_final_kernel, dim3((a.n_cams * 33 + 255) / 256), dim3(256), 0, st, a.n_cams, a.cam_chunk_start, a.partial,
+                           a.Hcc, a.gc, a.rhs);
     STBA_HIP(hipGetLastError());
     return STBA_OK;
 }

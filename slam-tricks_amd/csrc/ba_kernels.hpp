@@ -78,15 +78,17 @@ struct SchurArgs {
 };
 // the Schur complement for dense visibility as a symmetric rank-k product (ba_kernels.hip, "DENSE visibility")
 struct SchurDenseArgs {
-    int n_cams, n_pts, n_obs;
-    const int* obs_cam; const int* obs_pt; const int* cam_start; const int* cam_perm;
+    int n_cams, n_chunks;                         // chunks of <= CAM_CHUNK observations of one camera (the camera-block machinery's)
+    const int* chunk_begin; const int* chunk_end; const int* cam_chunk_start; const int* cam_perm;
+    const int* obs_cam; const int* obs_pt;
     const double* J8; const unsigned char* omask; const double* Jc12; const double2* r;
     const double* Hinv6; const double* gp;
     double* Y; size_t ldy; size_t kcols;         // [lda][ldy], kcols = 3 n_pts rounded up to 16 (<= ldy); zero where nothing is observed
-    double* v;                                    // [kcols]
+    double* partial;                              // schur_dense_partial_doubles(n_chunks)
     double* ws;                                   // workspace of chol_yyt_workspace_doubles(lda, kcols) doubles (or null)
     double* S; int lda; double* rhs; double* Hcc; double* gc;
 };
+size_t schur_dense_partial_doubles(int n_chunks);
 int launch_schur_dense(const SchurDenseArgs& a, hipStream_t st);
 size_t schur_rows_lds_bytes(int max_cols);
 int launch_schur_rows(const SchurArgs& a, int n_tasks, hipStream_t st);

@@ -31,6 +31,7 @@
 #include <atomic>
 #include <cstdlib>
 #include <map>
+#include <mutex>
 #include <queue>
 #include <string>
 #include <vector>
@@ -2368,14 +2369,16 @@ int chol_spd_inverse_dev(double* W, int ldw, int np, int n_real, int* flag_dev, 
 // workgroup per (tile, K slice): the update task's loop (syrk_tile512_gen) over the slice's K range on a zero accumulator; with
 // more than one slice the partial tiles go to a workspace and are added in slice order (no atomics: bitwise reproducible).
 __global__ __launch_bounds__(512) void yyt_tile_kernel(const double* __restrict__ Y, size_t ldy, double* __restrict__ S, int lda, int ntiles, int nsplit,
-                                                       int chunks_per_split, int chunks_total, double* __restrict__ ws) {
+                                                       int chunks_per_split, int chunks_total, double* __restrict__ ws, const int2* __restrict__ tile_ij,
+                                                       int per_xcd) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    // slices of one tile side by side (they share nothing), tiles of one tile row in consecutive blocks
-    const int tile = blockIdx.x % ntiles, split = blockIdx.x / ntiles;
-    int I = (int)((sqrt(8.0 * tile + 1.0) - 1.0) * 0.5);
-    while ((I + 1) * (I + 2) / 2 <= tile) ++I;
-    while (I * (I + 1) / 2 > tile) --I;
-    const int J = tile - I * (I + 1) / 2;
+    // XCD-aware order: workgroup b runs on XCD b % 8; every XCD walks ONE contiguous stretch of the work list (K slice major, tiles
+    // in 8 x 8 blocks of the tile grid), so the ~64 workgroups resident on an XCD at a time are one block of tiles of one K slice:
+    // they stream 16 row panels of Y between them instead of 128, started together, and find each other's chunks in the XCD's L2
+    const int w = (int)(blockIdx.x % 8) * per_xcd + (int)(blockIdx.x / 8);
+    if (blockIdx.x / 8 >= (unsigned)per_xcd || w >= ntiles * nsplit) return;
+    const int split = w / ntiles, tile = w % ntiles;
+    const int I = tile_ij[tile].x, J = tile_ij[tile].y;
     const int c0 = split * chunks_per_split, c1 = min(chunks_total, c0 + chunks_per_split);
     double* Cb = (nsplit == 1) ? S + (size_t)I * NB * lda + (size_t)J * NB : ws + ((size_t)split * ntiles + tile) * NB * NB;
     const int ldc = (nsplit == 1) ? lda : NB;
@@ -2388,13 +2391,11 @@ __global__ __launch_bounds__(512) void yyt_tile_kernel(const double* __restrict_
 }
 // S tile = sum of the slices' partial tiles, in slice order; diagonal tiles keep their lower triangle only (the strictly upper part
 // of the matrix is never read, but the diagonal 6 x 6 blocks are completed by later kernels that expect zeros there)
-__global__ __launch_bounds__(256) void yyt_reduce_kernel(const double* __restrict__ ws, int ntiles, int nsplit, double* __restrict__ S, int lda) {
+__global__ __launch_bounds__(256) void yyt_reduce_kernel(const double* __restrict__ ws, int ntiles, int nsplit, double* __restrict__ S, int lda,
+                                                         const int2* __restrict__ tile_ij) {
     const int tile = blockIdx.x / (NB * NB / 256);
     const int e = (blockIdx.x % (NB * NB / 256)) * 256 + threadIdx.x;
-    int I = (int)((sqrt(8.0 * tile + 1.0) - 1.0) * 0.5);
-    while ((I + 1) * (I + 2) / 2 <= tile) ++I;
-    while (I * (I + 1) / 2 > tile) --I;
-    const int J = tile - I * (I + 1) / 2;
+    const int I = tile_ij[tile].x, J = tile_ij[tile].y;
     const int r = e / NB, c = e % NB;
     double s = 0.0;
     if (nsplit == 1) s = S[((size_t)I * NB + r) * lda + (size_t)J * NB + c];
@@ -2404,7 +2405,9 @@ __global__ __launch_bounds__(256) void yyt_reduce_kernel(const double* __restric
 }
 // K slices: enough workgroups to fill the part several times over when the matrix has few tiles
 static int yyt_splits(int ntiles, int chunks_total) {
-    int ns = (ntiles >= 1024) ? 1 : (1024 + ntiles - 1) / ntiles;
+    // (two workgroups fit a CU: 512 at a time.  1128 tiles of a 6000 x 6000 system as ONE slice each are 2.2 rounds of 512 -- the third
+    // round runs a fifth full; at least eight rounds' worth of workgroups keep that tail under a few per cent)
+    int ns = (4096 + ntiles - 1) / ntiles;
     ns = std::min(ns, 64);
     ns = std::min(ns, std::max(1, chunks_total / 8));     // at least 128 columns per slice
     return std::max(1, ns);
@@ -2413,6 +2416,29 @@ size_t chol_yyt_workspace_doubles(int lda, size_t kcols) {
     const int nb = lda / NB, ntiles = nb * (nb + 1) / 2;
     const int ns = yyt_splits(ntiles, (int)(kcols / 16));
     return ns == 1 ? 0 : (size_t)ns * ntiles * NB * NB;
+}
+// the tiles of the lower triangle in 8 x 8 blocks of the tile grid (block rows top down, blocks left to right, row-major inside)
+static int yyt_tile_list(int nb, int2** out_dev) {
+    static std::mutex m;
+    static std::map<std::pair<int, int>, int2*> cache;      // (device, nb) -> list
+    int dev = 0;
+    STBA_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> g(m);
+    auto it = cache.find({dev, nb});
+    if (it == cache.end()) {
+        std::vector<int2> h;
+        for (int bi = 0; bi * 8 < nb; ++bi)
+            for (int bj = 0; bj <= bi; ++bj)
+                for (int i = bi * 8; i < std::min(nb, bi * 8 + 8); ++i)
+                    for (int j = bj * 8; j < std::min(nb, bj * 8 + 8); ++j)
+                        if (j <= i) h.push_back(make_int2(i, j));
+        int2* d = nullptr;
+        STBA_HIP(hipMalloc(reinterpret_cast<void**>(&d), h.size() * sizeof(int2)));
+        STBA_HIP(hipMemcpy(d, h.data(), h.size() * sizeof(int2), hipMemcpyHostToDevice));
+        it = cache.emplace(std::make_pair(dev, nb), d).first;
+    }
+    *out_dev = it->second;
+    return STBA_OK;
 }
 int chol_yyt_lower_dev(const double* Y, size_t ldy, size_t kcols, double* S, int lda, double* ws, hipStream_t st) {
     if (lda % NB != 0 || kcols % 16 != 0 || ldy < kcols) return fail(STBA_ERR_INVALID_ARGUMENT, "chol_yyt_lower_dev: bad dimensions");
@@ -2427,8 +2453,11 @@ int chol_yyt_lower_dev(const double* Y, size_t ldy, size_t kcols, double* S, int
         STBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(yyt_tile_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         return STBA_OK;
     }));
-    hipLaunchKernelGGL(yyt_tile_kernel, dim3((unsigned)(ntiles * ns)), dim3(512), LDS, st, Y, ldy, S, lda, ntiles, ns, cps, chunks_total, ws);
-    hipLaunchKernelGGL(yyt_reduce_kernel, dim3((unsigned)(ntiles * (NB * NB / 256))), dim3(256), 0, st, ws, ntiles, ns, S, lda);
+    int2* tile_ij = nullptr;
+    STBA_TRY(yyt_tile_list(nb, &tile_ij));
+    const int per_xcd = (ntiles * ns + 7) / 8;
+    hipLaunchKernelGGL(yyt_tile_kernel, dim3((unsigned)(per_xcd * 8)), dim3(512), LDS, st, Y, ldy, S, lda, ntiles, ns, cps, chunks_total, ws, tile_ij, per_xcd);
+    hipLaunchKernelGGL(yyt_reduce_kernel, dim3((unsigned)(ntiles * (NB * NB / 256))), dim3(256), 0, st, ws, ntiles, ns, S, lda, tile_ij);
     STBA_HIP(hipGetLastError());
     return STBA_OK;
 }

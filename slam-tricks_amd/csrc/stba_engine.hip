@@ -366,10 +366,9 @@ static int ba_dense_alloc(stba_ba* b) {
         return fail(STBA_ERR_INVALID_ARGUMENT, "the dense form of the Schur complement needs " + std::to_string((ycount + wcount) * 8 / (1 << 20)) +
                     " MiB (6 cameras x 3 landmarks doubles, padded), more than the device has free");
     STBA_TRY(dev_alloc(&b->Y, ycount));
-    STBA_TRY(dev_alloc(&b->yv, kcols));
+    STBA_TRY(dev_alloc(&b->yv, schur_dense_partial_doubles(b->n_chunks)));      // (the chunk partials of the camera sums)
     if (wcount) STBA_TRY(dev_alloc(&b->yws, wcount));
     STBA_HIP(hipMemsetAsync(b->Y, 0, ycount * sizeof(double), b->st));
-    STBA_HIP(hipMemsetAsync(b->yv, 0, kcols * sizeof(double), b->st));
     b->ldy = ldy; b->ykcols = kcols;
     return STBA_OK;
 }
@@ -379,10 +378,11 @@ static int ba_schur_step(stba_ba* b) {
     if (b->schur_mode == STBA_SCHUR_DENSE) {
         STBA_TRY(ba_dense_alloc(b));
         SchurDenseArgs da;
-        da.n_cams = b->nc; da.n_pts = b->np; da.n_obs = b->no;
-        da.obs_cam = b->obs_cam; da.obs_pt = b->obs_pt; da.cam_start = b->cam_start; da.cam_perm = b->cam_perm;
+        da.n_cams = b->nc; da.n_chunks = b->n_chunks;
+        da.chunk_begin = b->chunk_begin; da.chunk_end = b->chunk_end; da.cam_chunk_start = b->cam_chunk_start; da.cam_perm = b->cam_perm;
+        da.obs_cam = b->obs_cam; da.obs_pt = b->obs_pt;
         da.J8 = b->J8; da.omask = b->omask; da.Jc12 = b->hl_fn ? b->Jc12 : nullptr; da.r = b->r; da.Hinv6 = b->Hinv6; da.gp = b->gp;
-        da.Y = b->Y; da.ldy = b->ldy; da.kcols = b->ykcols; da.v = b->yv; da.ws = b->yws;
+        da.Y = b->Y; da.ldy = b->ldy; da.kcols = b->ykcols; da.partial = b->yv; da.ws = b->yws;
         da.S = b->S(); da.lda = b->lda; da.rhs = b->rhs(); da.Hcc = b->Hcc; da.gc = b->gc;
         return launch_schur_dense(da, b->st);
     }
