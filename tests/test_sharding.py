@@ -113,16 +113,21 @@ def test_two_rank_gloo_step_equals_single_process(scenes, O):
 
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_cams,n_pts,max_obs,sparse", [(24, 1500, 8, False), (200, 4000, 3, True)])
+@pytest.mark.parametrize("n_cams,n_pts,max_obs,sparse", [(24, 1500, 8, False), (200, 4000, 3, True), (40, 12000, 0, False)])
 def test_two_shards_on_one_gpu(scenes, O, n_cams, n_pts, max_obs, sparse):
     """two engines = two landmark shards, driven from two threads; the all-reduce hook sums the
     engines' device buffers in-process.  The sharded LM must follow the single-engine LM.
     Second case: few cameras per landmark -> most 6x6 blocks of the reduced system are zero on every rank,
-    and only the union of the non-zero blocks may travel (a 0/1 block mask is summed once, first)."""
+    and only the union of the non-zero blocks may travel (a 0/1 block mask is summed once, first).
+    Third case (max_obs = 0): dense visibility -- both shards and the single engine take the matrix-core form of the Schur complement
+    by themselves (no pair plan anywhere), each shard's product runs over its own landmarks, the partial systems are summed."""
     import torch
     st = importlib.import_module("slam-tricks_amd")
     sharding = importlib.import_module("slam-tricks_amd.sharding")
-    s = scenes.st20_scene(n_cams=n_cams, n_pts=n_pts, max_obs_per_pt=max_obs, seed=6, pix_noise=1e-3)
+    if max_obs == 0:
+        s = scenes.st20_scene(n_cams=n_cams, n_pts=n_pts, max_obs_per_pt=None, seed=6, pix_noise=1e-3, half_w=3.0, half_h=3.0)
+    else:
+        s = scenes.st20_scene(n_cams=n_cams, n_pts=n_pts, max_obs_per_pt=max_obs, seed=6, pix_noise=1e-3)
     world = 2
     bar = threading.Barrier(world)
     slots = [None] * world
@@ -149,6 +154,7 @@ def test_two_shards_on_one_gpu(scenes, O, n_cams, n_pts, max_obs, sparse):
         sh = sharding.make_shard(s, rank, world)
         e = st.BAEngine(sh["cams0"], sh["pts0"], sh["obs_cam"], sh["obs_pt"], sh["obs_feat"], sh["cam_fixed"])
         e.set_allreduce(make_hook(rank), rank, world)
+        assert (e.schur_mode() == e.SCHUR_DENSE) == (max_obs == 0)
         summ, tr = e.solve()
         out[rank] = (summ, tr, e.get_params(), sh)
 
