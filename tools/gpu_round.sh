@@ -2,7 +2,7 @@
 #   PMC passes of the Jacobian / assembly / factorisation kernels, stamped with the build head (tools/pmc_round.sh) -- FIRST, so that
 #   the bench line below can cite them (copy them to profiles/ before the final bench if the line is to name committed files);
 #   full bench line; rocprofv3 kernel summary of the same command; kernel timeline of one LM iteration; C4 line + its kernel summary;
-#   rocSOLVER cross-check; factorisation size sweep.
+#   rocSOLVER cross-check; factorisation size sweep; the dense-visibility table and bench line.
 # Regenerating profiles/ for a round = this script + `cp gpurun_out/<tag>_* profiles/`.
 export TMPDIR=/tmp
 TAG=${1:-tmp}
@@ -22,6 +22,9 @@ bash $R/tools/gpu_iter_trace.sh > $O/${TAG}_iter_trace.txt 2>&1
 bash $R/tools/gpu_c4.sh $TAG > $O/${TAG}_c4.log 2>&1
 python $R/tools/rocsolver_potrf.py 6000 12000 24000 > $O/${TAG}_rocsolver_potrf.txt 2>&1
 python $R/tools/size_sweep.py 3000 6000 9000 12000 16000 24000 > $O/${TAG}_size_sweep.txt 2>&1
+# dense visibility: the two forms of the Schur complement side by side, and the landmark-heavy bench line (not a BASELINE config)
+python $R/tools/dense_schur_time.py 29 600 60 12000 100 8000 300 8000 1000 20000 100 200000 2>&1 | grep -v amdgpu.ids > $O/${TAG}_dense_schur.txt
+python $R/bench.py --cams 100 --pts 200000 --dense-visibility --no-cpu-baseline --no-library-baseline --steps 20 --reps 3 > $O/${TAG}_dense_bench.json 2> $O/${TAG}_dense_bench.err
 head -12 $O/${TAG}_kernel_stats.csv | cut -c1-160
 tail -3 $O/${TAG}_bench_full.err
 cat $O/${TAG}_size_sweep.txt
