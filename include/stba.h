@@ -356,7 +356,12 @@ int stba_pg_create(stba_pg** out, int n_nodes, int n_edges, const double* poses,
 int stba_pg_destroy(stba_pg* pg);
 /* multi-GPU: this engine holds one shard of the EDGES (all nodes replicated); the hook sums the gradient and
  * diagonal blocks (42 n doubles per linearisation), every matrix-vector product of the PCG (6 n doubles) and
- * the cost scalars across ranks.  rank 0 owns the once-only damping term. */
+ * the cost scalars across ranks.  rank 0 owns the once-only damping term.
+ * REQUIREMENT on the hook: every rank must receive BIT-IDENTICAL sums (what ncclAllReduce / MPI_Allreduce give: one reduction
+ * order for all ranks).  The solve state is replicated and every rank decides from ITS copy of the device-side convergence
+ * flag how many further products -- i.e. collectives -- to enqueue; a hook whose result differs in the last bit between ranks
+ * (a reduce + broadcast is fine, a per-rank gather-and-sum in rank-dependent order is not) can make ranks disagree by one
+ * chunk of PCG iterations and hang in mismatched collectives. */
 int stba_pg_set_allreduce(stba_pg* pg, stba_allreduce_fn fn, void* user, int rank, int world_size);
 int stba_pg_set_comm(stba_pg* pg, stba_comm* comm);
 int stba_pg_get_poses(stba_pg* pg, double* poses);

@@ -58,6 +58,7 @@ class LMSummary(C.Structure):
 ITER_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double,
                       C.c_double, C.c_int)
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+LINEARIZE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
 RESIDUAL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double))
 PLUS_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double))
 
@@ -201,6 +202,28 @@ class BAEngine:
         cb = ALLREDUCE_FN(fn)
         self._keep.append(cb)
         _chk(lib().stba_ba_set_allreduce(self._h, cb, None, rank, world), "stba_ba_set_allreduce")
+
+    def set_host_linearizer(self, fn):
+        """fn(cams[nc,7], pts[np,3], want_jac) -> (r[no,2], Jc[no,2,6] | None, Jp[no,2,3] | None) in the CALLER's observation order
+        (stba_ba_set_host_linearizer: the factors are evaluated on the host, everything behind them runs on the device)"""
+        nc, np_, no = self.nc, self.np_, self.no
+
+        def tramp(user, cams_p, pts_p, r_p, jc_p, jp_p):
+            try:
+                cams = np.ctypeslib.as_array(C.cast(cams_p, C.POINTER(C.c_double)), (nc, 7))
+                pts = np.ctypeslib.as_array(C.cast(pts_p, C.POINTER(C.c_double)), (np_, 3))
+                want = bool(jc_p)
+                r, Jc, Jp = fn(cams, pts, want)
+                np.ctypeslib.as_array(C.cast(r_p, C.POINTER(C.c_double)), (no, 2))[:] = r
+                if want:
+                    np.ctypeslib.as_array(C.cast(jc_p, C.POINTER(C.c_double)), (no, 2, 6))[:] = Jc
+                    np.ctypeslib.as_array(C.cast(jp_p, C.POINTER(C.c_double)), (no, 2, 3))[:] = Jp
+                return 0
+            except Exception:
+                return 1
+        cb = LINEARIZE_FN(tramp)
+        self._keep.append(cb)
+        _chk(lib().stba_ba_set_host_linearizer(self._h, cb, None), "stba_ba_set_host_linearizer")
 
     def set_comm(self, comm):
         """landmark shard of a multi-GPU solve: cross-rank sums through a native RCCL communicator"""

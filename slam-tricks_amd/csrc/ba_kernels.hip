@@ -464,11 +464,14 @@ int launch_linear_finish(const double* cost_partial, int n_cost, const double* g
 // reduces them, lane 0 writes the chunk partial; a second kernel adds the chunks of a camera
 // in order (deterministic, no atomics).
 // ===========================================================================================
+// (GEN: host-linearised factors -- the camera block comes from its own array Jc12, not from the closed form behind J8)
+template <bool GEN>
 __global__ __launch_bounds__(256) void ba_camera_partial_kernel(int n_chunks, const int* __restrict__ chunk_begin,
                                                                 const int* __restrict__ chunk_end,
                                                                 const int* __restrict__ cam_perm,
                                                                 const double* __restrict__ J8,
                                                                 const unsigned char* __restrict__ omask,
+                                                                const double* __restrict__ Jc12,
                                                                 const double2* __restrict__ r,
                                                                 double* __restrict__ partial) {
     const int lane = threadIdx.x & 63;
@@ -481,7 +484,7 @@ __global__ __launch_bounds__(256) void ba_camera_partial_kernel(int n_chunks, co
     for (int p = chunk_begin[ch] + lane; p < e; p += 64) {
         const int i = cam_perm[p];
         double j[12], jpu[6];
-        load_jc_jp(J8, omask, i, j, jpu);
+        load_jc_jp<GEN>(J8, omask, i, j, jpu, Jc12);
         const double2 ri = r[i];
         int idx = 0;
 #pragma unroll
@@ -525,10 +528,13 @@ __global__ __launch_bounds__(256) void ba_camera_final_kernel(int n_cams, const 
 
 int launch_camera_blocks(int n_cams, int n_chunks, const int* chunk_begin, const int* chunk_end,
                          const int* cam_chunk_start, const int* cam_perm, const double* J8, const unsigned char* omask,
-                         const double2* r, double* partial, double* Hcc, double* gc, hipStream_t st) {
-    if (n_chunks > 0)
-        hipLaunchKernelGGL(ba_camera_partial_kernel, dim3((n_chunks + 3) / 4), dim3(256), 0, st, n_chunks,
-                           chunk_begin, chunk_end, cam_perm, J8, omask, r, partial);
+                         const double* Jc12, const double2* r, double* partial, double* Hcc, double* gc, hipStream_t st) {
+    if (n_chunks > 0) {
+        if (Jc12) hipLaunchKernelGGL(ba_camera_partial_kernel<true>, dim3((n_chunks + 3) / 4), dim3(256), 0, st, n_chunks,
+                                     chunk_begin, chunk_end, cam_perm, J8, omask, Jc12, r, partial);
+        else hipLaunchKernelGGL(ba_camera_partial_kernel<false>, dim3((n_chunks + 3) / 4), dim3(256), 0, st, n_chunks,
+                                chunk_begin, chunk_end, cam_perm, J8, omask, Jc12, r, partial);
+    }
     hipLaunchKernelGGL(ba_camera_final_kernel, dim3((n_cams * 27 + 255) / 256), dim3(256), 0, st, n_cams,
                        cam_chunk_start, partial, Hcc, gc);
     STBA_HIP(hipGetLastError());
@@ -670,15 +676,19 @@ __global__ __launch_bounds__(SCHUR_THREADS, GEN ? 2 : 4) void ba_schur_pairs_ker
     const int row_ncols = a.row_col_ptr[c + 1] - a.row_col_ptr[c];
     const int clo = a.task_col_lo[task], chi = a.task_col_hi[task];       // this task's slice of the row's blocks
     const int col0 = a.row_col_ptr[c] + clo, ncols = chi - clo;
-    double* acc = smem;                          // [ncols][SCHUR_BLK_LD]
+    double* acc = smem;                          // [accumulator slots][SCHUR_BLK_LD]: a block has one slot, or several consecutive ones (parts)
     double* racc = smem + (size_t)a.max_cols * SCHUR_BLK_LD;   // [8]
     double* cpart = racc + 8;                    // [8 waves][SCHUR_CAM_LD]: the waves' partial camera blocks and (i, i) terms
     int* cols = reinterpret_cast<int*>(cpart + 8 * SCHUR_CAM_LD);    // [ncols]
+    int* vsf = cols + a.max_cols;                // [ncols + 1]: first accumulator slot of every block, and the slot count
     const int tid = threadIdx.x;
     const bool diag_piece = (chi == row_ncols);  // (the diagonal block is the last one of its row)
-    for (int e = tid; e < ncols * SCHUR_BLK_LD; e += SCHUR_THREADS) acc[e] = 0.0;
+    const int* vs_g = a.vs_first + a.task_vs_ptr[task];
+    const int nslots = vs_g[ncols];
+    for (int e = tid; e < nslots * SCHUR_BLK_LD; e += SCHUR_THREADS) acc[e] = 0.0;
     if (tid < 8) racc[tid] = 0.0;
     for (int e = tid; e < ncols; e += SCHUR_THREADS) cols[e] = a.row_cols[col0 + e];
+    for (int e = tid; e <= ncols; e += SCHUR_THREADS) vsf[e] = vs_g[e];
     {
         // this slice's stretch of the camera's six rows of S is zeroed HERE (the whole row up to the end of the diagonal
         // 128-tile, shared out between the slices; nothing right of it is ever read): the stores drain under the pair loop
@@ -694,14 +704,17 @@ __global__ __launch_bounds__(SCHUR_THREADS, GEN ? 2 : 4) void ba_schur_pairs_ker
     // One pair per lane and trip.  The record carries (i, l, landmark, slot), so all gathers of a pair are one level
     // deep.  (Two pairs in flight per lane -- the second pair's gathers requested before the first is computed -- was
     // measured 7 % slower: the kernel is not bound by the gather latency.)
-    const int ke = a.pair_end[task];
+    // Every wave walks ITS OWN list: the host dealt the task's blocks (parts of heavy blocks) to the eight waves, so all the LDS
+    // adds that meet in one address come from one wave, in program order -- S is bitwise reproducible (see stba_ba_create).
+    const int wv = tid >> 6;
+    const int ke = a.pair_end[task * (SCHUR_THREADS / 64) + wv];
     const int rot = tid % ROTS;
     // (the pair record runs one trip ahead: one dependent memory round trip less per trip)
-    int k = a.pair_begin[task] + tid;
+    int k = a.pair_begin[task * (SCHUR_THREADS / 64) + wv] + (tid & 63);
     int4 rn = (k < ke) ? a.pair_rec[k] : make_int4(0, 0, 0, 0);
-    for (; k < ke; k += SCHUR_THREADS) {
+    for (; k < ke; k += 64) {
         const int4 rc = rn;
-        if (k + SCHUR_THREADS < ke) rn = a.pair_rec[k + SCHUR_THREADS];
+        if (k + 64 < ke) rn = a.pair_rec[k + 64];
         double Hi[6], jc[12], jp[6], jc2[12], jp2[6];
 #pragma unroll
         for (int k2 = 0; k2 < 6; ++k2) Hi[k2] = a.Hinv6[(size_t)rc.z * 6 + k2];
@@ -826,7 +839,7 @@ __global__ __launch_bounds__(SCHUR_THREADS, GEN ? 2 : 4) void ba_schur_pairs_ker
             if (tid < 21) {
                 int q = 0, b = tid;
                 while (b > q) { ++q; b -= q; }   // tid = q(q+1)/2 + b
-                acc[(size_t)(ncols - 1) * SCHUR_BLK_LD + q * 6 + b] += s2;      // (the diagonal block is the slice's last one)
+                acc[(size_t)vsf[ncols - 1] * SCHUR_BLK_LD + q * 6 + b] += s2;      // (the diagonal block is the slice's last one)
             } else {
                 racc[tid - 21] += s2;
             }
@@ -837,7 +850,10 @@ __global__ __launch_bounds__(SCHUR_THREADS, GEN ? 2 : 4) void ba_schur_pairs_ker
         const int slot = e / 36, k = e - slot * 36, q = k / 6, b = k - q * 6;
         const int c2 = cols[slot];
         if (c2 == c && b > q) continue;
-        a.S[(size_t)(c * 6 + q) * a.lda + c2 * 6 + b] = acc[slot * SCHUR_BLK_LD + k];
+        const int v1 = vsf[slot + 1];
+        double sum = acc[vsf[slot] * SCHUR_BLK_LD + k];
+        for (int v = vsf[slot] + 1; v < v1; ++v) sum += acc[v * SCHUR_BLK_LD + k];     // the parts of a heavy block, in order
+        a.S[(size_t)(c * 6 + q) * a.lda + c2 * 6 + b] = sum;
     }
     if (diag_piece) {                            // (the slice with the diagonal block carries the right-hand side and the camera blocks)
         if (tid < 6) a.rhs[c * 6 + tid] = racc[tid];
@@ -885,14 +901,14 @@ __device__ inline void chol3_of_sym6(const double h[6], double R[6]) {
 // Schur step owes for its camera: the camera block Jc^T Jc (21), Jc^T r (6) and the right-hand side sum_i W_i Hpp^-1 gp (6); a
 // second kernel adds a camera's chunks in order (no atomics: bitwise reproducible).
 constexpr int YCAM_LD = 36;      // doubles per chunk partial: 21 + 6 + 6, padded
-template <bool GEN>
+template <bool GEN, bool DUP>
 __global__ __launch_bounds__(256) void ba_schur_dense_chunk_kernel(int n_chunks, const int* __restrict__ chunk_begin, const int* __restrict__ chunk_end,
                                                                    const int* __restrict__ cam_perm, const int* __restrict__ obs_cam,
                                                                    const int* __restrict__ obs_pt, const double* __restrict__ J8,
                                                                    const unsigned char* __restrict__ omask, const double* __restrict__ Jc12,
                                                                    const double2* __restrict__ r, const double* __restrict__ Hinv6,
                                                                    const double* __restrict__ gp, double* __restrict__ Y, size_t ldy,
-                                                                   double* __restrict__ partial) {
+                                                                   double* __restrict__ partial, const unsigned char* __restrict__ dup_run) {
     const int lane = threadIdx.x & 63;
     const int ch = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (ch >= n_chunks) return;
@@ -912,19 +928,49 @@ __global__ __launch_bounds__(256) void ba_schur_dense_chunk_kernel(int n_chunks,
         chol3_of_sym6(h, R);
         const double t0 = h[0] * g0 + h[1] * g1 + h[2] * g2, t1 = h[1] * g0 + h[3] * g1 + h[4] * g2, t2 = h[2] * g0 + h[4] * g1 + h[5] * g2;
         int idx = 0;
+        double wrow[DUP ? 18 : 1];
 #pragma unroll
         for (int q = 0; q < 6; ++q) {
             const double w0 = jc[q] * jp[0] + jc[6 + q] * jp[3];
             const double w1 = jc[q] * jp[1] + jc[6 + q] * jp[4];
             const double w2 = jc[q] * jp[2] + jc[6 + q] * jp[5];
-            double* y = Y + (size_t)(c * 6 + q) * ldy + (size_t)j * 3;
-            y[0] = w0 * R[0] + w1 * R[1] + w2 * R[2];
-            y[1] = w1 * R[3] + w2 * R[4];
-            y[2] = w2 * R[5];
+            if constexpr (DUP) { wrow[q * 3] = w0; wrow[q * 3 + 1] = w1; wrow[q * 3 + 2] = w2; }
+            else {
+                double* y = Y + (size_t)(c * 6 + q) * ldy + (size_t)j * 3;
+                y[0] = w0 * R[0] + w1 * R[1] + w2 * R[2];
+                y[1] = w1 * R[3] + w2 * R[4];
+                y[2] = w2 * R[5];
+            }
 #pragma unroll
             for (int b = 0; b <= q; ++b) acc[idx++] += jc[q] * jc[b] + jc[6 + q] * jc[6 + b];
             acc[21 + q] += jc[q] * ri.x + jc[6 + q] * ri.y;
             acc[27 + q] += w0 * t0 + w1 * t1 + w2 * t2;
+        }
+        // Several observations of the SAME (camera, landmark) pair (stereo residuals on one pose block, two factors on one pair): the
+        // block of Y is the SUM of their W (S = -sum_j (sum_i W_i) Hpp^-1 (sum_l W_l)^T is bilinear in the per-camera sums).  They sit
+        // next to each other in the camera's list; the first one of a run adds its followers' W in list order and writes the block,
+        // the followers only take part in the camera sums above.  dup_run: 0 = alone, k = leader of k followers, 255 = follower
+        // (DUP = false when the problem has no such pair -- the usual case: the blocks are written in the loop above).
+        if constexpr (DUP) {
+        const unsigned run = dup_run[p];
+        if (run == 255u) continue;
+        for (unsigned d = 1; d <= run; ++d) {
+            double jc2[12], jp2[6];
+            load_jc_jp<GEN>(J8, omask, cam_perm[p + d], jc2, jp2, Jc12);
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                wrow[q * 3] += jc2[q] * jp2[0] + jc2[6 + q] * jp2[3];
+                wrow[q * 3 + 1] += jc2[q] * jp2[1] + jc2[6 + q] * jp2[4];
+                wrow[q * 3 + 2] += jc2[q] * jp2[2] + jc2[6 + q] * jp2[5];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            double* y = Y + (size_t)(c * 6 + q) * ldy + (size_t)j * 3;
+            y[0] = wrow[q * 3] * R[0] + wrow[q * 3 + 1] * R[1] + wrow[q * 3 + 2] * R[2];
+            y[1] = wrow[q * 3 + 1] * R[3] + wrow[q * 3 + 2] * R[4];
+            y[2] = wrow[q * 3 + 2] * R[5];
+        }
         }
     }
 #pragma unroll
@@ -959,10 +1005,12 @@ size_t schur_dense_partial_doubles(int n_chunks) { return (size_t)std::max(1, n_
 
 int launch_schur_dense(const SchurDenseArgs& a, hipStream_t st) {
     if (a.n_chunks > 0) {
-        if (a.Jc12) hipLaunchKernelGGL(ba_schur_dense_chunk_kernel<true>, dim3((a.n_chunks + 3) / 4), dim3(256), 0, st, a.n_chunks, a.chunk_begin, a.chunk_end,
-                                       a.cam_perm, a.obs_cam, a.obs_pt, a.J8, a.omask, a.Jc12, a.r, a.Hinv6, a.gp, a.Y, a.ldy, a.partial);
-        else hipLaunchKernelGGL(ba_schur_dense_chunk_kernel<false>, dim3((a.n_chunks + 3) / 4), dim3(256), 0, st, a.n_chunks, a.chunk_begin, a.chunk_end,
-                                a.cam_perm, a.obs_cam, a.obs_pt, a.J8, a.omask, a.Jc12, a.r, a.Hinv6, a.gp, a.Y, a.ldy, a.partial);
+        const dim3 grid((a.n_chunks + 3) / 4);
+#define STBA_DENSE_CHUNK(GEN_, DUP_) hipLaunchKernelGGL((ba_schur_dense_chunk_kernel<GEN_, DUP_>), grid, dim3(256), 0, st, a.n_chunks, a.chunk_begin, \
+            a.chunk_end, a.cam_perm, a.obs_cam, a.obs_pt, a.J8, a.omask, a.Jc12, a.r, a.Hinv6, a.gp, a.Y, a.ldy, a.partial, a.dup_run)
+        if (a.Jc12) { if (a.dup_run) STBA_DENSE_CHUNK(true, true); else STBA_DENSE_CHUNK(true, false); }
+        else { if (a.dup_run) STBA_DENSE_CHUNK(false, true); else STBA_DENSE_CHUNK(false, false); }
+#undef STBA_DENSE_CHUNK
     }
     STBA_TRY(chol_yyt_lower_dev(a.Y, a.ldy, a.kcols, a.S, a.lda, a.ws, st));
     if (a.n_cams > 0)
@@ -973,7 +1021,7 @@ int launch_schur_dense(const SchurDenseArgs& a, hipStream_t st) {
 }
 
 size_t schur_rows_lds_bytes(int max_cols) {
-    return ((size_t)max_cols * SCHUR_BLK_LD + 8 + 8 * SCHUR_CAM_LD) * sizeof(double) + (size_t)max_cols * sizeof(int) + 16;
+    return ((size_t)max_cols * SCHUR_BLK_LD + 8 + 8 * SCHUR_CAM_LD) * sizeof(double) + ((size_t)2 * max_cols + 1) * sizeof(int) + 16;
 }
 
 int launch_schur_rows(const SchurArgs& a, int n_tasks, hipStream_t st) {
@@ -983,7 +1031,7 @@ int launch_schur_rows(const SchurArgs& a, int n_tasks, hipStream_t st) {
     static DeviceOnce attr;
     STBA_TRY(attr.run([]() -> int {
         STBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_schur_pairs_kernel<SCHUR_ROTS>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)schur_rows_lds_bytes(SCHUR_SPLIT_COLS)));
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)schur_rows_lds_bytes(SCHUR_MAX_SLOTS)));
         return STBA_OK;
     }));
     // (column rotations measured at C5: 1 / 2 / 3 / 6 -> 0.283 / 0.268 / 0.264 / 0.266 ms)
@@ -991,7 +1039,7 @@ int launch_schur_rows(const SchurArgs& a, int n_tasks, hipStream_t st) {
         static DeviceOnce attr_gen;
         STBA_TRY(attr_gen.run([]() -> int {
             STBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_schur_pairs_kernel<SCHUR_ROTS, true>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)schur_rows_lds_bytes(SCHUR_SPLIT_COLS)));
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)schur_rows_lds_bytes(SCHUR_MAX_SLOTS)));
             return STBA_OK;
         }));
         hipLaunchKernelGGL((ba_schur_pairs_kernel<SCHUR_ROTS, true>), dim3(n_tasks), dim3(SCHUR_THREADS), lds, st, a);

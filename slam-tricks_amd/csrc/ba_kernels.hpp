@@ -39,7 +39,7 @@ int launch_trial_finish(const double* cost_partial, int n_cost, const double* pa
                         const int* flag, double* out, double* host_out, double host_seq, hipStream_t st);
 int launch_camera_blocks(int n_cams, int n_chunks, const int* chunk_begin, const int* chunk_end,
                          const int* cam_chunk_start, const int* cam_perm, const double* J8, const unsigned char* omask,
-                         const double2* r, double* partial, double* Hcc, double* gc, hipStream_t st);
+                         const double* Jc12, const double2* r, double* partial, double* Hcc, double* gc, hipStream_t st);
 int launch_lm_diagonal(int n, int bs, int bstride, int kind, const double* H, double* scale, int init_scale,
                        int use_scaling, double radius, double dmin, double dmax, double* d, hipStream_t st);
 int launch_point_damp_invert(int n_pts, const double* Hpp6, const unsigned char* pt_fixed, double* scale, int init_scale,
@@ -50,7 +50,8 @@ int launch_point_invert(int n_pts, const double* Hpp6, const double* dp, const u
 // Schur complement of the landmark blocks, row-wise with LDS accumulation (plan built on the host at create time:
 // stba_ba_create).  SCHUR_SPLIT_COLS: non-zero blocks one task accumulates in LDS (two workgroups per CU);
 // SCHUR_TASK_PAIRS: most (i, l) observation pairs per task (unlimited: smaller tasks measured slower).
-constexpr int SCHUR_SPLIT_COLS = 256;
+constexpr int SCHUR_MAX_SLOTS = 256;                        // LDS accumulator slots of a task: two workgroups of 81.5 KB per CU
+constexpr int SCHUR_SPLIT_COLS = SCHUR_MAX_SLOTS - 8;       // blocks per task; a heavy block takes up to one extra slot per wave (parts)
 constexpr int SCHUR_TASK_PAIRS = 1 << 30;
 // LDS stride of one 6x6 accumulator block, in doubles: odd, so that the same entry of different blocks falls
 // into different bank pairs (36 = 72 dwords = 8 mod 64 gave 8-way conflicts on every ds_add_f64: measured,
@@ -72,7 +73,8 @@ struct SchurArgs {
     double* Hcc; double* gc;                         // camera blocks J_c^T J_c, J_c^T r: written by the slice that holds the diagonal block
     // every (observation i of the row's camera, observation l of the same landmark with camera(l) <= camera(i)) of the
     // slice, with the LDS slot of its 6x6 block resolved on the host
-    const int* pair_begin; const int* pair_end;      // per task
+    const int* pair_begin; const int* pair_end;      // per (task, wave): every block is accumulated by one wave (bitwise reproducible)
+    const int* task_vs_ptr; const int* vs_first;     // per task: [blocks + 1] first accumulator slot of every block of the slice
     const int* obs_pt;                               // landmark of every observation
     const int4* pair_rec;                            // (i, l, landmark, slot | 0x8000 if diagonal block), l != i
 };
@@ -85,6 +87,7 @@ struct SchurDenseArgs {
     const double* Hinv6; const double* gp;
     double* Y; size_t ldy; size_t kcols;         // [lda][ldy], kcols = 3 n_pts rounded up to 16 (<= ldy); zero where nothing is observed
     double* partial;                              // schur_dense_partial_doubles(n_chunks)
+    const unsigned char* dup_run;                 // per position of cam_perm: repeated (camera, landmark) pairs (null: none), see the chunk kernel
     double* ws;                                   // workspace of chol_yyt_workspace_doubles(lda, kcols) doubles (or null)
     double* S; int lda; double* rhs; double* Hcc; double* gc;
 };

@@ -93,7 +93,8 @@ struct stba_ba {
     int *task_col_lo = nullptr, *task_col_hi = nullptr;
     int n_tasks = 0, max_cols = 0;
     // pair plan of the Schur kernel (see ba_schur_pairs_kernel)
-    int *pair_begin = nullptr, *pair_end = nullptr;
+    int *pair_begin = nullptr, *pair_end = nullptr;      // per (task, wave)
+    int *task_vs_ptr = nullptr, *vs_first = nullptr;     // per task: first accumulator slot of every block of its slice (+ the slot count)
     int4* pair_rec = nullptr;           // (i, l, landmark, slot | flags)
     double schur_pairs = 0.0, schur_lds_atomics = 0.0;   // per launch of the Schur kernel (measurement)
     // the Schur complement as a dense symmetric product (dense visibility; ba_kernels.hip "DENSE visibility", stba_ba_set_schur_mode)
@@ -101,6 +102,7 @@ struct stba_ba {
     bool have_pair_plan = false;
     double* Y = nullptr; size_t ldy = 0, ykcols = 0;     // [lda][ldy]
     double *yv = nullptr, *yws = nullptr;
+    unsigned char* dup_run = nullptr;                    // repeated (camera, landmark) pairs, per position of cam_perm (null: none)
     unsigned char *cam_fixed = nullptr, *pt_fixed = nullptr;
     double2* r = nullptr;
     double* J8 = nullptr;            // compact Jacobian [n_obs][8] (ba_kernels.hip)
@@ -109,7 +111,7 @@ struct stba_ba {
     stba_ba_linearize_fn hl_fn = nullptr;
     void* hl_user = nullptr;
     double* Jc12 = nullptr;          // [n_obs][12]
-    std::vector<double> hl_cams, hl_pts, hl_r, hl_jc, hl_jp, hl_stage;   // host staging (caller order | engine order)
+    std::vector<double> hl_cams, hl_pts, hl_r, hl_jc, hl_jp, hl_stage, hl_cost_stage;   // host staging (caller order | engine order)
     unsigned char* omask = nullptr;  // per observation: constant dofs of its camera (bits 0..5) | constant landmark (bit 6); null if none
     double *Hpp6 = nullptr, *gp = nullptr, *Hinv6 = nullptr, *dp = nullptr, *scale_p = nullptr;
     double *Hcc = nullptr, *gc = nullptr, *cam_partial = nullptr, *dc = nullptr, *scale_c = nullptr;
@@ -164,7 +166,7 @@ static void ba_free(stba_ba* b) {
     F(b->pt_fixed); F(b->r); F(b->J8); F(b->Jc12); F(b->omask); F(b->Hpp6); F(b->gp); F(b->Hinv6); F(b->dp); F(b->scale_p);
     F(b->Hcc); F(b->gc); F(b->cam_partial); F(b->dc); F(b->scale_c); F(b->Sbuf); F(b->Spack); F(b->pk_blocks); F(b->dxc); F(b->dxp);
     F(b->task_cam); F(b->cam_start); F(b->task_col_lo); F(b->task_col_hi); F(b->row_col_ptr); F(b->row_cols);
-    F(b->pair_begin); F(b->pair_end); F(b->pair_rec); F(b->Y); F(b->yv); F(b->yws);
+    F(b->pair_begin); F(b->pair_end); F(b->pair_rec); F(b->task_vs_ptr); F(b->vs_first); F(b->Y); F(b->yv); F(b->yws); F(b->dup_run);
     F(b->cost_partial); F(b->upd_partial_c); F(b->upd_partial_p); F(b->trial); F(b->flag);
     for (auto& e : b->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : b->ev_ar) if (e) (void)hipEventDestroy(e);
@@ -202,10 +204,13 @@ static int ba_host_linearize(stba_ba* b, int which, bool with_jac) {
     double c2 = 0.0;
     for (size_t k = 0; k < no * 2; ++k) c2 += b->hl_r[k] * b->hl_r[k];
     if (!std::isfinite(c2)) return fail(STBA_ERR_CALLBACK, "host lineariser: non-finite residual");
+    // (the cost partials have a staging buffer of their own: the copy is asynchronous, and the big staging buffer below is
+    // resized and overwritten right behind it -- in the cost-only call nothing waits for it before the next call refills it)
+    b->hl_cost_stage.assign((size_t)b->lin_grid, 0.0);
+    b->hl_cost_stage[0] = c2;
+    STBA_TRY(upload(b->cost_partial, b->hl_cost_stage.data(), b->hl_cost_stage.size(), b->st));
+    STBA_HIP(hipStreamSynchronize(b->st));
     std::vector<double>& st = b->hl_stage;
-    st.assign((size_t)b->lin_grid, 0.0);
-    st[0] = c2;
-    STBA_TRY(upload(b->cost_partial, st.data(), st.size(), b->st));
     if (with_jac) {
         st.resize(no * 12);
         for (size_t p = 0; p < no; ++p) { const size_t i = (size_t)b->perm[p]; memcpy(&st[p * 2], &b->hl_r[i * 2], 2 * sizeof(double)); }
@@ -253,7 +258,7 @@ static int ba_linearize_lm(stba_ba* b, int which) {
 }
 static int ba_camera_blocks(stba_ba* b) {
     return launch_camera_blocks(b->nc, b->n_chunks, b->chunk_begin, b->chunk_end, b->cam_chunk_start, b->cam_perm,
-                                b->J8, b->omask, b->r, b->cam_partial, b->Hcc, b->gc, b->st);
+                                b->J8, b->omask, b->hl_fn ? b->Jc12 : nullptr, b->r, b->cam_partial, b->Hcc, b->gc, b->st);
 }
 
 struct Damping {
@@ -382,7 +387,7 @@ static int ba_schur_step(stba_ba* b) {
         da.chunk_begin = b->chunk_begin; da.chunk_end = b->chunk_end; da.cam_chunk_start = b->cam_chunk_start; da.cam_perm = b->cam_perm;
         da.obs_cam = b->obs_cam; da.obs_pt = b->obs_pt;
         da.J8 = b->J8; da.omask = b->omask; da.Jc12 = b->hl_fn ? b->Jc12 : nullptr; da.r = b->r; da.Hinv6 = b->Hinv6; da.gp = b->gp;
-        da.Y = b->Y; da.ldy = b->ldy; da.kcols = b->ykcols; da.partial = b->yv; da.ws = b->yws;
+        da.Y = b->Y; da.ldy = b->ldy; da.kcols = b->ykcols; da.partial = b->yv; da.ws = b->yws; da.dup_run = b->dup_run;
         da.S = b->S(); da.lda = b->lda; da.rhs = b->rhs(); da.Hcc = b->Hcc; da.gc = b->gc;
         return launch_schur_dense(da, b->st);
     }
@@ -392,6 +397,7 @@ static int ba_schur_step(stba_ba* b) {
     sa.J8 = b->J8; sa.omask = b->omask; sa.Jc12 = b->hl_fn ? b->Jc12 : nullptr; sa.r = b->r; sa.Hinv6 = b->Hinv6; sa.gp = b->gp;
     sa.S = b->S(); sa.lda = b->lda; sa.rhs = b->rhs(); sa.Hcc = b->Hcc; sa.gc = b->gc;
     sa.obs_pt = b->obs_pt; sa.pair_begin = b->pair_begin; sa.pair_end = b->pair_end; sa.pair_rec = b->pair_rec;
+    sa.task_vs_ptr = b->task_vs_ptr; sa.vs_first = b->vs_first;
     return launch_schur_rows(sa, b->n_tasks, b->st);
 }
 
@@ -1024,6 +1030,24 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
     }
     cam_chunk_start[n_cams] = (int)chunk_begin.size();
     b->n_chunks = (int)chunk_begin.size();
+    // Several observations of one (camera, landmark) pair -- stereo residuals on one pose block, two factors on one pair through the
+    // host-linearised path: in a camera's list (landmarks ascending) they are neighbours.  The pair plan treats them like any other
+    // pair of observations; the dense form writes ONE block of Y per (camera, landmark) and must sum them (ba_schur_dense_chunk_kernel).
+    std::vector<unsigned char> dup_run;
+    size_t n_dup = 0;
+    for (int c = 0; c < n_cams; ++c)
+        for (int q = cam_start[c]; q < cam_start[c + 1];) {
+            int e = q + 1;
+            while (e < cam_start[c + 1] && s_pt[cam_perm[e]] == s_pt[cam_perm[q]]) ++e;
+            if (e - q > 1) {
+                if (e - q > 255) { ba_free(b); return fail(STBA_ERR_INVALID_ARGUMENT, "stba_ba_create: more than 255 observations of one (camera, landmark) pair"); }
+                if (dup_run.empty()) dup_run.assign((size_t)n_obs, 0);
+                dup_run[(size_t)q] = (unsigned char)(e - q - 1);
+                for (int k = q + 1; k < e; ++k) dup_run[(size_t)k] = 255;
+                n_dup += (size_t)(e - q - 1);
+            }
+            q = e;
+        }
     tmark("regroup observations");
     // ---- Schur plan.  Camera row c of the reduced system has one non-zero 6x6 block per partner camera c2 <= c it shares a
     // landmark with; every (observation i of c, observation l of the same landmark with camera(l) <= c) PAIR contributes to
@@ -1033,6 +1057,7 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
     // by default: see the task order below).  The pairs of every task are enumerated here once (the structure is static).
     std::vector<int> row_col_ptr(n_cams + 1, 0), row_cols, task_cam, task_col_lo, task_col_hi;
     std::vector<size_t> task_pairs;
+    std::vector<std::vector<int>> cnt_of;       // per camera row: pairs of every non-zero block (without the pairs (i, i))
     int task_max_cols = 0;
     size_t total_pairs = 0;
     for (int j = 0; j < n_pts; ++j) { const size_t k = (size_t)(pt_start[j + 1] - pt_start[j]); total_pairs += k * (k + 1) / 2; }
@@ -1042,7 +1067,7 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
         const bool have_info = hipMemGetInfo(&free_b, &total_b) == hipSuccess;
         const size_t cap = std::min<size_t>((size_t)1 << 30, have_info ? free_b / 2 / 16 : ((size_t)1 << 30));
         // dense visibility: the Schur complement as one symmetric product on the matrix cores instead (ba_kernels.hip): no plan
-        const double visibility = (n_pts > 0 && n_cams > 0) ? (double)n_obs / ((double)n_pts * n_cams) : 0.0;
+        const double visibility = (n_pts > 0 && n_cams > 0) ? (double)((size_t)n_obs - n_dup) / ((double)n_pts * n_cams) : 0.0;   // (distinct pairs)
         const size_t y_bytes = (size_t)b->lda * (((size_t)3 * n_pts + 31) / 16 * 16) * sizeof(double);
         const bool y_fits = !have_info || y_bytes < free_b / 2;
         if (total_pairs > cap && !y_fits) {
@@ -1066,7 +1091,8 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
             row_col_ptr[c + 1] = (int)row_cols.size();
         }
     } else {
-        std::vector<std::vector<int>> cols_of((size_t)n_cams), cnt_of((size_t)n_cams);
+        std::vector<std::vector<int>> cols_of((size_t)n_cams);
+        cnt_of.assign((size_t)n_cams, std::vector<int>());
         host_parallel_for(n_cams, [&](int c_lo, int c_hi, int) {
             std::vector<int> stamp(n_cams, -1), slot_of((size_t)n_cams, 0);
             for (int c = c_lo; c < c_hi; ++c) {
@@ -1123,26 +1149,80 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
     }
     tmark("row plan");
     b->n_tasks = (int)task_cam.size();
-    b->max_cols = task_max_cols;
-    // pair records (i, l, landmark, slot | flags) of every task, in task order
-    std::vector<int> pair_begin, pair_end;
+    // Pair records (i, l, landmark, accumulator slot | flags) of every task.  RUN-TO-RUN REPRODUCIBILITY (round 5): every 6 x 6
+    // block of a task is accumulated by ONE wave of the task's workgroup, so the ds_add_f64 that meet in an LDS address are all
+    // issued by the same wave, in program order, and S comes out bit-identical from launch to launch (with the pairs dealt to
+    // all 512 lanes in list order, as until round 4, the eight waves raced for the blocks and the sums differed in their last
+    // bits: 34 distinct final costs in 48 long LM runs).  A task's blocks are dealt to its waves heaviest first (LPT) by pair
+    // count; a block with more pairs than a wave's share is cut into PARTS with an accumulator slot each (consecutive slots,
+    // added in order when the block is written), so that two cameras with 5000 common landmarks still use all eight waves.
+    // Inside a wave the records keep the landmark-major order (locality of the gathers).
+    constexpr int NW = SCHUR_THREADS / 64;
+    std::vector<int> pair_begin, pair_end, task_vs_ptr, vs_first;
     std::vector<int4> pair_rec;
+    int max_slots = 0;
     if (build_pair_plan) {
         const int ntask = (int)task_cam.size();
-        pair_begin.resize((size_t)ntask); pair_end.resize((size_t)ntask);
+        pair_begin.resize((size_t)ntask * NW); pair_end.resize((size_t)ntask * NW);
         std::vector<size_t> cnt((size_t)ntask + 1, 0);
-        for (int k = 0; k < ntask; ++k) cnt[(size_t)k + 1] = cnt[(size_t)k] + task_pairs[(size_t)k];
+        task_vs_ptr.assign((size_t)ntask + 1, 0);
+        for (int k = 0; k < ntask; ++k) {
+            cnt[(size_t)k + 1] = cnt[(size_t)k] + task_pairs[(size_t)k];
+            task_vs_ptr[(size_t)k + 1] = task_vs_ptr[(size_t)k] + (task_col_hi[(size_t)k] - task_col_lo[(size_t)k]) + 1;
+        }
         pair_rec.resize(cnt[(size_t)ntask]);
-        host_parallel_for(ntask, [&](int k_lo, int k_hi, int) {
+        vs_first.assign((size_t)task_vs_ptr[(size_t)ntask], 0);
+        std::vector<int> max_slots_thr(64, 0);
+        host_parallel_for(ntask, [&](int k_lo, int k_hi, int tix) {
             std::vector<int> slot_of((size_t)n_cams, 0);
+            std::vector<int> psize, wave_of, seen, order;
+            std::vector<size_t> part_cnt;
             for (int k = k_lo; k < k_hi; ++k) {
                 const int c = task_cam[(size_t)k];
                 const int* cb = row_cols.data() + row_col_ptr[c];
                 const int nco = row_col_ptr[c + 1] - row_col_ptr[c];
                 for (int q = 0; q < nco; ++q) slot_of[(size_t)cb[q]] = q;
-                const int slo = task_col_lo[(size_t)k], shi = task_col_hi[(size_t)k];
-                size_t w = cnt[(size_t)k];
-                pair_begin[(size_t)k] = (int)w;
+                const int slo = task_col_lo[(size_t)k], shi = task_col_hi[(size_t)k], ncols = shi - slo;
+                const int* bc = cnt_of[(size_t)c].data() + slo;                 // pairs per block of the slice
+                const size_t total = task_pairs[(size_t)k];
+                const size_t target = std::max<size_t>(64, (total + NW - 1) / NW);
+                int* vsf = vs_first.data() + task_vs_ptr[(size_t)k];
+                psize.assign((size_t)ncols, 1);
+                int nvs = 0;
+                for (int q = 0; q < ncols; ++q) {
+                    const int np_ = std::max(1, (int)(((size_t)bc[q] + target - 1) / target));
+                    psize[(size_t)q] = std::max(1, (bc[q] + np_ - 1) / np_);
+                    vsf[q] = nvs;
+                    nvs += np_;
+                }
+                vsf[ncols] = nvs;
+                max_slots_thr[(size_t)(tix & 63)] = std::max(max_slots_thr[(size_t)(tix & 63)], nvs);
+                // parts -> waves, heaviest first
+                part_cnt.assign((size_t)nvs, 0);
+                for (int q = 0; q < ncols; ++q)
+                    for (int v = vsf[q]; v < vsf[q + 1]; ++v)
+                        part_cnt[(size_t)v] = (size_t)std::max(0, std::min(psize[(size_t)q], bc[q] - (v - vsf[q]) * psize[(size_t)q]));
+                order.resize((size_t)nvs);
+                for (int v = 0; v < nvs; ++v) order[(size_t)v] = v;
+                std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return part_cnt[(size_t)x] > part_cnt[(size_t)y]; });
+                size_t load[NW] = {0};
+                wave_of.assign((size_t)nvs, 0);
+                for (int v : order) {
+                    int best = 0;
+                    for (int w2 = 1; w2 < NW; ++w2) if (load[w2] < load[best]) best = w2;
+                    wave_of[(size_t)v] = best;
+                    load[best] += part_cnt[(size_t)v];
+                }
+                size_t wpos[NW];
+                {
+                    size_t off = cnt[(size_t)k];
+                    for (int w2 = 0; w2 < NW; ++w2) {
+                        pair_begin[(size_t)k * NW + w2] = (int)off; wpos[w2] = off;
+                        off += load[w2];
+                        pair_end[(size_t)k * NW + w2] = (int)off;
+                    }
+                }
+                seen.assign((size_t)ncols, 0);
                 for (int p = cam_start[c]; p < cam_start[c + 1]; ++p) {
                     const int i = cam_perm[p];
                     const int j = s_pt[i];
@@ -1153,16 +1233,18 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
                         if (c2 > c || l == i) continue;
                         const int sl = slot_of[(size_t)c2];
                         if (sl < slo || sl >= shi) continue;
-                        pair_rec[w] = make_int4(i, l, j, (sl - slo) | (c2 == c ? 0x8000 : 0));
-                        ++w;
+                        const int q = sl - slo;
+                        const int v = vsf[q] + seen[(size_t)q]++ / psize[(size_t)q];
+                        pair_rec[wpos[wave_of[(size_t)v]]++] = make_int4(i, l, j, v | (c2 == c ? 0x8000 : 0));
                     }
                 }
-                pair_end[(size_t)k] = (int)w;
                 // (dealing the records out so that every 32 consecutive ones hit 32 different LDS bank pairs was measured:
                 // the bank conflicts it removes cost less than the locality of the landmark-major order it destroys)
             }
         });
+        for (int v : max_slots_thr) max_slots = std::max(max_slots, v);
     }
+    b->max_cols = std::max(task_max_cols, max_slots);       // accumulator slots of the largest task (blocks + extra parts)
     {   // LDS atomics of one launch: 36 per pair (21 in a diagonal block)
         double at = 0.0;
         for (const int4& pr : pair_rec) at += (pr.w & 0x8000) ? 21.0 : 36.0;
@@ -1196,8 +1278,10 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
     A_(dev_alloc(&b->row_col_ptr, nc + 1)); A_(dev_alloc(&b->row_cols, std::max<size_t>(row_cols.size(), 1)));
     A_(dev_alloc(&b->pair_begin, std::max<size_t>(pair_begin.size(), 1))); A_(dev_alloc(&b->pair_end, std::max<size_t>(pair_end.size(), 1)));
     A_(dev_alloc(&b->pair_rec, std::max<size_t>(pair_rec.size(), 1)));
+    A_(dev_alloc(&b->task_vs_ptr, std::max<size_t>(task_vs_ptr.size(), 1))); A_(dev_alloc(&b->vs_first, std::max<size_t>(vs_first.size(), 1)));
     if (cam_fixed) A_(dev_alloc(&b->cam_fixed, nc));
     if (pt_fixed) A_(dev_alloc(&b->pt_fixed, np));
+    if (!dup_run.empty()) { A_(dev_alloc(&b->dup_run, no)); A_(upload(b->dup_run, dup_run.data(), no, b->st)); }
     A_(dev_alloc(&b->r, no)); A_(dev_alloc(&b->J8, no * 8));
     if (cam_fixed || pt_fixed) A_(dev_alloc(&b->omask, no));
     A_(dev_alloc(&b->Hpp6, np * 6)); A_(dev_alloc(&b->gp, np * 3)); A_(dev_alloc(&b->Hinv6, np * 6));
@@ -1228,6 +1312,7 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
     if (!row_cols.empty()) A_(upload(b->row_cols, row_cols.data(), row_cols.size(), b->st));
     A_(upload(b->pair_begin, pair_begin.data(), pair_begin.size(), b->st)); A_(upload(b->pair_end, pair_end.data(), pair_end.size(), b->st));
     if (!pair_rec.empty()) A_(upload(b->pair_rec, pair_rec.data(), pair_rec.size(), b->st));
+    A_(upload(b->task_vs_ptr, task_vs_ptr.data(), task_vs_ptr.size(), b->st)); A_(upload(b->vs_first, vs_first.data(), vs_first.size(), b->st));
     if (cam_fixed) A_(upload(b->cam_fixed, cmask.data(), nc, b->st));
     std::vector<unsigned char> omask;
     if (b->omask) {

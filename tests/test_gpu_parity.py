@@ -649,3 +649,165 @@ def test_dense_visibility_picks_the_dense_form_by_itself(st, scenes):
     assert summ.termination_type == 0 and summ.final_cost < 1e-3 * c0
     dq, dt = pose_err(e.get_params()[0], s["cams_true"])
     assert dq < 1e-3 and dt < 1e-2                                             # (1e-3 pixel noise: the truth up to the noise)
+
+
+@pytest.mark.gpu
+def test_dense_schur_form_with_repeated_camera_landmark_pairs(st, O, scenes):
+    """two (three) observations of one (camera, landmark) pair -- stereo residuals on one pose block: the dense form writes ONE block
+    of Y per pair and must sum them (it used to keep the last writer's); against the pair plan and the oracle"""
+    s = _dense_visibility_scene(scenes, 12, 300, seed=11)
+    rng = np.random.default_rng(5)
+    no = len(s["obs_cam"])
+    twice = rng.choice(no, 200, replace=False)
+    thrice = twice[:40]
+    extra = np.concatenate([twice, thrice])
+    s["obs_cam"] = np.concatenate([s["obs_cam"], s["obs_cam"][extra]])
+    s["obs_pt"] = np.concatenate([s["obs_pt"], s["obs_pt"][extra]])
+    s["obs_feat"] = np.concatenate([s["obs_feat"], s["obs_feat"][extra] + rng.normal(0, 2e-3, (len(extra), 2))])
+    e, o = engine(st, s), oracle(O, s)
+    e.evaluate(); e.normal_blocks()
+    _, ro, Jco, Jpo = o.evaluate()
+    dc = rng.uniform(0.01, 0.1, (e.nc, 6)); dp = rng.uniform(0.01, 0.1, (e.np_, 3))
+    S1, rhs1 = e.reduced_system(dc, dp)
+    So, rhso = o.reduced_system(ro, Jco, Jpo, dc, dp)
+    scale = np.abs(So).max()
+    assert np.abs(np.tril(S1) - np.tril(So)).max() < 1e-10 * scale          # the pair plan treats them like any other pair
+    e.set_schur_mode(e.SCHUR_DENSE)
+    e.evaluate(); e.normal_blocks()
+    S2, rhs2 = e.reduced_system(dc, dp)
+    assert np.abs(np.tril(S2) - np.tril(So)).max() < 1e-10 * scale
+    assert np.abs(rhs2 - rhso).max() < 1e-10 * max(1.0, np.abs(rhso).max())
+    S3, _ = e.reduced_system(dc, dp)
+    assert np.array_equal(np.tril(S3), np.tril(S2))                          # still no race: one writer per block of Y
+    # and the whole solve, dense form against the oracle
+    e2 = engine(st, s); e2.set_schur_mode(e2.SCHUR_DENSE)
+    s2, t2 = e2.solve(); so, to = o.solve()
+    assert s2.termination_type == 0 and s2.num_iterations == so.num_iterations
+    assert np.allclose(t2[:, 0], to[:, 0], rtol=1e-8, atol=1e-12)
+
+
+@pytest.mark.gpu
+def test_normal_blocks_with_a_host_lineariser(st, O, small):
+    """stba_ba_normal_blocks with host-linearised factors: Hcc / gc must come from the caller's camera Jacobians, not
+    from the built-in closed form.  The factor here is the reprojection scaled by 2 (so 4 Hcc, 2 gc of the built-in one)."""
+    e0, o = engine(st, small), oracle(O, small)
+    _, r0, Jc0, Jp0 = e0.evaluate()
+    H0, g0, P0, q0 = e0.normal_blocks()
+    e1 = engine(st, small)
+    calls = []
+
+    def lin(cams, pts, want_jac):
+        calls.append(want_jac)
+        return 2.0 * r0, (2.0 * Jc0 if want_jac else None), (2.0 * Jp0 if want_jac else None)
+    e1.set_host_linearizer(lin)
+    c1, r1, _, _ = e1.evaluate(jac=False)
+    assert calls and np.allclose(r1, 2.0 * r0, rtol=0, atol=0)
+    H1, g1, P1, q1 = e1.normal_blocks()
+    assert np.abs(H1 - 4.0 * H0).max() < 1e-12 * np.abs(H0).max() and np.abs(g1 - 4.0 * g0).max() < 1e-12 * np.abs(g0).max()
+    assert np.abs(P1 - 4.0 * P0).max() < 1e-12 * np.abs(P0).max() and np.abs(q1 - 4.0 * q0).max() < 1e-12 * np.abs(q0).max()
+    Ho, go, _, _ = o.normal_blocks(*o.evaluate()[1:])
+    assert np.abs(H1 - 4.0 * Ho).max() < 1e-11 * np.abs(Ho).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", ["c5", "c2", "st20"])
+def test_pair_plan_reduced_system_is_bitwise_reproducible(st, scenes, cfg):
+    """north_star's "wavefront-segmented reductions" / SURVEY 4(iii): the Schur complement by the PAIR plan (the default form) is
+    bit-identical from call to call -- every 6 x 6 block is accumulated by one wave of its task, in program order (round 5; until
+    round 4 the eight waves of a task raced for the blocks with LDS atomics and S differed in its last bits from run to run).
+    c5: BASELINE config 5 at full size; c2: two cameras with 5000 common landmarks (one block holds every pair: it is cut into
+    parts over the eight waves); st20: the reference's 29 x 600.  Whole LM runs then end at ONE final cost."""
+    if cfg == "c5":
+        s = scenes.st20_scene(n_cams=1000, n_pts=100000, max_obs_per_pt=10, seed=20, pix_noise=1e-3)
+    elif cfg == "c2":
+        s = scenes.two_view_scene(n_pts=5000, seed=3)
+    else:
+        s = scenes.st20_scene()
+    e = engine(st, s)
+    assert e.schur_mode() == e.SCHUR_PAIRS
+    e.evaluate(); e.normal_blocks()
+    rng = np.random.default_rng(1)
+    dc = rng.uniform(0.01, 0.1, (e.nc, 6)); dp = rng.uniform(0.01, 0.1, (e.np_, 3))
+    S0, rhs0 = e.reduced_system(dc, dp)
+    L0 = np.tril(S0)
+    assert np.isfinite(L0).all() and np.abs(L0).max() > 0
+    for _ in range(9 if cfg != "c5" else 5):
+        S1, rhs1 = e.reduced_system(dc, dp)
+        assert np.array_equal(np.tril(S1), L0) and np.array_equal(rhs1, rhs0)
+    # a second engine on the same data builds the same plan and the same bits
+    e2 = engine(st, s)
+    e2.evaluate(); e2.normal_blocks()
+    S2, rhs2 = e2.reduced_system(dc, dp)
+    assert np.array_equal(np.tril(S2), L0) and np.array_equal(rhs2, rhs0)
+    # whole runs: the same trace, bit for bit
+    finals = set()
+    for _ in range(3):
+        e.set_params(s["cams0"], s["pts0"])
+        summ, tr = e.lm_iterations(12)
+        finals.add(float(summ.final_cost).hex())
+    assert len(finals) == 1, finals
+
+
+@pytest.mark.gpu
+def test_dense_schur_form_against_the_oracle_where_the_tiling_is_live(st, O, scenes):
+    """the matrix-core form of the Schur complement against orc_ba_reduced_system at 1260 rows: ten tile rows with a ragged last
+    one (1260 = 9 x 128 + 108), 55 tiles cut into 64 K slices of nine 16-column rounds each, a constant dof in the middle of the
+    matrix and a camera that sees nothing (until now the oracle comparison stopped at 300 rows)"""
+    s = _dense_visibility_scene(scenes, 210, 3000, seed=9)
+    s["cam_fixed"] = s["cam_fixed"].copy(); s["cam_fixed"][100, 2] = 1; s["cam_fixed"][177, 5] = 1
+    dead = 63
+    m = s["obs_cam"] != dead
+    for k in ("obs_cam", "obs_pt", "obs_feat"):
+        s[k] = s[k][m]
+    e, o = engine(st, s), oracle(O, s)
+    e.set_schur_mode(e.SCHUR_DENSE)
+    e.evaluate(); e.normal_blocks()
+    _, ro, Jco, Jpo = o.evaluate()
+    rng = np.random.default_rng(4)
+    dc = rng.uniform(0.01, 0.1, (e.nc, 6)); dp = rng.uniform(0.01, 0.1, (e.np_, 3))
+    S2, rhs2 = e.reduced_system(dc, dp)
+    So, rhso = o.reduced_system(ro, Jco, Jpo, dc, dp)
+    scale = np.abs(So).max()
+    assert S2.shape == (1260, 1260)
+    # block by block, so that a tile that is wrong somewhere shows up as itself: (tile row, tile column) of the worst entry
+    D = np.abs(np.tril(S2) - np.tril(So))
+    worst = np.unravel_index(np.argmax(D), D.shape)
+    assert D.max() < 1e-10 * scale, (D.max() / scale, worst[0] // 128, worst[1] // 128)
+    assert np.abs(rhs2 - rhso).max() < 1e-10 * max(1.0, np.abs(rhso).max())
+    blk = slice(6 * dead, 6 * dead + 6)                                     # the camera without observations: its damping only
+    assert np.abs(np.tril(S2)[blk, :6 * dead]).max() == 0.0
+    dxc = e.solve_reduced()
+    ref = np.linalg.solve(np.tril(So) + np.tril(So, -1).T, rhso)
+    assert np.abs(dxc - ref).max() < 1e-9 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.gpu
+def test_auto_selected_dense_form_follows_the_oracle_trace(st, O, scenes):
+    """the engine's own choice of the dense form (120 cameras x 8000 landmarks at 59 % visibility, no pair plan) against the oracle's
+    LM run: same iteration count, same accept / reject sequence, cost trace to 1e-8, poses to 1e-7 (this case
+    was only held against the truth up to the noise)"""
+    s = _dense_visibility_scene(scenes, 120, 8000, seed=3)
+    e, o = engine(st, s), oracle(O, s)
+    assert e.schur_mode() == e.SCHUR_DENSE
+    so, tro = o.solve(num_threads=16)
+    summ, tr = e.solve()
+    n = so.num_iterations
+    assert summ.termination_type == 0 and summ.num_iterations == n, (summ.as_dict(), so.as_dict())
+    assert np.array_equal(tr[: n + 1, 6], tro[: n + 1, 6])
+    assert np.allclose(tr[: n + 1, 0], tro[: n + 1, 0], rtol=1e-8, atol=1e-14)
+    dq, dt = pose_err(e.get_params()[0], o.cams)
+    assert dq < 1e-7 and dt < 1e-7, (dq, dt)
+
+
+@pytest.mark.gpu
+def test_more_cameras_than_the_linearise_kernels_lds_table(st, O, scenes):
+    """1700 cameras: the camera table (56 B each) no longer fits the linearise kernel's LDS next to its staging tile, so the
+    <cams-in-LDS = false> instantiations run (launch_linearize, ba_kernels.hip) -- residuals, Jacobians and the cost-only pass
+    against the oracle, element by element"""
+    s = scenes.st20_scene(n_cams=1700, n_pts=4000, max_obs_per_pt=5, seed=12, pix_noise=1e-3, retriangulate=False)
+    e, o = engine(st, s), oracle(O, s)
+    cost, r, Jc, Jp = e.evaluate()
+    co, ro, Jco, Jpo = o.evaluate()
+    assert abs(cost - co) <= 1e-12 * co
+    assert np.abs(r - ro).max() < 1e-13 and np.abs(Jc - Jco).max() < 1e-11 and np.abs(Jp - Jpo).max() < 1e-11
+    assert abs(e.cost() - co) <= 1e-12 * co                                  # the cost-only instantiation

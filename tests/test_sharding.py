@@ -174,6 +174,14 @@ def test_two_shards_on_one_gpu(scenes, O, n_cams, n_pts, max_obs, sparse):
         assert np.abs(cams - cams1).max() < 1e-9
         assert np.abs(pts - pts1[sh["lo"]:sh["hi"]]).max() < 1e-6      # weakly observed depths amplify round-off
     assert np.array_equal(out[0][2][0], out[1][2][0])       # identical camera blocks on both "ranks"
+    # and against the ORACLE (not only against the single engine): same trace, same poses
+    import oracle_py
+    o = oracle_py.BA(s["cams0"], s["pts0"], s["obs_cam"], s["obs_pt"], s["obs_feat"], s["cam_fixed"])
+    so, tro = o.solve(num_threads=16)
+    n = so.num_iterations
+    assert out[0][0].num_iterations == n and np.array_equal(out[0][1][: n + 1, 6], tro[: n + 1, 6])
+    assert np.allclose(out[0][1][: n + 1, 0], tro[: n + 1, 0], rtol=1e-8, atol=1e-14)
+    assert np.abs(out[0][2][0][:, 4:] - o.cams[:, 4:]).max() < 1e-7
     # what travelled: the block mask once, then the packed system (sparse case: far fewer than the triangle)
     n = 6 * n_cams
     lda = ((n + 1 + 127) // 128) * 128
