@@ -71,6 +71,173 @@ def load_scene(args, rank):
     return s
 
 
+def make_engine(st, sharding, torch, dist, sh, stream, rank, world, local_rank, have_gpu, args):
+    """this rank's engine on `stream`, with the cross-rank sum wired up: (engine, native communicator or None, description)"""
+    eng = st.BAEngine(sh["cams0"], sh["pts0"], sh["obs_cam"], sh["obs_pt"], sh["obs_feat"], sh["cam_fixed"], stream=stream)
+    collective = "none"
+    comm = None
+    if world > 1:
+        if args.hook == "native":
+            # the decision native communicator | torch hook is COLLECTIVE: rank 0 always broadcasts (the id or None), and after
+            # the communicator is created the ranks agree on whether every one of them succeeded -- a rank that fell back
+            # alone would leave the others blocked in ncclCommInitRank or issue mismatched collectives
+            uid = None
+            if rank == 0:
+                try:
+                    uid = st.comm_unique_id()
+                except Exception as e:      # noqa: BLE001
+                    print(f"[rank 0] native communicator: no unique id ({e!r})", file=sys.stderr, flush=True)
+            box = [uid]
+            dist.broadcast_object_list(box, src=0)
+            ok = 0.0
+            if box[0] is not None:
+                try:
+                    comm = st.Comm(box[0], rank, world, device=local_rank)
+                    ok = 1.0
+                except Exception as e:      # noqa: BLE001
+                    print(f"[rank {rank}] native communicator failed ({e!r})", file=sys.stderr, flush=True)
+                    comm = None
+            agree = torch.tensor([ok], dtype=torch.float64, device="cuda" if (have_gpu and args.backend == "nccl") else "cpu")
+            dist.all_reduce(agree, op=dist.ReduceOp.MIN)
+            if float(agree.item()) >= 1.0:
+                eng.set_comm(comm)
+                collective = "native RCCL (ncclAllReduce on the engine stream, stba_comm)"
+            else:
+                if comm is not None:
+                    comm.close()
+                comm = None
+                if rank == 0:
+                    print("native communicator not available on every rank: all ranks use the torch hook", file=sys.stderr, flush=True)
+        if comm is None:
+            eng.set_allreduce(sharding.torch_allreduce_hook(dist, torch), rank, world)
+            collective = "torch.distributed all_reduce (RCCL) through the Python hook"
+    return eng, comm, collective
+
+
+def ranks_hold_identical_cameras(eng, torch, dist, world, have_gpu, args):
+    """every rank factors the same reduced system, so the camera blocks must be BIT-identical everywhere: compared in-run
+    (a 64-bit digest of the camera array per rank, gathered)"""
+    import hashlib
+    cams, _ = eng.get_params()
+    dig = int.from_bytes(hashlib.sha1(np.ascontiguousarray(cams).tobytes()).digest()[:7], "little")
+    if world == 1:
+        return True, [dig]
+    dev = "cuda" if (have_gpu and args.backend == "nccl") else "cpu"
+    mine = torch.tensor([dig], dtype=torch.int64, device=dev)
+    allv = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(allv, mine)
+    vals = [int(v.item()) for v in allv]
+    return all(v == vals[0] for v in vals), vals
+
+
+def predicted_scaling(ph, ms_step, allreduce_ms, ar_bytes, world, note):
+    """what landmark sharding can and cannot buy, from ONE run's phase times (a model, printed so that a measured N-GPU point can be
+    held against it): factorisation + backward substitution replicated on every rank, Jacobian / Schur / back-substitution /
+    trial-cost work divided by N, one packed all-reduce of the reduced system per build added (bounds: a ring over one xGMI link,
+    48 GB/s each way; reduce-scatter + all-gather over all N - 1 links)"""
+    t_repl = ph["ms_solve"]
+    t_shard = max(0.0, ph["ms_linearize"] + ph["ms_schur"] - allreduce_ms + ph["ms_backsub"] + ph["ms_cost"]) * world
+    t_other = max(0.0, ms_step - (ph["ms_linearize"] + ph["ms_schur"] + ph["ms_solve"] + ph["ms_backsub"] + ph["ms_cost"]))
+    pred = {}
+    for N in (1, 2, 4, 8):
+        ring = 0.0 if N == 1 else 2.0 * (N - 1) / N * ar_bytes / 48e9 * 1e3
+        direct = 0.0 if N == 1 else 2.0 * ar_bytes / N / 48e9 * 1e3
+        lo, hi = t_repl + t_other + t_shard / N + direct, t_repl + t_other + t_shard / N + ring
+        pred[str(N)] = {"ms_per_step_best": lo, "ms_per_step_ring": hi, "it_per_s_best": 1e3 / lo, "it_per_s_ring": 1e3 / hi}
+    base = pred["1"]["ms_per_step_best"]
+    return {"model": "T(N) = replicated (factorisation + backward substitution) + other + sharded / N + all-reduce(N); terms from this run's "
+                     "phase_ms_per_step; all-reduce of the packed reduced system: ring over one 48 GB/s xGMI link | direct over N - 1 links",
+            "replicated_ms": t_repl, "sharded_ms_total": t_shard, "other_ms": t_other, "allreduce_bytes": ar_bytes,
+            "per_gpus": pred, "speedup_at_8_best": base / pred["8"]["ms_per_step_best"],
+            "speedup_at_8_ring": base / pred["8"]["ms_per_step_ring"], "note": note}
+
+
+def time_scene(st, sharding, torch, dist, s, args, rank, world, local_rank, have_gpu, steps, reps, warmup):
+    """the bench protocol on one scene: shard, engine + collective, warm-up, R x K timed LM iterations (barrier + synchronise on both
+    sides, max over ranks, median over repetitions), one instrumented pass for the phase times, the in-run identity check"""
+    sh = sharding.make_shard(s, rank, world)
+    stream_obj = torch.cuda.Stream()
+    eng, comm, collective = make_engine(st, sharding, torch, dist, sh, stream_obj.cuda_stream, rank, world, local_rank, have_gpu, args)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+    if warmup > 0:
+        eng.lm_iterations(warmup)
+    rep_ms, summ = [], None
+    for _ in range(max(1, reps)):
+        eng.set_params(sh["cams0"], sh["pts0"])
+        sync()
+        t0 = time.perf_counter()
+        summ, _ = eng.lm_iterations(steps)
+        sync()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if (have_gpu and args.backend == "nccl") else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        rep_ms.append(1e3 * dt / steps)
+    same, digests = ranks_hold_identical_cameras(eng, torch, dist, world, have_gpu, args)
+    ms_step = float(np.median(rep_ms))
+    eng.set_params(sh["cams0"], sh["pts0"])
+    sync()
+    summ_i, _ = eng.lm_iterations(steps, phase_timing=1)
+    sync()
+    phase_keys = ("ms_linearize", "ms_schur", "ms_solve", "ms_backsub", "ms_cost", "ms_allreduce")
+    phases = np.array([getattr(summ_i, k) / steps for k in phase_keys], dtype=np.float64)
+    if world > 1:
+        tp = torch.tensor(phases, dtype=torch.float64, device="cuda" if (have_gpu and args.backend == "nccl") else "cpu")
+        dist.all_reduce(tp, op=dist.ReduceOp.MAX)
+        phases = tp.cpu().numpy()
+    n_cams, n_pts, n_obs = len(s["cams0"]), len(s["pts0"]), len(s["obs_cam"])
+    ph = {k: float(v) for k, v in zip(phase_keys[:5], phases[:5])}
+    ar_bytes = float(summ_i.allreduce_bytes / max(1, summ_i.allreduce_calls)) if world > 1 else 40.7e6 * (n_cams / 1000.0) ** 2
+    local_counts = np.zeros(world, dtype=np.float64)
+    local_counts[rank] = float(len(sh["obs_cam"]))
+    if world > 1:
+        tc = torch.tensor(local_counts, dtype=torch.float64, device="cuda" if (have_gpu and args.backend == "nccl") else "cpu")
+        dist.all_reduce(tc)
+        local_counts = tc.cpu().numpy()
+    out = {"value": 1e3 / ms_step, "unit": "LM iterations/s", "residuals_per_sec": 1e3 / ms_step * 2.0 * n_obs, "ms_per_step": ms_step,
+           "n_cams": n_cams, "n_pts": n_pts, "n_obs": n_obs, "observations_per_rank": [int(v) for v in local_counts],
+           "reps_ms_per_step": rep_ms, "steps": steps, "n_gpus": world, "scaling": "strong",
+           "config": {"workload": f"{n_cams} cams, {n_pts} pts, {n_obs} obs, Schur + dense {6 * n_cams}x{6 * n_cams} Cholesky, "
+                                  "st20 spiral/cube scene seed 20, pixel noise 1e-3",
+                      "collective": collective, "schur_form": "dense product" if eng.schur_mode() == eng.SCHUR_DENSE else "pair plan"},
+           "phase_ms_per_step": ph, "allreduce_ms": float(phases[5]), "allreduce_bytes": ar_bytes,
+           "camera_blocks_identical_on_all_ranks": bool(same), "final_cost": summ.final_cost,
+           "predicted_scaling": predicted_scaling(ph, ms_step, float(phases[5]), ar_bytes, world,
+                                                  "few cameras, many landmarks: the replicated factorisation is small and everything else divides by N")}
+    eng.close()
+    if comm is not None:
+        comm.close()
+    return out
+
+
+def load_second_scene(args, rank):
+    """the landmark-heavy scene (few cameras, many landmarks, 10 observations per landmark); the landmarks start at their true positions
+    (no re-triangulation pass: at 10^7 observations that alone took minutes), the cameras at the reference's noise"""
+    scenes = importlib.import_module("slam-tricks_amd.scenes")
+    tag = f"c{args.second_cams}_p{args.second_pts}_m10_s20_notri"
+    cache = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"stba_scene_{tag}.npz")
+    if os.path.exists(cache):
+        try:
+            z = np.load(cache)
+            return {k: z[k] for k in z.files}
+        except Exception:
+            pass
+    s = scenes.st20_scene(n_cams=args.second_cams, n_pts=args.second_pts, max_obs_per_pt=10, seed=20, pix_noise=1e-3, retriangulate=False)
+    if rank == 0:
+        try:
+            np.savez(cache + f".tmp{os.getpid()}.npz", **s)
+            os.replace(cache + f".tmp{os.getpid()}.npz", cache)
+        except Exception:
+            pass
+    return s
+
+
 def free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -292,7 +459,15 @@ def main():
     ap.add_argument("--hook", default="native", choices=["native", "torch"], help="cross-rank sum: native RCCL communicator | torch.distributed hook")
     ap.add_argument("--config", default="c5", choices=["c5", "c4"], help="c5: the headline BA workload (default); c4: the 10k-node pose graph")
     ap.add_argument("--pg-nodes", type=int, default=10000)
+    ap.add_argument("--second-scene", action="store_true",
+                    help="also time the LANDMARK-HEAVY scene (--second-cams x --second-pts, 10 observations per landmark) and emit it under the key "
+                         "`landmark_heavy` with its own predicted_scaling; on by itself with --gpus N > 1: a driver with several GPUs then records the "
+                         "headline C5 curve (flat: the replicated factorisation) and the one landmark sharding can scale on, in one call")
+    ap.add_argument("--no-second-scene", action="store_true")
+    ap.add_argument("--second-cams", type=int, default=100)
+    ap.add_argument("--second-pts", type=int, default=1000000)
     args = ap.parse_args()
+    want_second = (args.second_scene or args.gpus > 1) and not args.no_second_scene and not args.dense_visibility
     if args.config == "c4":
         if args.gpus != 1:
             raise SystemExit("bench.py --config c4 measures one GPU")
@@ -336,6 +511,16 @@ def main():
             counts = torch.zeros(world, dtype=torch.float64)
             counts[rank] = float(len(sh["obs_cam"]))
             dist.all_reduce(counts)
+            second = None
+            if want_second:
+                s2 = load_second_scene(args, rank)
+                sh2 = sharding.make_shard(s2, rank, world)
+                c2 = torch.zeros(world, dtype=torch.float64)
+                c2[rank] = float(len(sh2["obs_cam"]))
+                dist.all_reduce(c2)
+                second = {"value": None, "skipped": "no HIP device", "n_obs": int(len(s2["obs_cam"])), "n_cams": int(len(s2["cams0"])),
+                          "n_pts": int(len(s2["pts0"])), "observations_per_rank": [int(v) for v in c2.tolist()],
+                          "predicted_scaling": None, "camera_blocks_identical_on_all_ranks": None}
             dist.barrier()
             if rank == 0:
                 # (the keys that explain an N > 1 line are present, without values: nothing ran)
@@ -345,7 +530,8 @@ def main():
                                   "sharded_observations": int(counts.sum().item()), "n_obs": n_obs,
                                   "observations_per_rank": [int(v) for v in counts.tolist()],
                                   "phase_ms_per_step": None, "allreduce_ms": None, "allreduce_bytes": None,
-                                  "allreduce_calls_per_step": None}), flush=True)
+                                  "allreduce_calls_per_step": None, "camera_blocks_identical_on_all_ranks": None,
+                                  "landmark_heavy": second}), flush=True)
             dist.destroy_process_group()
             return
         raise SystemExit("bench.py needs an MI355X: libstba has no CPU fallback")
@@ -353,44 +539,7 @@ def main():
     # the engine runs on its own (non-default) stream; collectives are enqueued on the same stream
     stream_obj = torch.cuda.Stream()
     stream = stream_obj.cuda_stream
-    eng = st.BAEngine(sh["cams0"], sh["pts0"], sh["obs_cam"], sh["obs_pt"], sh["obs_feat"], sh["cam_fixed"], stream=stream)
-    collective = "none"
-    comm = None
-    if world > 1:
-        if args.hook == "native":
-            # the decision native communicator | torch hook is COLLECTIVE: rank 0 always broadcasts (the id or None), and after
-            # the communicator is created the ranks agree on whether every one of them succeeded -- a rank that fell back
-            # alone would leave the others blocked in ncclCommInitRank or issue mismatched collectives
-            uid = None
-            if rank == 0:
-                try:
-                    uid = st.comm_unique_id()
-                except Exception as e:      # noqa: BLE001
-                    print(f"[rank 0] native communicator: no unique id ({e!r})", file=sys.stderr, flush=True)
-            box = [uid]
-            dist.broadcast_object_list(box, src=0)
-            ok = 0.0
-            if box[0] is not None:
-                try:
-                    comm = st.Comm(box[0], rank, world, device=local_rank)
-                    ok = 1.0
-                except Exception as e:      # noqa: BLE001
-                    print(f"[rank {rank}] native communicator failed ({e!r})", file=sys.stderr, flush=True)
-                    comm = None
-            agree = torch.tensor([ok], dtype=torch.float64, device="cuda" if (have_gpu and args.backend == "nccl") else "cpu")
-            dist.all_reduce(agree, op=dist.ReduceOp.MIN)
-            if float(agree.item()) >= 1.0:
-                eng.set_comm(comm)
-                collective = "native RCCL (ncclAllReduce on the engine stream, stba_comm)"
-            else:
-                if comm is not None:
-                    comm.close()
-                comm = None
-                if rank == 0:
-                    print("native communicator not available on every rank: all ranks use the torch hook", file=sys.stderr, flush=True)
-        if comm is None:
-            eng.set_allreduce(sharding.torch_allreduce_hook(dist, torch), rank, world)
-            collective = "torch.distributed all_reduce (RCCL) through the Python hook"
+    eng, comm, collective = make_engine(st, sharding, torch, dist, sh, stream, rank, world, local_rank, have_gpu, args)
 
     def sync():
         torch.cuda.synchronize()
@@ -416,6 +565,7 @@ def main():
         rep_ms.append(1e3 * dt / args.steps)
     ms_step = float(np.median(rep_ms))
     it_per_s = 1e3 / ms_step
+    cams_same, _ = ranks_hold_identical_cameras(eng, torch, dist, world, have_gpu, args)
     out = {
         "metric": "LM iterations/sec + residuals/sec, 1k-cam/100k-pt BA",
         "value": it_per_s, "unit": "LM iterations/s",
@@ -430,6 +580,7 @@ def main():
                    "parallelism": f"landmark-shard x{world}" if world > 1 else "single GPU",
                    "collective": collective, "n_cams": n_cams, "n_pts": n_pts, "n_obs": n_obs},
         "final_cost": summ.final_cost,
+        "camera_blocks_identical_on_all_ranks": bool(cams_same),    # every rank factors the same reduced system: compared in-run, bit for bit
     }
     # Device time per phase: ONE MORE run of K steps with stba_lm_options::phase_timing on (hipEvents between the phases; the
     # timed repetitions above run without them: an event record costs ~5 us of idle GPU and an iteration would take eight),
@@ -461,6 +612,13 @@ def main():
     out["allreduce_calls_per_step"] = float(summ.allreduce_calls / args.steps)
     out["observations_per_rank"] = [int(v) for v in local_counts]
 
+    if want_second:
+        # the landmark-heavy scene, same protocol, all ranks (fewer steps: an iteration is ~10x the observations of C5)
+        s2 = load_second_scene(args, rank)
+        out["landmark_heavy"] = time_scene(st, sharding, torch, dist, s2, args, rank, world, local_rank, have_gpu,
+                                           steps=max(2, min(args.steps, 20)), reps=min(args.reps, 3), warmup=min(args.warmup, 2))
+        out["landmark_heavy"]["note"] = ("not a BASELINE config: the workload landmark sharding scales on (DESIGN.md 6), timed next to the headline so "
+                                         "that one multi-GPU call records both curves")
     if rank == 0:
         # ---- roofline legs, measured live with hipEvents on the engine's stream
         ms_jac = eng.time_linearize(20)
@@ -601,7 +759,22 @@ def main():
             # the reference pins num_threads = 1 (test_ceres.h:143); also report the best OpenMP setting
             # (measured on the GPU box's 2 x EPYC 9575F: 16 threads is the optimum of the oracle)
             it1, n1, r1, d1 = time_oracle(1, 8.0, 1)
-            thb = min(ncpu, 16)
+            # thread-count sweep ON THIS BOX (every speed-up used to be quoted against 16 of the box's logical cores
+            # without a look at the others): two fixed-work iterations per setting, the best one is then measured properly
+            sweep = {}
+            for th in (16, 32, 64, 128):
+                if th > ncpu and th != 16:
+                    continue
+                th = min(th, ncpu)
+                ba = fresh()
+                ba.solve(fixed_iterations=1, num_threads=th)            # (first touch / thread team start-up outside the timing)
+                ba = fresh()
+                tc = time.perf_counter()
+                ba.solve(fixed_iterations=2, num_threads=th)
+                sweep[th] = 2.0 / (time.perf_counter() - tc)
+            thb = max(sweep, key=sweep.get)
+            out["cpu_thread_sweep"] = {"lm_iterations_per_sec_by_threads": {str(k): v for k, v in sweep.items()}, "best": thb,
+                                       "logical_cores_on_box": ncpu, "sample": "2 fixed-work LM iterations of the C5 problem per setting, oracle C Cholesky"}
             itb, nb_, rb, db = time_oracle(thb, 8.0, 5)
             plain = {"value": itb, "unit": "LM iterations/s", "cores": thb, "kind": "port", "cpu_model": model,
                      "logical_cores_on_box": ncpu, "residuals_per_sec": itb * 2.0 * n_obs,
@@ -658,25 +831,11 @@ def main():
         # the Jacobian / Schur / back-substitution / trial-cost work divides by N, and one packed all-reduce of the reduced system
         # per build is added (bounds: a ring over one xGMI link, 48 GB/s each way; reduce-scatter + all-gather over all N - 1 links)
         if local_counts.sum() > 0:
-            ph = out["phase_ms_per_step"]
-            t_repl = ph["ms_solve"]
-            t_shard = max(0.0, ph["ms_linearize"] + ph["ms_schur"] - out["allreduce_ms"] + ph["ms_backsub"] + ph["ms_cost"]) * world
-            t_other = max(0.0, ms_step - (ph["ms_linearize"] + ph["ms_schur"] + ph["ms_solve"] + ph["ms_backsub"] + ph["ms_cost"]))
             ar_bytes = out["allreduce_bytes"] if world > 1 else (4.0 * nred * (nred + 1) if args.dense_visibility else 40.7e6 * (n_cams / 1000.0) ** 2)
-            pred = {}
-            for N in (1, 2, 4, 8):
-                ring = 0.0 if N == 1 else 2.0 * (N - 1) / N * ar_bytes / 48e9 * 1e3
-                direct = 0.0 if N == 1 else 2.0 * ar_bytes / N / 48e9 * 1e3
-                lo, hi = t_repl + t_other + t_shard / N + direct, t_repl + t_other + t_shard / N + ring
-                pred[str(N)] = {"ms_per_step_best": lo, "ms_per_step_ring": hi, "it_per_s_best": 1e3 / lo, "it_per_s_ring": 1e3 / hi}
-            base = pred["1"]["ms_per_step_best"]
-            out["predicted_scaling"] = {"model": "T(N) = replicated (factorisation + backward substitution) + other + sharded / N + all-reduce(N); terms from this run's "
-                                                 "phase_ms_per_step; all-reduce of the packed reduced system: ring over one 48 GB/s xGMI link | direct over N - 1 links",
-                                        "replicated_ms": t_repl, "sharded_ms_total": t_shard, "other_ms": t_other, "allreduce_bytes": ar_bytes,
-                                        "per_gpus": pred, "speedup_at_8_best": base / pred["8"]["ms_per_step_best"],
-                                        "speedup_at_8_ring": base / pred["8"]["ms_per_step_ring"],
-                                        "note": "strong scaling of C5 is bounded by the replicated factorisation (DESIGN.md 6); a problem with few cameras and many "
-                                                "landmarks (python bench.py --gpus N --cams 100 --pts 1000000) is where landmark sharding scales"}
+            out["predicted_scaling"] = predicted_scaling(out["phase_ms_per_step"], ms_step, out["allreduce_ms"], ar_bytes, world,
+                                                         "strong scaling of C5 is bounded by the replicated factorisation (DESIGN.md 6); a problem with few "
+                                                         "cameras and many landmarks is where landmark sharding scales: see the key `landmark_heavy` "
+                                                         "(emitted with --gpus N > 1, or --second-scene)")
         # ---- library cross-check: rocSOLVER's potrf + potrs of the same size on the same box, a stated baseline
         # like the CPU leg.  librocsolver is dlopen'ed by the TOOL, never by libstba.
         if world == 1 and not args.no_library_baseline:

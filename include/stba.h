@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define STBA_VERSION 4
+#define STBA_VERSION 5
 
 /* status codes */
 enum {
@@ -58,7 +58,7 @@ enum {
 
 const char* stba_status_string(int status);
 const char* stba_last_error(void);      /* thread-local detail of the last failure */
-int stba_version(void);
+int stba_version(void);                 /* 5: stba_lm_options grew function_tolerance_takes_step (append-only) */
 /* number of visible HIP devices (0 => every compute entry point returns STBA_ERR_NO_DEVICE) */
 int stba_device_count(void);
 
@@ -82,6 +82,15 @@ typedef struct {
     int    phase_timing;                  /* 0 (default): no per-phase device times.  1: hipEvents between the phases of every
                                            * iteration fill stba_lm_summary::ms_* -- an event is a packet of its own on the queue
                                            * and costs ~5 us of idle GPU, ~1.5 % of a C5 iteration for the eight it takes */
+    int    function_tolerance_takes_step; /* what happens to the trial step on which |cost change| <= function_tolerance * cost fires:
+                                           * 1 (default): it is taken if it is a decrease (rho > min_relative_decrease), THEN convergence
+                                           *    is reported -- the reading of Ceres' documentation this build started from;
+                                           * 0: convergence is reported at once and the step is NOT taken -- the order of the refactored
+                                           *    TrustRegionMinimizer (Ceres >= 1.12 through 2.1, as this build's authors remember it:
+                                           *    ParameterToleranceReached(), FunctionToleranceReached() in front of IsStepSuccessful()).
+                                           * No Ceres exists in this image to settle it (tools/ceres_baseline.cpp on a box that has one
+                                           * does, in one run); the final parameters differ by one step of relative cost change
+                                           * <= 1e-6 either way.  The oracle carries the same switch (orc_lm_options). */
 } stba_lm_options;
 
 void stba_lm_default_options(stba_lm_options* opt);

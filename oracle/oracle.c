@@ -263,6 +263,7 @@ void orc_lm_default_options(orc_lm_options* o) {
     o->jacobi_scaling = 1;
     o->num_threads = 1;
     o->fixed_iterations = 0;
+    o->function_tolerance_takes_step = 1;
 }
 
 /* ======================================================================================
@@ -790,8 +791,9 @@ int orc_ba_solve(orc_ba_problem* p, const orc_lm_options* opt, orc_lm_summary* s
                     break;
                 }
                 if (fabs(cost_change) <= opt->function_tolerance * cost) {
-                    /* Ceres takes the step if it is a decrease before reporting convergence */
-                    if (rho > opt->min_relative_decrease) {
+                    /* the step is taken if it is a decrease before convergence is reported -- or not at all
+                     * (function_tolerance_takes_step = 0: the other reading of Ceres, oracle.h) */
+                    if (opt->function_tolerance_takes_step && rho > opt->min_relative_decrease) {
                         memcpy(p->cams, w.cams_new, sizeof(double) * 7 * nc);
                         memcpy(p->pts, w.pts_new, sizeof(double) * 3 * np);
                         cost = new_cost; ++sum->num_successful_steps;
@@ -1030,7 +1032,7 @@ int orc_dense_lm(orc_residual_fn fn, orc_plus_fn plus, void* user, int n_params,
                 break;
             }
             if (fabs(cost_change) <= opt->function_tolerance * cost) {
-                if (rho > opt->min_relative_decrease) {
+                if (opt->function_tolerance_takes_step && rho > opt->min_relative_decrease) {
                     memcpy(x, xn, sizeof(double) * n_params); cost = new_cost; ++sum->num_successful_steps;
                     if (trace) trace[iter * ORC_TRACE_COLS + 6] = 1;
                 }
@@ -1804,7 +1806,7 @@ int orc_pg_solve_sparse(orc_pg_problem* p, const orc_lm_options* opt, orc_lm_sum
                 break;
             }
             if (fabs(cost_change) <= opt->function_tolerance * cost) {
-                if (rho > opt->min_relative_decrease) {
+                if (opt->function_tolerance_takes_step && rho > opt->min_relative_decrease) {
                     memcpy(p->poses, xn, sizeof(double) * 7 * (size_t)n); cost = new_cost; ++sum->num_successful_steps;
                     if (trace) trace[iter * ORC_TRACE_COLS + 6] = 1;
                 }

@@ -30,7 +30,8 @@ class LMOptions(C.Structure):
                 ("parameter_tolerance", C.c_double),
                 ("jacobi_scaling", C.c_int),
                 ("num_threads", C.c_int),
-                ("fixed_iterations", C.c_int)]
+                ("fixed_iterations", C.c_int),
+                ("function_tolerance_takes_step", C.c_int)]
 
 
 class LMSummary(C.Structure):

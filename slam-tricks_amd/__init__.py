@@ -37,7 +37,7 @@ class LMOptions(C.Structure):
                 ("gradient_tolerance", C.c_double), ("parameter_tolerance", C.c_double),
                 ("jacobi_scaling", C.c_int), ("num_threads", C.c_int),
                 ("minimizer_progress_to_stdout", C.c_int), ("update_state_every_iteration", C.c_int),
-                ("phase_timing", C.c_int)]
+                ("phase_timing", C.c_int), ("function_tolerance_takes_step", C.c_int)]
 
 
 class LMSummary(C.Structure):

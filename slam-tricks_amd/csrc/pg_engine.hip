@@ -1415,7 +1415,7 @@ int stba_pg_solve(stba_pg* g, const stba_lm_options* opt_in, const stba_pcg_opti
             if (step_norm <= opt.parameter_tolerance * (x_norm + opt.parameter_tolerance)) {
                 s.termination_type = STBA_CONVERGENCE; s.termination_reason = STBA_TERM_PARAMETER; stop = true;
             } else if (std::fabs(cost_change) <= opt.function_tolerance * cost) {
-                if (rho > opt.min_relative_decrease) { g->cur = nxt; cost = new_cost; ++s.num_successful_steps; accepted = true; g->coarse_valid = false; }
+                if (opt.function_tolerance_takes_step && rho > opt.min_relative_decrease) { g->cur = nxt; cost = new_cost; ++s.num_successful_steps; accepted = true; g->coarse_valid = false; }
                 s.termination_type = STBA_CONVERGENCE; s.termination_reason = STBA_TERM_FUNCTION; stop = true;
             }
             if (!stop) accepted = rho > opt.min_relative_decrease;

@@ -567,6 +567,7 @@ static void default_options(stba_lm_options* o) {
     o->minimizer_progress_to_stdout = 0;
     o->update_state_every_iteration = 0;
     o->phase_timing = 0;
+    o->function_tolerance_takes_step = 1;
 }
 
 // reads {cost2, gpmax slots, gc} after a reduced-system build and returns cost / gradient max norm
@@ -808,7 +809,8 @@ static int ba_run_lm(stba_ba* b, const stba_lm_options* opt_in, int fixed_iterat
                     s.termination_type = STBA_CONVERGENCE; s.termination_reason = STBA_TERM_PARAMETER;
                     stop = true;
                 } else if (std::fabs(cost_change) <= opt.function_tolerance * L.cost) {
-                    if (rho > opt.min_relative_decrease) {
+                    // (function_tolerance_takes_step, stba.h: 1 = the decreasing step is taken before convergence is reported; 0 = not)
+                    if (opt.function_tolerance_takes_step && rho > opt.min_relative_decrease) {
                         b->cur ^= 1; L.cost = new_cost; ++s.num_successful_steps; accepted = true;
                     }
                     s.termination_type = STBA_CONVERGENCE; s.termination_reason = STBA_TERM_FUNCTION;
@@ -2003,13 +2005,14 @@ int stba_dense_solve(stba_residual_fn fn, stba_plus_fn plus, void* user, int n_p
                 break;
             }
             if (std::fabs(cost_change) <= opt.function_tolerance * cost) {
-                if (rho > opt.min_relative_decrease) {
+                const bool take = opt.function_tolerance_takes_step && rho > opt.min_relative_decrease;      // (stba.h)
+                if (take) {
                     memcpy(x, xn.data(), sizeof(double) * n_params); cost = new_cost; ++s.num_successful_steps;
                     if (trace) trace[(size_t)iter * STBA_TRACE_COLS + 6] = 1;
                 }
                 s.termination_type = STBA_CONVERGENCE; s.termination_reason = STBA_TERM_FUNCTION;
                 if (trace) { trace[(size_t)iter * STBA_TRACE_COLS + 5] = radius; trace[(size_t)iter * STBA_TRACE_COLS + 2] = gmax; }
-                if (cb) (void)cb(cb_user, iter, cost, cost_change, gmax, step_norm, radius, rho > opt.min_relative_decrease ? 1 : 0);
+                if (cb) (void)cb(cb_user, iter, cost, cost_change, gmax, step_norm, radius, take ? 1 : 0);
                 break;
             }
             accepted = rho > opt.min_relative_decrease;

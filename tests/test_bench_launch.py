@@ -18,7 +18,8 @@ def _env(tmp_path):
 
 def test_bench_gpus_2_launches_two_ranks(tmp_path):
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--cams", "8",
-                        "--pts", "200", "--obs-per-pt", "4", "--steps", "2", "--warmup", "0", "--no-cpu-baseline"],
+                        "--pts", "200", "--obs-per-pt", "4", "--steps", "2", "--warmup", "0", "--no-cpu-baseline",
+                        "--second-cams", "5", "--second-pts", "600"],
                        capture_output=True, text=True, timeout=600, env=_env(tmp_path), cwd=str(tmp_path))
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
@@ -35,6 +36,15 @@ def test_bench_gpus_2_launches_two_ranks(tmp_path):
         assert key in d, key
     assert len(d["observations_per_rank"]) == 2 and sum(d["observations_per_rank"]) == d["n_obs"]
     assert min(d["observations_per_rank"]) > 0.4 * d["n_obs"]          # balanced by observation count
+    # with N > 1 the LANDMARK-HEAVY scene is timed in the same call, under its own key: both shards cover it, and the
+    # keys that make its line readable are there; every rank's camera blocks are compared bit for bit in-run
+    assert "camera_blocks_identical_on_all_ranks" in d
+    lh = d["landmark_heavy"]
+    assert lh is not None and lh["n_cams"] == 5 and sum(lh["observations_per_rank"]) == lh["n_obs"] and len(lh["observations_per_rank"]) == 2
+    for key in ("value", "predicted_scaling", "camera_blocks_identical_on_all_ranks"):
+        assert key in lh, key
+    if st_has_gpu:
+        assert d["camera_blocks_identical_on_all_ranks"] is True and lh["camera_blocks_identical_on_all_ranks"] is True
 
 
 def test_bench_refuses_a_rank_count_that_is_not_gpus(tmp_path):

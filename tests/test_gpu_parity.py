@@ -811,3 +811,22 @@ def test_more_cameras_than_the_linearise_kernels_lds_table(st, O, scenes):
     assert abs(cost - co) <= 1e-12 * co
     assert np.abs(r - ro).max() < 1e-13 and np.abs(Jc - Jco).max() < 1e-11 and np.abs(Jp - Jpo).max() < 1e-11
     assert abs(e.cost() - co) <= 1e-12 * co                                  # the cost-only instantiation
+
+
+@pytest.mark.gpu
+def test_function_tolerance_switch_follows_the_oracle(st, O, scenes):
+    """stba_lm_options::function_tolerance_takes_step = 0 (the step on which the function tolerance fires is not taken): engine and oracle
+    agree on that reading as well -- same iteration count, same trace, last step refused, parameters one step behind the default's"""
+    s = scenes.st20_scene(pix_noise=1e-3)
+    e1, e0 = engine(st, s), engine(st, s)
+    o0 = oracle(O, s)
+    s1, t1 = e1.solve()
+    s0, t0 = e0.solve(function_tolerance_takes_step=0)
+    so, to = o0.solve(function_tolerance_takes_step=0)
+    n = so.num_iterations
+    assert s0.num_iterations == n == s1.num_iterations and s0.termination_reason == so.termination_reason == 2
+    assert np.array_equal(t0[: n + 1, 6], to[: n + 1, 6]) and t0[n, 6] == 0 and t1[n, 6] == 1
+    assert np.allclose(t0[: n + 1, 0], to[: n + 1, 0], rtol=1e-9)
+    assert abs(s0.final_cost - so.final_cost) <= 1e-9 * so.final_cost and s0.final_cost >= s1.final_cost
+    dq, dt = pose_err(e0.get_params()[0], o0.cams)
+    assert dq < 1e-8 and dt < 1e-8

@@ -194,3 +194,23 @@ def test_lapack_backed_reduced_solve_follows_the_c_factorisation(O, scenes):
     assert np.array_equal(tr0[:, 6], tr1[:, 6])
     assert np.allclose(tr0[:, 0], tr1[:, 0], rtol=1e-10)
     assert np.abs(c0 - c1).max() < 1e-10 and np.abs(p0 - p1).max() < 1e-9
+
+
+def test_function_tolerance_switch(O, scenes):
+    """the one reading of Ceres that changes results: is the step on which the function tolerance fires taken?
+    1 (default, as before): yes, if it decreases the cost; 0: no.  Same iterations, same trace up to the last row, one accepted step
+    and one tiny cost change apart; the final parameters agree far inside north_star's tolerances either way."""
+    s = scenes.st20_scene(pix_noise=1e-3)
+    mk = lambda: O.BA(s["cams0"], s["pts0"], s["obs_cam"], s["obs_pt"], s["obs_feat"], s["cam_fixed"])
+    o1, o0 = mk(), mk()
+    s1, t1 = o1.solve()
+    s0, t0 = o0.solve(function_tolerance_takes_step=0)
+    assert s1.termination_reason == O.TERM_FUNCTION if hasattr(O, "TERM_FUNCTION") else s1.termination_reason == 2
+    assert s0.termination_reason == s1.termination_reason and s0.num_iterations == s1.num_iterations
+    n = s1.num_iterations
+    assert np.array_equal(t0[:n, :], t1[:n, :])                     # identical until the last iteration
+    assert t1[n, 6] == 1 and t0[n, 6] == 0                          # the last step: taken | not taken
+    assert s0.num_successful_steps == s1.num_successful_steps - 1
+    assert s0.final_cost == t1[n - 1, 0] and s1.final_cost == t1[n, 0]
+    assert 0 <= s0.final_cost - s1.final_cost <= 1e-6 * s0.final_cost
+    assert np.abs(o0.cams - o1.cams).max() < 1e-5
