@@ -1151,14 +1151,20 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
     }
     tmark("row plan");
     b->n_tasks = (int)task_cam.size();
-    // Pair records (i, l, landmark, accumulator slot | flags) of every task.  RUN-TO-RUN REPRODUCIBILITY (round 5): every 6 x 6
-    // block of a task is accumulated by ONE wave of the task's workgroup, so the ds_add_f64 that meet in an LDS address are all
-    // issued by the same wave, in program order, and S comes out bit-identical from launch to launch (with the pairs dealt to
+    // Pair records (i, l, landmark, accumulator slot | flags) of every task.  RUN-TO-RUN REPRODUCIBILITY (round 5): every LDS
+    // accumulator slot of a task is added to by ONE wave of the task's workgroup, so the ds_add_f64 that meet in an LDS address are
+    // all issued by the same wave, in program order, and S comes out bit-identical from launch to launch (with the pairs dealt to
     // all 512 lanes in list order, as until round 4, the eight waves raced for the blocks and the sums differed in their last
-    // bits: 34 distinct final costs in 48 long LM runs).  A task's blocks are dealt to its waves heaviest first (LPT) by pair
-    // count; a block with more pairs than a wave's share is cut into PARTS with an accumulator slot each (consecutive slots,
-    // added in order when the block is written), so that two cameras with 5000 common landmarks still use all eight waves.
-    // Inside a wave the records keep the landmark-major order (locality of the gathers).
+    // bits: 34 distinct final costs in 48 long LM runs).
+    // How the slots are dealt matters for speed.  A first version gave every 6 x 6 block to one wave (heaviest first): correct, and
+    // 0.340 instead of 0.257 ms -- a wave's 64 lanes then hold pairs of 64 different landmarks (a landmark's partners are different
+    // cameras, i.e. different blocks, i.e. different waves), so the own record J_i and the inverse landmark block are requested 64
+    // times per instruction instead of ~12, and a wave that owns a heavy block adds to the same addresses in most of its lanes.
+    // So: the camera's observation list (landmarks ascending) is cut into EIGHT RANGES of equal pair count, one per wave; a heavy
+    // block gets up to eight PARTS -- accumulator slots of its own, consecutive, added in order when the block is written -- one per
+    // range (or per two / four ranges), and part k goes to a wave of its ranges.  A wave's list is then, for the blocks that hold
+    // most of the pairs, exactly the pairs of the landmarks of its range in the old order: the same coalescing and the same mix of
+    // blocks per instruction as before.  Light blocks (one part) are dealt to the least loaded wave.
     constexpr int NW = SCHUR_THREADS / 64;
     std::vector<int> pair_begin, pair_end, task_vs_ptr, vs_first;
     std::vector<int4> pair_rec;
@@ -1177,8 +1183,8 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
         std::vector<int> max_slots_thr(64, 0);
         host_parallel_for(ntask, [&](int k_lo, int k_hi, int tix) {
             std::vector<int> slot_of((size_t)n_cams, 0);
-            std::vector<int> psize, wave_of, seen, order;
-            std::vector<size_t> part_cnt;
+            std::vector<int> nparts, wave_of, order, cntR;
+            std::vector<unsigned char> range_of;
             for (int k = k_lo; k < k_hi; ++k) {
                 const int c = task_cam[(size_t)k];
                 const int* cb = row_cols.data() + row_col_ptr[c];
@@ -1187,33 +1193,60 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
                 const int slo = task_col_lo[(size_t)k], shi = task_col_hi[(size_t)k], ncols = shi - slo;
                 const int* bc = cnt_of[(size_t)c].data() + slo;                 // pairs per block of the slice
                 const size_t total = task_pairs[(size_t)k];
-                const size_t target = std::max<size_t>(64, (total + NW - 1) / NW);
                 int* vsf = vs_first.data() + task_vs_ptr[(size_t)k];
-                psize.assign((size_t)ncols, 1);
-                int nvs = 0;
-                for (int q = 0; q < ncols; ++q) {
-                    const int np_ = std::max(1, (int)(((size_t)bc[q] + target - 1) / target));
-                    psize[(size_t)q] = std::max(1, (bc[q] + np_ - 1) / np_);
-                    vsf[q] = nvs;
-                    nvs += np_;
+                // ---- pass 1: the range of every observation of the camera (equal shares of THIS task's pairs), pairs per (block, range)
+                const int p0 = cam_start[c], p1 = cam_start[c + 1];
+                range_of.assign((size_t)(p1 - p0), 0);
+                cntR.assign((size_t)ncols * NW, 0);
+                {
+                    size_t before = 0;
+                    for (int p = p0; p < p1; ++p) {
+                        const int i = cam_perm[p];
+                        const int j = s_pt[i];
+                        const int w = total > 0 ? (int)std::min<size_t>(NW - 1, before * NW / total) : 0;
+                        range_of[(size_t)(p - p0)] = (unsigned char)w;
+                        for (int l = pt_start[j]; l < pt_start[j + 1]; ++l) {
+                            const int c2 = s_cam[l];
+                            if (c2 > c || l == i) continue;
+                            const int sl = slot_of[(size_t)c2];
+                            if (sl < slo || sl >= shi) continue;
+                            ++cntR[(size_t)(sl - slo) * NW + w];
+                            ++before;
+                        }
+                    }
                 }
+                // ---- parts per block: 8 / 4 / 2 / 1 by pair count; the threshold doubles until the slots fit the LDS accumulator
+                nparts.assign((size_t)ncols, 1);
+                int nvs = 0;
+                for (int thr = 24;; thr *= 2) {
+                    nvs = 0;
+                    for (int q = 0; q < ncols; ++q) {
+                        const int np_ = bc[q] >= 8 * thr ? 8 : bc[q] >= 4 * thr ? 4 : bc[q] >= 2 * thr ? 2 : 1;
+                        nparts[(size_t)q] = np_;
+                        nvs += np_;
+                    }
+                    if (nvs <= SCHUR_MAX_SLOTS || thr > (1 << 28)) break;
+                }
+                nvs = 0;
+                for (int q = 0; q < ncols; ++q) { vsf[q] = nvs; nvs += nparts[(size_t)q]; }
                 vsf[ncols] = nvs;
                 max_slots_thr[(size_t)(tix & 63)] = std::max(max_slots_thr[(size_t)(tix & 63)], nvs);
-                // parts -> waves, heaviest first
-                part_cnt.assign((size_t)nvs, 0);
-                for (int q = 0; q < ncols; ++q)
-                    for (int v = vsf[q]; v < vsf[q + 1]; ++v)
-                        part_cnt[(size_t)v] = (size_t)std::max(0, std::min(psize[(size_t)q], bc[q] - (v - vsf[q]) * psize[(size_t)q]));
-                order.resize((size_t)nvs);
-                for (int v = 0; v < nvs; ++v) order[(size_t)v] = v;
-                std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return part_cnt[(size_t)x] > part_cnt[(size_t)y]; });
+                // ---- slots -> waves: a part goes to the least loaded wave among the ranges it covers; blocks heaviest first
+                order.resize((size_t)ncols);
+                for (int q = 0; q < ncols; ++q) order[(size_t)q] = q;
+                std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return bc[x] > bc[y]; });
                 size_t load[NW] = {0};
                 wave_of.assign((size_t)nvs, 0);
-                for (int v : order) {
-                    int best = 0;
-                    for (int w2 = 1; w2 < NW; ++w2) if (load[w2] < load[best]) best = w2;
-                    wave_of[(size_t)v] = best;
-                    load[best] += part_cnt[(size_t)v];
+                for (int q : order) {
+                    const int np_ = nparts[(size_t)q], span = NW / np_;
+                    for (int part = 0; part < np_; ++part) {
+                        size_t pc = 0;
+                        for (int w = part * span; w < (part + 1) * span; ++w) pc += (size_t)cntR[(size_t)q * NW + w];
+                        int best = part * span;
+                        for (int w = part * span + 1; w < (part + 1) * span; ++w) if (load[w] < load[best]) best = w;
+                        wave_of[(size_t)(vsf[q] + part)] = best;
+                        load[best] += pc;
+                    }
                 }
                 size_t wpos[NW];
                 {
@@ -1224,10 +1257,11 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
                         pair_end[(size_t)k * NW + w2] = (int)off;
                     }
                 }
-                seen.assign((size_t)ncols, 0);
-                for (int p = cam_start[c]; p < cam_start[c + 1]; ++p) {
+                // ---- pass 2: the records, every wave's list in landmark-major order
+                for (int p = p0; p < p1; ++p) {
                     const int i = cam_perm[p];
                     const int j = s_pt[i];
+                    const int w = range_of[(size_t)(p - p0)];
                     for (int l = pt_start[j]; l < pt_start[j + 1]; ++l) {
                         const int c2 = s_cam[l];
                         // (the pairs (i, i) -- an observation's own term of the diagonal block and of the right-hand side -- are
@@ -1236,12 +1270,10 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
                         const int sl = slot_of[(size_t)c2];
                         if (sl < slo || sl >= shi) continue;
                         const int q = sl - slo;
-                        const int v = vsf[q] + seen[(size_t)q]++ / psize[(size_t)q];
+                        const int v = vsf[q] + w / (NW / nparts[(size_t)q]);
                         pair_rec[wpos[wave_of[(size_t)v]]++] = make_int4(i, l, j, v | (c2 == c ? 0x8000 : 0));
                     }
                 }
-                // (dealing the records out so that every 32 consecutive ones hit 32 different LDS bank pairs was measured:
-                // the bank conflicts it removes cost less than the locality of the landmark-major order it destroys)
             }
         });
         for (int v : max_slots_thr) max_slots = std::max(max_slots, v);

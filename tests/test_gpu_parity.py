@@ -664,6 +664,9 @@ def test_dense_schur_form_with_repeated_camera_landmark_pairs(st, O, scenes):
     s["obs_cam"] = np.concatenate([s["obs_cam"], s["obs_cam"][extra]])
     s["obs_pt"] = np.concatenate([s["obs_pt"], s["obs_pt"][extra]])
     s["obs_feat"] = np.concatenate([s["obs_feat"], s["obs_feat"][extra] + rng.normal(0, 2e-3, (len(extra), 2))])
+    order = np.argsort(s["obs_pt"], kind="stable")                           # (the oracle wants landmark-major observations)
+    for k in ("obs_cam", "obs_pt", "obs_feat"):
+        s[k] = s[k][order]
     e, o = engine(st, s), oracle(O, s)
     e.evaluate(); e.normal_blocks()
     _, ro, Jco, Jpo = o.evaluate()
