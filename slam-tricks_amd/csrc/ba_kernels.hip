@@ -668,7 +668,7 @@ int launch_point_invert(int n_pts, const double* Hpp6, const double* dp, const u
 // reduction over the camera's observations, whose records are in this CU's caches at that moment (as a kernel of its
 // own that gather cost 46 us per iteration).  Fixed summation order: Hcc and gc are bitwise reproducible.
 // ===========================================================================================
-template <int ROTS, bool GEN = false>
+template <int ROTS, bool GEN = false, int MODE = 0>
 __global__ __launch_bounds__(SCHUR_THREADS, GEN ? 2 : 4) void ba_schur_pairs_kernel(SchurArgs a) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int task = blockIdx.x;
@@ -689,6 +689,7 @@ __global__ __launch_bounds__(SCHUR_THREADS, GEN ? 2 : 4) void ba_schur_pairs_ker
     if (tid < 8) racc[tid] = 0.0;
     for (int e = tid; e < ncols; e += SCHUR_THREADS) cols[e] = a.row_cols[col0 + e];
     for (int e = tid; e <= ncols; e += SCHUR_THREADS) vsf[e] = vs_g[e];
+    if (tid == 0) vsf[a.max_cols + 1] = 0;       // the token of mode 1
     {
         // this slice's stretch of the camera's six rows of S is zeroed HERE (the whole row up to the end of the diagonal
         // 128-tile, shared out between the slices; nothing right of it is ever read): the stores drain under the pair loop
@@ -706,15 +707,28 @@ __global__ __launch_bounds__(SCHUR_THREADS, GEN ? 2 : 4) void ba_schur_pairs_ker
     // measured 7 % slower: the kernel is not bound by the gather latency.)
     // Every wave walks ITS OWN list: the host dealt the task's blocks (parts of heavy blocks) to the eight waves, so all the LDS
     // adds that meet in one address come from one wave, in program order -- S is bitwise reproducible (see stba_ba_create).
+    // a.mode 1 (round 5, second form): ONE list per task walked by all 512 lanes as until round 4 (lane t takes pair t + 512 trip),
+    // and the eight waves add their contributions of a trip IN WAVE ORDER: a token in LDS -- wave w of trip n waits for 8 n + w,
+    // adds, waits for its LDS operations, passes 8 n + w + 1 on.  Same order of additions into every address in every run.
+    // a.mode 2: the same list without the token (the round-4 kernel: arrival order; kept as the timing reference).
     const int wv = tid >> 6;
-    const int ke = a.pair_end[task * (SCHUR_THREADS / 64) + wv];
+    constexpr int mode = MODE;                   // (the product build instantiates mode 0 only; debug builds all three: tools/dbg/schur_modes.py)
+    const int stride = mode == 0 ? 64 : SCHUR_THREADS;
+    const int ent = task * (SCHUR_THREADS / 64) + (mode == 0 ? wv : 0);
+    const int kb = a.pair_begin[ent], ke = a.pair_end[ent];
+    const int ntrips = (ke - kb + stride - 1) / stride;
+    int* turn = vsf + a.max_cols + 1;
     const int rot = tid % ROTS;
     // (the pair record runs one trip ahead: one dependent memory round trip less per trip)
-    int k = a.pair_begin[task * (SCHUR_THREADS / 64) + wv] + (tid & 63);
+    int k = kb + (mode == 0 ? (tid & 63) : tid);
     int4 rn = (k < ke) ? a.pair_rec[k] : make_int4(0, 0, 0, 0);
-    for (; k < ke; k += 64) {
+    for (int trip = 0; trip < ntrips; ++trip, k += stride) {
         const int4 rc = rn;
-        if (k + 64 < ke) rn = a.pair_rec[k + 64];
+        const bool valid = k < ke;
+        if (k + stride < ke) rn = a.pair_rec[k + stride];
+        if (mode == 1) {
+            // (the gathers below are requested first: the wait for the token hides behind them only if they are in flight)
+        }
         double Hi[6], jc[12], jp[6], jc2[12], jp2[6];
 #pragma unroll
         for (int k2 = 0; k2 < 6; ++k2) Hi[k2] = a.Hinv6[(size_t)rc.z * 6 + k2];
@@ -733,6 +747,11 @@ __global__ __launch_bounds__(SCHUR_THREADS, GEN ? 2 : 4) void ba_schur_pairs_ker
             E[q * 3 + 2] = w0 * Hi[2] + w1 * Hi[4] + w2 * Hi[5];
         }
         double* blk = acc + (size_t)(sl & 0x3fffu) * SCHUR_BLK_LD;
+        if (mode == 1) {
+            const int want = trip * (SCHUR_THREADS / 64) + wv;
+            while (__hip_atomic_load(turn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != want) __builtin_amdgcn_s_sleep(1);
+        }
+        if (valid) {
         // The lanes of a wave walk the six columns of their blocks in ROTS different rotations (lane mod ROTS): the pairs of
         // one wave hit the same block again and again -- the cameras next to c share most of its landmarks: 25 of 64 lanes
         // share their block with an earlier lane, the busiest block of a wave has 7 -- and lanes that add to the SAME
@@ -756,6 +775,11 @@ __global__ __launch_bounds__(SCHUR_THREADS, GEN ? 2 : 4) void ba_schur_pairs_ker
 #pragma unroll
             for (int q = 0; q < 6; ++q)
                 unsafeAtomicAdd(&col[q * 6], -(E[q * 3] * w0 + E[q * 3 + 1] * w1 + E[q * 3 + 2] * w2));
+        }
+        }
+        if (mode == 1) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if ((tid & 63) == 0) __hip_atomic_store(turn, trip * (SCHUR_THREADS / 64) + wv + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
     if (diag_piece) {
@@ -1021,30 +1045,33 @@ int launch_schur_dense(const SchurDenseArgs& a, hipStream_t st) {
 }
 
 size_t schur_rows_lds_bytes(int max_cols) {
-    return ((size_t)max_cols * SCHUR_BLK_LD + 8 + 8 * SCHUR_CAM_LD) * sizeof(double) + ((size_t)2 * max_cols + 1) * sizeof(int) + 16;
+    return ((size_t)max_cols * SCHUR_BLK_LD + 8 + 8 * SCHUR_CAM_LD) * sizeof(double) + ((size_t)2 * max_cols + 2) * sizeof(int) + 16;
+}
+
+// (GEN: host-linearised factors, a.Jc12 -- the same kernel with the camera block read from its own array)
+template <bool GEN, int MODE>
+static int launch_schur_inst(const SchurArgs& a, int n_tasks, size_t lds, hipStream_t st) {
+    // the largest task the engine ever builds (SCHUR_MAX_SLOTS accumulator slots) fixes the LDS limit, once per device
+    static DeviceOnce attr;
+    STBA_TRY(attr.run([]() -> int {
+        STBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_schur_pairs_kernel<SCHUR_ROTS, GEN, MODE>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)schur_rows_lds_bytes(SCHUR_MAX_SLOTS)));
+        return STBA_OK;
+    }));
+    hipLaunchKernelGGL((ba_schur_pairs_kernel<SCHUR_ROTS, GEN, MODE>), dim3(n_tasks), dim3(SCHUR_THREADS), lds, st, a);
+    return STBA_OK;
 }
 
 int launch_schur_rows(const SchurArgs& a, int n_tasks, hipStream_t st) {
     if (n_tasks <= 0) return STBA_OK;
     const size_t lds = schur_rows_lds_bytes(a.max_cols);
-    // the largest slice the engine ever builds (SCHUR_SPLIT_COLS blocks) fixes the limit, once per device
-    static DeviceOnce attr;
-    STBA_TRY(attr.run([]() -> int {
-        STBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_schur_pairs_kernel<SCHUR_ROTS>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)schur_rows_lds_bytes(SCHUR_MAX_SLOTS)));
-        return STBA_OK;
-    }));
     // (column rotations measured at C5: 1 / 2 / 3 / 6 -> 0.283 / 0.268 / 0.264 / 0.266 ms)
-    if (a.Jc12) {       // host-linearised factors: the same kernel with the camera block read from its own array
-        static DeviceOnce attr_gen;
-        STBA_TRY(attr_gen.run([]() -> int {
-            STBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_schur_pairs_kernel<SCHUR_ROTS, true>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)schur_rows_lds_bytes(SCHUR_MAX_SLOTS)));
-            return STBA_OK;
-        }));
-        hipLaunchKernelGGL((ba_schur_pairs_kernel<SCHUR_ROTS, true>), dim3(n_tasks), dim3(SCHUR_THREADS), lds, st, a);
-    } else
-    hipLaunchKernelGGL(ba_schur_pairs_kernel<SCHUR_ROTS>, dim3(n_tasks), dim3(SCHUR_THREADS), lds, st, a);
+#ifdef STBA_DEBUG_KNOBS
+    if (a.mode == 1) STBA_TRY(a.Jc12 ? (launch_schur_inst<true, 1>(a, n_tasks, lds, st)) : (launch_schur_inst<false, 1>(a, n_tasks, lds, st)));
+    else if (a.mode == 2) STBA_TRY(a.Jc12 ? (launch_schur_inst<true, 2>(a, n_tasks, lds, st)) : (launch_schur_inst<false, 2>(a, n_tasks, lds, st)));
+    else
+#endif
+    STBA_TRY(a.Jc12 ? (launch_schur_inst<true, 0>(a, n_tasks, lds, st)) : (launch_schur_inst<false, 0>(a, n_tasks, lds, st)));
     STBA_HIP(hipGetLastError());
     return STBA_OK;
 }

@@ -50,6 +50,7 @@ int launch_point_invert(int n_pts, const double* Hpp6, const double* dp, const u
 // Schur complement of the landmark blocks, row-wise with LDS accumulation (plan built on the host at create time:
 // stba_ba_create).  SCHUR_SPLIT_COLS: non-zero blocks one task accumulates in LDS (two workgroups per CU);
 // SCHUR_TASK_PAIRS: most (i, l) observation pairs per task (unlimited: smaller tasks measured slower).
+constexpr int SCHUR_PLAN_DEFAULT = 3;                       // SchurArgs::mode of the product build
 constexpr int SCHUR_MAX_SLOTS = 256;                        // LDS accumulator slots of a task: two workgroups of 81.5 KB per CU
 constexpr int SCHUR_SPLIT_COLS = SCHUR_MAX_SLOTS - 8;       // blocks per task; a heavy block takes up to one extra slot per wave (parts)
 constexpr int SCHUR_TASK_PAIRS = 1 << 30;
@@ -74,6 +75,7 @@ struct SchurArgs {
     // every (observation i of the row's camera, observation l of the same landmark with camera(l) <= camera(i)) of the
     // slice, with the LDS slot of its 6x6 block resolved on the host
     const int* pair_begin; const int* pair_end;      // per (task, wave): every block is accumulated by one wave (bitwise reproducible)
+    int mode = 0;                                    // 0: per-wave lists (slots dealt to waves) | 1: one list, waves add in turn (token) | 2: one list, arrival order
     const int* task_vs_ptr; const int* vs_first;     // per task: [blocks + 1] first accumulator slot of every block of the slice
     const int* obs_pt;                               // landmark of every observation
     const int4* pair_rec;                            // (i, l, landmark, slot | 0x8000 if diagonal block), l != i

@@ -95,6 +95,7 @@ struct stba_ba {
     // pair plan of the Schur kernel (see ba_schur_pairs_kernel)
     int *pair_begin = nullptr, *pair_end = nullptr;      // per (task, wave)
     int *task_vs_ptr = nullptr, *vs_first = nullptr;     // per task: first accumulator slot of every block of its slice (+ the slot count)
+    int schur_plan_mode = 0;                              // SchurArgs::mode the plan was built for
     int4* pair_rec = nullptr;           // (i, l, landmark, slot | flags)
     double schur_pairs = 0.0, schur_lds_atomics = 0.0;   // per launch of the Schur kernel (measurement)
     // the Schur complement as a dense symmetric product (dense visibility; ba_kernels.hip "DENSE visibility", stba_ba_set_schur_mode)
@@ -397,7 +398,7 @@ static int ba_schur_step(stba_ba* b) {
     sa.J8 = b->J8; sa.omask = b->omask; sa.Jc12 = b->hl_fn ? b->Jc12 : nullptr; sa.r = b->r; sa.Hinv6 = b->Hinv6; sa.gp = b->gp;
     sa.S = b->S(); sa.lda = b->lda; sa.rhs = b->rhs(); sa.Hcc = b->Hcc; sa.gc = b->gc;
     sa.obs_pt = b->obs_pt; sa.pair_begin = b->pair_begin; sa.pair_end = b->pair_end; sa.pair_rec = b->pair_rec;
-    sa.task_vs_ptr = b->task_vs_ptr; sa.vs_first = b->vs_first;
+    sa.task_vs_ptr = b->task_vs_ptr; sa.vs_first = b->vs_first; sa.mode = b->schur_plan_mode;
     return launch_schur_rows(sa, b->n_tasks, b->st);
 }
 
@@ -1166,6 +1167,11 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
     // most of the pairs, exactly the pairs of the landmarks of its range in the old order: the same coalescing and the same mix of
     // blocks per instruction as before.  Light blocks (one part) are dealt to the least loaded wave.
     constexpr int NW = SCHUR_THREADS / 64;
+    // (debug builds: STBA_SCHUR_PLAN = 1: one list per task, the waves add in turn (token); 2: one list, arrival order -- the round-4 kernel)
+    const int plan_knob = std::min(3, std::max(0, knob_int("STBA_SCHUR_PLAN", SCHUR_PLAN_DEFAULT)));
+    const bool plan_stripes = plan_knob == 3;
+    const int plan_mode = plan_stripes ? 0 : plan_knob;
+    b->schur_plan_mode = plan_mode;
     std::vector<int> pair_begin, pair_end, task_vs_ptr, vs_first;
     std::vector<int4> pair_rec;
     int max_slots = 0;
@@ -1203,7 +1209,9 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
                     for (int p = p0; p < p1; ++p) {
                         const int i = cam_perm[p];
                         const int j = s_pt[i];
-                        const int w = total > 0 ? (int)std::min<size_t>(NW - 1, before * NW / total) : 0;
+                        // (plan 3: STRIPES -- the list dealt to the waves in runs of ~64 pairs, round robin, so that at any moment the eight
+                        // waves work side by side in one stretch of the list as they did with the shared list)
+                        const int w = plan_stripes ? (int)((before / 64) % NW) : total > 0 ? (int)std::min<size_t>(NW - 1, before * NW / total) : 0;
                         range_of[(size_t)(p - p0)] = (unsigned char)w;
                         for (int l = pt_start[j]; l < pt_start[j + 1]; ++l) {
                             const int c2 = s_cam[l];
@@ -1215,17 +1223,24 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
                         }
                     }
                 }
-                // ---- parts per block: 8 / 4 / 2 / 1 by pair count; the threshold doubles until the slots fit the LDS accumulator
+                // ---- parts per block.  A pair whose block has one part is handled by the block's wave whatever landmark it belongs to: its
+                // own record and inverse landmark block are then requested by a lane of their own instead of by the handful of neighbouring
+                // lanes that hold the same landmark's other pairs (~25 instead of ~12 cache lines per gather instruction).  With P parts the
+                // share of such FOREIGN pairs of a block of m pairs is 1 - P / 8, so every accumulator slot spent on a block makes m / 8 of
+                // its pairs local, whatever P: the blocks are upgraded heaviest first, to eight parts each, while slots last.
                 nparts.assign((size_t)ncols, 1);
-                int nvs = 0;
-                for (int thr = 24;; thr *= 2) {
-                    nvs = 0;
-                    for (int q = 0; q < ncols; ++q) {
-                        const int np_ = bc[q] >= 8 * thr ? 8 : bc[q] >= 4 * thr ? 4 : bc[q] >= 2 * thr ? 2 : 1;
+                int nvs = ncols;
+                if (plan_mode == 0) {
+                    order.resize((size_t)ncols);
+                    for (int q = 0; q < ncols; ++q) order[(size_t)q] = q;
+                    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return bc[x] > bc[y]; });
+                    for (int q : order) {
+                        if (bc[q] < 16) break;                              // (nothing to gain below a couple of pairs per wave)
+                        const int np_ = (SCHUR_MAX_SLOTS - nvs >= 7) ? 8 : (SCHUR_MAX_SLOTS - nvs >= 3) ? 4 : (SCHUR_MAX_SLOTS - nvs >= 1) ? 2 : 1;
+                        if (np_ == 1) break;
                         nparts[(size_t)q] = np_;
-                        nvs += np_;
+                        nvs += np_ - 1;
                     }
-                    if (nvs <= SCHUR_MAX_SLOTS || thr > (1 << 28)) break;
                 }
                 nvs = 0;
                 for (int q = 0; q < ncols; ++q) { vsf[q] = nvs; nvs += nparts[(size_t)q]; }
@@ -1244,6 +1259,7 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
                         for (int w = part * span; w < (part + 1) * span; ++w) pc += (size_t)cntR[(size_t)q * NW + w];
                         int best = part * span;
                         for (int w = part * span + 1; w < (part + 1) * span; ++w) if (load[w] < load[best]) best = w;
+                        if (plan_mode != 0) best = 0;       // one list per task (the kernel's modes 1 and 2): everything in wave 0's range of the table
                         wave_of[(size_t)(vsf[q] + part)] = best;
                         load[best] += pc;
                     }

@@ -37,7 +37,7 @@ for r in range(rounds):
     for l in libs:
         p = run(CHILD % (ROOT, n, n), l)
         x = [y for y in p.stdout.splitlines() if y.startswith("RESULT")]
-        if x: res[l].append(float(x[0].split()[1]))
+        if x: res[l].append((float(x[0].split()[1]), float(x[0].split()[2])))
 for l in libs:
-    v = np.array(res[l])
-    print(f"{l:20s} median {np.median(v):.4f} min {v.min():.4f} max {v.max():.4f} ms ({len(v)} runs)", flush=True)
+    v = np.array([r[0] for r in res[l]]); w = np.array([r[1] for r in res[l]])
+    print(f"{l:20s} factor median {np.median(v):.4f} min {v.min():.4f} max {v.max():.4f} ms | backward median {np.median(w):.4f} | sum {np.median(v + w):.4f} ({len(v)} runs)", flush=True)
