@@ -1170,6 +1170,7 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
     // (debug builds: STBA_SCHUR_PLAN = 1: one list per task, the waves add in turn (token); 2: one list, arrival order -- the round-4 kernel)
     const int plan_knob = std::min(3, std::max(0, knob_int("STBA_SCHUR_PLAN", SCHUR_PLAN_DEFAULT)));
     const bool plan_stripes = plan_knob == 3;
+    const bool plan_runs = knob_int("STBA_SCHUR_RUNS", 1) != 0;
     const int plan_mode = plan_stripes ? 0 : plan_knob;
     b->schur_plan_mode = plan_mode;
     std::vector<int> pair_begin, pair_end, task_vs_ptr, vs_first;
@@ -1254,6 +1255,7 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
                 wave_of.assign((size_t)nvs, 0);
                 for (int q : order) {
                     const int np_ = nparts[(size_t)q], span = NW / np_;
+                    if (np_ == 1 && plan_mode == 0 && plan_runs) continue;        // (light blocks: in column runs, below)
                     for (int part = 0; part < np_; ++part) {
                         size_t pc = 0;
                         for (int w = part * span; w < (part + 1) * span; ++w) pc += (size_t)cntR[(size_t)q * NW + w];
@@ -1262,6 +1264,19 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
                         if (plan_mode != 0) best = 0;       // one list per task (the kernel's modes 1 and 2): everything in wave 0's range of the table
                         wave_of[(size_t)(vsf[q] + part)] = best;
                         load[best] += pc;
+                    }
+                }
+                if (plan_mode == 0 && plan_runs) {
+                    // Light blocks (one part) in RUNS of consecutive columns: the cameras next to each other in the column list see the same
+                    // landmarks, so a landmark's pairs in light blocks mostly fall to one wave, side by side in its list -- and share the
+                    // requests for the landmark's own record and inverse block again.  The runs fill the waves up to an equal share.
+                    const size_t target = (total + NW - 1) / NW;
+                    int cw = 0;
+                    for (int q = 0; q < ncols; ++q) {
+                        if (nparts[(size_t)q] != 1) continue;
+                        while (cw < NW - 1 && load[cw] >= target) ++cw;
+                        wave_of[(size_t)vsf[q]] = cw;
+                        load[cw] += (size_t)bc[q];
                     }
                 }
                 size_t wpos[NW];

@@ -10,8 +10,8 @@ s = bench.load_scene(A, 0)
 rng = np.random.default_rng(1)
 dc = rng.uniform(0.01, 0.1, (1000, 6)); dp = rng.uniform(0.01, 0.1, (len(s["pts0"]), 3))
 ref = None
-for mode in (2, 0, 3, 2, 0, 3):
-    os.environ["STBA_SCHUR_PLAN"] = str(mode)
+for mode, runs in ((2, 1), (3, 0), (3, 1), (2, 1), (3, 0), (3, 1)):
+    os.environ["STBA_SCHUR_PLAN"] = str(mode); os.environ["STBA_SCHUR_RUNS"] = str(runs)
     eng = st.BAEngine(s["cams0"], s["pts0"], s["obs_cam"], s["obs_pt"], s["obs_feat"], s["cam_fixed"])
     eng.evaluate(jac=False); eng.normal_blocks()
     S0, r0 = eng.reduced_system(dc, dp)
@@ -23,5 +23,5 @@ for mode in (2, 0, 3, 2, 0, 3):
     dev = np.abs(np.tril(S0) - ref).max() / np.abs(ref).max()
     eng.lm_iterations(2)
     ms, atomics, pairs = eng.time_schur(20)
-    print(f"mode {mode}: schur {ms:.4f} ms  reproducible {same}  max rel dev from the first form {dev:.2e}", flush=True)
+    print(f"mode {mode} runs {runs}: schur {ms:.4f} ms  reproducible {same}  max rel dev from the first form {dev:.2e}", flush=True)
     eng.close()
