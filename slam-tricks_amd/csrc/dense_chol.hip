@@ -1779,6 +1779,7 @@ static void mega_build_tasks(int nblk, const MegaMachine& mach, std::vector<int4
     // priority boosts for those rows, an urgent list per XCD claimed by whichever workgroup is free (a parked workgroup
     // starts a critical task the moment its last flag flips; a claimed task pays 2-5 us per hand-over), the last update of
     // a tile fused into the panel solve that consumes it.  DESIGN.md 4 has the numbers.
+    static const double ADV_D = knob_double("STBA_MEGA_ADV_D", 0.0), ADV_TU = knob_double("STBA_MEGA_ADV_TU", 0.0);
     typedef std::pair<double, int> PI;
     typedef std::priority_queue<PI, std::vector<PI>, std::greater<PI>> Heap;
     std::vector<Heap> ready_h((size_t)nl);
@@ -1800,7 +1801,12 @@ static void mega_build_tasks(int nblk, const MegaMachine& mach, std::vector<int4
                 const int k = hb.top().second;
                 hb.pop();
                 Node& nd = nodes[(size_t)k];
-                order[(size_t)l].push_back({idl.back(), now, k});
+                // (ADVANCE: the tickets of the critical hand-off -- D and TU -- are moved up in their list by so many microseconds of model
+                // time, so that a workgroup is already parked on them when their last input arrives instead of reaching them a 42 us
+                // update task later; a parked workgroup idles, which is cheap: at most five tickets per panel and list)
+                const int ty = nd.tk.x & 0xff;
+                const double adv = ty == TASK_D ? ADV_D : ty == TASK_TU ? ADV_TU : 0.0;
+                order[(size_t)l].push_back({idl.back() - adv, now, k});
                 idl.pop_back();
                 nd.start = now;
                 events.push(PI(now + nd.dur, k));
