@@ -722,9 +722,11 @@ __global__ __launch_bounds__(SCHUR_THREADS, GEN ? 2 : 4) void ba_schur_pairs_ker
     // (the pair record runs one trip ahead: one dependent memory round trip less per trip)
     int k = kb + (mode == 0 ? (tid & 63) : tid);
     int4 rn = (k < ke) ? a.pair_rec[k] : make_int4(0, 0, 0, 0);
-    for (int trip = 0; trip < ntrips; ++trip, k += stride) {
+    // (mode 0: every lane leaves when ITS share of the wave's list is done, as in the round-4 loop; the shared-list modes run a common
+    // trip count -- the token must pass through every wave)
+    for (int trip = 0; mode == 0 ? (k < ke) : (trip < ntrips); ++trip, k += stride) {
         const int4 rc = rn;
-        const bool valid = k < ke;
+        const bool valid = mode == 0 ? true : (k < ke);
         if (k + stride < ke) rn = a.pair_rec[k + stride];
         if (mode == 1) {
             // (the gathers below are requested first: the wait for the token hides behind them only if they are in flight)
