@@ -1118,9 +1118,20 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
                 }
             }
         });
+        // FEW camera rows (round 5; the landmark-heavy scenes, e.g. 100 cameras x 1 000 000 landmarks): a task per row leaves most of the
+        // 512 workgroup slots empty, so every row is cut into TWO slices of about equal pair count -- measured on 100 x 1 000 000
+        // (45 M pairs): one slice per row 10.8 ms, two 4.7, three 5.8, four 6.9 (every further slice walks the camera's observation
+        // list once more and finds fewer of a landmark's pairs side by side)
+        const bool two_slices = n_cams <= 256 && total_pairs > ((size_t)1 << 22) && TASK_PAIRS == SCHUR_TASK_PAIRS;
         for (int c = 0; c < n_cams; ++c) {
             const std::vector<int>& tmp = cols_of[(size_t)c];
             const std::vector<int>& cnt = cnt_of[(size_t)c];
+            size_t row_cap = (size_t)TASK_PAIRS;
+            if (two_slices) {
+                size_t rp = 0;
+                for (int v : cnt) rp += (size_t)v;
+                row_cap = std::max<size_t>((size_t)1 << 18, rp / 2 + 1);       // (2^18 measured best where a row holds 450 k pairs: 4.7 ms, balanced halves 5.5)
+            }
             row_cols.insert(row_cols.end(), tmp.begin(), tmp.end());
             row_col_ptr[c + 1] = (int)row_cols.size();
             const int ncols_c = (int)tmp.size();
@@ -1130,7 +1141,7 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
                 // close the slice in front of column q when it is full, and at the end of the row (a camera without
                 // observations still gets one empty task: it zeroes its rows and writes its zero camera block)
                 const bool end = q == ncols_c;
-                const bool full = !end && q > lo && (acc + (size_t)cnt[(size_t)q] > (size_t)TASK_PAIRS || q - lo >= SCHUR_SPLIT_COLS);
+                const bool full = !end && q > lo && (acc + (size_t)cnt[(size_t)q] > row_cap || q - lo >= SCHUR_SPLIT_COLS);
                 if (full || end) {
                     task_cam.push_back(c); task_col_lo.push_back(lo); task_col_hi.push_back(q); task_pairs.push_back(acc);
                     task_max_cols = std::max(task_max_cols, q - lo);
