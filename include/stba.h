@@ -359,6 +359,8 @@ typedef struct {
     int    coarse_dim;                  /* unknowns of the coarse space (0: none) */
     int    coarse_refreshes;            /* coarse operators inverted */
     double last_eta;                    /* forcing term of the last solve */
+    int    coarse_failures;             /* coarse operators whose factorisation met a non-positive pivot: the coarse correction was
+                                         * switched off (block Jacobi alone) until the next refresh (stba_version() >= 5) */
 } stba_pcg_summary;
 int stba_pg_create(stba_pg** out, int n_nodes, int n_edges, const double* poses, const int* edge_i, const int* edge_j,
                    const double* meas, const unsigned char* node_fixed, void* hip_stream);

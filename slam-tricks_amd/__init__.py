@@ -330,7 +330,8 @@ class PCGOptions(C.Structure):
 
 class PCGSummary(C.Structure):
     _fields_ = [("iterations_total", C.c_int), ("solves", C.c_int), ("hit_cap", C.c_int), ("max_iterations_in_a_solve", C.c_int),
-                ("coarse_dim", C.c_int), ("coarse_refreshes", C.c_int), ("last_eta", C.c_double)]
+                ("coarse_dim", C.c_int), ("coarse_refreshes", C.c_int), ("last_eta", C.c_double),
+                ("coarse_failures", C.c_int)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

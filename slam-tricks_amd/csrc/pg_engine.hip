@@ -608,13 +608,19 @@ __global__ __launch_bounds__(256) void pg_coarse_assemble_kernel(int nc, int np,
     W[r * ldw + c] = v;
 }
 
-// Ainv = -(lower right block of W), symmetric, full
-__global__ __launch_bounds__(256) void pg_coarse_finish_kernel(int nc, int np, const double* __restrict__ W, double* __restrict__ Ainv) {
+// Ainv = -(lower right block of W), symmetric, full.  cflag: the pivot flag of the partial factorisation that made W -- a non-positive
+// pivot (or a NaN) in P^T (J^T J + D) P leaves garbage there: the coarse correction is then switched OFF for this operator (Ainv = 0:
+// z = z0, block Jacobi alone, still a symmetric positive definite preconditioner) and counted (stba_pcg_summary::coarse_failures),
+// instead of sending the PCG into NaNs and the LM step into a rejection nobody can explain.
+__global__ __launch_bounds__(256) void pg_coarse_finish_kernel(int nc, int np, const double* __restrict__ W, double* __restrict__ Ainv,
+                                                               const int* __restrict__ cflag, int* __restrict__ fail_count) {
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const bool bad = cflag[0] != 0;
+    if (idx == 0 && bad) atomicAdd(fail_count, 1);
     if (idx >= (size_t)nc * nc) return;
     const int r = (int)(idx / nc), c = (int)(idx % nc);
     const int hi = max(r, c), lo = min(r, c);
-    Ainv[idx] = -W[((size_t)np + hi) * (2 * (size_t)np) + np + lo];
+    Ainv[idx] = bad ? 0.0 : -W[((size_t)np + hi) * (2 * (size_t)np) + np + lo];
 }
 
 // restriction of a workgroup's 128 nodes: w[node][u] = (P_node^T r_node)[u] sits in LDS; the groups that END in this
@@ -968,7 +974,7 @@ struct stba_pg {
     int* end_node = nullptr;                             // owner node of every edge end of the CSR
     double *AdP = nullptr, *Ac0 = nullptr, *W = nullptr, *Ainv = nullptr, *inv_work = nullptr, *rc_part = nullptr, *zc = nullptr,
            *part_cz = nullptr, *part_u = nullptr, *scal_dev = nullptr, *contrib = nullptr, *Dc = nullptr;
-    int* cflag = nullptr;
+    int* cflag = nullptr;            // [0]: pivot flag of the coarse factorisation, [1]: coarse operators that failed (this solve)
     PcgState* state = nullptr;
     PcgExport *exp_host = nullptr, *exp_dev = nullptr;   // mapped
     double *fin_host = nullptr, *fin_dev = nullptr;      // mapped: trial / linearisation scalars + sequence number
@@ -1131,7 +1137,7 @@ int stba_pg_create(stba_pg** out, int n_nodes, int n_edges, const double* poses,
     A_(dalloc(&g->node_start, n + 1)); A_(dalloc(&g->end_code, 2 * m)); A_(dalloc(&g->u, 12 * m));
     A_(dalloc(&g->end_node, 2 * m)); A_(dalloc(&g->contrib, 2 * m * 28));
     g->nb_nodes4 = (n_nodes + PG_NPW - 1) / PG_NPW;
-    A_(dalloc(&g->part_u, (size_t)g->nb_nodes * 4 + 4)); A_(dalloc(&g->scal_dev, 16)); A_(dalloc(&g->state, 1)); A_(dalloc(&g->cflag, 1));
+    A_(dalloc(&g->part_u, (size_t)g->nb_nodes * 4 + 4)); A_(dalloc(&g->scal_dev, 16)); A_(dalloc(&g->state, 1)); A_(dalloc(&g->cflag, 2));
     if (hipHostMalloc(reinterpret_cast<void**>(&g->exp_host), sizeof(PcgExport), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
         hipHostGetDevicePointer(reinterpret_cast<void**>(&g->exp_dev), g->exp_host, 0) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void**>(&g->fin_host), 16 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
@@ -1255,6 +1261,7 @@ int stba_pg_solve(stba_pg* g, const stba_lm_options* opt_in, const stba_pcg_opti
     const int N = 6 * g->n;
     STBA_TRY(pg_setup_coarse(g, pcg.coarse_group));
     const bool coarse = g->agg > 0;
+    if (coarse) STBA_HIP(hipMemsetAsync(g->cflag + 1, 0, sizeof(int), g->st));      // this solve's count of failed coarse operators
     const bool multi = (g->ar != nullptr);
     const int chunk = std::max(1, pcg.check_every);
     const bool forcing = pcg.forcing_eta0 > 0.0;
@@ -1323,7 +1330,8 @@ int stba_pg_solve(stba_pg* g, const stba_lm_options* opt_in, const stba_pcg_opti
             hipLaunchKernelGGL(pg_coarse_dc_kernel, dim3(g->na), dim3(256), 0, g->st, g->n, g->agg, g->AdP, g->d, g->Dc);
             hipLaunchKernelGGL(pg_coarse_assemble_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, g->st, g->nc, g->np, g->Ac0, g->Dc, g->W);
             STBA_TRY(chol_spd_inverse_dev(g->W, 2 * g->np, g->np, g->nc, g->cflag, g->inv_work, g->st));
-            hipLaunchKernelGGL(pg_coarse_finish_kernel, dim3((unsigned)(((size_t)g->nc * g->nc + 255) / 256)), dim3(256), 0, g->st, g->nc, g->np, g->W, g->Ainv);
+            hipLaunchKernelGGL(pg_coarse_finish_kernel, dim3((unsigned)(((size_t)g->nc * g->nc + 255) / 256)), dim3(256), 0, g->st, g->nc, g->np, g->W, g->Ainv,
+                               g->cflag, g->cflag + 1);
             g->coarse_valid = true;
             since_refresh = 0;
             ++ps.coarse_refreshes;
@@ -1459,6 +1467,11 @@ int stba_pg_solve(stba_pg* g, const stba_lm_options* opt_in, const stba_pcg_opti
     s.seconds_total = wall() - t0;
     if (summary) *summary = s;
     if (pcg_iterations_total) *pcg_iterations_total = ps.iterations_total;
+    if (coarse) {        // (how many coarse operators could not be factored: counted on the device, read once per solve)
+        int cf = 0;
+        if (hipMemcpyAsync(&cf, g->cflag + 1, sizeof(int), hipMemcpyDeviceToHost, g->st) == hipSuccess && hipStreamSynchronize(g->st) == hipSuccess)
+            ps.coarse_failures = cf;
+    }
     g->last_pcg = ps;
     return STBA_OK;
 }

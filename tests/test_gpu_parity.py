@@ -833,3 +833,26 @@ def test_function_tolerance_switch_follows_the_oracle(st, O, scenes):
     assert abs(s0.final_cost - so.final_cost) <= 1e-9 * so.final_cost and s0.final_cost >= s1.final_cost
     dq, dt = pose_err(e0.get_params()[0], o0.cams)
     assert dq < 1e-8 and dt < 1e-8
+
+
+@pytest.mark.gpu
+def test_few_camera_rows_cut_into_two_slices_match_the_oracle(st, O, scenes):
+    """40 cameras x 100 000 landmarks (5 M observation pairs on 40 camera rows): every row's Schur task is cut into two slices (round 5:
+    a task per row left most workgroup slots empty) -- reduced system against the oracle, bitwise reproducible, and the LM trace"""
+    s = scenes.st20_scene(n_cams=40, n_pts=100000, max_obs_per_pt=10, seed=5, pix_noise=1e-3, retriangulate=False)
+    e, o = engine(st, s), oracle(O, s)
+    assert e.schur_mode() == e.SCHUR_PAIRS
+    e.evaluate(); e.normal_blocks()
+    _, ro, Jco, Jpo = o.evaluate()
+    rng = np.random.default_rng(8)
+    dc = rng.uniform(0.01, 0.1, (e.nc, 6)); dp = rng.uniform(0.01, 0.1, (e.np_, 3))
+    S1, rhs1 = e.reduced_system(dc, dp)
+    So, rhso = o.reduced_system(ro, Jco, Jpo, dc, dp)
+    scale = np.abs(So).max()
+    assert np.abs(np.tril(S1) - np.tril(So)).max() < 1e-10 * scale
+    assert np.abs(rhs1 - rhso).max() < 1e-10 * max(1.0, np.abs(rhso).max())
+    S2, rhs2 = e.reduced_system(dc, dp)
+    assert np.array_equal(np.tril(S2), np.tril(S1)) and np.array_equal(rhs2, rhs1)
+    summ, tr = e.lm_iterations(3)
+    so, tro = o.solve(fixed_iterations=3, num_threads=16)
+    assert np.allclose(tr[:, 0], tro[:, 0], rtol=1e-8) and np.array_equal(tr[:, 6], tro[:, 6])

@@ -129,6 +129,7 @@ def test_pg_config_c4_full_size(st, O, c4):
     assert abs(ate1 - gold["ate_final"]) <= 1e-3 * gold["ate_final"] and ate1 < 0.05 * gold["ate_initial"]
     ps = e.pcg_summary()
     assert ps.hit_cap == 0 and ps.iterations_total <= 100 * summ.num_iterations and ps.coarse_dim == 942
+    assert ps.coarse_failures == 0 and ps.coarse_refreshes >= summ.num_iterations      # every coarse operator factored (the flag is read now)
     # residual at the solution agrees with the oracle's evaluation of the same poses
     o = O.PG(poses, s["edge_i"], s["edge_j"], s["meas"], s["node_fixed"])
     assert abs(o.evaluate(jac=False)[0] - summ.final_cost) <= 1e-9 * summ.final_cost
