@@ -1119,19 +1119,17 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
             }
         });
         // FEW camera rows (round 5; the landmark-heavy scenes, e.g. 100 cameras x 1 000 000 landmarks): a task per row leaves most of the
-        // 512 workgroup slots empty, so every row is cut into TWO slices of about equal pair count -- measured on 100 x 1 000 000
+        // 512 workgroup slots empty, so the rows are cut into slices by pair count, about two per row -- measured on 100 x 1 000 000
         // (45 M pairs): one slice per row 10.8 ms, two 4.7, three 5.8, four 6.9 (every further slice walks the camera's observation
-        // list once more and finds fewer of a landmark's pairs side by side)
-        const bool two_slices = n_cams <= 256 && total_pairs > ((size_t)1 << 22) && TASK_PAIRS == SCHUR_TASK_PAIRS;
+        // list once more and finds fewer of a landmark's pairs side by side); on one eighth of it 1.30 / 0.48 / 0.56 ms
+        const bool two_slices = n_cams <= 256 && total_pairs > ((size_t)1 << 20) && TASK_PAIRS == SCHUR_TASK_PAIRS;
         for (int c = 0; c < n_cams; ++c) {
             const std::vector<int>& tmp = cols_of[(size_t)c];
             const std::vector<int>& cnt = cnt_of[(size_t)c];
-            size_t row_cap = (size_t)TASK_PAIRS;
-            if (two_slices) {
-                size_t rp = 0;
-                for (int v : cnt) rp += (size_t)v;
-                row_cap = std::max<size_t>((size_t)1 << 18, rp / 2 + 1);       // (2^18 measured best where a row holds 450 k pairs: 4.7 ms, balanced halves 5.5)
-            }
+            // (ONE cap for all rows, 0.58 of the mean pairs per row: most rows fall into two slices, a heavy row into three, and no task is
+            // longer than the cap -- the kernel ends with its longest task.  450 k pairs per row: 4.7 ms against 5.5 for equal halves of
+            // every row and 6.5 for 58 / 42 of every row; 56 k per row -- one rank's share at eight ranks -- 0.48 ms against 1.30 uncut)
+            const size_t row_cap = two_slices ? std::max<size_t>(4096, (size_t)(0.58 * (double)total_pairs / (double)n_cams) + 1) : (size_t)TASK_PAIRS;
             row_cols.insert(row_cols.end(), tmp.begin(), tmp.end());
             row_col_ptr[c + 1] = (int)row_cols.size();
             const int ncols_c = (int)tmp.size();
