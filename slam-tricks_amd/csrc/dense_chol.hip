@@ -1607,6 +1607,7 @@ static void mega_build_tasks(int nblk, const MegaMachine& mach, std::vector<int4
     double DUR_K = 18.0;           // one more panel (K += 128) inside a batched trailing update (measured: 24 us for one panel, 42 for two)
     static const int BATCH_KNOB = knob_int("STBA_MEGA_BATCH", 0);
     const int BATCH = BATCH_KNOB > 0 ? std::min(64, BATCH_KNOB) : mega_default_batch(nblk);
+    static const int FAR = std::max(0, knob_int("STBA_MEGA_FAR", 0));
     static const int BLAG = std::max(0, knob_int("STBA_MEGA_BLAG", 2));      // (round 3, with the shorter chain tasks: 3 -> 2: -0.02 ms; 1: the same; 0: +0.25 ms)
     if (const char* e = knob_str("STBA_MEGA_DUR")) sscanf(e, "%lf,%lf,%lf,%lf,%lf,%lf", &DUR[0], &DUR[1], &DUR[2], &DUR[3], &DUR[4], &DUR[5]);
     auto add = [&](int type, int b, int i, int j, double prio) {
@@ -1663,7 +1664,11 @@ static void mega_build_tasks(int nblk, const MegaMachine& mach, std::vector<int4
             // (the last BLAG panels before the final one stay single tasks: a long batch there would sit on the path to
             // the tile's panel solve)
             const int lim = j - 2 - BLAG;
-            const int b0 = (BATCH <= 1 || b > lim) ? b : (b / BATCH) * BATCH, last = (BATCH <= 1 || b > lim) ? b : std::min(b0 + BATCH - 1, lim);
+            // (FAR batches, debug knob STBA_MEGA_FAR = f > 0: a group of 2 BATCH panels whose last one is still more than f panels in front of
+            // column j goes in ONE pass -- longer tasks only where the chains are far away)
+            int BJ = BATCH;
+            if (FAR > 0 && BATCH > 1 && j - ((b / (2 * BATCH)) * 2 * BATCH + 2 * BATCH - 1) > FAR) BJ = 2 * BATCH;
+            const int b0 = (BJ <= 1 || b > lim) ? b : (b / BJ) * BJ, last = (BJ <= 1 || b > lim) ? b : std::min(b0 + BJ - 1, lim);
             if (b != last) continue;
             const int nb = b - b0 + 1;
             for (int i = j; i < NBK; ++i) {
