@@ -1,0 +1,105 @@
+"""Differential fuzz of the BA path against the oracle: seeded random SHAPES rather than the handful of fixed scenes of
+test_gpu_parity.py -- camera and landmark counts from 2 x 5 to 90 x 1200, ragged observation counts, narrow and wide fields of
+view (sparse and dense visibility), constant camera dofs, constant landmarks, a camera nobody observes through, repeated
+(camera, landmark) pairs.  Every case: residuals and Jacobians element by element, the normal blocks, the reduced system in
+BOTH forms of the Schur complement, and the whole LM solve (iteration count, cost trace) -- all against oracle/.  The scenes of
+the reference itself (sim_data.cpp:22-172) are one point of this space: 29 cameras, 600 landmarks, every landmark seen by the
+cameras whose frustum holds it."""
+import importlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CASES = 36
+BIG_CASES = 10
+
+
+@pytest.fixture(scope="module")
+def st():
+    mod = importlib.import_module("slam-tricks_amd")
+    assert mod.device_count() > 0, "GPU tests need a HIP device"
+    return mod
+
+
+def _case(scenes, k, big=False):
+    rng = np.random.default_rng((5000 if big else 1000) + k)
+    nc = int(rng.integers(100, 421)) if big else int(rng.integers(2, 91))
+    npt = int(rng.integers(500, 6001)) if big else int(rng.integers(5, 1201))
+    hw = float(rng.choice([0.6, 1.0, 1.5, 3.0]))
+    mo = None if (not big and rng.random() < 0.4) else int(rng.integers(2, max(3, min(nc, 40))))      # (big: always capped, the oracle is a CPU)
+    # (big cases: a rough start -- some of them make the LM loop reject steps -- and the persistent factorisation, n > 768)
+    noise = (float(rng.choice([0.05, 0.15, 0.3])), float(rng.choice([1.0, 3.0, 6.0]))) if big else (0.05, 1.0)
+    s = scenes.st20_scene(n_cams=nc, n_pts=npt, max_obs_per_pt=mo, seed=int(rng.integers(1, 10000)), pos_noise=noise[0], ang_noise_deg=noise[1],
+                          pix_noise=1e-3, half_w=hw, half_h=hw, retriangulate=False)
+    oc, op, of = s["obs_cam"].copy(), s["obs_pt"].copy(), s["obs_feat"].copy()
+    pts0 = s["pts0"].copy()
+    what = []
+    if rng.random() < 0.3 and nc > 3:                       # a camera that observes nothing
+        dead = int(rng.integers(1, nc - 1))
+        m = oc != dead
+        oc, op, of = oc[m], op[m], of[m]
+        what.append("dead camera")
+    if rng.random() < 0.3 and len(oc) > 20:                 # repeated (camera, landmark) pairs: stereo residuals on one pose block
+        extra = rng.choice(len(oc), max(1, len(oc) // 15), replace=False)
+        oc = np.concatenate([oc, oc[extra]])
+        op = np.concatenate([op, op[extra]])
+        of = np.concatenate([of, of[extra] + rng.normal(0, 1e-3, (len(extra), 2))])
+        what.append("repeated pairs")
+    order = np.argsort(op, kind="stable")                   # (the oracle wants landmark-major observations)
+    oc, op, of = oc[order].astype(np.int32), op[order].astype(np.int32), of[order]
+    cf = s["cam_fixed"].copy()
+    for _ in range(int(rng.integers(0, 5))):
+        cf[int(rng.integers(0, nc)), int(rng.integers(0, 6))] = 1
+    pf = None
+    if rng.random() < 0.4:
+        pf = (rng.random(len(pts0)) < 0.15).astype(np.uint8)
+        what.append("constant landmarks")
+    return dict(cams0=s["cams0"], pts0=pts0, obs_cam=oc, obs_pt=op, obs_feat=of, cam_fixed=cf, pt_fixed=pf, what=what, rng=rng)
+
+
+@pytest.mark.parametrize("k", [f"s{i}" for i in range(CASES)] + [f"b{i}" for i in range(BIG_CASES)])
+def test_random_shape_against_the_oracle(st, O, scenes, k):
+    c = _case(scenes, int(k[1:]), big=k[0] == "b")
+    if len(c["obs_cam"]) == 0:
+        pytest.skip("the frustum test left no observation")
+    args = (c["cams0"], c["pts0"], c["obs_cam"], c["obs_pt"], c["obs_feat"], c["cam_fixed"])
+    rng = c["rng"]
+    o = O.BA(*args, pt_fixed=c["pt_fixed"])
+    e = st.BAEngine(*args, pt_fixed=c["pt_fixed"])
+    cost, r, Jc, Jp = e.evaluate()
+    costo, ro, Jco, Jpo = o.evaluate()
+    assert abs(cost - costo) <= 1e-13 * max(1.0, costo)
+    for a, b in ((r, ro), (Jc, Jco), (Jp, Jpo)):
+        assert np.abs(a - b).max() <= 1e-12 * max(1.0, np.abs(b).max())
+    Hs = e.normal_blocks()
+    Hso = o.normal_blocks(ro, Jco, Jpo)
+    for a, b in zip(Hs, Hso):
+        assert np.abs(a - b).max() <= 1e-12 * max(1.0, np.abs(b).max())
+    dc = rng.uniform(0.01, 0.1, (e.nc, 6))
+    dp = rng.uniform(0.01, 0.1, (e.np_, 3))
+    So, rhso = o.reduced_system(ro, Jco, Jpo, dc, dp)
+    scale = max(1.0, np.abs(So).max())
+    for mode in (e.SCHUR_PAIRS, e.SCHUR_DENSE):
+        e.set_schur_mode(mode)
+        e.evaluate(); e.normal_blocks()
+        S, rhs = e.reduced_system(dc, dp)
+        assert np.abs(np.tril(S) - np.tril(So)).max() < 1e-10 * scale, (mode, c["what"])
+        assert np.abs(rhs - rhso).max() < 1e-10 * max(1.0, np.abs(rhso).max()), (mode, c["what"])
+        S2, rhs2 = e.reduced_system(dc, dp)
+        assert np.array_equal(np.tril(S2), np.tril(S)) and np.array_equal(rhs2, rhs)       # both forms are reproducible bit for bit
+    # the whole solve, both forms
+    so, to = o.solve()
+    for mode in (0, 2):        # (0: the engine picks the form itself; 2: the dense form whatever the visibility)
+        e2 = st.BAEngine(*args, pt_fixed=c["pt_fixed"])
+        if mode:
+            e2.set_schur_mode(mode)
+        s2, t2 = e2.solve()
+        assert s2.termination_type == so.termination_type and s2.num_iterations == so.num_iterations, (mode, c["what"])
+        assert np.allclose(t2[:, 0], to[:, 0], rtol=1e-7, atol=1e-13), (mode, c["what"])
+        cams, pts = e2.get_params()
+        co, po = o.cams, o.pts
+        assert np.abs(pts - po).max() < 1e-5 * max(1.0, np.abs(po).max())
+        dq = np.minimum(np.abs(cams[:, :4] - co[:, :4]).max(1), np.abs(cams[:, :4] + co[:, :4]).max(1)).max()
+        assert dq < 1e-5 and np.abs(cams[:, 4:] - co[:, 4:]).max() < 1e-5
