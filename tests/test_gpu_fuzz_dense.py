@@ -1,0 +1,94 @@
+"""Differential fuzz of the dense paths against the oracle: the callback-driven dense LM (st17-ceres' curve fit / PnP shape:
+solver.hpp:247-385 builds such problems) on random model families, sizes from 1 x 1 to 3000 x 40, with and without box bounds
+(ceres_bound.cpp:25-68) and a manifold Plus; and the calibration kernel + Gauss-Newton loop (calib.cpp:282-422) on random board
+and view counts."""
+import importlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def st():
+    mod = importlib.import_module("slam-tricks_amd")
+    assert mod.device_count() > 0
+    return mod
+
+
+def _problem(k):
+    rng = np.random.default_rng(9000 + k)
+    kind = ["linear", "exp", "poly", "rosenbrock", "circle"][k % 5]
+    if kind == "linear":                      # r = A p - b: one exact step, any shape (also more parameters than residuals)
+        m, n = int(rng.integers(1, 3001)), int(rng.integers(1, 41))
+        A, b = rng.normal(size=(m, n)), rng.normal(size=m)
+        return kind, (lambda p: (A @ p - b, A)), rng.normal(size=n), m, None
+    if kind == "exp":                         # y = a exp(b x) + c
+        m = int(rng.integers(3, 2001))
+        x = np.sort(rng.uniform(0, 2, m)); tr = np.array([rng.uniform(0.5, 3), rng.uniform(-1.5, 1.0), rng.uniform(-1, 1)])
+        y = tr[0] * np.exp(tr[1] * x) + tr[2] + rng.normal(0, 1e-2, m)
+
+        def res(p):
+            e = np.exp(p[1] * x)
+            return p[0] * e + p[2] - y, np.stack([e, p[0] * x * e, np.ones_like(x)], 1)
+        return kind, res, tr + rng.normal(0, 0.2, 3), m, (tr - 0.05, tr + 0.4)
+    if kind == "poly":                        # the reference's parabola generalised: degree d, Vandermonde Jacobian
+        m, d = int(rng.integers(5, 1501)), int(rng.integers(1, 9))
+        x = rng.uniform(-1, 1, m); V = np.stack([x ** i for i in range(d + 1)], 1); c = rng.normal(size=d + 1)
+        y = V @ c + rng.normal(0, 1e-3, m)
+        return kind, (lambda p: (V @ p - y, V)), np.zeros(d + 1), m, None
+    if kind == "rosenbrock":                  # chained Rosenbrock: curved valley, the LM loop rejects steps on the way
+        n = int(rng.integers(2, 13))
+
+        def res(p):
+            r = np.zeros(2 * (n - 1)); J = np.zeros((2 * (n - 1), n))
+            for i in range(n - 1):
+                r[2 * i] = 10.0 * (p[i + 1] - p[i] ** 2); J[2 * i, i] = -20.0 * p[i]; J[2 * i, i + 1] = 10.0
+                r[2 * i + 1] = 1.0 - p[i]; J[2 * i + 1, i] = -1.0
+            return r, J
+        return kind, res, rng.uniform(-1.5, 1.5, n), 2 * (n - 1), None
+    m = int(rng.integers(4, 801))             # circle fit: centre + radius from noisy points
+    t = rng.uniform(0, 2 * np.pi, m); c = rng.normal(size=2); R = rng.uniform(0.5, 3)
+    P = c + R * np.stack([np.cos(t), np.sin(t)], 1) + rng.normal(0, 1e-2, (m, 2))
+
+    def res(p):
+        d = P - p[:2]; nrm = np.linalg.norm(d, axis=1)
+        return nrm - p[2], np.concatenate([-d / nrm[:, None], -np.ones((m, 1))], 1)
+    return kind, res, np.array([c[0] + 0.3, c[1] - 0.2, R * 1.3]), m, (np.array([-10.0, -10.0, 0.1]), np.array([10.0, 10.0, R * 1.1]))
+
+
+@pytest.mark.parametrize("k", range(30))
+def test_random_dense_problem_follows_the_oracle(st, O, k):
+    kind, res, x0, m, bounds = _problem(k)
+    for lo, up in ((None, None),) + (((bounds[0], bounds[1]),) if bounds else ()):
+        x00 = x0 if lo is None else np.clip(x0, lo, up)
+        p, summ, tr = st.dense_solve(res, x00, m, lower=lo, upper=up, max_num_iterations=100)
+        po, so, tro = O.dense_lm(res, x00, m, lower=lo, upper=up, max_num_iterations=100)
+        assert summ.termination_type == so.termination_type and summ.num_iterations == so.num_iterations, kind
+        assert np.array_equal(tr[:, 6], tro[:, 6]), kind                       # the same steps accepted and rejected
+        # (1e-7: the candidate cost of a REJECTED step near a bound is where conditioning amplifies the last bit -- 2.5e-9 seen;
+        # accepted iterates agree to 1e-11)
+        assert np.allclose(tr[:, 0], tro[:, 0], rtol=1e-7, atol=1e-22), kind
+        assert np.allclose(p, po, rtol=1e-8, atol=1e-10), kind
+        if lo is not None:
+            assert np.all(p >= lo) and np.all(p <= up)
+
+
+@pytest.mark.parametrize("k", range(8))
+def test_random_calibration_shape_follows_the_oracle(st, O, scenes, k):
+    rng = np.random.default_rng(9500 + k)
+    nv, rows, cols = int(rng.integers(3, 33)), int(rng.integers(3, 13)), int(rng.integers(3, 15))
+    s = scenes.calib_scene(n_views=nv, rows=rows, cols=cols, seed=int(rng.integers(1, 1000)), pix_noise=float(rng.choice([0.0, 0.3, 1.0])))
+    params = np.concatenate([s["intr_true"] * (1 + 1e-3), s["xis_true"].reshape(-1) + 1e-3])
+    sse, e, Ji, Jx = st.calib_evaluate(params, s["obj"], s["img"])
+    sso, eo, Jio, Jxo = O.calib_evaluate(params, s["obj"], s["img"])
+    assert abs(sse - sso) <= 1e-12 * sso and np.abs(e - eo).max() < 1e-9
+    assert np.abs(Ji - Jio).max() <= 1e-11 * np.abs(Jio).max() and np.abs(Jx - Jxo).max() <= 1e-11 * np.abs(Jxo).max()
+    p0 = np.concatenate([s["intr_true"][:4] * (1 + 5e-3), np.zeros(5), s["xis_true"].reshape(-1)])
+    p, it, tr = st.calib_gauss_newton(p0, s["obj"], s["img"], 10)
+    po, ito, tro = O.calib_gauss_newton(p0, s["obj"], s["img"], 10)
+    assert it == ito
+    n = np.count_nonzero(~np.isnan(tro))
+    assert np.allclose(tr[:n], tro[:n], rtol=1e-8)
+    assert np.allclose(p[:4], po[:4], rtol=1e-9)
