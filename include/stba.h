@@ -95,6 +95,9 @@ typedef struct {
 
 void stba_lm_default_options(stba_lm_options* opt);
 
+/* STBA_FAILURE: the START point could not be evaluated -- a non-finite cost, i.e. a non-finite input or residual (Ceres: "Initial
+ * residual and Jacobian evaluation failed"; reason STBA_TERM_SOLVER_FAIL, zero iterations, parameters untouched) -- or a callback
+ * failed.  A non-finite cost at a TRIAL point is an unsuccessful step, as in Ceres: rejected, the radius shrinks, the solve goes on. */
 enum { STBA_CONVERGENCE = 0, STBA_NO_CONVERGENCE = 1, STBA_FAILURE = 2 };
 enum { STBA_TERM_NONE = 0, STBA_TERM_GRADIENT = 1, STBA_TERM_FUNCTION = 2, STBA_TERM_PARAMETER = 3,
        STBA_TERM_MAX_ITER = 4, STBA_TERM_MIN_RADIUS = 5, STBA_TERM_SOLVER_FAIL = 6,

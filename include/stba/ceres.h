@@ -646,6 +646,8 @@ inline void FillSummary(const stba_lm_summary& s, const std::vector<double>& tra
     out->num_successful_steps = s.num_successful_steps; out->num_unsuccessful_steps = s.num_unsuccessful_steps;
     out->termination_type = s.termination_type == STBA_CONVERGENCE ? CONVERGENCE
                             : s.termination_type == STBA_NO_CONVERGENCE ? NO_CONVERGENCE : FAILURE;
+    if (s.termination_type == STBA_FAILURE && !std::isfinite(s.initial_cost))
+        out->message = "Initial residual and Jacobian evaluation failed.";      // (Ceres' wording for a non-finite start point)
     out->iterations.clear();
     for (int i = 0; i <= s.num_iterations; ++i) {
         const double* t = &trace[(size_t)i * STBA_TRACE_COLS];

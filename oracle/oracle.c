@@ -700,6 +700,13 @@ int orc_ba_solve(orc_ba_problem* p, const orc_lm_options* opt, orc_lm_summary* s
     const int fixed = opt->fixed_iterations;
     const int max_iter = fixed > 0 ? fixed : opt->max_num_iterations;
 
+    /* Ceres: a residual block that returns a non-finite value fails its evaluation, and a failed evaluation of the START point
+     * ends the solve as FAILURE before any step ("Initial residual and Jacobian evaluation failed", TrustRegionMinimizer::Init);
+     * at a trial point the same failure is only an unsuccessful step -- the rho test below rejects a non-finite cost */
+    if (!isfinite(cost)) {
+        sum->termination_type = ORC_FAILURE; sum->termination_reason = ORC_TERM_SOLVER_FAIL;
+        goto done;
+    }
     if (!fixed && gmax <= opt->gradient_tolerance) {
         sum->termination_type = ORC_CONVERGENCE; sum->termination_reason = ORC_TERM_GRADIENT;
         goto done;
@@ -958,6 +965,10 @@ int orc_dense_lm(orc_residual_fn fn, orc_plus_fn plus, void* user, int n_params,
     for (int i = 0; i < n_res; ++i) cost += r[i] * r[i];
     cost *= 0.5;
     sum->initial_cost = cost;
+    if (!isfinite(cost)) {       /* (Ceres: initial evaluation failed -- see orc_ba_solve) */
+        rc = ORC_FAILURE; sum->termination_reason = ORC_TERM_SOLVER_FAIL; sum->final_cost = cost;
+        goto out;
+    }
     DENSE_LINEARIZE();
     for (int a = 0; a < n; ++a) scale[a] = opt->jacobi_scaling ? 1.0 / (1.0 + sqrt(H[a * n + a])) : 1.0;
 
@@ -1678,6 +1689,7 @@ int orc_pg_solve_sparse(orc_pg_problem* p, const orc_lm_options* opt, orc_lm_sum
     x_norm = sqrt(x_norm);
     int iter = 0;
     if (trace) { memset(trace, 0, sizeof(double) * ORC_TRACE_COLS); trace[0] = cost; trace[2] = gmax; trace[5] = radius; trace[6] = 1; }
+    if (!isfinite(cost)) { rc = ORC_FAILURE; sum->termination_reason = ORC_TERM_SOLVER_FAIL; goto fin; }      /* (Ceres: initial evaluation failed) */
     if (gmax <= opt->gradient_tolerance) { rc = ORC_CONVERGENCE; sum->termination_reason = ORC_TERM_GRADIENT; goto fin; }
 
     while (1) {

@@ -1314,6 +1314,7 @@ int stba_pg_solve(stba_pg* g, const stba_lm_options* opt_in, const stba_pcg_opti
     s.termination_type = STBA_NO_CONVERGENCE; s.termination_reason = STBA_TERM_MAX_ITER;
     bool done = gmax <= opt.gradient_tolerance;
     if (done) { s.termination_type = STBA_CONVERGENCE; s.termination_reason = STBA_TERM_GRADIENT; }
+    if (!std::isfinite(cost)) { s.termination_type = STBA_FAILURE; s.termination_reason = STBA_TERM_SOLVER_FAIL; done = true; }   // (Ceres: initial evaluation failed, see stba_ba_solve)
     int since_refresh = 0;
     while (!done) {
         if (iter >= opt.max_num_iterations) break;

@@ -695,6 +695,13 @@ static int ba_run_lm(stba_ba* b, const stba_lm_options* opt_in, int fixed_iterat
             if (opt.minimizer_progress_to_stdout)
                 printf("iter      cost      cost_change  |gradient|   |step|    tr_ratio  tr_radius\n"
                        "%4d  %.6e    0.00e+00    %.2e   0.00e+00   0.00e+00  %.2e\n", 0, L.cost, L.gmax, L.radius);
+            // Ceres: a residual block that returns a non-finite value fails its evaluation, and a failed evaluation of the START
+            // point ends the solve as FAILURE before any step ("Initial residual and Jacobian evaluation failed"); at a trial
+            // point it is an unsuccessful step -- the rho test rejects a non-finite cost.  (oracle.c: orc_ba_solve)
+            if (!std::isfinite(L.cost)) {
+                s.termination_type = STBA_FAILURE; s.termination_reason = STBA_TERM_SOLVER_FAIL;
+                break;
+            }
             if (!fixed && L.gmax <= opt.gradient_tolerance) {
                 s.termination_type = STBA_CONVERGENCE; s.termination_reason = STBA_TERM_GRADIENT;
                 break;
@@ -2027,7 +2034,8 @@ int stba_dense_solve(stba_residual_fn fn, stba_plus_fn plus, void* user, int n_p
     if (trace) { memset(trace, 0, sizeof(double) * STBA_TRACE_COLS); trace[0] = cost; trace[2] = gmax; trace[5] = radius; trace[6] = 1; }
     s.termination_type = STBA_NO_CONVERGENCE; s.termination_reason = STBA_TERM_MAX_ITER;
     bool done = false;
-    if (gmax <= opt.gradient_tolerance) { s.termination_type = STBA_CONVERGENCE; s.termination_reason = STBA_TERM_GRADIENT; done = true; }
+    if (!std::isfinite(cost)) { s.termination_type = STBA_FAILURE; s.termination_reason = STBA_TERM_SOLVER_FAIL; done = true; }    // (Ceres: initial evaluation failed, see stba_ba_solve)
+    else if (gmax <= opt.gradient_tolerance) { s.termination_type = STBA_CONVERGENCE; s.termination_reason = STBA_TERM_GRADIENT; done = true; }
     while (!done) {
         if (iter >= opt.max_num_iterations) { s.termination_type = STBA_NO_CONVERGENCE; s.termination_reason = STBA_TERM_MAX_ITER; break; }
         if (radius < opt.min_trust_region_radius) { s.termination_type = STBA_CONVERGENCE; s.termination_reason = STBA_TERM_MIN_RADIUS; break; }

@@ -214,3 +214,29 @@ def test_function_tolerance_switch(O, scenes):
     assert s0.final_cost == t1[n - 1, 0] and s1.final_cost == t1[n, 0]
     assert 0 <= s0.final_cost - s1.final_cost <= 1e-6 * s0.final_cost
     assert np.abs(o0.cams - o1.cams).max() < 1e-5
+
+
+def test_non_finite_start_point_is_a_failure_before_any_step(O, scenes):
+    """Ceres' rule (a residual block returning a non-finite value fails its evaluation; a failed INITIAL evaluation ends the solve
+    as FAILURE, TrustRegionMinimizer::Init), in all three LM loops of the oracle; nothing is moved"""
+    s = scenes.st20_scene(n_cams=8, n_pts=60, max_obs_per_pt=5, seed=3, pix_noise=1e-3)
+    feat = s["obs_feat"].copy()
+    feat[7, 0] = np.nan
+    o = O.BA(s["cams0"], s["pts0"], s["obs_cam"], s["obs_pt"], feat, s["cam_fixed"])
+    so, tr = o.solve(max_num_iterations=10)
+    assert (so.termination_type, so.num_iterations, so.num_successful_steps) == (2, 0, 0) and np.isnan(so.initial_cost)
+    assert np.array_equal(o.cams, s["cams0"]) and np.array_equal(o.pts, s["pts0"])
+    x = np.linspace(0, 1, 20)
+
+    def res(p):
+        r = p[0] * x - 2.0 * x
+        r[3] = np.inf
+        return r, x[:, None]
+    p, sd, _ = O.dense_lm(res, [0.5], 20)
+    assert (sd.termination_type, sd.num_iterations) == (2, 0) and p[0] == 0.5
+    g = scenes.pose_graph_scene(n_nodes=30, loops_per_node=2, seed=3)
+    meas = g["meas"].copy()
+    meas[5, 2] = np.nan
+    pg = O.PG(g["poses0"], g["edge_i"], g["edge_j"], meas, g["node_fixed"])
+    sp = pg.solve_sparse(max_num_iterations=5)[0]
+    assert (sp.termination_type, sp.num_iterations) == (2, 0) and np.array_equal(pg.poses, g["poses0"])
