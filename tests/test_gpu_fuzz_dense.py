@@ -92,3 +92,28 @@ def test_random_calibration_shape_follows_the_oracle(st, O, scenes, k):
     n = np.count_nonzero(~np.isnan(tro))
     assert np.allclose(tr[:n], tro[:n], rtol=1e-8)
     assert np.allclose(p[:4], po[:4], rtol=1e-9)
+
+
+@pytest.mark.parametrize("k", range(24))
+def test_random_size_cholesky_against_lapack(st, k):
+    """the factorisation at sizes nobody chose: 1 to 3600 (stage kernels below 768, the persistent program above), every residue of
+    the 128-wide panels, well and badly scaled rows; the factor against numpy's (LAPACK dpotrf), the solve through the residual,
+    and a failing pivot at a random place must be reported, not factored"""
+    rng = np.random.default_rng(9900 + k)
+    n = int(rng.integers(1, 3601)) if k % 4 else int(rng.integers(1, 28)) * 128 + int(rng.integers(-1, 2))
+    B = rng.normal(size=(n, n)) * (np.exp(rng.uniform(-2, 2, n))[:, None] if k % 3 == 0 else 1.0)
+    A = B @ B.T + np.diag(rng.uniform(0.5, 2.0, n) * n)
+    b = rng.normal(size=n)
+    x = st.cholesky_solve(A, b)
+    assert np.abs(A @ x - b).max() <= 1e-10 * (np.abs(A).max() * np.abs(x).max() + np.abs(b).max())
+    L = st.cholesky_factor(A)
+    Lr = np.linalg.cholesky(A)
+    assert np.abs(L - Lr).max() <= 1e-11 * np.abs(Lr).max()
+    assert np.array_equal(st.cholesky_factor(A), L)                      # the task graph fixes every operation: bit for bit again
+    if n > 2:
+        bad = int(rng.integers(0, n))
+        A2 = A.copy()
+        A2[bad, bad] = -abs(A2[bad, bad])
+        with pytest.raises(st.StbaError) as e:
+            st.cholesky_solve(A2, b)
+        assert e.value.code == -4
