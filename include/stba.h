@@ -352,6 +352,11 @@ typedef struct {
     int    coarse_group;         /* nodes per group of the coarse space, a power of two; 0: automatic (<= 200 groups, >= 8 nodes);
                                   * -1: no coarse space (block Jacobi only, the round-3 preconditioner) */
     int    coarse_refresh_every; /* 1: LM iterations between re-inversions of the coarse operator while only the damping changes */
+    int    one_kernel_solve;     /* 1: the PCG solve of an LM iteration as ONE persistent kernel (two stamped exchanges per iteration
+                                  * instead of four launches) where the graph allows: one rank, a coarse space of <= 256 groups of
+                                  * <= 64 nodes; 0: always four launches per iteration; 2: as 1 with a time-out of zero, so that the way back is
+                                  * taken -- a solve whose workgroups are not all resident gives up and is repeated with launches, and the
+                                  * engine stays with launches (stba_version() >= 5) */
 } stba_pcg_options;
 void stba_pcg_default_options(stba_pcg_options* o);
 typedef struct {
@@ -364,6 +369,8 @@ typedef struct {
     double last_eta;                    /* forcing term of the last solve */
     int    coarse_failures;             /* coarse operators whose factorisation met a non-positive pivot: the coarse correction was
                                          * switched off (block Jacobi alone) until the next refresh (stba_version() >= 5) */
+    int    one_kernel_solves;           /* linear solves that ran as one persistent kernel (stba_pcg_options::one_kernel_solve); a solve
+                                         * whose workgroups were not all resident is repeated with launches and not counted */
 } stba_pcg_summary;
 int stba_pg_create(stba_pg** out, int n_nodes, int n_edges, const double* poses, const int* edge_i, const int* edge_j,
                    const double* meas, const unsigned char* node_fixed, void* hip_stream);

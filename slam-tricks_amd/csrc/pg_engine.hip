@@ -536,15 +536,35 @@ __global__ __launch_bounds__(256) void pg_coarse_build_kernel(int n, int m, int 
                                                               const int* __restrict__ ei, const int* __restrict__ ej,
                                                               const double* __restrict__ Ji, const double* __restrict__ Jj,
                                                               const double* __restrict__ AdP, double* __restrict__ Ac0) {
-    extern __shared__ double rowp[];            // [6][nc]
-    const int a = blockIdx.x, t = threadIdx.x;
+    extern __shared__ double rowp[];            // [6][nc] | four lists of edge ends (int)
+    __shared__ double dgp[4][36];
+    const int a = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
     for (int q = t; q < 6 * nc; q += 256) rowp[q] = 0.0;
-    __syncthreads();
     const int k0 = a * agg, k1 = min(n, k0 + agg);
     const int c0 = node_start[k0], c1 = node_start[k1];
+    // REPRODUCIBLE sums (round 5; until then the four waves added to the row panel in arrival order and the preconditioner -- hence
+    // every PCG iterate -- differed in the last bits from run to run): every block of the panel is added to by ONE wave, the wave
+    // (other group) mod 4, whose adds meet an LDS address in program and lane order.  Each wave first collects ITS ends, in CSR
+    // order, into a list of its own (ballot + prefix count), then works through the list with all lanes.
+    int* mylist = reinterpret_cast<int*>(rowp + (size_t)6 * nc) + (size_t)wv * (c1 - c0);
+    int cnt = 0;
+    for (int cb = c0; cb < c1; cb += 64) {
+        const int c = cb + lane;
+        bool mine = false;
+        if (c < c1) {
+            const int code = end_code[c], e = code >> 1;
+            const int other = (code & 1) ? ei[e] : ej[e];
+            mine = ((other / agg) & 3) == wv;
+        }
+        const unsigned long long bal = __ballot(mine);
+        if (mine) mylist[cnt + __popcll(bal & ((1ull << lane) - 1ull))] = c;
+        cnt += __popcll(bal);
+    }
+    __syncthreads();
     double dg[36];
     for (int q = 0; q < 36; ++q) dg[q] = 0.0;
-    for (int c = c0 + t; c < c1; c += 256) {
+    for (int idx = lane; idx < cnt; idx += 64) {
+        const int c = mylist[idx];
         const int self = end_node[c], code = end_code[c], e = code >> 1, side = code & 1;
         const int other = side ? ei[e] : ej[e];
         const double* Js = (side ? Jj : Ji) + e;
@@ -577,11 +597,14 @@ __global__ __launch_bounds__(256) void pg_coarse_build_kernel(int n, int m, int 
                 else unsafeAtomicAdd(&rowp[u * nc + 6 * ao + v], so);
             }
     }
+    // the diagonal block, which every end adds to: register sums, a shuffle tree per wave, the four waves in order
     for (int q = 0; q < 36; ++q) {
         double v = dg[q];
         for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-        if ((t & 63) == 0) unsafeAtomicAdd(&rowp[(q / 6) * nc + 6 * a + (q % 6)], v);
+        if (lane == 0) dgp[wv][q] = v;
     }
+    __syncthreads();
+    if (t < 36) rowp[(t / 6) * nc + 6 * a + (t % 6)] = (dgp[0][t] + dgp[1][t]) + (dgp[2][t] + dgp[3][t]);
     __syncthreads();
     for (int q = t; q < 6 * nc; q += 256) Ac0[(size_t)(6 * a + q / nc) * nc + (q % nc)] = rowp[q];
 }
@@ -865,6 +888,262 @@ __global__ __launch_bounds__(PG_NT) void pg_pcg_dir4_kernel(int n, int agg, int 
     }
 }
 
+// ================================================================= round 5: the PCG solve of an LM iteration as ONE kernel
+// Four launches per PCG iteration cost ~44 us for ~34 us of kernels (C4), every kernel a chain of three memory round trips on an
+// empty machine.  Round 3's persistent loop (four grid BARRIERS per iteration, 59 us) was slower still; what a barrier costs is not
+// the exchange but the counter: arrive, wait for the count, then fetch the data.  Here nothing is counted.  One workgroup per
+// GROUP of the coarse space (<= 64 nodes, <= 256 groups: all resident, one per CU) keeps its nodes' x, r, p, s, u, w and its six rows
+// of the coarse inverse in REGISTERS for the whole solve, and an iteration has two exchanges, each a block of data with a STAMP
+// behind it (agent-scope write-through stores, agent-scope loads: no fence, no cache invalidate):
+//   A  the group's slice of u = M^-1 r; an edge end waits for the stamp of the ONE group that owns its remote node, reads 48 bytes;
+//   B  nine doubles per group -- the partial sums of (r, u), (w, u), (r, r) and the group's six entries of P^T w -- which every
+//      group reads from every group: an all-gather of 157 x 72 bytes at C4.
+// Two exchanges suffice because the iteration is the Chronopoulos-Gear form of PCG (w = A u instead of q = A p; p and s = A p by
+// recurrence; both dot products of a step in ONE reduction), and because the coarse residual is carried by recurrence, replicated
+// in every group: r_c <- r_c - alpha P^T s, P^T s = P^T w + beta P^T s -- so the restriction never needs a gather of its own.
+// Measured skeleton (tools/exp/pcg_skeleton.hip, no arithmetic): 6.0 us per iteration (A 2.6, B 3.8).
+// The matrix is applied ASSEMBLED: (H_ii + D_i) u_i from the diagonal blocks the linearisation leaves, plus one 6 x 6 block
+// B_e = Ji^T Jj per edge END (its transpose for the other end), written once per linearisation in the order the groups read
+// them (pg_offdiag_kernel), 36 coalesced loads per end and iteration out of the XCD's L2.
+// Several ranks (edge shards) keep the launch-per-kernel path: their product needs a cross-rank sum in every iteration.
+constexpr int PP_T = 512;            // threads of a group's workgroup (384 = 64 nodes x 6 components carry the vectors)
+constexpr int PP_VCAP = 1536;        // edge ends of one group whose products fit the LDS buffer
+constexpr int PP_NCMAX = 1536;       // coarse unknowns: three columns of the group's six inverse rows per thread
+constexpr int PP_SLOT = 16;          // doubles per group in the all-gather block (9 used)
+constexpr int PP_STAMP = 16;         // ints between two stamps (a 64-byte line each)
+constexpr int PP_TIMED_OUT = 2;      // PcgState::hit_cap: a stamp never came (the workgroups were not all resident): the caller repeats the solve with launches
+
+struct PpArgs {
+    int n, agg, log2agg, na, nc, base, max_iters;
+    double eta;
+    const int *node_start, *end_rem;
+    const double *Bend, *Hd, *d, *Minv, *AdP, *Ainv, *g;
+    double *x, *ubuf, *pbuf;
+    int *ustamp, *pstamp;
+    PcgState* state;
+    long long spin_limit;
+};
+
+inline size_t pp_lds_bytes(int na, int nc) { return ((size_t)2 * nc + (size_t)na * PP_SLOT + 768 + (size_t)PP_VCAP * 6 + 128 + 16) * sizeof(double); }
+
+__device__ __forceinline__ int pp_ld_i(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double pp_ld(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void pp_st(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// B_e = Ji^T Jj of every edge, stored COMPONENT-major over the CSR positions of the edge ENDS ([36][2 m]): column end_pos[2 e] (the
+// end at i, which multiplies u_j) gets B_e, column end_pos[2 e + 1] (the end at j, which multiplies u_i) its transpose
+__global__ __launch_bounds__(256) void pg_offdiag_kernel(int m, const double* __restrict__ Ji, const double* __restrict__ Jj,
+                                                         const int* __restrict__ end_pos, double* __restrict__ Bend) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= m) return;
+    double A[36], B[36];
+    for (int k = 0; k < 36; ++k) { A[k] = Ji[(size_t)k * m + e]; B[k] = Jj[(size_t)k * m + e]; }
+    const size_t m2 = 2 * (size_t)m;
+    const size_t c0 = (size_t)end_pos[2 * e], c1 = (size_t)end_pos[2 * e + 1];
+    for (int a = 0; a < 6; ++a)
+        for (int b = 0; b < 6; ++b) {
+            double s = 0.0;
+            for (int r = 0; r < 6; ++r) s += A[r * 6 + a] * B[r * 6 + b];
+            Bend[(size_t)(a * 6 + b) * m2 + c0] = s;
+            Bend[(size_t)(b * 6 + a) * m2 + c1] = s;
+        }
+}
+
+__global__ __launch_bounds__(PP_T) void pg_pcg_persistent_kernel(PpArgs a) {
+    extern __shared__ double pp_sm[];
+    __shared__ int s_abort;
+    const int t = threadIdx.x, grp = blockIdx.x, lane = t & 63, wv = t >> 6;
+    const int n = a.n, agg = a.agg, na = a.na, nc = a.nc;
+    double* rc = pp_sm;                       // [nc]   coarse residual P^T r, replicated in every group
+    double* pts = rc + nc;                    // [nc]   P^T s
+    double* gat = pts + nc;                   // [na][PP_SLOT]  the gathered block of exchange B
+    double* ul = gat + (size_t)na * PP_SLOT;  // [384]  this group's u (the diagonal term reads it)
+    double* rl = ul + 384;                    // [384]  this group's r (block Jacobi reads a node's six)
+    double* vbuf = rl + 384;                  // [PP_VCAP][6]  products of the edge ends
+    double* red = vbuf + (size_t)PP_VCAP * 6; // [8][16] per-wave partial sums
+    double* sc = red + 128;                   // [16]  the group's sums | zc at 8..13
+    if (t == 0) s_abort = 0;
+    // ---- what a thread keeps for the whole solve
+    const int nl = t / 6, q = t - nl * 6;
+    const int node = grp * agg + nl;
+    const bool act = t < agg * 6 && node < n;
+    const size_t o = (size_t)node * 6 + q;
+    double mrow[6] = {0, 0, 0, 0, 0, 0}, hrow[6] = {0, 0, 0, 0, 0, 0}, prow[6] = {0, 0, 0, 0, 0, 0};
+    double r = 0.0, x = 0.0, p = 0.0, s = 0.0, u = 0.0, w = 0.0;
+    int e0 = 0, e1 = 0;
+    const int c0 = a.node_start[min(n, grp * agg)], c1 = a.node_start[min(n, (grp + 1) * agg)];
+    if (act) {
+        for (int b = 0; b < 6; ++b) {
+            mrow[b] = a.Minv[(size_t)node * 36 + q * 6 + b];
+            hrow[b] = a.Hd[(size_t)node * 36 + q * 6 + b];
+            prow[b] = a.AdP[(size_t)node * 36 + q * 6 + b];
+        }
+        hrow[q] += a.d[o];
+        r = -a.g[o];
+        e0 = a.node_start[node] - c0; e1 = a.node_start[node + 1] - c0;
+    }
+    double acol[3][6];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int c = t + j * PP_T;
+#pragma unroll
+        for (int rr_ = 0; rr_ < 6; ++rr_) acol[j][rr_] = (c < nc) ? a.Ainv[(size_t)(grp * 6 + rr_) * nc + c] : 0.0;
+    }
+    const size_t m2 = (size_t)a.node_start[n];        // edge ends = 2 m
+    __syncthreads();
+
+    // K values per thread -> the group's sums in sc[off .. off + K): a shuffle tree per wave, the eight waves in order
+    auto group_sum = [&](const double* v, int K, int off) {
+        for (int k = 0; k < K; ++k) {
+            double y = v[k];
+            for (int d2 = 32; d2 > 0; d2 >>= 1) y += __shfl_down(y, d2, 64);
+            if (lane == 0) red[wv * 16 + k] = y;
+        }
+        __syncthreads();
+        if (t < K) { double y = 0.0; for (int w2 = 0; w2 < PP_T / 64; ++w2) y += red[w2 * 16 + t]; sc[off + t] = y; }
+        __syncthreads();
+    };
+    // exchange B: sc[0 .. K) of every group -> gat[group][0 .. K)
+    auto all_gather = [&](int round, int K) {
+        double* mine = a.pbuf + ((size_t)(round & 1) * na + grp) * PP_SLOT;
+        if (t < K) { pp_st(mine + t, sc[t]); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        __syncthreads();
+        if (t == 0) __hip_atomic_store(&a.pstamp[grp * PP_STAMP], a.base + round + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t < na) {
+            bool ok = true;
+            long long spins = 0;
+            while (pp_ld_i(&a.pstamp[t * PP_STAMP]) - (a.base + round + 1) < 0) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > a.spin_limit) { ok = false; s_abort = 1; break; }
+            }
+            if (ok) {
+                const double* src = a.pbuf + ((size_t)(round & 1) * na + t) * PP_SLOT;
+                for (int k = 0; k < K; ++k) gat[t * PP_SLOT + k] = pp_ld(src + k);
+            }
+        }
+        __syncthreads();
+    };
+    // a scalar of the gathered block summed over the groups (wave k sums entry k: the same order in every group)
+    auto gathered_sums = [&](int K) {
+        if (wv < K) {
+            double y = 0.0;
+            for (int j = lane; j < na; j += 64) y += gat[j * PP_SLOT + wv];
+            for (int d2 = 32; d2 > 0; d2 >>= 1) y += __shfl_xor(y, d2, 64);
+            if (lane == 0) sc[wv] = y;
+        }
+        __syncthreads();
+    };
+    auto coarse_and_u = [&]() {        // zc = (own six rows of the inverse) rc; u = Minv r + P zc
+        double zp[6];
+#pragma unroll
+        for (int rr_ = 0; rr_ < 6; ++rr_) {
+            double y = 0.0;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { const int c = t + j * PP_T; if (c < nc) y += acol[j][rr_] * rc[c]; }
+            zp[rr_] = y;
+        }
+        if (t < 384) rl[t] = r;
+        group_sum(zp, 6, 8);
+        double z0 = 0.0;
+        if (act) {
+            for (int b = 0; b < 6; ++b) z0 += mrow[b] * rl[nl * 6 + b];
+            for (int b = 0; b < 6; ++b) z0 += prow[b] * sc[8 + b];
+        }
+        u = z0;
+    };
+    auto finish = [&](int iters, int cap, double rr0, double rr, double tol2) {
+        if (act) a.x[o] = x;
+        if (grp == 0 && t == 0) {
+            a.state->rr0 = rr0; a.state->rr = rr; a.state->tol2 = tol2; a.state->iters = iters; a.state->done = 1; a.state->hit_cap = cap;
+        }
+    };
+
+    // ---- start: x = 0, r = -g; |r|^2 and P^T r gathered; u = M^-1 r
+    {
+        double v[7];
+        v[0] = r * r;
+        for (int b = 0; b < 6; ++b) v[1 + b] = prow[b] * r;
+        group_sum(v, 7, 0);
+        all_gather(0, 7);
+        if (s_abort) { finish(0, PP_TIMED_OUT, 0.0, 0.0, 0.0); return; }
+        for (int c = t; c < nc; c += PP_T) { rc[c] = gat[(c / 6) * PP_SLOT + 1 + (c % 6)]; pts[c] = 0.0; }
+        gathered_sums(1);
+    }
+    const double rr0 = sc[0];
+    __syncthreads();
+    if (!(rr0 > 0.0) || !isfinite(rr0)) { finish(0, 0, rr0, rr0, 0.0); return; }
+    const double tol2 = a.eta * a.eta * rr0;
+    coarse_and_u();
+    double gamma_old = 1.0, alpha_old = 1.0;
+    const size_t N6 = (size_t)n * 6;
+    for (int k = 0;; ++k) {
+        // ---- exchange A: publish the group's u
+        double* ub = a.ubuf + (size_t)(k & 1) * N6;
+        if (act) { pp_st(ub + o, u); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        if (t < 384) ul[t] = u;
+        __syncthreads();
+        if (t == 0) __hip_atomic_store(&a.ustamp[grp * PP_STAMP], a.base + k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // ---- off-diagonal blocks times the remote ends' u
+        for (int c = c0 + t; c < c1; c += PP_T) {
+            double B[36];
+#pragma unroll
+            for (int b = 0; b < 36; ++b) B[b] = a.Bend[(size_t)b * m2 + c];
+            const int rem = a.end_rem[c];
+            const int* stamp = &a.ustamp[(rem >> a.log2agg) * PP_STAMP];
+            bool ok = true;
+            long long spins = 0;
+            while (pp_ld_i(stamp) - (a.base + k + 1) < 0) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > a.spin_limit) { ok = false; s_abort = 1; break; }
+            }
+            double ur[6] = {0, 0, 0, 0, 0, 0};
+            if (ok) for (int b = 0; b < 6; ++b) ur[b] = pp_ld(ub + (size_t)rem * 6 + b);
+#pragma unroll
+            for (int aa = 0; aa < 6; ++aa) {
+                double y = 0.0;
+#pragma unroll
+                for (int b = 0; b < 6; ++b) y += B[aa * 6 + b] * ur[b];
+                vbuf[(size_t)(c - c0) * 6 + aa] = y;
+            }
+        }
+        __syncthreads();
+        if (s_abort) { finish(k, PP_TIMED_OUT, rr0, 0.0, tol2); return; }
+        w = 0.0;
+        if (act) {
+            for (int b = 0; b < 6; ++b) w += hrow[b] * ul[nl * 6 + b];
+            for (int e = e0; e < e1; ++e) w += vbuf[(size_t)e * 6 + q];
+        }
+        // ---- exchange B: (r, u), (w, u), (r, r), P^T w
+        {
+            double v[9];
+            v[0] = r * u; v[1] = w * u; v[2] = r * r;
+            for (int b = 0; b < 6; ++b) v[3 + b] = prow[b] * w;
+            group_sum(v, 9, 0);
+            all_gather(k + 1, 9);
+            if (s_abort) { finish(k, PP_TIMED_OUT, rr0, 0.0, tol2); return; }
+            gathered_sums(3);
+        }
+        const double gamma = sc[0], delta = sc[1], rr = sc[2];
+        // the residual of k updates: the stopping test (the first iteration always runs, as with the launches)
+        if (k > 0 && !(rr > tol2)) { finish(k, 0, rr0, rr, tol2); return; }
+        if (k >= a.max_iters) { finish(k, 1, rr0, rr, tol2); return; }
+        const double beta = (k == 0) ? 0.0 : gamma / gamma_old;
+        const double den = (k == 0) ? delta : delta - beta * gamma / alpha_old;
+        if (!(den > 0.0) || !isfinite(den) || !isfinite(gamma)) { finish(k, 1, rr0, rr, tol2); return; }     // (breakdown: never seen; reported as a capped solve)
+        const double alpha = gamma / den;
+        p = u + beta * p; s = w + beta * s;
+        x += alpha * p; r -= alpha * s;
+        for (int c = t; c < nc; c += PP_T) {
+            const double ps = gat[(c / 6) * PP_SLOT + 3 + (c % 6)] + beta * pts[c];
+            pts[c] = ps;
+            rc[c] -= alpha * ps;
+        }
+        gamma_old = gamma; alpha_old = alpha;
+        __syncthreads();
+        coarse_and_u();
+    }
+}
+
 // trial point of an LM iteration: the scalars the host decides on, summed on the device and written to mapped host memory
 // (one rank) or to a device block the cross-rank sum goes over first.  out: {cost2_new, |J x|^2, g.x, |dx|^2, |x|^2, seq}
 __global__ __launch_bounds__(256) void pg_trial_finish_kernel(int nb_e, const double* __restrict__ part_e, int nb_tt,
@@ -980,6 +1259,14 @@ struct stba_pg {
     double *fin_host = nullptr, *fin_dev = nullptr;      // mapped: trial / linearisation scalars + sequence number
     double seq = 0.0;
     int nb_nodes4 = 1;
+    // ---- round 5: the PCG solve as one persistent kernel (pg_pcg_persistent_kernel)
+    int *end_pos = nullptr, *end_rem = nullptr;          // CSR position of the edge end 2 e + side | remote node of the end at a CSR position
+    double *Bend = nullptr, *ubuf = nullptr, *pbuf = nullptr;
+    int *ustamp = nullptr, *pstamp = nullptr;
+    int max_group_ends = 0;                              // edge ends of the largest group of the coarse space
+    int pp_base = 0;                                     // stamps only grow: the next solve starts behind the last one's
+    bool bend_valid = false, pp_disabled = false;
+    std::vector<int> h_node_start;
     bool coarse_valid = false;
     double coarse_radius = 0.0;
     stba_pcg_summary last_pcg;
@@ -994,6 +1281,7 @@ void pg_free(stba_pg* g) {
     F(g->part_b); F(g->part_c); F(g->part_d); F(g->fixed); F(g->scalar); F(g->node_start); F(g->end_code); F(g->u);
     F(g->end_node); F(g->AdP); F(g->Ac0); F(g->W); F(g->Ainv); F(g->inv_work); F(g->rc_part); F(g->zc); F(g->part_cz); F(g->part_u);
     F(g->scal_dev); F(g->cflag); F(g->state); F(g->contrib); F(g->Dc);
+    F(g->end_pos); F(g->end_rem); F(g->Bend); F(g->ubuf); F(g->pbuf); F(g->ustamp); F(g->pstamp);
     if (g->exp_host) (void)hipHostFree(g->exp_host);
     if (g->fin_host) (void)hipHostFree(g->fin_host);
     if (g->own && g->st) (void)hipStreamDestroy(g->st);
@@ -1013,6 +1301,7 @@ int pg_linearize(stba_pg* g, int which, bool jac) {
     hipLaunchKernelGGL(pg_linearize_kernel, dim3(g->nb_edges), dim3(256), 0, g->st, g->m, g->poses[which], g->ei, g->ej,
                        g->meas, g->fixed, jac ? 1 : 0, jac ? g->r : nullptr, g->Ji, g->Jj, g->part_e, jac ? g->contrib : nullptr);
     STBA_HIP(hipGetLastError());
+    if (jac) g->bend_valid = false;
     return STBA_OK;
 }
 
@@ -1051,7 +1340,11 @@ static int pg_setup_coarse(stba_pg* g, int group_opt) {
     if (agg < 2 || (agg & (agg - 1)) != 0) return fail(STBA_ERR_INVALID_ARGUMENT, "stba_pg_solve: coarse_group must be a power of two >= 2 (0: automatic, -1: off)");
     if (agg == g->agg) return STBA_OK;
     const int na = (g->n + agg - 1) / agg, nc = 6 * na, np = ((nc + 127) / 128) * 128, parts = std::max(1, agg / PG_NPW);
-    if ((size_t)6 * nc * sizeof(double) > 150 * 1024) return fail(STBA_ERR_INVALID_ARGUMENT, "stba_pg_solve: coarse space too large for this group size");
+    int max_ends = 0;
+    for (int a = 0; a < na; ++a)
+        max_ends = std::max(max_ends, g->h_node_start[(size_t)std::min(g->n, (a + 1) * agg)] - g->h_node_start[(size_t)std::min(g->n, a * agg)]);
+    if ((size_t)6 * nc * sizeof(double) + (size_t)4 * max_ends * sizeof(int) > 150 * 1024)
+        return fail(STBA_ERR_INVALID_ARGUMENT, "stba_pg_solve: coarse space too large for this group size");
     auto F = [](void* p) { if (p) (void)hipFree(p); };
     F(g->AdP); F(g->Ac0); F(g->W); F(g->Ainv); F(g->inv_work); F(g->rc_part); F(g->zc); F(g->part_cz); F(g->Dc);
     g->AdP = g->Ac0 = g->W = g->Ainv = g->inv_work = g->rc_part = g->zc = g->part_cz = g->Dc = nullptr;
@@ -1065,7 +1358,7 @@ static int pg_setup_coarse(stba_pg* g, int group_opt) {
         STBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pg_coarse_build_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         return STBA_OK;
     }));
-    g->agg = agg; g->na = na; g->nc = nc; g->np = np; g->parts = parts;
+    g->agg = agg; g->na = na; g->nc = nc; g->np = np; g->parts = parts; g->max_group_ends = max_ends;
     g->coarse_valid = false;
     return STBA_OK;
 }
@@ -1103,6 +1396,7 @@ void stba_pcg_default_options(stba_pcg_options* o) {
     o->forcing_eta_min = 1e-10;
     o->coarse_group = 0;
     o->coarse_refresh_every = 1;
+    o->one_kernel_solve = 1;
 }
 
 int stba_pg_create(stba_pg** out, int n_nodes, int n_edges, const double* poses, const int* edge_i, const int* edge_j,
@@ -1136,6 +1430,11 @@ int stba_pg_create(stba_pg** out, int n_nodes, int n_edges, const double* poses,
     if (node_fixed) A_(dalloc(&g->fixed, n));
     A_(dalloc(&g->node_start, n + 1)); A_(dalloc(&g->end_code, 2 * m)); A_(dalloc(&g->u, 12 * m));
     A_(dalloc(&g->end_node, 2 * m)); A_(dalloc(&g->contrib, 2 * m * 28));
+    A_(dalloc(&g->end_pos, 2 * m)); A_(dalloc(&g->end_rem, 2 * m)); A_(dalloc(&g->Bend, 72 * m)); A_(dalloc(&g->ubuf, 12 * n));
+    A_(dalloc(&g->pbuf, (size_t)2 * 256 * PP_SLOT)); A_(dalloc(&g->ustamp, (size_t)256 * PP_STAMP)); A_(dalloc(&g->pstamp, (size_t)256 * PP_STAMP));
+    if (hipMemsetAsync(g->ustamp, 0, 256 * PP_STAMP * sizeof(int), g->st) != hipSuccess ||
+        hipMemsetAsync(g->pstamp, 0, 256 * PP_STAMP * sizeof(int), g->st) != hipSuccess)
+        return bail(fail(STBA_ERR_HIP, "stba_pg_create: memset"));
     g->nb_nodes4 = (n_nodes + PG_NPW - 1) / PG_NPW;
     A_(dalloc(&g->part_u, (size_t)g->nb_nodes * 4 + 4)); A_(dalloc(&g->scal_dev, 16)); A_(dalloc(&g->state, 1)); A_(dalloc(&g->cflag, 2));
     if (hipHostMalloc(reinterpret_cast<void**>(&g->exp_host), sizeof(PcgExport), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
@@ -1150,14 +1449,21 @@ int stba_pg_create(stba_pg** out, int n_nodes, int n_edges, const double* poses,
         std::vector<int> start((size_t)n_nodes + 1, 0), code(2 * m);
         for (int e = 0; e < n_edges; ++e) { ++start[(size_t)edge_i[e] + 1]; ++start[(size_t)edge_j[e] + 1]; }
         for (int i = 0; i < n_nodes; ++i) start[(size_t)i + 1] += start[(size_t)i];
-        std::vector<int> fill(start.begin(), start.end() - 1), owner(2 * m);
+        std::vector<int> fill(start.begin(), start.end() - 1), owner(2 * m), pos(2 * m), rem(2 * m);
         for (int e = 0; e < n_edges; ++e) {
             owner[(size_t)fill[(size_t)edge_i[e]]] = edge_i[e];
+            rem[(size_t)fill[(size_t)edge_i[e]]] = edge_j[e];
+            pos[(size_t)2 * e] = fill[(size_t)edge_i[e]];
             code[(size_t)fill[(size_t)edge_i[e]]++] = 2 * e;
             owner[(size_t)fill[(size_t)edge_j[e]]] = edge_j[e];
+            rem[(size_t)fill[(size_t)edge_j[e]]] = edge_i[e];
+            pos[(size_t)2 * e + 1] = fill[(size_t)edge_j[e]];
             code[(size_t)fill[(size_t)edge_j[e]]++] = 2 * e + 1;
         }
-        if (hipMemcpyAsync(g->node_start, start.data(), (n + 1) * sizeof(int), hipMemcpyHostToDevice, g->st) != hipSuccess ||
+        g->h_node_start = start;
+        if (hipMemcpyAsync(g->end_pos, pos.data(), 2 * m * sizeof(int), hipMemcpyHostToDevice, g->st) != hipSuccess ||
+            hipMemcpyAsync(g->end_rem, rem.data(), 2 * m * sizeof(int), hipMemcpyHostToDevice, g->st) != hipSuccess ||
+            hipMemcpyAsync(g->node_start, start.data(), (n + 1) * sizeof(int), hipMemcpyHostToDevice, g->st) != hipSuccess ||
             hipMemcpyAsync(g->end_code, code.data(), 2 * m * sizeof(int), hipMemcpyHostToDevice, g->st) != hipSuccess ||
             hipMemcpyAsync(g->end_node, owner.data(), 2 * m * sizeof(int), hipMemcpyHostToDevice, g->st) != hipSuccess ||
             hipStreamSynchronize(g->st) != hipSuccess)
@@ -1269,6 +1575,22 @@ int stba_pg_solve(stba_pg* g, const stba_lm_options* opt_in, const stba_pcg_opti
     memset(&ps, 0, sizeof ps);
     ps.coarse_dim = coarse ? g->nc : 0;
     double* fin = g->fin_host;
+    // the PCG solve as one kernel: one rank, a coarse space whose groups fit a workgroup (<= 64 nodes, all their edge-end products
+    // in LDS) and are all resident at once (one per CU)
+    bool pp_ok = pcg.one_kernel_solve != 0 && !multi && coarse && g->agg <= 64 && g->na <= 256 && g->nc <= PP_NCMAX &&
+                 pp_lds_bytes(g->na, g->nc) <= (size_t)160 * 1024 - 64;
+    if (pp_ok) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || g->na > cus) pp_ok = false;
+        if (g->max_group_ends > PP_VCAP) pp_ok = false;
+    }
+    if (pp_ok) {
+        static DeviceOnce attr;
+        STBA_TRY(attr.run([]() -> int {
+            STBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pg_pcg_persistent_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+            return STBA_OK;
+        }));
+    }
 
     // ---- linearisation at the current point: residuals, Jacobians, gradient | diagonal blocks, the coarse basis and matrix
     auto linearize_enqueue = [&]() -> int {
@@ -1278,7 +1600,7 @@ int stba_pg_solve(stba_pg* g, const stba_lm_options* opt_in, const stba_pcg_opti
         hipLaunchKernelGGL(pg_gnorm_kernel, dim3(g->nb_vec), dim3(256), 0, g->st, N, g->g, g->part_c);
         if (coarse) {
             hipLaunchKernelGGL(pg_coarse_basis_kernel, dim3(g->nb_nodes), dim3(256), 0, g->st, g->n, g->agg, g->poses[g->cur], g->fixed, g->AdP);
-            hipLaunchKernelGGL(pg_coarse_build_kernel, dim3(g->na), dim3(256), (size_t)6 * g->nc * sizeof(double), g->st, g->n, g->m, g->agg, g->nc,
+            hipLaunchKernelGGL(pg_coarse_build_kernel, dim3(g->na), dim3(256), (size_t)6 * g->nc * sizeof(double) + (size_t)4 * g->max_group_ends * sizeof(int), g->st, g->n, g->m, g->agg, g->nc,
                                g->node_start, g->end_code, g->end_node, g->ei, g->ej, g->Ji, g->Jj, g->AdP, g->Ac0);
             if (g->ar && g->ar(g->ar_user, g->Ac0, (size_t)g->nc * g->nc, g->st) != 0) return fail(STBA_ERR_CALLBACK, "all-reduce hook failed");
             g->coarse_valid = false;
@@ -1341,71 +1663,110 @@ int stba_pg_solve(stba_pg* g, const stba_lm_options* opt_in, const stba_pcg_opti
         // ---- PCG on (J^T J + D) x = -g, stopped on the device at |r| <= eta |g|
         const double eta_k = forcing ? eta : pcg.relative_tolerance;
         const double* AdP = coarse ? g->AdP : nullptr;
-        // (every kernel of the previous solve has finished -- the host has read the trial block behind them -- so the exported
-        // block can be taken back: the wait below must not see the previous solve's tick count and `done`)
-        g->exp_host->ticks = 0; g->exp_host->done = 0;
-        std::atomic_thread_fence(std::memory_order_seq_cst);
-        hipLaunchKernelGGL(pg_pcg_init4_kernel, dim3(g->nb_nodes4), dim3(PG_NT), 0, g->st, g->n, g->agg, g->g, g->Minv, AdP, g->x, g->rr, g->z,
-                           g->rc_part, g->part_a);
-        if (coarse)
-            hipLaunchKernelGGL(pg_coarse_solve_kernel, dim3((g->nc + 3) / 4), dim3(256), 0, g->st, g->nc, g->parts, (const PcgState*)nullptr, g->Ainv, g->rc_part,
-                               g->zc, g->part_cz);
-        hipLaunchKernelGGL(pg_pcg_dir4_kernel, dim3(g->nb_nodes4), dim3(PG_NT), 0, g->st, g->n, g->agg, 1, 1, eta_k, pcg.max_iterations, g->state, g->exp_dev,
-                           g->nb_nodes4, g->part_a, (g->nc + 3) / 4, coarse ? g->part_cz : nullptr, AdP, g->zc, g->z, g->d, g->p, g->part_d);
-        STBA_HIP(hipGetLastError());
-        int enq = 0;
-        bool pcg_done = false;
-        STBA_TRY(pg_wait_mapped<int>(g, &g->exp_host->ticks, 1, true));          // (also: the previous solve's ticks are gone)
-        if (g->exp_host->done) pcg_done = true;
-        while (!pcg_done && enq < pcg.max_iterations) {
-            const int todo = std::min(chunk, pcg.max_iterations - enq);
-            for (int c = 0; c < todo; ++c, ++enq) {
-                const int slot = enq & 1;
-                if (!multi) {
-                    hipLaunchKernelGGL(pg_edge_product_kernel, dim3(g->nb_edges), dim3(256), 0, g->st, g->m, g->ei, g->ej, g->Ji, g->Jj, g->p, g->u,
-                                       g->part_c, g->state);
-                    hipLaunchKernelGGL(pg_pcg_update4_kernel<true>, dim3(g->nb_nodes4), dim3(PG_NT), 0, g->st, g->n, g->m, g->agg, slot, g->state, g->nb_edges,
-                                       g->part_c, g->nb_nodes4, g->part_d, g->Minv, AdP, g->d, g->node_start, g->end_code, g->u, (const double*)nullptr,
-                                       g->p, g->x, g->rr, g->z, g->rc_part, g->part_a);
-                } else {
-                    STBA_TRY(pg_apply(g, g->p, g->q, true));
-                    hipLaunchKernelGGL(pg_dot_kernel, dim3(g->nb_vec), dim3(256), 0, g->st, N, g->p, g->q, g->part_c);
-                    hipLaunchKernelGGL(pg_pcg_update4_kernel<false>, dim3(g->nb_nodes4), dim3(PG_NT), 0, g->st, g->n, g->m, g->agg, slot, g->state, g->nb_vec,
-                                       g->part_c, 0, (const double*)nullptr, g->Minv, AdP, g->d, g->node_start, g->end_code, g->u, g->q,
-                                       g->p, g->x, g->rr, g->z, g->rc_part, g->part_a);
+        const int nxt = g->cur ^ 1;
+        auto pcg_by_launches = [&]() -> int {
+            // (every kernel of the previous solve has finished -- the host has read the trial block behind them -- so the exported
+            // block can be taken back: the wait below must not see the previous solve's tick count and `done`)
+            g->exp_host->ticks = 0; g->exp_host->done = 0;
+            std::atomic_thread_fence(std::memory_order_seq_cst);
+            hipLaunchKernelGGL(pg_pcg_init4_kernel, dim3(g->nb_nodes4), dim3(PG_NT), 0, g->st, g->n, g->agg, g->g, g->Minv, AdP, g->x, g->rr, g->z,
+                               g->rc_part, g->part_a);
+            if (coarse)
+                hipLaunchKernelGGL(pg_coarse_solve_kernel, dim3((g->nc + 3) / 4), dim3(256), 0, g->st, g->nc, g->parts, (const PcgState*)nullptr, g->Ainv, g->rc_part,
+                                   g->zc, g->part_cz);
+            hipLaunchKernelGGL(pg_pcg_dir4_kernel, dim3(g->nb_nodes4), dim3(PG_NT), 0, g->st, g->n, g->agg, 1, 1, eta_k, pcg.max_iterations, g->state, g->exp_dev,
+                               g->nb_nodes4, g->part_a, (g->nc + 3) / 4, coarse ? g->part_cz : nullptr, AdP, g->zc, g->z, g->d, g->p, g->part_d);
+            STBA_HIP(hipGetLastError());
+            int enq = 0;
+            bool pcg_done = false;
+            STBA_TRY(pg_wait_mapped<int>(g, &g->exp_host->ticks, 1, true));          // (also: the previous solve's ticks are gone)
+            if (g->exp_host->done) pcg_done = true;
+            while (!pcg_done && enq < pcg.max_iterations) {
+                const int todo = std::min(chunk, pcg.max_iterations - enq);
+                for (int c = 0; c < todo; ++c, ++enq) {
+                    const int slot = enq & 1;
+                    if (!multi) {
+                        hipLaunchKernelGGL(pg_edge_product_kernel, dim3(g->nb_edges), dim3(256), 0, g->st, g->m, g->ei, g->ej, g->Ji, g->Jj, g->p, g->u,
+                                           g->part_c, g->state);
+                        hipLaunchKernelGGL(pg_pcg_update4_kernel<true>, dim3(g->nb_nodes4), dim3(PG_NT), 0, g->st, g->n, g->m, g->agg, slot, g->state, g->nb_edges,
+                                           g->part_c, g->nb_nodes4, g->part_d, g->Minv, AdP, g->d, g->node_start, g->end_code, g->u, (const double*)nullptr,
+                                           g->p, g->x, g->rr, g->z, g->rc_part, g->part_a);
+                    } else {
+                        STBA_TRY(pg_apply(g, g->p, g->q, true));
+                        hipLaunchKernelGGL(pg_dot_kernel, dim3(g->nb_vec), dim3(256), 0, g->st, N, g->p, g->q, g->part_c);
+                        hipLaunchKernelGGL(pg_pcg_update4_kernel<false>, dim3(g->nb_nodes4), dim3(PG_NT), 0, g->st, g->n, g->m, g->agg, slot, g->state, g->nb_vec,
+                                           g->part_c, 0, (const double*)nullptr, g->Minv, AdP, g->d, g->node_start, g->end_code, g->u, g->q,
+                                           g->p, g->x, g->rr, g->z, g->rc_part, g->part_a);
+                    }
+                    if (coarse)
+                        hipLaunchKernelGGL(pg_coarse_solve_kernel, dim3((g->nc + 3) / 4), dim3(256), 0, g->st, g->nc, g->parts, g->state, g->Ainv, g->rc_part, g->zc,
+                                           g->part_cz);
+                    hipLaunchKernelGGL(pg_pcg_dir4_kernel, dim3(g->nb_nodes4), dim3(PG_NT), 0, g->st, g->n, g->agg, slot, 0, eta_k, pcg.max_iterations, g->state,
+                                       g->exp_dev, g->nb_nodes4, g->part_a, (g->nc + 3) / 4, coarse ? g->part_cz : nullptr, AdP, g->zc, g->z, g->d, g->p, g->part_d);
                 }
-                if (coarse)
-                    hipLaunchKernelGGL(pg_coarse_solve_kernel, dim3((g->nc + 3) / 4), dim3(256), 0, g->st, g->nc, g->parts, g->state, g->Ainv, g->rc_part, g->zc,
-                                       g->part_cz);
-                hipLaunchKernelGGL(pg_pcg_dir4_kernel, dim3(g->nb_nodes4), dim3(PG_NT), 0, g->st, g->n, g->agg, slot, 0, eta_k, pcg.max_iterations, g->state,
-                                   g->exp_dev, g->nb_nodes4, g->part_a, (g->nc + 3) / 4, coarse ? g->part_cz : nullptr, AdP, g->zc, g->z, g->d, g->p, g->part_d);
+                STBA_HIP(hipGetLastError());
+                // one rank: the host looks at the chunk BEFORE the one it has just enqueued (the stream never runs dry; the kernels of a
+                // chunk enqueued past convergence return at once).  Several ranks: every rank must enqueue the same collectives, so the
+                // decision waits for the chunk itself -- the solve state is replicated and every rank sees the same `done`.
+                const int want = 1 + (multi ? enq : enq - todo);
+                STBA_TRY(pg_wait_mapped<int>(g, &g->exp_host->ticks, want, true));
+                if (g->exp_host->done) pcg_done = true;
+            }
+            return STBA_OK;
+        };
+        // the same solve as ONE kernel (see pg_pcg_persistent_kernel): nothing for the host to watch, the trial point follows on the stream
+        auto pcg_one_kernel = [&]() -> int {
+            if (!g->bend_valid) {
+                hipLaunchKernelGGL(pg_offdiag_kernel, dim3(g->nb_edges), dim3(256), 0, g->st, g->m, g->Ji, g->Jj, g->end_pos, g->Bend);
+                g->bend_valid = true;
+            }
+            if (g->pp_base > (1 << 30)) {        // (stamps only grow; long before they wrap they are taken back to zero)
+                STBA_HIP(hipMemsetAsync(g->ustamp, 0, 256 * PP_STAMP * sizeof(int), g->st));
+                STBA_HIP(hipMemsetAsync(g->pstamp, 0, 256 * PP_STAMP * sizeof(int), g->st));
+                g->pp_base = 0;
+            }
+            PpArgs a;
+            a.n = g->n; a.agg = g->agg; a.log2agg = 0; while ((1 << a.log2agg) < g->agg) ++a.log2agg;
+            a.na = g->na; a.nc = g->nc; a.base = g->pp_base; a.max_iters = pcg.max_iterations; a.eta = eta_k;
+            a.node_start = g->node_start; a.end_rem = g->end_rem; a.Bend = g->Bend; a.Hd = g->Hd; a.d = g->d; a.Minv = g->Minv; a.AdP = g->AdP;
+            a.Ainv = g->Ainv; a.g = g->g; a.x = g->x; a.ubuf = g->ubuf; a.pbuf = g->pbuf; a.ustamp = g->ustamp; a.pstamp = g->pstamp;
+            a.state = g->state; a.spin_limit = pcg.one_kernel_solve == 2 ? 0 : 1ll << 18;      // (a poll is a memory round trip, ~1 us: a quarter of a second; 2: the test of the way back)
+            hipLaunchKernelGGL(pg_pcg_persistent_kernel, dim3(g->na), dim3(PP_T), pp_lds_bytes(g->na, g->nc), g->st, a);
+            STBA_HIP(hipGetLastError());
+            g->pp_base += pcg.max_iterations + 8;
+            return STBA_OK;
+        };
+        auto trial_point = [&]() -> int {
+            // ---- model change, trial point: |J x|^2 from the edge kernel (its |t_e|^2 sums), g.x and the step norms from the update kernel
+            hipLaunchKernelGGL(pg_edge_product_kernel, dim3(g->nb_edges), dim3(256), 0, g->st, g->m, g->ei, g->ej, g->Ji, g->Jj, g->x, g->u, g->part_b,
+                               (const PcgState*)nullptr);
+            hipLaunchKernelGGL(pg_update4_kernel, dim3(g->nb_nodes), dim3(256), 0, g->st, g->n, g->poses[g->cur], g->x, g->g, g->fixed, g->poses[nxt], g->part_u);
+            STBA_TRY(pg_linearize(g, nxt, false));
+            g->seq += 1.0;
+            if (!multi) {
+                hipLaunchKernelGGL(pg_trial_finish_kernel, dim3(1), dim3(256), 0, g->st, g->nb_edges, g->part_e, g->nb_edges, g->part_b, g->nb_nodes, g->part_u,
+                                   g->state, g->fin_dev, g->seq);
+            } else {
+                hipLaunchKernelGGL(pg_trial_finish_kernel, dim3(1), dim3(256), 0, g->st, g->nb_edges, g->part_e, g->nb_edges, g->part_b, g->nb_nodes, g->part_u,
+                                   g->state, g->scal_dev, g->seq);
+                if (g->ar(g->ar_user, g->scal_dev, 2, g->st) != 0) return fail(STBA_ERR_CALLBACK, "all-reduce hook failed");      // cost and |J x|^2 over the edge shards
+                hipLaunchKernelGGL(pg_export_kernel, dim3(1), dim3(64), 0, g->st, 8, g->scal_dev, g->fin_dev, g->seq);
             }
             STBA_HIP(hipGetLastError());
-            // one rank: the host looks at the chunk BEFORE the one it has just enqueued (the stream never runs dry; the kernels of a
-            // chunk enqueued past convergence return at once).  Several ranks: every rank must enqueue the same collectives, so the
-            // decision waits for the chunk itself -- the solve state is replicated and every rank sees the same `done`.
-            const int want = 1 + (multi ? enq : enq - todo);
-            STBA_TRY(pg_wait_mapped<int>(g, &g->exp_host->ticks, want, true));
-            if (g->exp_host->done) pcg_done = true;
+            STBA_TRY(pg_wait_mapped<double>(g, &fin[8], g->seq, false));
+            return STBA_OK;
+        };
+        const bool one_kernel = pp_ok && !g->pp_disabled;
+        if (one_kernel) STBA_TRY(pcg_one_kernel()); else STBA_TRY(pcg_by_launches());
+        STBA_TRY(trial_point());
+        if (one_kernel && fin[6] != (double)PP_TIMED_OUT) ++ps.one_kernel_solves;
+        if (one_kernel && fin[6] == (double)PP_TIMED_OUT) {
+            // a stamp never came: the workgroups were not all resident (another process on the device).  Once is enough: this
+            // engine solves with launches from here on, starting with this very iteration.
+            g->pp_disabled = true;
+            STBA_TRY(pcg_by_launches());
+            STBA_TRY(trial_point());
         }
-        // ---- model change, trial point: |J x|^2 from the edge kernel (its |t_e|^2 sums), g.x and the step norms from the update kernel
-        hipLaunchKernelGGL(pg_edge_product_kernel, dim3(g->nb_edges), dim3(256), 0, g->st, g->m, g->ei, g->ej, g->Ji, g->Jj, g->x, g->u, g->part_b,
-                           (const PcgState*)nullptr);
-        const int nxt = g->cur ^ 1;
-        hipLaunchKernelGGL(pg_update4_kernel, dim3(g->nb_nodes), dim3(256), 0, g->st, g->n, g->poses[g->cur], g->x, g->g, g->fixed, g->poses[nxt], g->part_u);
-        STBA_TRY(pg_linearize(g, nxt, false));
-        g->seq += 1.0;
-        if (!multi) {
-            hipLaunchKernelGGL(pg_trial_finish_kernel, dim3(1), dim3(256), 0, g->st, g->nb_edges, g->part_e, g->nb_edges, g->part_b, g->nb_nodes, g->part_u,
-                               g->state, g->fin_dev, g->seq);
-        } else {
-            hipLaunchKernelGGL(pg_trial_finish_kernel, dim3(1), dim3(256), 0, g->st, g->nb_edges, g->part_e, g->nb_edges, g->part_b, g->nb_nodes, g->part_u,
-                               g->state, g->scal_dev, g->seq);
-            if (g->ar(g->ar_user, g->scal_dev, 2, g->st) != 0) return fail(STBA_ERR_CALLBACK, "all-reduce hook failed");      // cost and |J x|^2 over the edge shards
-            hipLaunchKernelGGL(pg_export_kernel, dim3(1), dim3(64), 0, g->st, 8, g->scal_dev, g->fin_dev, g->seq);
-        }
-        STBA_HIP(hipGetLastError());
-        STBA_TRY(pg_wait_mapped<double>(g, &fin[8], g->seq, false));
         const double new_cost = 0.5 * fin[0], xhx = fin[1], gx = fin[2], step2 = fin[3], x2 = fin[4];
         const int k = (int)fin[5];
         const bool capped = fin[6] != 0.0;

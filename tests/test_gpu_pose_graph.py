@@ -133,3 +133,30 @@ def test_pg_config_c4_full_size(st, O, c4):
     # residual at the solution agrees with the oracle's evaluation of the same poses
     o = O.PG(poses, s["edge_i"], s["edge_j"], s["meas"], s["node_fixed"])
     assert abs(o.evaluate(jac=False)[0] - summ.final_cost) <= 1e-9 * summ.final_cost
+
+
+def test_pg_one_kernel_solve_and_the_way_back(st, O, c4):
+    """round 5: the PCG solve of an LM iteration as one persistent kernel (two stamped exchanges per iteration).  Same LM trace as four
+    launches per iteration (the PCG recurrences differ -- Chronopoulos-Gear -- so the bits do not have to agree, the iteration counts and
+    the converged quantities do); the summary says which path ran; and the time-out path: a solve that gives up is repeated with
+    launches and the result is the launches' own, bit for bit."""
+    s, gold = c4
+    res = {}
+    for mode in (1, 0, 2, 11):                 # (11: the one-kernel solve once more -- run to run it must give the same bits)
+        e = st.PGEngine(s["poses0"], s["edge_i"], s["edge_j"], s["meas"], s["node_fixed"])
+        summ, tr, pcg_total = e.solve(pcg=e.pcg_options(one_kernel_solve=mode % 10))
+        res[mode] = (summ, tr, pcg_total, e.get_poses(), e.pcg_summary())
+    assert np.array_equal(res[11][1], res[1][1]) and np.array_equal(res[11][3], res[1][3])
+    assert res[1][4].one_kernel_solves == res[1][4].solves > 0 and res[0][4].one_kernel_solves == 0 and res[2][4].one_kernel_solves == 0
+    assert res[1][0].num_iterations == res[0][0].num_iterations and abs(res[1][2] - res[0][2]) <= 0.05 * res[0][2]
+    assert np.allclose(res[1][1][:, 0], res[0][1][:, 0], rtol=1e-6) and pose_diff(res[1][3], res[0][3]) < 1e-6
+    assert np.array_equal(res[2][1], res[0][1]) and np.array_equal(res[2][3], res[0][3]) and res[2][2] == res[0][2]
+    # small graphs take the same path (3 groups of 8 nodes here) and follow the dense oracle
+    import importlib
+    scenes = importlib.import_module("slam-tricks_amd.scenes")
+    g = scenes.pose_graph_scene(n_nodes=24, loops_per_node=2, seed=2, sigma_t=0.02, sigma_r=0.004, turns=2)
+    e = st.PGEngine(g["poses0"], g["edge_i"], g["edge_j"], g["meas"], g["node_fixed"])
+    summ, tr, _ = e.solve(pcg=e.pcg_options(forcing_eta0=0.0))
+    so, tro = O.PG(g["poses0"], g["edge_i"], g["edge_j"], g["meas"], g["node_fixed"]).solve()
+    assert e.pcg_summary().one_kernel_solves == summ.num_iterations == so.num_iterations
+    assert np.allclose(tr[:, 0], tro[: len(tr), 0], rtol=1e-7)

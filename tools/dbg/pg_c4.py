@@ -5,7 +5,8 @@ import numpy as np
 st = importlib.import_module("slam-tricks_amd")
 scenes = importlib.import_module("slam-tricks_amd.scenes")
 s = scenes.pose_graph_scene(n_nodes=10000, loops_per_node=3, seed=4)
-for kw in (dict(), dict(coarse_refresh_every=2), dict(coarse_refresh_every=3), dict(coarse_refresh_every=4), dict(coarse_refresh_every=100), dict(check_every=2), dict(check_every=6)):
+KWS = (dict(), dict(one_kernel_solve=0), dict(forcing_eta0=0.0), dict(forcing_eta0=0.0, one_kernel_solve=0)) if os.environ.get('PG_AB') else (dict(), dict(coarse_refresh_every=2), dict(coarse_refresh_every=3), dict(coarse_refresh_every=4), dict(coarse_refresh_every=100), dict(check_every=2), dict(check_every=6))
+for kw in KWS:
     best = None
     for rep in range(3):
         e = st.PGEngine(s["poses0"], s["edge_i"], s["edge_j"], s["meas"], s["node_fixed"])

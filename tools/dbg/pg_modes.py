@@ -1,0 +1,19 @@
+"""C4 solve under stba_pcg_options::one_kernel_solve = 0 / 0 / 2 / 1 / 1: which runs agree bit for bit"""
+import importlib, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import numpy as np
+st = importlib.import_module("slam-tricks_amd")
+scenes = importlib.import_module("slam-tricks_amd.scenes")
+s = scenes.pose_graph_scene(n_nodes=int(sys.argv[1]) if len(sys.argv) > 1 else 10000, loops_per_node=3, seed=4)
+out = []
+for mode in (0, 0, 2, 2, 1, 1):
+    e = st.PGEngine(s["poses0"], s["edge_i"], s["edge_j"], s["meas"], s["node_fixed"])
+    summ, tr, tot = e.solve(pcg=e.pcg_options(one_kernel_solve=mode))
+    out.append((mode, tr.copy(), e.get_poses(), tot, e.pcg_summary().as_dict()))
+    print(mode, summ.num_iterations, tot, "%.15g" % summ.final_cost, out[-1][4]["one_kernel_solves"])
+for a in range(len(out)):
+    for b in range(a + 1, len(out)):
+        same = np.array_equal(out[a][1], out[b][1]) and np.array_equal(out[a][2], out[b][2])
+        d = np.abs(out[a][1][:, 0] - out[b][1][:, 0]) / out[a][1][:, 0]
+        print(out[a][0], out[b][0], "bitwise" if same else "differ: first trace row %d, max rel %.2e" % (int(np.argmax(d > 0)), d.max()))

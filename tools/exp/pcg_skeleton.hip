@@ -1,0 +1,111 @@
+// What would ONE persistent PCG solve of the C4 pose graph cost per iteration if it exchanged only what it must?  The communication
+// skeleton of a two-exchange (Chronopoulos-Gear) PCG iteration, no arithmetic worth the name:
+//   157 workgroups (one per group of 64 nodes = one coarse aggregate), 512 threads = one thread per edge END, the edge Jacobians would
+//   live in registers;
+//   exchange A: every thread reads the 6 doubles of its REMOTE node's z from the owner's slice (stamp of the owner awaited first);
+//   exchange B: every workgroup publishes 8 partial sums (2 dot products + 6 restricted entries), every workgroup reads all 157 x 8;
+//   then 384 doubles of the own z slice are published for the next iteration.
+// Data and stamps travel as agent-scope (sc1) stores and loads: write-through, no cache-wide fence, no L2 invalidate.
+// build: hipcc --offload-arch=gfx950 -O3 -o pcg_skeleton.bin pcg_skeleton.hip ; run: ./pcg_skeleton.bin
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+
+constexpr int G = 157, T = 512, NPG = 64, STAMP_STRIDE = 16;
+
+__device__ __forceinline__ int ld_stamp(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double ld_d(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_d(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+template <int MODE>   // 0: both exchanges; 1: exchange A only; 2: exchange B only
+__global__ __launch_bounds__(T) void skeleton(double* z /*[2][G*384]*/, double* part /*[2][G][8]*/, int* zstamp, int* pstamp, int iters,
+                                              int n_nodes, int hop, double* out, int* hung) {
+    __shared__ double red[T];
+    __shared__ double all[G * 8];
+    const int g = blockIdx.x, t = threadIdx.x;
+    const int own = g * NPG + (t >> 3);
+    int rem;
+    switch (t & 7) {
+        case 0: rem = own - 1; break;
+        case 1: rem = own + 1; break;
+        case 2: case 3: case 4: rem = own - hop + (t & 7) - 3; break;
+        default: rem = own + hop + (t & 7) - 6; break;
+    }
+    rem = min(max(rem, 0), n_nodes - 1);
+    const int rg = rem / NPG;
+    double acc = 0.0, zc = 1.0 + 1e-3 * t;
+    long long spins = 0;
+    for (int it = 1; it <= iters; ++it) {
+        double s = 0.0;
+        if (MODE != 2) {
+            // ---- exchange A: the remote node's z of iteration it - 1
+            while (ld_stamp(&zstamp[rg * STAMP_STRIDE]) < it - 1) { __builtin_amdgcn_s_sleep(1); if (++spins > (1ll << 24)) { *hung = 1; return; } }
+            const double* zr = z + (size_t)((it - 1) & 1) * G * 384 + (size_t)rem * 6;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) s += ld_d(zr + a);
+        }
+        red[t] = s + zc;
+        __syncthreads();
+        if ((t & 7) == 0) { double q = 0; for (int a = 0; a < 8; ++a) q += red[t + a]; red[t] = q; }      // (a node's edge ends)
+        __syncthreads();
+        if (MODE != 1) {
+            // ---- exchange B: 8 partial sums per workgroup, all-gathered
+            if (t < 8) { double q = 0; for (int a = t * 8; a < T; a += 64) q += red[a]; st_d(&part[((size_t)(it & 1) * G + g) * 8 + t], q); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+            __syncthreads();
+            if (t == 0) __hip_atomic_store(&pstamp[g * STAMP_STRIDE], it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t < G) {
+                while (ld_stamp(&pstamp[t * STAMP_STRIDE]) < it) { __builtin_amdgcn_s_sleep(1); if (++spins > (1ll << 24)) { *hung = 1; return; } }
+                const double* pp = part + ((size_t)(it & 1) * G + t) * 8;
+#pragma unroll
+                for (int a = 0; a < 8; ++a) all[t * 8 + a] = ld_d(pp + a);
+            }
+            __syncthreads();
+            double q = 0;
+            for (int a = t; a < 4 * G * 8; a += T) q += all[a % (G * 8)];      // (stands for the 6 x 942 coarse rows: ~11 multiply-adds per thread)
+            zc = 0.5 * zc + 1e-9 * q;
+        }
+        acc += zc;
+        // ---- publish the own slice of z for the next iteration
+        if (MODE != 2) {
+            if (t < 384) { st_d(z + (size_t)(it & 1) * G * 384 + (size_t)g * 384 + t, zc + 1e-6 * it); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+            __syncthreads();
+            if (t == 0) __hip_atomic_store(&zstamp[g * STAMP_STRIDE], it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    out[g * T + t] = acc;
+}
+
+template <int MODE>
+double run(int iters, int hop) {
+    const int n = G * NPG;
+    double *z, *part, *out; int *zs, *ps, *hung;
+    (void)hipMalloc(&z, sizeof(double) * 2 * G * 384); (void)hipMalloc(&part, sizeof(double) * 2 * G * 8); (void)hipMalloc(&out, sizeof(double) * G * T);
+    (void)hipMalloc(&zs, sizeof(int) * G * STAMP_STRIDE); (void)hipMalloc(&ps, sizeof(int) * G * STAMP_STRIDE); (void)hipMalloc(&hung, 4);
+    (void)hipMemset(z, 0, sizeof(double) * 2 * G * 384); (void)hipMemset(part, 0, sizeof(double) * 2 * G * 8);
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    float best = 1e30f;
+    for (int rep = 0; rep < 4; ++rep) {
+        (void)hipMemset(zs, 0, sizeof(int) * G * STAMP_STRIDE); (void)hipMemset(ps, 0, sizeof(int) * G * STAMP_STRIDE); (void)hipMemset(hung, 0, 4);
+        (void)hipDeviceSynchronize();
+        (void)hipEventRecord(e0);
+        skeleton<MODE><<<G, T>>>(z, part, zs, ps, iters, n, hop, out, hung);
+        (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+        int h; (void)hipMemcpy(&h, hung, 4, hipMemcpyDeviceToHost);
+        if (h) { printf("HUNG (mode %d)\n", MODE); return -1; }
+        if (rep && ms < best) best = ms;
+    }
+    (void)hipFree(z); (void)hipFree(part); (void)hipFree(out); (void)hipFree(zs); (void)hipFree(ps); (void)hipFree(hung);
+    return best;
+}
+
+int main() {
+    for (int hop : {1000, 64}) {
+        const double a1 = run<0>(1000, hop), a2 = run<0>(3000, hop);
+        const double b1 = run<1>(1000, hop), b2 = run<1>(3000, hop);
+        const double c1 = run<2>(1000, hop), c2 = run<2>(3000, hop);
+        printf("loop closures %4d nodes away: both exchanges %.2f us per iteration | neighbour exchange only %.2f | all-gather of partial sums only %.2f\n",
+               hop, (a2 - a1) / 2000 * 1e3, (b2 - b1) / 2000 * 1e3, (c2 - c1) / 2000 * 1e3);
+    }
+    return 0;
+}
