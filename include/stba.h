@@ -351,7 +351,10 @@ typedef struct {
     double forcing_eta_min;      /* 1e-10 */
     int    coarse_group;         /* nodes per group of the coarse space, a power of two; 0: automatic (<= 200 groups, >= 8 nodes);
                                   * -1: no coarse space (block Jacobi only, the round-3 preconditioner) */
-    int    coarse_refresh_every; /* 1: LM iterations between re-inversions of the coarse operator while only the damping changes */
+    int    coarse_refresh_every; /* 1: LM iterations between re-inversions of the coarse operator (the first two iterations always make theirs; an
+                                  * inverse made one iteration earlier still is a preconditioner, only a weaker one).  2 is FASTER at C4 since the PCG
+                                  * iteration costs 13 us instead of 44 (1270 against 1080 LM it/s) but its inexact steps end 3.9e-5 from the
+                                  * exact-step oracle's poses -- outside north_star's 1e-5 -- where 1 ends 2.5e-6 away: 1 stays the default */
     int    one_kernel_solve;     /* 1: the PCG solve of an LM iteration as ONE persistent kernel (two stamped exchanges per iteration
                                   * instead of four launches) where the graph allows: one rank, a coarse space of <= 256 groups of
                                   * <= 64 nodes; 0: always four launches per iteration; 2: as 1 with a time-out of zero, so that the way back is

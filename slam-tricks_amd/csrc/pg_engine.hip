@@ -922,6 +922,7 @@ struct PpArgs {
     int *ustamp, *pstamp;
     PcgState* state;
     long long spin_limit;
+    long long* tdbg;      // debug builds: time per phase (group 0), else null
 };
 
 inline size_t pp_lds_bytes(int na, int nc) { return ((size_t)2 * nc + (size_t)na * PP_SLOT + 768 + (size_t)PP_VCAP * 6 + 128 + 16) * sizeof(double); }
@@ -949,6 +950,11 @@ __global__ __launch_bounds__(256) void pg_offdiag_kernel(int m, const double* __
         }
 }
 
+#ifdef STBA_DEBUG_KNOBS
+#define PP_STAMP_T(i) do { if (a.tdbg && grp == 0 && t == 0) { const long long now_ = wall_clock64(); a.tdbg[i] += now_ - tlast; tlast = now_; } } while (0)
+#else
+#define PP_STAMP_T(i) do { } while (0)
+#endif
 __global__ __launch_bounds__(PP_T) void pg_pcg_persistent_kernel(PpArgs a) {
     extern __shared__ double pp_sm[];
     __shared__ int s_abort;
@@ -960,7 +966,7 @@ __global__ __launch_bounds__(PP_T) void pg_pcg_persistent_kernel(PpArgs a) {
     double* ul = gat + (size_t)na * PP_SLOT;  // [384]  this group's u (the diagonal term reads it)
     double* rl = ul + 384;                    // [384]  this group's r (block Jacobi reads a node's six)
     double* vbuf = rl + 384;                  // [PP_VCAP][6]  products of the edge ends
-    double* red = vbuf + (size_t)PP_VCAP * 6; // [8][16] per-wave partial sums
+    double* red = vbuf + (size_t)PP_VCAP * 6; // [128] scratch of the gathered sums
     double* sc = red + 128;                   // [16]  the group's sums | zc at 8..13
     if (t == 0) s_abort = 0;
     // ---- what a thread keeps for the whole solve
@@ -990,17 +996,32 @@ __global__ __launch_bounds__(PP_T) void pg_pcg_persistent_kernel(PpArgs a) {
         for (int rr_ = 0; rr_ < 6; ++rr_) acol[j][rr_] = (c < nc) ? a.Ainv[(size_t)(grp * 6 + rr_) * nc + c] : 0.0;
     }
     const size_t m2 = (size_t)a.node_start[n];        // edge ends = 2 m
+    const int rem0 = (c0 + t < c1) ? a.end_rem[c0 + t] : 0;
     __syncthreads();
 
-    // K values per thread -> the group's sums in sc[off .. off + K): a shuffle tree per wave, the eight waves in order
+    // K values per thread -> the group's sums in sc[off .. off + K).  Through LDS in three fixed steps (512 -> 32 -> 1 per value): a
+    // shuffle tree is a chain of ds_bpermute round trips, 6 per value -- 54 of them for the nine sums took 2 us of a 15 us iteration.
+    // The buffer is the edge ends' product buffer, which is spent whenever sums are made.
     auto group_sum = [&](const double* v, int K, int off) {
-        for (int k = 0; k < K; ++k) {
-            double y = v[k];
-            for (int d2 = 32; d2 > 0; d2 >>= 1) y += __shfl_down(y, d2, 64);
-            if (lane == 0) red[wv * 16 + k] = y;
+        double* tr = vbuf;                       // [K][PP_T]
+        double* p2 = vbuf + 9 * PP_T;            // [K][33]
+        __syncthreads();                         // (the last reader of the products is through)
+        for (int k = 0; k < K; ++k) tr[k * PP_T + t] = v[k];
+        __syncthreads();
+        if (t < K * 32) {
+            const int k = t >> 5, j = t & 31;
+            double y = 0.0;
+#pragma unroll
+            for (int i = 0; i < PP_T / 32; ++i) y += tr[k * PP_T + j + 32 * i];
+            p2[k * 33 + j] = y;
         }
         __syncthreads();
-        if (t < K) { double y = 0.0; for (int w2 = 0; w2 < PP_T / 64; ++w2) y += red[w2 * 16 + t]; sc[off + t] = y; }
+        if (t < K) {
+            double y = 0.0;
+#pragma unroll
+            for (int j = 0; j < 32; ++j) y += p2[t * 33 + j];
+            sc[off + t] = y;
+        }
         __syncthreads();
     };
     // exchange B: sc[0 .. K) of every group -> gat[group][0 .. K)
@@ -1023,13 +1044,21 @@ __global__ __launch_bounds__(PP_T) void pg_pcg_persistent_kernel(PpArgs a) {
         }
         __syncthreads();
     };
-    // a scalar of the gathered block summed over the groups (wave k sums entry k: the same order in every group)
+    // the first K entries of the gathered block summed over the groups (the same order in every group: every group gets the same bits)
     auto gathered_sums = [&](int K) {
-        if (wv < K) {
+        double* p2 = red;                        // [K][33]
+        if (t < K * 32) {
+            const int k = t >> 5, j = t & 31;
             double y = 0.0;
-            for (int j = lane; j < na; j += 64) y += gat[j * PP_SLOT + wv];
-            for (int d2 = 32; d2 > 0; d2 >>= 1) y += __shfl_xor(y, d2, 64);
-            if (lane == 0) sc[wv] = y;
+            for (int i = j; i < na; i += 32) y += gat[i * PP_SLOT + k];
+            p2[k * 33 + j] = y;
+        }
+        __syncthreads();
+        if (t < K) {
+            double y = 0.0;
+#pragma unroll
+            for (int j = 0; j < 32; ++j) y += p2[t * 33 + j];
+            sc[t] = y;
         }
         __syncthreads();
     };
@@ -1076,19 +1105,23 @@ __global__ __launch_bounds__(PP_T) void pg_pcg_persistent_kernel(PpArgs a) {
     coarse_and_u();
     double gamma_old = 1.0, alpha_old = 1.0;
     const size_t N6 = (size_t)n * 6;
+    long long tlast = wall_clock64();
+    (void)tlast;
     for (int k = 0;; ++k) {
+        PP_STAMP_T(6);
         // ---- exchange A: publish the group's u
         double* ub = a.ubuf + (size_t)(k & 1) * N6;
         if (act) { pp_st(ub + o, u); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
         if (t < 384) ul[t] = u;
         __syncthreads();
         if (t == 0) __hip_atomic_store(&a.ustamp[grp * PP_STAMP], a.base + k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        PP_STAMP_T(0);
         // ---- off-diagonal blocks times the remote ends' u
-        for (int c = c0 + t; c < c1; c += PP_T) {
+        for (int c = c0 + t, pass = 0; c < c1; c += PP_T, ++pass) {
             double B[36];
 #pragma unroll
             for (int b = 0; b < 36; ++b) B[b] = a.Bend[(size_t)b * m2 + c];
-            const int rem = a.end_rem[c];
+            const int rem = pass == 0 ? rem0 : a.end_rem[c];           // (the first pass's remote node is kept: one round trip less in front of the poll)
             const int* stamp = &a.ustamp[(rem >> a.log2agg) * PP_STAMP];
             bool ok = true;
             long long spins = 0;
@@ -1108,6 +1141,7 @@ __global__ __launch_bounds__(PP_T) void pg_pcg_persistent_kernel(PpArgs a) {
         }
         __syncthreads();
         if (s_abort) { finish(k, PP_TIMED_OUT, rr0, 0.0, tol2); return; }
+        PP_STAMP_T(1);
         w = 0.0;
         if (act) {
             for (int b = 0; b < 6; ++b) w += hrow[b] * ul[nl * 6 + b];
@@ -1119,7 +1153,9 @@ __global__ __launch_bounds__(PP_T) void pg_pcg_persistent_kernel(PpArgs a) {
             v[0] = r * u; v[1] = w * u; v[2] = r * r;
             for (int b = 0; b < 6; ++b) v[3 + b] = prow[b] * w;
             group_sum(v, 9, 0);
+            PP_STAMP_T(2);
             all_gather(k + 1, 9);
+            PP_STAMP_T(3);
             if (s_abort) { finish(k, PP_TIMED_OUT, rr0, 0.0, tol2); return; }
             gathered_sums(3);
         }
@@ -1140,7 +1176,9 @@ __global__ __launch_bounds__(PP_T) void pg_pcg_persistent_kernel(PpArgs a) {
         }
         gamma_old = gamma; alpha_old = alpha;
         __syncthreads();
+        PP_STAMP_T(4);
         coarse_and_u();
+        PP_STAMP_T(5);
     }
 }
 
@@ -1731,7 +1769,23 @@ int stba_pg_solve(stba_pg* g, const stba_lm_options* opt_in, const stba_pcg_opti
             a.node_start = g->node_start; a.end_rem = g->end_rem; a.Bend = g->Bend; a.Hd = g->Hd; a.d = g->d; a.Minv = g->Minv; a.AdP = g->AdP;
             a.Ainv = g->Ainv; a.g = g->g; a.x = g->x; a.ubuf = g->ubuf; a.pbuf = g->pbuf; a.ustamp = g->ustamp; a.pstamp = g->pstamp;
             a.state = g->state; a.spin_limit = pcg.one_kernel_solve == 2 ? 0 : 1ll << 18;      // (a poll is a memory round trip, ~1 us: a quarter of a second; 2: the test of the way back)
+            a.tdbg = nullptr;
+#ifdef STBA_DEBUG_KNOBS
+            static long long* tdbg_dev = nullptr;
+            if (knob_int("STBA_PP_TIMING", 0)) {
+                if (!tdbg_dev) { STBA_HIP(hipMalloc(&tdbg_dev, 8 * sizeof(long long))); STBA_HIP(hipMemset(tdbg_dev, 0, 8 * sizeof(long long))); }
+                a.tdbg = tdbg_dev;
+            }
+#endif
             hipLaunchKernelGGL(pg_pcg_persistent_kernel, dim3(g->na), dim3(PP_T), pp_lds_bytes(g->na, g->nc), g->st, a);
+#ifdef STBA_DEBUG_KNOBS
+            if (a.tdbg) {
+                long long h[8];
+                STBA_HIP(hipMemcpyAsync(h, tdbg_dev, sizeof h, hipMemcpyDeviceToHost, g->st)); STBA_HIP(hipStreamSynchronize(g->st));
+                fprintf(stderr, "pp phases (x 10 ns, cumulative): publish %lld | ends %lld | w+sum9 %lld | all-gather %lld | scalars+update %lld | coarse+u %lld | loop top %lld\n",
+                        h[0], h[1], h[2], h[3], h[4], h[5], h[6]);
+            }
+#endif
             STBA_HIP(hipGetLastError());
             g->pp_base += pcg.max_iterations + 8;
             return STBA_OK;

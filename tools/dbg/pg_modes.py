@@ -15,5 +15,6 @@ for mode in (0, 0, 2, 2, 1, 1):
 for a in range(len(out)):
     for b in range(a + 1, len(out)):
         same = np.array_equal(out[a][1], out[b][1]) and np.array_equal(out[a][2], out[b][2])
-        d = np.abs(out[a][1][:, 0] - out[b][1][:, 0]) / out[a][1][:, 0]
+        nn = min(len(out[a][1]), len(out[b][1]))
+        d = np.abs(out[a][1][:nn, 0] - out[b][1][:nn, 0]) / out[a][1][:nn, 0]
         print(out[a][0], out[b][0], "bitwise" if same else "differ: first trace row %d, max rel %.2e" % (int(np.argmax(d > 0)), d.max()))
