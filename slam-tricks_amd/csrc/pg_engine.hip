@@ -526,85 +526,100 @@ __global__ __launch_bounds__(256) void pg_coarse_basis_kernel(int n, int agg, co
 }
 
 // Galerkin coarse matrix without the damping term, Ac0 = P^T J^T J P (nc x nc, dense): one workgroup per group of nodes
-// = six rows of Ac0.  Every edge END of the group's nodes is one work item: with G_s = J_self P_self, G_o = J_other P_other
-// it adds G_s^T G_s to the diagonal block and G_s^T G_o to block (group, group of the other node) -- the other end does the
-// same from its side, so the four blocks of an edge are all made and no workgroup writes another one's rows.  The row panel
-// is accumulated in LDS (ds_add_f64; the diagonal block, which every item adds to, as register sums + a shuffle tree first)
-// and written once, zeros included: no global atomics, no memset.
-__global__ __launch_bounds__(256) void pg_coarse_build_kernel(int n, int m, int agg, int nc, const int* __restrict__ node_start,
-                                                              const int* __restrict__ end_code, const int* __restrict__ end_node,
-                                                              const int* __restrict__ ei, const int* __restrict__ ej,
-                                                              const double* __restrict__ Ji, const double* __restrict__ Jj,
+// = six rows of Ac0, from the ASSEMBLED blocks (round 5; until then every edge end re-made G = J P from two scattered Jacobians, 71 us):
+//   the diagonal block of the group gets  sum over its nodes of P_i^T Hd_i P_i  (Hd_i = the node's diagonal block of J^T J, which
+//   the linearisation leaves) and, for every edge end whose other node lies in the same group, P_s^T B P_o;
+//   block (group, group of the other node) gets P_s^T B P_o for every other end -- B = J_s^T J_o is the end's block of
+//   pg_offdiag_kernel, read coalesced in CSR order.  The other end does the same from its side, so the four blocks of an edge are
+//   all made and no workgroup writes another one's rows.
+// The row panel is accumulated in LDS and written once, zeros included: no global atomics, no memset.
+// REPRODUCIBLE sums (round 5; until then the four waves added to the panel in arrival order and the preconditioner -- hence every
+// PCG iterate -- differed in the last bits from run to run): every block of the panel is added to by ONE wave, the wave
+// (other group) mod 4, whose adds meet an LDS address in program and lane order.  Each wave first collects ITS ends, in CSR order,
+// into a list of its own (ballot + prefix count), then works through the list with all lanes.
+// Several ranks (edge shards): Hd is the cross-rank sum, so only rank 0 adds the nodes' term (add_nodes).
+__global__ __launch_bounds__(256) void pg_coarse_build_kernel(int n, int agg, int nc, int add_nodes, const int* __restrict__ node_start,
+                                                              const int* __restrict__ end_node, const int* __restrict__ end_rem,
+                                                              const double* __restrict__ Bend, const double* __restrict__ Hd,
                                                               const double* __restrict__ AdP, double* __restrict__ Ac0) {
     extern __shared__ double rowp[];            // [6][nc] | four lists of edge ends (int)
     __shared__ double dgp[4][36];
+    __shared__ double dnode[64][37];
     const int a = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
     for (int q = t; q < 6 * nc; q += 256) rowp[q] = 0.0;
     const int k0 = a * agg, k1 = min(n, k0 + agg);
     const int c0 = node_start[k0], c1 = node_start[k1];
-    // REPRODUCIBLE sums (round 5; until then the four waves added to the row panel in arrival order and the preconditioner -- hence
-    // every PCG iterate -- differed in the last bits from run to run): every block of the panel is added to by ONE wave, the wave
-    // (other group) mod 4, whose adds meet an LDS address in program and lane order.  Each wave first collects ITS ends, in CSR
-    // order, into a list of its own (ballot + prefix count), then works through the list with all lanes.
+    const size_t m2 = (size_t)node_start[n];
     int* mylist = reinterpret_cast<int*>(rowp + (size_t)6 * nc) + (size_t)wv * (c1 - c0);
     int cnt = 0;
     for (int cb = c0; cb < c1; cb += 64) {
         const int c = cb + lane;
-        bool mine = false;
-        if (c < c1) {
-            const int code = end_code[c], e = code >> 1;
-            const int other = (code & 1) ? ei[e] : ej[e];
-            mine = ((other / agg) & 3) == wv;
-        }
+        const bool mine = c < c1 && ((end_rem[c] / agg) & 3) == wv;
         const unsigned long long bal = __ballot(mine);
         if (mine) mylist[cnt + __popcll(bal & ((1ull << lane) - 1ull))] = c;
         cnt += __popcll(bal);
+    }
+    // the nodes' term: one node per thread (groups of more than 64 nodes: in rounds), summed over the nodes in order below
+    double dsum = 0.0;                          // thread q < 36: entry q of the diagonal block
+    for (int base = k0; base < k1; base += 64) {
+        __syncthreads();
+        const int node = base + t;
+        if (t < 64) {
+            double M[36];
+            for (int q = 0; q < 36; ++q) M[q] = 0.0;
+            if (node < k1 && add_nodes) {
+                double H[36], P[36], T[36];
+                for (int q = 0; q < 36; ++q) { H[q] = Hd[(size_t)node * 36 + q]; P[q] = AdP[(size_t)node * 36 + q]; }
+                for (int i = 0; i < 6; ++i)
+                    for (int j = 0; j < 6; ++j) {
+                        double s2 = 0.0;
+                        for (int q = 0; q < 6; ++q) s2 += H[i * 6 + q] * P[q * 6 + j];
+                        T[i * 6 + j] = s2;
+                    }
+                for (int u = 0; u < 6; ++u)
+                    for (int v = 0; v < 6; ++v) {
+                        double s2 = 0.0;
+                        for (int q = 0; q < 6; ++q) s2 += P[q * 6 + u] * T[q * 6 + v];
+                        M[u * 6 + v] = s2;
+                    }
+            }
+            for (int q = 0; q < 36; ++q) dnode[t][q] = M[q];
+        }
+        __syncthreads();
+        if (t < 36) for (int i = 0; i < 64; ++i) dsum += dnode[i][t];
     }
     __syncthreads();
     double dg[36];
     for (int q = 0; q < 36; ++q) dg[q] = 0.0;
     for (int idx = lane; idx < cnt; idx += 64) {
         const int c = mylist[idx];
-        const int self = end_node[c], code = end_code[c], e = code >> 1, side = code & 1;
-        const int other = side ? ei[e] : ej[e];
-        const double* Js = (side ? Jj : Ji) + e;
-        const double* Jo = (side ? Ji : Jj) + e;
-        double Gs[36], Go[36];
-        {
-            double J[36], P[36];
-            for (int q = 0; q < 36; ++q) { J[q] = Js[(size_t)q * m]; P[q] = AdP[(size_t)self * 36 + q]; }
-            for (int i = 0; i < 6; ++i)
-                for (int j = 0; j < 6; ++j) {
-                    double s = 0.0;
-                    for (int q = 0; q < 6; ++q) s += J[i * 6 + q] * P[q * 6 + j];
-                    Gs[i * 6 + j] = s;
-                }
-            for (int q = 0; q < 36; ++q) { J[q] = Jo[(size_t)q * m]; P[q] = AdP[(size_t)other * 36 + q]; }
-            for (int i = 0; i < 6; ++i)
-                for (int j = 0; j < 6; ++j) {
-                    double s = 0.0;
-                    for (int q = 0; q < 6; ++q) s += J[i * 6 + q] * P[q * 6 + j];
-                    Go[i * 6 + j] = s;
-                }
-        }
+        const int self = end_node[c], other = end_rem[c];
+        double B[36], P[36], T[36];
+        for (int q = 0; q < 36; ++q) { B[q] = Bend[(size_t)q * m2 + c]; P[q] = AdP[(size_t)other * 36 + q]; }
+        for (int i = 0; i < 6; ++i)               // T = B P_o
+            for (int j = 0; j < 6; ++j) {
+                double s2 = 0.0;
+                for (int q = 0; q < 6; ++q) s2 += B[i * 6 + q] * P[q * 6 + j];
+                T[i * 6 + j] = s2;
+            }
+        for (int q = 0; q < 36; ++q) P[q] = AdP[(size_t)self * 36 + q];
         const int ao = other / agg;
         for (int u = 0; u < 6; ++u)
             for (int v = 0; v < 6; ++v) {
-                double ss = 0.0, so = 0.0;
-                for (int q = 0; q < 6; ++q) { ss += Gs[q * 6 + u] * Gs[q * 6 + v]; so += Gs[q * 6 + u] * Go[q * 6 + v]; }
-                dg[u * 6 + v] += ss;
+                double so = 0.0;
+                for (int q = 0; q < 6; ++q) so += P[q * 6 + u] * T[q * 6 + v];
                 if (ao == a) dg[u * 6 + v] += so;
                 else unsafeAtomicAdd(&rowp[u * nc + 6 * ao + v], so);
             }
     }
-    // the diagonal block, which every end adds to: register sums, a shuffle tree per wave, the four waves in order
+    // the diagonal block: the waves' register sums through a shuffle tree each, the four waves in order, then the nodes' term
     for (int q = 0; q < 36; ++q) {
         double v = dg[q];
         for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
         if (lane == 0) dgp[wv][q] = v;
     }
     __syncthreads();
-    if (t < 36) rowp[(t / 6) * nc + 6 * a + (t % 6)] = (dgp[0][t] + dgp[1][t]) + (dgp[2][t] + dgp[3][t]);
+    if (t < 36) rowp[(t / 6) * nc + 6 * a + (t % 6)] = ((dgp[0][t] + dgp[1][t]) + (dgp[2][t] + dgp[3][t])) + dsum;
     __syncthreads();
     for (int q = t; q < 6 * nc; q += 256) Ac0[(size_t)(6 * a + q / nc) * nc + (q % nc)] = rowp[q];
 }
@@ -958,7 +973,7 @@ __global__ __launch_bounds__(256) void pg_offdiag_kernel(int m, const double* __
 __global__ __launch_bounds__(PP_T) void pg_pcg_persistent_kernel(PpArgs a) {
     extern __shared__ double pp_sm[];
     __shared__ int s_abort;
-    const int t = threadIdx.x, grp = blockIdx.x, lane = t & 63, wv = t >> 6;
+    const int t = threadIdx.x, grp = blockIdx.x;
     const int n = a.n, agg = a.agg, na = a.na, nc = a.nc;
     double* rc = pp_sm;                       // [nc]   coarse residual P^T r, replicated in every group
     double* pts = rc + nc;                    // [nc]   P^T s
@@ -1381,7 +1396,7 @@ static int pg_setup_coarse(stba_pg* g, int group_opt) {
     int max_ends = 0;
     for (int a = 0; a < na; ++a)
         max_ends = std::max(max_ends, g->h_node_start[(size_t)std::min(g->n, (a + 1) * agg)] - g->h_node_start[(size_t)std::min(g->n, a * agg)]);
-    if ((size_t)6 * nc * sizeof(double) + (size_t)4 * max_ends * sizeof(int) > 150 * 1024)
+    if ((size_t)6 * nc * sizeof(double) + (size_t)4 * max_ends * sizeof(int) > 136 * 1024)       // (+ 20 KB static in pg_coarse_build_kernel)
         return fail(STBA_ERR_INVALID_ARGUMENT, "stba_pg_solve: coarse space too large for this group size");
     auto F = [](void* p) { if (p) (void)hipFree(p); };
     F(g->AdP); F(g->Ac0); F(g->W); F(g->Ainv); F(g->inv_work); F(g->rc_part); F(g->zc); F(g->part_cz); F(g->Dc);
@@ -1393,7 +1408,7 @@ static int pg_setup_coarse(stba_pg* g, int group_opt) {
     STBA_HIP(hipMemsetAsync(g->rc_part, 0, (size_t)na * parts * 6 * sizeof(double), g->st));
     static DeviceOnce attr;
     STBA_TRY(attr.run([]() -> int {
-        STBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pg_coarse_build_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        STBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pg_coarse_build_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024));
         return STBA_OK;
     }));
     g->agg = agg; g->na = na; g->nc = nc; g->np = np; g->parts = parts; g->max_group_ends = max_ends;
@@ -1638,8 +1653,12 @@ int stba_pg_solve(stba_pg* g, const stba_lm_options* opt_in, const stba_pcg_opti
         hipLaunchKernelGGL(pg_gnorm_kernel, dim3(g->nb_vec), dim3(256), 0, g->st, N, g->g, g->part_c);
         if (coarse) {
             hipLaunchKernelGGL(pg_coarse_basis_kernel, dim3(g->nb_nodes), dim3(256), 0, g->st, g->n, g->agg, g->poses[g->cur], g->fixed, g->AdP);
-            hipLaunchKernelGGL(pg_coarse_build_kernel, dim3(g->na), dim3(256), (size_t)6 * g->nc * sizeof(double) + (size_t)4 * g->max_group_ends * sizeof(int), g->st, g->n, g->m, g->agg, g->nc,
-                               g->node_start, g->end_code, g->end_node, g->ei, g->ej, g->Ji, g->Jj, g->AdP, g->Ac0);
+            if (!g->bend_valid) {
+                hipLaunchKernelGGL(pg_offdiag_kernel, dim3(g->nb_edges), dim3(256), 0, g->st, g->m, g->Ji, g->Jj, g->end_pos, g->Bend);
+                g->bend_valid = true;
+            }
+            hipLaunchKernelGGL(pg_coarse_build_kernel, dim3(g->na), dim3(256), (size_t)6 * g->nc * sizeof(double) + (size_t)4 * g->max_group_ends * sizeof(int), g->st, g->n, g->agg, g->nc,
+                               (!g->ar || g->rank == 0) ? 1 : 0, g->node_start, g->end_node, g->end_rem, g->Bend, g->Hd, g->AdP, g->Ac0);
             if (g->ar && g->ar(g->ar_user, g->Ac0, (size_t)g->nc * g->nc, g->st) != 0) return fail(STBA_ERR_CALLBACK, "all-reduce hook failed");
             g->coarse_valid = false;
         }
