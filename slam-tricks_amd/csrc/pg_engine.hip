@@ -1136,7 +1136,11 @@ __global__ __launch_bounds__(PP_T) void pg_pcg_persistent_kernel(PpArgs a) {
             double B[36];
 #pragma unroll
             for (int b = 0; b < 36; ++b) B[b] = a.Bend[(size_t)b * m2 + c];
-            const int rem = pass == 0 ? rem0 : a.end_rem[c];           // (the first pass's remote node is kept: one round trip less in front of the poll)
+            // (the first pass's remote node is kept: one round trip less in front of the poll.  Half the groups have more than 512 ends
+            // at C4 and make a second trip; measured and not kept: both trips' stamps polled together and the block loads behind the
+            // poll, 1070 against 1090 LM it/s -- the loads no longer overlap the wait; both ends' blocks in flight at once: 184-472
+            // bytes of scratch per lane, 780 LM it/s)
+            const int rem = pass == 0 ? rem0 : a.end_rem[c];
             const int* stamp = &a.ustamp[(rem >> a.log2agg) * PP_STAMP];
             bool ok = true;
             long long spins = 0;
