@@ -17,9 +17,13 @@ __device__ __forceinline__ int ld_stamp(const int* p) { return __hip_atomic_load
 __device__ __forceinline__ double ld_d(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_d(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+__device__ __forceinline__ double expect_z(int it, int node, int a) { return 1.0 + 1e-3 * it + 1e-6 * node + 1e-9 * a; }
+__device__ __forceinline__ double expect_p(int it, int g, int a) { return 2.0 + 1e-3 * it + 1e-6 * g + 1e-9 * a; }
+
+// (every value a reader accepts behind a stamp is CHECKED against what the writer must have written: `stale` counts the misses)
 template <int MODE>   // 0: both exchanges; 1: exchange A only; 2: exchange B only
 __global__ __launch_bounds__(T) void skeleton(double* z /*[2][G*384]*/, double* part /*[2][G][8]*/, int* zstamp, int* pstamp, int iters,
-                                              int n_nodes, int hop, double* out, int* hung) {
+                                              int n_nodes, int hop, double* out, int* hung, unsigned long long* stale) {
     __shared__ double red[T];
     __shared__ double all[G * 8];
     const int g = blockIdx.x, t = threadIdx.x;
@@ -35,6 +39,7 @@ __global__ __launch_bounds__(T) void skeleton(double* z /*[2][G*384]*/, double* 
     const int rg = rem / NPG;
     double acc = 0.0, zc = 1.0 + 1e-3 * t;
     long long spins = 0;
+    unsigned long long bad = 0;
     for (int it = 1; it <= iters; ++it) {
         double s = 0.0;
         if (MODE != 2) {
@@ -42,7 +47,7 @@ __global__ __launch_bounds__(T) void skeleton(double* z /*[2][G*384]*/, double* 
             while (ld_stamp(&zstamp[rg * STAMP_STRIDE]) < it - 1) { __builtin_amdgcn_s_sleep(1); if (++spins > (1ll << 24)) { *hung = 1; return; } }
             const double* zr = z + (size_t)((it - 1) & 1) * G * 384 + (size_t)rem * 6;
 #pragma unroll
-            for (int a = 0; a < 6; ++a) s += ld_d(zr + a);
+            for (int a = 0; a < 6; ++a) { const double v = ld_d(zr + a); if (it > 1 && v != expect_z(it - 1, rem, a)) ++bad; s += v; }
         }
         red[t] = s + zc;
         __syncthreads();
@@ -50,14 +55,14 @@ __global__ __launch_bounds__(T) void skeleton(double* z /*[2][G*384]*/, double* 
         __syncthreads();
         if (MODE != 1) {
             // ---- exchange B: 8 partial sums per workgroup, all-gathered
-            if (t < 8) { double q = 0; for (int a = t * 8; a < T; a += 64) q += red[a]; st_d(&part[((size_t)(it & 1) * G + g) * 8 + t], q); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+            if (t < 8) { double q = 0; for (int a = t * 8; a < T; a += 64) q += red[a]; st_d(&part[((size_t)(it & 1) * G + g) * 8 + t], expect_p(it, g, t) + 0.0 * q); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
             __syncthreads();
             if (t == 0) __hip_atomic_store(&pstamp[g * STAMP_STRIDE], it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (t < G) {
                 while (ld_stamp(&pstamp[t * STAMP_STRIDE]) < it) { __builtin_amdgcn_s_sleep(1); if (++spins > (1ll << 24)) { *hung = 1; return; } }
                 const double* pp = part + ((size_t)(it & 1) * G + t) * 8;
 #pragma unroll
-                for (int a = 0; a < 8; ++a) all[t * 8 + a] = ld_d(pp + a);
+                for (int a = 0; a < 8; ++a) { const double v = ld_d(pp + a); if (v != expect_p(it, t, a)) ++bad; all[t * 8 + a] = v; }
             }
             __syncthreads();
             double q = 0;
@@ -67,12 +72,13 @@ __global__ __launch_bounds__(T) void skeleton(double* z /*[2][G*384]*/, double* 
         acc += zc;
         // ---- publish the own slice of z for the next iteration
         if (MODE != 2) {
-            if (t < 384) { st_d(z + (size_t)(it & 1) * G * 384 + (size_t)g * 384 + t, zc + 1e-6 * it); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+            if (t < 384) { st_d(z + (size_t)(it & 1) * G * 384 + (size_t)g * 384 + t, expect_z(it, g * NPG + t / 6, t % 6) + 0.0 * zc); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
             __syncthreads();
             if (t == 0) __hip_atomic_store(&zstamp[g * STAMP_STRIDE], it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     out[g * T + t] = acc;
+    if (bad) atomicAdd(stale, bad);
 }
 
 // ---- the same two exchanges WITHOUT stamps: every double travels as a 16-byte (value, round) pair, one global_store_dwordx4 /
@@ -90,8 +96,6 @@ __device__ __forceinline__ double2v ld_pair(const double2v* p) {
     asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(x) : "v"(p) : "memory");
     return x;
 }
-__device__ __forceinline__ double expect_z(int it, int node, int a) { return 1.0 + 1e-3 * it + 1e-6 * node + 1e-9 * a; }
-__device__ __forceinline__ double expect_p(int it, int g, int a) { return 2.0 + 1e-3 * it + 1e-6 * g + 1e-9 * a; }
 
 __global__ __launch_bounds__(T) void skeleton_tagged(double2v* z /*[2][G*384]*/, double2v* part /*[2][G][8]*/, int iters, int n_nodes, int hop,
                                                      double* out, int* hung, unsigned long long* torn) {
@@ -175,10 +179,12 @@ double run_tagged(int iters, int hop, unsigned long long* torn_out) {
     return best;
 }
 
+unsigned long long g_stale = 0;
 template <int MODE>
 double run(int iters, int hop) {
     const int n = G * NPG;
-    double *z, *part, *out; int *zs, *ps, *hung;
+    double *z, *part, *out; int *zs, *ps, *hung; unsigned long long* stale;
+    (void)hipMalloc(&stale, 8); (void)hipMemset(stale, 0, 8);
     (void)hipMalloc(&z, sizeof(double) * 2 * G * 384); (void)hipMalloc(&part, sizeof(double) * 2 * G * 8); (void)hipMalloc(&out, sizeof(double) * G * T);
     (void)hipMalloc(&zs, sizeof(int) * G * STAMP_STRIDE); (void)hipMalloc(&ps, sizeof(int) * G * STAMP_STRIDE); (void)hipMalloc(&hung, 4);
     (void)hipMemset(z, 0, sizeof(double) * 2 * G * 384); (void)hipMemset(part, 0, sizeof(double) * 2 * G * 8);
@@ -188,24 +194,35 @@ double run(int iters, int hop) {
         (void)hipMemset(zs, 0, sizeof(int) * G * STAMP_STRIDE); (void)hipMemset(ps, 0, sizeof(int) * G * STAMP_STRIDE); (void)hipMemset(hung, 0, 4);
         (void)hipDeviceSynchronize();
         (void)hipEventRecord(e0);
-        skeleton<MODE><<<G, T>>>(z, part, zs, ps, iters, n, hop, out, hung);
+        skeleton<MODE><<<G, T>>>(z, part, zs, ps, iters, n, hop, out, hung, stale);
         (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
         float ms; (void)hipEventElapsedTime(&ms, e0, e1);
         int h; (void)hipMemcpy(&h, hung, 4, hipMemcpyDeviceToHost);
         if (h) { printf("HUNG (mode %d)\n", MODE); return -1; }
         if (rep && ms < best) best = ms;
     }
-    (void)hipFree(z); (void)hipFree(part); (void)hipFree(out); (void)hipFree(zs); (void)hipFree(ps); (void)hipFree(hung);
+    unsigned long long st = 0; (void)hipMemcpy(&st, stale, 8, hipMemcpyDeviceToHost); g_stale += st;
+    (void)hipFree(z); (void)hipFree(part); (void)hipFree(out); (void)hipFree(zs); (void)hipFree(ps); (void)hipFree(hung); (void)hipFree(stale);
     return best;
 }
 
 int main() {
     for (int hop : {1000, 64}) {
+        const unsigned long long s0 = g_stale;
         const double a1 = run<0>(1000, hop), a2 = run<0>(3000, hop);
-        const double b1 = run<1>(1000, hop), b2 = run<1>(3000, hop);
+        const unsigned long long s1 = g_stale;
+        const double b1 = run<1>(1000, hop), b2 = run<1>(3000, hop);      // (without exchange B a workgroup may run two rounds ahead of one that does not feed it: its misses do not count)
+        const unsigned long long s2 = g_stale;
         const double c1 = run<2>(1000, hop), c2 = run<2>(3000, hop);
+        printf("   values not what the writer wrote: both exchanges %llu | neighbour exchange only %llu (unordered without B) | all-gather only %llu\n", s1 - s0, s2 - s1, g_stale - s2);
         printf("loop closures %4d nodes away: both exchanges %.2f us per iteration | neighbour exchange only %.2f | all-gather of partial sums only %.2f\n",
                hop, (a2 - a1) / 2000 * 1e3, (b2 - b1) / 2000 * 1e3, (c2 - c1) / 2000 * 1e3);
+    }
+    {   // a long run of the stamped form, every accepted value checked
+        const unsigned long long s0 = g_stale;
+        (void)run<0>(50000, 1000);
+        printf("stamped exchanges, a long run: %.1f million values accepted behind a stamp, %llu of them not what the writer wrote\n",
+               4.0 * 50000 * (G * 512.0 * 6 + G * (double)G * 8) / 1e6, g_stale - s0);
     }
     for (int hop : {1000, 64}) {
         unsigned long long t1 = 0, t2 = 0;
