@@ -711,6 +711,20 @@ inline bool ProbeReprojectionValue(const CostFunction* cost, double* feature) {
     return true;
 }
 
+// value check of one residual block AT ITS OWN DATA: the parameter values the block holds right now.  The generic probe points can
+// miss a cost that departs from the reprojection factor only where ITS data lie (a clamp far off the image, a robust weight): the
+// point that matters is the one the solve starts from -- checked for every recognised block before the solve -- and the one it ends
+// at -- checked after it (VerifyRecognisedBlocks).
+inline bool ReprojectionValueAtData(const CostFunction* cost, const double* q, const double* t, const double* L, const double* feature) {
+    const double* p[3] = {q, t, L};
+    double r[2] = {0, 0}, proj[2];
+    if (!cost->Evaluate(p, r, nullptr)) return false;
+    ReprojectionAt(q, t, L, proj);
+    for (int i = 0; i < 2; ++i)
+        if (!(std::fabs(r[i] - (proj[i] - feature[i])) <= 1e-11 * (1.0 + std::fabs(proj[i]) + std::fabs(feature[i])))) return false;
+    return true;
+}
+
 // derivative check, once per cost-function TYPE: the ambient Jacobians the user's Evaluate returns, composed
 // with the quaternion right-plus chart, must equal the closed form the HIP kernel evaluates
 // (A hat(pInC) | -A R^T | A R^T, A = d proj / d pInC; SURVEY.md header fact 2).
@@ -767,6 +781,8 @@ inline bool DetectBa(Problem& p, BaLayout* L, bool probe = true) {
         else {
             // the user's own cost function (test_ceres.h:111-121): accepted iff it IS the reprojection factor
             if (!ProbeReprojectionValue(r.cost, feature)) return false;
+            if (r.blocks.size() != 3 || !ReprojectionValueAtData(r.cost, p.blocks()[r.blocks[0]].ptr, p.blocks()[r.blocks[1]].ptr,
+                                                                p.blocks()[r.blocks[2]].ptr, feature)) return false;
             const std::type_index ti(typeid(*r.cost));
             if (!checked_types.count(ti)) {
                 if (!ProbeReprojectionJacobian(r.cost)) return false;
@@ -1077,16 +1093,48 @@ inline void Solve(const Solver::Options& options, Problem* problem, Solver::Summ
     *summary = Solver::Summary();
     internal::BaLayout L;
     // CONTRACT of the recognition (DetectBa): a user cost function is replaced by the built-in device factor if it equals
-    // proj(conj(q)(L - t)) - feature at four probe points, one of them behind the camera (1e-12) and, once per C++ type, its Jacobian equals the closed form
-    // at one of them (1e-9).  A cost that agrees there and differs elsewhere (a clamp that only fires far off the image, say)
-    // would be replaced silently: Solver::Options::force_callback_path = true (or STBA_CERES_FORCE_CALLBACK=1 in the
-    // environment) keeps every block on the generic path, where the user's Evaluate is what runs.
+    // proj(conj(q)(L - t)) - feature at four generic probe points, one of them behind the camera (1e-12), AT ITS OWN DATA -- the
+    // parameter values the block holds when Solve is called (1e-11) -- and, once per C++ type, its Jacobian equals the closed form at a
+    // probe point (1e-9).  After the solve every recognised block is evaluated once more, at the point the solve ENDED at: a cost
+    // that departed from the factor on the way is solved again with its own code (below).  What remains unchecked is a cost that
+    // differs from the factor only at iterates in between; Solver::Options::force_callback_path = true (or
+    // STBA_CERES_FORCE_CALLBACK=1 in the environment) keeps every block on the generic path, where the user's Evaluate is what runs.
+    // The summary's message names the number of blocks taken over.
     const char* fe = std::getenv("STBA_CERES_FORCE_CALLBACK");
     const bool force_cb = options.force_callback_path || (fe && *fe && *fe != '0');
     bool ba = !force_cb && internal::DetectBa(*problem, &L);
     if (ba)
         for (int rb : L.rot_block) ba = ba && internal::UsesQuaternionRightPlus(problem->blocks()[rb].local);
-    if (ba) { summary->execution_path = "gpu-ba"; internal::SolveBa(options, problem, L, summary); return; }
+    if (ba) {
+        // The recognised blocks are checked at their own data before the solve (DetectBa) and AFTER it, at the point the solve ends at:
+        // a user cost that is the reprojection factor at the probe points and at the start but departs from it on the way (a clamp, a
+        // robust weight that sets in) is caught here -- the parameters go back to where they were and the problem is solved again with
+        // the user's own Evaluate on the host-linearised device path.  The summary's message says which of the two happened.
+        std::vector<std::vector<double>> saved;
+        size_t n_user = 0;
+        for (auto& r : problem->residuals()) if (!dynamic_cast<ReprojectionFactor*>(r.cost)) ++n_user;
+        if (n_user) for (auto& b : problem->blocks()) saved.emplace_back(b.ptr, b.ptr + b.size);
+        summary->execution_path = "gpu-ba";
+        internal::SolveBa(options, problem, L, summary);
+        bool still = true;
+        if (n_user && summary->termination_type != FAILURE) {
+            size_t k = 0;
+            for (auto& r : problem->residuals()) {
+                if (!dynamic_cast<ReprojectionFactor*>(r.cost) &&
+                    !internal::ReprojectionValueAtData(r.cost, problem->blocks()[r.blocks[0]].ptr, problem->blocks()[r.blocks[1]].ptr,
+                                                       problem->blocks()[r.blocks[2]].ptr, &L.feat[2 * k])) { still = false; break; }
+                ++k;
+            }
+        }
+        if (still) {
+            if (n_user) summary->message += (summary->message.empty() ? "" : " ") + std::to_string(n_user) +
+                                            " user cost functions recognised as the reprojection factor (probe points, start point, end point) and evaluated by the device kernel.";
+            return;
+        }
+        for (size_t i = 0; i < saved.size(); ++i) std::copy(saved[i].begin(), saved[i].end(), problem->blocks()[i].ptr);
+        *summary = Solver::Summary();
+        summary->message = "a user cost function taken for the reprojection factor differs from it at the solution: solved again with the user's Evaluate.";
+    }
     // BA-SHAPED, but not (or not to be taken for) the built-in factor: every residual block is {quaternion 4, position 3,
     // landmark 3} -> 2 with the quaternion right-plus chart.  The user's cost functions are evaluated on the host, in bulk, into
     // the device engine's residual / Jacobian buffers, and the Schur complement, the factorisation, the back-substitution and the

@@ -185,6 +185,45 @@ struct ScaledProjectFactor {
     }
 };
 
+// The reprojection factor EXCEPT where the landmark lies further than `far` from the origin: there the residual is doubled.  With `far`
+// beyond every generic probe point this functor passes the probes; it is caught at its own DATA (DetectBa evaluates every recognised
+// block at the parameter values it holds) and keeps its own code ("gpu-ba-hostjac").
+struct FarScaledProjectFactor {
+    double feature[2], far2;
+    FarScaledProjectFactor(const double* f, double far) { feature[0] = f[0]; feature[1] = f[1]; far2 = far * far; }
+    static auto Create(const double* f, double far) { return new ceres::DynamicAutoDiffCostFunction<FarScaledProjectFactor>(new FarScaledProjectFactor(f, far)); }
+    template <typename T> bool operator()(T const* const* parameters, T* residuals) const {
+        const T* q = parameters[0]; const T* t = parameters[1]; const T* L = parameters[2];
+        T d[3] = {L[0] - t[0], L[1] - t[1], L[2] - t[2]}, pc[3];
+        QuatConjRotate(q, d, pc);
+        const T n2 = L[0] * L[0] + L[1] * L[1] + L[2] * L[2];
+        const T w = (n2 > T(far2)) ? T(2.0) : T(1.0);
+        residuals[0] = w * (pc[0] / pc[2] - T(feature[0]));
+        residuals[1] = w * (pc[1] / pc[2] - T(feature[1]));
+        return true;
+    }
+};
+
+// The reprojection factor at the probe points AND at the start point; it departs from it once its landmark has MOVED (between 1e-7 and
+// 0.5 away from where it started): only the check at the END of the solve can see that.  Solve() must notice, put the parameters
+// back and solve again with this functor's own code.
+struct MovedScaledProjectFactor {
+    double feature[2], L0[3];
+    MovedScaledProjectFactor(const double* f, const double* l0) { feature[0] = f[0]; feature[1] = f[1]; L0[0] = l0[0]; L0[1] = l0[1]; L0[2] = l0[2]; }
+    static auto Create(const double* f, const double* l0) { return new ceres::DynamicAutoDiffCostFunction<MovedScaledProjectFactor>(new MovedScaledProjectFactor(f, l0)); }
+    template <typename T> bool operator()(T const* const* parameters, T* residuals) const {
+        const T* q = parameters[0]; const T* t = parameters[1]; const T* L = parameters[2];
+        T d[3] = {L[0] - t[0], L[1] - t[1], L[2] - t[2]}, pc[3];
+        QuatConjRotate(q, d, pc);
+        const T m[3] = {L[0] - T(L0[0]), L[1] - T(L0[1]), L[2] - T(L0[2])};
+        const T m2 = m[0] * m[0] + m[1] * m[1] + m[2] * m[2];
+        const T w = (m2 > T(1e-14) && m2 < T(0.25)) ? T(1.5) : T(1.0);
+        residuals[0] = w * (pc[0] / pc[2] - T(feature[0]));
+        residuals[1] = w * (pc[1] / pc[2] - T(feature[1]));
+        return true;
+    }
+};
+
 // sim_data.h:165-194: the per-landmark triangulation factor of the scene generator.  NOTE the residual's sign,
 // feature - proj (sim_data.h:191), the opposite of ProjectFactor's; WtoC is the INVERSE camera pose (sim_data.cpp:303).
 struct Triangulation {
@@ -243,6 +282,8 @@ static void print_vec(const char* key, const double* v, int n) {
 
 // test_ceres.h:98-152.  kind 0: the built-in ReprojectionFactor; 1: the user's ProjectFactor exactly as the
 // reference constructs it (test_ceres.h:109-130); 2: a user functor that is NOT the reprojection factor.
+static double g_far = 1e30;                 // FarScaledProjectFactor's radius
+static std::vector<double> g_pts0;          // the landmarks' start positions (MovedScaledProjectFactor)
 static void SolveBA(Scene& s, int kind, const char* tag, int max_iterations = 50, int print_cams = -1) {
     ceres::LocalParameterization* localParameterization = new LieLocalParameterization();
     ceres::Problem problem;
@@ -255,8 +296,18 @@ static void SolveBA(Scene& s, int kind, const char* tag, int max_iterations = 50
             costFunc->AddParameterBlock(4); costFunc->AddParameterBlock(3); costFunc->AddParameterBlock(3);
             costFunc->SetNumResiduals(2);
             problem.AddResidualBlock(costFunc, nullptr, {so3, pos, lm});
-        } else {
+        } else if (kind == 2) {
             auto costFunc = ScaledProjectFactor::Create(&s.feat[i * 2]);
+            costFunc->AddParameterBlock(4); costFunc->AddParameterBlock(3); costFunc->AddParameterBlock(3);
+            costFunc->SetNumResiduals(2);
+            problem.AddResidualBlock(costFunc, nullptr, {so3, pos, lm});
+        } else if (kind == 3) {
+            auto costFunc = FarScaledProjectFactor::Create(&s.feat[i * 2], g_far);
+            costFunc->AddParameterBlock(4); costFunc->AddParameterBlock(3); costFunc->AddParameterBlock(3);
+            costFunc->SetNumResiduals(2);
+            problem.AddResidualBlock(costFunc, nullptr, {so3, pos, lm});
+        } else {
+            auto costFunc = MovedScaledProjectFactor::Create(&s.feat[i * 2], &g_pts0[s.op[i] * 3]);
             costFunc->AddParameterBlock(4); costFunc->AddParameterBlock(3); costFunc->AddParameterBlock(3);
             costFunc->SetNumResiduals(2);
             problem.AddResidualBlock(costFunc, nullptr, {so3, pos, lm});
@@ -289,7 +340,8 @@ static void ProbeOnly(Scene& s, int kind, const char* tag) {
         double* so3 = &s.cams[s.oc[i] * 7]; double* pos = so3 + 4; double* lm = &s.pts[s.op[i] * 3];
         ceres::CostFunction* cf;
         if (kind == 1) { auto c = ProjectFactor::Create(&s.feat[i * 2]); c->AddParameterBlock(4); c->AddParameterBlock(3); c->AddParameterBlock(3); c->SetNumResiduals(2); cf = c; }
-        else { auto c = ScaledProjectFactor::Create(&s.feat[i * 2]); c->AddParameterBlock(4); c->AddParameterBlock(3); c->AddParameterBlock(3); c->SetNumResiduals(2); cf = c; }
+        else if (kind == 2) { auto c = ScaledProjectFactor::Create(&s.feat[i * 2]); c->AddParameterBlock(4); c->AddParameterBlock(3); c->AddParameterBlock(3); c->SetNumResiduals(2); cf = c; }
+        else { auto c = FarScaledProjectFactor::Create(&s.feat[i * 2], g_far); c->AddParameterBlock(4); c->AddParameterBlock(3); c->AddParameterBlock(3); c->SetNumResiduals(2); cf = c; }
         problem.AddResidualBlock(cf, nullptr, {so3, pos, lm});
         problem.AddParameterBlock(so3, 4, lp);
     }
@@ -308,6 +360,23 @@ int main(int argc, char** argv) {
         if (!s.load(argv[2])) { std::printf("scene_load_failed\n"); return 2; }
         { Scene a = s; ProbeOnly(a, 1, "probe_user"); }
         { Scene a = s; ProbeOnly(a, 2, "probe_scaled"); }
+        if (argc >= 4) {      // a functor that IS the factor at every probe point and is not at (some of) its own data
+            g_far = std::atof(argv[3]);
+            { Scene a = s; ProbeOnly(a, 3, "probe_far"); }
+            g_far = 1e30;
+            { Scene a = s; ProbeOnly(a, 3, "probe_far_never"); }
+        }
+        return 0;
+    }
+    // ---- "verify <scene> <far>": the recognition's checks at the data -- before the solve (kind 3) and after it (kind 4)
+    if (argc >= 4 && std::strcmp(argv[1], "verify") == 0) {
+        Scene s;
+        if (!s.load(argv[2])) { std::printf("scene_load_failed\n"); return 2; }
+        g_far = std::atof(argv[3]);
+        { Scene a = s; SolveBA(a, 3, "ba_far"); }
+        g_pts0 = s.pts;
+        { Scene a = s; SolveBA(a, 4, "ba_moved"); }
+        { Scene a = s; SolveBA(a, 1, "ba_user"); }
         return 0;
     }
     // ---- "tri <scene>": sim_data.cpp:298-311 -- one ceres::Problem PER LANDMARK (cameras fixed: they are not parameter

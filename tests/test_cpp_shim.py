@@ -78,6 +78,13 @@ def test_reference_ba_functor_is_recognised_on_the_host(exe, tmp_path, scenes):
     assert toks[:8] == ["detected", "1", "cams", str(len(s["cams0"])), "pts", str(len(s["pts0"])), "obs", str(len(s["obs_cam"]))]
     assert float(toks[-1]) < 1e-15
     assert out["probe_scaled"].split()[1] == "0"
+    # a functor that IS the reprojection factor at every generic probe point and differs where (some of) its own data lie -- landmarks
+    # further than `far` from the origin, `far` beyond every probe point: caught by the check at the blocks' own parameter values
+    norms = np.linalg.norm(s["pts0"], axis=1)
+    far = float(max(3.6, np.quantile(norms, 0.7)))
+    assert (norms > far).any()
+    out = run(exe, "probe", f, repr(far))
+    assert out["probe_far"].split()[1] == "0" and out["probe_far_never"].split()[1] == "1"
 
 
 def vec(out, key):
@@ -373,3 +380,22 @@ def test_pose_graph_through_the_operator_api(exe, tmp_path, scenes, O):
     p2 = vec(out2, "pg_poses").reshape(-1, 7)
     dq = np.minimum(np.abs(p2[:, :4] - o2.poses[:, :4]).max(1), np.abs(p2[:, :4] + o2.poses[:, :4]).max(1)).max()
     assert dq < 1e-7 and np.abs(p2[:, 4:] - o2.poses[:, 4:]).max() < 1e-6
+
+
+@pytest.mark.gpu
+def test_recognised_blocks_are_checked_at_their_data_before_and_after_the_solve(exe, tmp_path, scenes):
+    """the recognition of a user cost function as the reprojection factor is no longer a matter of four generic probe
+    points.  A functor that differs from the factor only where its own data lie is caught before the solve and runs its own code
+    (gpu-ba-hostjac); one that departs from it only once the landmarks have moved is caught by the check at the END of the solve --
+    the parameters go back, the problem is solved again with the user's Evaluate, and the summary says so; the reference's own functor
+    passes both checks and the summary's message says how many blocks were taken over."""
+    s = scenes.st20_scene(n_cams=10, n_pts=120, seed=3, pos_noise=0.05, ang_noise_deg=0.5)
+    f = str(tmp_path / "s.bin")
+    write_scene(f, s)
+    norms = np.linalg.norm(s["pts0"], axis=1)
+    far = float(max(3.6, np.quantile(norms, 0.7)))
+    out = run(exe, "verify", f, repr(far))
+    assert out["ba_far_path"] == "gpu-ba-hostjac" and out["ba_far_term"].split()[0] == "0"
+    assert out["ba_moved_path"] == "gpu-ba-hostjac" and "differs from it at the solution" in out["ba_moved_report"]
+    assert out["ba_moved_term"].split()[0] == "0"
+    assert out["ba_user_path"] == "gpu-ba" and "recognised as the reprojection factor" in out["ba_user_report"]
