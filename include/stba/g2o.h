@@ -193,9 +193,21 @@ public:
         const int rc = stba_ba_solve(ba, &o, &s, trace.data(), nullptr, nullptr);
         int done = 0;
         if (rc == STBA_OK) {
+            const std::vector<double> c7_start = c7, p3_start = p3;
             stba_ba_get_params(ba, c7.data(), p3.data());
             for (int c = 0; c < nc; ++c) cams[c]->set_raw(&c7[(size_t)c * 7]);
             for (int j = 0; j < np; ++j) pts[j]->set_raw(&p3[(size_t)j * 3]);
+            // the edges were the reprojection residual at the START point; they must still be at the point the solve ended at (a
+            // computeError with a clamp or a weight that sets in on the way is not what the device minimised): if one is not, the
+            // estimates go back to where they were and nothing is reported as optimised
+            for (int k = 0; k < no; ++k)
+                if (!probe_edge(_edges[k], k)) {
+                    for (int c = 0; c < nc; ++c) cams[c]->set_raw(&c7_start[(size_t)c * 7]);
+                    for (int j = 0; j < np; ++j) pts[j]->set_raw(&p3_start[(size_t)j * 3]);
+                    _message += " (at the solution: the estimates were put back)";
+                    stba_ba_destroy(ba);
+                    return 0;
+                }
             _chi2 = 2.0 * s.final_cost;   // g2o reports chi^2 = sum r^2, Ceres 1/2 sum r^2
             done = s.num_iterations;
             if (_verbose)
