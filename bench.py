@@ -464,6 +464,8 @@ def main():
                          "`landmark_heavy` with its own predicted_scaling; on by itself with --gpus N > 1: a driver with several GPUs then records the "
                          "headline C5 curve (flat: the replicated factorisation) and the one landmark sharding can scale on, in one call")
     ap.add_argument("--no-second-scene", action="store_true")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal of the N-rank path on a one-GPU box: all ranks on device 0 (use with --backend gloo --hook torch; the times mean nothing)")
     ap.add_argument("--second-cams", type=int, default=100)
     ap.add_argument("--second-pts", type=int, default=1000000)
     args = ap.parse_args()
@@ -481,6 +483,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.share_gpu:
+        local_rank = 0          # (the N-rank path rehearsed on a box with ONE device: every rank on device 0, gloo + the torch hook)
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
                          f"(python bench.py --gpus N does it itself)")
