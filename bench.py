@@ -127,7 +127,22 @@ def ranks_hold_identical_cameras(eng, torch, dist, world, have_gpu, args):
     allv = [torch.zeros_like(mine) for _ in range(world)]
     dist.all_gather(allv, mine)
     vals = [int(v.item()) for v in allv]
-    return all(v == vals[0] for v in vals), vals
+    same = all(v == vals[0] for v in vals)
+    # what a `false` would mean: how far apart the ranks are, and whether a rank's persistent factorisation gave up (a time-out sends it
+    # to the stage kernels, whose order of operations -- and last bits -- differ: seen when several processes share ONE device)
+    global LAST_RANK_CHECK
+    st = importlib.import_module("slam-tricks_amd")
+    mc = torch.from_numpy(np.ascontiguousarray(cams)).to(dev)
+    ref = mc.clone()
+    dist.broadcast(ref, src=0)
+    far = torch.tensor([float((mc - ref).abs().max()), float(st.cholesky_timeout_count())], dtype=torch.float64, device=dev)
+    allf = [torch.zeros_like(far) for _ in range(world)]
+    dist.all_gather(allf, far)
+    LAST_RANK_CHECK = {"max_abs_diff_to_rank0": max(float(v[0]) for v in allf), "factorisation_timeouts_per_rank": [int(v[1]) for v in allf]}
+    return same, vals
+
+
+LAST_RANK_CHECK = None
 
 
 def predicted_scaling(ph, ms_step, allreduce_ms, ar_bytes, world, note):
@@ -207,7 +222,7 @@ def time_scene(st, sharding, torch, dist, s, args, rank, world, local_rank, have
                                   "st20 spiral/cube scene seed 20, pixel noise 1e-3",
                       "collective": collective, "schur_form": "dense product" if eng.schur_mode() == eng.SCHUR_DENSE else "pair plan"},
            "phase_ms_per_step": ph, "allreduce_ms": float(phases[5]), "allreduce_bytes": ar_bytes,
-           "camera_blocks_identical_on_all_ranks": bool(same), "final_cost": summ.final_cost,
+           "camera_blocks_identical_on_all_ranks": bool(same), "rank_check": LAST_RANK_CHECK, "final_cost": summ.final_cost,
            "predicted_scaling": predicted_scaling(ph, ms_step, float(phases[5]), ar_bytes, world,
                                                   "few cameras, many landmarks: the replicated factorisation is small and everything else divides by N")}
     eng.close()
@@ -570,6 +585,7 @@ def main():
     ms_step = float(np.median(rep_ms))
     it_per_s = 1e3 / ms_step
     cams_same, _ = ranks_hold_identical_cameras(eng, torch, dist, world, have_gpu, args)
+    rank_check = LAST_RANK_CHECK
     out = {
         "metric": "LM iterations/sec + residuals/sec, 1k-cam/100k-pt BA",
         "value": it_per_s, "unit": "LM iterations/s",
@@ -585,6 +601,7 @@ def main():
                    "collective": collective, "n_cams": n_cams, "n_pts": n_pts, "n_obs": n_obs},
         "final_cost": summ.final_cost,
         "camera_blocks_identical_on_all_ranks": bool(cams_same),    # every rank factors the same reduced system: compared in-run, bit for bit
+        "rank_check": rank_check,       # (several ranks: largest distance of a rank's camera blocks from rank 0's, factorisation time-outs per rank)
     }
     # Device time per phase: ONE MORE run of K steps with stba_lm_options::phase_timing on (hipEvents between the phases; the
     # timed repetitions above run without them: an event record costs ~5 us of idle GPU and an iteration would take eight),
