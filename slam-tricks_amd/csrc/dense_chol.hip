@@ -2136,6 +2136,16 @@ void chol_note_timeout() {
     std::lock_guard<std::mutex> g(D.m);
     D.cooldown = 64;
 }
+// several ranks: ANOTHER rank's factorisation gave up.  This rank goes through the stage kernels for the same 64 factorisations, so that
+// all ranks keep factoring the identical reduced system with the identical schedule -- the two schedules differ in the last bits, and
+// every rank must hold the same camera blocks (include/stba.h, stba_ba_set_allreduce).  Not counted as a time-out of this rank.
+void chol_note_peer_timeout() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return;
+    MegaDevice& D = mega_device(dev);
+    std::lock_guard<std::mutex> g(D.m);
+    D.cooldown = 64;
+}
 int chol_timeout_count() { return g_timeouts.load(); }
 
 // which schedule a factorisation runs through

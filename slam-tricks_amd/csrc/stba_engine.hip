@@ -777,6 +777,7 @@ static int ba_run_lm(stba_ba* b, const stba_lm_options* opt_in, int fixed_iterat
             // them -- and this iteration runs again, the factorisation through the stage kernels, which need nothing
             // resident (chol_note_timeout: so do the next ones on this device).
             if (flag_h == CHOL_FLAG_TIMEOUT) chol_note_timeout();
+            else chol_note_peer_timeout();      // (another rank's gave up: the same schedule on every rank, or their last bits part)
             // (a device that keeps timing out is shared for good: the cool-down is renewed every time, so a long run goes on through
             // the stage kernels instead of failing; only time-outs that come back-to-back without a good iteration in between --
             // the stage kernels cannot time out -- end the solve)
