@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define STBA_VERSION 5
+#define STBA_VERSION 6
 
 /* status codes */
 enum {
@@ -58,7 +58,7 @@ enum {
 
 const char* stba_status_string(int status);
 const char* stba_last_error(void);      /* thread-local detail of the last failure */
-int stba_version(void);                 /* 5: stba_lm_options grew function_tolerance_takes_step (append-only) */
+int stba_version(void);                 /* 6: stba_pcg_options grew coarse_async, forcing_step_accuracy (append-only); 5: stba_lm_options grew function_tolerance_takes_step */
 /* number of visible HIP devices (0 => every compute entry point returns STBA_ERR_NO_DEVICE) */
 int stba_device_count(void);
 
@@ -178,7 +178,8 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
 int stba_ba_destroy(stba_ba* ba);
 /* form of the Schur complement (above): STBA_SCHUR_AUTO = what stba_ba_create chose.  STBA_SCHUR_PAIRS fails if the engine was
  * created without a pair plan (too many pairs), STBA_SCHUR_DENSE if Y does not fit the device. */
-enum { STBA_SCHUR_AUTO = 0, STBA_SCHUR_PAIRS = 1, STBA_SCHUR_DENSE = 2 };
+enum { STBA_SCHUR_AUTO = 0, STBA_SCHUR_PAIRS = 1, STBA_SCHUR_DENSE = 2,
+       STBA_SCHUR_PAIRS_RECORDS = 3 };     /* (stba_version() >= 6) the pair plan fed from per-observation 6 x 3 records Y = (Jc^T Jp) chol(Hpp^-1) */
 int stba_ba_set_schur_mode(stba_ba* ba, int mode);
 int stba_ba_schur_mode(const stba_ba* ba, int* mode);
 int stba_ba_set_params(stba_ba* ba, const double* cams, const double* pts);
@@ -360,6 +361,13 @@ typedef struct {
                                   * <= 64 nodes; 0: always four launches per iteration; 2: as 1 with a time-out of zero, so that the way back is
                                   * taken -- a solve whose workgroups are not all resident gives up and is repeated with launches, and the
                                   * engine stays with launches (stba_version() >= 5) */
+    int    coarse_async;         /* 1 (stba_version() >= 6): the coarse operator is inverted on a SECOND stream, next to the PCG kernel, and applied one
+                                  * LM iteration late -- iteration k preconditions with the inverse of iteration k - 1's operator; the first solve
+                                  * runs on block Jacobi alone (forcing sequence) or waits for its inverse (exact steps).  Ordered by events:
+                                  * run-to-run reproducible.  0: inverted in line, as until version 5 (coarse_refresh_every applies) */
+    double forcing_step_accuracy;/* 2e-6 (stba_version() >= 6): the forcing term is also kept below (this) / (predicted length of the next
+                                  * step), so that the last inexact step before convergence is accurate to about this much in the
+                                  * parameters; 0: Eisenstat & Walker's sequence alone */
 } stba_pcg_options;
 void stba_pcg_default_options(stba_pcg_options* o);
 typedef struct {

@@ -9,7 +9,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["dense_chol.hip", "ba_kernels.hip", "stba_engine.hip", "pg_engine.hip", "two_view.hip", "calib_io.cpp", "comm.cpp"]
+SOURCES = ["dense_chol.hip", "ba_kernels.hip", "stba_engine.hip", "pg_engine.hip", "small_dense.hip", "two_view.hip", "calib_io.cpp", "comm.cpp"]
 HEADERS = ["common.hpp", "ba_kernels.hpp", "small_linalg.hpp", os.path.join("..", "..", "include", "stba.h")]
 LIB = os.path.join(HERE, "libstba.so")
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-munsafe-fp-atomics", "-Wall",

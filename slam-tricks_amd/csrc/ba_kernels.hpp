@@ -79,6 +79,7 @@ struct SchurArgs {
     const int* task_vs_ptr; const int* vs_first;     // per task: [blocks + 1] first accumulator slot of every block of the slice
     const int* obs_pt;                               // landmark of every observation
     const int4* pair_rec;                            // (i, l, landmark, slot | 0x8000 if diagonal block), l != i
+    double* Yrec = nullptr; int n_obs = 0;           // round 6, record form: Y_i = (Jc^T Jp) chol(Hpp^-1) [n_obs][18], made by the launch itself
 };
 // the Schur complement for dense visibility as a symmetric rank-k product (ba_kernels.hip, "DENSE visibility")
 struct SchurDenseArgs {
@@ -132,5 +133,18 @@ int launch_calib_arrow_iteration(int n_views, int n_corners, double* params, con
                                  double* scratch, int* state, double* sse_trace, hipStream_t st);
 int launch_dense_normal(int n_res, int n, const double* J, const double* r, double* H, int ldh, double* g,
                         hipStream_t st);
+
+// ---- small dense problems (small_dense.hip): one kernel launch per LM step, pooled workspace, mapped host buffers
+constexpr int SMALL_DENSE_MAX_N = 32;
+struct SmallDenseWs;
+bool small_dense_fits(int n_res, int n);
+int small_dense_acquire(SmallDenseWs** ws, int n_res, int n);
+void small_dense_release(SmallDenseWs* ws);
+double* small_dense_J(SmallDenseWs* ws);     // where the residual callback writes J (n_res x n) and r (n_res): pinned, mapped
+double* small_dense_r(SmallDenseWs* ws);
+// H = J^T J, g = J^T r (relinearize) or the H, g of the last linearisation; Jacobi scaling fixed when `first`; solves
+// (H + D(radius)) dx = -g.  dx, g: pointers into mapped host memory, valid until the next step.  pivot_flag: 0 or row + 1
+int small_dense_step(SmallDenseWs* ws, int n_res, int n, bool relinearize, bool first, bool jacobi, double radius, double dmin,
+                     double dmax, const double** dx, const double** g, double* model_change, int* pivot_flag);
 
 }  // namespace stba

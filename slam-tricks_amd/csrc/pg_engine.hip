@@ -1326,6 +1326,12 @@ struct stba_pg {
     std::vector<int> h_node_start;
     bool coarse_valid = false;
     double coarse_radius = 0.0;
+    // ---- round 6: the coarse inverse OFF the critical path (stba_pcg_options::coarse_async): a second stream inverts the coarse
+    // operator of LM iteration k while the first runs iteration k's PCG with the inverse made during iteration k - 1
+    hipStream_t st2 = nullptr;
+    hipEvent_t ev_in = nullptr, ev_job[2] = {nullptr, nullptr};
+    double* Ainv2 = nullptr;         // the second buffer of the pair (Ainv is the first)
+    bool job_in_flight = false;
     stba_pcg_summary last_pcg;
 };
 
@@ -1339,6 +1345,10 @@ void pg_free(stba_pg* g) {
     F(g->end_node); F(g->AdP); F(g->Ac0); F(g->W); F(g->Ainv); F(g->inv_work); F(g->rc_part); F(g->zc); F(g->part_cz); F(g->part_u);
     F(g->scal_dev); F(g->cflag); F(g->state); F(g->contrib); F(g->Dc);
     F(g->end_pos); F(g->end_rem); F(g->Bend); F(g->ubuf); F(g->pbuf); F(g->ustamp); F(g->pstamp);
+    if (g->st2) { (void)hipStreamSynchronize(g->st2); chol_forget_stream(g->st2); (void)hipStreamDestroy(g->st2); }
+    if (g->ev_in) (void)hipEventDestroy(g->ev_in);
+    for (auto& e : g->ev_job) if (e) (void)hipEventDestroy(e);
+    F(g->Ainv2);
     if (g->exp_host) (void)hipHostFree(g->exp_host);
     if (g->fin_host) (void)hipHostFree(g->fin_host);
     if (g->own && g->st) (void)hipStreamDestroy(g->st);
@@ -1403,11 +1413,13 @@ static int pg_setup_coarse(stba_pg* g, int group_opt) {
     if ((size_t)6 * nc * sizeof(double) + (size_t)4 * max_ends * sizeof(int) > 136 * 1024)       // (+ 20 KB static in pg_coarse_build_kernel)
         return fail(STBA_ERR_INVALID_ARGUMENT, "stba_pg_solve: coarse space too large for this group size");
     auto F = [](void* p) { if (p) (void)hipFree(p); };
-    F(g->AdP); F(g->Ac0); F(g->W); F(g->Ainv); F(g->inv_work); F(g->rc_part); F(g->zc); F(g->part_cz); F(g->Dc);
-    g->AdP = g->Ac0 = g->W = g->Ainv = g->inv_work = g->rc_part = g->zc = g->part_cz = g->Dc = nullptr;
+    if (g->st2) STBA_HIP(hipStreamSynchronize(g->st2));       // (a job of the last solve may still be writing W / an inverse)
+    g->job_in_flight = false;
+    F(g->AdP); F(g->Ac0); F(g->W); F(g->Ainv); F(g->Ainv2); F(g->inv_work); F(g->rc_part); F(g->zc); F(g->part_cz); F(g->Dc);
+    g->AdP = g->Ac0 = g->W = g->Ainv = g->Ainv2 = g->inv_work = g->rc_part = g->zc = g->part_cz = g->Dc = nullptr;
     g->agg = 0;
     STBA_TRY(dalloc(&g->AdP, (size_t)g->n * 36)); STBA_TRY(dalloc(&g->Ac0, (size_t)nc * nc)); STBA_TRY(dalloc(&g->W, (size_t)4 * np * np));
-    STBA_TRY(dalloc(&g->Ainv, (size_t)nc * nc)); STBA_TRY(dalloc(&g->Dc, (size_t)na * 36)); STBA_TRY(dalloc(&g->inv_work, chol_spd_inverse_workspace_doubles(np)));
+    STBA_TRY(dalloc(&g->Ainv, (size_t)nc * nc)); STBA_TRY(dalloc(&g->Ainv2, (size_t)nc * nc)); STBA_TRY(dalloc(&g->Dc, (size_t)na * 36)); STBA_TRY(dalloc(&g->inv_work, chol_spd_inverse_workspace_doubles(np)));
     STBA_TRY(dalloc(&g->rc_part, (size_t)na * parts * 6)); STBA_TRY(dalloc(&g->zc, (size_t)nc)); STBA_TRY(dalloc(&g->part_cz, (size_t)((nc + 3) / 4) * 2 + 2));
     STBA_HIP(hipMemsetAsync(g->rc_part, 0, (size_t)na * parts * 6 * sizeof(double), g->st));
     static DeviceOnce attr;
@@ -1454,6 +1466,8 @@ void stba_pcg_default_options(stba_pcg_options* o) {
     o->coarse_group = 0;
     o->coarse_refresh_every = 1;
     o->one_kernel_solve = 1;
+    o->coarse_async = 1;
+    o->forcing_step_accuracy = 2e-6;
 }
 
 int stba_pg_create(stba_pg** out, int n_nodes, int n_edges, const double* poses, const int* edge_i, const int* edge_j,
@@ -1624,6 +1638,17 @@ int stba_pg_solve(stba_pg* g, const stba_lm_options* opt_in, const stba_pcg_opti
     const int N = 6 * g->n;
     STBA_TRY(pg_setup_coarse(g, pcg.coarse_group));
     const bool coarse = g->agg > 0;
+    // the second stream of the coarse inverse (see the loop); a job of the previous solve may still be in flight: it is awaited here,
+    // where it costs nothing, instead of at the end of that solve, where it would have been the last 0.3 ms of its wall time
+    const bool async_inv = coarse && pcg.coarse_async != 0;
+    if (async_inv) {
+        if (!g->st2) {
+            STBA_HIP(hipStreamCreateWithFlags(&g->st2, hipStreamNonBlocking));
+            STBA_HIP(hipEventCreateWithFlags(&g->ev_in, hipEventDisableTiming));
+            for (auto& e : g->ev_job) STBA_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
+        if (g->job_in_flight) { STBA_HIP(hipStreamSynchronize(g->st2)); g->job_in_flight = false; }
+    }
     if (coarse) STBA_HIP(hipMemsetAsync(g->cflag + 1, 0, sizeof(int), g->st));      // this solve's count of failed coarse operators
     const bool multi = (g->ar != nullptr);
     const int chunk = std::max(1, pcg.check_every);
@@ -1637,16 +1662,19 @@ int stba_pg_solve(stba_pg* g, const stba_lm_options* opt_in, const stba_pcg_opti
     bool pp_ok = pcg.one_kernel_solve != 0 && !multi && coarse && g->agg <= 64 && g->na <= 256 && g->nc <= PP_NCMAX &&
                  pp_lds_bytes(g->na, g->nc) <= (size_t)160 * 1024 - 64;
     if (pp_ok) {
-        int dev = 0, cus = 0;
+        int dev = 0, cus = 0, lds_max = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || g->na > cus) pp_ok = false;
+        // (the LDS a workgroup may opt in to is a property of the device and the driver: asked, not assumed -- advisor, round 5)
+        if (pp_ok && (hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || pp_lds_bytes(g->na, g->nc) > (size_t)std::max(0, lds_max - 64))) pp_ok = false;
         if (g->max_group_ends > PP_VCAP) pp_ok = false;
     }
     if (pp_ok) {
         static DeviceOnce attr;
-        STBA_TRY(attr.run([]() -> int {
-            STBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pg_pcg_persistent_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
-            return STBA_OK;
-        }));
+        // a device that refuses the attribute takes the launch path; that is not a failed solve
+        if (attr.run([]() -> int {
+                STBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pg_pcg_persistent_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+                return STBA_OK;
+            }) != STBA_OK) { pp_ok = false; g->pp_disabled = true; (void)hipGetLastError(); }
     }
 
     // ---- linearisation at the current point: residuals, Jacobians, gradient | diagonal blocks, the coarse basis and matrix
@@ -1698,7 +1726,7 @@ int stba_pg_solve(stba_pg* g, const stba_lm_options* opt_in, const stba_pcg_opti
     bool done = gmax <= opt.gradient_tolerance;
     if (done) { s.termination_type = STBA_CONVERGENCE; s.termination_reason = STBA_TERM_GRADIENT; }
     if (!std::isfinite(cost)) { s.termination_type = STBA_FAILURE; s.termination_reason = STBA_TERM_SOLVER_FAIL; done = true; }   // (Ceres: initial evaluation failed, see stba_ba_solve)
-    int since_refresh = 0;
+    int since_refresh = 0, jobs = 0;
     while (!done) {
         if (iter >= opt.max_num_iterations) break;
         if (radius < opt.min_trust_region_radius) { s.termination_type = STBA_CONVERGENCE; s.termination_reason = STBA_TERM_MIN_RADIUS; break; }
@@ -1706,7 +1734,43 @@ int stba_pg_solve(stba_pg* g, const stba_lm_options* opt_in, const stba_pcg_opti
         hipLaunchKernelGGL(pg_precond_kernel, dim3(g->nb_nodes), dim3(256), 0, g->st, g->n, g->Hd, g->scale, scale_init ? 0 : 1,
                            opt.jacobi_scaling, radius, opt.min_lm_diagonal, opt.max_lm_diagonal, g->fixed, g->d, g->Minv);
         scale_init = true;
-        // ---- coarse operator (P^T (J^T J + D) P)^-1: rebuilt when the linearisation or (every coarse_refresh_every-th time) the damping changed
+        // ---- coarse operator (P^T (J^T J + D) P)^-1
+        const double* Ainv_use = g->Ainv;
+        if (coarse && async_inv) {
+            // ROUND 6: off the critical path.  The inversion (eight panels of a ~45 us chain on a handful of CUs: 0.39 of a 0.92 ms LM
+            // iteration at C4) runs on a SECOND stream, next to this iteration's PCG kernel (157 workgroups on 256 CUs), and is applied one LM
+            // iteration LATE: iteration k preconditions with the inverse of iteration k - 1's operator -- an inverse made at the
+            // previous linearisation / damping still is a preconditioner, only a weaker one (coarse_refresh_every = 2 had measured
+            // + 9 % PCG iterations).  The very first solve has no predecessor: with a forcing sequence (eta_0 = 0.1: a loose solve)
+            // it runs on block Jacobi alone (Ainv = 0), with exact steps it waits for its own inverse.  Everything is ordered by
+            // events, so the result does not depend on timing: run to run the same bits.
+            //   stream 1: precond_k | wait job_{k-1} | Dc_k, assemble W_k | record IN_k | PCG_k (Ainv of job_{k-1}) | trial ...
+            //   stream 2:                                                   wait IN_k   | invert W_k -> Ainv[k & 1] | record job_k
+            const int wbuf = jobs & 1;
+            double* Aw = wbuf ? g->Ainv2 : g->Ainv;
+            const double* Ar = wbuf ? g->Ainv : g->Ainv2;        // written by the previous job (or zeroed below)
+            if (jobs == 0) STBA_HIP(hipMemsetAsync(const_cast<double*>(Ar), 0, (size_t)g->nc * g->nc * sizeof(double), g->st));
+            else STBA_HIP(hipStreamWaitEvent(g->st, g->ev_job[(jobs - 1) & 1], 0));
+            const size_t cnt = (size_t)3 * g->np * g->np;
+            hipLaunchKernelGGL(pg_coarse_dc_kernel, dim3(g->na), dim3(256), 0, g->st, g->n, g->agg, g->AdP, g->d, g->Dc);
+            hipLaunchKernelGGL(pg_coarse_assemble_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, g->st, g->nc, g->np, g->Ac0, g->Dc, g->W);
+            STBA_HIP(hipEventRecord(g->ev_in, g->st));
+            STBA_HIP(hipStreamWaitEvent(g->st2, g->ev_in, 0));
+            STBA_TRY(chol_spd_inverse_dev(g->W, 2 * g->np, g->np, g->nc, g->cflag, g->inv_work, g->st2));
+            hipLaunchKernelGGL(pg_coarse_finish_kernel, dim3((unsigned)(((size_t)g->nc * g->nc + 255) / 256)), dim3(256), 0, g->st2, g->nc, g->np, g->W, Aw,
+                               g->cflag, g->cflag + 1);
+            STBA_HIP(hipEventRecord(g->ev_job[wbuf], g->st2));
+            g->job_in_flight = true;
+            Ainv_use = Ar;
+            if (jobs == 0 && !forcing) {                         // exact steps: the first solve waits for its own inverse
+                STBA_HIP(hipStreamWaitEvent(g->st, g->ev_job[wbuf], 0));
+                Ainv_use = Aw;
+            }
+            ++jobs;
+            g->coarse_valid = true;
+            ++ps.coarse_refreshes;
+        } else
+        // (synchronous form, coarse_async = 0) rebuilt when the linearisation or (every coarse_refresh_every-th time) the damping changed
         // (the inverse is a preconditioner: one made at an earlier linearisation / damping still is one, only weaker -- with
         // coarse_refresh_every = k it is re-made every k-th LM iteration; the first two iterations always make theirs)
         if (coarse && (ps.coarse_refreshes < 2 || since_refresh >= std::max(1, pcg.coarse_refresh_every))) {
@@ -1733,7 +1797,7 @@ int stba_pg_solve(stba_pg* g, const stba_lm_options* opt_in, const stba_pcg_opti
             hipLaunchKernelGGL(pg_pcg_init4_kernel, dim3(g->nb_nodes4), dim3(PG_NT), 0, g->st, g->n, g->agg, g->g, g->Minv, AdP, g->x, g->rr, g->z,
                                g->rc_part, g->part_a);
             if (coarse)
-                hipLaunchKernelGGL(pg_coarse_solve_kernel, dim3((g->nc + 3) / 4), dim3(256), 0, g->st, g->nc, g->parts, (const PcgState*)nullptr, g->Ainv, g->rc_part,
+                hipLaunchKernelGGL(pg_coarse_solve_kernel, dim3((g->nc + 3) / 4), dim3(256), 0, g->st, g->nc, g->parts, (const PcgState*)nullptr, Ainv_use, g->rc_part,
                                    g->zc, g->part_cz);
             hipLaunchKernelGGL(pg_pcg_dir4_kernel, dim3(g->nb_nodes4), dim3(PG_NT), 0, g->st, g->n, g->agg, 1, 1, eta_k, pcg.max_iterations, g->state, g->exp_dev,
                                g->nb_nodes4, g->part_a, (g->nc + 3) / 4, coarse ? g->part_cz : nullptr, AdP, g->zc, g->z, g->d, g->p, g->part_d);
@@ -1760,7 +1824,7 @@ int stba_pg_solve(stba_pg* g, const stba_lm_options* opt_in, const stba_pcg_opti
                                            g->p, g->x, g->rr, g->z, g->rc_part, g->part_a);
                     }
                     if (coarse)
-                        hipLaunchKernelGGL(pg_coarse_solve_kernel, dim3((g->nc + 3) / 4), dim3(256), 0, g->st, g->nc, g->parts, g->state, g->Ainv, g->rc_part, g->zc,
+                        hipLaunchKernelGGL(pg_coarse_solve_kernel, dim3((g->nc + 3) / 4), dim3(256), 0, g->st, g->nc, g->parts, g->state, Ainv_use, g->rc_part, g->zc,
                                            g->part_cz);
                     hipLaunchKernelGGL(pg_pcg_dir4_kernel, dim3(g->nb_nodes4), dim3(PG_NT), 0, g->st, g->n, g->agg, slot, 0, eta_k, pcg.max_iterations, g->state,
                                        g->exp_dev, g->nb_nodes4, g->part_a, (g->nc + 3) / 4, coarse ? g->part_cz : nullptr, AdP, g->zc, g->z, g->d, g->p, g->part_d);
@@ -1790,7 +1854,7 @@ int stba_pg_solve(stba_pg* g, const stba_lm_options* opt_in, const stba_pcg_opti
             a.n = g->n; a.agg = g->agg; a.log2agg = 0; while ((1 << a.log2agg) < g->agg) ++a.log2agg;
             a.na = g->na; a.nc = g->nc; a.base = g->pp_base; a.max_iters = pcg.max_iterations; a.eta = eta_k;
             a.node_start = g->node_start; a.end_rem = g->end_rem; a.Bend = g->Bend; a.Hd = g->Hd; a.d = g->d; a.Minv = g->Minv; a.AdP = g->AdP;
-            a.Ainv = g->Ainv; a.g = g->g; a.x = g->x; a.ubuf = g->ubuf; a.pbuf = g->pbuf; a.ustamp = g->ustamp; a.pstamp = g->pstamp;
+            a.Ainv = Ainv_use; a.g = g->g; a.x = g->x; a.ubuf = g->ubuf; a.pbuf = g->pbuf; a.ustamp = g->ustamp; a.pstamp = g->pstamp;
             a.state = g->state; a.spin_limit = pcg.one_kernel_solve == 2 ? 0 : 1ll << 18;      // (a poll is a memory round trip, ~1 us: a quarter of a second; 2: the test of the way back)
             a.tdbg = nullptr;
 #ifdef STBA_DEBUG_KNOBS
@@ -1889,6 +1953,14 @@ int stba_pg_solve(stba_pg* g, const stba_lm_options* opt_in, const stba_pcg_opti
                 double e2 = 0.9 * g2_new / g2;
                 if (0.9 * eta * eta > 0.1) e2 = std::max(e2, 0.9 * eta * eta);
                 eta = std::min(pcg.forcing_eta0, std::max(pcg.forcing_eta_min, e2));
+                // (round 6) ... and tight enough that the step it stops is accurate to forcing_step_accuracy in the parameters:
+                // the next step is about |step| |g_{k+1}| / |g_k| long (Newton: the step follows the gradient), a solve stopped at
+                // eta leaves about eta times that as its error -- and the error of the LAST step before the function tolerance
+                // fires is what the converged poses keep (north_star asks for 1e-5 on poses against exact steps)
+                if (pcg.forcing_step_accuracy > 0.0 && step_norm > 0.0) {
+                    const double pred = step_norm * std::sqrt(g2_new / g2);
+                    if (pred > 0.0 && std::isfinite(pred)) eta = std::max(pcg.forcing_eta_min, std::min(eta, pcg.forcing_step_accuracy / pred));
+                }
             }
             g2 = g2_new;
             if (trace) { trace[(size_t)iter * STBA_TRACE_COLS + 2] = gmax; trace[(size_t)iter * STBA_TRACE_COLS + 5] = radius; }

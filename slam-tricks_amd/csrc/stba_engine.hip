@@ -102,6 +102,7 @@ struct stba_ba {
     int schur_mode = STBA_SCHUR_PAIRS, schur_mode_auto = STBA_SCHUR_PAIRS;
     bool have_pair_plan = false;
     double* Y = nullptr; size_t ldy = 0, ykcols = 0;     // [lda][ldy]
+    double* Yrec = nullptr;                              // STBA_SCHUR_PAIRS_RECORDS: [n_obs][18]
     double *yv = nullptr, *yws = nullptr;
     unsigned char* dup_run = nullptr;                    // repeated (camera, landmark) pairs, per position of cam_perm (null: none)
     unsigned char *cam_fixed = nullptr, *pt_fixed = nullptr;
@@ -167,7 +168,7 @@ static void ba_free(stba_ba* b) {
     F(b->pt_fixed); F(b->r); F(b->J8); F(b->Jc12); F(b->omask); F(b->Hpp6); F(b->gp); F(b->Hinv6); F(b->dp); F(b->scale_p);
     F(b->Hcc); F(b->gc); F(b->cam_partial); F(b->dc); F(b->scale_c); F(b->Sbuf); F(b->Spack); F(b->pk_blocks); F(b->dxc); F(b->dxp);
     F(b->task_cam); F(b->cam_start); F(b->task_col_lo); F(b->task_col_hi); F(b->row_col_ptr); F(b->row_cols);
-    F(b->pair_begin); F(b->pair_end); F(b->pair_rec); F(b->task_vs_ptr); F(b->vs_first); F(b->Y); F(b->yv); F(b->yws); F(b->dup_run);
+    F(b->pair_begin); F(b->pair_end); F(b->pair_rec); F(b->task_vs_ptr); F(b->vs_first); F(b->Y); F(b->Yrec); F(b->yv); F(b->yws); F(b->dup_run);
     F(b->cost_partial); F(b->upd_partial_c); F(b->upd_partial_p); F(b->trial); F(b->flag);
     for (auto& e : b->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : b->ev_ar) if (e) (void)hipEventDestroy(e);
@@ -399,6 +400,10 @@ static int ba_schur_step(stba_ba* b) {
     sa.S = b->S(); sa.lda = b->lda; sa.rhs = b->rhs(); sa.Hcc = b->Hcc; sa.gc = b->gc;
     sa.obs_pt = b->obs_pt; sa.pair_begin = b->pair_begin; sa.pair_end = b->pair_end; sa.pair_rec = b->pair_rec;
     sa.task_vs_ptr = b->task_vs_ptr; sa.vs_first = b->vs_first; sa.mode = b->schur_plan_mode;
+    if (b->schur_mode == STBA_SCHUR_PAIRS_RECORDS) {
+        if (!b->Yrec) STBA_TRY(dev_alloc(&b->Yrec, (size_t)std::max(b->no, 1) * 18));
+        sa.Yrec = b->Yrec; sa.n_obs = b->no;
+    }
     return launch_schur_rows(sa, b->n_tasks, b->st);
 }
 
@@ -1415,9 +1420,9 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
 }
 
 int stba_ba_set_schur_mode(stba_ba* ba, int mode) {
-    if (!ba || mode < STBA_SCHUR_AUTO || mode > STBA_SCHUR_DENSE) return fail(STBA_ERR_INVALID_ARGUMENT, "stba_ba_set_schur_mode: bad argument");
+    if (!ba || mode < STBA_SCHUR_AUTO || mode > STBA_SCHUR_PAIRS_RECORDS) return fail(STBA_ERR_INVALID_ARGUMENT, "stba_ba_set_schur_mode: bad argument");
     if (mode == STBA_SCHUR_AUTO) mode = ba->schur_mode_auto;
-    if (mode == STBA_SCHUR_PAIRS && !ba->have_pair_plan)
+    if ((mode == STBA_SCHUR_PAIRS || mode == STBA_SCHUR_PAIRS_RECORDS) && !ba->have_pair_plan)
         return fail(STBA_ERR_INVALID_ARGUMENT, "stba_ba_set_schur_mode: this engine was created without a pair plan (too many observation pairs)");
     if (mode == STBA_SCHUR_DENSE) STBA_TRY(ba_dense_alloc(ba));
     ba->schur_mode = mode;
@@ -1971,6 +1976,149 @@ int stba_calib_gauss_newton(int n_views, int n_corners, double* params, const do
 }
 
 // ---------------------------------------------------------------------------------------------
+// The same LM loop for SMALL problems (<= 32 local parameters: the reference's PnP call sites, its per-landmark triangulation,
+// the bounds demo, the curve fit): one kernel launch per step (small_dense.hip), no allocation, no copy and no synchronise per
+// solve -- the published workload of the reference is 0.12-0.22 ms per Solve() (st17-ceres/img/release.png), the general path
+// below took 3.5 ms.  Control flow, constants and trace columns are those of the general loop, statement for statement.
+// ---------------------------------------------------------------------------------------------
+static int dense_solve_small(stba_residual_fn fn, stba_plus_fn plus, void* user, int n_params, int n, int n_res, double* x,
+                             const double* lower, const double* upper, const stba_lm_options& opt, stba_lm_summary* summary,
+                             double* trace, stba_iteration_callback cb, void* cb_user) {
+    SmallDenseWs* ws = nullptr;
+    STBA_TRY(small_dense_acquire(&ws, n_res, n));
+    struct Release { SmallDenseWs* w; ~Release() { small_dense_release(w); } } release{ws};
+    double* r = small_dense_r(ws);
+    double* J = small_dense_J(ws);
+    constexpr int NMAX = SMALL_DENSE_MAX_N;
+    std::vector<double> xn((size_t)n_params), rn((size_t)n_res);
+    double dx[NMAX], g[NMAX];
+    stba_lm_summary s;
+    memset(&s, 0, sizeof s);
+    const double t_start = wall_s();
+    const bool bounded = lower || upper;
+    auto gmax_of = [&]() {
+        double m = 0.0;
+        for (int a = 0; a < n; ++a) {
+            if (!bounded) m = std::max(m, std::fabs(g[a]));
+            else {
+                double y = x[a] - g[a];
+                if (lower && y < lower[a]) y = lower[a];
+                if (upper && y > upper[a]) y = upper[a];
+                m = std::max(m, std::fabs(x[a] - y));
+            }
+        }
+        return m;
+    };
+    auto norm_of = [&](const double* v, int k) { double q = 0; for (int a = 0; a < k; ++a) q += v[a] * v[a]; return std::sqrt(q); };
+    double model_change = 0.0;
+    int flag_h = 0;
+    bool first = true;
+    auto step = [&](bool relinearize, double radius) -> int {     // (H + D) dx = -g on the device; g refreshed when relinearised
+        const double *dxp = nullptr, *gp = nullptr;
+        STBA_TRY(small_dense_step(ws, n_res, n, relinearize, first, opt.jacobi_scaling != 0, radius, opt.min_lm_diagonal,
+                                  opt.max_lm_diagonal, &dxp, &gp, &model_change, &flag_h));
+        first = false;
+        for (int a = 0; a < n; ++a) { dx[a] = dxp[a]; g[a] = gp[a]; }
+        return STBA_OK;
+    };
+
+    if (fn(user, x, r, J) != 0) return fail(STBA_ERR_CALLBACK, "residual callback failed");
+    double cost = 0.0;
+    for (int i = 0; i < n_res; ++i) cost += r[i] * r[i];
+    cost *= 0.5;
+    s.initial_cost = cost;
+    double radius = opt.initial_trust_region_radius, decrease = 2.0, x_norm = norm_of(x, n_params), gmax = 0.0;
+    int iter = 0;
+    bool done = false, have_step = false;
+    s.termination_type = STBA_NO_CONVERGENCE; s.termination_reason = STBA_TERM_MAX_ITER;
+    if (!std::isfinite(cost)) { s.termination_type = STBA_FAILURE; s.termination_reason = STBA_TERM_SOLVER_FAIL; done = true; }
+    else {
+        STBA_TRY(step(true, radius));
+        have_step = true;
+        gmax = gmax_of();
+        if (gmax <= opt.gradient_tolerance) { s.termination_type = STBA_CONVERGENCE; s.termination_reason = STBA_TERM_GRADIENT; done = true; }
+    }
+    if (trace) { memset(trace, 0, sizeof(double) * STBA_TRACE_COLS); trace[0] = cost; trace[2] = gmax; trace[5] = radius; trace[6] = 1; }
+    while (!done) {
+        if (iter >= opt.max_num_iterations) { s.termination_type = STBA_NO_CONVERGENCE; s.termination_reason = STBA_TERM_MAX_ITER; break; }
+        if (radius < opt.min_trust_region_radius) { s.termination_type = STBA_CONVERGENCE; s.termination_reason = STBA_TERM_MIN_RADIUS; break; }
+        ++iter;
+        if (!have_step) STBA_TRY(step(false, radius));
+        have_step = false;
+        bool ok = (flag_h == 0);
+        double new_cost = 0.0, step_norm = 0.0, rho = 0.0, cost_change = 0.0;
+        if (ok && (!(model_change > 0.0) || !std::isfinite(model_change))) ok = false;
+        bool accepted = false;
+        if (ok) {
+            if (plus) plus(user, x, dx, xn.data());
+            else for (int a = 0; a < n_params; ++a) xn[a] = x[a] + dx[a];
+            if (bounded)
+                for (int a = 0; a < n_params; ++a) {
+                    if (lower && xn[a] < lower[a]) xn[a] = lower[a];
+                    if (upper && xn[a] > upper[a]) xn[a] = upper[a];
+                }
+            if (fn(user, xn.data(), rn.data(), nullptr) != 0) ok = false;
+        }
+        if (ok) {
+            for (double v : rn) new_cost += v * v;
+            new_cost *= 0.5;
+            for (int a = 0; a < n_params; ++a) step_norm += (xn[a] - x[a]) * (xn[a] - x[a]);
+            step_norm = std::sqrt(step_norm);
+            cost_change = cost - new_cost;
+            rho = cost_change / model_change;
+            if (trace) { double* tr = trace + (size_t)iter * STBA_TRACE_COLS; tr[0] = new_cost; tr[1] = cost_change; tr[3] = step_norm; tr[4] = rho; }
+            if (step_norm <= opt.parameter_tolerance * (x_norm + opt.parameter_tolerance)) {
+                s.termination_type = STBA_CONVERGENCE; s.termination_reason = STBA_TERM_PARAMETER;
+                if (trace) { trace[(size_t)iter * STBA_TRACE_COLS + 5] = radius; trace[(size_t)iter * STBA_TRACE_COLS + 2] = gmax; }
+                if (cb) (void)cb(cb_user, iter, cost, cost_change, gmax, step_norm, radius, 0);
+                break;
+            }
+            if (std::fabs(cost_change) <= opt.function_tolerance * cost) {
+                const bool take = opt.function_tolerance_takes_step && rho > opt.min_relative_decrease;      // (stba.h)
+                if (take) {
+                    memcpy(x, xn.data(), sizeof(double) * n_params); cost = new_cost; ++s.num_successful_steps;
+                    if (trace) trace[(size_t)iter * STBA_TRACE_COLS + 6] = 1;
+                }
+                s.termination_type = STBA_CONVERGENCE; s.termination_reason = STBA_TERM_FUNCTION;
+                if (trace) { trace[(size_t)iter * STBA_TRACE_COLS + 5] = radius; trace[(size_t)iter * STBA_TRACE_COLS + 2] = gmax; }
+                if (cb) (void)cb(cb_user, iter, cost, cost_change, gmax, step_norm, radius, take ? 1 : 0);
+                break;
+            }
+            accepted = rho > opt.min_relative_decrease;
+        }
+        if (accepted) {
+            memcpy(x, xn.data(), sizeof(double) * n_params);
+            cost = new_cost; x_norm = norm_of(x, n_params); ++s.num_successful_steps;
+            if (fn(user, x, r, J) != 0) return fail(STBA_ERR_CALLBACK, "residual callback failed");
+            const double t = 2.0 * rho - 1.0;
+            radius = std::min(opt.max_trust_region_radius, radius / std::max(1.0 / 3.0, 1.0 - t * t * t));
+            decrease = 2.0;
+            STBA_TRY(step(true, radius));             // the next iteration's step rides along with the new linearisation
+            have_step = true;
+            gmax = gmax_of();
+        } else {
+            ++s.num_unsuccessful_steps;
+            radius /= decrease; decrease *= 2.0;
+        }
+        if (trace) {
+            double* tr = trace + (size_t)iter * STBA_TRACE_COLS;
+            if (!ok) { tr[0] = cost; tr[1] = 0; tr[3] = 0; tr[4] = 0; }
+            tr[2] = gmax; tr[5] = radius; tr[6] = accepted ? 1 : 0;
+        }
+        if (opt.minimizer_progress_to_stdout)
+            printf("%4d  %.6e   % .2e    %.2e   %.2e  % .2e  %.2e\n", iter, cost, cost_change, gmax, step_norm, rho, radius);
+        if (cb && cb(cb_user, iter, cost, cost_change, gmax, step_norm, radius, accepted ? 1 : 0) != 0) {
+            s.termination_type = STBA_CONVERGENCE; s.termination_reason = STBA_TERM_USER; break;
+        }
+        if (accepted && gmax <= opt.gradient_tolerance) { s.termination_type = STBA_CONVERGENCE; s.termination_reason = STBA_TERM_GRADIENT; break; }
+    }
+    s.num_iterations = iter; s.final_cost = cost; s.final_radius = radius; s.final_gradient_max_norm = gmax;
+    s.seconds_total = wall_s() - t_start;
+    if (summary) *summary = s;
+    return STBA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // small dense LM problems: residual blocks evaluated by a host callback (the user's
 // CostFunction::Evaluate), normal equations + damped Cholesky step on the device.
 // ---------------------------------------------------------------------------------------------
@@ -1987,6 +2135,8 @@ int stba_dense_solve(stba_residual_fn fn, stba_plus_fn plus, void* user, int n_p
     stba_lm_options opt;
     if (opt_in) opt = *opt_in; else default_options(&opt);
     const int n = n_local;
+    if (small_dense_fits(n_res, n))
+        return dense_solve_small(fn, plus, user, n_params, n, n_res, x, lower, upper, opt, summary, trace, cb, cb_user);
     DenseWs w;
     STBA_TRY(w.init(n, nullptr));
     double *dJ = nullptr, *dr = nullptr, *dH = nullptr, *dg = nullptr;

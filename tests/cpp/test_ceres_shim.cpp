@@ -417,6 +417,106 @@ int main(int argc, char** argv) {
         SolveBA(s, 1, "ba_user", std::atoi(argv[3]), 1000000);
         return 0;
     }
+    // ---- "time_ba <scene> <max_iterations> <reps> [threads]": wall-clock of the reference's BA call site as the reference times it
+    // (test_ceres.h:103-104,149: the timer starts in front of the problem construction) -- construction and Solve() separately,
+    // Solve()'s own phases from Summary::phases.  One line per repetition; the caller takes the median.
+    if (argc >= 5 && std::strcmp(argv[1], "time_ba") == 0) {
+        Scene s0;
+        if (!s0.load(argv[2])) { std::printf("scene_load_failed\n"); return 2; }
+        const int max_it = std::atoi(argv[3]), reps = std::atoi(argv[4]), threads = argc > 5 ? std::atoi(argv[5]) : 1;
+        for (int rep = 0; rep < reps; ++rep) {
+            Scene s = s0;
+            const auto t0 = std::chrono::steady_clock::now();
+            double t_build, t_solve, t_destroy;
+            ceres::Solver::Summary summary;
+            {
+                ceres::LocalParameterization* localParameterization = new LieLocalParameterization();
+                ceres::Problem problem;
+                for (int i = 0; i < s.no; ++i) {
+                    double* so3 = &s.cams[s.oc[i] * 7]; double* pos = so3 + 4; double* lm = &s.pts[s.op[i] * 3];
+                    auto costFunc = ProjectFactor::Create(&s.feat[i * 2]);
+                    costFunc->AddParameterBlock(4); costFunc->AddParameterBlock(3); costFunc->AddParameterBlock(3);
+                    costFunc->SetNumResiduals(2);
+                    problem.AddResidualBlock(costFunc, nullptr, {so3, pos, lm});
+                    problem.AddParameterBlock(so3, 4, localParameterization);
+                    if (s.fixed[s.oc[i]]) { problem.SetParameterBlockConstant(so3); problem.SetParameterBlockConstant(pos); }
+                }
+                ceres::Solver::Options options;
+                options.num_threads = threads;
+                options.linear_solver_type = ceres::SPARSE_SCHUR;
+                options.max_num_iterations = max_it;
+                const auto t1 = std::chrono::steady_clock::now();
+                ceres::Solve(options, &problem, &summary);
+                const auto t2 = std::chrono::steady_clock::now();
+                t_build = std::chrono::duration<double>(t1 - t0).count();
+                t_solve = std::chrono::duration<double>(t2 - t1).count();
+            }
+            t_destroy = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() - t_build - t_solve;
+            const auto& ph = summary.phases;
+            std::printf("time_ba_%d path %s term %d iters %d initial %.17g final %.17g build %.6f solve %.6f destroy %.6f recognise %.6f pack %.6f "
+                        "engine_create %.6f device_solve %.6f write_back %.6f verify %.6f resolve %.6f minimizer %.6f\n",
+                        rep, summary.execution_path.c_str(), (int)summary.termination_type, (int)summary.iterations.size() - 1, summary.initial_cost,
+                        summary.final_cost, t_build, t_solve, t_destroy, ph.recognise, ph.pack, ph.engine_create, ph.device_solve, ph.write_back,
+                        ph.verify, ph.resolve, summary.minimizer_time_in_seconds);
+            if (rep == reps - 1) print_vec("time_ba_cams", s.cams.data(), std::min(s.nc, 1000000) * 7);
+        }
+        return 0;
+    }
+    // ---- "time_pnp <pnp file> <reps>": the reference's PUBLISHED workload (st17-ceres/img/release.png: 0.223 / 0.138 / 0.124 ms for
+    // SolvePnPWith{DynamicAutoDiff, AutoDiff, SizedCostFunction}, solver.hpp:247-385), timed as the reference times it (solver.hpp:253-288:
+    // the timer spans problem construction + Solve, countTime = true: no callback).  Prints every repetition's wall time in ms.
+    if (argc >= 4 && std::strcmp(argv[1], "time_pnp") == 0) {
+        std::ifstream f(argv[2], std::ios::binary);
+        int n; f.read((char*)&n, 4);
+        double truth[7], init[7];
+        f.read((char*)truth, 56); f.read((char*)init, 56);
+        std::vector<CorrPair> data(n);
+        for (auto& c : data) { f.read((char*)c.point, 24); f.read((char*)c.feature, 16); }
+        if (!f) { std::printf("pnp_load_failed\n"); return 2; }
+        const int reps = std::atoi(argv[3]);
+        const char* names[3] = {"pnp_dyn", "pnp_auto", "pnp_sized"};
+        for (int variant = 0; variant < 3; ++variant) {
+            std::vector<double> ms;
+            double pose[7] = {0}; int iters = 0, term = -1; double final_cost = 0; std::string path;
+            for (int rep = 0; rep < reps; ++rep) {
+                const auto t0 = std::chrono::steady_clock::now();
+                ceres::Solver::Summary summary;
+                if (variant < 2) {
+                    double SO3[4], POS[3]; std::memcpy(SO3, init, 32); std::memcpy(POS, init + 4, 24);
+                    ceres::LocalParameterization* lp = new LieLocalParameterization();
+                    ceres::Problem problem;
+                    for (const auto& item : data) {
+                        if (variant == 0) {
+                            auto costFunc = PnPDynamicAutoDiffFunctor::Create(item);
+                            costFunc->AddParameterBlock(4); costFunc->AddParameterBlock(3); costFunc->SetNumResiduals(2);
+                            problem.AddResidualBlock(costFunc, nullptr, {SO3, POS});
+                        } else problem.AddResidualBlock(PnPAutoDiffFunctor::Create(item), nullptr, {SO3, POS});
+                        problem.AddParameterBlock(SO3, 4, lp);
+                    }
+                    ceres::Solver::Options options; options.num_threads = 1; options.linear_solver_type = ceres::DENSE_QR;
+                    ceres::Solve(options, &problem, &summary);
+                    std::memcpy(pose, SO3, 32); std::memcpy(pose + 4, POS, 24);
+                } else {
+                    double so3[3], POS[3]; So3Log(init, so3); std::memcpy(POS, init + 4, 24);
+                    ceres::LocalParameterization* lp = new LieR3LocalParameterization();
+                    ceres::Problem problem;
+                    for (const auto& item : data) {
+                        problem.AddResidualBlock(new PnPSizedCostFunction(item, true), nullptr, {so3, POS});
+                        problem.AddParameterBlock(so3, 3, lp);
+                    }
+                    ceres::Solver::Options options; options.num_threads = 1; options.linear_solver_type = ceres::DENSE_QR;
+                    ceres::Solve(options, &problem, &summary);
+                    So3Exp(so3, pose); std::memcpy(pose + 4, POS, 24);
+                }
+                ms.push_back(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+                iters = (int)summary.iterations.size() - 1; term = (int)summary.termination_type; final_cost = summary.final_cost; path = summary.execution_path;
+            }
+            std::printf("%s path %s term %d iters %d final %.17g\n", names[variant], path.c_str(), term, iters, final_cost);
+            print_vec((std::string(names[variant]) + "_ms").c_str(), ms.data(), (int)ms.size());
+            print_vec((std::string(names[variant]) + "_pose").c_str(), pose, 7);
+        }
+        return 0;
+    }
     if (argc >= 3 && std::strcmp(argv[1], "pg") == 0) {
         // a pose graph through the operator API: one 7-double block per pose with the SE3 right-plus chart, one RelativePoseFactor
         // per edge (build-defined, BASELINE config C4).  argv[3] = "dense": force the generic host path (checks Evaluate / the chart)

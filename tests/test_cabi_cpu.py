@@ -27,7 +27,7 @@ def test_header_symbols_are_exported(st):
     L = st.lib()
     for name in declared:
         assert hasattr(L, name), name
-    assert L.stba_version() == 5
+    assert L.stba_version() == 6
 
 
 def test_shipped_library_reads_no_experiment_knobs(st):
