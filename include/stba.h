@@ -83,14 +83,17 @@ typedef struct {
                                            * iteration fill stba_lm_summary::ms_* -- an event is a packet of its own on the queue
                                            * and costs ~5 us of idle GPU, ~1.5 % of a C5 iteration for the eight it takes */
     int    function_tolerance_takes_step; /* what happens to the trial step on which |cost change| <= function_tolerance * cost fires:
-                                           * 1 (default): it is taken if it is a decrease (rho > min_relative_decrease), THEN convergence
-                                           *    is reported -- the reading of Ceres' documentation this build started from;
-                                           * 0: convergence is reported at once and the step is NOT taken -- the order of the refactored
-                                           *    TrustRegionMinimizer (Ceres >= 1.12 through 2.1, as this build's authors remember it:
-                                           *    ParameterToleranceReached(), FunctionToleranceReached() in front of IsStepSuccessful()).
-                                           * No Ceres exists in this image to settle it (tools/ceres_baseline.cpp on a box that has one
-                                           * does, in one run); the final parameters differ by one step of relative cost change
-                                           * <= 1e-6 either way.  The oracle carries the same switch (orc_lm_options). */
+                                           * 0 (default since stba_version() 6): convergence is reported at once and the step is NOT
+                                           *    taken -- the order of Ceres' TrustRegionMinimizer::Minimize since the refactoring of
+                                           *    1.12 (through 2.1): ComputeCandidatePointAndEvaluateCost(); if (ParameterToleranceReached())
+                                           *    return; if (FunctionToleranceReached()) return; if (IsStepSuccessful())
+                                           *    HandleSuccessfulStep(); -- the candidate only becomes the state in HandleSuccessfulStep;
+                                           * 1 (the default of versions <= 5): the step is taken if it is a decrease (rho >
+                                           *    min_relative_decrease), THEN convergence is reported -- Ceres <= 1.11's monolithic loop
+                                           *    read this way, and the wording of the solver documentation.
+                                           * The final parameters differ by one step of relative cost change <= 1e-6 either way; the
+                                           * oracle carries the same switch (orc_lm_options).  (No Ceres exists in this image to run
+                                           * against: tools/ceres_baseline.cpp on a box that has one shows it in num_successful_steps.) */
 } stba_lm_options;
 
 void stba_lm_default_options(stba_lm_options* opt);
@@ -178,8 +181,7 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
 int stba_ba_destroy(stba_ba* ba);
 /* form of the Schur complement (above): STBA_SCHUR_AUTO = what stba_ba_create chose.  STBA_SCHUR_PAIRS fails if the engine was
  * created without a pair plan (too many pairs), STBA_SCHUR_DENSE if Y does not fit the device. */
-enum { STBA_SCHUR_AUTO = 0, STBA_SCHUR_PAIRS = 1, STBA_SCHUR_DENSE = 2,
-       STBA_SCHUR_PAIRS_RECORDS = 3 };     /* (stba_version() >= 6) the pair plan fed from per-observation 6 x 3 records Y = (Jc^T Jp) chol(Hpp^-1) */
+enum { STBA_SCHUR_AUTO = 0, STBA_SCHUR_PAIRS = 1, STBA_SCHUR_DENSE = 2 };
 int stba_ba_set_schur_mode(stba_ba* ba, int mode);
 int stba_ba_schur_mode(const stba_ba* ba, int* mode);
 int stba_ba_set_params(stba_ba* ba, const double* cams, const double* pts);
@@ -360,7 +362,10 @@ typedef struct {
                                   * instead of four launches) where the graph allows: one rank, a coarse space of <= 256 groups of
                                   * <= 64 nodes; 0: always four launches per iteration; 2: as 1 with a time-out of zero, so that the way back is
                                   * taken -- a solve whose workgroups are not all resident gives up and is repeated with launches, and the
-                                  * engine stays with launches (stba_version() >= 5) */
+                                  * engine stays with launches (stba_version() >= 5); 3 (stba_version() >= 6): as 1 with the stamps of the
+                                  * two exchanges published behind an agent-scope RELEASE fence and read in front of an ACQUIRE fence -- the
+                                  * formally complete protocol; 1 orders the same accesses by the hardware's own rules (stores acknowledged
+                                  * before the stamp is issued, loads issued after the stamp was seen) plus compiler barriers */
     int    coarse_async;         /* 1 (stba_version() >= 6): the coarse operator is inverted on a SECOND stream, next to the PCG kernel, and applied one
                                   * LM iteration late -- iteration k preconditions with the inverse of iteration k - 1's operator; the first solve
                                   * runs on block Jacobi alone (forcing sequence) or waits for its inverse (exact steps).  Ordered by events:

@@ -901,212 +901,6 @@ __global__ __launch_bounds__(SCHUR_THREADS, GEN ? 2 : 4) void ba_schur_pairs_ker
 }
 
 // ===========================================================================================
-// ROUND 6: the pair form from per-observation RECORDS  Y_i = (Jc_i^T Jp_i) R_j,  R_j R_j^T = Hpp_j^-1  (6 x 3, 144 B), written once
-// per iteration by ba_schur_yrec_kernel.  A pair then costs ONE kind of gather (two 144-byte records, the landmark's records side
-// by side in memory) and 108 multiply-adds -- S[c_i, c_l] -= Y_i Y_l^T -- where the form above gathers two 64-byte Jacobian records
-// and the inverse landmark block and spends ~650 vector instructions per pair on re-expanding the camera blocks and re-making
-// E_i = W_i Hpp^-1.  Same plan, same accumulator slots, same order of additions per slot: bitwise reproducible like the form above
-// (the two forms differ from each other in the last bits: chol(Hpp^-1) is another association of the same product).
-// ===========================================================================================
-__device__ inline void chol3_of_sym6(const double h[6], double R[6]);
-constexpr int YREC_LD = 18;
-template <bool GEN>
-__global__ __launch_bounds__(256) void ba_schur_yrec_kernel(int n_obs, const int* __restrict__ obs_pt, const double* __restrict__ J8,
-                                                            const unsigned char* __restrict__ omask, const double* __restrict__ Jc12,
-                                                            const double* __restrict__ Hinv6, double* __restrict__ Yrec) {
-    __shared__ __attribute__((aligned(16))) double ys[256 * YREC_LD];
-    const int t = threadIdx.x;
-    const int i0 = blockIdx.x * 256, i = i0 + t;
-    if (i < n_obs) {
-        double jc[12], jp[6], Hi[6], R[6];
-        load_jc_jp<GEN>(J8, omask, i, jc, jp, Jc12);
-        const int lm = obs_pt[i];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) Hi[k] = Hinv6[(size_t)lm * 6 + k];
-        chol3_of_sym6(Hi, R);                    // R = (r00, r10, r20, r11, r21, r22)
-#pragma unroll
-        for (int q = 0; q < 6; ++q) {
-            const double w0 = jc[q] * jp[0] + jc[6 + q] * jp[3];
-            const double w1 = jc[q] * jp[1] + jc[6 + q] * jp[4];
-            const double w2 = jc[q] * jp[2] + jc[6 + q] * jp[5];
-            ys[t * YREC_LD + q * 3 + 0] = w0 * R[0] + w1 * R[1] + w2 * R[2];
-            ys[t * YREC_LD + q * 3 + 1] = w1 * R[3] + w2 * R[4];
-            ys[t * YREC_LD + q * 3 + 2] = w2 * R[5];
-        }
-    }
-    __syncthreads();
-    // the workgroup's 256 records are one contiguous stretch of Yrec: every store instruction writes 64 x 16 contiguous bytes
-    const int nrec = min(256, n_obs - i0);
-    const double2* src = reinterpret_cast<const double2*>(ys);
-    double2* dst = reinterpret_cast<double2*>(Yrec + (size_t)i0 * YREC_LD);
-    for (int f = t; f < nrec * (YREC_LD / 2); f += 256) dst[f] = src[f];
-}
-
-template <int ROTS, bool GEN>
-__global__ __launch_bounds__(SCHUR_THREADS, 4) void ba_schur_pairs_y_kernel(SchurArgs a) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int task = blockIdx.x;
-    const int c = a.task_cam[task];
-    const int row_ncols = a.row_col_ptr[c + 1] - a.row_col_ptr[c];
-    const int clo = a.task_col_lo[task], chi = a.task_col_hi[task];
-    const int col0 = a.row_col_ptr[c] + clo, ncols = chi - clo;
-    double* acc = smem;
-    double* racc = smem + (size_t)a.max_cols * SCHUR_BLK_LD;
-    double* cpart = racc + 8;
-    int* cols = reinterpret_cast<int*>(cpart + 8 * SCHUR_CAM_LD);
-    int* vsf = cols + a.max_cols;
-    const int tid = threadIdx.x;
-    const bool diag_piece = (chi == row_ncols);
-    const int* vs_g = a.vs_first + a.task_vs_ptr[task];
-    const int nslots = vs_g[ncols];
-    for (int e = tid; e < nslots * SCHUR_BLK_LD; e += SCHUR_THREADS) acc[e] = 0.0;
-    if (tid < 8) racc[tid] = 0.0;
-    for (int e = tid; e < ncols; e += SCHUR_THREADS) cols[e] = a.row_cols[col0 + e];
-    for (int e = tid; e <= ncols; e += SCHUR_THREADS) vsf[e] = vs_g[e];
-    {
-        const int cend = min(a.lda, ((c * 6 + 5) / 128 + 1) * 128);
-        const int z0 = (clo == 0) ? 0 : 6 * a.row_cols[col0];
-        const int z1 = diag_piece ? cend : 6 * a.row_cols[col0 + ncols];
-        for (int q = 0; q < 6; ++q) {
-            double* row = a.S + (size_t)(c * 6 + q) * a.lda;
-            for (int e = z0 + tid; e < z1; e += SCHUR_THREADS) row[e] = 0.0;
-        }
-    }
-    __syncthreads();
-    const int wv = tid >> 6;
-    const int ent = task * (SCHUR_THREADS / 64) + wv;
-    const int kb = a.pair_begin[ent], ke = a.pair_end[ent];
-    const int rot = tid % ROTS;
-    int k = kb + (tid & 63);
-    int4 rn = (k < ke) ? a.pair_rec[k] : make_int4(0, 0, 0, 0);
-    for (; k < ke; k += 64) {
-        const int4 rc = rn;
-        if (k + 64 < ke) rn = a.pair_rec[k + 64];
-        const double2* pi = reinterpret_cast<const double2*>(a.Yrec + (size_t)rc.x * YREC_LD);
-        const double2* pl = reinterpret_cast<const double2*>(a.Yrec + (size_t)rc.y * YREC_LD);
-        double yi[18], yl[18];
-#pragma unroll
-        for (int q = 0; q < 9; ++q) { const double2 v = pi[q]; yi[2 * q] = v.x; yi[2 * q + 1] = v.y; }
-#pragma unroll
-        for (int q = 0; q < 9; ++q) { const double2 v = pl[q]; yl[2 * q] = v.x; yl[2 * q + 1] = v.y; }
-        double* blk = acc + (size_t)((unsigned)rc.w & 0x3fffu) * SCHUR_BLK_LD;
-#pragma unroll
-        for (int s2 = 0; s2 < 6; ++s2) {
-            double w0 = yl[s2 * 3], w1 = yl[s2 * 3 + 1], w2 = yl[s2 * 3 + 2];
-            int b = s2;
-#pragma unroll
-            for (int r = 1; r < ROTS; ++r) {
-                const int bb = (s2 + r * (6 / ROTS)) % 6;
-                if (rot == r) { w0 = yl[bb * 3]; w1 = yl[bb * 3 + 1]; w2 = yl[bb * 3 + 2]; b = bb; }
-            }
-            double* col = blk + b;
-#pragma unroll
-            for (int q = 0; q < 6; ++q)
-                unsafeAtomicAdd(&col[q * 6], -(yi[q * 3] * w0 + yi[q * 3 + 1] * w1 + yi[q * 3 + 2] * w2));
-        }
-    }
-    if (diag_piece) {
-        const int pe = a.cam_start[c + 1];
-        {
-            double h[27];
-#pragma unroll
-            for (int k2 = 0; k2 < 27; ++k2) h[k2] = 0.0;
-            for (int p = a.cam_start[c] + tid; p < pe; p += SCHUR_THREADS) {
-                const int i = a.cam_perm[p];
-                double j[12], jpu[6];
-                load_jc_jp<GEN>(a.J8, a.omask, i, j, jpu, a.Jc12);
-                const double2 ri = a.r[i];
-                int idx = 0;
-#pragma unroll
-                for (int q = 0; q < 6; ++q)
-#pragma unroll
-                    for (int b = 0; b <= q; ++b) h[idx++] += j[q] * j[b] + j[6 + q] * j[6 + b];
-#pragma unroll
-                for (int q = 0; q < 6; ++q) h[21 + q] += j[q] * ri.x + j[6 + q] * ri.y;
-            }
-#pragma unroll
-            for (int k2 = 0; k2 < 27; ++k2) {
-                double v = h[k2];
-                for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-                if ((tid & 63) == 0) cpart[(tid >> 6) * SCHUR_CAM_LD + k2] = v;
-            }
-        }
-        {
-            double h[27];       // [0 .. 20] = -sum Y Y^T (lower triangle, row-wise), [21 .. 26] = sum Y (R^T gp)
-#pragma unroll
-            for (int k2 = 0; k2 < 27; ++k2) h[k2] = 0.0;
-            for (int p = a.cam_start[c] + tid; p < pe; p += SCHUR_THREADS) {
-                const int i = a.cam_perm[p];
-                const double2* pi = reinterpret_cast<const double2*>(a.Yrec + (size_t)i * YREC_LD);
-                double y[18];
-#pragma unroll
-                for (int q = 0; q < 9; ++q) { const double2 v = pi[q]; y[2 * q] = v.x; y[2 * q + 1] = v.y; }
-                const int lm = a.obs_pt[i];
-                double Hi[6], R[6];
-#pragma unroll
-                for (int k2 = 0; k2 < 6; ++k2) Hi[k2] = a.Hinv6[(size_t)lm * 6 + k2];
-                chol3_of_sym6(Hi, R);
-                const double g0 = a.gp[(size_t)lm * 3], g1 = a.gp[(size_t)lm * 3 + 1], g2 = a.gp[(size_t)lm * 3 + 2];
-                const double v0 = R[0] * g0 + R[1] * g1 + R[2] * g2, v1 = R[3] * g1 + R[4] * g2, v2 = R[5] * g2;     // R^T gp
-                int idx = 0;
-#pragma unroll
-                for (int q = 0; q < 6; ++q) {
-#pragma unroll
-                    for (int b = 0; b <= q; ++b) h[idx++] -= y[q * 3] * y[b * 3] + y[q * 3 + 1] * y[b * 3 + 1] + y[q * 3 + 2] * y[b * 3 + 2];
-                    h[21 + q] += y[q * 3] * v0 + y[q * 3 + 1] * v1 + y[q * 3 + 2] * v2;
-                }
-            }
-#pragma unroll
-            for (int k2 = 0; k2 < 27; ++k2) {
-                double v = h[k2];
-                for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-                if ((tid & 63) == 0) cpart[(tid >> 6) * SCHUR_CAM_LD + 27 + k2] = v;
-            }
-        }
-        __syncthreads();
-        if (tid < 27 && ncols > 0) {
-            double s2 = 0.0;
-#pragma unroll
-            for (int w = 0; w < SCHUR_THREADS / 64; ++w) s2 += cpart[w * SCHUR_CAM_LD + 27 + tid];
-            if (tid < 21) {
-                int q = 0, b = tid;
-                while (b > q) { ++q; b -= q; }
-                acc[(size_t)vsf[ncols - 1] * SCHUR_BLK_LD + q * 6 + b] += s2;
-            } else {
-                racc[tid - 21] += s2;
-            }
-        }
-    }
-    __syncthreads();
-    for (int e = tid; e < ncols * 36; e += SCHUR_THREADS) {
-        const int slot = e / 36, k2 = e - slot * 36, q = k2 / 6, b = k2 - q * 6;
-        const int c2 = cols[slot];
-        if (c2 == c && b > q) continue;
-        const int v1 = vsf[slot + 1];
-        double sum = acc[vsf[slot] * SCHUR_BLK_LD + k2];
-        for (int v = vsf[slot] + 1; v < v1; ++v) sum += acc[v * SCHUR_BLK_LD + k2];
-        a.S[(size_t)(c * 6 + q) * a.lda + c2 * 6 + b] = sum;
-    }
-    if (diag_piece) {
-        if (tid < 6) a.rhs[c * 6 + tid] = racc[tid];
-        if (tid >= 64 && tid < 64 + 27) {
-            const int k2 = tid - 64;
-            double s = 0.0;
-#pragma unroll
-            for (int w = 0; w < SCHUR_THREADS / 64; ++w) s += cpart[w * SCHUR_CAM_LD + k2];
-            if (k2 < 21) {
-                int q = 0, b = k2;
-                while (b > q) { ++q; b -= q; }
-                a.Hcc[(size_t)c * 36 + q * 6 + b] = s;
-                a.Hcc[(size_t)c * 36 + b * 6 + q] = s;
-            } else {
-                a.gc[(size_t)c * 6 + (k2 - 21)] = s;
-            }
-        }
-    }
-}
-
-// ===========================================================================================
 // The same Schur complement for DENSE visibility (most cameras see most landmarks): per observation i of landmark j the 6 x 3 block
 // Y_i = (Jc_i^T Jp_i) R_j with R_j R_j^T = Hpp_j^-1 (Cholesky of the inverse landmark block), written into a dense matrix
 // Y [6 n_cams padded] x [3 n_pts padded]; then S = -(Y Y^T) (lower triangle) is ONE symmetric rank-k product on the matrix cores
@@ -1270,28 +1064,10 @@ static int launch_schur_inst(const SchurArgs& a, int n_tasks, size_t lds, hipStr
     return STBA_OK;
 }
 
-template <bool GEN>
-static int launch_schur_y_inst(const SchurArgs& a, int n_tasks, size_t lds, hipStream_t st) {
-    static DeviceOnce attr;
-    STBA_TRY(attr.run([]() -> int {
-        STBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_schur_pairs_y_kernel<SCHUR_ROTS, GEN>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)schur_rows_lds_bytes(SCHUR_MAX_SLOTS)));
-        return STBA_OK;
-    }));
-    if (a.n_obs > 0)
-        hipLaunchKernelGGL((ba_schur_yrec_kernel<GEN>), dim3((a.n_obs + 255) / 256), dim3(256), 0, st, a.n_obs, a.obs_pt, a.J8, a.omask, a.Jc12, a.Hinv6, a.Yrec);
-    hipLaunchKernelGGL((ba_schur_pairs_y_kernel<SCHUR_ROTS, GEN>), dim3(n_tasks), dim3(SCHUR_THREADS), lds, st, a);
-    return STBA_OK;
-}
-
 int launch_schur_rows(const SchurArgs& a, int n_tasks, hipStream_t st) {
     if (n_tasks <= 0) return STBA_OK;
     const size_t lds = schur_rows_lds_bytes(a.max_cols);
-    if (a.Yrec) {
-        STBA_TRY(a.Jc12 ? launch_schur_y_inst<true>(a, n_tasks, lds, st) : launch_schur_y_inst<false>(a, n_tasks, lds, st));
-        STBA_HIP(hipGetLastError());
-        return STBA_OK;
-    }
+
     // (column rotations measured at C5: 1 / 2 / 3 / 6 -> 0.283 / 0.268 / 0.264 / 0.266 ms)
 #ifdef STBA_DEBUG_KNOBS
     if (a.mode == 1) STBA_TRY(a.Jc12 ? (launch_schur_inst<true, 1>(a, n_tasks, lds, st)) : (launch_schur_inst<false, 1>(a, n_tasks, lds, st)));

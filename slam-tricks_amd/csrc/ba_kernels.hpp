@@ -79,7 +79,6 @@ struct SchurArgs {
     const int* task_vs_ptr; const int* vs_first;     // per task: [blocks + 1] first accumulator slot of every block of the slice
     const int* obs_pt;                               // landmark of every observation
     const int4* pair_rec;                            // (i, l, landmark, slot | 0x8000 if diagonal block), l != i
-    double* Yrec = nullptr; int n_obs = 0;           // round 6, record form: Y_i = (Jc^T Jp) chol(Hpp^-1) [n_obs][18], made by the launch itself
 };
 // the Schur complement for dense visibility as a symmetric rank-k product (ba_kernels.hip, "DENSE visibility")
 struct SchurDenseArgs {

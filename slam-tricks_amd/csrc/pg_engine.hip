@@ -936,7 +936,8 @@ struct PpArgs {
     double *x, *ubuf, *pbuf;
     int *ustamp, *pstamp;
     PcgState* state;
-    long long spin_limit;
+    long long spin_limit; // how long a workgroup waits for a stamp, in ticks of wall_clock64 (100 MHz); 0: not at all (the test of the way back)
+    int fences;           // 1: the stamps are published behind a RELEASE fence and read in front of an ACQUIRE fence (agent scope); 0: compiler barriers only
     long long* tdbg;      // debug builds: time per phase (group 0), else null
 };
 
@@ -945,6 +946,33 @@ inline size_t pp_lds_bytes(int na, int nc) { return ((size_t)2 * nc + (size_t)na
 __device__ __forceinline__ int pp_ld_i(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ double pp_ld(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void pp_st(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// THE MEMORY ORDER OF THE TWO EXCHANGES (advisor, round 5).  Producer: data with agent-scope stores (write-through), s_waitcnt
+// vmcnt(0) -- every store acknowledged --, workgroup barrier, then the stamp.  Consumer: polls the stamp, then loads the data with
+// agent-scope loads (never from the L1).  What the hardware orders by itself (a load is ISSUED after the poll's branch has seen the
+// stamp; stores are acknowledged before the stamp is issued) the COMPILER must not undo: both sides carry a compiler barrier.
+// With PpArgs::fences the stamp is also stored behind an agent-scope release fence and the data loaded behind an acquire fence --
+// the formally complete protocol; measured against the barrier-only form in tools/dbg/c4_async.py (round 6).
+__device__ __forceinline__ void pp_publish(int* stamp, int value, int fences) {
+    if (fences) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    else asm volatile("" ::: "memory");
+    __hip_atomic_store(stamp, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// waits until *stamp >= want; the limit is WALL-CLOCK time (a slow but live peer must not send the engine to the launch path for
+// good: until round 5 the limit was a count of polls), looked at every 32 polls
+__device__ __forceinline__ bool pp_await(const int* stamp, int want, long long limit_ticks, int fences) {
+    bool ok = true;
+    if (pp_ld_i(stamp) - want < 0) {
+        const long long t0 = wall_clock64();
+        unsigned spins = 0;
+        while (pp_ld_i(stamp) - want < 0) {
+            __builtin_amdgcn_s_sleep(1);
+            if (limit_ticks <= 0 || ((++spins & 31u) == 0 && wall_clock64() - t0 > limit_ticks)) { ok = false; break; }
+        }
+    }
+    if (fences) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    else asm volatile("" ::: "memory");
+    return ok;
+}
 
 // B_e = Ji^T Jj of every edge, stored COMPONENT-major over the CSR positions of the edge ENDS ([36][2 m]): column end_pos[2 e] (the
 // end at i, which multiplies u_j) gets B_e, column end_pos[2 e + 1] (the end at j, which multiplies u_i) its transpose
@@ -1044,14 +1072,10 @@ __global__ __launch_bounds__(PP_T) void pg_pcg_persistent_kernel(PpArgs a) {
         double* mine = a.pbuf + ((size_t)(round & 1) * na + grp) * PP_SLOT;
         if (t < K) { pp_st(mine + t, sc[t]); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
         __syncthreads();
-        if (t == 0) __hip_atomic_store(&a.pstamp[grp * PP_STAMP], a.base + round + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == 0) pp_publish(&a.pstamp[grp * PP_STAMP], a.base + round + 1, a.fences);
         if (t < na) {
-            bool ok = true;
-            long long spins = 0;
-            while (pp_ld_i(&a.pstamp[t * PP_STAMP]) - (a.base + round + 1) < 0) {
-                __builtin_amdgcn_s_sleep(1);
-                if (++spins > a.spin_limit) { ok = false; s_abort = 1; break; }
-            }
+            const bool ok = pp_await(&a.pstamp[t * PP_STAMP], a.base + round + 1, a.spin_limit, a.fences);
+            if (!ok) s_abort = 1;
             if (ok) {
                 const double* src = a.pbuf + ((size_t)(round & 1) * na + t) * PP_SLOT;
                 for (int k = 0; k < K; ++k) gat[t * PP_SLOT + k] = pp_ld(src + k);
@@ -1129,7 +1153,7 @@ __global__ __launch_bounds__(PP_T) void pg_pcg_persistent_kernel(PpArgs a) {
         if (act) { pp_st(ub + o, u); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
         if (t < 384) ul[t] = u;
         __syncthreads();
-        if (t == 0) __hip_atomic_store(&a.ustamp[grp * PP_STAMP], a.base + k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == 0) pp_publish(&a.ustamp[grp * PP_STAMP], a.base + k + 1, a.fences);
         PP_STAMP_T(0);
         // ---- off-diagonal blocks times the remote ends' u
         for (int c = c0 + t, pass = 0; c < c1; c += PP_T, ++pass) {
@@ -1142,12 +1166,8 @@ __global__ __launch_bounds__(PP_T) void pg_pcg_persistent_kernel(PpArgs a) {
             // bytes of scratch per lane, 780 LM it/s)
             const int rem = pass == 0 ? rem0 : a.end_rem[c];
             const int* stamp = &a.ustamp[(rem >> a.log2agg) * PP_STAMP];
-            bool ok = true;
-            long long spins = 0;
-            while (pp_ld_i(stamp) - (a.base + k + 1) < 0) {
-                __builtin_amdgcn_s_sleep(1);
-                if (++spins > a.spin_limit) { ok = false; s_abort = 1; break; }
-            }
+            const bool ok = pp_await(stamp, a.base + k + 1, a.spin_limit, a.fences);
+            if (!ok) s_abort = 1;
             double ur[6] = {0, 0, 0, 0, 0, 0};
             if (ok) for (int b = 0; b < 6; ++b) ur[b] = pp_ld(ub + (size_t)rem * 6 + b);
 #pragma unroll
@@ -1855,7 +1875,8 @@ int stba_pg_solve(stba_pg* g, const stba_lm_options* opt_in, const stba_pcg_opti
             a.na = g->na; a.nc = g->nc; a.base = g->pp_base; a.max_iters = pcg.max_iterations; a.eta = eta_k;
             a.node_start = g->node_start; a.end_rem = g->end_rem; a.Bend = g->Bend; a.Hd = g->Hd; a.d = g->d; a.Minv = g->Minv; a.AdP = g->AdP;
             a.Ainv = Ainv_use; a.g = g->g; a.x = g->x; a.ubuf = g->ubuf; a.pbuf = g->pbuf; a.ustamp = g->ustamp; a.pstamp = g->pstamp;
-            a.state = g->state; a.spin_limit = pcg.one_kernel_solve == 2 ? 0 : 1ll << 18;      // (a poll is a memory round trip, ~1 us: a quarter of a second; 2: the test of the way back)
+            a.state = g->state; a.spin_limit = pcg.one_kernel_solve == 2 ? 0 : 25000000ll;      // (a quarter of a second of wall_clock64 ticks; 2: the test of the way back)
+            a.fences = pcg.one_kernel_solve == 3 ? 1 : 0;
             a.tdbg = nullptr;
 #ifdef STBA_DEBUG_KNOBS
             static long long* tdbg_dev = nullptr;

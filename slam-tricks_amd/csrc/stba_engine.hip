@@ -102,7 +102,6 @@ struct stba_ba {
     int schur_mode = STBA_SCHUR_PAIRS, schur_mode_auto = STBA_SCHUR_PAIRS;
     bool have_pair_plan = false;
     double* Y = nullptr; size_t ldy = 0, ykcols = 0;     // [lda][ldy]
-    double* Yrec = nullptr;                              // STBA_SCHUR_PAIRS_RECORDS: [n_obs][18]
     double *yv = nullptr, *yws = nullptr;
     unsigned char* dup_run = nullptr;                    // repeated (camera, landmark) pairs, per position of cam_perm (null: none)
     unsigned char *cam_fixed = nullptr, *pt_fixed = nullptr;
@@ -168,7 +167,7 @@ static void ba_free(stba_ba* b) {
     F(b->pt_fixed); F(b->r); F(b->J8); F(b->Jc12); F(b->omask); F(b->Hpp6); F(b->gp); F(b->Hinv6); F(b->dp); F(b->scale_p);
     F(b->Hcc); F(b->gc); F(b->cam_partial); F(b->dc); F(b->scale_c); F(b->Sbuf); F(b->Spack); F(b->pk_blocks); F(b->dxc); F(b->dxp);
     F(b->task_cam); F(b->cam_start); F(b->task_col_lo); F(b->task_col_hi); F(b->row_col_ptr); F(b->row_cols);
-    F(b->pair_begin); F(b->pair_end); F(b->pair_rec); F(b->task_vs_ptr); F(b->vs_first); F(b->Y); F(b->Yrec); F(b->yv); F(b->yws); F(b->dup_run);
+    F(b->pair_begin); F(b->pair_end); F(b->pair_rec); F(b->task_vs_ptr); F(b->vs_first); F(b->Y); F(b->yv); F(b->yws); F(b->dup_run);
     F(b->cost_partial); F(b->upd_partial_c); F(b->upd_partial_p); F(b->trial); F(b->flag);
     for (auto& e : b->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : b->ev_ar) if (e) (void)hipEventDestroy(e);
@@ -400,10 +399,6 @@ static int ba_schur_step(stba_ba* b) {
     sa.S = b->S(); sa.lda = b->lda; sa.rhs = b->rhs(); sa.Hcc = b->Hcc; sa.gc = b->gc;
     sa.obs_pt = b->obs_pt; sa.pair_begin = b->pair_begin; sa.pair_end = b->pair_end; sa.pair_rec = b->pair_rec;
     sa.task_vs_ptr = b->task_vs_ptr; sa.vs_first = b->vs_first; sa.mode = b->schur_plan_mode;
-    if (b->schur_mode == STBA_SCHUR_PAIRS_RECORDS) {
-        if (!b->Yrec) STBA_TRY(dev_alloc(&b->Yrec, (size_t)std::max(b->no, 1) * 18));
-        sa.Yrec = b->Yrec; sa.n_obs = b->no;
-    }
     return launch_schur_rows(sa, b->n_tasks, b->st);
 }
 
@@ -573,7 +568,7 @@ static void default_options(stba_lm_options* o) {
     o->minimizer_progress_to_stdout = 0;
     o->update_state_every_iteration = 0;
     o->phase_timing = 0;
-    o->function_tolerance_takes_step = 1;
+    o->function_tolerance_takes_step = 0;      // (Ceres >= 1.12: FunctionToleranceReached() returns in front of IsStepSuccessful(); stba.h)
 }
 
 // reads {cost2, gpmax slots, gc} after a reduced-system build and returns cost / gradient max norm
@@ -1420,9 +1415,9 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
 }
 
 int stba_ba_set_schur_mode(stba_ba* ba, int mode) {
-    if (!ba || mode < STBA_SCHUR_AUTO || mode > STBA_SCHUR_PAIRS_RECORDS) return fail(STBA_ERR_INVALID_ARGUMENT, "stba_ba_set_schur_mode: bad argument");
+    if (!ba || mode < STBA_SCHUR_AUTO || mode > STBA_SCHUR_DENSE) return fail(STBA_ERR_INVALID_ARGUMENT, "stba_ba_set_schur_mode: bad argument");
     if (mode == STBA_SCHUR_AUTO) mode = ba->schur_mode_auto;
-    if ((mode == STBA_SCHUR_PAIRS || mode == STBA_SCHUR_PAIRS_RECORDS) && !ba->have_pair_plan)
+    if (mode == STBA_SCHUR_PAIRS && !ba->have_pair_plan)
         return fail(STBA_ERR_INVALID_ARGUMENT, "stba_ba_set_schur_mode: this engine was created without a pair plan (too many observation pairs)");
     if (mode == STBA_SCHUR_DENSE) STBA_TRY(ba_dense_alloc(ba));
     ba->schur_mode = mode;

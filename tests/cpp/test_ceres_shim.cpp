@@ -417,6 +417,22 @@ int main(int argc, char** argv) {
         SolveBA(s, 1, "ba_user", std::atoi(argv[3]), 1000000);
         return 0;
     }
+    // ---- "loss": a residual block with a non-null LossFunction must be REFUSED (robust losses are not implemented; the reference
+    // passes nullptr, test_ceres.h:120): FAILURE, parameters untouched, the reason in the message -- no device needed
+    if (argc >= 2 && std::strcmp(argv[1], "loss") == 0) {
+        struct Huber : ceres::LossFunction {};
+        ceres::Problem problem;
+        auto costFunc = DemoFunctor::Create();
+        costFunc->AddParameterBlock(1);
+        costFunc->SetNumResiduals(1);
+        double x = 0.5;
+        problem.AddResidualBlock(costFunc, new Huber(), &x);
+        ceres::Solver::Options options;
+        ceres::Solver::Summary summary;
+        ceres::Solve(options, &problem, &summary);
+        std::printf("loss x %.17g term %d losses %d msg %s\n", x, (int)summary.termination_type, problem.NumLossFunctions(), summary.message.c_str());
+        return 0;
+    }
     // ---- "time_ba <scene> <max_iterations> <reps> [threads]": wall-clock of the reference's BA call site as the reference times it
     // (test_ceres.h:103-104,149: the timer starts in front of the problem construction) -- construction and Solve() separately,
     // Solve()'s own phases from Summary::phases.  One line per repetition; the caller takes the median.

@@ -66,6 +66,16 @@ def test_shim_compiles_and_fails_loudly_without_device(exe):
         assert abs(float(out["bound_0"].split()[1]) - 3.0) < 1e-8
 
 
+def test_a_loss_function_is_refused_loudly(exe):
+    """VERDICT r5 missing 6: Problem::AddResidualBlock(cost, loss, ...) with a non-null loss used to store it and solve UNWEIGHTED.
+    Now Solve() refuses: FAILURE, the parameter untouched, the message names the reason (also on stderr).  No device needed."""
+    p = subprocess.run([exe, "loss"], capture_output=True, text=True, timeout=60)
+    assert p.returncode == 0
+    toks = p.stdout.split()
+    assert toks[0] == "loss" and float(toks[2]) == 0.5 and toks[4] == "2" and toks[6] == "1"
+    assert "LossFunction" in p.stdout and "not implemented" in p.stdout and "LossFunction" in p.stderr
+
+
 def test_reference_ba_functor_is_recognised_on_the_host(exe, tmp_path, scenes):
     """Solve()'s dispatch (no device needed): the reference's own ProjectFactor behind DynamicAutoDiffCostFunction
     (test_ceres.h:47-81,109-121) is recognised as the reprojection factor, every `feature` is recovered exactly
@@ -177,6 +187,42 @@ def test_generic_ba_factor_beyond_the_dense_limit(exe, tmp_path, scenes, O):
     cams = vec(out, "ba_generic_cams").reshape(-1, 7)
     dq = np.minimum(np.abs(cams[:, :4] - o.cams[:, :4]).max(1), np.abs(cams[:, :4] + o.cams[:, :4]).max(1)).max()
     assert dq < 1e-6 and np.abs(cams[:, 4:] - o.cams[:, 4:]).max() < 1e-6
+
+
+@pytest.mark.gpu
+def test_published_pnp_workload_through_the_operator_api(exe, tmp_path, scenes):
+    """round 6: the three st17 PnP call sites as bench.py times them (construction + Solve per call, solver.hpp:253-288): every
+    repetition ends at the published pose, through the small dense path (one kernel launch per LM step), in well under the 3.5 ms
+    a Solve() of this size took until round 5 -- the bound here is loose on purpose (a shared box), bench.py reports the number."""
+    pnp = scenes.pnp_scene(seed=17)
+    f = str(tmp_path / "pnp.bin")
+    write_pnp(f, pnp)
+    out = run(exe, "time_pnp", f, "20")
+    truth = pnp["pose_true"]
+    for tag in ("pnp_dyn", "pnp_auto", "pnp_sized"):
+        toks = out[tag].split()
+        d = {toks[i]: toks[i + 1] for i in range(0, len(toks), 2)}
+        assert d["path"] == "gpu-dense-callback" and d["term"] == "0" and float(d["final"]) < 1e-14
+        pose = vec(out, tag + "_pose")
+        assert qerr(pose[:4], truth[:4]) < 1e-7 and np.abs(pose[4:] - truth[4:]).max() < 1e-6
+        ms = vec(out, tag + "_ms")
+        assert len(ms) == 20 and np.median(ms[1:]) < 2.0, ms
+
+
+@pytest.mark.gpu
+def test_drop_in_phases_are_reported(exe, tmp_path, scenes):
+    """Solver::Summary carries Ceres' timing fields and the header's own phase timers; they add up to the wall time of Solve()"""
+    s = scenes.st20_scene()
+    f = str(tmp_path / "s.bin")
+    write_scene(f, s)
+    out = run(exe, "time_ba", f, "50", "2")
+    toks = out["time_ba_1"].split()
+    d = {toks[i]: toks[i + 1] for i in range(0, len(toks), 2)}
+    assert d["path"] == "gpu-ba" and d["term"] == "0"
+    parts = sum(float(d[k]) for k in ("recognise", "pack", "engine_create", "device_solve", "write_back", "verify", "resolve"))
+    assert 0.0 < float(d["device_solve"]) <= parts <= float(d["solve"]) * 1.001 + 1e-4
+    assert parts >= 0.9 * float(d["solve"]) - 1e-3
+    assert float(d["minimizer"]) <= float(d["device_solve"]) + 1e-6
 
 
 @pytest.mark.gpu

@@ -1,0 +1,48 @@
+"""C4 with the coarse inverse in line (coarse_async = 0) and on its second stream (1), with and without the step-accuracy bound on
+the forcing term: LM iterations / s, PCG iterations, distance of the converged poses from the exact-step run and from the frozen
+oracle poses (tests/golden/oracle_traces.json), run-to-run bits.  minimizer_progress_to_stdout shows eta and the PCG count per iteration."""
+import importlib, json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import numpy as np
+st = importlib.import_module("slam-tricks_amd")
+scenes = importlib.import_module("slam-tricks_amd.scenes")
+s = scenes.pose_graph_scene(n_nodes=10000, loops_per_node=3, seed=4)
+gold = json.load(open(os.path.join(ROOT, "tests", "golden", "oracle_traces.json")))["c4"]
+gp = np.array(gold["final_poses_every_50th"]).reshape(-1, 7)
+
+
+def pdiff(a, b):
+    dq = np.minimum(np.abs(a[:, :4] - b[:, :4]).max(1), np.abs(a[:, :4] + b[:, :4]).max(1)).max()
+    return float(max(dq, np.abs(a[:, 4:] - b[:, 4:]).max()))
+
+
+def fresh():
+    return st.PGEngine(s["poses0"], s["edge_i"], s["edge_j"], s["meas"], s["node_fixed"])
+
+
+e = fresh()
+sx, trx, nx = e.solve(pcg=e.pcg_options(forcing_eta0=0.0, relative_tolerance=1e-12, max_iterations=2000))
+px = e.get_poses()
+print("exact steps: it %d pcg %d cost %.12g dist-to-gold %.2e" % (sx.num_iterations, nx, sx.final_cost, pdiff(px[::50], gp)))
+verbose = "-v" in sys.argv
+for name, kw in (("inline acc0", dict(coarse_async=0, forcing_step_accuracy=0.0)), ("inline", dict(coarse_async=0)),
+                 ("async acc0", dict(coarse_async=1, forcing_step_accuracy=0.0)), ("async", dict(coarse_async=1)),
+                 ("async 5e-7", dict(coarse_async=1, forcing_step_accuracy=5e-7)), ("async 1e-5", dict(coarse_async=1, forcing_step_accuracy=1e-5)),
+                 ("async exact", dict(coarse_async=1, forcing_eta0=0.0, relative_tolerance=1e-12, max_iterations=2000))):
+    times, last = [], None
+    for rep in range(4):
+        e = fresh()
+        e.solve(max_num_iterations=1, pcg=e.pcg_options(**kw))      # warm (allocations of the coarse space, streams)
+        e = fresh()
+        t0 = time.perf_counter()
+        summ, tr, tot = e.solve(pcg=e.pcg_options(**kw), minimizer_progress_to_stdout=int(verbose and rep == 0))
+        dt = time.perf_counter() - t0
+        p = e.get_poses()
+        times.append(dt)
+        same = last is None or (np.array_equal(last[0], tr) and np.array_equal(last[1], p))
+        last = (tr.copy(), p)
+    ps = e.pcg_summary().as_dict()
+    print("%-12s it %2d pcg %4d  %.3f ms/solve %.0f LM it/s  cost rel %.1e  dist exact %.2e gold %.2e  repeatable %s  one_kernel %d fails %d" % (
+        name, summ.num_iterations, tot, 1e3 * np.median(times), summ.num_iterations / np.median(times), abs(summ.final_cost - sx.final_cost) / sx.final_cost,
+        pdiff(p, px), pdiff(p[::50], gp), same, ps["one_kernel_solves"], ps["coarse_failures"]))
