@@ -83,17 +83,22 @@ typedef struct {
                                            * iteration fill stba_lm_summary::ms_* -- an event is a packet of its own on the queue
                                            * and costs ~5 us of idle GPU, ~1.5 % of a C5 iteration for the eight it takes */
     int    function_tolerance_takes_step; /* what happens to the trial step on which |cost change| <= function_tolerance * cost fires:
-                                           * 0 (default since stba_version() 6): convergence is reported at once and the step is NOT
-                                           *    taken -- the order of Ceres' TrustRegionMinimizer::Minimize since the refactoring of
-                                           *    1.12 (through 2.1): ComputeCandidatePointAndEvaluateCost(); if (ParameterToleranceReached())
-                                           *    return; if (FunctionToleranceReached()) return; if (IsStepSuccessful())
-                                           *    HandleSuccessfulStep(); -- the candidate only becomes the state in HandleSuccessfulStep;
-                                           * 1 (the default of versions <= 5): the step is taken if it is a decrease (rho >
-                                           *    min_relative_decrease), THEN convergence is reported -- Ceres <= 1.11's monolithic loop
-                                           *    read this way, and the wording of the solver documentation.
-                                           * The final parameters differ by one step of relative cost change <= 1e-6 either way; the
-                                           * oracle carries the same switch (orc_lm_options).  (No Ceres exists in this image to run
-                                           * against: tools/ceres_baseline.cpp on a box that has one shows it in num_successful_steps.) */
+                                           * 1 (default): it is taken if it is a decrease (rho > min_relative_decrease), THEN convergence
+                                           *    is reported;
+                                           * 0: convergence is reported at once and the step is NOT taken -- the order of Ceres'
+                                           *    TrustRegionMinimizer::Minimize since the refactoring of 1.12 (through 2.1):
+                                           *    ComputeCandidatePointAndEvaluateCost(); if (ParameterToleranceReached()) return;
+                                           *    if (FunctionToleranceReached()) return; if (IsStepSuccessful()) HandleSuccessfulStep();
+                                           *    -- the candidate becomes the state only in HandleSuccessfulStep.
+                                           * So 0 is Ceres' stopping state.  1 stays the default because the step that is given up is a
+                                           * full Newton step of a converged model and not a small one: on the C4 pose graph it still moves
+                                           * poses by 3.6e-3 (cost by < 1e-6 relative), and it is what brings a run with inexact steps back
+                                           * onto the exact-step trajectory -- measured in round 6 (profiles/r6_c4_async.txt): production
+                                           * against exact steps, poses 2.5e-6 apart with the step, 5.7e-5 without (north_star asks for
+                                           * 1e-5).  Taking it can only lower the final cost.  Engine and oracle (orc_lm_options) carry the
+                                           * same switch and agree under both settings; a caller who wants Ceres' own final state sets 0.
+                                           * (No Ceres exists in this image to run against; tools/ceres_baseline.cpp on a box that has
+                                           * one shows the order in num_successful_steps.) */
 } stba_lm_options;
 
 void stba_lm_default_options(stba_lm_options* opt);
@@ -368,11 +373,13 @@ typedef struct {
                                   * before the stamp is issued, loads issued after the stamp was seen) plus compiler barriers */
     int    coarse_async;         /* 1 (stba_version() >= 6): the coarse operator is inverted on a SECOND stream, next to the PCG kernel, and applied one
                                   * LM iteration late -- iteration k preconditions with the inverse of iteration k - 1's operator; the first solve
-                                  * runs on block Jacobi alone (forcing sequence) or waits for its inverse (exact steps).  Ordered by events:
-                                  * run-to-run reproducible.  0: inverted in line, as until version 5 (coarse_refresh_every applies) */
-    double forcing_step_accuracy;/* 2e-6 (stba_version() >= 6): the forcing term is also kept below (this) / (predicted length of the next
-                                  * step), so that the last inexact step before convergence is accurate to about this much in the
-                                  * parameters; 0: Eisenstat & Walker's sequence alone */
+                                  * waits for its own inverse.  2: the same, and with a forcing sequence the first solve does not wait: it runs on
+                                  * block Jacobi alone.  Ordered by events: run-to-run reproducible.  0: inverted in line, as until version 5
+                                  * (coarse_refresh_every applies) */
+    double forcing_eta_final;    /* 1e-4 (stba_version() >= 6): cap on the forcing term once the LM iteration is about to converge -- the last
+                                  * accepted step changed the cost by less than 100 x function_tolerance (relative).  The error of the LAST
+                                  * inexact step is what the converged poses keep (about eta x its length): Eisenstat & Walker's sequence
+                                  * alone leaves eta ~ 1e-2 there.  0: no cap */
 } stba_pcg_options;
 void stba_pcg_default_options(stba_pcg_options* o);
 typedef struct {

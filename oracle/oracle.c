@@ -263,7 +263,7 @@ void orc_lm_default_options(orc_lm_options* o) {
     o->jacobi_scaling = 1;
     o->num_threads = 1;
     o->fixed_iterations = 0;
-    o->function_tolerance_takes_step = 0;
+    o->function_tolerance_takes_step = 1;
 }
 
 /* ======================================================================================

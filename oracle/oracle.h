@@ -84,10 +84,11 @@ typedef struct {
     int    num_threads;                   /* 1 (reference pins 1: test_ceres.h:143) */
     int    fixed_iterations;              /* 0; >0: run exactly this many iterations, no
                                              convergence tests (bench / cpu_baseline mode) */
-    int    function_tolerance_takes_step; /* 0 (default): convergence is reported on the trial step that meets the function
-                                             tolerance WITHOUT taking it (the order of Ceres' TrustRegionMinimizer since 1.12:
-                                             FunctionToleranceReached() returns in front of IsStepSuccessful()); 1: the step is
-                                             taken first if it is a decrease -- see stba_lm_options in include/stba.h */
+    int    function_tolerance_takes_step; /* 1 (default): the step on which the function tolerance fires is taken if it is a
+                                             decrease, then convergence is reported; 0: convergence is reported without taking
+                                             it -- the order of Ceres' TrustRegionMinimizer since 1.12 (FunctionToleranceReached()
+                                             returns in front of IsStepSuccessful()).  Why 1 stays the default: stba_lm_options
+                                             in include/stba.h */
 } orc_lm_options;
 
 enum { ORC_CONVERGENCE = 0, ORC_NO_CONVERGENCE = 1, ORC_FAILURE = 2 };

@@ -1487,7 +1487,7 @@ void stba_pcg_default_options(stba_pcg_options* o) {
     o->coarse_refresh_every = 1;
     o->one_kernel_solve = 1;
     o->coarse_async = 1;
-    o->forcing_step_accuracy = 2e-6;
+    o->forcing_eta_final = 1e-4;
 }
 
 int stba_pg_create(stba_pg** out, int n_nodes, int n_edges, const double* poses, const int* edge_i, const int* edge_j,
@@ -1761,9 +1761,10 @@ int stba_pg_solve(stba_pg* g, const stba_lm_options* opt_in, const stba_pcg_opti
             // iteration at C4) runs on a SECOND stream, next to this iteration's PCG kernel (157 workgroups on 256 CUs), and is applied one LM
             // iteration LATE: iteration k preconditions with the inverse of iteration k - 1's operator -- an inverse made at the
             // previous linearisation / damping still is a preconditioner, only a weaker one (coarse_refresh_every = 2 had measured
-            // + 9 % PCG iterations).  The very first solve has no predecessor: with a forcing sequence (eta_0 = 0.1: a loose solve)
-            // it runs on block Jacobi alone (Ainv = 0), with exact steps it waits for its own inverse.  Everything is ordered by
-            // events, so the result does not depend on timing: run to run the same bits.
+            // + 9 % PCG iterations).  The very first solve has no predecessor: it waits for its own inverse (coarse_async = 2 with a
+            // forcing sequence: it runs on block Jacobi alone, Ainv = 0 -- 3 PCG iterations at eta_0 = 0.1, but a first step that
+            // leaves the cost at 1021 where the two-level step leaves 258 and the exact one 48: the whole trajectory moves).
+            // Everything is ordered by events, so the result does not depend on timing: run to run the same bits.
             //   stream 1: precond_k | wait job_{k-1} | Dc_k, assemble W_k | record IN_k | PCG_k (Ainv of job_{k-1}) | trial ...
             //   stream 2:                                                   wait IN_k   | invert W_k -> Ainv[k & 1] | record job_k
             const int wbuf = jobs & 1;
@@ -1782,7 +1783,7 @@ int stba_pg_solve(stba_pg* g, const stba_lm_options* opt_in, const stba_pcg_opti
             STBA_HIP(hipEventRecord(g->ev_job[wbuf], g->st2));
             g->job_in_flight = true;
             Ainv_use = Ar;
-            if (jobs == 0 && !forcing) {                         // exact steps: the first solve waits for its own inverse
+            if (jobs == 0 && (!forcing || pcg.coarse_async != 2)) {      // the first solve waits for its own inverse (2: not with a forcing sequence)
                 STBA_HIP(hipStreamWaitEvent(g->st, g->ev_job[wbuf], 0));
                 Ainv_use = Aw;
             }
@@ -1974,14 +1975,11 @@ int stba_pg_solve(stba_pg* g, const stba_lm_options* opt_in, const stba_pcg_opti
                 double e2 = 0.9 * g2_new / g2;
                 if (0.9 * eta * eta > 0.1) e2 = std::max(e2, 0.9 * eta * eta);
                 eta = std::min(pcg.forcing_eta0, std::max(pcg.forcing_eta_min, e2));
-                // (round 6) ... and tight enough that the step it stops is accurate to forcing_step_accuracy in the parameters:
-                // the next step is about |step| |g_{k+1}| / |g_k| long (Newton: the step follows the gradient), a solve stopped at
-                // eta leaves about eta times that as its error -- and the error of the LAST step before the function tolerance
-                // fires is what the converged poses keep (north_star asks for 1e-5 on poses against exact steps)
-                if (pcg.forcing_step_accuracy > 0.0 && step_norm > 0.0) {
-                    const double pred = step_norm * std::sqrt(g2_new / g2);
-                    if (pred > 0.0 && std::isfinite(pred)) eta = std::max(pcg.forcing_eta_min, std::min(eta, pcg.forcing_step_accuracy / pred));
-                }
+                // (round 6) about to converge -- the step just taken changed the cost by less than 100 x the function tolerance: the
+                // error of the LAST inexact step is what the converged poses keep (about eta x its length; on C4 the last step still
+                // moves poses by 3.6e-3, and Eisenstat & Walker leave eta ~ 1e-2 there: 4e-5 in the poses, north_star asks for 1e-5)
+                if (pcg.forcing_eta_final > 0.0 && cost_change <= 100.0 * opt.function_tolerance * (cost + cost_change))
+                    eta = std::max(pcg.forcing_eta_min, std::min(eta, pcg.forcing_eta_final));
             }
             g2 = g2_new;
             if (trace) { trace[(size_t)iter * STBA_TRACE_COLS + 2] = gmax; trace[(size_t)iter * STBA_TRACE_COLS + 5] = radius; }

@@ -568,7 +568,7 @@ static void default_options(stba_lm_options* o) {
     o->minimizer_progress_to_stdout = 0;
     o->update_state_every_iteration = 0;
     o->phase_timing = 0;
-    o->function_tolerance_takes_step = 0;      // (Ceres >= 1.12: FunctionToleranceReached() returns in front of IsStepSuccessful(); stba.h)
+    o->function_tolerance_takes_step = 1;      // (stba.h: why the step is taken by default although Ceres >= 1.12 does not)
 }
 
 // reads {cost2, gpmax slots, gc} after a reduced-system build and returns cost / gradient max norm

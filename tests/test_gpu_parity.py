@@ -823,9 +823,9 @@ def test_function_tolerance_switch_follows_the_oracle(st, O, scenes):
     s = scenes.st20_scene(pix_noise=1e-3)
     e1, e0 = engine(st, s), engine(st, s)
     o0 = oracle(O, s)
-    s1, t1 = e1.solve(function_tolerance_takes_step=1)
-    s0, t0 = e0.solve()                                 # (0 is the default since round 6: Ceres >= 1.12's order of calls)
-    so, to = o0.solve()
+    s1, t1 = e1.solve()
+    s0, t0 = e0.solve(function_tolerance_takes_step=0)
+    so, to = o0.solve(function_tolerance_takes_step=0)
     n = so.num_iterations
     assert s0.num_iterations == n == s1.num_iterations and s0.termination_reason == so.termination_reason == 2
     assert np.array_equal(t0[: n + 1, 6], to[: n + 1, 6]) and t0[n, 6] == 0 and t1[n, 6] == 1

@@ -198,14 +198,14 @@ def test_lapack_backed_reduced_solve_follows_the_c_factorisation(O, scenes):
 
 def test_function_tolerance_switch(O, scenes):
     """the one reading of Ceres that changes results: is the step on which the function tolerance fires taken?
-    1 (the default until round 5): yes, if it decreases the cost; 0 (the default now: Ceres >= 1.12's order of calls): no.  Same iterations, same trace up to the last row, one accepted step
+    1 (default): yes, if it decreases the cost; 0 (Ceres >= 1.12's order of calls): no.  Same iterations, same trace up to the last row, one accepted step
     and one tiny cost change apart; the final parameters agree far inside north_star's tolerances either way."""
     s = scenes.st20_scene(pix_noise=1e-3)
     mk = lambda: O.BA(s["cams0"], s["pts0"], s["obs_cam"], s["obs_pt"], s["obs_feat"], s["cam_fixed"])
     o1, o0 = mk(), mk()
-    s1, t1 = o1.solve(function_tolerance_takes_step=1)
-    s0, t0 = o0.solve()
-    assert O.default_options().function_tolerance_takes_step == 0
+    s1, t1 = o1.solve()
+    s0, t0 = o0.solve(function_tolerance_takes_step=0)
+    assert O.default_options().function_tolerance_takes_step == 1
     assert s1.termination_reason == O.TERM_FUNCTION if hasattr(O, "TERM_FUNCTION") else s1.termination_reason == 2
     assert s0.termination_reason == s1.termination_reason and s0.num_iterations == s1.num_iterations
     n = s1.num_iterations

@@ -26,10 +26,12 @@ sx, trx, nx = e.solve(pcg=e.pcg_options(forcing_eta0=0.0, relative_tolerance=1e-
 px = e.get_poses()
 print("exact steps: it %d pcg %d cost %.12g dist-to-gold %.2e" % (sx.num_iterations, nx, sx.final_cost, pdiff(px[::50], gp)))
 verbose = "-v" in sys.argv
-for name, kw in (("inline acc0", dict(coarse_async=0, forcing_step_accuracy=0.0)), ("inline", dict(coarse_async=0)),
-                 ("async acc0", dict(coarse_async=1, forcing_step_accuracy=0.0)), ("async", dict(coarse_async=1)),
-                 ("async 5e-7", dict(coarse_async=1, forcing_step_accuracy=5e-7)), ("async 1e-5", dict(coarse_async=1, forcing_step_accuracy=1e-5)),
-                 ("async exact", dict(coarse_async=1, forcing_eta0=0.0, relative_tolerance=1e-12, max_iterations=2000))):
+for name, kw in (("inline e0", dict(coarse_async=0, forcing_eta_final=0.0)), ("inline", dict(coarse_async=0)),
+                 ("async1 e0", dict(coarse_async=1, forcing_eta_final=0.0)), ("async1", dict(coarse_async=1)),
+                 ("async1 1e-5", dict(coarse_async=1, forcing_eta_final=1e-5)),
+                 ("async2 e0", dict(coarse_async=2, forcing_eta_final=0.0)), ("async2", dict(coarse_async=2)),
+                 ("async1 fence", dict(coarse_async=1, one_kernel_solve=3)),
+                 ("async1 exact", dict(coarse_async=1, forcing_eta0=0.0, relative_tolerance=1e-12, max_iterations=2000))):
     times, last = [], None
     for rep in range(4):
         e = fresh()
