@@ -279,6 +279,30 @@ def cpu_model():
     return "unknown"
 
 
+def cpu_quota():
+    """CPUs this process may use at once: the cgroup's cpu.max quota (v2) / cfs quota (v1) and the affinity mask -- on the GPU boxes of
+    this pool the container sees 256 logical cores and is throttled to 16 CPUs' worth of time (cpu.max = 1600000 100000,
+    profiles/r6_host_cpu_quota.txt): OpenMP teams larger than that run SLOWER, which is what the thread sweep of round 5 showed"""
+    q = None
+    try:
+        a, b = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if a != "max":
+            q = float(a) / float(b)
+    except Exception:
+        try:
+            a = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            b = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if a > 0:
+                q = a / b
+        except Exception:
+            pass
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except Exception:
+        aff = os.cpu_count() or 1
+    return q, aff
+
+
 def pose_err(a, b):
     dq = np.minimum(np.abs(a[:, :4] - b[:, :4]).max(1), np.abs(a[:, :4] + b[:, :4]).max(1)).max()
     return float(dq), float(np.abs(a[:, 4:] - b[:, 4:]).max())
@@ -360,7 +384,7 @@ def drop_in_rows(s, eng, out):
             if gate and gate.get("passed"):
                 # the CPU port's whole solve (same start, same iterations, matched result) against the same solve THROUGH THE API
                 d["speedup_vs_cpu_port_through_the_api"] = gate["cpu_solve_seconds"] / d["seconds"]["solve"]
-                d["speedup_note"] = (f"CPU port to convergence {gate['cpu_solve_seconds']:.2f} s ({gate['cpu_dense_solver']}, 16 threads) / ceres::Solve() "
+                d["speedup_note"] = (f"CPU port to convergence {gate['cpu_solve_seconds']:.2f} s ({gate['cpu_dense_solver']}, {gate.get('cpu_threads', 16)} threads) / ceres::Solve() "
                                      f"{d['seconds']['solve']:.3f} s wall (recognition, engine creation, device solve, write-back, end-point check)")
             d["note"] = ("seconds, median of 5: `build` = the caller's 10^6 AddResidualBlock (its cost with Ceres too), `solve` = ceres::Solve() wall, of "
                          "which recognise / pack / engine_create / device_solve / write_back / verify are the header's own phase timers; one host thread")
@@ -454,6 +478,20 @@ def bench_c4(args):
     e = fresh()
     ms_lin, ms_mv = e.time_kernels(reps=200)
     b_lin, b_mv = pg_bytes_per_edge(n, m)
+    # the dominant kernel of the production solve: the persistent PCG kernel, timed LIVE with hipEvents on the engine's stream around
+    # every linear solve of one more whole solve (stba_lm_options::phase_timing -> stba_pcg_summary::linear_solve_ms)
+    e = fresh()
+    summ_t, _, pcg_t = e.solve(max_num_iterations=args.steps, phase_timing=1)
+    ps_t = e.pcg_summary().as_dict()
+    n_solves = max(int(ps_t["solves"]), 1)
+    ms_pcg_launch = ps_t["linear_solve_ms"] / n_solves
+    us_pcg_iter = 1e3 * ps_t["linear_solve_ms"] / max(pcg_t + n_solves, 1)      # (+1 per solve: the start-up pass has both exchanges too)
+    # algorithmic bytes of one PCG iteration of the ASSEMBLED operator: one 6x6 block (288 B) + the remote node's u (48 B) per edge end,
+    # diagonal block + M^-1 + P rows live in registers; u published (48 B per node) and nine partial sums all-gathered
+    na = max(1, (n + 63) // 64)
+    b_pcg_iter = (288.0 + 48.0) * 2 * m + 48.0 * n + 72.0 * na * na
+    pcg_per_launch = (pcg_t + n_solves) / n_solves
+    EXCHANGE_FLOOR_US = 6.0          # tools/exp/pcg_skeleton.hip, profiles/r5_pcg_skeleton.txt: both stamped exchanges of an iteration, nothing else
     products = pcg_total + iters                       # one more product per LM iteration (model decrease)
     out = {
         "metric": "LM iterations/sec, 10k-node / 40k-edge pose graph (BASELINE config 4)", "value": iters / dt, "unit": "LM iterations/s",
@@ -471,12 +509,21 @@ def bench_c4(args):
                         "lm_iterations_per_sec": summ_x.num_iterations / dt_x, "final_cost": summ_x.final_cost,
                         "note": "the same solve with the PCG run to 1e-12 (forcing_eta0 = 0): the LM trace the oracle's is compared with"},
         "reps_solve_seconds": [r[0] for r in reps], "timing": "median of reps",
-        "roofline": {"kernel": "pg_edge_product_kernel (t = J [p_i; p_j], u = J^T t per edge, component-major Jacobians; the node kernel gathers u)",
+        "roofline": {"kernel": "pg_pcg_persistent_kernel (the whole PCG solve of an LM iteration: assembled operator, two stamped exchanges per iteration)",
+                     "bound": "hbm", "achieved": b_pcg_iter * pcg_per_launch / (ms_pcg_launch * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": b_pcg_iter * pcg_per_launch / (ms_pcg_launch * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                     "ms_per_launch": ms_pcg_launch, "launches": n_solves, "pcg_iterations_per_launch": pcg_per_launch,
+                     "algorithmic_bytes_per_pcg_iteration": b_pcg_iter, "algorithmic_bytes_per_launch": b_pcg_iter * pcg_per_launch,
+                     "us_per_pcg_iteration": us_pcg_iter, "exchange_floor_us_per_pcg_iteration": EXCHANGE_FLOOR_US,
+                     "frac_of_exchange_floor": EXCHANGE_FLOOR_US / max(us_pcg_iter, 1e-9),
+                     "share_of_solve": ps_t["linear_solve_ms"] * 1e-3 / max(dt, 1e-12),
+                     "note": f"{b_pcg_iter / 1e6:.1f} MB per PCG iteration, resident in the L2s after the first pass (8 x 4 MB): the HBM figure is the schema's, the "
+                             "bound that binds is LATENCY -- an iteration is two dependent device-wide exchanges (neighbours' u; nine partial sums "
+                             "all-gathered), 6.0 us for both in the bare skeleton; `frac_of_exchange_floor` is the fraction to read"},
+        "roofline_edge_product": {"kernel": "pg_edge_product_kernel (the launch path's product, and the trial point's |J x|^2)",
                      "bound": "hbm", "achieved": b_mv * m / (ms_mv * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": b_mv * m / (ms_mv * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "ms_per_launch": ms_mv,
-                     "algorithmic_bytes_per_edge": b_mv, "algorithmic_bytes_per_launch": b_mv * m,
-                     "note": f"{b_mv * m / 1e6:.1f} MB per product: 3.5 us at 8 TB/s -- at this size a launch is latency, not bandwidth: "
-                             "the 40k-edge graph fills 157 of 256 CUs once, and a PCG iteration is four dependent launches"},
+                     "algorithmic_bytes_per_edge": b_mv, "algorithmic_bytes_per_launch": b_mv * m},
         "roofline_linearize": {"kernel": "pg_linearize_kernel (residual + both 6x6 Jacobians per edge)", "bound": "hbm",
                                "achieved": b_lin * m / (ms_lin * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": b_lin * m / (ms_lin * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "ms_per_launch": ms_lin,
@@ -791,6 +838,11 @@ def main():
             import oracle_py as O       # cpu_baseline leg only: the oracle is the thing timed / the checker here
             ncpu = os.cpu_count() or 1
             model = cpu_model()
+            quota, affinity = cpu_quota()
+            usable = int(max(1, min(affinity, round(quota) if quota else affinity)))
+            out["host_cpu"] = {"model": model, "logical_cores": ncpu, "affinity_cores": affinity, "cgroup_cpu_quota": quota, "usable_cores": usable,
+                               "note": "the CPU legs run on `usable_cores` = min(affinity, cgroup quota): thread teams larger than the quota are throttled by "
+                                       "the container runtime and run slower (cpu_thread_sweep shows it)"}
 
             def fresh():
                 return O.BA(s["cams0"], s["pts0"], s["obs_cam"], s["obs_pt"], s["obs_feat"], s["cam_fixed"])
@@ -799,10 +851,11 @@ def main():
             # test_ceres.h:148; north_star: "same converged parameters"); the oracle factors with LAPACK here so that the
             # ~30 iterations take seconds
             ob = fresh()
-            gate_blas = O.use_lapack(True, threads=min(ncpu, 16))
+            gate_threads = min(usable, 64)
+            gate_blas = O.use_lapack(True, threads=gate_threads)
             tg = time.perf_counter()
             try:
-                so, tro = ob.solve(num_threads=min(ncpu, 16))
+                so, tro = ob.solve(num_threads=gate_threads)
             finally:
                 O.use_lapack(False)
             t_gate = time.perf_counter() - tg
@@ -818,7 +871,7 @@ def main():
                                           "gpu_final_cost": sg.final_cost, "cpu_final_cost": so.final_cost,
                                           "relative_cost_difference": rel_cost, "pose_dq": dq, "pose_dt": dtp,
                                           "same_accept_reject_sequence": same_seq, "gpu_solve_seconds": sg.seconds_total,
-                                          "cpu_solve_seconds": t_gate, "cpu_dense_solver": gate_blas or "oracle C Cholesky",
+                                          "cpu_solve_seconds": t_gate, "cpu_threads": gate_threads, "cpu_dense_solver": gate_blas or "oracle C Cholesky",
                                           "tolerances": {"cost_rel": 1e-6, "pose": 1e-5}, "passed": matched}
 
             def time_oracle(threads, budget_s, runs):
@@ -844,10 +897,7 @@ def main():
             # thread-count sweep ON THIS BOX (every speed-up used to be quoted against 16 of the box's logical cores
             # without a look at the others): two fixed-work iterations per setting, the best one is then measured properly
             sweep = {}
-            for th in (16, 32, 64, 128):
-                if th > ncpu and th != 16:
-                    continue
-                th = min(th, ncpu)
+            for th in sorted({max(1, usable // 2), usable, min(ncpu, 2 * usable), min(ncpu, 4 * usable)}):
                 ba = fresh()
                 ba.solve(fixed_iterations=1, num_threads=th)            # (first touch / thread team start-up outside the timing)
                 ba = fresh()
@@ -856,7 +906,10 @@ def main():
                 sweep[th] = 2.0 / (time.perf_counter() - tc)
             thb = max(sweep, key=sweep.get)
             out["cpu_thread_sweep"] = {"lm_iterations_per_sec_by_threads": {str(k): v for k, v in sweep.items()}, "best": thb,
-                                       "logical_cores_on_box": ncpu, "sample": "2 fixed-work LM iterations of the C5 problem per setting, oracle C Cholesky"}
+                                       "logical_cores_on_box": ncpu, "usable_cores": usable, "cgroup_cpu_quota": quota,
+                                       "sample": "2 fixed-work LM iterations of the C5 problem per setting (half, once, twice and four times the usable "
+                                                 "cores), oracle C Cholesky; round 6: the port's assembly no longer walks every observation in every thread "
+                                                 "(oracle.c, ba_index) -- what is left above `usable_cores` is the container's CPU quota, not the port"}
             itb, nb_, rb, db = time_oracle(thb, 8.0, 5)
             plain = {"value": itb, "unit": "LM iterations/s", "cores": thb, "kind": "port", "cpu_model": model,
                      "logical_cores_on_box": ncpu, "residuals_per_sec": itb * 2.0 * n_obs,
@@ -866,7 +919,7 @@ def main():
             out["cpu_baseline"] = plain
             # the same port with the reduced system factored by LAPACK (the OpenBLAS scipy ships): the fair opponent for a
             # dense 6000 x 6000 FP64 Cholesky.  The faster of the two is THE cpu_baseline.
-            blas_threads = min(ncpu, 16)      # (measured on the GPU box: dpotrf n = 6000 runs 80 ms at 16 threads, 258 ms at 64; tools/cpu_blas_check.py)
+            blas_threads = min(usable, 64)    # (the GPU boxes' quota is 16 CPUs: dpotrf n = 6000 runs 80 ms at 16 threads, 258 ms at 64 -- throttled; tools/cpu_blas_check.py)
             blas = O.use_lapack(True, threads=blas_threads)
             if blas:
                 try:

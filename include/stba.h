@@ -376,10 +376,13 @@ typedef struct {
                                   * waits for its own inverse.  2: the same, and with a forcing sequence the first solve does not wait: it runs on
                                   * block Jacobi alone.  Ordered by events: run-to-run reproducible.  0: inverted in line, as until version 5
                                   * (coarse_refresh_every applies) */
-    double forcing_eta_final;    /* 1e-4 (stba_version() >= 6): cap on the forcing term once the LM iteration is about to converge -- the last
+    double forcing_eta_final;    /* 0 = off (stba_version() >= 6; measured without effect on C4: profiles/r6_c4_async.txt): cap on the forcing term once the LM iteration is about to converge -- the last
                                   * accepted step changed the cost by less than 100 x function_tolerance (relative).  The error of the LAST
                                   * inexact step is what the converged poses keep (about eta x its length): Eisenstat & Walker's sequence
                                   * alone leaves eta ~ 1e-2 there.  0: no cap */
+    double coarse_eta;           /* 0 (stba_version() >= 6; one-kernel solve with a forcing sequence only): the solve also runs until the COARSE
+                                  * residual |P^T r| has fallen to this fraction of its start value -- the coarse space holds the smooth, weakly
+                                  * constrained modes, where a small residual is a large error */
 } stba_pcg_options;
 void stba_pcg_default_options(stba_pcg_options* o);
 typedef struct {
@@ -394,6 +397,8 @@ typedef struct {
                                          * switched off (block Jacobi alone) until the next refresh (stba_version() >= 5) */
     int    one_kernel_solves;           /* linear solves that ran as one persistent kernel (stba_pcg_options::one_kernel_solve); a solve
                                          * whose workgroups were not all resident is repeated with launches and not counted */
+    double linear_solve_ms;             /* (stba_version() >= 6) with stba_lm_options::phase_timing: device time of all linear solves of the
+                                         * LM solve, hipEvents on the engine's stream around the persistent kernel (or the PCG launches); else 0 */
 } stba_pcg_summary;
 int stba_pg_create(stba_pg** out, int n_nodes, int n_edges, const double* poses, const int* edge_i, const int* edge_j,
                    const double* meas, const unsigned char* node_fixed, void* hip_stream);

@@ -326,13 +326,13 @@ class PCGOptions(C.Structure):
     _fields_ = [("max_iterations", C.c_int), ("relative_tolerance", C.c_double), ("check_every", C.c_int),
                 ("forcing_eta0", C.c_double), ("forcing_eta_min", C.c_double), ("coarse_group", C.c_int),
                 ("coarse_refresh_every", C.c_int), ("one_kernel_solve", C.c_int),
-                ("coarse_async", C.c_int), ("forcing_eta_final", C.c_double)]
+                ("coarse_async", C.c_int), ("forcing_eta_final", C.c_double), ("coarse_eta", C.c_double)]
 
 
 class PCGSummary(C.Structure):
     _fields_ = [("iterations_total", C.c_int), ("solves", C.c_int), ("hit_cap", C.c_int), ("max_iterations_in_a_solve", C.c_int),
                 ("coarse_dim", C.c_int), ("coarse_refreshes", C.c_int), ("last_eta", C.c_double),
-                ("coarse_failures", C.c_int), ("one_kernel_solves", C.c_int)]
+                ("coarse_failures", C.c_int), ("one_kernel_solves", C.c_int), ("linear_solve_ms", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -937,6 +937,7 @@ struct PpArgs {
     int *ustamp, *pstamp;
     PcgState* state;
     long long spin_limit; // how long a workgroup waits for a stamp, in ticks of wall_clock64 (100 MHz); 0: not at all (the test of the way back)
+    double eta_c;         // tolerance on |P^T r| / |P^T r_0| in the stopping test (<= 0: none)
     int fences;           // 1: the stamps are published behind a RELEASE fence and read in front of an ACQUIRE fence (agent scope); 0: compiler barriers only
     long long* tdbg;      // debug builds: time per phase (group 0), else null
 };
@@ -1101,8 +1102,9 @@ __global__ __launch_bounds__(PP_T) void pg_pcg_persistent_kernel(PpArgs a) {
         }
         __syncthreads();
     };
+    double rc2 = 0.0;                  // |P^T r|^2 of the current residual (the same bits in every group)
     auto coarse_and_u = [&]() {        // zc = (own six rows of the inverse) rc; u = Minv r + P zc
-        double zp[6];
+        double zp[7];
 #pragma unroll
         for (int rr_ = 0; rr_ < 6; ++rr_) {
             double y = 0.0;
@@ -1110,8 +1112,15 @@ __global__ __launch_bounds__(PP_T) void pg_pcg_persistent_kernel(PpArgs a) {
             for (int j = 0; j < 3; ++j) { const int c = t + j * PP_T; if (c < nc) y += acol[j][rr_] * rc[c]; }
             zp[rr_] = y;
         }
+        {
+            double y = 0.0;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { const int c = t + j * PP_T; if (c < nc) y += rc[c] * rc[c]; }
+            zp[6] = y;
+        }
         if (t < 384) rl[t] = r;
-        group_sum(zp, 6, 8);
+        group_sum(zp, 7, 8);
+        rc2 = sc[14];
         double z0 = 0.0;
         if (act) {
             for (int b = 0; b < 6; ++b) z0 += mrow[b] * rl[nl * 6 + b];
@@ -1142,6 +1151,10 @@ __global__ __launch_bounds__(PP_T) void pg_pcg_persistent_kernel(PpArgs a) {
     if (!(rr0 > 0.0) || !isfinite(rr0)) { finish(0, 0, rr0, rr0, 0.0); return; }
     const double tol2 = a.eta * a.eta * rr0;
     coarse_and_u();
+    // (round 6) the COARSE residual has a tolerance of its own: the coarse space holds the smooth, weakly constrained modes of the
+    // graph, where a residual of eta |g| is a large error -- with the inverse of the PREVIOUS operator as coarse solver (coarse_async)
+    // that error is what moves the LM trajectory away from the exact-step one.  eta_c <= 0: no such test
+    const double tolc2 = a.eta_c > 0.0 ? a.eta_c * a.eta_c * rc2 : -1.0;
     double gamma_old = 1.0, alpha_old = 1.0;
     const size_t N6 = (size_t)n * 6;
     long long tlast = wall_clock64();
@@ -1200,7 +1213,7 @@ __global__ __launch_bounds__(PP_T) void pg_pcg_persistent_kernel(PpArgs a) {
         }
         const double gamma = sc[0], delta = sc[1], rr = sc[2];
         // the residual of k updates: the stopping test (the first iteration always runs, as with the launches)
-        if (k > 0 && !(rr > tol2)) { finish(k, 0, rr0, rr, tol2); return; }
+        if (k > 0 && !(rr > tol2) && !(tolc2 >= 0.0 && rc2 > tolc2)) { finish(k, 0, rr0, rr, tol2); return; }
         if (k >= a.max_iters) { finish(k, 1, rr0, rr, tol2); return; }
         const double beta = (k == 0) ? 0.0 : gamma / gamma_old;
         const double den = (k == 0) ? delta : delta - beta * gamma / alpha_old;
@@ -1349,9 +1362,10 @@ struct stba_pg {
     // ---- round 6: the coarse inverse OFF the critical path (stba_pcg_options::coarse_async): a second stream inverts the coarse
     // operator of LM iteration k while the first runs iteration k's PCG with the inverse made during iteration k - 1
     hipStream_t st2 = nullptr;
-    hipEvent_t ev_in = nullptr, ev_job[2] = {nullptr, nullptr};
+    hipEvent_t ev_in = nullptr, ev_read = nullptr, ev_job[2] = {nullptr, nullptr};
     double* Ainv2 = nullptr;         // the second buffer of the pair (Ainv is the first)
-    bool job_in_flight = false;
+    hipEvent_t ev_t[2] = {nullptr, nullptr};      // stba_lm_options::phase_timing: around the linear solve
+    bool job_in_flight = false, job_reads_pending = false, ac0_valid = false;
     stba_pcg_summary last_pcg;
 };
 
@@ -1367,7 +1381,9 @@ void pg_free(stba_pg* g) {
     F(g->end_pos); F(g->end_rem); F(g->Bend); F(g->ubuf); F(g->pbuf); F(g->ustamp); F(g->pstamp);
     if (g->st2) { (void)hipStreamSynchronize(g->st2); chol_forget_stream(g->st2); (void)hipStreamDestroy(g->st2); }
     if (g->ev_in) (void)hipEventDestroy(g->ev_in);
+    if (g->ev_read) (void)hipEventDestroy(g->ev_read);
     for (auto& e : g->ev_job) if (e) (void)hipEventDestroy(e);
+    for (auto& e : g->ev_t) if (e) (void)hipEventDestroy(e);
     F(g->Ainv2);
     if (g->exp_host) (void)hipHostFree(g->exp_host);
     if (g->fin_host) (void)hipHostFree(g->fin_host);
@@ -1487,7 +1503,8 @@ void stba_pcg_default_options(stba_pcg_options* o) {
     o->coarse_refresh_every = 1;
     o->one_kernel_solve = 1;
     o->coarse_async = 1;
-    o->forcing_eta_final = 1e-4;
+    o->forcing_eta_final = 0.0;
+    o->coarse_eta = 0.0;
 }
 
 int stba_pg_create(stba_pg** out, int n_nodes, int n_edges, const double* poses, const int* edge_i, const int* edge_j,
@@ -1665,10 +1682,13 @@ int stba_pg_solve(stba_pg* g, const stba_lm_options* opt_in, const stba_pcg_opti
         if (!g->st2) {
             STBA_HIP(hipStreamCreateWithFlags(&g->st2, hipStreamNonBlocking));
             STBA_HIP(hipEventCreateWithFlags(&g->ev_in, hipEventDisableTiming));
+            STBA_HIP(hipEventCreateWithFlags(&g->ev_read, hipEventDisableTiming));
             for (auto& e : g->ev_job) STBA_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         }
         if (g->job_in_flight) { STBA_HIP(hipStreamSynchronize(g->st2)); g->job_in_flight = false; }
+        g->job_reads_pending = false;
     }
+    const bool build_on_st2 = async_inv && !g->ar;
     if (coarse) STBA_HIP(hipMemsetAsync(g->cflag + 1, 0, sizeof(int), g->st));      // this solve's count of failed coarse operators
     const bool multi = (g->ar != nullptr);
     const int chunk = std::max(1, pcg.check_every);
@@ -1699,6 +1719,9 @@ int stba_pg_solve(stba_pg* g, const stba_lm_options* opt_in, const stba_pcg_opti
 
     // ---- linearisation at the current point: residuals, Jacobians, gradient | diagonal blocks, the coarse basis and matrix
     auto linearize_enqueue = [&]() -> int {
+        // (the job of the second stream reads the blocks, the coarse basis and the damping of the linearisation it belongs to: the next
+        // linearisation waits until it has -- an event that has long fired by then)
+        if (g->job_reads_pending) { STBA_HIP(hipStreamWaitEvent(g->st, g->ev_read, 0)); g->job_reads_pending = false; }
         STBA_TRY(pg_linearize(g, g->cur, true));
         hipLaunchKernelGGL(pg_gather_blocks_kernel, dim3(g->nb_nodes4), dim3(PG_NT), 0, g->st, g->n, g->node_start, g->end_code, g->contrib, g->g, g->Hd);
         if (g->ar && g->ar(g->ar_user, g->g, (size_t)g->n * 42, g->st) != 0) return fail(STBA_ERR_CALLBACK, "all-reduce hook failed");
@@ -1709,10 +1732,15 @@ int stba_pg_solve(stba_pg* g, const stba_lm_options* opt_in, const stba_pcg_opti
                 hipLaunchKernelGGL(pg_offdiag_kernel, dim3(g->nb_edges), dim3(256), 0, g->st, g->m, g->Ji, g->Jj, g->end_pos, g->Bend);
                 g->bend_valid = true;
             }
-            hipLaunchKernelGGL(pg_coarse_build_kernel, dim3(g->na), dim3(256), (size_t)6 * g->nc * sizeof(double) + (size_t)4 * g->max_group_ends * sizeof(int), g->st, g->n, g->agg, g->nc,
-                               (!g->ar || g->rank == 0) ? 1 : 0, g->node_start, g->end_node, g->end_rem, g->Bend, g->Hd, g->AdP, g->Ac0);
-            if (g->ar && g->ar(g->ar_user, g->Ac0, (size_t)g->nc * g->nc, g->st) != 0) return fail(STBA_ERR_CALLBACK, "all-reduce hook failed");
+            // (one rank with the coarse inverse on its second stream: the coarse MATRIX is only read by that job, and is built there --
+            // 55 us of every LM iteration off the critical path; several ranks sum it with the hook, on the engine's stream)
+            if (!build_on_st2) {
+                hipLaunchKernelGGL(pg_coarse_build_kernel, dim3(g->na), dim3(256), (size_t)6 * g->nc * sizeof(double) + (size_t)4 * g->max_group_ends * sizeof(int), g->st, g->n, g->agg, g->nc,
+                                   (!g->ar || g->rank == 0) ? 1 : 0, g->node_start, g->end_node, g->end_rem, g->Bend, g->Hd, g->AdP, g->Ac0);
+                if (g->ar && g->ar(g->ar_user, g->Ac0, (size_t)g->nc * g->nc, g->st) != 0) return fail(STBA_ERR_CALLBACK, "all-reduce hook failed");
+            }
             g->coarse_valid = false;
+            g->ac0_valid = false;
         }
         STBA_HIP(hipGetLastError());
         return STBA_OK;
@@ -1751,6 +1779,7 @@ int stba_pg_solve(stba_pg* g, const stba_lm_options* opt_in, const stba_pcg_opti
         if (iter >= opt.max_num_iterations) break;
         if (radius < opt.min_trust_region_radius) { s.termination_type = STBA_CONVERGENCE; s.termination_reason = STBA_TERM_MIN_RADIUS; break; }
         ++iter;
+        if (g->job_reads_pending) { STBA_HIP(hipStreamWaitEvent(g->st, g->ev_read, 0)); g->job_reads_pending = false; }    // (a rejected step: no linearisation in between)
         hipLaunchKernelGGL(pg_precond_kernel, dim3(g->nb_nodes), dim3(256), 0, g->st, g->n, g->Hd, g->scale, scale_init ? 0 : 1,
                            opt.jacobi_scaling, radius, opt.min_lm_diagonal, opt.max_lm_diagonal, g->fixed, g->d, g->Minv);
         scale_init = true;
@@ -1765,18 +1794,36 @@ int stba_pg_solve(stba_pg* g, const stba_lm_options* opt_in, const stba_pcg_opti
             // forcing sequence: it runs on block Jacobi alone, Ainv = 0 -- 3 PCG iterations at eta_0 = 0.1, but a first step that
             // leaves the cost at 1021 where the two-level step leaves 258 and the exact one 48: the whole trajectory moves).
             // Everything is ordered by events, so the result does not depend on timing: run to run the same bits.
-            //   stream 1: precond_k | wait job_{k-1} | Dc_k, assemble W_k | record IN_k | PCG_k (Ainv of job_{k-1}) | trial ...
-            //   stream 2:                                                   wait IN_k   | invert W_k -> Ainv[k & 1] | record job_k
+            //   stream 1: precond_k | wait job_{k-1} | record IN_k | PCG_k (Ainv of job_{k-1}) | trial | wait READ_k | linearise ...
+            //   stream 2:                              wait IN_k   | coarse matrix, Dc_k, assemble W_k | record READ_k | invert -> Ainv[k & 1] | record job_k
+            // (several ranks: coarse matrix -- summed by the hook --, Dc_k and W_k stay on stream 1, IN_k is recorded behind them)
             const int wbuf = jobs & 1;
             double* Aw = wbuf ? g->Ainv2 : g->Ainv;
             const double* Ar = wbuf ? g->Ainv : g->Ainv2;        // written by the previous job (or zeroed below)
             if (jobs == 0) STBA_HIP(hipMemsetAsync(const_cast<double*>(Ar), 0, (size_t)g->nc * g->nc * sizeof(double), g->st));
             else STBA_HIP(hipStreamWaitEvent(g->st, g->ev_job[(jobs - 1) & 1], 0));
             const size_t cnt = (size_t)3 * g->np * g->np;
-            hipLaunchKernelGGL(pg_coarse_dc_kernel, dim3(g->na), dim3(256), 0, g->st, g->n, g->agg, g->AdP, g->d, g->Dc);
-            hipLaunchKernelGGL(pg_coarse_assemble_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, g->st, g->nc, g->np, g->Ac0, g->Dc, g->W);
-            STBA_HIP(hipEventRecord(g->ev_in, g->st));
-            STBA_HIP(hipStreamWaitEvent(g->st2, g->ev_in, 0));
+            if (build_on_st2) {
+                // one rank: everything the inverse needs is made on the second stream -- coarse matrix (from the blocks, the diagonal
+                // blocks and the basis of THIS linearisation), its damping term, the workspace; READ_k tells the first stream when
+                // its next linearisation / preconditioner kernel may overwrite those inputs
+                STBA_HIP(hipEventRecord(g->ev_in, g->st));
+                STBA_HIP(hipStreamWaitEvent(g->st2, g->ev_in, 0));
+                if (!g->ac0_valid) {
+                    hipLaunchKernelGGL(pg_coarse_build_kernel, dim3(g->na), dim3(256), (size_t)6 * g->nc * sizeof(double) + (size_t)4 * g->max_group_ends * sizeof(int), g->st2, g->n, g->agg, g->nc,
+                                       1, g->node_start, g->end_node, g->end_rem, g->Bend, g->Hd, g->AdP, g->Ac0);
+                    g->ac0_valid = true;
+                }
+                hipLaunchKernelGGL(pg_coarse_dc_kernel, dim3(g->na), dim3(256), 0, g->st2, g->n, g->agg, g->AdP, g->d, g->Dc);
+                hipLaunchKernelGGL(pg_coarse_assemble_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, g->st2, g->nc, g->np, g->Ac0, g->Dc, g->W);
+                STBA_HIP(hipEventRecord(g->ev_read, g->st2));
+                g->job_reads_pending = true;
+            } else {
+                hipLaunchKernelGGL(pg_coarse_dc_kernel, dim3(g->na), dim3(256), 0, g->st, g->n, g->agg, g->AdP, g->d, g->Dc);
+                hipLaunchKernelGGL(pg_coarse_assemble_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, g->st, g->nc, g->np, g->Ac0, g->Dc, g->W);
+                STBA_HIP(hipEventRecord(g->ev_in, g->st));
+                STBA_HIP(hipStreamWaitEvent(g->st2, g->ev_in, 0));
+            }
             STBA_TRY(chol_spd_inverse_dev(g->W, 2 * g->np, g->np, g->nc, g->cflag, g->inv_work, g->st2));
             hipLaunchKernelGGL(pg_coarse_finish_kernel, dim3((unsigned)(((size_t)g->nc * g->nc + 255) / 256)), dim3(256), 0, g->st2, g->nc, g->np, g->W, Aw,
                                g->cflag, g->cflag + 1);
@@ -1878,6 +1925,7 @@ int stba_pg_solve(stba_pg* g, const stba_lm_options* opt_in, const stba_pcg_opti
             a.Ainv = Ainv_use; a.g = g->g; a.x = g->x; a.ubuf = g->ubuf; a.pbuf = g->pbuf; a.ustamp = g->ustamp; a.pstamp = g->pstamp;
             a.state = g->state; a.spin_limit = pcg.one_kernel_solve == 2 ? 0 : 25000000ll;      // (a quarter of a second of wall_clock64 ticks; 2: the test of the way back)
             a.fences = pcg.one_kernel_solve == 3 ? 1 : 0;
+            a.eta_c = forcing ? pcg.coarse_eta : 0.0;
             a.tdbg = nullptr;
 #ifdef STBA_DEBUG_KNOBS
             static long long* tdbg_dev = nullptr;
@@ -1920,8 +1968,20 @@ int stba_pg_solve(stba_pg* g, const stba_lm_options* opt_in, const stba_pcg_opti
             return STBA_OK;
         };
         const bool one_kernel = pp_ok && !g->pp_disabled;
+        // (stba_lm_options::phase_timing: hipEvents around the linear solve -- the persistent kernel, or the launches of the PCG loop --
+        // for bench.py's roofline of the C4 line; an event is a packet of its own on the queue, so only on request)
+        const bool timing = opt.phase_timing != 0;
+        if (timing && !g->ev_t[0]) { STBA_HIP(hipEventCreate(&g->ev_t[0])); STBA_HIP(hipEventCreate(&g->ev_t[1])); }
+        if (timing) STBA_HIP(hipEventRecord(g->ev_t[0], g->st));
         if (one_kernel) STBA_TRY(pcg_one_kernel()); else STBA_TRY(pcg_by_launches());
+        if (timing) STBA_HIP(hipEventRecord(g->ev_t[1], g->st));
         STBA_TRY(trial_point());
+        if (timing) {
+            float ms = 0.f;
+            STBA_HIP(hipEventSynchronize(g->ev_t[1]));
+            STBA_HIP(hipEventElapsedTime(&ms, g->ev_t[0], g->ev_t[1]));
+            ps.linear_solve_ms += (double)ms;
+        }
         if (one_kernel && fin[6] != (double)PP_TIMED_OUT) ++ps.one_kernel_solves;
         if (one_kernel && fin[6] == (double)PP_TIMED_OUT) {
             // a stamp never came: the workgroups were not all resident (another process on the device).  Once is enough: this

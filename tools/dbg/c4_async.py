@@ -26,12 +26,14 @@ sx, trx, nx = e.solve(pcg=e.pcg_options(forcing_eta0=0.0, relative_tolerance=1e-
 px = e.get_poses()
 print("exact steps: it %d pcg %d cost %.12g dist-to-gold %.2e" % (sx.num_iterations, nx, sx.final_cost, pdiff(px[::50], gp)))
 verbose = "-v" in sys.argv
-for name, kw in (("inline e0", dict(coarse_async=0, forcing_eta_final=0.0)), ("inline", dict(coarse_async=0)),
-                 ("async1 e0", dict(coarse_async=1, forcing_eta_final=0.0)), ("async1", dict(coarse_async=1)),
-                 ("async1 1e-5", dict(coarse_async=1, forcing_eta_final=1e-5)),
-                 ("async2 e0", dict(coarse_async=2, forcing_eta_final=0.0)), ("async2", dict(coarse_async=2)),
-                 ("async1 fence", dict(coarse_async=1, one_kernel_solve=3)),
-                 ("async1 exact", dict(coarse_async=1, forcing_eta0=0.0, relative_tolerance=1e-12, max_iterations=2000))):
+for name, kw in (("inline", dict(coarse_async=0)),
+                 ("async1", dict(coarse_async=1)),
+                 ("async1 ce1e-1", dict(coarse_async=1, coarse_eta=1e-1)), ("async1 ce1e-2", dict(coarse_async=1, coarse_eta=1e-2)),
+                 ("async1 ce1e-3", dict(coarse_async=1, coarse_eta=1e-3)), ("async1 ce1e-4", dict(coarse_async=1, coarse_eta=1e-4)),
+                 ("async1 ce1e-6", dict(coarse_async=1, coarse_eta=1e-6)),
+                 ("inline ce1e-3", dict(coarse_async=0, coarse_eta=1e-3)),
+                 ("async1 e0=1e-2", dict(coarse_async=1, forcing_eta0=1e-2)), ("async1 e0=1e-3", dict(coarse_async=1, forcing_eta0=1e-3)),
+                 ("async2 ce1e-3", dict(coarse_async=2, coarse_eta=1e-3))):
     times, last = [], None
     for rep in range(4):
         e = fresh()
