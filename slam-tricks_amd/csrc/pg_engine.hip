@@ -1502,9 +1502,10 @@ void stba_pcg_default_options(stba_pcg_options* o) {
     o->coarse_group = 0;
     o->coarse_refresh_every = 1;
     o->one_kernel_solve = 1;
-    o->coarse_async = 1;
+    o->coarse_async = 0;      // (1: +25 % LM it/s at C4, but the converged poses end 6e-5 from the exact-step trajectory instead of 2.5e-6: stba.h)
     o->forcing_eta_final = 0.0;
     o->coarse_eta = 0.0;
+    o->coarse_async_after = 1;
 }
 
 int stba_pg_create(stba_pg** out, int n_nodes, int n_edges, const double* poses, const int* edge_i, const int* edge_j,
@@ -1830,7 +1831,9 @@ int stba_pg_solve(stba_pg* g, const stba_lm_options* opt_in, const stba_pcg_opti
             STBA_HIP(hipEventRecord(g->ev_job[wbuf], g->st2));
             g->job_in_flight = true;
             Ainv_use = Ar;
-            if (jobs == 0 && (!forcing || pcg.coarse_async != 2)) {      // the first solve waits for its own inverse (2: not with a forcing sequence)
+            // the first solve(s) wait for their own inverse (coarse_async = 2: not with a forcing sequence; coarse_async_after: how many
+            // LM iterations do -- the operator changes most in the first iterations)
+            if ((jobs == 0 && (!forcing || pcg.coarse_async != 2)) || (pcg.coarse_async != 2 && iter <= pcg.coarse_async_after)) {
                 STBA_HIP(hipStreamWaitEvent(g->st, g->ev_job[wbuf], 0));
                 Ainv_use = Aw;
             }

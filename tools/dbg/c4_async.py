@@ -27,13 +27,12 @@ px = e.get_poses()
 print("exact steps: it %d pcg %d cost %.12g dist-to-gold %.2e" % (sx.num_iterations, nx, sx.final_cost, pdiff(px[::50], gp)))
 verbose = "-v" in sys.argv
 for name, kw in (("inline", dict(coarse_async=0)),
-                 ("async1", dict(coarse_async=1)),
-                 ("async1 ce1e-1", dict(coarse_async=1, coarse_eta=1e-1)), ("async1 ce1e-2", dict(coarse_async=1, coarse_eta=1e-2)),
-                 ("async1 ce1e-3", dict(coarse_async=1, coarse_eta=1e-3)), ("async1 ce1e-4", dict(coarse_async=1, coarse_eta=1e-4)),
-                 ("async1 ce1e-6", dict(coarse_async=1, coarse_eta=1e-6)),
-                 ("inline ce1e-3", dict(coarse_async=0, coarse_eta=1e-3)),
-                 ("async1 e0=1e-2", dict(coarse_async=1, forcing_eta0=1e-2)), ("async1 e0=1e-3", dict(coarse_async=1, forcing_eta0=1e-3)),
-                 ("async2 ce1e-3", dict(coarse_async=2, coarse_eta=1e-3))):
+                 ("async1 after1", dict(coarse_async=1, coarse_async_after=1)), ("async1 after2", dict(coarse_async=1, coarse_async_after=2)),
+                 ("async1 after3", dict(coarse_async=1, coarse_async_after=3)), ("async1 after4", dict(coarse_async=1, coarse_async_after=4)),
+                 ("async1 after5", dict(coarse_async=1, coarse_async_after=5)), ("async1 after6", dict(coarse_async=1, coarse_async_after=6)),
+                 ("async1 after7", dict(coarse_async=1, coarse_async_after=7)),
+                 ("after3 ce1e-2", dict(coarse_async=1, coarse_async_after=3, coarse_eta=1e-2)),
+                 ("after3 ce1e-3", dict(coarse_async=1, coarse_async_after=3, coarse_eta=1e-3))):
     times, last = [], None
     for rep in range(4):
         e = fresh()
