@@ -371,15 +371,16 @@ typedef struct {
                                   * two exchanges published behind an agent-scope RELEASE fence and read in front of an ACQUIRE fence -- the
                                   * formally complete protocol; 1 orders the same accesses by the hardware's own rules (stores acknowledged
                                   * before the stamp is issued, loads issued after the stamp was seen) plus compiler barriers */
-    int    coarse_async;         /* 0 (stba_version() >= 6).  1: the coarse operator is built and inverted on a SECOND stream, next to the PCG kernel, and
-                                  * applied one LM iteration late -- iteration k preconditions with the inverse of iteration k - 1's operator; the
-                                  * first solve waits for its own inverse.  2: the same, and with a forcing sequence the first solve does not wait
-                                  * (block Jacobi alone).  Ordered by events: run-to-run reproducible.  MEASURED at C4 (profiles/r6_c4_async.txt):
-                                  * 1080 -> 1350 (1) / 1515 (2) LM it/s, same iteration count, final cost 2e-11 apart -- and the converged poses
-                                  * 6e-5 / 1.5e-4 from the exact-step trajectory where the in-line inverse ends 2.5e-6 away: the coarse space IS the
-                                  * graph's weakly constrained modes, and a stale coarse solver leaves its error exactly there.  north_star asks
-                                  * for 1e-5 on poses, so 0 (inverted in line, as until version 5) stays the default; coarse_eta buys the accuracy
-                                  * back at the price of the speed (1e-4: 6.9e-7, 920 LM it/s) */
+    int    coarse_async;         /* 1 (stba_version() >= 6): the coarse operator is built and inverted on a SECOND stream, next to the PCG kernel, and
+                                  * applied one LM iteration late -- iteration k preconditions with the inverse of iteration k - 1's operator --
+                                  * EXCEPT behind a long step (coarse_async_decrease) and in the first iteration(s) (coarse_async_after), which
+                                  * wait for the inverse of their own operator.  2: lag always, and with a forcing sequence the first solve runs
+                                  * on block Jacobi alone.  0: always in line, as until version 5 (coarse_refresh_every applies).  Ordered by
+                                  * events: run-to-run reproducible.  MEASURED at C4 (profiles/r6_c4_async*.txt), LM it/s | distance of the
+                                  * converged poses from the exact-step trajectory: in line 1075 | 2.5e-6; lag from iteration 2 on 1380 | 6.0e-5;
+                                  * from 3 on 1382 | 3.9e-5; from 4 on (this rule's choice) 1341 | 2.9e-6; mode 2 1515 | 1.5e-4.  The coarse space
+                                  * IS the graph's weakly constrained modes: a coarse solver that is stale by a long step leaves its error exactly
+                                  * there, and north_star asks for 1e-5 on poses */
     double forcing_eta_final;    /* 0 = off (stba_version() >= 6; measured without effect on C4: profiles/r6_c4_async.txt): cap on the forcing term once the LM iteration is about to converge -- the last
                                   * accepted step changed the cost by less than 100 x function_tolerance (relative).  The error of the LAST
                                   * inexact step is what the converged poses keep (about eta x its length): Eisenstat & Walker's sequence
@@ -387,8 +388,9 @@ typedef struct {
     double coarse_eta;           /* 0 (stba_version() >= 6; one-kernel solve with a forcing sequence only): the solve also runs until the COARSE
                                   * residual |P^T r| has fallen to this fraction of its start value -- the coarse space holds the smooth, weakly
                                   * constrained modes, where a small residual is a large error */
-    int    coarse_async_after;   /* 1 (with coarse_async = 1): the first so many LM iterations wait for the inverse of their OWN coarse operator
-                                  * (the operator changes most while the steps are long); later ones use the previous iteration's */
+    int    coarse_async_after;   /* 1 (with coarse_async = 1): the first so many LM iterations wait for the inverse of their OWN coarse operator */
+    double coarse_async_decrease;/* 0.5 (with coarse_async = 1): an iteration that follows an accepted step which took MORE than this fraction off
+                                  * the cost also waits for its own inverse: the operator is stale by exactly that step */
 } stba_pcg_options;
 void stba_pcg_default_options(stba_pcg_options* o);
 typedef struct {

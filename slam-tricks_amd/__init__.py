@@ -326,7 +326,8 @@ class PCGOptions(C.Structure):
     _fields_ = [("max_iterations", C.c_int), ("relative_tolerance", C.c_double), ("check_every", C.c_int),
                 ("forcing_eta0", C.c_double), ("forcing_eta_min", C.c_double), ("coarse_group", C.c_int),
                 ("coarse_refresh_every", C.c_int), ("one_kernel_solve", C.c_int),
-                ("coarse_async", C.c_int), ("forcing_eta_final", C.c_double), ("coarse_eta", C.c_double), ("coarse_async_after", C.c_int)]
+                ("coarse_async", C.c_int), ("forcing_eta_final", C.c_double), ("coarse_eta", C.c_double), ("coarse_async_after", C.c_int),
+                ("coarse_async_decrease", C.c_double)]
 
 
 class PCGSummary(C.Structure):

@@ -1490,6 +1490,17 @@ static int pg_wait_mapped(stba_pg* g, const volatile T* slot, T want, bool at_le
     return STBA_OK;
 }
 
+// the first stream waits for an event of the second one only if the event has NOT fired yet when the dependent work is enqueued: a
+// wait packet costs ~10 us of idle GPU even when its event has long fired (dense_chol.hip's note on the same), and here it nearly
+// always has -- the job it guards started a whole PCG solve earlier.  The data flow is the same either way: same bits.
+static int pg_wait_if_pending(hipStream_t st, hipEvent_t ev) {
+    const hipError_t q = hipEventQuery(ev);
+    if (q == hipSuccess) return STBA_OK;
+    if (q != hipErrorNotReady) { (void)hipGetLastError(); }
+    STBA_HIP(hipStreamWaitEvent(st, ev, 0));
+    return STBA_OK;
+}
+
 extern "C" {
 
 void stba_pcg_default_options(stba_pcg_options* o) {
@@ -1502,10 +1513,11 @@ void stba_pcg_default_options(stba_pcg_options* o) {
     o->coarse_group = 0;
     o->coarse_refresh_every = 1;
     o->one_kernel_solve = 1;
-    o->coarse_async = 0;      // (1: +25 % LM it/s at C4, but the converged poses end 6e-5 from the exact-step trajectory instead of 2.5e-6: stba.h)
+    o->coarse_async = 1;
     o->forcing_eta_final = 0.0;
     o->coarse_eta = 0.0;
     o->coarse_async_after = 1;
+    o->coarse_async_decrease = 0.5;
 }
 
 int stba_pg_create(stba_pg** out, int n_nodes, int n_edges, const double* poses, const int* edge_i, const int* edge_j,
@@ -1722,7 +1734,7 @@ int stba_pg_solve(stba_pg* g, const stba_lm_options* opt_in, const stba_pcg_opti
     auto linearize_enqueue = [&]() -> int {
         // (the job of the second stream reads the blocks, the coarse basis and the damping of the linearisation it belongs to: the next
         // linearisation waits until it has -- an event that has long fired by then)
-        if (g->job_reads_pending) { STBA_HIP(hipStreamWaitEvent(g->st, g->ev_read, 0)); g->job_reads_pending = false; }
+        if (g->job_reads_pending) { STBA_TRY(pg_wait_if_pending(g->st, g->ev_read)); g->job_reads_pending = false; }
         STBA_TRY(pg_linearize(g, g->cur, true));
         hipLaunchKernelGGL(pg_gather_blocks_kernel, dim3(g->nb_nodes4), dim3(PG_NT), 0, g->st, g->n, g->node_start, g->end_code, g->contrib, g->g, g->Hd);
         if (g->ar && g->ar(g->ar_user, g->g, (size_t)g->n * 42, g->st) != 0) return fail(STBA_ERR_CALLBACK, "all-reduce hook failed");
@@ -1776,11 +1788,12 @@ int stba_pg_solve(stba_pg* g, const stba_lm_options* opt_in, const stba_pcg_opti
     if (done) { s.termination_type = STBA_CONVERGENCE; s.termination_reason = STBA_TERM_GRADIENT; }
     if (!std::isfinite(cost)) { s.termination_type = STBA_FAILURE; s.termination_reason = STBA_TERM_SOLVER_FAIL; done = true; }   // (Ceres: initial evaluation failed, see stba_ba_solve)
     int since_refresh = 0, jobs = 0;
+    double last_rel_decrease = 1.0;      // of the last accepted step: (cost before - cost after) / cost before
     while (!done) {
         if (iter >= opt.max_num_iterations) break;
         if (radius < opt.min_trust_region_radius) { s.termination_type = STBA_CONVERGENCE; s.termination_reason = STBA_TERM_MIN_RADIUS; break; }
         ++iter;
-        if (g->job_reads_pending) { STBA_HIP(hipStreamWaitEvent(g->st, g->ev_read, 0)); g->job_reads_pending = false; }    // (a rejected step: no linearisation in between)
+        if (g->job_reads_pending) { STBA_TRY(pg_wait_if_pending(g->st, g->ev_read)); g->job_reads_pending = false; }    // (a rejected step: no linearisation in between)
         hipLaunchKernelGGL(pg_precond_kernel, dim3(g->nb_nodes), dim3(256), 0, g->st, g->n, g->Hd, g->scale, scale_init ? 0 : 1,
                            opt.jacobi_scaling, radius, opt.min_lm_diagonal, opt.max_lm_diagonal, g->fixed, g->d, g->Minv);
         scale_init = true;
@@ -1802,7 +1815,7 @@ int stba_pg_solve(stba_pg* g, const stba_lm_options* opt_in, const stba_pcg_opti
             double* Aw = wbuf ? g->Ainv2 : g->Ainv;
             const double* Ar = wbuf ? g->Ainv : g->Ainv2;        // written by the previous job (or zeroed below)
             if (jobs == 0) STBA_HIP(hipMemsetAsync(const_cast<double*>(Ar), 0, (size_t)g->nc * g->nc * sizeof(double), g->st));
-            else STBA_HIP(hipStreamWaitEvent(g->st, g->ev_job[(jobs - 1) & 1], 0));
+            else STBA_TRY(pg_wait_if_pending(g->st, g->ev_job[(jobs - 1) & 1]));
             const size_t cnt = (size_t)3 * g->np * g->np;
             if (build_on_st2) {
                 // one rank: everything the inverse needs is made on the second stream -- coarse matrix (from the blocks, the diagonal
@@ -1833,7 +1846,14 @@ int stba_pg_solve(stba_pg* g, const stba_lm_options* opt_in, const stba_pcg_opti
             Ainv_use = Ar;
             // the first solve(s) wait for their own inverse (coarse_async = 2: not with a forcing sequence; coarse_async_after: how many
             // LM iterations do -- the operator changes most in the first iterations)
-            if ((jobs == 0 && (!forcing || pcg.coarse_async != 2)) || (pcg.coarse_async != 2 && iter <= pcg.coarse_async_after)) {
+            // -- and every solve that follows a LONG step: the operator is stale by exactly the step that was just taken.  At C4
+            // (profiles/r6_c4_async.txt) the steps of the first three iterations take 98 %, 97 % and 45 % off the cost, the later ones
+            // 1 % and less; preconditioning iteration 3 with iteration 2's operator ends 3.9e-5 from the exact-step poses,
+            // iterations 4 .. 9 with their predecessors' 2.9e-6 (in line: 2.5e-6).  Rule: lag only behind a step that took at most
+            // coarse_async_decrease (0.5) off the cost.
+            const bool own = (jobs == 0 && (!forcing || pcg.coarse_async != 2)) ||
+                             (pcg.coarse_async != 2 && (iter <= pcg.coarse_async_after || last_rel_decrease > pcg.coarse_async_decrease));
+            if (own) {
                 STBA_HIP(hipStreamWaitEvent(g->st, g->ev_job[wbuf], 0));
                 Ainv_use = Aw;
             }
@@ -2025,6 +2045,7 @@ int stba_pg_solve(stba_pg* g, const stba_lm_options* opt_in, const stba_pcg_opti
         if (accepted) {
             g->cur = nxt;
             ++s.num_successful_steps;
+            last_rel_decrease = cost > 0.0 ? cost_change / cost : 1.0;
             const double t = 2.0 * rho - 1.0;
             radius = std::min(opt.max_trust_region_radius, radius / std::max(1.0 / 3.0, 1.0 - t * t * t));
             decrease = 2.0;

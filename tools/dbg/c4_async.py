@@ -26,13 +26,10 @@ sx, trx, nx = e.solve(pcg=e.pcg_options(forcing_eta0=0.0, relative_tolerance=1e-
 px = e.get_poses()
 print("exact steps: it %d pcg %d cost %.12g dist-to-gold %.2e" % (sx.num_iterations, nx, sx.final_cost, pdiff(px[::50], gp)))
 verbose = "-v" in sys.argv
-for name, kw in (("inline", dict(coarse_async=0)),
-                 ("async1 after1", dict(coarse_async=1, coarse_async_after=1)), ("async1 after2", dict(coarse_async=1, coarse_async_after=2)),
-                 ("async1 after3", dict(coarse_async=1, coarse_async_after=3)), ("async1 after4", dict(coarse_async=1, coarse_async_after=4)),
-                 ("async1 after5", dict(coarse_async=1, coarse_async_after=5)), ("async1 after6", dict(coarse_async=1, coarse_async_after=6)),
-                 ("async1 after7", dict(coarse_async=1, coarse_async_after=7)),
-                 ("after3 ce1e-2", dict(coarse_async=1, coarse_async_after=3, coarse_eta=1e-2)),
-                 ("after3 ce1e-3", dict(coarse_async=1, coarse_async_after=3, coarse_eta=1e-3))):
+for name, kw in (("inline", dict(coarse_async=0)), ("default", dict()),
+                 ("decrease 0.3", dict(coarse_async_decrease=0.3)), ("decrease 0.9", dict(coarse_async_decrease=0.9)),
+                 ("always", dict(coarse_async_decrease=1.0)), ("mode 2", dict(coarse_async=2)),
+                 ("fences", dict(one_kernel_solve=3))):
     times, last = [], None
     for rep in range(4):
         e = fresh()
