@@ -384,7 +384,7 @@ def drop_in_rows(s, eng, out):
             if gate and gate.get("passed"):
                 # the CPU port's whole solve (same start, same iterations, matched result) against the same solve THROUGH THE API
                 d["speedup_vs_cpu_port_through_the_api"] = gate["cpu_solve_seconds"] / d["seconds"]["solve"]
-                d["speedup_note"] = (f"CPU port to convergence {gate['cpu_solve_seconds']:.2f} s ({gate['cpu_dense_solver']}, {gate.get('cpu_threads', 16)} threads) / ceres::Solve() "
+                d["speedup_note"] = (f"CPU port to convergence {gate['cpu_solve_seconds']:.2f} s ({gate['cpu_dense_solver']}) / ceres::Solve() "
                                      f"{d['seconds']['solve']:.3f} s wall (recognition, engine creation, device solve, write-back, end-point check)")
             d["note"] = ("seconds, median of 5: `build` = the caller's 10^6 AddResidualBlock (its cost with Ceres too), `solve` = ceres::Solve() wall, of "
                          "which recognise / pack / engine_create / device_solve / write_back / verify are the header's own phase timers; one host thread")

@@ -86,6 +86,7 @@ int chol_factor_solve_stages(double* A_dev, int lda, int n, double* x_dev, int* 
 void chol_forget_stream(hipStream_t st);   // before a stream that ran factorisations is destroyed (after synchronising it)
 void chol_note_timeout();
 void chol_note_peer_timeout();
+void chol_count_timeout();
 void chol_set_spin_limit_us(double us);    // how long a workgroup waits for a dependency before it gives up; 0: automatic
 int chol_timeout_count();
 

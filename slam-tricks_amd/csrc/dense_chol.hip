@@ -2136,6 +2136,7 @@ void chol_note_timeout() {
     std::lock_guard<std::mutex> g(D.m);
     D.cooldown = 64;
 }
+void chol_count_timeout() { g_timeouts.fetch_add(1); }     // (counted, the device not marked: several ranks keep their own cool-down)
 // several ranks: ANOTHER rank's factorisation gave up.  This rank goes through the stage kernels for the same 64 factorisations, so that
 // all ranks keep factoring the identical reduced system with the identical schedule -- the two schedules differ in the last bits, and
 // every rank must hold the same camera blocks (include/stba.h, stba_ba_set_allreduce).  Not counted as a time-out of this rank.

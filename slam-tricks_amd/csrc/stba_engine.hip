@@ -104,6 +104,8 @@ struct stba_ba {
     double* Y = nullptr; size_t ldy = 0, ykcols = 0;     // [lda][ldy]
     double *yv = nullptr, *yws = nullptr;
     unsigned char* dup_run = nullptr;                    // repeated (camera, landmark) pairs, per position of cam_perm (null: none)
+    bool dup_overflow = false;                           // some pair has more than 255 observations: the DENSE form cannot take this problem
+    int stage_cooldown = 0;                              // several ranks: factorisations left that take the stage kernels (see ba_run_lm)
     unsigned char *cam_fixed = nullptr, *pt_fixed = nullptr;
     double2* r = nullptr;
     double* J8 = nullptr;            // compact Jacobian [n_obs][8] (ba_kernels.hip)
@@ -711,7 +713,10 @@ static int ba_run_lm(stba_ba* b, const stba_lm_options* opt_in, int fixed_iterat
         ++iter;
         // ---- factor + solve, back-substitute, trial point
         int flag_h = 0;
-        STBA_TRY(chol_factor_solve_dev(b->S(), b->lda, b->n, b->dxc, b->flag, b->st));
+        // (several ranks behind a time-out of ANY rank: this engine's own cool-down -- every rank counts the same factorisations
+        // through the stage kernels, whatever else shares its device or its process)
+        if (b->stage_cooldown > 0) { --b->stage_cooldown; STBA_TRY(chol_factor_solve_stages(b->S(), b->lda, b->n, b->dxc, b->flag, b->st)); }
+        else STBA_TRY(chol_factor_solve_dev(b->S(), b->lda, b->n, b->dxc, b->flag, b->st));
         if (timing) STBA_HIP(hipEventRecord(ev[4], b->st));
         STBA_TRY(ba_backsub_trial(b));
         if (timing) STBA_HIP(hipEventRecord(ev[5], b->st));
@@ -776,8 +781,13 @@ static int ba_run_lm(stba_ba* b, const stba_lm_options* opt_in, int fixed_iterat
             // device is shared with another process).  S is half factored; it is rebuilt from the blocks -- the engine owns
             // them -- and this iteration runs again, the factorisation through the stage kernels, which need nothing
             // resident (chol_note_timeout: so do the next ones on this device).
-            if (flag_h == CHOL_FLAG_TIMEOUT) chol_note_timeout();
-            else chol_note_peer_timeout();      // (another rank's gave up: the same schedule on every rank, or their last bits part)
+            // One rank: the DEVICE is marked (it is shared with somebody: the next 64 factorisations of anybody on it take the stage
+            // kernels).  Several ranks: every rank -- the one that gave up and its peers -- starts the same cool-down of ITS ENGINE, so
+            // that all of them factor the identical system with the identical schedule for the same 64 factorisations (the two
+            // schedules differ in the last bits, and every rank must hold the same camera blocks); a counter in the shared
+            // per-device state (round 5) was decremented by whoever else factored on that device (advisor, round 5).
+            if (b->ar) { b->stage_cooldown = 64; if (flag_h == CHOL_FLAG_TIMEOUT) chol_count_timeout(); }
+            else chol_note_timeout();
             // (a device that keeps timing out is shared for good: the cool-down is renewed every time, so a long run goes on through
             // the stage kernels instead of failing; only time-outs that come back-to-back without a good iteration in between --
             // the stage kernels cannot time out -- end the solve)
@@ -1051,9 +1061,11 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
             int e = q + 1;
             while (e < cam_start[c + 1] && s_pt[cam_perm[e]] == s_pt[cam_perm[q]]) ++e;
             if (e - q > 1) {
-                if (e - q > 255) { ba_free(b); return fail(STBA_ERR_INVALID_ARGUMENT, "stba_ba_create: more than 255 observations of one (camera, landmark) pair"); }
+                // (the run table is one byte per observation and only the DENSE form reads it: a longer run is refused where that form
+                // is chosen, not here -- the pair plan handles any number of observations of one pair; advisor, round 5)
+                if (e - q > 255) b->dup_overflow = true;
                 if (dup_run.empty()) dup_run.assign((size_t)n_obs, 0);
-                dup_run[(size_t)q] = (unsigned char)(e - q - 1);
+                dup_run[(size_t)q] = (unsigned char)std::min(254, e - q - 1);
                 for (int k = q + 1; k < e; ++k) dup_run[(size_t)k] = 255;
                 n_dup += (size_t)(e - q - 1);
             }
@@ -1091,6 +1103,10 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
         // (measured, tools/dense_schur_time.py, 59 % visibility: 29 x 600 -- 94 k pairs -- 0.053 ms either way; 60 x 12 000 -- 7.8 M pairs --
         // 1.30 ms by the plan, 0.30 ms as a product; 100 x 8000 -- 14 M -- 1.53 against 0.37 ms)
         if (total_pairs > cap || (total_pairs > ((size_t)1 << 20) && visibility >= 0.3 && y_fits)) b->schur_mode = b->schur_mode_auto = STBA_SCHUR_DENSE;
+    }
+    if (b->schur_mode == STBA_SCHUR_DENSE && b->dup_overflow) {
+        ba_free(b);
+        return fail(STBA_ERR_INVALID_ARGUMENT, "stba_ba_create: more than 255 observations of one (camera, landmark) pair in a problem that needs the dense form of the Schur complement");
     }
     const bool build_pair_plan = b->schur_mode != STBA_SCHUR_DENSE;
     b->have_pair_plan = build_pair_plan;
@@ -1419,6 +1435,8 @@ int stba_ba_set_schur_mode(stba_ba* ba, int mode) {
     if (mode == STBA_SCHUR_AUTO) mode = ba->schur_mode_auto;
     if (mode == STBA_SCHUR_PAIRS && !ba->have_pair_plan)
         return fail(STBA_ERR_INVALID_ARGUMENT, "stba_ba_set_schur_mode: this engine was created without a pair plan (too many observation pairs)");
+    if (mode == STBA_SCHUR_DENSE && ba->dup_overflow)
+        return fail(STBA_ERR_INVALID_ARGUMENT, "stba_ba_set_schur_mode: more than 255 observations of one (camera, landmark) pair: the dense form cannot take this problem");
     if (mode == STBA_SCHUR_DENSE) STBA_TRY(ba_dense_alloc(ba));
     ba->schur_mode = mode;
     ba->have_reduced = ba->have_dxc = ba->have_dxp = false;

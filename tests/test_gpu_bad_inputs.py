@@ -127,3 +127,32 @@ def test_non_finite_residual_from_a_callback_fails_like_the_oracle(st, O):
     assert summ.termination_type == so.termination_type and summ.num_iterations == so.num_iterations
     assert np.array_equal(tr[:, 6], tro[:, 6]) and (tr[1:, 6] == 0).any()          # the same steps rejected, at least one
     assert np.allclose(p, po, rtol=1e-7) and p[0] <= 1.9
+
+
+def test_many_observations_of_one_pair_run_on_the_pair_plan_and_are_refused_by_the_dense_form(st, O, small):
+    """300 observations of ONE (camera, landmark) pair -- a legitimate input (many factors on one pair).  The pair plan
+    takes any number; only the dense form's run table (one byte per observation) cannot: create succeeds, the reduced system
+    equals the oracle's, and switching THIS engine to the dense form is refused with an error code."""
+    a = _args(small)
+    c0, p0 = int(a[2][0]), int(a[3][0])
+    extra = 300
+    rng = np.random.default_rng(4)
+    # landmark-major order is the engine's own business: append anywhere
+    a[2] = np.concatenate([a[2], np.full(extra, c0, a[2].dtype)])
+    a[3] = np.concatenate([a[3], np.full(extra, p0, a[3].dtype)])
+    a[4] = np.concatenate([a[4], a[4][0] + rng.normal(0, 1e-3, (extra, 2))])
+    order = np.argsort(a[3], kind="stable")
+    a[2], a[3], a[4] = a[2][order], a[3][order], a[4][order]
+    e = st.BAEngine(*a)
+    o = O.BA(*a)
+    assert e.schur_mode() == e.SCHUR_PAIRS
+    e.evaluate(); e.normal_blocks()
+    _, ro, Jco, Jpo = o.evaluate()
+    dc = np.full((e.nc, 6), 0.05); dp = np.full((e.np_, 3), 0.05)
+    S, rhs = e.reduced_system(dc, dp)
+    So, rhso = o.reduced_system(ro, Jco, Jpo, dc, dp)
+    assert np.abs(np.tril(S) - np.tril(So)).max() < 1e-10 * np.abs(So).max()
+    assert np.abs(rhs - rhso).max() < 1e-10 * max(1.0, np.abs(rhso).max())
+    with pytest.raises(Exception) as ei:
+        e.set_schur_mode(e.SCHUR_DENSE)
+    assert "255" in str(ei.value)
