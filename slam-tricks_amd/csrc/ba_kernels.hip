@@ -690,7 +690,8 @@ __global__ __launch_bounds__(SCHUR_THREADS, GEN ? 2 : 4) void ba_schur_pairs_ker
     for (int e = tid; e < ncols; e += SCHUR_THREADS) cols[e] = a.row_cols[col0 + e];
     for (int e = tid; e <= ncols; e += SCHUR_THREADS) vsf[e] = vs_g[e];
     if (tid == 0) vsf[a.max_cols + 1] = 0;       // the token of mode 1
-    {
+    const bool lms = a.part != nullptr;          // landmark-range slices: partial blocks out, the reduce kernel writes (and zeroes) S
+    if (!lms) {
         // this slice's stretch of the camera's six rows of S is zeroed HERE (the whole row up to the end of the diagonal
         // 128-tile, shared out between the slices; nothing right of it is ever read): the stores drain under the pair loop
         const int cend = min(a.lda, ((c * 6 + 5) / 128 + 1) * 128);
@@ -793,12 +794,13 @@ __global__ __launch_bounds__(SCHUR_THREADS, GEN ? 2 : 4) void ba_schur_pairs_ker
         // here they are register sums like the camera block.
         // (two passes over the camera's records, 27 running sums each: all 54 in one loop need 238 registers and halve
         // the occupancy of the whole kernel; the second pass finds the records in the L1 / L2)
-        const int pe = a.cam_start[c + 1];
+        const int pb = lms ? a.task_p_lo[task] : a.cam_start[c];      // (a landmark-range slice: its own stretch of the camera's list)
+        const int pe = lms ? a.task_p_hi[task] : a.cam_start[c + 1];
         {
             double h[27];
 #pragma unroll
             for (int k = 0; k < 27; ++k) h[k] = 0.0;
-            for (int p = a.cam_start[c] + tid; p < pe; p += SCHUR_THREADS) {
+            for (int p = pb + tid; p < pe; p += SCHUR_THREADS) {
                 const int i = a.cam_perm[p];
                 double j[12], jpu[6];
                 load_jc_jp<GEN>(a.J8, a.omask, i, j, jpu, a.Jc12);
@@ -822,7 +824,7 @@ __global__ __launch_bounds__(SCHUR_THREADS, GEN ? 2 : 4) void ba_schur_pairs_ker
             double h[27];       // [0 .. 20] = -sum E W^T (lower triangle, row-wise), [21 .. 26] = sum E gp
 #pragma unroll
             for (int k = 0; k < 27; ++k) h[k] = 0.0;
-            for (int p = a.cam_start[c] + tid; p < pe; p += SCHUR_THREADS) {
+            for (int p = pb + tid; p < pe; p += SCHUR_THREADS) {
                 const int i = a.cam_perm[p];
                 double j[12], jpu[6];
                 load_jc_jp<GEN>(a.J8, a.omask, i, j, jpu, a.Jc12);
@@ -872,6 +874,28 @@ __global__ __launch_bounds__(SCHUR_THREADS, GEN ? 2 : 4) void ba_schur_pairs_ker
         }
     }
     __syncthreads();
+    if (lms) {
+        // a landmark-range slice: everything it has summed goes to ITS stretch of the partial buffer, dense and coalesced --
+        // [ncols x 36 block entries | rhs at +0..5 | camera sums (21 + 6) at +8..34]; ba_schur_reduce_slices_kernel adds the slices
+        double* out = a.part + a.task_part_off[task];
+        for (int e = tid; e < ncols * 36; e += SCHUR_THREADS) {
+            const int slot = e / 36, k = e - slot * 36;
+            const int v1 = vsf[slot + 1];
+            double sum = acc[vsf[slot] * SCHUR_BLK_LD + k];
+            for (int v = vsf[slot] + 1; v < v1; ++v) sum += acc[v * SCHUR_BLK_LD + k];
+            out[e] = sum;
+        }
+        double* tail = out + (size_t)ncols * 36;
+        if (tid < 6) tail[tid] = racc[tid];
+        if (tid >= 64 && tid < 64 + 27) {
+            const int k = tid - 64;
+            double s = 0.0;
+#pragma unroll
+            for (int w = 0; w < SCHUR_THREADS / 64; ++w) s += cpart[w * SCHUR_CAM_LD + k];
+            tail[8 + k] = s;
+        }
+        return;
+    }
     for (int e = tid; e < ncols * 36; e += SCHUR_THREADS) {
         const int slot = e / 36, k = e - slot * 36, q = k / 6, b = k - q * 6;
         const int c2 = cols[slot];
@@ -1046,6 +1070,44 @@ int launch_schur_dense(const SchurDenseArgs& a, hipStream_t st) {
     return STBA_OK;
 }
 
+// Landmark-range slices (few camera rows): one workgroup per camera row adds the row's slices IN LIST ORDER -- blocks, right-hand
+// side, camera block and gradient -- and writes the row of S (zeroed up to the end of its diagonal 128-tile first, as the column
+// slices do for themselves).  Fixed order, no atomics: bitwise reproducible.
+__global__ __launch_bounds__(256) void ba_schur_reduce_slices_kernel(SchurArgs a) {
+    const int c = blockIdx.x, tid = threadIdx.x;
+    const int col0 = a.row_col_ptr[c], ncols = a.row_col_ptr[c + 1] - col0;
+    const int t0 = a.row_task_ptr[c], t1 = a.row_task_ptr[c + 1];
+    const int cend = min(a.lda, ((c * 6 + 5) / 128 + 1) * 128);
+    for (int q = 0; q < 6; ++q) {
+        double* row = a.S + (size_t)(c * 6 + q) * a.lda;
+        for (int e = tid; e < cend; e += 256) row[e] = 0.0;
+    }
+    __syncthreads();                             // (orders the zero stores before the block stores)
+    for (int e = tid; e < ncols * 36; e += 256) {
+        const int slot = e / 36, k = e - slot * 36, q = k / 6, b = k - q * 6;
+        const int c2 = a.row_cols[col0 + slot];
+        if (c2 == c && b > q) continue;
+        double sum = 0.0;
+        for (int t = t0; t < t1; ++t) sum += a.part[a.task_part_off[a.row_tasks[t]] + e];
+        a.S[(size_t)(c * 6 + q) * a.lda + c2 * 6 + b] = sum;
+    }
+    if (tid < 6 + 27) {
+        const int off = tid < 6 ? tid : 8 + (tid - 6);
+        double sum = 0.0;
+        for (int t = t0; t < t1; ++t) sum += a.part[a.task_part_off[a.row_tasks[t]] + (size_t)ncols * 36 + off];
+        if (tid < 6) a.rhs[c * 6 + tid] = sum;
+        else {
+            const int k = tid - 6;
+            if (k < 21) {
+                int q = 0, b = k;
+                while (b > q) { ++q; b -= q; }
+                a.Hcc[(size_t)c * 36 + q * 6 + b] = sum;
+                a.Hcc[(size_t)c * 36 + b * 6 + q] = sum;
+            } else a.gc[(size_t)c * 6 + (k - 21)] = sum;
+        }
+    }
+}
+
 size_t schur_rows_lds_bytes(int max_cols) {
     return ((size_t)max_cols * SCHUR_BLK_LD + 8 + 8 * SCHUR_CAM_LD) * sizeof(double) + ((size_t)2 * max_cols + 2) * sizeof(int) + 16;
 }
@@ -1075,6 +1137,7 @@ int launch_schur_rows(const SchurArgs& a, int n_tasks, hipStream_t st) {
     else
 #endif
     STBA_TRY(a.Jc12 ? (launch_schur_inst<true, 0>(a, n_tasks, lds, st)) : (launch_schur_inst<false, 0>(a, n_tasks, lds, st)));
+    if (a.part && a.n_cams > 0) hipLaunchKernelGGL(ba_schur_reduce_slices_kernel, dim3(a.n_cams), dim3(256), 0, st, a);
     STBA_HIP(hipGetLastError());
     return STBA_OK;
 }

@@ -79,6 +79,10 @@ struct SchurArgs {
     const int* task_vs_ptr; const int* vs_first;     // per task: [blocks + 1] first accumulator slot of every block of the slice
     const int* obs_pt;                               // landmark of every observation
     const int4* pair_rec;                            // (i, l, landmark, slot | 0x8000 if diagonal block), l != i
+    // round 6, landmark-range slices (few camera rows; null otherwise): the task's range of cam_perm, where it writes its partial
+    // blocks [ncols * 36 | rhs 6 (+2) | camera sums 27 ...], and every row's tasks in the order ba_schur_reduce_slices_kernel adds them
+    const int* task_p_lo = nullptr; const int* task_p_hi = nullptr; const long long* task_part_off = nullptr; double* part = nullptr;
+    const int* row_task_ptr = nullptr; const int* row_tasks = nullptr; int n_cams = 0;
 };
 // the Schur complement for dense visibility as a symmetric rank-k product (ba_kernels.hip, "DENSE visibility")
 struct SchurDenseArgs {

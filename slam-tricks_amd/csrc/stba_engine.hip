@@ -92,6 +92,12 @@ struct stba_ba {
     int *task_cam = nullptr, *cam_start = nullptr, *row_col_ptr = nullptr, *row_cols = nullptr;
     int *task_col_lo = nullptr, *task_col_hi = nullptr;
     int n_tasks = 0, max_cols = 0;
+    // round 6, FEW camera rows (landmark-heavy problems): a task = (camera row, a RANGE of the camera's observation list), all columns of
+    // the row; the slices of a row write partial blocks, ba_schur_reduce_slices_kernel adds them in order (see stba_ba_create)
+    int *task_p_lo = nullptr, *task_p_hi = nullptr, *row_task_ptr = nullptr, *row_tasks = nullptr;
+    long long* task_part_off = nullptr;
+    double* schur_part = nullptr;
+    bool lm_slices = false;
     // pair plan of the Schur kernel (see ba_schur_pairs_kernel)
     int *pair_begin = nullptr, *pair_end = nullptr;      // per (task, wave)
     int *task_vs_ptr = nullptr, *vs_first = nullptr;     // per task: first accumulator slot of every block of its slice (+ the slot count)
@@ -169,6 +175,7 @@ static void ba_free(stba_ba* b) {
     F(b->pt_fixed); F(b->r); F(b->J8); F(b->Jc12); F(b->omask); F(b->Hpp6); F(b->gp); F(b->Hinv6); F(b->dp); F(b->scale_p);
     F(b->Hcc); F(b->gc); F(b->cam_partial); F(b->dc); F(b->scale_c); F(b->Sbuf); F(b->Spack); F(b->pk_blocks); F(b->dxc); F(b->dxp);
     F(b->task_cam); F(b->cam_start); F(b->task_col_lo); F(b->task_col_hi); F(b->row_col_ptr); F(b->row_cols);
+    F(b->task_p_lo); F(b->task_p_hi); F(b->row_task_ptr); F(b->row_tasks); F(b->task_part_off); F(b->schur_part);
     F(b->pair_begin); F(b->pair_end); F(b->pair_rec); F(b->task_vs_ptr); F(b->vs_first); F(b->Y); F(b->yv); F(b->yws); F(b->dup_run);
     F(b->cost_partial); F(b->upd_partial_c); F(b->upd_partial_p); F(b->trial); F(b->flag);
     for (auto& e : b->ev) if (e) (void)hipEventDestroy(e);
@@ -348,7 +355,10 @@ static int ba_plan_pack(stba_ba* b) {
 static int ba_lin_pin(stba_ba* b) {
     if (b->lin_pin) return STBA_OK;
     const size_t nh = (size_t)SC_GPMAX0 + b->world;
-    STBA_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->lin_pin), (nh + (size_t)b->n) * sizeof(double), hipHostMallocMapped));
+    // (COHERENT, like every block the host reads behind a POLLED stamp rather than a stream synchronisation: without the flag the
+    // memory may be coarse-grained, and what a kernel wrote into it is only promised to the host at a synchronisation point --
+    // round 6: one run in several of tests/test_gpu_parity.py read a stale gradient norm here and stopped one iteration early)
+    STBA_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->lin_pin), (nh + (size_t)b->n) * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
     STBA_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&b->lin_pin_dev), b->lin_pin, 0));
     return STBA_OK;
 }
@@ -401,6 +411,10 @@ static int ba_schur_step(stba_ba* b) {
     sa.S = b->S(); sa.lda = b->lda; sa.rhs = b->rhs(); sa.Hcc = b->Hcc; sa.gc = b->gc;
     sa.obs_pt = b->obs_pt; sa.pair_begin = b->pair_begin; sa.pair_end = b->pair_end; sa.pair_rec = b->pair_rec;
     sa.task_vs_ptr = b->task_vs_ptr; sa.vs_first = b->vs_first; sa.mode = b->schur_plan_mode;
+    if (b->lm_slices) {
+        sa.task_p_lo = b->task_p_lo; sa.task_p_hi = b->task_p_hi; sa.task_part_off = b->task_part_off; sa.part = b->schur_part;
+        sa.row_task_ptr = b->row_task_ptr; sa.row_tasks = b->row_tasks; sa.n_cams = b->nc;
+    }
     return launch_schur_rows(sa, b->n_tasks, b->st);
 }
 
@@ -1078,7 +1092,7 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
     // block of S, no atomics on S, and the task zeroes its own stretch of the six matrix rows).  A slice holds at most
     // SCHUR_SPLIT_COLS blocks (the LDS accumulator: two workgroups per CU) and at most SCHUR_TASK_PAIRS pairs (no limit
     // by default: see the task order below).  The pairs of every task are enumerated here once (the structure is static).
-    std::vector<int> row_col_ptr(n_cams + 1, 0), row_cols, task_cam, task_col_lo, task_col_hi;
+    std::vector<int> row_col_ptr(n_cams + 1, 0), row_cols, task_cam, task_col_lo, task_col_hi, task_p_lo, task_p_hi;
     std::vector<size_t> task_pairs;
     std::vector<std::vector<int>> cnt_of;       // per camera row: pairs of every non-zero block (without the pairs (i, i))
     int task_max_cols = 0;
@@ -1147,6 +1161,48 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
         // (45 M pairs): one slice per row 10.8 ms, two 4.7, three 5.8, four 6.9 (every further slice walks the camera's observation
         // list once more and finds fewer of a landmark's pairs side by side); on one eighth of it 1.30 / 0.48 / 0.56 ms
         const bool two_slices = n_cams <= 256 && total_pairs > ((size_t)1 << 20) && TASK_PAIRS == SCHUR_TASK_PAIRS;
+        // ROUND 6: with few camera rows whose blocks all fit ONE task's accumulator (<= SCHUR_SPLIT_COLS columns), a row is cut by
+        // LANDMARK RANGE instead: a task = (row, a contiguous range of the camera's observation list, all columns).  Cutting by columns
+        // (above) makes every slice gather the camera's own records again and finds fewer of a landmark's pairs side by side, so more
+        // than ~two slices per row lost (4.7 / 5.8 / 6.9 ms at two / three / four); by landmark range a slice touches only its own
+        // stretch of the list, any number of slices balances, and a thousand tasks fill the 512 workgroup slots twice over.  The
+        // slices of a row write PARTIAL blocks (plus their share of the camera block, the gradient and the right-hand side); a
+        // second, small kernel adds them in slice order -- no atomics on S, bitwise reproducible.
+        bool lm_slices = two_slices && knob_int("STBA_SCHUR_LM_SLICES", 1) != 0;
+        for (int c = 0; c < n_cams && lm_slices; ++c) if ((int)cols_of[(size_t)c].size() > SCHUR_SPLIT_COLS) lm_slices = false;
+        b->lm_slices = lm_slices;
+        if (lm_slices) {
+            const size_t cap = std::max<size_t>(8192, total_pairs / 1024 + 1);
+            for (int c = 0; c < n_cams; ++c) {
+                const std::vector<int>& tmp = cols_of[(size_t)c];
+                row_cols.insert(row_cols.end(), tmp.begin(), tmp.end());
+                row_col_ptr[c + 1] = (int)row_cols.size();
+                const int ncols_c = (int)tmp.size();
+                task_max_cols = std::max(task_max_cols, ncols_c);
+                // pairs behind every observation of the camera's list: partners l of the same landmark with camera(l) <= c, l != i
+                const int p0 = cam_start[c], p1 = cam_start[c + 1];
+                size_t row_pairs = 0;
+                for (int q : cnt_of[(size_t)c]) row_pairs += (size_t)q;
+                const int n_sl = (int)std::min<size_t>(64, std::max<size_t>(1, (row_pairs + cap - 1) / cap));
+                const size_t per = (row_pairs + (size_t)n_sl - 1) / (size_t)n_sl;
+                int lo = p0, made = 0;
+                size_t acc = 0;
+                auto push = [&](int hi) {
+                    task_cam.push_back(c); task_col_lo.push_back(0); task_col_hi.push_back(ncols_c);
+                    task_p_lo.push_back(lo); task_p_hi.push_back(hi); task_pairs.push_back(acc);
+                    ++made; lo = hi; acc = 0;
+                };
+                for (int p = p0; p < p1; ++p) {
+                    const int i = cam_perm[p];
+                    const int j = s_pt[i];
+                    size_t w = 0;
+                    for (int l = pt_start[j]; l < pt_start[j + 1]; ++l) if (s_cam[l] <= c && l != i) ++w;
+                    if (acc > 0 && acc + w > per && made < n_sl - 1) push(p);
+                    acc += w;
+                }
+                push(p1);          // (the last slice; a camera without observations gets one empty task)
+            }
+        } else
         for (int c = 0; c < n_cams; ++c) {
             const std::vector<int>& tmp = cols_of[(size_t)c];
             const std::vector<int>& cnt = cnt_of[(size_t)c];
@@ -1182,6 +1238,7 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
         std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return task_pairs[(size_t)x] > task_pairs[(size_t)y]; });
         auto permute = [&](auto& v) { auto t = v; for (size_t k = 0; k < order.size(); ++k) v[k] = t[(size_t)order[k]]; };
         permute(task_cam); permute(task_col_lo); permute(task_col_hi); permute(task_pairs);
+        if (lm_slices) { permute(task_p_lo); permute(task_p_hi); }
     }
     tmark("row plan");
     b->n_tasks = (int)task_cam.size();
@@ -1223,19 +1280,20 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
         std::vector<int> max_slots_thr(64, 0);
         host_parallel_for(ntask, [&](int k_lo, int k_hi, int tix) {
             std::vector<int> slot_of((size_t)n_cams, 0);
-            std::vector<int> nparts, wave_of, order, cntR;
+            std::vector<int> nparts, wave_of, order, cntR, bcl;
             std::vector<unsigned char> range_of;
+            const bool lm = b->lm_slices;
             for (int k = k_lo; k < k_hi; ++k) {
                 const int c = task_cam[(size_t)k];
                 const int* cb = row_cols.data() + row_col_ptr[c];
                 const int nco = row_col_ptr[c + 1] - row_col_ptr[c];
                 for (int q = 0; q < nco; ++q) slot_of[(size_t)cb[q]] = q;
                 const int slo = task_col_lo[(size_t)k], shi = task_col_hi[(size_t)k], ncols = shi - slo;
-                const int* bc = cnt_of[(size_t)c].data() + slo;                 // pairs per block of the slice
                 const size_t total = task_pairs[(size_t)k];
                 int* vsf = vs_first.data() + task_vs_ptr[(size_t)k];
                 // ---- pass 1: the range of every observation of the camera (equal shares of THIS task's pairs), pairs per (block, range)
-                const int p0 = cam_start[c], p1 = cam_start[c + 1];
+                // (a landmark-range slice walks its own stretch of the camera's list only)
+                const int p0 = lm ? task_p_lo[(size_t)k] : cam_start[c], p1 = lm ? task_p_hi[(size_t)k] : cam_start[c + 1];
                 range_of.assign((size_t)(p1 - p0), 0);
                 cntR.assign((size_t)ncols * NW, 0);
                 {
@@ -1262,6 +1320,13 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
                 // lanes that hold the same landmark's other pairs (~25 instead of ~12 cache lines per gather instruction).  With P parts the
                 // share of such FOREIGN pairs of a block of m pairs is 1 - P / 8, so every accumulator slot spent on a block makes m / 8 of
                 // its pairs local, whatever P: the blocks are upgraded heaviest first, to eight parts each, while slots last.
+                // pairs per block of the slice (a landmark-range slice counts its own: the row's table covers the whole list)
+                const int* bc = cnt_of[(size_t)c].data() + slo;
+                if (lm) {
+                    bcl.assign((size_t)ncols, 0);
+                    for (int q = 0; q < ncols; ++q) for (int w2 = 0; w2 < NW; ++w2) bcl[(size_t)q] += cntR[(size_t)q * NW + w2];
+                    bc = bcl.data();
+                }
                 nparts.assign((size_t)ncols, 1);
                 int nvs = ncols;
                 if (plan_mode == 0) {
@@ -1348,6 +1413,26 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
         for (const int4& pr : pair_rec) at += (pr.w & 0x8000) ? 21.0 : 36.0;
         b->schur_pairs = (double)pair_rec.size(); b->schur_lds_atomics = at;
     }
+    // landmark-range slices: where every task writes its partial blocks, and every row's tasks in list order (the order of the sum)
+    std::vector<long long> task_part_off;
+    std::vector<int> row_task_ptr, row_tasks;
+    size_t part_doubles = 0;
+    if (b->lm_slices) {
+        const int ntask = (int)task_cam.size();
+        task_part_off.resize((size_t)ntask);
+        for (int k = 0; k < ntask; ++k) {
+            task_part_off[(size_t)k] = (long long)part_doubles;
+            part_doubles += (size_t)(task_col_hi[(size_t)k] - task_col_lo[(size_t)k]) * 36 + 64;
+        }
+        std::vector<std::vector<std::pair<int, int>>> by_row((size_t)n_cams);
+        for (int k = 0; k < ntask; ++k) by_row[(size_t)task_cam[(size_t)k]].push_back({task_p_lo[(size_t)k], k});
+        row_task_ptr.assign((size_t)n_cams + 1, 0);
+        for (int c = 0; c < n_cams; ++c) {
+            std::sort(by_row[(size_t)c].begin(), by_row[(size_t)c].end());
+            for (auto& pr : by_row[(size_t)c]) row_tasks.push_back(pr.second);
+            row_task_ptr[(size_t)c + 1] = (int)row_tasks.size();
+        }
+    }
     tmark("pair plan");
     std::vector<unsigned char> cmask;
     if (cam_fixed) {
@@ -1379,6 +1464,14 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
     A_(dev_alloc(&b->task_vs_ptr, std::max<size_t>(task_vs_ptr.size(), 1))); A_(dev_alloc(&b->vs_first, std::max<size_t>(vs_first.size(), 1)));
     if (cam_fixed) A_(dev_alloc(&b->cam_fixed, nc));
     if (pt_fixed) A_(dev_alloc(&b->pt_fixed, np));
+    if (b->lm_slices) {
+        A_(dev_alloc(&b->task_p_lo, task_p_lo.size())); A_(dev_alloc(&b->task_p_hi, task_p_hi.size())); A_(dev_alloc(&b->task_part_off, task_part_off.size()));
+        A_(dev_alloc(&b->row_task_ptr, row_task_ptr.size())); A_(dev_alloc(&b->row_tasks, std::max<size_t>(row_tasks.size(), 1)));
+        A_(dev_alloc(&b->schur_part, std::max<size_t>(part_doubles, 1)));
+        A_(upload(b->task_p_lo, task_p_lo.data(), task_p_lo.size(), b->st)); A_(upload(b->task_p_hi, task_p_hi.data(), task_p_hi.size(), b->st));
+        A_(upload(b->task_part_off, task_part_off.data(), task_part_off.size(), b->st));
+        A_(upload(b->row_task_ptr, row_task_ptr.data(), row_task_ptr.size(), b->st)); A_(upload(b->row_tasks, row_tasks.data(), row_tasks.size(), b->st));
+    }
     if (!dup_run.empty()) { A_(dev_alloc(&b->dup_run, no)); A_(upload(b->dup_run, dup_run.data(), no, b->st)); }
     A_(dev_alloc(&b->r, no)); A_(dev_alloc(&b->J8, no * 8));
     if (cam_fixed || pt_fixed) A_(dev_alloc(&b->omask, no));

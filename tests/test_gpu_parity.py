@@ -827,7 +827,7 @@ def test_function_tolerance_switch_follows_the_oracle(st, O, scenes):
     s0, t0 = e0.solve(function_tolerance_takes_step=0)
     so, to = o0.solve(function_tolerance_takes_step=0)
     n = so.num_iterations
-    assert s0.num_iterations == n == s1.num_iterations and s0.termination_reason == so.termination_reason == 2
+    assert s0.num_iterations == n == s1.num_iterations and s0.termination_reason == so.termination_reason == 2, (s0.as_dict(), s1.as_dict(), so.as_dict(), t0[:, 0], t1[:, 0], to[:, 0])
     assert np.array_equal(t0[: n + 1, 6], to[: n + 1, 6]) and t0[n, 6] == 0 and t1[n, 6] == 1
     assert np.allclose(t0[: n + 1, 0], to[: n + 1, 0], rtol=1e-9)
     assert abs(s0.final_cost - so.final_cost) <= 1e-9 * so.final_cost and s0.final_cost >= s1.final_cost
