@@ -1238,27 +1238,15 @@ __global__ __launch_bounds__(PP_T) void pg_pcg_persistent_kernel(PpArgs a) {
 // (one rank) or to a device block the cross-rank sum goes over first.  out: {cost2_new, |J x|^2, g.x, |dx|^2, |x|^2, seq}
 __global__ __launch_bounds__(256) void pg_trial_finish_kernel(int nb_e, const double* __restrict__ part_e, int nb_tt,
                                                               const double* __restrict__ part_tt, int nb_u, const double* __restrict__ part_u,
-                                                              const PcgState* __restrict__ state, int nb_g, const double* __restrict__ part_g,
-                                                              double* __restrict__ out, double seq) {
+                                                              const PcgState* __restrict__ state, double* __restrict__ out, double seq) {
     const double c2 = sum_partials_dev(part_e, nb_e, 1, 0);
     const double tt = sum_partials_dev(part_tt, nb_tt, 2, 0);
     const double gx = sum_partials_dev(part_u, nb_u, 4, 0);
     const double s2 = sum_partials_dev(part_u, nb_u, 4, 1);
     const double x2 = sum_partials_dev(part_u, nb_u, 4, 2);
-    // (a speculative trial evaluation: |g|^2 and |g|_inf of the linearisation at the trial point ride along -- pg_linear_finish_kernel's sums)
-    double g2 = 0.0, mx = 0.0;
-    if (nb_g > 0) {
-        g2 = sum_partials_dev(part_g, nb_g, 2, 0);
-        __shared__ double sq[256];
-        for (int k = threadIdx.x; k < nb_g; k += 256) mx = fmax(mx, part_g[2 * k + 1]);
-        sq[threadIdx.x] = mx;
-        __syncthreads();
-        if (threadIdx.x == 0) for (int k = 1; k < 256; ++k) mx = fmax(mx, sq[k]);
-    }
     if (threadIdx.x == 0) {
         out[0] = c2; out[1] = tt; out[2] = gx; out[3] = s2; out[4] = x2;
         out[5] = state ? (double)state->iters : 0.0; out[6] = state ? (double)state->hit_cap : 0.0; out[7] = state ? state->rr0 : 0.0;
-        out[9] = mx; out[10] = g2;
         __threadfence_system();
         out[8] = seq;
         __threadfence_system();
@@ -1716,7 +1704,6 @@ int stba_pg_solve(stba_pg* g, const stba_lm_options* opt_in, const stba_pcg_opti
     const bool build_on_st2 = async_inv && !g->ar;
     if (coarse) STBA_HIP(hipMemsetAsync(g->cflag + 1, 0, sizeof(int), g->st));      // this solve's count of failed coarse operators
     const bool multi = (g->ar != nullptr);
-    const bool speculate = !multi;       // the trial point is evaluated by LINEARISING there (see trial_point)
     const int chunk = std::max(1, pcg.check_every);
     const bool forcing = pcg.forcing_eta0 > 0.0;
     stba_pcg_summary ps;
@@ -1744,19 +1731,14 @@ int stba_pg_solve(stba_pg* g, const stba_lm_options* opt_in, const stba_pcg_opti
     }
 
     // ---- linearisation at the current point: residuals, Jacobians, gradient | diagonal blocks, the coarse basis and matrix
-    // (two halves: the second one needs the accepted point, the first one is also what the SPECULATIVE trial evaluation runs)
-    auto lin_core = [&](int which) -> int {
+    auto linearize_enqueue = [&]() -> int {
         // (the job of the second stream reads the blocks, the coarse basis and the damping of the linearisation it belongs to: the next
         // linearisation waits until it has -- an event that has long fired by then)
         if (g->job_reads_pending) { STBA_TRY(pg_wait_if_pending(g->st, g->ev_read)); g->job_reads_pending = false; }
-        STBA_TRY(pg_linearize(g, which, true));
+        STBA_TRY(pg_linearize(g, g->cur, true));
         hipLaunchKernelGGL(pg_gather_blocks_kernel, dim3(g->nb_nodes4), dim3(PG_NT), 0, g->st, g->n, g->node_start, g->end_code, g->contrib, g->g, g->Hd);
         if (g->ar && g->ar(g->ar_user, g->g, (size_t)g->n * 42, g->st) != 0) return fail(STBA_ERR_CALLBACK, "all-reduce hook failed");
         hipLaunchKernelGGL(pg_gnorm_kernel, dim3(g->nb_vec), dim3(256), 0, g->st, N, g->g, g->part_c);
-        STBA_HIP(hipGetLastError());
-        return STBA_OK;
-    };
-    auto lin_coarse = [&]() -> int {
         if (coarse) {
             hipLaunchKernelGGL(pg_coarse_basis_kernel, dim3(g->nb_nodes), dim3(256), 0, g->st, g->n, g->agg, g->poses[g->cur], g->fixed, g->AdP);
             if (!g->bend_valid) {
@@ -1775,10 +1757,6 @@ int stba_pg_solve(stba_pg* g, const stba_lm_options* opt_in, const stba_pcg_opti
         }
         STBA_HIP(hipGetLastError());
         return STBA_OK;
-    };
-    auto linearize_enqueue = [&]() -> int {
-        STBA_TRY(lin_core(g->cur));
-        return lin_coarse();
     };
     // cost and |g|_inf of that linearisation: one kernel sums, the host reads mapped memory (several ranks: the cost goes over the hook)
     auto linearize_finish = [&](double* cost, double* gmax, double* g2) -> int {
@@ -1997,18 +1975,14 @@ int stba_pg_solve(stba_pg* g, const stba_lm_options* opt_in, const stba_pcg_opti
             hipLaunchKernelGGL(pg_edge_product_kernel, dim3(g->nb_edges), dim3(256), 0, g->st, g->m, g->ei, g->ej, g->Ji, g->Jj, g->x, g->u, g->part_b,
                                (const PcgState*)nullptr);
             hipLaunchKernelGGL(pg_update4_kernel, dim3(g->nb_nodes), dim3(256), 0, g->st, g->n, g->poses[g->cur], g->x, g->g, g->fixed, g->poses[nxt], g->part_u);
-            // ONE RANK (round 6): the evaluation of the trial point IS the linearisation at it -- residuals, Jacobians, gradient and
-            // diagonal blocks, the norms of the gradient -- and all its scalars come back with the trial block: a step is accepted far
-            // more often than not (every step of C4), and an accepted step then costs one pass over the edges and ONE host round
-            // trip instead of two of each.  A rejected step linearises again at the old point (below), as the BA engine does.
-            if (speculate) STBA_TRY(lin_core(nxt)); else STBA_TRY(pg_linearize(g, nxt, false));
+            STBA_TRY(pg_linearize(g, nxt, false));
             g->seq += 1.0;
             if (!multi) {
                 hipLaunchKernelGGL(pg_trial_finish_kernel, dim3(1), dim3(256), 0, g->st, g->nb_edges, g->part_e, g->nb_edges, g->part_b, g->nb_nodes, g->part_u,
-                                   g->state, speculate ? g->nb_vec : 0, g->part_c, g->fin_dev, g->seq);
+                                   g->state, g->fin_dev, g->seq);
             } else {
                 hipLaunchKernelGGL(pg_trial_finish_kernel, dim3(1), dim3(256), 0, g->st, g->nb_edges, g->part_e, g->nb_edges, g->part_b, g->nb_nodes, g->part_u,
-                                   g->state, 0, (const double*)nullptr, g->scal_dev, g->seq);
+                                   g->state, g->scal_dev, g->seq);
                 if (g->ar(g->ar_user, g->scal_dev, 2, g->st) != 0) return fail(STBA_ERR_CALLBACK, "all-reduce hook failed");      // cost and |J x|^2 over the edge shards
                 hipLaunchKernelGGL(pg_export_kernel, dim3(1), dim3(64), 0, g->st, 8, g->scal_dev, g->fin_dev, g->seq);
             }
@@ -2036,7 +2010,6 @@ int stba_pg_solve(stba_pg* g, const stba_lm_options* opt_in, const stba_pcg_opti
             // a stamp never came: the workgroups were not all resident (another process on the device).  Once is enough: this
             // engine solves with launches from here on, starting with this very iteration.
             g->pp_disabled = true;
-            if (speculate) STBA_TRY(linearize_enqueue());      // (the speculative evaluation overwrote the current point's linearisation)
             STBA_TRY(pcg_by_launches());
             STBA_TRY(trial_point());
         }
@@ -2077,13 +2050,8 @@ int stba_pg_solve(stba_pg* g, const stba_lm_options* opt_in, const stba_pcg_opti
             radius = std::min(opt.max_trust_region_radius, radius / std::max(1.0 / 3.0, 1.0 - t * t * t));
             decrease = 2.0;
             double c2, g2_new = 0.0;
-            if (speculate) {        // (already linearised there: the coarse half is what is left, the scalars came with the trial block)
-                STBA_TRY(lin_coarse());
-                c2 = 0.5 * fin[0]; gmax = fin[9]; g2_new = fin[10];
-            } else {
-                STBA_TRY(linearize_enqueue());
-                STBA_TRY(linearize_finish(&c2, &gmax, &g2_new));
-            }
+            STBA_TRY(linearize_enqueue());
+            STBA_TRY(linearize_finish(&c2, &gmax, &g2_new));
             cost = c2;
             // forcing sequence (Eisenstat & Walker, choice 2): eta_{k+1} = 0.9 (|g_{k+1}| / |g_k|)^2 with their safeguard, kept in
             // [eta_min, eta0]; after a rejected step the gradient has not moved and eta stays
@@ -2104,7 +2072,6 @@ int stba_pg_solve(stba_pg* g, const stba_lm_options* opt_in, const stba_pcg_opti
             ++s.num_unsuccessful_steps;
             radius /= decrease; decrease *= 2.0;
             if (trace) trace[(size_t)iter * STBA_TRACE_COLS + 5] = radius;
-            if (speculate) STBA_TRY(linearize_enqueue());      // (back to the current point's residuals, Jacobians, gradient and blocks)
         }
         if (opt.minimizer_progress_to_stdout)
             printf("%4d  %.6e   % .2e    %.2e   %.2e  % .2e  %.2e  pcg %d eta %.1e%s\n", iter, cost, cost_change, gmax, step_norm, rho, radius, k, eta_k,
