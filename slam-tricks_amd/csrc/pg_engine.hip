@@ -31,6 +31,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <functional>
 #include <vector>
 
 #include "ba_kernels.hpp"
@@ -1799,6 +1800,8 @@ int stba_pg_solve(stba_pg* g, const stba_lm_options* opt_in, const stba_pcg_opti
         scale_init = true;
         // ---- coarse operator (P^T (J^T J + D) P)^-1
         const double* Ainv_use = g->Ainv;
+        std::function<int()> job;
+        bool job_deferred = false;
         if (coarse && async_inv) {
             // ROUND 6: off the critical path.  The inversion (eight panels of a ~45 us chain on a handful of CUs: 0.39 of a 0.92 ms LM
             // iteration at C4) runs on a SECOND stream, next to this iteration's PCG kernel (157 workgroups on 256 CUs), and is applied one LM
@@ -1816,34 +1819,6 @@ int stba_pg_solve(stba_pg* g, const stba_lm_options* opt_in, const stba_pcg_opti
             const double* Ar = wbuf ? g->Ainv : g->Ainv2;        // written by the previous job (or zeroed below)
             if (jobs == 0) STBA_HIP(hipMemsetAsync(const_cast<double*>(Ar), 0, (size_t)g->nc * g->nc * sizeof(double), g->st));
             else STBA_TRY(pg_wait_if_pending(g->st, g->ev_job[(jobs - 1) & 1]));
-            const size_t cnt = (size_t)3 * g->np * g->np;
-            if (build_on_st2) {
-                // one rank: everything the inverse needs is made on the second stream -- coarse matrix (from the blocks, the diagonal
-                // blocks and the basis of THIS linearisation), its damping term, the workspace; READ_k tells the first stream when
-                // its next linearisation / preconditioner kernel may overwrite those inputs
-                STBA_HIP(hipEventRecord(g->ev_in, g->st));
-                STBA_HIP(hipStreamWaitEvent(g->st2, g->ev_in, 0));
-                if (!g->ac0_valid) {
-                    hipLaunchKernelGGL(pg_coarse_build_kernel, dim3(g->na), dim3(256), (size_t)6 * g->nc * sizeof(double) + (size_t)4 * g->max_group_ends * sizeof(int), g->st2, g->n, g->agg, g->nc,
-                                       1, g->node_start, g->end_node, g->end_rem, g->Bend, g->Hd, g->AdP, g->Ac0);
-                    g->ac0_valid = true;
-                }
-                hipLaunchKernelGGL(pg_coarse_dc_kernel, dim3(g->na), dim3(256), 0, g->st2, g->n, g->agg, g->AdP, g->d, g->Dc);
-                hipLaunchKernelGGL(pg_coarse_assemble_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, g->st2, g->nc, g->np, g->Ac0, g->Dc, g->W);
-                STBA_HIP(hipEventRecord(g->ev_read, g->st2));
-                g->job_reads_pending = true;
-            } else {
-                hipLaunchKernelGGL(pg_coarse_dc_kernel, dim3(g->na), dim3(256), 0, g->st, g->n, g->agg, g->AdP, g->d, g->Dc);
-                hipLaunchKernelGGL(pg_coarse_assemble_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, g->st, g->nc, g->np, g->Ac0, g->Dc, g->W);
-                STBA_HIP(hipEventRecord(g->ev_in, g->st));
-                STBA_HIP(hipStreamWaitEvent(g->st2, g->ev_in, 0));
-            }
-            STBA_TRY(chol_spd_inverse_dev(g->W, 2 * g->np, g->np, g->nc, g->cflag, g->inv_work, g->st2));
-            hipLaunchKernelGGL(pg_coarse_finish_kernel, dim3((unsigned)(((size_t)g->nc * g->nc + 255) / 256)), dim3(256), 0, g->st2, g->nc, g->np, g->W, Aw,
-                               g->cflag, g->cflag + 1);
-            STBA_HIP(hipEventRecord(g->ev_job[wbuf], g->st2));
-            g->job_in_flight = true;
-            Ainv_use = Ar;
             // the first solve(s) wait for their own inverse (coarse_async = 2: not with a forcing sequence; coarse_async_after: how many
             // LM iterations do -- the operator changes most in the first iterations)
             // -- and every solve that follows a LONG step: the operator is stale by exactly the step that was just taken.  At C4
@@ -1851,12 +1826,50 @@ int stba_pg_solve(stba_pg* g, const stba_lm_options* opt_in, const stba_pcg_opti
             // 1 % and less; preconditioning iteration 3 with iteration 2's operator ends 3.9e-5 from the exact-step poses,
             // iterations 4 .. 9 with their predecessors' 2.9e-6 (in line: 2.5e-6).  Rule: lag only behind a step that took at most
             // coarse_async_decrease (0.5) off the cost.
-            const bool own = (jobs == 0 && (!forcing || pcg.coarse_async != 2)) ||
-                             (pcg.coarse_async != 2 && (iter <= pcg.coarse_async_after || last_rel_decrease > pcg.coarse_async_decrease));
+            // (also measured, profiles/r6_c4_async_coarse_tolerance_behind_long_steps.txt: not waiting behind a long step either and
+            // giving THAT solve a tolerance on the coarse residual instead -- 3e-4 is what the poses need (2.4e-6), and then the extra
+            // PCG iterations cost more than the wait: 1323 against 1411 LM it/s)
+            const bool long_step = iter <= pcg.coarse_async_after || last_rel_decrease > pcg.coarse_async_decrease;
+            const bool own = (jobs == 0 && (!forcing || pcg.coarse_async != 2)) || (pcg.coarse_async != 2 && long_step);
+            const size_t cnt = (size_t)3 * g->np * g->np;
+            if (!build_on_st2) {
+                hipLaunchKernelGGL(pg_coarse_dc_kernel, dim3(g->na), dim3(256), 0, g->st, g->n, g->agg, g->AdP, g->d, g->Dc);
+                hipLaunchKernelGGL(pg_coarse_assemble_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, g->st, g->nc, g->np, g->Ac0, g->Dc, g->W);
+            }
+            STBA_HIP(hipEventRecord(g->ev_in, g->st));
+            // THE JOB: ~ 30 launches on the second stream.  Enqueueing them takes the HOST ~ 250 us -- so when this iteration does not
+            // wait for them (the usual case), the PCG kernel is launched FIRST and the job is enqueued while it runs: with the job in
+            // front, the kernel timeline showed the first stream idle for 277 us of every 760 us iteration, waiting for the host
+            // (profiles/r6_c4_iter_trace.txt)
+            job = [=]() -> int {
+                STBA_HIP(hipStreamWaitEvent(g->st2, g->ev_in, 0));
+                if (build_on_st2) {
+                    // one rank: everything the inverse needs is made on the second stream -- coarse matrix (from the blocks, the
+                    // diagonal blocks and the basis of THIS linearisation), its damping term, the workspace; READ_k tells the first
+                    // stream when its next linearisation / preconditioner kernel may overwrite those inputs
+                    if (!g->ac0_valid) {
+                        hipLaunchKernelGGL(pg_coarse_build_kernel, dim3(g->na), dim3(256), (size_t)6 * g->nc * sizeof(double) + (size_t)4 * g->max_group_ends * sizeof(int), g->st2, g->n, g->agg, g->nc,
+                                           1, g->node_start, g->end_node, g->end_rem, g->Bend, g->Hd, g->AdP, g->Ac0);
+                        g->ac0_valid = true;
+                    }
+                    hipLaunchKernelGGL(pg_coarse_dc_kernel, dim3(g->na), dim3(256), 0, g->st2, g->n, g->agg, g->AdP, g->d, g->Dc);
+                    hipLaunchKernelGGL(pg_coarse_assemble_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, g->st2, g->nc, g->np, g->Ac0, g->Dc, g->W);
+                    STBA_HIP(hipEventRecord(g->ev_read, g->st2));
+                    g->job_reads_pending = true;
+                }
+                STBA_TRY(chol_spd_inverse_dev(g->W, 2 * g->np, g->np, g->nc, g->cflag, g->inv_work, g->st2));
+                hipLaunchKernelGGL(pg_coarse_finish_kernel, dim3((unsigned)(((size_t)g->nc * g->nc + 255) / 256)), dim3(256), 0, g->st2, g->nc, g->np, g->W, Aw,
+                                   g->cflag, g->cflag + 1);
+                STBA_HIP(hipEventRecord(g->ev_job[wbuf], g->st2));
+                g->job_in_flight = true;
+                return STBA_OK;
+            };
+            Ainv_use = Ar;
             if (own) {
+                STBA_TRY(job());
                 STBA_HIP(hipStreamWaitEvent(g->st, g->ev_job[wbuf], 0));
                 Ainv_use = Aw;
-            }
+            } else job_deferred = true;
             ++jobs;
             g->coarse_valid = true;
             ++ps.coarse_refreshes;
@@ -1996,8 +2009,10 @@ int stba_pg_solve(stba_pg* g, const stba_lm_options* opt_in, const stba_pcg_opti
         const bool timing = opt.phase_timing != 0;
         if (timing && !g->ev_t[0]) { STBA_HIP(hipEventCreate(&g->ev_t[0])); STBA_HIP(hipEventCreate(&g->ev_t[1])); }
         if (timing) STBA_HIP(hipEventRecord(g->ev_t[0], g->st));
+        if (!one_kernel && job_deferred) { STBA_TRY(job()); job_deferred = false; }      // (the launch path talks to the host all along: the job goes first)
         if (one_kernel) STBA_TRY(pcg_one_kernel()); else STBA_TRY(pcg_by_launches());
         if (timing) STBA_HIP(hipEventRecord(g->ev_t[1], g->st));
+        if (job_deferred) { STBA_TRY(job()); job_deferred = false; }
         STBA_TRY(trial_point());
         if (timing) {
             float ms = 0.f;
