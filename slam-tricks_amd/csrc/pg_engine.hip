@@ -1469,6 +1469,16 @@ static int pg_setup_coarse(stba_pg* g, int group_opt) {
     return STBA_OK;
 }
 
+// the second stream of the coarse inverse and its events (stba_pg_solve, coarse_async)
+static int pg_second_stream(stba_pg* g) {
+    if (g->st2) return STBA_OK;
+    STBA_HIP(hipStreamCreateWithFlags(&g->st2, hipStreamNonBlocking));
+    STBA_HIP(hipEventCreateWithFlags(&g->ev_in, hipEventDisableTiming));
+    STBA_HIP(hipEventCreateWithFlags(&g->ev_read, hipEventDisableTiming));
+    for (auto& e : g->ev_job) STBA_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    return STBA_OK;
+}
+
 // waits until the sequence number behind a block in mapped host memory is `seq` (the stream is queried now and then so
 // that a device fault ends the wait)
 template <class T>
@@ -1598,6 +1608,12 @@ int stba_pg_create(stba_pg** out, int n_nodes, int n_edges, const double* poses,
         (node_fixed && hipMemcpyAsync(g->fixed, node_fixed, n, hipMemcpyHostToDevice, g->st) != hipSuccess) ||
         hipStreamSynchronize(g->st) != hipSuccess)
         return bail(fail(STBA_ERR_HIP, "stba_pg_create: upload failed"));
+    // The buffers of the default coarse space, the second stream and its events are made HERE (round 6): a solve used to begin with
+    // a dozen allocations (the 33 MB inversion workspace among them), a stream and four events -- ~ 0.4 ms of a 6.4 ms C4 solve
+    // on a fresh engine, inside the time every caller and bench.py measure.  (A solve with another group size makes its own; a
+    // graph too large for the default space is told so by the solve, not here.)
+    if (pg_setup_coarse(g, 0) == STBA_OK && g->agg > 0) (void)pg_second_stream(g);
+    (void)hipStreamSynchronize(g->st);
     *out = g;
     return STBA_OK;
 }
@@ -1693,12 +1709,7 @@ int stba_pg_solve(stba_pg* g, const stba_lm_options* opt_in, const stba_pcg_opti
     // where it costs nothing, instead of at the end of that solve, where it would have been the last 0.3 ms of its wall time
     const bool async_inv = coarse && pcg.coarse_async != 0;
     if (async_inv) {
-        if (!g->st2) {
-            STBA_HIP(hipStreamCreateWithFlags(&g->st2, hipStreamNonBlocking));
-            STBA_HIP(hipEventCreateWithFlags(&g->ev_in, hipEventDisableTiming));
-            STBA_HIP(hipEventCreateWithFlags(&g->ev_read, hipEventDisableTiming));
-            for (auto& e : g->ev_job) STBA_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        }
+        STBA_TRY(pg_second_stream(g));
         if (g->job_in_flight) { STBA_HIP(hipStreamSynchronize(g->st2)); g->job_in_flight = false; }
         g->job_reads_pending = false;
     }
@@ -1775,6 +1786,28 @@ int stba_pg_solve(stba_pg* g, const stba_lm_options* opt_in, const stba_pcg_opti
         return STBA_OK;
     };
 
+    // the HEAD of the second stream's job (one rank): everything the inverse needs -- the coarse matrix from the blocks, the diagonal
+    // blocks and the basis of THIS linearisation, its damping term, the workspace; READ_k tells the first stream when its next
+    // linearisation / preconditioner kernel may overwrite those inputs.  Three launches: behind an accepted step they are enqueued
+    // at once (the preconditioner kernel in front of them), so that they run under the host's wait for the new point's scalars
+    // instead of at the start of the PCG kernel, with which the inversion then competes for CUs.
+    bool head_done = false;
+    auto job_head = [&]() -> int {
+        const size_t cnt = (size_t)3 * g->np * g->np;
+        STBA_HIP(hipStreamWaitEvent(g->st2, g->ev_in, 0));
+        if (!g->ac0_valid) {
+            hipLaunchKernelGGL(pg_coarse_build_kernel, dim3(g->na), dim3(256), (size_t)6 * g->nc * sizeof(double) + (size_t)4 * g->max_group_ends * sizeof(int), g->st2, g->n, g->agg, g->nc,
+                               1, g->node_start, g->end_node, g->end_rem, g->Bend, g->Hd, g->AdP, g->Ac0);
+            g->ac0_valid = true;
+        }
+        hipLaunchKernelGGL(pg_coarse_dc_kernel, dim3(g->na), dim3(256), 0, g->st2, g->n, g->agg, g->AdP, g->d, g->Dc);
+        hipLaunchKernelGGL(pg_coarse_assemble_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, g->st2, g->nc, g->np, g->Ac0, g->Dc, g->W);
+        STBA_HIP(hipEventRecord(g->ev_read, g->st2));
+        g->job_reads_pending = true;
+        g->job_in_flight = true;
+        return STBA_OK;
+    };
+
     double cost = 0.0, gmax = 0.0, g2 = 0.0;
     STBA_TRY(linearize_enqueue());
     STBA_TRY(linearize_finish(&cost, &gmax, &g2));
@@ -1794,10 +1827,14 @@ int stba_pg_solve(stba_pg* g, const stba_lm_options* opt_in, const stba_pcg_opti
         if (iter >= opt.max_num_iterations) break;
         if (radius < opt.min_trust_region_radius) { s.termination_type = STBA_CONVERGENCE; s.termination_reason = STBA_TERM_MIN_RADIUS; break; }
         ++iter;
-        if (g->job_reads_pending) { STBA_TRY(pg_wait_if_pending(g->st, g->ev_read)); g->job_reads_pending = false; }    // (a rejected step: no linearisation in between)
-        hipLaunchKernelGGL(pg_precond_kernel, dim3(g->nb_nodes), dim3(256), 0, g->st, g->n, g->Hd, g->scale, scale_init ? 0 : 1,
-                           opt.jacobi_scaling, radius, opt.min_lm_diagonal, opt.max_lm_diagonal, g->fixed, g->d, g->Minv);
-        scale_init = true;
+        const bool head_was_done = head_done;       // (behind an accepted step the preconditioner and the job's head are already on their way)
+        if (!head_done) {
+            if (g->job_reads_pending) { STBA_TRY(pg_wait_if_pending(g->st, g->ev_read)); g->job_reads_pending = false; }    // (a rejected step: no linearisation in between)
+            hipLaunchKernelGGL(pg_precond_kernel, dim3(g->nb_nodes), dim3(256), 0, g->st, g->n, g->Hd, g->scale, scale_init ? 0 : 1,
+                               opt.jacobi_scaling, radius, opt.min_lm_diagonal, opt.max_lm_diagonal, g->fixed, g->d, g->Minv);
+            scale_init = true;
+        }
+        head_done = false;
         // ---- coarse operator (P^T (J^T J + D) P)^-1
         const double* Ainv_use = g->Ainv;
         std::function<int()> job;
@@ -1836,27 +1873,13 @@ int stba_pg_solve(stba_pg* g, const stba_lm_options* opt_in, const stba_pcg_opti
                 hipLaunchKernelGGL(pg_coarse_dc_kernel, dim3(g->na), dim3(256), 0, g->st, g->n, g->agg, g->AdP, g->d, g->Dc);
                 hipLaunchKernelGGL(pg_coarse_assemble_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, g->st, g->nc, g->np, g->Ac0, g->Dc, g->W);
             }
-            STBA_HIP(hipEventRecord(g->ev_in, g->st));
+            if (!head_was_done) STBA_HIP(hipEventRecord(g->ev_in, g->st));
             // THE JOB: ~ 30 launches on the second stream.  Enqueueing them takes the HOST ~ 250 us -- so when this iteration does not
             // wait for them (the usual case), the PCG kernel is launched FIRST and the job is enqueued while it runs: with the job in
             // front, the kernel timeline showed the first stream idle for 277 us of every 760 us iteration, waiting for the host
             // (profiles/r6_c4_iter_trace.txt)
-            job = [=]() -> int {
-                STBA_HIP(hipStreamWaitEvent(g->st2, g->ev_in, 0));
-                if (build_on_st2) {
-                    // one rank: everything the inverse needs is made on the second stream -- coarse matrix (from the blocks, the
-                    // diagonal blocks and the basis of THIS linearisation), its damping term, the workspace; READ_k tells the first
-                    // stream when its next linearisation / preconditioner kernel may overwrite those inputs
-                    if (!g->ac0_valid) {
-                        hipLaunchKernelGGL(pg_coarse_build_kernel, dim3(g->na), dim3(256), (size_t)6 * g->nc * sizeof(double) + (size_t)4 * g->max_group_ends * sizeof(int), g->st2, g->n, g->agg, g->nc,
-                                           1, g->node_start, g->end_node, g->end_rem, g->Bend, g->Hd, g->AdP, g->Ac0);
-                        g->ac0_valid = true;
-                    }
-                    hipLaunchKernelGGL(pg_coarse_dc_kernel, dim3(g->na), dim3(256), 0, g->st2, g->n, g->agg, g->AdP, g->d, g->Dc);
-                    hipLaunchKernelGGL(pg_coarse_assemble_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, g->st2, g->nc, g->np, g->Ac0, g->Dc, g->W);
-                    STBA_HIP(hipEventRecord(g->ev_read, g->st2));
-                    g->job_reads_pending = true;
-                }
+            job = [=, &job_head]() -> int {
+                if (!head_was_done) { if (build_on_st2) STBA_TRY(job_head()); else STBA_HIP(hipStreamWaitEvent(g->st2, g->ev_in, 0)); }
                 STBA_TRY(chol_spd_inverse_dev(g->W, 2 * g->np, g->np, g->nc, g->cflag, g->inv_work, g->st2));
                 hipLaunchKernelGGL(pg_coarse_finish_kernel, dim3((unsigned)(((size_t)g->nc * g->nc + 255) / 256)), dim3(256), 0, g->st2, g->nc, g->np, g->W, Aw,
                                    g->cflag, g->cflag + 1);
@@ -2066,6 +2089,14 @@ int stba_pg_solve(stba_pg* g, const stba_lm_options* opt_in, const stba_pcg_opti
             decrease = 2.0;
             double c2, g2_new = 0.0;
             STBA_TRY(linearize_enqueue());
+            if (async_inv && build_on_st2) {        // the next iteration's preconditioner kernel and the head of its job, at once (job_head)
+                hipLaunchKernelGGL(pg_precond_kernel, dim3(g->nb_nodes), dim3(256), 0, g->st, g->n, g->Hd, g->scale, scale_init ? 0 : 1,
+                                   opt.jacobi_scaling, radius, opt.min_lm_diagonal, opt.max_lm_diagonal, g->fixed, g->d, g->Minv);
+                scale_init = true;
+                STBA_HIP(hipEventRecord(g->ev_in, g->st));
+                STBA_TRY(job_head());
+                head_done = true;
+            }
             STBA_TRY(linearize_finish(&c2, &gmax, &g2_new));
             cost = c2;
             // forcing sequence (Eisenstat & Walker, choice 2): eta_{k+1} = 0.9 (|g_{k+1}| / |g_k|)^2 with their safeguard, kept in
