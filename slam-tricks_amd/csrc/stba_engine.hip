@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <memory>
 #include <thread>
 #include <vector>
 
@@ -1264,7 +1265,10 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
     const int plan_mode = plan_stripes ? 0 : plan_knob;
     b->schur_plan_mode = plan_mode;
     std::vector<int> pair_begin, pair_end, task_vs_ptr, vs_first;
-    std::vector<int4> pair_rec;
+    // (not a std::vector: its resize() would write 72 MB of zeros at C5, on one thread, in front of the threads that fill it)
+    std::unique_ptr<int4[]> pair_rec;
+    size_t n_pair_rec = 0;
+    std::vector<size_t> diag_pairs_thr(64, 0);
     int max_slots = 0;
     if (build_pair_plan) {
         const int ntask = (int)task_cam.size();
@@ -1275,7 +1279,8 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
             cnt[(size_t)k + 1] = cnt[(size_t)k] + task_pairs[(size_t)k];
             task_vs_ptr[(size_t)k + 1] = task_vs_ptr[(size_t)k] + (task_col_hi[(size_t)k] - task_col_lo[(size_t)k]) + 1;
         }
-        pair_rec.resize(cnt[(size_t)ntask]);
+        n_pair_rec = cnt[(size_t)ntask];
+        pair_rec.reset(new int4[std::max<size_t>(n_pair_rec, 1)]);
         vs_first.assign((size_t)task_vs_ptr[(size_t)ntask], 0);
         std::vector<int> max_slots_thr(64, 0);
         host_parallel_for(ntask, [&](int k_lo, int k_hi, int tix) {
@@ -1401,6 +1406,7 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
                         const int q = sl - slo;
                         const int v = vsf[q] + w / (NW / nparts[(size_t)q]);
                         pair_rec[wpos[wave_of[(size_t)v]]++] = make_int4(i, l, j, v | (c2 == c ? 0x8000 : 0));
+                        if (c2 == c) ++diag_pairs_thr[(size_t)(tix & 63)];
                     }
                 }
             }
@@ -1410,8 +1416,10 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
     b->max_cols = std::max(task_max_cols, max_slots);       // accumulator slots of the largest task (blocks + extra parts)
     {   // LDS atomics of one launch: 36 per pair (21 in a diagonal block)
         double at = 0.0;
-        for (const int4& pr : pair_rec) at += (pr.w & 0x8000) ? 21.0 : 36.0;
-        b->schur_pairs = (double)pair_rec.size(); b->schur_lds_atomics = at;
+        size_t n_diag = 0;
+        for (size_t v : diag_pairs_thr) n_diag += v;
+        at = 36.0 * (double)(n_pair_rec - n_diag) + 21.0 * (double)n_diag;
+        b->schur_pairs = (double)n_pair_rec; b->schur_lds_atomics = at;
     }
     // landmark-range slices: where every task writes its partial blocks, and every row's tasks in list order (the order of the sum)
     std::vector<long long> task_part_off;
@@ -1460,7 +1468,7 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
     A_(dev_alloc(&b->task_col_lo, std::max<size_t>(task_cam.size(), 1))); A_(dev_alloc(&b->task_col_hi, std::max<size_t>(task_cam.size(), 1)));
     A_(dev_alloc(&b->row_col_ptr, nc + 1)); A_(dev_alloc(&b->row_cols, std::max<size_t>(row_cols.size(), 1)));
     A_(dev_alloc(&b->pair_begin, std::max<size_t>(pair_begin.size(), 1))); A_(dev_alloc(&b->pair_end, std::max<size_t>(pair_end.size(), 1)));
-    A_(dev_alloc(&b->pair_rec, std::max<size_t>(pair_rec.size(), 1)));
+    A_(dev_alloc(&b->pair_rec, std::max<size_t>(n_pair_rec, 1)));
     A_(dev_alloc(&b->task_vs_ptr, std::max<size_t>(task_vs_ptr.size(), 1))); A_(dev_alloc(&b->vs_first, std::max<size_t>(vs_first.size(), 1)));
     if (cam_fixed) A_(dev_alloc(&b->cam_fixed, nc));
     if (pt_fixed) A_(dev_alloc(&b->pt_fixed, np));
@@ -1502,7 +1510,7 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
     A_(upload(b->row_col_ptr, row_col_ptr.data(), nc + 1, b->st));
     if (!row_cols.empty()) A_(upload(b->row_cols, row_cols.data(), row_cols.size(), b->st));
     A_(upload(b->pair_begin, pair_begin.data(), pair_begin.size(), b->st)); A_(upload(b->pair_end, pair_end.data(), pair_end.size(), b->st));
-    if (!pair_rec.empty()) A_(upload(b->pair_rec, pair_rec.data(), pair_rec.size(), b->st));
+    if (n_pair_rec > 0) A_(upload(b->pair_rec, pair_rec.get(), n_pair_rec, b->st));
     A_(upload(b->task_vs_ptr, task_vs_ptr.data(), task_vs_ptr.size(), b->st)); A_(upload(b->vs_first, vs_first.data(), vs_first.size(), b->st));
     if (cam_fixed) A_(upload(b->cam_fixed, cmask.data(), nc, b->st));
     std::vector<unsigned char> omask;
