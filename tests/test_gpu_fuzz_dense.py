@@ -117,3 +117,29 @@ def test_random_size_cholesky_against_lapack(st, k):
         with pytest.raises(st.StbaError) as e:
             st.cholesky_solve(A2, b)
         assert e.value.code == -4
+
+
+def test_small_dense_path_with_a_slow_callback_and_a_change_of_size(st, O):
+    """round 6: up to 32 unknowns the device side of a dense LM step is one kernel launch from a POOLED workspace (small_dense.hip).
+    A callback that takes seconds changes nothing, and solves of different sizes back to back reuse the workspace without seeing each
+    other's state.  (A variant in which one kernel SERVED the whole solve -- commands and answers through mapped host memory -- was
+    built, passed this test, and was slower: 0.187 / 0.178 / 0.226 ms per PnP Solve() against 0.169 / 0.162 / 0.205; a device that polls
+    host memory and reads the Jacobian with system-scope loads loses more than the launches cost.  tools/exp/small_dense_server_kernel.patch)"""
+    import time
+    kind, res, x0, m, _ = _problem(2)            # "poly": Vandermonde Jacobian
+    calls = {"n": 0}
+
+    def slow(p):
+        calls["n"] += 1
+        if calls["n"] == 3:
+            time.sleep(2.6)
+        return res(p)
+    p, summ, tr = st.dense_solve(slow, x0, m, max_num_iterations=100)
+    po, so, tro = O.dense_lm(res, x0, m, max_num_iterations=100)
+    assert summ.termination_type == so.termination_type and summ.num_iterations == so.num_iterations
+    assert np.allclose(tr[:, 0], tro[:, 0], rtol=1e-7, atol=1e-22) and np.allclose(p, po, rtol=1e-8, atol=1e-10)
+    for k in (4, 0, 3, 1):                        # circle (3 unknowns), linear (any), rosenbrock, exp: sizes change from solve to solve
+        kind, res2, x2, m2, _ = _problem(k)
+        p2, s2, t2 = st.dense_solve(res2, x2, m2, max_num_iterations=100)
+        po2, so2, to2 = O.dense_lm(res2, x2, m2, max_num_iterations=100)
+        assert s2.num_iterations == so2.num_iterations and np.allclose(p2, po2, rtol=1e-8, atol=1e-10), kind

@@ -16,7 +16,7 @@ if [ "$2" != "nopmc" ]; then
 fi
 python $R/bench.py > $O/${TAG}_bench_full.json 2> $O/${TAG}_bench_full.err
 P=/tmp/prof_$TAG; rm -rf $P; mkdir -p $P
-(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $P -- python $R/bench.py --steps 20 --reps 2 --warmup 2 --no-cpu-baseline --no-library-baseline > $P/bench.json 2> $P/bench.err)
+(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $P -- python $R/bench.py --steps 20 --reps 2 --warmup 2 --no-cpu-baseline --no-library-baseline --no-drop-in > $P/bench.json 2> $P/bench.err)
 find $P -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/${TAG}_kernel_stats.csv
 bash $R/tools/gpu_iter_trace.sh > $O/${TAG}_iter_trace.txt 2>&1
 bash $R/tools/gpu_c4.sh $TAG > $O/${TAG}_c4.log 2>&1
