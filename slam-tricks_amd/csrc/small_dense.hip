@@ -129,7 +129,7 @@ __global__ __launch_bounds__(SD_THREADS) void dense_small_step_kernel(SmallStepA
         if (lane < n) { a.out[lane] = b; a.out[n + lane] = gs[lane]; }
         if (lane == 0) { a.out[2 * n] = m; a.out[2 * n + 1] = (double)bad_pivot; }
         __threadfence_system();
-        if (lane == 0) { a.out[2 * n + 2] = a.stamp; __threadfence_system(); }
+        if (lane == 0) a.out[2 * n + 2] = a.stamp;       // (the kernel's end publishes it: a second fence here was 2 us of every 15 us step)
     }
 }
 
