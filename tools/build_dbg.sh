@@ -6,7 +6,7 @@ R=$(cd $(dirname $0)/.. && pwd)
 mkdir -p $R/tmp_libs/obj_$NAME
 FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -munsafe-fp-atomics -Wno-unused-function -Wno-unused-result -DSTBA_DEBUG_KNOBS $@"
 pids=""
-for s in dense_chol.hip ba_kernels.hip stba_engine.hip pg_engine.hip two_view.hip calib_io.cpp comm.cpp; do
+for s in dense_chol.hip ba_kernels.hip stba_engine.hip pg_engine.hip small_dense.hip two_view.hip calib_io.cpp comm.cpp; do
   o=$R/tmp_libs/obj_$NAME/${s%.*}.o
   /opt/rocm/bin/hipcc $FLAGS -c $R/slam-tricks_amd/csrc/$s -o $o & pids="$pids $!"
 done
