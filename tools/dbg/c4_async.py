@@ -26,7 +26,8 @@ sx, trx, nx = e.solve(pcg=e.pcg_options(forcing_eta0=0.0, relative_tolerance=1e-
 px = e.get_poses()
 print("exact steps: it %d pcg %d cost %.12g dist-to-gold %.2e" % (sx.num_iterations, nx, sx.final_cost, pdiff(px[::50], gp)))
 verbose = "-v" in sys.argv
-for name, kw in (("inline", dict(coarse_async=0)), ("default", dict()),
+for name, kw in (("inline", dict(coarse_async=0)), ("default", dict()), ("no speculation", dict(speculative_trial=0)), ("default", dict()),
+                 ("no speculation", dict(speculative_trial=0)),
                  ("decrease 0.3", dict(coarse_async_decrease=0.3)), ("decrease 0.9", dict(coarse_async_decrease=0.9)),
                  ("always", dict(coarse_async_decrease=1.0)), ("mode 2", dict(coarse_async=2)),
                  ("fences", dict(one_kernel_solve=3))):
