@@ -719,7 +719,6 @@ __global__ __launch_bounds__(SCHUR_THREADS, GEN ? 2 : 4) void ba_schur_pairs_ker
     const int kb = a.pair_begin[ent], ke = a.pair_end[ent];
     const int ntrips = (ke - kb + stride - 1) / stride;
     int* turn = vsf + a.max_cols + 1;
-    const int rot = tid % ROTS;
     // (the pair record runs one trip ahead: one dependent memory round trip less per trip)
     int k = kb + (mode == 0 ? (tid & 63) : tid);
     int4 rn = (k < ke) ? a.pair_rec[k] : make_int4(0, 0, 0, 0);
@@ -738,6 +737,7 @@ __global__ __launch_bounds__(SCHUR_THREADS, GEN ? 2 : 4) void ba_schur_pairs_ker
         load_jc_jp<GEN>(a.J8, a.omask, rc.x, jc, jp, a.Jc12);
         load_jc_jp<GEN>(a.J8, a.omask, rc.y, jc2, jp2, a.Jc12);
         const unsigned sl = (unsigned)rc.w;
+        const int rot = (int)((sl >> 16) & 7u);          // the column this lane starts at: dealt by the host (stba_ba_create), 0 .. ROTS - 1
         // E_i = (Jc_i^T Jp_i) Hinv_j recomputed per pair (cheaper than a pre-pass that stores it)
         double E[18];
 #pragma unroll

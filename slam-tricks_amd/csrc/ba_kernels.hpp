@@ -59,7 +59,7 @@ constexpr int SCHUR_TASK_PAIRS = 1 << 30;
 // the kernel was bound by them)
 constexpr int SCHUR_BLK_LD = 37;
 constexpr int SCHUR_CAM_LD = 56;      // per wave of a diagonal slice: 21 + 6 sums of the camera block, 21 + 6 of the pairs (i, i), padded
-constexpr int SCHUR_ROTS = 3;        // column rotations of the Schur kernel's lanes (lane mod SCHUR_ROTS), see its pair loop
+constexpr int SCHUR_ROTS = 6;        // column rotations of the Schur kernel's lanes (dealt per pair by the host: bits 16..18 of the record), see its pair loop
 constexpr int SCHUR_THREADS = 512;    // 8 waves per task, two tasks per CU: 16 waves hide the L2 gathers
 struct SchurArgs {
     const int* task_cam; const int* cam_start;       // camera row of the task; the camera's range of cam_perm

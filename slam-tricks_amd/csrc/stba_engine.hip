@@ -1262,6 +1262,7 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
     const int plan_knob = std::min(3, std::max(0, knob_int("STBA_SCHUR_PLAN", SCHUR_PLAN_DEFAULT)));
     const bool plan_stripes = plan_knob == 3;
     const bool plan_runs = knob_int("STBA_SCHUR_RUNS", 1) != 0;
+    const bool rot_by_rank = knob_int("STBA_SCHUR_ROT_RANK", 1) != 0;
     const int plan_mode = plan_stripes ? 0 : plan_knob;
     b->schur_plan_mode = plan_mode;
     std::vector<int> pair_begin, pair_end, task_vs_ptr, vs_first;
@@ -1285,7 +1286,7 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
         std::vector<int> max_slots_thr(64, 0);
         host_parallel_for(ntask, [&](int k_lo, int k_hi, int tix) {
             std::vector<int> slot_of((size_t)n_cams, 0);
-            std::vector<int> nparts, wave_of, order, cntR, bcl;
+            std::vector<int> nparts, wave_of, order, cntR, bcl, rank_of;
             std::vector<unsigned char> range_of;
             const bool lm = b->lm_slices;
             for (int k = k_lo; k < k_hi; ++k) {
@@ -1407,6 +1408,29 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
                         const int v = vsf[q] + w / (NW / nparts[(size_t)q]);
                         pair_rec[wpos[wave_of[(size_t)v]]++] = make_int4(i, l, j, v | (c2 == c ? 0x8000 : 0));
                         if (c2 == c) ++diag_pairs_thr[(size_t)(tix & 63)];
+                    }
+                }
+                // ---- the COLUMN ROTATION of every pair (bits 16..18 of its fourth word).  The 64 pairs of one wave instruction that add
+                // to the SAME block are served one after the other by ds_add_f64 unless they meet in different addresses: the kernel
+                // lets a lane walk the six columns of its block starting at column `rotation`.  Round 6: the rotation is the pair's RANK
+                // among the pairs of its trip that share its accumulator slot (mod 6) -- the host knows who meets whom.  Until then
+                // it was lane mod 3, which does nothing where a landmark has 9 or 12 partners: the lanes that meet -- the same partner
+                // camera, consecutive landmarks -- are then 9 or 12 lanes apart.
+                {
+                    rank_of.assign((size_t)nvs, 0);
+                    const size_t t_lo = cnt[(size_t)k], t_hi = cnt[(size_t)k + 1];
+                    for (int w2 = 0; w2 < NW; ++w2) {
+                        const size_t lb = (size_t)pair_begin[(size_t)k * NW + w2], le = (size_t)pair_end[(size_t)k * NW + w2];
+                        (void)t_lo; (void)t_hi;
+                        for (size_t x0 = lb; x0 < le; x0 += 64) {
+                            const size_t x1 = std::min(le, x0 + 64);
+                            for (size_t x = x0; x < x1; ++x) {
+                                const int v = pair_rec[x].w & 0x3fff;
+                                const int rot = rot_by_rank ? rank_of[(size_t)v]++ % 6 : 2 * (int)((x - x0) % 3);
+                                pair_rec[x].w |= rot << 16;
+                            }
+                            if (rot_by_rank) for (size_t x = x0; x < x1; ++x) rank_of[(size_t)(pair_rec[x].w & 0x3fff)] = 0;
+                        }
                     }
                 }
             }
