@@ -755,10 +755,11 @@ __global__ __launch_bounds__(SCHUR_THREADS, GEN ? 2 : 4) void ba_schur_pairs_ker
             while (__hip_atomic_load(turn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != want) __builtin_amdgcn_s_sleep(1);
         }
         if (valid) {
-        // The lanes of a wave walk the six columns of their blocks in ROTS different rotations (lane mod ROTS): the pairs of
-        // one wave hit the same block again and again -- the cameras next to c share most of its landmarks: 25 of 64 lanes
-        // share their block with an earlier lane, the busiest block of a wave has 7 -- and lanes that add to the SAME
-        // address in the same instruction are served one after the other.  With the rotation they meet in different columns.
+        // The lanes of a wave walk the six columns of their blocks in ROTS different rotations: the pairs of one wave hit the same
+        // block again and again -- the cameras next to c share most of its landmarks: 25 of 64 lanes share their block with an
+        // earlier lane, the busiest block of a wave has 7 -- and lanes that add to the SAME address in the same instruction are
+        // served one after the other.  With the rotation they meet in different columns.  The rotation comes with the record:
+        // the host deals it as the pair's rank among the pairs of its trip that share its slot (round 6; lane mod 3 until then).
 #pragma unroll
         for (int s2 = 0; s2 < 6; ++s2) {
             double ja = jc2[s2], jb = jc2[6 + s2];
