@@ -25,6 +25,7 @@ namespace stba {
 namespace {
 
 constexpr int SD_THREADS = 256;
+constexpr int SD_STAMP_AT = 2 * SMALL_DENSE_MAX_N + 2;
 constexpr int SD_STAGE_DOUBLES = 5632;     // J and r staged in LDS when n_res * (n + 1) fits (44 KB); device scratch otherwise
 
 struct SmallStepArgs {
@@ -34,7 +35,7 @@ struct SmallStepArgs {
     double* H;             // device: n x n (kept between launches)
     double* g;             // device: n
     double* scale;         // device: n (Jacobi scaling, fixed at the first linearisation)
-    double* out;           // mapped host: [0, n) dx | [n, 2n) g | [2n] model cost change | [2n + 1] pivot flag | [2n + 2] stamp
+    double* out;           // mapped host: [0, n) dx | [n, 2n) g | [2n] model cost change | [2n + 1] pivot flag | [SD_STAMP_AT] stamp (a fixed place: the workspace is reused with other n)
     int n_res, n, relinearize, first, jacobi;
     double radius, dmin, dmax, stamp;
 };
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(SD_THREADS) void dense_small_step_kernel(SmallStepA
         if (lane < n) { a.out[lane] = b; a.out[n + lane] = gs[lane]; }
         if (lane == 0) { a.out[2 * n] = m; a.out[2 * n + 1] = (double)bad_pivot; }
         __threadfence_system();
-        if (lane == 0) a.out[2 * n + 2] = a.stamp;       // (the kernel's end publishes it: a second fence here was 2 us of every 15 us step)
+        if (lane == 0) a.out[SD_STAMP_AT] = a.stamp;       // (the kernel's end publishes it: a second fence here was 2 us of every 15 us step)
     }
 }
 
@@ -223,14 +224,14 @@ int small_dense_step(SmallDenseWs* w, int n_res, int n, bool relinearize, bool f
     STBA_HIP(hipGetLastError());
     volatile double* h = w->hout;
     const double t0 = wall_now();
-    for (unsigned long spin = 1; h[2 * n + 2] != a.stamp; ++spin) {
+    for (unsigned long spin = 1; h[SD_STAMP_AT] != a.stamp; ++spin) {
         if ((spin & 0xfff) == 0) {
             const hipError_t q = hipStreamQuery(w->st);
             if (q != hipSuccess && q != hipErrorNotReady) return fail(STBA_ERR_HIP, std::string("small dense step: ") + hipGetErrorString(q));
-            if (q == hipSuccess && h[2 * n + 2] != a.stamp) {
+            if (q == hipSuccess && h[SD_STAMP_AT] != a.stamp) {
                 // the kernel is done and its stamp has not been seen: one synchronise settles what the host may read
                 STBA_HIP(hipStreamSynchronize(w->st));
-                if (h[2 * n + 2] != a.stamp) return fail(STBA_ERR_HIP, "small dense step: the result never arrived in mapped host memory");
+                if (h[SD_STAMP_AT] != a.stamp) return fail(STBA_ERR_HIP, "small dense step: the result never arrived in mapped host memory");
             }
             if (wall_now() - t0 > 60.0) return fail(STBA_ERR_HIP, "small dense step: timed out");
         }
