@@ -794,9 +794,13 @@ def main():
                      "algorithmic_flops_per_launch": chol_flops, "launches_per_lm_iteration": 1,
                      "microbench_ceiling": FP64_MFMA_MEASURED_CEILING_TFLOPS,
                      "frac_of_microbench_ceiling": chol_tflops / FP64_MFMA_MEASURED_CEILING_TFLOPS}
-        # the Schur-complement kernel: bound by LDS FP64 atomics (ds_add_f64 into the 6x6 accumulator blocks of a camera
-        # row).  Peak = what the microbenchmark retires with THIS address pattern (random block per lane, 36 consecutive
-        # doubles, 37-double block stride): profiles/lds_atomic_f64_microbench.txt, 2.38 lane-ops per cycle and CU
+        # the Schur-complement kernel.  Round 6 settled what bounds it: with the LDS-atomic collisions dealt away by the host it gains
+        # 1-3 %, without atomics at all (register sums per block run) it LOSES 37 % on the landmark-heavy scene -- it is bound by what
+        # it gathers (profiles/r6_schur_rot_rank.txt, r6_landmark_range_slices_register_runs.txt).  Algorithmic bytes per launch: per
+        # pair a 16 B plan record, two 64 B Jacobian records and the 48 B inverse landmark block; the zero fill of the lower triangle
+        # of S up to the diagonal tiles; one 288 B store per pair-carrying block is inside the zero fill's footprint and not counted twice.
+        # The LDS-atomic rate is kept as a second figure (peak = the microbenchmark's rate with THIS address pattern,
+        # profiles/lds_atomic_f64_microbench.txt, 2.38 lane-ops per cycle and CU).
         ms_schur, schur_atomics, schur_pairs = eng.time_schur(10)
         pk_path, pk = pmc_file("assembly_kernels")
         schur_traffic = None
@@ -805,15 +809,20 @@ def main():
                 if "schur_pairs" in kname and "hbm_bytes_per_launch_raw" in kd:
                     schur_traffic = kd["hbm_bytes_per_launch_raw"]
         LDS_ATOMIC_PEAK = 1459.2      # G lane-ops/s, all 256 CUs, Schur pattern (7.5 per cycle and CU without conflicts: 4617 G/s)
+        lda_s = ((nred + 1 + 127) // 128) * 128
+        zero_bytes = sum(6 * min(lda_s, ((6 * c + 5) // 128 + 1) * 128) * 8 for c in range(n_cams))
+        schur_bytes = 192.0 * schur_pairs + zero_bytes
+        schur_gbs = schur_bytes / (ms_schur * 1e-3) / 1e9
         out["roofline_schur"] = {"kernel": "ba_schur_pairs_kernel (row-wise Schur complement, LDS accumulation; camera blocks on the way)",
-                                 "bound": "lds-atomic", "achieved": schur_atomics / (ms_schur * 1e-3) / 1e9, "peak": LDS_ATOMIC_PEAK,
-                                 "unit": "G ds_add_f64 lane-ops/s", "frac": schur_atomics / (ms_schur * 1e-3) / 1e9 / LDS_ATOMIC_PEAK,
-                                 "ms_per_launch": ms_schur, "lds_atomics_per_launch": schur_atomics, "pairs_per_launch": schur_pairs,
-                                 "floor_ms": schur_atomics / (LDS_ATOMIC_PEAK * 1e9) * 1e3,
+                                 "bound": "hbm", "achieved": schur_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": schur_gbs / HBM_PEAK_GBS,
+                                 "algorithmic_bytes_per_launch": schur_bytes, "bytes_per_pair": 192, "zero_fill_bytes": zero_bytes,
+                                 "ms_per_launch": ms_schur, "pairs_per_launch": schur_pairs,
+                                 "lds_atomic": {"achieved": schur_atomics / (ms_schur * 1e-3) / 1e9, "peak": LDS_ATOMIC_PEAK, "unit": "G ds_add_f64 lane-ops/s",
+                                                "frac": schur_atomics / (ms_schur * 1e-3) / 1e9 / LDS_ATOMIC_PEAK, "per_launch": schur_atomics,
+                                                "floor_ms": schur_atomics / (LDS_ATOMIC_PEAK * 1e9) * 1e3},
                                  "traffic": schur_traffic,
                                  "traffic_source": traffic_source(pk_path, pk, "FETCH_SIZE + WRITE_SIZE per launch at C5, RAW (the pair loop gathers 64-B records: "
-                                                                  "narrow requests, not the wide coalesced reads the gfx950 doubling is for); the second bound of the "
-                                                                  "kernel: 65 MB of Jacobian records are fetched several times over by the pair loop")}
+                                                                  "narrow requests, not the wide coalesced reads the gfx950 doubling is for)")}
         if eng.schur_mode() == eng.SCHUR_DENSE:
             # dense visibility: S = -(Y Y^T) on the matrix cores; algorithmic flops of the lower triangle: n^2 / 2 entries x K x 2
             n_local_pts = len(sh["pts0"])
