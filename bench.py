@@ -796,9 +796,7 @@ def main():
                      "frac_of_microbench_ceiling": chol_tflops / FP64_MFMA_MEASURED_CEILING_TFLOPS}
         # the Schur-complement kernel.  Round 6 settled what bounds it: with the LDS-atomic collisions dealt away by the host it gains
         # 1-3 %, without atomics at all (register sums per block run) it LOSES 37 % on the landmark-heavy scene -- it is bound by what
-        # it gathers (profiles/r6_schur_rot_rank.txt, r6_landmark_range_slices_register_runs.txt).  Algorithmic bytes per launch: per
-        # pair a 16 B plan record, two 64 B Jacobian records and the 48 B inverse landmark block; the zero fill of the lower triangle
-        # of S up to the diagonal tiles; one 288 B store per pair-carrying block is inside the zero fill's footprint and not counted twice.
+        # it gathers (profiles/r6_schur_rot_rank.txt, r6_landmark_range_slices_register_runs.txt).
         # The LDS-atomic rate is kept as a second figure (peak = the microbenchmark's rate with THIS address pattern,
         # profiles/lds_atomic_f64_microbench.txt, 2.38 lane-ops per cycle and CU).
         ms_schur, schur_atomics, schur_pairs = eng.time_schur(10)
@@ -811,11 +809,20 @@ def main():
         LDS_ATOMIC_PEAK = 1459.2      # G lane-ops/s, all 256 CUs, Schur pattern (7.5 per cycle and CU without conflicts: 4617 G/s)
         lda_s = ((nred + 1 + 127) // 128) * 128
         zero_bytes = sum(6 * min(lda_s, ((6 * c + 5) // 128 + 1) * 128) * 8 for c in range(n_cams))
-        schur_bytes = 192.0 * schur_pairs + zero_bytes
+        # ALGORITHMIC bytes = everything the step must touch, once: the observations' 64 B Jacobian records, the landmarks' 48 B inverse
+        # blocks, the 16 B plan record of every pair, the lower triangle of S written once (zeros included).  What the pair formulation
+        # GATHERS is several times that (every pair asks for two records and a block again: 192 B per pair) -- reported beside it.
+        n_local_pts_s = len(sh["pts0"])
+        schur_bytes = 64.0 * local_obs + 48.0 * n_local_pts_s + 16.0 * schur_pairs + zero_bytes
+        gathered_bytes = 192.0 * schur_pairs + zero_bytes
         schur_gbs = schur_bytes / (ms_schur * 1e-3) / 1e9
         out["roofline_schur"] = {"kernel": "ba_schur_pairs_kernel (row-wise Schur complement, LDS accumulation; camera blocks on the way)",
                                  "bound": "hbm", "achieved": schur_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": schur_gbs / HBM_PEAK_GBS,
-                                 "algorithmic_bytes_per_launch": schur_bytes, "bytes_per_pair": 192, "zero_fill_bytes": zero_bytes,
+                                 "algorithmic_bytes_per_launch": schur_bytes, "zero_fill_bytes": zero_bytes,
+                                 "gathered": {"bytes_per_launch": gathered_bytes, "bytes_per_pair": 192, "GB/s": gathered_bytes / (ms_schur * 1e-3) / 1e9,
+                                              "frac": gathered_bytes / (ms_schur * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                              "what": "what the pair loop asks for (two 64 B records, a 48 B block and a 16 B plan record per pair) + the zero fill: "
+                                                      "the caches serve part of it, the counter traffic is what reached the fabric"},
                                  "ms_per_launch": ms_schur, "pairs_per_launch": schur_pairs,
                                  "lds_atomic": {"achieved": schur_atomics / (ms_schur * 1e-3) / 1e9, "peak": LDS_ATOMIC_PEAK, "unit": "G ds_add_f64 lane-ops/s",
                                                 "frac": schur_atomics / (ms_schur * 1e-3) / 1e9 / LDS_ATOMIC_PEAK, "per_launch": schur_atomics,
