@@ -732,10 +732,15 @@ __global__ __launch_bounds__(SCHUR_THREADS, GEN ? 2 : 4) void ba_schur_pairs_ker
             // (the gathers below are requested first: the wait for the token hides behind them only if they are in flight)
         }
         double Hi[6], jc[12], jp[6], jc2[12], jp2[6];
+#ifdef STBA_DEBUG_KNOBS
+        const int gi = (a.ablate & 1) ? (rc.x & 63) : rc.x, gl = (a.ablate & 1) ? (rc.y & 63) : rc.y, gz = (a.ablate & 1) ? (rc.z & 63) : rc.z;
+#else
+        const int gi = rc.x, gl = rc.y, gz = rc.z;
+#endif
 #pragma unroll
-        for (int k2 = 0; k2 < 6; ++k2) Hi[k2] = a.Hinv6[(size_t)rc.z * 6 + k2];
-        load_jc_jp<GEN>(a.J8, a.omask, rc.x, jc, jp, a.Jc12);
-        load_jc_jp<GEN>(a.J8, a.omask, rc.y, jc2, jp2, a.Jc12);
+        for (int k2 = 0; k2 < 6; ++k2) Hi[k2] = a.Hinv6[(size_t)gz * 6 + k2];
+        load_jc_jp<GEN>(a.J8, a.omask, gi, jc, jp, a.Jc12);
+        load_jc_jp<GEN>(a.J8, a.omask, gl, jc2, jp2, a.Jc12);
         const unsigned sl = (unsigned)rc.w;
         const int rot = (int)((sl >> 16) & 7u);          // the column this lane starts at: dealt by the host (stba_ba_create), 0 .. ROTS - 1
         // E_i = (Jc_i^T Jp_i) Hinv_j recomputed per pair (cheaper than a pre-pass that stores it)
@@ -776,6 +781,14 @@ __global__ __launch_bounds__(SCHUR_THREADS, GEN ? 2 : 4) void ba_schur_pairs_ker
             // (no tests for zero contributions of constant dofs: adding a zero is harmless)
             // (every entry, also the upper triangle of a diagonal block, which the write-out never reads -- pairs in the
             // diagonal block are the rare (i, l != i) of one camera, and a test per atomic costs an exec-mask branch each)
+#ifdef STBA_DEBUG_KNOBS
+            if (a.ablate & 2) {
+                double sacc = 0.0;
+#pragma unroll
+                for (int q = 0; q < 6; ++q) sacc += E[q * 3] * w0 + E[q * 3 + 1] * w1 + E[q * 3 + 2] * w2;
+                if (sacc == 1.2345e300) unsafeAtomicAdd(&col[0], sacc);
+            } else
+#endif
 #pragma unroll
             for (int q = 0; q < 6; ++q)
                 unsafeAtomicAdd(&col[q * 6], -(E[q * 3] * w0 + E[q * 3 + 1] * w1 + E[q * 3 + 2] * w2));

@@ -83,6 +83,7 @@ struct SchurArgs {
     // blocks [ncols * 36 | rhs 6 (+2) | camera sums 27 ...], and every row's tasks in the order ba_schur_reduce_slices_kernel adds them
     const int* task_p_lo = nullptr; const int* task_p_hi = nullptr; const long long* task_part_off = nullptr; double* part = nullptr;
     const int* row_task_ptr = nullptr; const int* row_tasks = nullptr; int n_cams = 0;
+    int ablate = 0;
 };
 // the Schur complement for dense visibility as a symmetric rank-k product (ba_kernels.hip, "DENSE visibility")
 struct SchurDenseArgs {

@@ -416,6 +416,7 @@ static int ba_schur_step(stba_ba* b) {
         sa.task_p_lo = b->task_p_lo; sa.task_p_hi = b->task_p_hi; sa.task_part_off = b->task_part_off; sa.part = b->schur_part;
         sa.row_task_ptr = b->row_task_ptr; sa.row_tasks = b->row_tasks; sa.n_cams = b->nc;
     }
+    sa.ablate = knob_int("STBA_SCHUR_ABLATE", 0);
     return launch_schur_rows(sa, b->n_tasks, b->st);
 }
 
