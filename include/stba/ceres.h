@@ -144,8 +144,10 @@ protected:
     std::vector<int>* mutable_parameter_block_sizes() { return &parameter_block_sizes_; }
     void set_num_residuals(int n) { num_residuals_ = n; }
 private:
+    friend class Problem;
     std::vector<int> parameter_block_sizes_;
     int num_residuals_ = 0;
+    bool owned_by_problem_ = false;      // set by the Problem that will delete it: a cost function shared by residual blocks is freed once
 };
 
 template <int kNumResiduals, int... Ns>
@@ -505,11 +507,7 @@ public:
     ~Problem() {
         // the reference never frees what it news (solver.hpp:104,258; test_ceres.h:56,106): the problem
         // owns cost functions and parameterisations, shared pointers are freed once.
-        if (options_.cost_function_ownership == TAKE_OWNERSHIP) {
-            std::sort(owned_costs_.begin(), owned_costs_.end());
-            owned_costs_.erase(std::unique(owned_costs_.begin(), owned_costs_.end()), owned_costs_.end());
-            for (auto* c : owned_costs_) delete c;
-        }
+        if (options_.cost_function_ownership == TAKE_OWNERSHIP) for (auto* c : owned_costs_) delete c;
         if (options_.local_parameterization_ownership == TAKE_OWNERSHIP) for (auto* l : owned_params_) delete l;
         if (options_.loss_function_ownership == TAKE_OWNERSHIP) for (auto* l : owned_losses_) delete l;
     }
@@ -537,7 +535,9 @@ public:
         r.blocks.pool = &block_pool_; r.blocks.off = (int)block_pool_.size(); r.blocks.n = (int)n_blocks;
         for (size_t i = 0; i < n_blocks; ++i) block_pool_.push_back(block(blocks[i], sizes[i]).index);
         residuals_.push_back(r);
-        owned_costs_.push_back(cost);
+        // (a cost function shared by several residual blocks is listed once: the mark lives in the cost function -- sorting 10^6
+        // pointers at destruction was a fifth of the destructor's time)
+        if (options_.cost_function_ownership == TAKE_OWNERSHIP && !cost->owned_by_problem_) { cost->owned_by_problem_ = true; owned_costs_.push_back(cost); }
         if (loss) { owned_losses_.insert(loss); ++num_loss_functions_; }
     }
     int NumLossFunctions() const { return num_loss_functions_; }   // residual blocks added with a non-null LossFunction (Solve refuses them)
@@ -592,7 +592,7 @@ private:
     std::vector<Residual> residuals_;
     std::vector<int> block_pool_;
     std::unordered_map<double*, int> index_;
-    std::vector<CostFunction*> owned_costs_;       // (with repeats: made unique when the problem is destroyed)
+    std::vector<CostFunction*> owned_costs_;       // (every cost function once: CostFunction::owned_by_problem_)
     int num_loss_functions_ = 0;
     std::set<LocalParameterization*> owned_params_;
     std::set<LossFunction*> owned_losses_;

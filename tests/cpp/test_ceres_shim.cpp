@@ -431,6 +431,32 @@ int main(int argc, char** argv) {
         ceres::Solver::Summary summary;
         ceres::Solve(options, &problem, &summary);
         std::printf("loss x %.17g term %d losses %d msg %s\n", x, (int)summary.termination_type, problem.NumLossFunctions(), summary.message.c_str());
+        // ownership: a cost function added to two residual blocks is deleted ONCE with the problem; one added to a problem that
+        // does not take ownership is left alone
+        static int deleted = 0;
+        struct Counted : ceres::SizedCostFunction<1, 1> {
+            ~Counted() override { ++deleted; }
+            bool Evaluate(double const* const* p, double* r, double** J) const override { r[0] = p[0][0]; if (J && J[0]) J[0][0] = 1.0; return true; }
+        };
+        double a = 1.0, b = 2.0;
+        {
+            ceres::Problem owner;
+            auto* shared = new Counted();
+            owner.AddResidualBlock(shared, nullptr, &a);
+            owner.AddResidualBlock(shared, nullptr, &b);
+            owner.AddResidualBlock(new Counted(), nullptr, &a);
+        }
+        const int after_owner = deleted;
+        Counted* kept = new Counted();
+        {
+            ceres::Problem::Options po;
+            po.cost_function_ownership = ceres::DO_NOT_TAKE_OWNERSHIP;
+            ceres::Problem borrower(po);
+            borrower.AddResidualBlock(kept, nullptr, &a);
+        }
+        const int after_borrower = deleted;
+        delete kept;
+        std::printf("ownership deleted_by_owner %d deleted_by_borrower %d\n", after_owner, after_borrower - after_owner);
         return 0;
     }
     // ---- "time_ba <scene> <max_iterations> <reps> [threads]": wall-clock of the reference's BA call site as the reference times it

@@ -74,6 +74,10 @@ def test_a_loss_function_is_refused_loudly(exe):
     toks = p.stdout.split()
     assert toks[0] == "loss" and float(toks[2]) == 0.5 and toks[4] == "2" and toks[6] == "1"
     assert "LossFunction" in p.stdout and "not implemented" in p.stdout and "LossFunction" in p.stderr
+    # ownership (the same run): a cost function shared by two residual blocks is deleted once with the problem that owns it
+    # (two cost functions -> two deletions), a problem that does not take ownership deletes nothing
+    own = [l for l in p.stdout.splitlines() if l.startswith("ownership")][0].split()
+    assert own[2] == "2" and own[4] == "0"
 
 
 def test_reference_ba_functor_is_recognised_on_the_host(exe, tmp_path, scenes):
