@@ -244,20 +244,20 @@ __global__ __launch_bounds__(256) void trial_finish_kernel(const double* __restr
         if (threadIdx.x < 7) res[threadIdx.x] = s[threadIdx.x][0];
         __syncthreads();
     }
+    __shared__ double hp[9];
     if (threadIdx.x < 8) {
         // block layout (stba_engine.hip, TS_*): [cost2, step2, x2, model | timed out | the three camera sums]; entry 4 = 1.0 if the
         // factorisation of this iteration timed out on this rank (CHOL_FLAG_TIMEOUT): it lies inside the prefix the ranks sum
         const int k = threadIdx.x;
         const double v = k < 4 ? res[k] : k == 4 ? ((flag[0] == CHOL_FLAG_TIMEOUT) ? 1.0 : 0.0) : res[k - 1];
         out[k] = v;
-        if (host_out) host_out[k] = v;
-    } else if (threadIdx.x == 8 && host_out) host_out[8] = (double)flag[0];
+        hp[k] = v;
+    } else if (threadIdx.x == 8) hp[8] = (double)flag[0];
     if (host_out) {
-        // the host polls host_out[9] (no event on the stream: an event record is ~5 us of idle GPU): the block first,
-        // system-wide, then the sequence number
-        __threadfence_system();
+        // the host polls the block (no event on the stream: an event record is ~5 us of idle GPU): the eight sums and the
+        // factorisation's flag as a STAMPED BLOCK, every 64-byte line with the sequence number and a check word of its own (common.hpp)
         __syncthreads();
-        if (threadIdx.x == 0) { host_out[9] = host_seq; __threadfence_system(); }
+        if (threadIdx.x < 64) stamped_store_wave(host_out, hp, 9, host_seq, threadIdx.x);
     }
 }
 

@@ -63,6 +63,75 @@ struct DeviceOnce {
     }
 };
 
+// ---- stamped blocks: a kernel hands a few doubles to the POLLING host through pinned, mapped host memory ------------------
+// (no event, no copy, no synchronise: an event record costs ~5 us of idle GPU, a copy ~30.)  The obvious protocol -- the payload,
+// __threadfence_system(), a sequence number behind it -- is NOT enough on this platform: MEASURED in round 6 (tools/dbg/tri_repeat.py,
+// profiles/r6_tri_repeat*.txt), the host saw the new sequence number and still read the OLD payload from ANOTHER cache line once in
+// ~50 000 hand-offs (600 tiny Solve() calls: 23 of 300 runs ended somewhere else; 0 of 300 with what follows), whatever fences the
+// kernel used.  So every 64-byte line validates ITSELF: six payload doubles, a CHECK word (a multiplicative hash of their bit patterns
+// and the stamp's -- not their xor: the old and the new payload of a line are related numbers, and equal changes in two words cancel
+// in an xor) and the stamp.  The host accepts a line only if its stamp is the one it waits for AND the check word fits what it has read;
+// a line caught half-written fails the check and is read again.  No assumption about the order or the atomicity of the device's stores.
+constexpr int STAMPED_PAYLOAD = 6;                       // payload doubles per 64-byte line
+constexpr unsigned long long STAMPED_SALT = 0x9E3779B97F4A7C15ull;
+__host__ __device__ inline unsigned long long stamped_mix(unsigned long long h, unsigned long long w) {
+    h = (h ^ w) * 0x100000001B3ull;          // (FNV-1a step on a 64-bit word, then the high bits folded down)
+    return h ^ (h >> 29);
+}
+__host__ __device__ inline int stamped_lines(int n_payload) { return (n_payload + STAMPED_PAYLOAD - 1) / STAMPED_PAYLOAD; }
+__host__ __device__ inline int stamped_doubles(int n_payload) { return 8 * stamped_lines(n_payload); }     // the block's size (64-byte aligned)
+#ifdef __HIPCC__
+__device__ inline double stamped_word(const double* src, int n_payload, double stamp, int l) {
+    const int line = l >> 3, w = l & 7;
+    if (w < STAMPED_PAYLOAD) { const int pi = line * STAMPED_PAYLOAD + w; return pi < n_payload ? src[pi] : 0.0; }
+    if (w == 7) return stamp;
+    unsigned long long chk = stamped_mix(STAMPED_SALT, (unsigned long long)__double_as_longlong(stamp));
+    for (int q = 0; q < STAMPED_PAYLOAD; ++q) {
+        const int pi = line * STAMPED_PAYLOAD + q;
+        chk = stamped_mix(chk, (unsigned long long)__double_as_longlong(pi < n_payload ? src[pi] : 0.0));
+    }
+    return __longlong_as_double((long long)chk);
+}
+// all 64 lanes of ONE wave (lane = 0 .. 63): a line is written by eight neighbouring lanes of one store instruction.
+// src: the payload where every lane can read it (LDS or global memory, complete before the call)
+__device__ inline void stamped_store_wave(double* out, const double* src, int n_payload, double stamp, int lane) {
+    const int total = stamped_doubles(n_payload);
+    for (int l = lane; l < total; l += 64) out[l] = stamped_word(src, n_payload, stamp, l);
+    __threadfence_system();
+}
+// ONE thread (a block of a line or two)
+__device__ inline void stamped_store_thread(double* out, const double* src, int n_payload, double stamp) {
+    const int total = stamped_doubles(n_payload);
+    for (int l = 0; l < total; ++l) out[l] = stamped_word(src, n_payload, stamp, l);
+    __threadfence_system();
+}
+#endif
+// host: one look at the block.  true: every line carries a stamp that `accept` takes (the same one in every line) and a fitting
+// check word; payload[0 .. n_payload) and *stamp_out are then what the device wrote for that stamp
+template <class Accept>
+inline bool stamped_try_read(const volatile double* in, int n_payload, Accept accept, double* payload, double* stamp_out = nullptr) {
+    const int nl = stamped_lines(n_payload);
+    double first_stamp = 0.0;
+    for (int L = 0; L < nl; ++L) {
+        unsigned long long w[8];
+        const volatile unsigned long long* src = reinterpret_cast<const volatile unsigned long long*>(in + 8 * L);
+        for (int q = 7; q >= 0; --q) w[q] = src[q];          // (the stamp first)
+        double st;
+        std::memcpy(&st, &w[7], sizeof st);
+        if (!accept(st) || (L > 0 && st != first_stamp)) return false;
+        first_stamp = st;
+        unsigned long long chk = stamped_mix(STAMPED_SALT, w[7]);
+        for (int q = 0; q < STAMPED_PAYLOAD; ++q) chk = stamped_mix(chk, w[q]);
+        if (chk != w[6]) return false;
+        for (int q = 0; q < STAMPED_PAYLOAD; ++q) {
+            const int pi = L * STAMPED_PAYLOAD + q;
+            if (pi < n_payload) std::memcpy(&payload[pi], &w[q], sizeof(double));
+        }
+    }
+    if (stamp_out) *stamp_out = first_stamp;
+    return true;
+}
+
 // ---- dense Cholesky on the device (dense_chol.hip) -----------------------------------------
 constexpr int CHOL_NB = 128;
 // padded order: multiple of CHOL_NB with at least one spare row (the last row carries the rhs)

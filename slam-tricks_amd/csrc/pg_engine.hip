@@ -163,10 +163,9 @@ struct PcgState {
     int iters, done, hit_cap, ticks;
 };
 // what the host polls (mapped, coherent host memory; written by workgroup 0 of the direction kernel, ticks last)
-struct PcgExport {
-    double rr0, rr;
-    int iters, done, hit_cap, ticks;
-};
+// what the launch-path PCG shows the polling host: a STAMPED block (common.hpp) of one line -- payload {rr0, rr, iters, done, hit_cap},
+// stamp = the tick count
+enum { PX_RR0 = 0, PX_RR = 1, PX_ITERS = 2, PX_DONE = 3, PX_HIT_CAP = 4, PX_COUNT = 5 };
 
 // ---------------------------------------------------------------- kernels
 __global__ __launch_bounds__(256) void pg_linearize_kernel(int n_edges, const double* __restrict__ poses,
@@ -833,7 +832,7 @@ __global__ __launch_bounds__(256) void pg_coarse_solve_kernel(int nc, int parts,
 // |r|^2 <= eta^2 |b|^2 (or the iteration cap) -- once `done` is set every later kernel of the solve returns at once, so the
 // host can enqueue iterations ahead of what it knows (it polls the exported block in mapped memory).
 __global__ __launch_bounds__(PG_NT) void pg_pcg_dir4_kernel(int n, int agg, int slot, int first, double eta, int max_iters, PcgState* __restrict__ state,
-                                                           PcgExport* __restrict__ exp_, int nb_rz, const double* __restrict__ part_rz, int nb_cz,
+                                                           double* __restrict__ exp_, int nb_rz, const double* __restrict__ part_rz, int nb_cz,
                                                            const double* __restrict__ part_cz, const double* __restrict__ AdP,
                                                            const double* __restrict__ zc, const double* __restrict__ z, const double* __restrict__ d,
                                                            double* __restrict__ p, double* __restrict__ part_dp) {
@@ -862,7 +861,10 @@ __global__ __launch_bounds__(PG_NT) void pg_pcg_dir4_kernel(int n, int agg, int 
         if (blockIdx.x == 0 && t == 0) {
             const int tk = state->ticks + 1;
             state->ticks = tk;
-            if (exp_) { __threadfence_system(); exp_->ticks = tk; __threadfence_system(); }
+            if (exp_) {        // (the same block again under the new tick)
+                const double px[PX_COUNT] = {state->rr0, state->rr, (double)state->iters, (double)state->done, (double)state->hit_cap};
+                stamped_store_thread(exp_, px, PX_COUNT, (double)tk);
+            }
         }
         return;
     }
@@ -896,10 +898,8 @@ __global__ __launch_bounds__(PG_NT) void pg_pcg_dir4_kernel(int n, int agg, int 
         state->rz[slot ^ 1] = rzn;
         state->rr0 = rr0; state->tol2 = tol2; state->rr = rr; state->iters = iters; state->done = done; state->hit_cap = cap; state->ticks = tk;
         if (exp_) {
-            exp_->rr0 = rr0; exp_->rr = rr; exp_->iters = iters; exp_->done = done; exp_->hit_cap = cap;
-            __threadfence_system();
-            exp_->ticks = tk;
-            __threadfence_system();
+            const double px[PX_COUNT] = {rr0, rr, (double)iters, (double)done, (double)cap};
+            stamped_store_thread(exp_, px, PX_COUNT, (double)tk);
         }
     }
 }
@@ -1245,13 +1245,13 @@ __global__ __launch_bounds__(256) void pg_trial_finish_kernel(int nb_e, const do
     const double gx = sum_partials_dev(part_u, nb_u, 4, 0);
     const double s2 = sum_partials_dev(part_u, nb_u, 4, 1);
     const double x2 = sum_partials_dev(part_u, nb_u, 4, 2);
+    __shared__ double hp[8];
     if (threadIdx.x == 0) {
-        out[0] = c2; out[1] = tt; out[2] = gx; out[3] = s2; out[4] = x2;
-        out[5] = state ? (double)state->iters : 0.0; out[6] = state ? (double)state->hit_cap : 0.0; out[7] = state ? state->rr0 : 0.0;
-        __threadfence_system();
-        out[8] = seq;
-        __threadfence_system();
+        hp[0] = c2; hp[1] = tt; hp[2] = gx; hp[3] = s2; hp[4] = x2;
+        hp[5] = state ? (double)state->iters : 0.0; hp[6] = state ? (double)state->hit_cap : 0.0; hp[7] = state ? state->rr0 : 0.0;
     }
+    __syncthreads();
+    if (threadIdx.x < 64) stamped_store_wave(out, hp, 8, seq, threadIdx.x);       // (a stamped block: common.hpp)
 }
 // linearisation: {cost2, |g|_inf, seq}
 __global__ __launch_bounds__(256) void pg_linear_finish_kernel(int nb_e, const double* __restrict__ part_e, int nb_g, const double* __restrict__ part_g,
@@ -1263,20 +1263,16 @@ __global__ __launch_bounds__(256) void pg_linear_finish_kernel(int nb_e, const d
     for (int k = threadIdx.x; k < nb_g; k += 256) mx = fmax(mx, part_g[2 * k + 1]);
     sq[threadIdx.x] = mx;
     __syncthreads();
+    __shared__ double hp[3];
     if (threadIdx.x == 0) {
         for (int k = 1; k < 256; ++k) mx = fmax(mx, sq[k]);
-        out[0] = c2; out[1] = mx; out[2] = g2;
-        __threadfence_system();
-        out[3] = seq;
-        __threadfence_system();
+        hp[0] = c2; hp[1] = mx; hp[2] = g2;
     }
+    __syncthreads();
+    if (threadIdx.x < 64) stamped_store_wave(out, hp, 3, seq, threadIdx.x);
 }
 __global__ void pg_export_kernel(int cnt, const double* __restrict__ src, double* __restrict__ out, double seq) {
-    const int k = threadIdx.x;
-    if (k < cnt) out[k] = src[k];
-    __threadfence_system();
-    __syncthreads();
-    if (k == 0) { out[cnt] = seq; __threadfence_system(); }
+    stamped_store_wave(out, src, cnt, seq, threadIdx.x);      // (one wave; src is device memory the previous kernel or collective left)
 }
 
 // trial poses + statistics of the step: partial[b] = {g.x, |x_new - x|^2, |x|^2, 0}
@@ -1346,7 +1342,8 @@ struct stba_pg {
            *part_cz = nullptr, *part_u = nullptr, *scal_dev = nullptr, *contrib = nullptr, *Dc = nullptr;
     int* cflag = nullptr;            // [0]: pivot flag of the coarse factorisation, [1]: coarse operators that failed (this solve)
     PcgState* state = nullptr;
-    PcgExport *exp_host = nullptr, *exp_dev = nullptr;   // mapped
+    double *exp_host = nullptr, *exp_dev = nullptr;      // mapped: the launch-path PCG's stamped block (PX_*)
+    double fin_vals[8] = {0};                            // the host's validated copy of the last trial / linearisation block
     double *fin_host = nullptr, *fin_dev = nullptr;      // mapped: trial / linearisation scalars + sequence number
     double seq = 0.0;
     int nb_nodes4 = 1;
@@ -1481,23 +1478,26 @@ static int pg_second_stream(stba_pg* g) {
 
 // waits until the sequence number behind a block in mapped host memory is `seq` (the stream is queried now and then so
 // that a device fault ends the wait)
-template <class T>
-static int pg_wait_mapped(stba_pg* g, const volatile T* slot, T want, bool at_least) {
+// (round 6: the blocks are STAMPED blocks, common.hpp -- a sequence number BEHIND a block was seen by the host ahead of payload in
+// another cache line -- and the host works on the validated copy `payload`)
+static int pg_wait_block(stba_pg* g, const volatile double* block, int n_payload, double want, bool at_least, double* payload) {
     const double t0 = wall();
-    for (unsigned long k = 1;; ++k) {
-        const T v = *slot;
-        if (at_least ? (v >= want) : (v == want)) break;
+    auto takes = [want, at_least](double st) { return at_least ? (st >= want) : (st == want); };
+    for (unsigned long k = 1; !stamped_try_read(block, n_payload, takes, payload); ++k) {
         if ((k & 0x3fff) == 0) {
             const hipError_t q = hipStreamQuery(g->st);
             if (q != hipSuccess && q != hipErrorNotReady) return fail(STBA_ERR_HIP, std::string("pose graph: stream failed: ") + hipGetErrorString(q));
-            if (q == hipSuccess) { const T v2 = *slot; if (!(at_least ? (v2 >= want) : (v2 == want))) return fail(STBA_ERR_HIP, "pose graph: the device never wrote the block the host waits for"); break; }
+            if (q == hipSuccess) {
+                STBA_HIP(hipStreamSynchronize(g->st));
+                if (!stamped_try_read(block, n_payload, takes, payload)) return fail(STBA_ERR_HIP, "pose graph: the device never wrote the block the host waits for");
+                break;
+            }
             if (wall() - t0 > 120.0) return fail(STBA_ERR_HIP, "pose graph: timed out waiting for the device");
         }
 #if defined(__x86_64__)
         __builtin_ia32_pause();
 #endif
     }
-    std::atomic_thread_fence(std::memory_order_acquire);
     return STBA_OK;
 }
 
@@ -1569,12 +1569,12 @@ int stba_pg_create(stba_pg** out, int n_nodes, int n_edges, const double* poses,
         return bail(fail(STBA_ERR_HIP, "stba_pg_create: memset"));
     g->nb_nodes4 = (n_nodes + PG_NPW - 1) / PG_NPW;
     A_(dalloc(&g->part_u, (size_t)g->nb_nodes * 4 + 4)); A_(dalloc(&g->scal_dev, 16)); A_(dalloc(&g->state, 1)); A_(dalloc(&g->cflag, 2));
-    if (hipHostMalloc(reinterpret_cast<void**>(&g->exp_host), sizeof(PcgExport), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+    if (hipHostMalloc(reinterpret_cast<void**>(&g->exp_host), (size_t)stamped_doubles(PX_COUNT) * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
         hipHostGetDevicePointer(reinterpret_cast<void**>(&g->exp_dev), g->exp_host, 0) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void**>(&g->fin_host), 16 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
         hipHostGetDevicePointer(reinterpret_cast<void**>(&g->fin_dev), g->fin_host, 0) != hipSuccess)
         return bail(fail(STBA_ERR_ALLOC, "stba_pg_create: mapped host memory"));
-    memset(g->exp_host, 0, sizeof(PcgExport)); memset(g->fin_host, 0, 16 * sizeof(double));
+    memset(g->exp_host, 0, (size_t)stamped_doubles(PX_COUNT) * sizeof(double)); memset(g->fin_host, 0, 16 * sizeof(double));
     memset(&g->last_pcg, 0, sizeof g->last_pcg);
 #undef A_
     {   // edge ends sorted by node (counting sort; stable: a node's ends in edge order)
@@ -1721,7 +1721,7 @@ int stba_pg_solve(stba_pg* g, const stba_lm_options* opt_in, const stba_pcg_opti
     stba_pcg_summary ps;
     memset(&ps, 0, sizeof ps);
     ps.coarse_dim = coarse ? g->nc : 0;
-    double* fin = g->fin_host;
+    double* fin = g->fin_vals;          // (the validated copy of the mapped block g->fin_host: pg_wait_block)
     // the PCG solve as one kernel: one rank, a coarse space whose groups fit a workgroup (<= 64 nodes, all their edge-end products
     // in LDS) and are all resident at once (one per CU)
     bool pp_ok = pcg.one_kernel_solve != 0 && !multi && coarse && g->agg <= 64 && g->na <= 256 && g->nc <= PP_NCMAX &&
@@ -1781,7 +1781,7 @@ int stba_pg_solve(stba_pg* g, const stba_lm_options* opt_in, const stba_pcg_opti
             hipLaunchKernelGGL(pg_export_kernel, dim3(1), dim3(64), 0, g->st, 3, g->scal_dev, g->fin_dev, g->seq);
         }
         STBA_HIP(hipGetLastError());
-        STBA_TRY(pg_wait_mapped<double>(g, &fin[3], g->seq, false));
+        STBA_TRY(pg_wait_block(g, g->fin_host, 3, g->seq, false, fin));
         *cost = 0.5 * fin[0]; *gmax = fin[1]; *g2 = fin[2];
         return STBA_OK;
     };
@@ -1919,7 +1919,7 @@ int stba_pg_solve(stba_pg* g, const stba_lm_options* opt_in, const stba_pcg_opti
         auto pcg_by_launches = [&]() -> int {
             // (every kernel of the previous solve has finished -- the host has read the trial block behind them -- so the exported
             // block can be taken back: the wait below must not see the previous solve's tick count and `done`)
-            g->exp_host->ticks = 0; g->exp_host->done = 0;
+            memset(g->exp_host, 0, (size_t)stamped_doubles(PX_COUNT) * sizeof(double));
             std::atomic_thread_fence(std::memory_order_seq_cst);
             hipLaunchKernelGGL(pg_pcg_init4_kernel, dim3(g->nb_nodes4), dim3(PG_NT), 0, g->st, g->n, g->agg, g->g, g->Minv, AdP, g->x, g->rr, g->z,
                                g->rc_part, g->part_a);
@@ -1931,8 +1931,9 @@ int stba_pg_solve(stba_pg* g, const stba_lm_options* opt_in, const stba_pcg_opti
             STBA_HIP(hipGetLastError());
             int enq = 0;
             bool pcg_done = false;
-            STBA_TRY(pg_wait_mapped<int>(g, &g->exp_host->ticks, 1, true));          // (also: the previous solve's ticks are gone)
-            if (g->exp_host->done) pcg_done = true;
+            double px[PX_COUNT];
+            STBA_TRY(pg_wait_block(g, g->exp_host, PX_COUNT, 1.0, true, px));          // (also: the previous solve's ticks are gone)
+            if (px[PX_DONE] != 0.0) pcg_done = true;
             while (!pcg_done && enq < pcg.max_iterations) {
                 const int todo = std::min(chunk, pcg.max_iterations - enq);
                 for (int c = 0; c < todo; ++c, ++enq) {
@@ -1961,8 +1962,8 @@ int stba_pg_solve(stba_pg* g, const stba_lm_options* opt_in, const stba_pcg_opti
                 // chunk enqueued past convergence return at once).  Several ranks: every rank must enqueue the same collectives, so the
                 // decision waits for the chunk itself -- the solve state is replicated and every rank sees the same `done`.
                 const int want = 1 + (multi ? enq : enq - todo);
-                STBA_TRY(pg_wait_mapped<int>(g, &g->exp_host->ticks, want, true));
-                if (g->exp_host->done) pcg_done = true;
+                STBA_TRY(pg_wait_block(g, g->exp_host, PX_COUNT, (double)want, true, px));
+                if (px[PX_DONE] != 0.0) pcg_done = true;
             }
             return STBA_OK;
         };
@@ -2023,7 +2024,7 @@ int stba_pg_solve(stba_pg* g, const stba_lm_options* opt_in, const stba_pcg_opti
                 hipLaunchKernelGGL(pg_export_kernel, dim3(1), dim3(64), 0, g->st, 8, g->scal_dev, g->fin_dev, g->seq);
             }
             STBA_HIP(hipGetLastError());
-            STBA_TRY(pg_wait_mapped<double>(g, &fin[8], g->seq, false));
+            STBA_TRY(pg_wait_block(g, g->fin_host, 8, g->seq, false, fin));
             return STBA_OK;
         };
         const bool one_kernel = pp_ok && !g->pp_disabled;

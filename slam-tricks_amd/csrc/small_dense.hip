@@ -25,7 +25,7 @@ namespace stba {
 namespace {
 
 constexpr int SD_THREADS = 256;
-constexpr int SD_STAMP_AT = 2 * SMALL_DENSE_MAX_N + 2;
+constexpr int SD_OUT_PAYLOAD_MAX = 2 * SMALL_DENSE_MAX_N + 2;     // dx | g | model cost change | pivot flag
 constexpr int SD_STAGE_DOUBLES = 5632;     // J and r staged in LDS when n_res * (n + 1) fits (44 KB); device scratch otherwise
 
 struct SmallStepArgs {
@@ -35,7 +35,7 @@ struct SmallStepArgs {
     double* H;             // device: n x n (kept between launches)
     double* g;             // device: n
     double* scale;         // device: n (Jacobi scaling, fixed at the first linearisation)
-    double* out;           // mapped host: [0, n) dx | [n, 2n) g | [2n] model cost change | [2n + 1] pivot flag | [SD_STAMP_AT] stamp (a fixed place: the workspace is reused with other n)
+    double* out;           // mapped host, a STAMPED BLOCK (common.hpp) of 2n + 2 payload doubles: [0, n) dx | [n, 2n) g | [2n] model cost change | [2n + 1] pivot flag
     int n_res, n, relinearize, first, jacobi;
     double radius, dmin, dmax, stamp;
 };
@@ -51,6 +51,7 @@ __global__ __launch_bounds__(SD_THREADS) void dense_small_step_kernel(SmallStepA
     __shared__ double Hs[SMALL_DENSE_MAX_N][SMALL_DENSE_MAX_N + 1];
     __shared__ double gs[SMALL_DENSE_MAX_N], dv[SMALL_DENSE_MAX_N], idiag[SMALL_DENSE_MAX_N];
     __shared__ int bad_pivot;
+    __shared__ double pay[SD_OUT_PAYLOAD_MAX];
     const int t = threadIdx.x, n = a.n, nres = a.n_res;
     const int lane = t & 63, wv = t >> 6;
     if (t == 0) bad_pivot = 0;
@@ -127,11 +128,13 @@ __global__ __launch_bounds__(SD_THREADS) void dense_small_step_kernel(SmallStepA
         }
         double m = (lane < n && !failed) ? (-0.5 * gs[lane] * b + 0.5 * dv[lane] * b * b) : 0.0;
         m = wave_sum(m);
-        if (lane < n) { a.out[lane] = b; a.out[n + lane] = gs[lane]; }
-        if (lane == 0) { a.out[2 * n] = m; a.out[2 * n + 1] = (double)bad_pivot; }
-        __threadfence_system();
-        if (lane == 0) a.out[SD_STAMP_AT] = a.stamp;       // (the kernel's end publishes it: a second fence here was 2 us of every 15 us step)
+        if (lane < n) { pay[lane] = b; pay[n + lane] = gs[lane]; }
+        if (lane == 0) { pay[2 * n] = m; pay[2 * n + 1] = (double)bad_pivot; }
     }
+    __syncthreads();
+    // the step, the gradient, the model change and the flag as ONE stamped block: every 64-byte line carries the stamp and a check
+    // word of its own (common.hpp: a stamp behind the payload was seen by the host BEFORE payload in another line, 1 in ~50 000 steps)
+    if (wv == 0) stamped_store_wave(a.out, pay, 2 * n + 2, a.stamp, lane);
 }
 
 std::mutex g_pool_mutex;
@@ -149,6 +152,7 @@ struct SmallDenseWs {
     double *scratch = nullptr, *H = nullptr, *g = nullptr, *scale = nullptr;
     size_t cap_j = 0, cap_r = 0;
     double stamp = 0.0;
+    double result[2 * SMALL_DENSE_MAX_N + 2];      // the host's validated copy of the last step's block
 };
 
 bool small_dense_fits(int n_res, int n) {
@@ -188,13 +192,13 @@ int small_dense_acquire(SmallDenseWs** out, int n_res, int n) {
         auto fail_new = [&](int rc) { delete w; return rc; };       // (a half-made workspace is dropped; its few buffers leak with the failed device)
         if (hipStreamCreateWithFlags(&w->st, hipStreamNonBlocking) != hipSuccess) return fail_new(fail(STBA_ERR_HIP, "small dense workspace: hipStreamCreate"));
         const size_t nn = SMALL_DENSE_MAX_N;
-        if (hipHostMalloc(reinterpret_cast<void**>(&w->hout), (2 * nn + 8) * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+        if (hipHostMalloc(reinterpret_cast<void**>(&w->hout), (size_t)stamped_doubles(SD_OUT_PAYLOAD_MAX) * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
             hipHostGetDevicePointer(reinterpret_cast<void**>(&w->dout), w->hout, 0) != hipSuccess ||
             hipMalloc(reinterpret_cast<void**>(&w->H), nn * nn * sizeof(double)) != hipSuccess ||
             hipMalloc(reinterpret_cast<void**>(&w->g), nn * sizeof(double)) != hipSuccess ||
             hipMalloc(reinterpret_cast<void**>(&w->scale), nn * sizeof(double)) != hipSuccess)
             return fail_new(fail(STBA_ERR_ALLOC, "small dense workspace: allocation failed"));
-        memset(w->hout, 0, (2 * nn + 8) * sizeof(double));
+        memset(w->hout, 0, (size_t)stamped_doubles(SD_OUT_PAYLOAD_MAX) * sizeof(double));
     }
     const int rc = ws_grow(w, (size_t)n_res * (size_t)n, (size_t)n_res);
     if (rc != STBA_OK) { small_dense_release(w); return rc; }
@@ -224,14 +228,17 @@ int small_dense_step(SmallDenseWs* w, int n_res, int n, bool relinearize, bool f
     STBA_HIP(hipGetLastError());
     volatile double* h = w->hout;
     const double t0 = wall_now();
-    for (unsigned long spin = 1; h[SD_STAMP_AT] != a.stamp; ++spin) {
+    const double want = a.stamp;
+    auto is_mine = [want](double st) { return st == want; };
+    for (unsigned long spin = 1; !stamped_try_read(h, 2 * n + 2, is_mine, w->result); ++spin) {
         if ((spin & 0xfff) == 0) {
             const hipError_t q = hipStreamQuery(w->st);
             if (q != hipSuccess && q != hipErrorNotReady) return fail(STBA_ERR_HIP, std::string("small dense step: ") + hipGetErrorString(q));
-            if (q == hipSuccess && h[SD_STAMP_AT] != a.stamp) {
-                // the kernel is done and its stamp has not been seen: one synchronise settles what the host may read
+            if (q == hipSuccess) {
+                // the kernel is done: one synchronise settles what the host may read
                 STBA_HIP(hipStreamSynchronize(w->st));
-                if (h[SD_STAMP_AT] != a.stamp) return fail(STBA_ERR_HIP, "small dense step: the result never arrived in mapped host memory");
+                if (!stamped_try_read(h, 2 * n + 2, is_mine, w->result)) return fail(STBA_ERR_HIP, "small dense step: the result never arrived in mapped host memory");
+                break;
             }
             if (wall_now() - t0 > 60.0) return fail(STBA_ERR_HIP, "small dense step: timed out");
         }
@@ -239,10 +246,9 @@ int small_dense_step(SmallDenseWs* w, int n_res, int n, bool relinearize, bool f
         __builtin_ia32_pause();
 #endif
     }
-    std::atomic_thread_fence(std::memory_order_acquire);
-    *dx = w->hout; *g = w->hout + n;
-    *model_change = w->hout[2 * n];
-    *pivot_flag = (int)w->hout[2 * n + 1];
+    *dx = w->result; *g = w->result + n;
+    *model_change = w->result[2 * n];
+    *pivot_flag = (int)w->result[2 * n + 1];
     return STBA_OK;
 }
 

@@ -131,7 +131,8 @@ struct stba_ba {
     double* trial = nullptr;   // TS_COUNT + 1 doubles
     double* ts_host = nullptr;   // mapped pinned host memory: the trial block + the factorisation flag, written by a kernel
     double* ts_host_dev = nullptr;
-    double ts_seq = 0.0;         // sequence number of the last trial block asked for (entry TS_COUNT + 1 of ts_host)
+    double ts_seq = 0.0;         // sequence number of the last trial block asked for (the stamp of the block's lines)
+    double ts_vals[TS_COUNT + 1] = {0};      // the host's validated copy of the last trial block (ba_wait_trial)
     int* flag = nullptr;
     int lin_grid = 1;
     stba_allreduce_fn ar = nullptr;
@@ -500,12 +501,12 @@ static int ba_fill_scalar_slots(stba_ba* b, double* cost2_dev) {
 
 // the trial block and the factorisation's flag into mapped host memory (several ranks; one rank: trial_finish_kernel does it)
 __global__ void export_trial_kernel(const double* __restrict__ trial, const int* __restrict__ flag, double* __restrict__ out, double seq) {
+    __shared__ double hp[TS_COUNT + 1];
     const int k = threadIdx.x;
-    if (k < TS_COUNT) out[k] = trial[k];
-    else if (k == TS_COUNT) out[k] = (double)flag[0];
-    __threadfence_system();
+    if (k < TS_COUNT) hp[k] = trial[k];
+    else if (k == TS_COUNT) hp[k] = (double)flag[0];
     __syncthreads();
-    if (k == 0) { out[TS_COUNT + 1] = seq; __threadfence_system(); }      // (the host polls this entry, see ba_wait_trial)
+    stamped_store_wave(out, hp, TS_COUNT + 1, seq, k);      // (one wave of 64; a stamped block: the host validates every line, see ba_wait_trial)
 }
 
 // back-substitution of the LM loop: dxp, and on the way the trial point (landmarks and cameras) + its step statistics
@@ -548,21 +549,27 @@ static int ba_trial(stba_ba* b, double* host_out, bool updated = false, bool wit
 // The host's side of the mapped-memory hand-off: the trial block is complete once the sequence number behind it is the
 // one this iteration's kernel was given.  (No event: a record between two kernels costs the GPU ~5 us, and the stream goes
 // straight on with the speculative work.)  The stream is queried now and then so that a device fault ends the wait.
+// (round 6: the block is a STAMPED block -- every 64-byte line carries the sequence number and a check word, common.hpp -- and the
+// host works on its validated copy b->ts_vals: a sequence number BEHIND the block was seen ahead of the block's other line)
 static int ba_wait_trial(stba_ba* b, double seq) {
     volatile double* h = b->ts_host;
     const double t0 = wall_s();
-    for (unsigned long n = 1; h[TS_COUNT + 1] != seq; ++n) {
+    auto is_mine = [seq](double st) { return st == seq; };
+    for (unsigned long n = 1; !stamped_try_read(h, TS_COUNT + 1, is_mine, b->ts_vals); ++n) {
         if ((n & 0x3fff) == 0) {
             const hipError_t q = hipStreamQuery(b->st);
             if (q != hipSuccess && q != hipErrorNotReady) return fail(STBA_ERR_HIP, std::string("stream failed while waiting for the trial point: ") + hipGetErrorString(q));
-            if (q == hipSuccess && h[TS_COUNT + 1] != seq) return fail(STBA_ERR_HIP, "the trial block never arrived in mapped host memory");
+            if (q == hipSuccess) {
+                STBA_HIP(hipStreamSynchronize(b->st));
+                if (!stamped_try_read(h, TS_COUNT + 1, is_mine, b->ts_vals)) return fail(STBA_ERR_HIP, "the trial block never arrived in mapped host memory");
+                break;
+            }
             if (wall_s() - t0 > 120.0) return fail(STBA_ERR_HIP, "timed out waiting for the trial point");
         }
 #if defined(__x86_64__)
         __builtin_ia32_pause();
 #endif
     }
-    std::atomic_thread_fence(std::memory_order_acquire);
     return STBA_OK;
 }
 
@@ -744,9 +751,9 @@ static int ba_run_lm(stba_ba* b, const stba_lm_options* opt_in, int fixed_iterat
         // the speculative build are enqueued on the stream like everything else.)
         const bool fast = deferred_ok && SPECULATE && !b->hl_fn;      // (host-linearised factors: the callback is synchronous host work)
         if (fast && !b->ts_host) {
-            STBA_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->ts_host), (TS_COUNT + 2) * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
+            STBA_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->ts_host), (size_t)stamped_doubles(TS_COUNT + 1) * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
             STBA_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&b->ts_host_dev), b->ts_host, 0));
-            b->ts_host[TS_COUNT + 1] = 0.0;
+            memset(b->ts_host, 0, (size_t)stamped_doubles(TS_COUNT + 1) * sizeof(double));
         }
         // (the speculative linearisation IS the evaluation of the trial point: one pass over the observations, not two)
         const bool speculate = fast && !(fixed && iter >= max_iter);
@@ -766,8 +773,8 @@ static int ba_run_lm(stba_ba* b, const stba_lm_options* opt_in, int fixed_iterat
                 speculated = true;
             }
             STBA_TRY(ba_wait_trial(b, seq));
-            for (int k = 0; k < TS_COUNT; ++k) ts[k] = b->ts_host[k];
-            flag_h = (int)b->ts_host[TS_COUNT];
+            for (int k = 0; k < TS_COUNT; ++k) ts[k] = b->ts_vals[k];
+            flag_h = (int)b->ts_vals[TS_COUNT];
         } else {
             STBA_TRY(download(ts, b->trial, TS_COUNT, b->st));
             STBA_TRY(download(&flag_h, b->flag, 1, b->st));

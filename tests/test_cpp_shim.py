@@ -251,6 +251,19 @@ def test_reference_ba_call_site_at_c5_size(exe, tmp_path, scenes, O):
 
 
 @pytest.mark.gpu
+def test_small_solves_end_with_the_same_bits_every_run(exe, tmp_path, scenes):
+    """600 tiny Solve() calls (the reference's per-landmark triangulation, sim_data.cpp:298-311) through the one-launch-per-step
+    path, five times over: every run prints the same landmarks, bit for bit.  Until the hand-off became a stamped block
+    (common.hpp) a step's result was now and then read before it had arrived -- one run in thirteen ended a few landmarks
+    somewhere else (tools/dbg/tri_repeat.py runs hundreds)."""
+    s = scenes.st20_scene(retriangulate=False)
+    f = str(tmp_path / "tri.bin")
+    write_scene(f, s)
+    lines = {run(exe, "tri", f)["tri_pts"] for _ in range(5)}
+    assert len(lines) == 1
+
+
+@pytest.mark.gpu
 def test_reference_triangulation_call_site_on_gpu(exe, tmp_path, scenes, O):
     """sim_data.cpp:298-311: the scene generator triangulates every landmark with its OWN ceres::Problem (cameras are
     not parameter blocks; AutoDiffCostFunction<Triangulation, 2, 3> per observation, sim_data.h:165-194, residual
