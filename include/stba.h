@@ -356,7 +356,14 @@ typedef struct {
     double relative_tolerance;   /* 1e-12 on |residual| / |rhs|: used when forcing_eta0 <= 0 (a fixed tolerance, i.e. exact steps) */
     int    check_every;          /* 4: PCG iterations enqueued between the host's looks at the device-side convergence flag */
     double forcing_eta0;         /* 0.1: first and largest forcing term; <= 0: fixed relative_tolerance */
-    double forcing_eta_min;      /* 1e-10 */
+    double forcing_eta_min;      /* 0.01 (round 6; 1e-10 until then): the floor of the forcing sequence.  Eisenstat & Walker's sequence
+                                  * falls quadratically near the solution and buys nothing there: the LM loop stops on its function
+                                  * tolerance, not on the linear residual.  Measured (floor: PCG iterations | converged poses from the
+                                  * exact-step run, north_star's gate 1e-5) -- C4: 1e-10: 217 | 2.9e-6, 0.01: 196 | 3.2e-6 (1444 -> 1505 LM
+                                  * it/s), 0.03: 168 | 3.5e-6, 0.1 (a constant eta, Ceres' default for inexact steps): 125 | 7.4e-6; but on
+                                  * a 400-node graph with twice the noise 6.8e-6 | 6.6e-6 | 1.1e-5 | 8.3e-6 and on 2000 nodes with three
+                                  * times the noise 1.0e-5 | 1.1e-5 | 2.6e-5 | 4.6e-5: 0.01 is the largest floor that leaves the answers
+                                  * where the sequence alone puts them (profiles/r6_pg_forcing_floor.txt, r6_c4_forcing.txt) */
     int    coarse_group;         /* nodes per group of the coarse space, a power of two; 0: automatic (<= 200 groups, >= 8 nodes);
                                   * -1: no coarse space (block Jacobi only, the round-3 preconditioner) */
     int    coarse_refresh_every; /* 1: LM iterations between re-inversions of the coarse operator (the first two iterations always make theirs; an

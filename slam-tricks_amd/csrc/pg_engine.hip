@@ -1520,7 +1520,7 @@ void stba_pcg_default_options(stba_pcg_options* o) {
     o->relative_tolerance = 1e-12;
     o->check_every = 4;
     o->forcing_eta0 = 0.1;
-    o->forcing_eta_min = 1e-10;
+    o->forcing_eta_min = 0.01;          // (stba.h: the measured reason)
     o->coarse_group = 0;
     o->coarse_refresh_every = 1;
     o->one_kernel_solve = 1;
