@@ -191,6 +191,14 @@ int stba_ba_set_schur_mode(stba_ba* ba, int mode);
 int stba_ba_schur_mode(const stba_ba* ba, int* mode);
 int stba_ba_set_params(stba_ba* ba, const double* cams, const double* pts);
 int stba_ba_get_params(stba_ba* ba, double* cams, double* pts);
+/* (round 6) the observations' features again, n_obs*2 in the order given to stba_ba_create: for a caller who learns them while the engine
+ * is being created -- include/stba/ceres.h creates the engine (regrouping, Schur plan, uploads: ~50 ms at 10^6 observations) on a helper
+ * thread while the calling thread evaluates the user's cost functions for their features, then hands them over here. */
+int stba_ba_set_features(stba_ba* ba, const double* obs_feat);
+/* the HIP device of the CALLING thread (a helper thread starts on device 0 whatever its parent had selected): read it on one thread,
+ * set it on the other */
+int stba_get_device(int* device);
+int stba_set_device(int device);
 /* BA-SHAPED problems whose factor is NOT the built-in reprojection (the reference's BA cost is a generic
  * DynamicAutoDiffCostFunction, test_ceres.h:56,109-121: a robustified, scaled or otherwise different 4+3+3 -> 2 factor must not
  * fall back to dense normal equations).  With a host lineariser the residuals and Jacobians of every observation come from the

@@ -848,9 +848,28 @@ inline bool VerifyRecognisedBlocks(Problem& p, const BaLayout& L, int threads) {
     return bad.load() == 0;
 }
 
+// the PER-BLOCK half of the recognition: every user block's feature (its residual at the canonical point) and its value at its own
+// data.  10^6 blocks = 2 x 10^6 calls of the user's Evaluate, on the calling thread (options.num_threads of them): the one part of the
+// recognition that costs time -- Solve runs it while a helper thread creates the device engine (SolveBa).
+inline bool DetectBaBlocks(Problem& p, BaLayout* L, int threads) {
+    auto& res = p.residuals();
+    auto& blk = p.blocks();
+    std::atomic<int> bad{0};
+    ParallelRanges(res.size(), threads, [&](size_t lo, size_t hi) {
+        for (size_t k = lo; k < hi; ++k) {
+            if (!L->user[k]) continue;
+            const auto& r = res[k];
+            if (!CanonicalFeature(r.cost, &L->feat[2 * k]) ||
+                !ReprojectionValueAtData(r.cost, blk[r.blocks[0]].ptr, blk[r.blocks[1]].ptr, blk[r.blocks[2]].ptr, &L->feat[2 * k])) { bad.store(1); return; }
+        }
+    });
+    return bad.load() == 0;
+}
+
 // probe = false: only the SHAPE is required (blocks 4 / 3 / 3 -> 2 residuals, quaternion chart on the first block, no bounds);
 // the factor itself stays the user's (host-linearised path, see Solve) and L->feat is left at zero.
-inline bool DetectBa(Problem& p, BaLayout* L, bool probe = true, int threads = 1) {
+// blocks_later = true: the structure and the per-TYPE probes only; the caller runs DetectBaBlocks itself.
+inline bool DetectBa(Problem& p, BaLayout* L, bool probe = true, int threads = 1, bool blocks_later = false) {
     auto& res = p.residuals();
     auto& blk = p.blocks();
     if (res.empty()) return false;
@@ -900,16 +919,8 @@ inline bool DetectBa(Problem& p, BaLayout* L, bool probe = true, int threads = 1
         double f[2];
         if (ft.second && (!ProbeReprojectionValue(ft.second, f) || !ProbeReprojectionJacobian(ft.second))) return false;
     }
-    std::atomic<int> bad{0};
-    ParallelRanges(nr, threads, [&](size_t lo, size_t hi) {
-        for (size_t k = lo; k < hi; ++k) {
-            if (!L->user[k]) continue;
-            const auto& r = res[k];
-            if (!CanonicalFeature(r.cost, &L->feat[2 * k]) ||
-                !ReprojectionValueAtData(r.cost, blk[r.blocks[0]].ptr, blk[r.blocks[1]].ptr, blk[r.blocks[2]].ptr, &L->feat[2 * k])) { bad.store(1); return; }
-        }
-    });
-    return bad.load() == 0;
+    if (blocks_later) return true;
+    return DetectBaBlocks(p, L, threads);
 }
 
 // numerically confirms that a user-supplied 4->3 parameterisation is q (x) exp(delta)
@@ -975,7 +986,12 @@ inline int BaHostLinearize(void* user, const double* cams, const double* pts, do
 
 inline double WallSeconds() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-inline bool SolveBa(const Solver::Options& o, Problem* p, const BaLayout& L, Solver::Summary* sum, bool host_jacobians = false) {
+// blocks_layout / blocks_ok (round 6): the per-block half of the recognition is still to be done (DetectBa(..., blocks_later)): it runs
+// HERE, on the calling thread, while a helper thread creates the device engine (regrouping, Schur plan, uploads: ~50 ms at 10^6
+// observations, next to ~35 ms of user Evaluate calls); the features it finds go to the engine afterwards (stba_ba_set_features).
+// *blocks_ok = false: a block is not the reprojection factor -- nothing was solved, the engine is gone, the caller goes on.
+inline bool SolveBa(const Solver::Options& o, Problem* p, const BaLayout& L, Solver::Summary* sum, bool host_jacobians = false,
+                    BaLayout* blocks_layout = nullptr, bool* blocks_ok = nullptr) {
     double t0 = WallSeconds();
     auto lap = [&](double* acc) { const double t1 = WallSeconds(); *acc += t1 - t0; t0 = t1; };
     const int nc = (int)L.rot_block.size(), np = (int)L.pt_block.size(), no = (int)L.obs_cam.size();
@@ -993,10 +1009,38 @@ inline bool SolveBa(const Solver::Options& o, Problem* p, const BaLayout& L, Sol
         pt_fixed[j] = p->blocks()[L.pt_block[j]].constant ? 1 : 0;
     }
     lap(&sum->phases.pack);
-    int rc = stba_ba_create(&sync.ba, nc, np, no, sync.cams.data(), sync.pts.data(), L.obs_cam.data(), L.obs_pt.data(),
+    int rc = STBA_OK;
+    std::string create_error;
+    auto create = [&]() {
+        rc = stba_ba_create(&sync.ba, nc, np, no, sync.cams.data(), sync.pts.data(), L.obs_cam.data(), L.obs_pt.data(),
                             L.feat.data(), cam_fixed.data(), pt_fixed.data(), nullptr);
+        if (rc != STBA_OK) create_error = stba_last_error();      // (the error text is thread-local: taken where it was set)
+    };
+    int device = 0;
+    if (blocks_layout && !std::getenv("STBA_CERES_NO_OVERLAP") && stba_get_device(&device) == STBA_OK) {
+        // (the helper thread creates the engine from the layout as it stands -- the user blocks' features still zero: nothing reads
+        // them before the first linearisation; it starts on device 0 whatever this thread has selected, hence stba_set_device)
+        std::thread helper([&]() { if ((rc = stba_set_device(device)) != STBA_OK) create_error = stba_last_error(); else create(); });
+        const double tb0 = WallSeconds();
+        const bool ok = DetectBaBlocks(*p, blocks_layout, o.num_threads);
+        const double t_blocks = WallSeconds() - tb0;
+        helper.join();
+        sum->phases.recognise += t_blocks;
+        t0 += t_blocks;                                             // (what is left of the creation's wall time goes to engine_create)
+        if (!ok) {
+            if (rc == STBA_OK) stba_ba_destroy(sync.ba);
+            lap(&sum->phases.engine_create);
+            if (blocks_ok) *blocks_ok = false;
+            return false;
+        }
+        if (rc == STBA_OK && (rc = stba_ba_set_features(sync.ba, L.feat.data())) != STBA_OK) { create_error = stba_last_error(); stba_ba_destroy(sync.ba); }
+    } else {
+        if (blocks_layout && !DetectBaBlocks(*p, blocks_layout, o.num_threads)) { if (blocks_ok) *blocks_ok = false; lap(&sum->phases.recognise); return false; }
+        if (blocks_layout) lap(&sum->phases.recognise);
+        create();
+    }
     lap(&sum->phases.engine_create);
-    if (rc != STBA_OK) { sum->termination_type = FAILURE; sum->message = std::string("stba_ba_create: ") + stba_last_error(); return false; }
+    if (rc != STBA_OK) { sum->termination_type = FAILURE; sum->message = std::string("stba_ba_create: ") + create_error; return false; }
     BaHostCtx hctx{p, &L, o.num_threads};
     if (host_jacobians && (rc = stba_ba_set_host_linearizer(sync.ba, &BaHostLinearize, &hctx)) != STBA_OK) {
         sum->termination_type = FAILURE; sum->message = std::string("stba_ba_set_host_linearizer: ") + stba_last_error();
@@ -1234,16 +1278,20 @@ inline void SolveDispatch(const Solver::Options& options, Problem* problem, Solv
     const char* fe = std::getenv("STBA_CERES_FORCE_CALLBACK");
     const bool force_cb = options.force_callback_path || (fe && *fe && *fe != '0');
     double t0 = WallSeconds();
-    bool ba = !force_cb && DetectBa(*problem, &L, true, options.num_threads);
+    bool ba = !force_cb && DetectBa(*problem, &L, true, options.num_threads, true);      // (the per-block half: inside SolveBa)
     if (ba)
         for (int rb : L.rot_block) ba = ba && UsesQuaternionRightPlus(problem->blocks()[rb].local);
     summary->phases.recognise = WallSeconds() - t0;
     std::string carried;
+    std::vector<double> saved;
     if (ba) {
-        std::vector<double> saved;
         if (L.n_user) for (auto& b : problem->blocks()) saved.insert(saved.end(), b.ptr, b.ptr + b.size);
         summary->execution_path = "gpu-ba";
-        SolveBa(options, problem, L, summary);
+        bool blocks_ok = true;
+        SolveBa(options, problem, L, summary, false, L.n_user ? &L : nullptr, &blocks_ok);
+        if (!blocks_ok) { ba = false; summary->execution_path.clear(); }       // a block is not the factor: on to the other paths, nothing was touched
+    }
+    if (ba) {
         t0 = WallSeconds();
         const bool still = summary->termination_type == FAILURE || VerifyRecognisedBlocks(*problem, L, options.num_threads);
         summary->phases.verify = WallSeconds() - t0;

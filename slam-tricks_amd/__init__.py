@@ -73,7 +73,8 @@ EXPORTS = ["stba_status_string", "stba_last_error", "stba_version", "stba_device
            "stba_pcg_default_options", "stba_pg_create", "stba_pg_destroy", "stba_pg_set_allreduce", "stba_pg_get_poses", "stba_pg_evaluate",
            "stba_pg_solve", "stba_pg_last_pcg_summary", "stba_pg_time_kernels", "stba_dense_solve", "stba_corners_read", "stba_corners_write", "stba_zhang_init", "stba_two_view_init", "stba_odometry_read", "stba_odometry_write", "stba_trajectory_ate",
            "stba_comm_unique_id", "stba_comm_create", "stba_comm_destroy", "stba_comm_rank", "stba_comm_allreduce_sum",
-           "stba_comm_allreduce_hook", "stba_ba_set_comm", "stba_pg_set_comm"]
+           "stba_comm_allreduce_hook", "stba_ba_set_comm", "stba_pg_set_comm",
+           "stba_ba_set_features", "stba_get_device", "stba_set_device"]
 
 
 def lib():
@@ -192,6 +193,12 @@ class BAEngine:
     def set_params(self, cams=None, pts=None):
         _chk(lib().stba_ba_set_params(self._h, _p(None if cams is None else _f64(cams)),
                                       _p(None if pts is None else _f64(pts))), "stba_ba_set_params")
+
+    def set_features(self, obs_feat):
+        """the observations' features again (n_obs x 2, the order given at creation): stba_ba_set_features"""
+        f = _f64(obs_feat)
+        assert f.size == 2 * self.no
+        _chk(lib().stba_ba_set_features(self._h, _p(f)), "stba_ba_set_features")
 
     def get_params(self):
         cams = np.zeros((self.nc, 7)); pts = np.zeros((self.np_, 3))

@@ -1597,6 +1597,32 @@ int stba_ba_set_params(stba_ba* b, const double* cams, const double* pts) {
     return STBA_OK;
 }
 
+int stba_ba_set_features(stba_ba* b, const double* obs_feat) {
+    if (!b || (!obs_feat && b->no > 0)) return fail(STBA_ERR_INVALID_ARGUMENT, "stba_ba_set_features: null argument");
+    if (b->no == 0) return STBA_OK;
+    std::vector<double> s_feat((size_t)b->no * 2);          // (the engine's order: landmark-major, b->perm = position -> the caller's index)
+    for (int p = 0; p < b->no; ++p) {
+        const size_t i = (size_t)b->perm[(size_t)p];
+        s_feat[2 * (size_t)p] = obs_feat[2 * i]; s_feat[2 * (size_t)p + 1] = obs_feat[2 * i + 1];
+    }
+    STBA_TRY(upload(reinterpret_cast<double*>(b->feat), s_feat.data(), (size_t)b->no * 2, b->st));
+    STBA_HIP(hipStreamSynchronize(b->st));
+    b->have_lin = b->have_blocks = b->have_reduced = b->have_dxc = b->have_dxp = false;
+    return STBA_OK;
+}
+
+int stba_get_device(int* device) {
+    if (!device) return fail(STBA_ERR_INVALID_ARGUMENT, "stba_get_device: null argument");
+    STBA_TRY(require_device());
+    STBA_HIP(hipGetDevice(device));
+    return STBA_OK;
+}
+int stba_set_device(int device) {
+    STBA_TRY(require_device());
+    STBA_HIP(hipSetDevice(device));
+    return STBA_OK;
+}
+
 int stba_ba_get_params(stba_ba* b, double* cams, double* pts) {
     if (!b) return fail(STBA_ERR_INVALID_ARGUMENT, "null engine");
     if (cams) STBA_TRY(download(cams, b->cams[b->cur], (size_t)b->nc * 7, b->st));

@@ -856,3 +856,23 @@ def test_few_camera_rows_cut_into_two_slices_match_the_oracle(st, O, scenes):
     summ, tr = e.lm_iterations(3)
     so, tro = o.solve(fixed_iterations=3, num_threads=16)
     assert np.allclose(tr[:, 0], tro[:, 0], rtol=1e-8) and np.array_equal(tr[:, 6], tro[:, 6])
+
+
+def test_features_handed_over_after_creation(st, small):
+    """round 6, stba_ba_set_features: an engine created with placeholder features and given the real ones afterwards (what the
+    operator API does: it learns the features from the user's cost functions while a helper thread creates the engine) solves
+    exactly like one created with them -- same trace, same parameters, bit for bit; observations in a shuffled order, so that the
+    engine's regrouping permutation is exercised."""
+    s = small
+    rng = np.random.default_rng(3)
+    perm = rng.permutation(len(s["obs_cam"]))
+    oc, op, of = s["obs_cam"][perm], s["obs_pt"][perm], s["obs_feat"][perm]
+    a = st.BAEngine(s["cams0"], s["pts0"], oc, op, of, s["cam_fixed"])
+    b = st.BAEngine(s["cams0"], s["pts0"], oc, op, np.zeros_like(of), s["cam_fixed"])
+    b.set_features(of)
+    sa, ta = a.solve()
+    sb, tb = b.solve()
+    assert sa.num_iterations == sb.num_iterations and np.array_equal(ta, tb)
+    ca, pa = a.get_params(); cb, pb = b.get_params()
+    assert np.array_equal(ca, cb) and np.array_equal(pa, pb)
+    assert st.lib().stba_ba_set_features(b._h, None) != 0          # (a null array is refused)
