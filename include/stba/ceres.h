@@ -991,7 +991,7 @@ inline double WallSeconds() { return std::chrono::duration<double>(std::chrono::
 // observations, next to ~35 ms of user Evaluate calls); the features it finds go to the engine afterwards (stba_ba_set_features).
 // *blocks_ok = false: a block is not the reprojection factor -- nothing was solved, the engine is gone, the caller goes on.
 inline bool SolveBa(const Solver::Options& o, Problem* p, const BaLayout& L, Solver::Summary* sum, bool host_jacobians = false,
-                    BaLayout* blocks_layout = nullptr, bool* blocks_ok = nullptr) {
+                    BaLayout* blocks_layout = nullptr, bool* blocks_ok = nullptr, std::thread* destroyer = nullptr) {
     double t0 = WallSeconds();
     auto lap = [&](double* acc) { const double t1 = WallSeconds(); *acc += t1 - t0; t0 = t1; };
     const int nc = (int)L.rot_block.size(), np = (int)L.pt_block.size(), no = (int)L.obs_cam.size();
@@ -1062,7 +1062,13 @@ inline bool SolveBa(const Solver::Options& o, Problem* p, const BaLayout& L, Sol
         sum->termination_type = FAILURE;
         sum->message = std::string("stba_ba_solve: ") + stba_last_error();
     }
-    stba_ba_destroy(sync.ba);
+    // (the engine's ~40 device buffers take a few ms to free: with `destroyer` that happens on a helper thread, next to the caller's
+    // end-point check of the recognised blocks; the caller joins it)
+    int dev_now = 0;
+    if (destroyer && stba_get_device(&dev_now) == STBA_OK) {
+        stba_ba* engine = sync.ba;
+        *destroyer = std::thread([engine, dev_now]() { if (stba_set_device(dev_now) == STBA_OK) stba_ba_destroy(engine); });
+    } else stba_ba_destroy(sync.ba);
     lap(&sum->phases.write_back);
     return rc == STBA_OK;
 }
@@ -1284,17 +1290,21 @@ inline void SolveDispatch(const Solver::Options& options, Problem* problem, Solv
     summary->phases.recognise = WallSeconds() - t0;
     std::string carried;
     std::vector<double> saved;
+    bool still_factor = true;
     if (ba) {
         if (L.n_user) for (auto& b : problem->blocks()) saved.insert(saved.end(), b.ptr, b.ptr + b.size);
         summary->execution_path = "gpu-ba";
         bool blocks_ok = true;
-        SolveBa(options, problem, L, summary, false, L.n_user ? &L : nullptr, &blocks_ok);
+        std::thread destroyer;
+        SolveBa(options, problem, L, summary, false, L.n_user ? &L : nullptr, &blocks_ok, L.n_user ? &destroyer : nullptr);
         if (!blocks_ok) { ba = false; summary->execution_path.clear(); }       // a block is not the factor: on to the other paths, nothing was touched
+        t0 = WallSeconds();
+        still_factor = !ba || summary->termination_type == FAILURE || VerifyRecognisedBlocks(*problem, L, options.num_threads);
+        if (destroyer.joinable()) destroyer.join();
+        if (ba) summary->phases.verify = WallSeconds() - t0;
     }
     if (ba) {
-        t0 = WallSeconds();
-        const bool still = summary->termination_type == FAILURE || VerifyRecognisedBlocks(*problem, L, options.num_threads);
-        summary->phases.verify = WallSeconds() - t0;
+        const bool still = still_factor;
         if (still) {
             if (L.n_user) summary->message += (summary->message.empty() ? "" : " ") + std::to_string(L.n_user) +
                                               " user cost functions recognised as the reprojection factor (probe points, start point, end point) and evaluated by the device kernel.";
