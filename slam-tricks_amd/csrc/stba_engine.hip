@@ -99,7 +99,7 @@ struct stba_ba {
     long long* task_part_off = nullptr;
     double* schur_part = nullptr;
     bool lm_slices = false;
-    std::thread janitor;        // frees the host-side temporaries of stba_ba_create (see there)
+    std::shared_ptr<void> create_leftovers;     // the host-side temporaries of stba_ba_create, kept until the engine goes (see there)
     // pair plan of the Schur kernel (see ba_schur_pairs_kernel)
     int *pair_begin = nullptr, *pair_end = nullptr;      // per (task, wave)
     int *task_vs_ptr = nullptr, *vs_first = nullptr;     // per task: first accumulator slot of every block of its slice (+ the slot count)
@@ -172,7 +172,7 @@ struct stba_ba {
 namespace stba {
 
 static void ba_free(stba_ba* b) {
-    if (b->janitor.joinable()) b->janitor.join();       // (frees what stba_ba_create's plan left on the host)
+    b->create_leftovers.reset();                        // (what stba_ba_create's plan left on the host)
     auto F = [](void* p) { if (p) (void)hipFree(p); };
     F(b->cams[0]); F(b->cams[1]); F(b->pts[0]); F(b->pts[1]); F(b->feat); F(b->obs_cam); F(b->obs_pt);
     F(b->pt_start); F(b->cam_perm); F(b->chunk_begin); F(b->chunk_end); F(b->cam_chunk_start); F(b->cam_fixed);
@@ -1565,8 +1565,10 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
 #undef A_
     tmark("uploads + sync");
     // The plan's host-side temporaries -- 16 bytes per pair, the regrouped observations: ~110 MB at C5 -- cost 11 of the 43 ms of this
-    // function just to FREE (measured: STBA_CREATE_TIMING in a debug build).  They are handed to a thread of their own, which the
-    // engine joins when it is destroyed; the caller gets its engine that much sooner.
+    // function just to FREE (measured: STBA_CREATE_TIMING in a debug build).  The engine keeps them and frees them when it is destroyed:
+    // the caller gets its engine that much sooner, and the operator API destroys its engine on a helper thread next to its end-point
+    // check anyway.  (Freed by a thread of their own right here: 10 ms off this function as well, but 2 ms ON a drop-in Solve() -- the
+    // munmap of 110 MB holds the process's address-space lock while the calling thread faults pages in.)
     {
         struct Garbage {
             std::unique_ptr<int4[]> pair_rec;
@@ -1578,10 +1580,7 @@ int stba_ba_create(stba_ba** out, int n_cams, int n_pts, int n_obs, const double
         Garbage* gb = new (std::nothrow) Garbage{std::move(pair_rec), std::move(s_cam), std::move(s_pt), std::move(cam_perm), std::move(pt_start),
                                                  std::move(vs_first), std::move(row_cols), std::move(s_feat), std::move(dup_run), std::move(omask),
                                                  std::move(cnt_of)};
-        if (gb) {
-            try { b->janitor = std::thread([gb]() { delete gb; }); }
-            catch (...) { delete gb; }
-        }
+        if (gb) b->create_leftovers = std::shared_ptr<void>(gb, [](void* q) { delete static_cast<Garbage*>(q); });
     }
     *out = b;
     return STBA_OK;
