@@ -812,6 +812,12 @@ inline bool ProbeReprojectionJacobian(const CostFunction* cost) {
     return true;
 }
 
+// joins a helper thread when the scope is left, however it is left
+struct JoinOnExit {
+    std::thread* t;
+    ~JoinOnExit() { if (t && t->joinable()) t->join(); }
+};
+
 // [lo, hi) in `threads` contiguous ranges, one std::thread each (threads <= 1: inline).  Used for the per-block evaluations of the
 // recognition only when Solver::Options::num_threads > 1 -- the caller's promise, as in Ceres, that Evaluate may run concurrently.
 template <class F> inline void ParallelRanges(size_t n, int threads, F fn) {
@@ -1021,6 +1027,7 @@ inline bool SolveBa(const Solver::Options& o, Problem* p, const BaLayout& L, Sol
         // (the helper thread creates the engine from the layout as it stands -- the user blocks' features still zero: nothing reads
         // them before the first linearisation; it starts on device 0 whatever this thread has selected, hence stba_set_device)
         std::thread helper([&]() { if ((rc = stba_set_device(device)) != STBA_OK) create_error = stba_last_error(); else create(); });
+        JoinOnExit helper_guard{&helper};                           // (a user Evaluate that throws must not leave the thread running)
         const double tb0 = WallSeconds();
         const bool ok = DetectBaBlocks(*p, blocks_layout, o.num_threads);
         const double t_blocks = WallSeconds() - tb0;
@@ -1296,6 +1303,7 @@ inline void SolveDispatch(const Solver::Options& options, Problem* problem, Solv
         summary->execution_path = "gpu-ba";
         bool blocks_ok = true;
         std::thread destroyer;
+        JoinOnExit destroyer_guard{&destroyer};
         SolveBa(options, problem, L, summary, false, L.n_user ? &L : nullptr, &blocks_ok, L.n_user ? &destroyer : nullptr);
         if (!blocks_ok) { ba = false; summary->execution_path.clear(); }       // a block is not the factor: on to the other paths, nothing was touched
         t0 = WallSeconds();
