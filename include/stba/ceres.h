@@ -53,6 +53,7 @@
 #include <thread>
 #include <typeindex>
 #include <typeinfo>
+#include <cstdint>
 #include <unordered_map>
 #include <vector>
 
@@ -213,7 +214,11 @@ class DynamicAutoDiffCostFunction : public CostFunction {
 public:
     explicit DynamicAutoDiffCostFunction(CostFunctor* functor, Ownership own = TAKE_OWNERSHIP) : functor_(functor), own_(own) {}
     ~DynamicAutoDiffCostFunction() override { if (own_ == TAKE_OWNERSHIP) delete functor_; }
-    void AddParameterBlock(int size) { mutable_parameter_block_sizes()->push_back(size); }
+    void AddParameterBlock(int size) {
+        auto* v = mutable_parameter_block_sizes();
+        if (v->capacity() == 0) v->reserve(4);       // (one allocation for the usual two to four blocks instead of one per doubling: 10^6 cost functions at C5)
+        v->push_back(size);
+    }
     void SetNumResiduals(int n) { set_num_residuals(n); }
     bool Evaluate(double const* const* parameters, double* residuals, double** jacobians) const override {
         const auto& sizes = parameter_block_sizes();
@@ -571,27 +576,56 @@ public:
     std::vector<Residual>& residuals() { return residuals_; }
 
 private:
+    // parameter block pointer -> index: an open-addressing table (four look-ups per residual block at the reference's BA call site,
+    // 4 x 10^6 at C5: std::unordered_map's node per key and its modulo were a third of the construction time)
+    struct PtrIndex {
+        std::vector<double*> keys; std::vector<int> vals; size_t used = 0; int shift = 64;
+        static size_t mix(const double* p) { return (size_t)((reinterpret_cast<std::uintptr_t>(p) >> 3) * 0x9E3779B97F4A7C15ull); }
+        void grow() {
+            const size_t cap = keys.empty() ? 1024 : keys.size() * 2;
+            std::vector<double*> k2(cap, nullptr); std::vector<int> v2(cap, 0);
+            int sh = 64; for (size_t c = cap; c > 1; c >>= 1) --sh;
+            for (size_t q = 0; q < keys.size(); ++q) if (keys[q]) {
+                size_t h = mix(keys[q]) >> sh;
+                while (k2[h]) h = (h + 1) & (cap - 1);
+                k2[h] = keys[q]; v2[h] = vals[q];
+            }
+            keys.swap(k2); vals.swap(v2); shift = sh;
+        }
+        int find(const double* p) const {
+            if (keys.empty()) return -1;
+            const size_t mask = keys.size() - 1;
+            for (size_t h = mix(p) >> shift;; h = (h + 1) & mask) { if (keys[h] == p) return vals[h]; if (!keys[h]) return -1; }
+        }
+        void insert(double* p, int v) {
+            if (2 * (used + 1) > keys.size()) grow();
+            const size_t mask = keys.size() - 1;
+            size_t h = mix(p) >> shift;
+            while (keys[h]) h = (h + 1) & mask;
+            keys[h] = p; vals[h] = v; ++used;
+        }
+    };
     Block& block(double* p, int size) {
-        auto it = index_.find(p);
-        if (it != index_.end()) {
-            if (blocks_[it->second].size != size) { std::fprintf(stderr, "stba_ceres: block re-added with another size\n"); std::abort(); }
-            return blocks_[it->second];
+        const int at = index_.find(p);
+        if (at >= 0) {
+            if (blocks_[(size_t)at].size != size) { std::fprintf(stderr, "stba_ceres: block re-added with another size\n"); std::abort(); }
+            return blocks_[(size_t)at];
         }
         Block b; b.ptr = p; b.size = size; b.index = (int)blocks_.size();
-        index_[p] = b.index;
+        index_.insert(p, b.index);
         blocks_.push_back(b);
         return blocks_.back();
     }
     Block& find(double* p) {
-        auto it = index_.find(p);
-        if (it == index_.end()) { std::fprintf(stderr, "stba_ceres: unknown parameter block\n"); std::abort(); }
-        return blocks_[it->second];
+        const int at = index_.find(p);
+        if (at < 0) { std::fprintf(stderr, "stba_ceres: unknown parameter block\n"); std::abort(); }
+        return blocks_[(size_t)at];
     }
     Options options_;
     std::vector<Block> blocks_;
     std::vector<Residual> residuals_;
     std::vector<int> block_pool_;
-    std::unordered_map<double*, int> index_;
+    PtrIndex index_;
     std::vector<CostFunction*> owned_costs_;       // (every cost function once: CostFunction::owned_by_problem_)
     int num_loss_functions_ = 0;
     std::set<LocalParameterization*> owned_params_;
