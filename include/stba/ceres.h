@@ -582,7 +582,7 @@ private:
         std::vector<double*> keys; std::vector<int> vals; size_t used = 0; int shift = 64;
         static size_t mix(const double* p) { return (size_t)((reinterpret_cast<std::uintptr_t>(p) >> 3) * 0x9E3779B97F4A7C15ull); }
         void grow() {
-            const size_t cap = keys.empty() ? 1024 : keys.size() * 2;
+            const size_t cap = keys.empty() ? 64 : keys.size() * 2;       // (small first: a PnP problem has two blocks)
             std::vector<double*> k2(cap, nullptr); std::vector<int> v2(cap, 0);
             int sh = 64; for (size_t c = cap; c > 1; c >>= 1) --sh;
             for (size_t q = 0; q < keys.size(); ++q) if (keys[q]) {
